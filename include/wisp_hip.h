@@ -1,0 +1,225 @@
+/*
+ * wisp_hip.h - C ABI of the MI355X (gfx950) neural-field hot path.
+ *
+ * Every entry point takes raw DEVICE pointers (unless a parameter says "host"), element counts, and the
+ * HIP stream to launch on; it allocates nothing that outlives the call, never synchronises the device
+ * unless stated, and returns 0 on success or a negative code (WISP_ERR_*).  wisp_last_error() returns a
+ * static string describing the last failure on the calling thread.  The caller owns all buffers
+ * (the Python host layer allocates them from torch so allocator and stream semantics stay PyTorch's).
+ *
+ * Each declaration cites the reference interface it replaces.  Reference paths are relative to
+ * NVIDIAGameWorks/kaolin-wisp; "kaolin" = NVIDIA Kaolin Core 0.13 (INSTALL.md:14), whose ops wisp calls.
+ */
+#ifndef WISP_HIP_H
+#define WISP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* wisp_stream_t; /* hipStream_t */
+
+enum { WISP_F32 = 0, WISP_F16 = 1, WISP_BF16 = 2 };
+
+enum {
+    WISP_OK = 0,
+    WISP_ERR_INVALID = -1,   /* bad argument (null pointer, unsupported dtype / dim / level) */
+    WISP_ERR_LAUNCH = -2,    /* hipGetLastError() after a launch; see wisp_last_error() */
+    WISP_ERR_UNSUPPORTED = -3
+};
+
+const char* wisp_last_error(void);
+/* ABI version of this library; bumped whenever a signature changes. */
+int wisp_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Hash / dense multi-resolution grid  (replaces wisp._C.ops.hashgrid_interpolate_cuda and
+ * ..._backward_cuda: wisp/csrc/ops/hashgrid_interpolate.h:18-33, .cpp:46-105, kernels
+ * wisp/csrc/ops/hashgrid_interpolate_cuda.cu:19-339, index math wisp/csrc/ops/hash_utils.cuh:17-112)
+ *
+ *  coords        f32 [n, coord_dim]   coord_dim in {2,3}, values in [-1,1]
+ *  codebook      dtype [sum_T, feature_dim]   all levels stacked (wisp/models/grids/utils.py:48-63)
+ *  first_idx     i64 [num_lods+1]     DEVICE; first row of each level in codebook
+ *  resolutions   i32 [num_lods]       HOST (the reference passes a CPU tensor, .cu:365)
+ *  feats         dtype [n, num_lods*feature_dim]; columns >= zero_from_col are written as 0
+ *                (HashGrid.interpolate 'cat' quirk, wisp/models/grids/hash_grid.py:226-229); pass
+ *                num_lods*feature_dim to disable.
+ * All levels are processed by ONE launch (the reference launches once per level, .cpp:61-64).
+ */
+int wisp_hashgrid_interpolate_fwd(const float* coords, int64_t n, int coord_dim,
+                                  const void* codebook, int dtype, int feature_dim,
+                                  const int64_t* first_idx, const int32_t* resolutions, int num_lods,
+                                  int codebook_bitwidth, int zero_from_col,
+                                  void* feats, wisp_stream_t stream);
+
+/*  grad_feats    dtype [n, num_lods*feature_dim]
+ *  grad_codebook f32 [sum_T, feature_dim]; ACCUMULATED into (caller zeroes it).  Always float32:
+ *                the reference adds in the table dtype with __half2 atomics (.cu:138-150); fp32
+ *                accumulation is a strict numerical improvement and is cast by the host if needed.
+ *  Columns >= zero_from_col receive no gradient.  grad w.r.t. coords is not provided (the reference's
+ *  is documented-broken, .cu:165-166,193-194, and no in-scope caller requests it).
+ */
+int wisp_hashgrid_interpolate_bwd(const float* coords, int64_t n, int coord_dim,
+                                  const void* grad_feats, int dtype, int feature_dim,
+                                  const int64_t* first_idx, const int32_t* resolutions, int num_lods,
+                                  int codebook_bitwidth, int zero_from_col,
+                                  float* grad_codebook, wisp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SPC octree queries  (replace kaolin.ops.spc.unbatched_query at wisp/accelstructs/octree_as.py:162,
+ * kaolin.render.spc.unbatched_raytrace at :183-185, mark_pack_boundaries at :300 and
+ * kaolin._C.render.spc.inclusive_sum_cuda at :351)
+ *
+ *  octree  u8 [n_nodes]   occupancy byte per non-leaf node, BFS / Morton order
+ *  exsum   i32 [n_nodes+1] exclusive prefix sum of popcount(octree)
+ *  points  i16 [n_points,3] point hierarchy
+ */
+int wisp_spc_query(const uint8_t* octree, const int32_t* exsum, const float* coords, int64_t n,
+                   int level, int with_parents, int64_t* pidx /* [n] or [n, level+1] */,
+                   wisp_stream_t stream);
+
+/* Morton-ordered occupancy bitfield of one level: bit m of bits[] is set iff the level-`level` cell with
+ * Morton code m exists.  bits: u32 [ceil(8^level / 32)], zeroed by the call. */
+int wisp_spc_build_bitfield(const int16_t* level_points, int64_t n_points, int level, uint32_t* bits,
+                            wisp_stream_t stream);
+
+/* Two-phase ray / octree intersection.  count: nuggets per ray; emit: writes them at offsets[r]
+ * (exclusive scan of counts), ordered by ray then front-to-back.  depth is [M,1] or [M,2]. */
+int wisp_spc_raytrace_count(const uint8_t* octree, const int16_t* points, const int32_t* exsum,
+                            const float* origins, const float* dirs, int64_t num_rays, int level,
+                            int32_t* counts, wisp_stream_t stream);
+int wisp_spc_raytrace_emit(const uint8_t* octree, const int16_t* points, const int32_t* exsum,
+                           const float* origins, const float* dirs, int64_t num_rays, int level,
+                           const int64_t* offsets, int with_exit,
+                           int32_t* ridx, int32_t* pidx, float* depth, wisp_stream_t stream);
+
+int wisp_mark_pack_boundaries_i64(const int64_t* ids, int64_t n, uint8_t* boundary, wisp_stream_t stream);
+int wisp_mark_pack_boundaries_i32(const int32_t* ids, int64_t n, uint8_t* boundary, wisp_stream_t stream);
+
+/* Exclusive scan of int32 counts into int64 offsets [n+1] (offsets[n] = total).
+ * workspace: at least wisp_scan_workspace_bytes(n) bytes of device scratch. */
+int64_t wisp_scan_workspace_bytes(int64_t n);
+int wisp_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* offsets, void* workspace,
+                            wisp_stream_t stream);
+/* int32 inclusive scan (kaolin inclusive_sum_cuda). */
+int wisp_inclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* workspace,
+                            wisp_stream_t stream);
+/* boundary flags -> pack start indices.  Phase 1 counts flags per 2048-element tile into counts
+ * [ceil(n/2048)]; after an exclusive scan phase 2 writes starts i64 [P]. */
+int wisp_boundary_tile_counts(const uint8_t* boundary, int64_t n, int32_t* counts, wisp_stream_t stream);
+int wisp_boundary_pack_starts(const uint8_t* boundary, int64_t n, const int64_t* tile_offsets,
+                              int64_t* starts, wisp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Raymarch sample generation  (replace OctreeAS._raymarch_ray / _raymarch_voxel / _raymarch_uniform,
+ * wisp/accelstructs/octree_as.py:188-374, wisp/ops/spc/sampling.py:35-71 and
+ * wisp._C.ops.uniform_sample_cuda, wisp/csrc/ops/uniform_sample_cuda.cu:18-98)
+ *
+ * 'ray' mode, two phases.  count: for every ray evaluates the num_samples stratified depths, tests
+ * occupancy and stores a hit mask (u32 [R, ceil(N/32)]) plus the per-ray hit count.  emit: expands the
+ * mask into the packed outputs at offsets[r].  jitter: f32 [R,N] in [0,1) or NULL, in which case a
+ * counter-based generator keyed by (seed, ray, step) is used (the reference uses torch.rand, unseeded).
+ * occ_bits: Morton bitfield of `level` (wisp_spc_build_bitfield) - or NULL to walk octree/exsum.
+ */
+int wisp_raymarch_ray_count(const uint32_t* occ_bits, const uint8_t* octree, const int32_t* exsum,
+                            const float* origins, const float* dirs, int64_t num_rays,
+                            float near, float far, int num_samples, int level,
+                            const float* jitter, uint64_t seed,
+                            uint32_t* hitmask, int32_t* counts, wisp_stream_t stream);
+int wisp_raymarch_ray_emit(const float* origins, const float* dirs, int64_t num_rays,
+                           float near, float far, int num_samples,
+                           const float* jitter, uint64_t seed,
+                           const uint32_t* hitmask, const int64_t* offsets,
+                           int64_t* ridx, float* samples, float* depth_samples, float* deltas,
+                           uint8_t* boundary, wisp_stream_t stream);
+
+/* 'voxel' mode: num_samples jittered samples inside every nugget; S = M*num_samples.
+ * nug_ridx i32 [M], nug_depth f32 [M,2]; jitter f32 [M,N] or NULL (+seed). */
+int wisp_raymarch_voxel_emit(const float* origins, const float* dirs,
+                             const int32_t* nug_ridx, const float* nug_depth, int64_t num_nuggets,
+                             int num_samples, const float* jitter, uint64_t seed,
+                             int64_t* ridx, float* samples, float* depth_samples, float* deltas,
+                             uint8_t* boundary, wisp_stream_t stream);
+
+/* 'uniform' mode: counts[i] = ceil(scale*exit) - ceil(scale*entry) per nugget, then emit at the
+ * exclusive scan of counts.  ray_first i64 [R+1] = nugget offsets per ray (the raytrace offsets). */
+int wisp_raymarch_uniform_count(const float* nug_depth, int64_t num_nuggets, float scale,
+                                int32_t* counts, wisp_stream_t stream);
+int wisp_raymarch_uniform_emit(const float* origins, const float* dirs,
+                               const int32_t* nug_ridx, const float* nug_depth, int64_t num_nuggets,
+                               float scale, const int64_t* sample_offsets, const int64_t* ray_first,
+                               int64_t* ridx, float* samples, float* depth_samples, uint8_t* boundary,
+                               wisp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Packed volume integration  (replace kaolin.render.spc.exponential_integration / sum_reduce / cumsum
+ * and the scatter block of PackedRFTracer.trace, wisp/tracers/packed_rf_tracer.py:143-165)
+ *
+ *  pack_starts i64 [P]  first sample of every pack (== boundary.nonzero()), S = total samples
+ */
+int wisp_packed_sum_reduce(const float* feats, int64_t num_samples, int channels,
+                           const int64_t* pack_starts, int64_t num_packs, float* out /* [P,C] */,
+                           wisp_stream_t stream);
+int wisp_packed_cumsum(const float* feats, int64_t num_samples, int channels,
+                       const int64_t* pack_starts, int64_t num_packs, int exclusive, int reverse,
+                       float* out /* [S,C] */, wisp_stream_t stream);
+
+/* Fused tracer compositing: tau = density*delta; w_i = exp(-sum_{j<i} tau_j)(1-exp(-tau_i));
+ * rgb[r] = bg*(1-sum w) + sum w*c ; alpha[r] = sum w ; depth[r] = sum w*t ; hit[r] = alpha > 0.
+ * Rays without samples get bg / 0 / 0 / false.  weights f32 [S] is an output (kaolin returns it).
+ * depths / out_depth may be NULL together. */
+int wisp_composite_fwd(const float* color /* [S,3] */, const float* density /* [S] */,
+                       const float* deltas /* [S] */, const float* depths /* [S] or NULL */,
+                       const int64_t* ridx /* [S] */, const int64_t* pack_starts, int64_t num_packs,
+                       int64_t num_samples, int64_t num_rays, const float* bg /* host [3] */,
+                       float* out_rgb /* [R,3] */, float* out_alpha /* [R] */,
+                       float* out_depth /* [R] or NULL */, uint8_t* out_hit /* [R] */,
+                       float* weights /* [S] */, wisp_stream_t stream);
+int wisp_composite_bwd(const float* grad_rgb /* [R,3] */, const float* grad_alpha /* [R] or NULL */,
+                       const float* grad_depth /* [R] or NULL */,
+                       const float* color, const float* density, const float* deltas, const float* depths,
+                       const int64_t* ridx, const int64_t* pack_starts, int64_t num_packs,
+                       int64_t num_samples, const float* bg /* host [3] */,
+                       float* grad_color /* [S,3] */, float* grad_density /* [S] */,
+                       wisp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused radiance-field decoder  (replaces NeuralRadianceField.rgba after grid.interpolate,
+ * wisp/models/nefs/nerf.py:245-264: decoder_density (Linear-ReLU-Linear) -> relu density + 15 geometry
+ * features -> cat positional-encoded view dir (wisp/models/embedders/positional_embedder.py:51-66)
+ * -> decoder_color (Linear-ReLU x2, Linear) -> sigmoid)
+ * See wisp_nerf_mlp.h section below; declared in this header so the loader sees one ABI.
+ *
+ *  feats   dtype_io [S, in_dim]          (in_dim <= 64)
+ *  dirs    f32 [S,3]
+ *  params  f32 packed, layout given by wisp_nerf_mlp_param_count(): W1[hid,in], b1[hid], W2[16,hid],
+ *          b2[16], W3[hid, 15+pe], b3[hid], W4[hid,hid], b4[hid], W5[3,hid], b5[3]   (row-major
+ *          [out,in] like nn.Linear.weight; biases present but zero when the model has bias=False)
+ *  compute_dtype: WISP_F32 (exact fp32 MFMA) or WISP_BF16 (bf16 MFMA, fp32 accumulate)
+ */
+int64_t wisp_nerf_mlp_param_count(int in_dim, int hidden, int view_freqs);
+int wisp_nerf_mlp_fwd(const void* feats, int dtype_io, const float* dirs, int64_t num_samples,
+                      int in_dim, int hidden, int view_freqs, const float* params, int compute_dtype,
+                      float* rgb /* [S,3] */, float* density /* [S] */, wisp_stream_t stream);
+int wisp_nerf_mlp_bwd(const void* feats, int dtype_io, const float* dirs, int64_t num_samples,
+                      int in_dim, int hidden, int view_freqs, const float* params, int compute_dtype,
+                      const float* grad_rgb /* [S,3] */, const float* grad_density /* [S] */,
+                      void* grad_feats /* dtype_io [S,in_dim] */, float* grad_params /* accumulated */,
+                      wisp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer  (replaces torch.optim.AdamW / apex FusedAdam over the flat parameter buffer,
+ * wisp/trainers/base_trainer.py:205-235, wisp/config/presets/torch.py:22-58)
+ * One launch over n contiguous fp32 parameters; grad_scale multiplies the gradient first
+ * (1/world_size for data-parallel mean).  step is the 1-based step count.
+ */
+int wisp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                    float grad_scale, int zero_grad /* also zero grad[] */, wisp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WISP_HIP_H */

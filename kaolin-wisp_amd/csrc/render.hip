@@ -1,0 +1,241 @@
+// Packed (ragged) volume integration for gfx950.
+//
+// Replaces kaolin.render.spc.{cumsum, sum_reduce, exponential_integration} and the scatter block of
+// PackedRFTracer.trace (wisp/tracers/packed_rf_tracer.py:143-165; semantics SURVEY.md Appendix A.4/A.5).
+// The reference runs exp, a CUB scan, a multiply, three atomic segmented reductions and four index_put
+// kernels; here one wave owns one pack (= one ray's samples): the exclusive transmittance sum is a 64-lane
+// shuffle scan carried across 64-sample chunks, the per-ray colour / alpha / depth sums are wave
+// reductions (deterministic, no atomics), and background blending + the scatter to per-ray buffers are
+// fused into the same kernel.
+#include "wisp_common.h"
+
+static __device__ __forceinline__ float wave_incl_scan_f(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+static __device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------- generic pack ops
+__global__ void __launch_bounds__(256)
+packed_sum_reduce_kernel(const float* __restrict__ feats, int64_t s_total, int channels,
+                         const int64_t* __restrict__ pack_starts, int64_t num_packs, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= num_packs) return;
+    const int64_t b = pack_starts[p], e = (p + 1 < num_packs) ? pack_starts[p + 1] : s_total;
+    for (int c = 0; c < channels; ++c) {
+        float acc = 0.0f;
+        for (int64_t i = b + lane; i < e; i += 64) acc += feats[i * channels + c];
+        acc = wave_sum_f(acc);
+        if (lane == 0) out[p * channels + c] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+packed_cumsum_kernel(const float* __restrict__ feats, int64_t s_total, int channels,
+                     const int64_t* __restrict__ pack_starts, int64_t num_packs, int exclusive, int reverse,
+                     float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= num_packs) return;
+    const int64_t b = pack_starts[p], e = (p + 1 < num_packs) ? pack_starts[p + 1] : s_total;
+    const int64_t len = e - b;
+    for (int c = 0; c < channels; ++c) {
+        float carry = 0.0f;
+        for (int64_t k0 = 0; k0 < len; k0 += 64) {
+            const int64_t k = k0 + lane;
+            const int64_t i = reverse ? (e - 1 - k) : (b + k);
+            const float v = (k < len) ? feats[i * channels + c] : 0.0f;
+            const float inc = wave_incl_scan_f(v, lane);
+            if (k < len) out[i * channels + c] = carry + (exclusive ? inc - v : inc);
+            carry += __shfl(inc, 63, 64);
+        }
+    }
+}
+
+extern "C" int wisp_packed_sum_reduce(const float* feats, int64_t num_samples, int channels, const int64_t* pack_starts,
+                                      int64_t num_packs, float* out, wisp_stream_t stream) {
+    WISP_REQUIRE(num_samples >= 0 && num_packs >= 0 && channels >= 1, "bad sizes");
+    if (num_packs == 0) return WISP_OK;
+    WISP_REQUIRE(feats && pack_starts && out, "null pointer");
+    hipLaunchKernelGGL(packed_sum_reduce_kernel, dim3((unsigned)ceil_div64(num_packs, 4)), dim3(256), 0,
+                       (hipStream_t)stream, feats, num_samples, channels, pack_starts, num_packs, out);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_packed_cumsum(const float* feats, int64_t num_samples, int channels, const int64_t* pack_starts,
+                                  int64_t num_packs, int exclusive, int reverse, float* out, wisp_stream_t stream) {
+    WISP_REQUIRE(num_samples >= 0 && num_packs >= 0 && channels >= 1, "bad sizes");
+    if (num_packs == 0) return WISP_OK;
+    WISP_REQUIRE(feats && pack_starts && out, "null pointer");
+    hipLaunchKernelGGL(packed_cumsum_kernel, dim3((unsigned)ceil_div64(num_packs, 4)), dim3(256), 0,
+                       (hipStream_t)stream, feats, num_samples, channels, pack_starts, num_packs, exclusive, reverse, out);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- fused compositing
+struct Bg { float r, g, b; };
+
+__global__ void __launch_bounds__(256)
+composite_init_kernel(int64_t num_rays, Bg bg, float* __restrict__ rgb, float* __restrict__ alpha,
+                      float* __restrict__ depth, uint8_t* __restrict__ hit) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= num_rays) return;
+    rgb[r * 3] = bg.r; rgb[r * 3 + 1] = bg.g; rgb[r * 3 + 2] = bg.b;     // packed_rf_tracer.py:143
+    alpha[r] = 0.0f;
+    if (depth) depth[r] = 0.0f;
+    hit[r] = 0;
+}
+
+__global__ void __launch_bounds__(256)
+composite_fwd_kernel(const float* __restrict__ color, const float* __restrict__ density,
+                     const float* __restrict__ deltas, const float* __restrict__ depths,
+                     const int64_t* __restrict__ ridx, const int64_t* __restrict__ pack_starts, int64_t num_packs,
+                     int64_t s_total, Bg bg, float* __restrict__ out_rgb, float* __restrict__ out_alpha,
+                     float* __restrict__ out_depth, uint8_t* __restrict__ out_hit, float* __restrict__ weights) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= num_packs) return;
+    const int64_t b = pack_starts[p], e = (p + 1 < num_packs) ? pack_starts[p + 1] : s_total;
+    float carry = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f, sa = 0.0f, sd = 0.0f;
+    for (int64_t k0 = b; k0 < e; k0 += 64) {
+        const int64_t i = k0 + lane;
+        const bool live = i < e;
+        const float tau = live ? density[i] * deltas[i] : 0.0f;           // :152
+        const float inc = wave_incl_scan_f(tau, lane);
+        const float excl = carry + (inc - tau);
+        carry += __shfl(inc, 63, 64);
+        if (live) {
+            const float T = expf(-excl);                                  // exponential_integration, exclusive=True
+            const float w = T * (1.0f - expf(-tau));
+            weights[i] = w;
+            sr += w * color[i * 3]; sg += w * color[i * 3 + 1]; sb += w * color[i * 3 + 2];
+            sa += w;
+            if (depths) sd += w * depths[i];
+        }
+    }
+    sr = wave_sum_f(sr); sg = wave_sum_f(sg); sb = wave_sum_f(sb); sa = wave_sum_f(sa);
+    if (depths) sd = wave_sum_f(sd);
+    if (lane == 0) {
+        const int64_t r = ridx[b];
+        out_alpha[r] = sa;                                                // :160-161
+        out_hit[r] = sa > 0.0f ? 1 : 0;                                   // :162
+        const float om = 1.0f - sa;
+        out_rgb[r * 3] = bg.r * om + sr; out_rgb[r * 3 + 1] = bg.g * om + sg; out_rgb[r * 3 + 2] = bg.b * om + sb;  // :165
+        if (out_depth) out_depth[r] = sd;                                 // :157-158
+    }
+}
+
+// dL/dc_i = w_i g_rgb ; G_i = g_rgb.(c_i - bg) + g_alpha + g_depth t_i ;
+// dL/dtau_i = G_i T_i exp(-tau_i) - sum_{k>i} G_k w_k ; dL/dsigma_i = dL/dtau_i * delta_i
+__global__ void __launch_bounds__(256)
+composite_bwd_kernel(const float* __restrict__ grad_rgb, const float* __restrict__ grad_alpha,
+                     const float* __restrict__ grad_depth, const float* __restrict__ color,
+                     const float* __restrict__ density, const float* __restrict__ deltas,
+                     const float* __restrict__ depths, const int64_t* __restrict__ ridx,
+                     const int64_t* __restrict__ pack_starts, int64_t num_packs, int64_t s_total, Bg bg,
+                     float* __restrict__ grad_color, float* __restrict__ grad_density) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= num_packs) return;
+    const int64_t b = pack_starts[p], e = (p + 1 < num_packs) ? pack_starts[p + 1] : s_total;
+    const int64_t r = ridx[b];
+    const float gr = grad_rgb[r * 3], gg = grad_rgb[r * 3 + 1], gb = grad_rgb[r * 3 + 2];
+    const float ga = grad_alpha ? grad_alpha[r] : 0.0f;
+    const float gd = (grad_depth && depths) ? grad_depth[r] : 0.0f;
+    // pass 1: total of G_k w_k over the pack
+    float carry = 0.0f, tot = 0.0f;
+    for (int64_t k0 = b; k0 < e; k0 += 64) {
+        const int64_t i = k0 + lane;
+        const bool live = i < e;
+        const float tau = live ? density[i] * deltas[i] : 0.0f;
+        const float inc = wave_incl_scan_f(tau, lane);
+        const float excl = carry + (inc - tau);
+        carry += __shfl(inc, 63, 64);
+        if (live) {
+            const float w = expf(-excl) * (1.0f - expf(-tau));
+            float G = gr * (color[i * 3] - bg.r) + gg * (color[i * 3 + 1] - bg.g) + gb * (color[i * 3 + 2] - bg.b) + ga;
+            if (depths) G += gd * depths[i];
+            tot += G * w;
+        }
+    }
+    tot = wave_sum_f(tot);
+    // pass 2: gradients, suffix = total - inclusive prefix of G w
+    carry = 0.0f;
+    float gcarry = 0.0f;
+    for (int64_t k0 = b; k0 < e; k0 += 64) {
+        const int64_t i = k0 + lane;
+        const bool live = i < e;
+        const float dl = live ? deltas[i] : 0.0f;
+        const float tau = live ? density[i] * dl : 0.0f;
+        const float inc = wave_incl_scan_f(tau, lane);
+        const float excl = carry + (inc - tau);
+        carry += __shfl(inc, 63, 64);
+        float T = 0.0f, et = 0.0f, w = 0.0f, G = 0.0f;
+        if (live) {
+            T = expf(-excl); et = expf(-tau); w = T * (1.0f - et);
+            G = gr * (color[i * 3] - bg.r) + gg * (color[i * 3 + 1] - bg.g) + gb * (color[i * 3 + 2] - bg.b) + ga;
+            if (depths) G += gd * depths[i];
+        }
+        const float gw = G * w;
+        const float ginc = wave_incl_scan_f(gw, lane);
+        const float suffix = tot - (gcarry + ginc);
+        gcarry += __shfl(ginc, 63, 64);
+        if (live) {
+            grad_color[i * 3] = w * gr; grad_color[i * 3 + 1] = w * gg; grad_color[i * 3 + 2] = w * gb;
+            grad_density[i] = (G * T * et - suffix) * dl;
+        }
+    }
+}
+
+extern "C" int wisp_composite_fwd(const float* color, const float* density, const float* deltas, const float* depths,
+                                  const int64_t* ridx, const int64_t* pack_starts, int64_t num_packs,
+                                  int64_t num_samples, int64_t num_rays, const float* bg, float* out_rgb,
+                                  float* out_alpha, float* out_depth, uint8_t* out_hit, float* weights,
+                                  wisp_stream_t stream) {
+    WISP_REQUIRE(num_rays >= 0 && num_packs >= 0 && num_samples >= 0, "bad sizes");
+    WISP_REQUIRE(bg, "null bg");
+    if (num_rays == 0) return WISP_OK;
+    WISP_REQUIRE(out_rgb && out_alpha && out_hit, "null output");
+    WISP_REQUIRE(out_depth == nullptr || depths != nullptr, "out_depth needs depths");
+    hipStream_t s = (hipStream_t)stream;
+    const Bg b{bg[0], bg[1], bg[2]};
+    hipLaunchKernelGGL(composite_init_kernel, dim3((unsigned)ceil_div64(num_rays, 256)), dim3(256), 0, s, num_rays, b,
+                       out_rgb, out_alpha, out_depth, out_hit);
+    if (num_packs > 0) {
+        WISP_REQUIRE(color && density && deltas && ridx && pack_starts && weights, "null pointer");
+        hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)ceil_div64(num_packs, 4)), dim3(256), 0, s, color,
+                           density, deltas, out_depth ? depths : nullptr, ridx, pack_starts, num_packs, num_samples, b,
+                           out_rgb, out_alpha, out_depth, out_hit, weights);
+    }
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_composite_bwd(const float* grad_rgb, const float* grad_alpha, const float* grad_depth,
+                                  const float* color, const float* density, const float* deltas, const float* depths,
+                                  const int64_t* ridx, const int64_t* pack_starts, int64_t num_packs,
+                                  int64_t num_samples, const float* bg, float* grad_color, float* grad_density,
+                                  wisp_stream_t stream) {
+    WISP_REQUIRE(num_packs >= 0 && num_samples >= 0 && bg, "bad sizes");
+    if (num_packs == 0) return WISP_OK;
+    WISP_REQUIRE(grad_rgb && color && density && deltas && ridx && pack_starts && grad_color && grad_density,
+                 "null pointer");
+    const Bg b{bg[0], bg[1], bg[2]};
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)ceil_div64(num_packs, 4)), dim3(256), 0,
+                       (hipStream_t)stream, grad_rgb, grad_alpha, grad_depth, color, density, deltas, depths, ridx,
+                       pack_starts, num_packs, num_samples, b, grad_color, grad_density);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

@@ -1,0 +1,411 @@
+// SPC octree leaves for gfx950: point query, Morton occupancy bitfield, ray/octree intersection,
+// pack-boundary utilities and the prefix sums the two-phase (count -> scan -> emit) kernels need.
+//
+// Replaces the Kaolin-Core ops wisp calls at wisp/accelstructs/octree_as.py:162 (unbatched_query),
+// :183-185 (unbatched_raytrace), :300/:228 (mark_pack_boundaries / mark_first_hit) and :351
+// (inclusive_sum_cuda).  Semantics: SURVEY.md Appendix A; float operation order: oracle/spc.py.
+#include "wisp_common.h"
+
+// ---------------------------------------------------------------------------------------------- query
+// child slot of quantised point q at depth l of a `level`-deep walk: xbit<<2 | ybit<<1 | zbit
+static __device__ __forceinline__ int child_slot(int qx, int qy, int qz, int sh) {
+    return (((qx >> sh) & 1) << 2) | (((qy >> sh) & 1) << 1) | ((qz >> sh) & 1);
+}
+
+static __device__ __forceinline__ bool quantize_inside(float x, float y, float z, int level, int& qx, int& qy, int& qz) {
+    // |x| <= 1 on every axis (NaN fails), q = min(floor(2^level * fl(0.5x + 0.5)), 2^level - 1)
+    const bool inside = (fabsf(x) <= 1.0f) && (fabsf(y) <= 1.0f) && (fabsf(z) <= 1.0f);
+    const float res = (float)(1 << level);
+    const int top = (1 << level) - 1;
+    qx = min((int)floorf(res * (0.5f * x + 0.5f)), top);
+    qy = min((int)floorf(res * (0.5f * y + 0.5f)), top);
+    qz = min((int)floorf(res * (0.5f * z + 0.5f)), top);
+    return inside;
+}
+
+__global__ void __launch_bounds__(256)
+spc_query_kernel(const uint8_t* __restrict__ octree, const int32_t* __restrict__ exsum,
+                 const float* __restrict__ coords, int64_t n, int level, int with_parents,
+                 int64_t* __restrict__ pidx) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int qx, qy, qz;
+        const bool inside = quantize_inside(coords[i * 3 + 0], coords[i * 3 + 1], coords[i * 3 + 2], level, qx, qy, qz);
+        int64_t node = inside ? 0 : -1;
+        int64_t* row = with_parents ? pidx + i * (level + 1) : nullptr;
+        if (row) row[0] = node;
+        for (int l = 0; l < level; ++l) {
+            if (node >= 0) {
+                const int c = child_slot(qx, qy, qz, level - 1 - l);
+                const uint32_t bits = octree[node];
+                node = ((bits >> c) & 1u) ? (int64_t)exsum[node] + __popc(bits & ((2u << c) - 1u)) : -1;
+            }
+            if (row) row[l + 1] = node;
+        }
+        if (!row) pidx[i] = node;
+    }
+}
+
+extern "C" int wisp_spc_query(const uint8_t* octree, const int32_t* exsum, const float* coords, int64_t n, int level,
+                              int with_parents, int64_t* pidx, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0 && level >= 0 && level <= 15, "bad n / level");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(exsum && coords && pidx && (octree || level == 0), "null pointer");
+    const int grid = (int)min64(ceil_div64(n, 256), 8192);
+    hipLaunchKernelGGL(spc_query_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, octree, exsum, coords, n, level,
+                       with_parents, pidx);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- bitfield
+static __device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z, int level) {
+    uint32_t m = 0;
+    for (int b = 0; b < level; ++b)
+        m |= (((x >> b) & 1u) << (3 * b + 2)) | (((y >> b) & 1u) << (3 * b + 1)) | (((z >> b) & 1u) << (3 * b));
+    return m;
+}
+
+__global__ void __launch_bounds__(256)
+spc_bitfield_kernel(const int16_t* __restrict__ pts, int64_t n, int level, uint32_t* __restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t m = morton3((uint32_t)pts[i * 3], (uint32_t)pts[i * 3 + 1], (uint32_t)pts[i * 3 + 2], level);
+    atomicOr(bits + (m >> 5), 1u << (m & 31u));
+}
+
+extern "C" int wisp_spc_build_bitfield(const int16_t* level_points, int64_t n_points, int level, uint32_t* bits,
+                                       wisp_stream_t stream) {
+    WISP_REQUIRE(level >= 0 && level <= 10 && bits && n_points >= 0, "level must be in [0,10]");
+    const int64_t cells = (int64_t)1 << (3 * level);
+    const int64_t words = (cells + 31) / 32;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(bits, 0, words * 4, s) != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, "memset");
+    if (n_points == 0) return WISP_OK;
+    WISP_REQUIRE(level_points, "null points");
+    hipLaunchKernelGGL(spc_bitfield_kernel, dim3((unsigned)ceil_div64(n_points, 256)), dim3(256), 0, s, level_points,
+                       n_points, level, bits);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- raytrace
+#define RT_MAX_LEVEL 15
+#define RT_BLOCK 128
+
+struct Slab { bool hit; float entry, exit; float cx, cy, cz; };
+
+// float32 slab test, operation order fixed by oracle/spc.py::slab_test (see comment there)
+static __device__ __forceinline__ Slab slab_test(float ox, float oy, float oz, float ix, float iy, float iz,
+                                                 int px, int py, int pz, int level) {
+    Slab s;
+    const float r = 1.0f / (float)(1 << level);
+    s.cx = r * (2.0f * (float)px + 1.0f) - 1.0f;     // exact in fp32 (power-of-two scaling)
+    s.cy = r * (2.0f * (float)py + 1.0f) - 1.0f;
+    s.cz = r * (2.0f * (float)pz + 1.0f) - 1.0f;
+    const float t0x = ((s.cx - r) - ox) * ix, t1x = ((s.cx + r) - ox) * ix;
+    const float t0y = ((s.cy - r) - oy) * iy, t1y = ((s.cy + r) - oy) * iy;
+    const float t0z = ((s.cz - r) - oz) * iz, t1z = ((s.cz + r) - oz) * iz;
+    const float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    const float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    s.entry = fmaxf(tmin, 0.0f);
+    s.exit = tmax;
+    s.hit = tmax > s.entry;
+    return s;
+}
+
+// Depth-first traversal with children visited in (i XOR code) order, code from the ray ORIGIN's octant
+// relative to the node centre.  EMIT = false: count only.
+template <bool EMIT>
+__global__ void __launch_bounds__(RT_BLOCK)
+spc_raytrace_kernel(const uint8_t* __restrict__ octree, const int16_t* __restrict__ points,
+                    const int32_t* __restrict__ exsum, const float* __restrict__ origins,
+                    const float* __restrict__ dirs, int64_t num_rays, int level, const int64_t* __restrict__ offsets,
+                    int with_exit, int32_t* __restrict__ counts, int32_t* __restrict__ out_ridx,
+                    int32_t* __restrict__ out_pidx, float* __restrict__ out_depth) {
+    __shared__ int32_t s_node[RT_MAX_LEVEL + 1][RT_BLOCK];
+    __shared__ uint32_t s_state[RT_MAX_LEVEL + 1][RT_BLOCK];   // iter (4b) | code (3b) << 4 | bits (8b) << 8
+    const int t = threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.x * RT_BLOCK + t;
+    if (r >= num_rays) return;
+    const float ox = origins[r * 3], oy = origins[r * 3 + 1], oz = origins[r * 3 + 2];
+    const float ix = __fdiv_rn(1.0f, dirs[r * 3]), iy = __fdiv_rn(1.0f, dirs[r * 3 + 1]), iz = __fdiv_rn(1.0f, dirs[r * 3 + 2]);
+    int64_t wr = EMIT ? offsets[r] : 0;
+    int32_t cnt = 0;
+
+    Slab s = slab_test(ox, oy, oz, ix, iy, iz, 0, 0, 0, 0);
+    if (s.hit) {
+        if (level == 0) {
+            if (EMIT) {
+                out_ridx[wr] = (int32_t)r; out_pidx[wr] = 0;
+                if (with_exit) { out_depth[wr * 2] = s.entry; out_depth[wr * 2 + 1] = s.exit; } else out_depth[wr] = s.entry;
+            }
+            cnt = 1;
+        } else {
+            int l = 0;
+            uint32_t code = ((ox > s.cx) ? 4u : 0u) | ((oy > s.cy) ? 2u : 0u) | ((oz > s.cz) ? 1u : 0u);
+            s_node[0][t] = 0;
+            s_state[0][t] = 0u | (code << 4) | ((uint32_t)octree[0] << 8);
+            while (l >= 0) {
+                const uint32_t st = s_state[l][t];
+                uint32_t it = st & 15u;
+                if (it >= 8u) { --l; continue; }
+                const uint32_t cd = (st >> 4) & 7u, bits = st >> 8;
+                const uint32_t j = it ^ cd;
+                s_state[l][t] = st + 1u;                       // advance iterator
+                if (!((bits >> j) & 1u)) continue;
+                const int32_t node = s_node[l][t];
+                const int32_t child = exsum[node] + __popc(bits & ((2u << j) - 1u));
+                const int px = points[(int64_t)child * 3], py = points[(int64_t)child * 3 + 1], pz = points[(int64_t)child * 3 + 2];
+                const Slab c = slab_test(ox, oy, oz, ix, iy, iz, px, py, pz, l + 1);
+                if (!c.hit) continue;
+                if (l + 1 == level) {
+                    if (EMIT) {
+                        out_ridx[wr] = (int32_t)r; out_pidx[wr] = child;
+                        if (with_exit) { out_depth[wr * 2] = c.entry; out_depth[wr * 2 + 1] = c.exit; } else out_depth[wr] = c.entry;
+                        ++wr;
+                    }
+                    ++cnt;
+                } else {
+                    ++l;
+                    const uint32_t ccode = ((ox > c.cx) ? 4u : 0u) | ((oy > c.cy) ? 2u : 0u) | ((oz > c.cz) ? 1u : 0u);
+                    s_node[l][t] = child;
+                    s_state[l][t] = 0u | (ccode << 4) | ((uint32_t)octree[child] << 8);
+                }
+            }
+        }
+    }
+    if (!EMIT) counts[r] = cnt;
+}
+
+extern "C" int wisp_spc_raytrace_count(const uint8_t* octree, const int16_t* points, const int32_t* exsum,
+                                       const float* origins, const float* dirs, int64_t num_rays, int level,
+                                       int32_t* counts, wisp_stream_t stream) {
+    WISP_REQUIRE(num_rays >= 0 && level >= 0 && level <= RT_MAX_LEVEL, "bad num_rays / level");
+    if (num_rays == 0) return WISP_OK;
+    WISP_REQUIRE(points && exsum && origins && dirs && counts && (octree || level == 0), "null pointer");
+    hipLaunchKernelGGL(spc_raytrace_kernel<false>, dim3((unsigned)ceil_div64(num_rays, RT_BLOCK)), dim3(RT_BLOCK), 0,
+                       (hipStream_t)stream, octree, points, exsum, origins, dirs, num_rays, level, nullptr, 0, counts,
+                       nullptr, nullptr, nullptr);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_spc_raytrace_emit(const uint8_t* octree, const int16_t* points, const int32_t* exsum,
+                                      const float* origins, const float* dirs, int64_t num_rays, int level,
+                                      const int64_t* offsets, int with_exit, int32_t* ridx, int32_t* pidx, float* depth,
+                                      wisp_stream_t stream) {
+    WISP_REQUIRE(num_rays >= 0 && level >= 0 && level <= RT_MAX_LEVEL, "bad num_rays / level");
+    if (num_rays == 0) return WISP_OK;
+    WISP_REQUIRE(points && exsum && origins && dirs && offsets && ridx && pidx && depth && (octree || level == 0),
+                 "null pointer");
+    hipLaunchKernelGGL(spc_raytrace_kernel<true>, dim3((unsigned)ceil_div64(num_rays, RT_BLOCK)), dim3(RT_BLOCK), 0,
+                       (hipStream_t)stream, octree, points, exsum, origins, dirs, num_rays, level, offsets, with_exit,
+                       nullptr, ridx, pidx, depth);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- pack boundaries
+template <typename I>
+__global__ void __launch_bounds__(256)
+mark_boundaries_kernel(const I* __restrict__ ids, int64_t n, uint8_t* __restrict__ b) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    b[i] = (i == 0 || ids[i] != ids[i - 1]) ? 1 : 0;
+}
+
+extern "C" int wisp_mark_pack_boundaries_i64(const int64_t* ids, int64_t n, uint8_t* boundary, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0, "negative n");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(ids && boundary, "null pointer");
+    hipLaunchKernelGGL(mark_boundaries_kernel<int64_t>, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, ids, n, boundary);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_mark_pack_boundaries_i32(const int32_t* ids, int64_t n, uint8_t* boundary, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0, "negative n");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(ids && boundary, "null pointer");
+    hipLaunchKernelGGL(mark_boundaries_kernel<int32_t>, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, ids, n, boundary);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- scans
+// Three-phase scan: (1) per-tile sums, (2) one workgroup scans the tile sums, (3) per-tile rescan with the
+// tile's base.  Tile = 256 threads x 8 items.  Wave-level scan by DPP-friendly __shfl_up over 64 lanes.
+#define SC_THREADS 256
+#define SC_ITEMS 8
+#define SC_TILE (SC_THREADS * SC_ITEMS)
+
+static __device__ __forceinline__ int64_t wave_incl_scan(int64_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across a 256-thread workgroup; returns exclusive prefix, *total = sum
+static __device__ __forceinline__ int64_t block_excl_scan(int64_t v, int64_t* total) {
+    __shared__ int64_t s_w[SC_THREADS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int64_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SC_THREADS / 64; ++k) {
+        const int64_t x = s_w[k];
+        if (k < w) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+template <typename IN>
+__global__ void __launch_bounds__(SC_THREADS)
+scan_tile_sums_kernel(const IN* __restrict__ in, int64_t n, int64_t* __restrict__ tile_sums) {
+    const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_ITEMS;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k)
+        if (base + k < n) s += (int64_t)in[base + k];
+    int64_t tot;
+    block_excl_scan(s, &tot);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// in-place exclusive scan of tile_sums by ONE workgroup; writes the grand total to *total_out (may be null)
+__global__ void __launch_bounds__(SC_THREADS)
+scan_spine_kernel(int64_t* __restrict__ tile_sums, int64_t nt, int64_t* __restrict__ total_out) {
+    int64_t carry = 0;
+    for (int64_t b = 0; b < nt; b += SC_THREADS) {
+        const int64_t i = b + threadIdx.x;
+        const int64_t v = i < nt ? tile_sums[i] : 0;
+        int64_t tot;
+        const int64_t ex = block_excl_scan(v, &tot);
+        if (i < nt) tile_sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+template <typename IN, typename OUT, bool INCLUSIVE>
+__global__ void __launch_bounds__(SC_THREADS)
+scan_apply_kernel(const IN* __restrict__ in, int64_t n, const int64_t* __restrict__ tile_base, OUT* __restrict__ out) {
+    const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_ITEMS;
+    int64_t v[SC_ITEMS];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k) {
+        v[k] = (base + k < n) ? (int64_t)in[base + k] : 0;
+        s += v[k];
+    }
+    int64_t tot;
+    int64_t run = block_excl_scan(s, &tot) + tile_base[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = (OUT)(INCLUSIVE ? run + v[k] : run);
+        run += v[k];
+    }
+}
+
+extern "C" int64_t wisp_scan_workspace_bytes(int64_t n) {
+    const int64_t nt = n > 0 ? ceil_div64(n, SC_TILE) : 1;
+    return (nt + 8) * 8;
+}
+
+extern "C" int wisp_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* offsets, void* workspace,
+                                       wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0 && offsets, "bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (hipMemsetAsync(offsets, 0, 8, s) != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, "memset");
+        return WISP_OK;
+    }
+    WISP_REQUIRE(counts && workspace, "null pointer");
+    int64_t* tiles = (int64_t*)workspace;
+    const int64_t nt = ceil_div64(n, SC_TILE);
+    hipLaunchKernelGGL(scan_tile_sums_kernel<int32_t>, dim3((unsigned)nt), dim3(SC_THREADS), 0, s, counts, n, tiles);
+    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(SC_THREADS), 0, s, tiles, nt, offsets + n);
+    hipLaunchKernelGGL((scan_apply_kernel<int32_t, int64_t, false>), dim3((unsigned)nt), dim3(SC_THREADS), 0, s, counts,
+                       n, tiles, offsets);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_inclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* workspace,
+                                       wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0, "negative n");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(in && out && workspace, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t* tiles = (int64_t*)workspace;
+    const int64_t nt = ceil_div64(n, SC_TILE);
+    hipLaunchKernelGGL(scan_tile_sums_kernel<int32_t>, dim3((unsigned)nt), dim3(SC_THREADS), 0, s, in, n, tiles);
+    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(SC_THREADS), 0, s, tiles, nt, (int64_t*)nullptr);
+    hipLaunchKernelGGL((scan_apply_kernel<int32_t, int32_t, true>), dim3((unsigned)nt), dim3(SC_THREADS), 0, s, in, n,
+                       tiles, out);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- boundary -> pack starts
+__global__ void __launch_bounds__(SC_THREADS)
+boundary_tile_counts_kernel(const uint8_t* __restrict__ b, int64_t n, int32_t* __restrict__ counts) {
+    const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_ITEMS;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k)
+        if (base + k < n) s += b[base + k] ? 1 : 0;
+    int64_t tot;
+    block_excl_scan(s, &tot);
+    if (threadIdx.x == 0) counts[blockIdx.x] = (int32_t)tot;
+}
+
+__global__ void __launch_bounds__(SC_THREADS)
+boundary_pack_starts_kernel(const uint8_t* __restrict__ b, int64_t n, const int64_t* __restrict__ tile_offsets,
+                            int64_t* __restrict__ starts) {
+    const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_ITEMS;
+    uint8_t f[SC_ITEMS];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k) {
+        f[k] = (base + k < n) ? b[base + k] : 0;
+        s += f[k] ? 1 : 0;
+    }
+    int64_t tot;
+    int64_t run = block_excl_scan(s, &tot) + tile_offsets[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k)
+        if (f[k]) starts[run++] = base + k;
+}
+
+extern "C" int wisp_boundary_tile_counts(const uint8_t* boundary, int64_t n, int32_t* counts, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0, "negative n");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(boundary && counts, "null pointer");
+    hipLaunchKernelGGL(boundary_tile_counts_kernel, dim3((unsigned)ceil_div64(n, SC_TILE)), dim3(SC_THREADS), 0,
+                       (hipStream_t)stream, boundary, n, counts);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_boundary_pack_starts(const uint8_t* boundary, int64_t n, const int64_t* tile_offsets,
+                                         int64_t* starts, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0, "negative n");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(boundary && tile_offsets && starts, "null pointer");
+    hipLaunchKernelGGL(boundary_pack_starts_kernel, dim3((unsigned)ceil_div64(n, SC_TILE)), dim3(SC_THREADS), 0,
+                       (hipStream_t)stream, boundary, n, tile_offsets, starts);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

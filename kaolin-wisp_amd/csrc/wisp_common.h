@@ -1,0 +1,57 @@
+// Shared device/host helpers for the gfx950 kernels.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/wisp_hip.h"
+
+#define WISP_WAVE 64
+
+extern thread_local char g_wisp_err[512];
+
+static inline int wisp_fail(int code, const char* what, const char* detail) {
+    snprintf(g_wisp_err, sizeof(g_wisp_err), "%s: %s", what, detail ? detail : "");
+    return code;
+}
+
+#define WISP_REQUIRE(cond, what)                                              \
+    do {                                                                      \
+        if (!(cond)) return wisp_fail(WISP_ERR_INVALID, __func__, what);      \
+    } while (0)
+
+#define WISP_CHECK_LAUNCH()                                                   \
+    do {                                                                      \
+        hipError_t e_ = hipGetLastError();                                    \
+        if (e_ != hipSuccess)                                                 \
+            return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t min64(int64_t a, int64_t b) { return a < b ? a : b; }
+
+// ---- storage-type conversion (tables / activations may be f32, f16 or bf16) ------------------------
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+    static __device__ __forceinline__ float to_f(float v) { return v; }
+    static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Cvt<__half> {
+    static __device__ __forceinline__ float to_f(__half v) { return __half2float(v); }
+    static __device__ __forceinline__ __half from_f(float v) { return __float2half_rn(v); }
+};
+template <> struct Cvt<__hip_bfloat16> {
+    static __device__ __forceinline__ float to_f(__hip_bfloat16 v) { return __bfloat162float(v); }
+    static __device__ __forceinline__ __hip_bfloat16 from_f(float v) { return __float2bfloat16(v); }
+};
+
+// Counter-based uniform [0,1) generator keyed by (seed, a, b): two rounds of a 64-bit mix
+// (splitmix64 finaliser).  Used only when the caller does not inject a jitter tensor.
+static __device__ __forceinline__ float wisp_uniform01(uint64_t seed, uint64_t a, uint64_t b) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (a + 1) + 0xD1B54A32D192ED03ull * (b + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0,1)
+}

@@ -1,0 +1,399 @@
+"""ctypes binding of libwisp_hip.so - the C ABI declared in include/wisp_hip.h.
+
+Plays the role of the reference's pybind module ``wisp._C`` (wisp/csrc/bindings.cpp:21-35) plus the
+Kaolin-Core leaves wisp calls.  There is NO fallback: if the shared library is missing, importing this
+module raises, and every op refuses tensors that are not on the GPU.
+The functions below are thin: they allocate outputs from torch (so the caching allocator and the
+current stream stay PyTorch's), pass raw device pointers + the current HIP stream, and check the status.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libwisp_hip.so"))
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"wisp HIP extension not built: {LIB_PATH} is missing. Build it with "
+        f"`make -C {os.path.dirname(LIB_PATH)}` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+        "There is no CPU fallback for the hot path.")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+F32, F16, BF16 = 0, 1, 2
+_DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+c_vp, c_i64, c_i32, c_f32, c_u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_uint64
+
+# name -> argtypes (restype int unless listed in _RESTYPES); mirrors include/wisp_hip.h one to one
+SIGNATURES = {
+    "wisp_hashgrid_interpolate_fwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
+    "wisp_hashgrid_interpolate_bwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
+    "wisp_spc_query": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
+    "wisp_spc_build_bitfield": [c_vp, c_i64, c_i32, c_vp, c_vp],
+    "wisp_spc_raytrace_count": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp],
+    "wisp_spc_raytrace_emit": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "wisp_mark_pack_boundaries_i64": [c_vp, c_i64, c_vp, c_vp],
+    "wisp_mark_pack_boundaries_i32": [c_vp, c_i64, c_vp, c_vp],
+    "wisp_scan_workspace_bytes": [c_i64],
+    "wisp_exclusive_scan_i32": [c_vp, c_i64, c_vp, c_vp, c_vp],
+    "wisp_inclusive_scan_i32": [c_vp, c_i64, c_vp, c_vp, c_vp],
+    "wisp_boundary_tile_counts": [c_vp, c_i64, c_vp, c_vp],
+    "wisp_boundary_pack_starts": [c_vp, c_i64, c_vp, c_vp, c_vp],
+    "wisp_raymarch_ray_count": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_i32, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp],
+    "wisp_raymarch_ray_emit": [c_vp, c_vp, c_i64, c_f32, c_f32, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_raymarch_voxel_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_raymarch_uniform_count": [c_vp, c_i64, c_f32, c_vp, c_vp],
+    "wisp_raymarch_uniform_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_packed_sum_reduce": [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
+    "wisp_packed_cumsum": [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
+    "wisp_composite_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_composite_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp],
+    "wisp_nerf_mlp_param_count": [c_i32, c_i32, c_i32],
+    "wisp_nerf_mlp_fwd": [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp],
+    "wisp_nerf_mlp_bwd": [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp],
+    "wisp_last_error": [],
+    "wisp_abi_version": [],
+}
+_RESTYPES = {"wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_last_error": ctypes.c_char_p}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here == header/library mismatch: fail loudly
+    _fn.argtypes = _args
+    _fn.restype = _RESTYPES.get(_name, c_i32)
+
+
+# Live HIP-event timing of selected kernels (bench.py sets TIMING = {} around its timed region).  Events are
+# recorded on the stream the kernel is launched on (torch's current stream).
+TIMING = None
+
+
+class _timed:
+    def __init__(self, name, units):
+        self.name, self.units = name, units
+
+    def __enter__(self):
+        if TIMING is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if TIMING is not None:
+            self.e1.record()
+            TIMING.setdefault(self.name, []).append((self.e0, self.e1, self.units))
+        return False
+
+
+def last_error():
+    return lib.wisp_last_error().decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def _stream():
+    return c_vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    """device pointer of a tensor (or NULL)."""
+    return c_vp(0) if t is None else c_vp(t.data_ptr())
+
+
+def _need(t, dtype=None, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"wisp HIP op: `{name}` must be a GPU tensor (the hot path has no CPU fallback); got "
+                           f"{type(t).__name__} on {getattr(t, 'device', None)}")
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _host_i32(values):
+    arr = np.ascontiguousarray(np.asarray(values, dtype=np.int32).reshape(-1))
+    return arr, arr.ctypes.data_as(c_vp)
+
+
+def _host_f32(values):
+    arr = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
+    return arr, arr.ctypes.data_as(c_vp)
+
+
+# ------------------------------------------------------------------------------------------------ hash grid
+def hashgrid_interpolate(coords, codebook, first_idx, resolutions, codebook_bitwidth, zero_from_col=None):
+    """feats[N, L*F] - the reference's wisp._C.ops.hashgrid_interpolate_cuda (hashgrid_interpolate.cpp:46-69)."""
+    coords = _need(coords, torch.float32, "coords")
+    codebook = _need(codebook, None, "codebook")
+    first_idx = _need(first_idx, torch.int64, "codebook_first_idx")
+    n, dim = coords.shape
+    L, F = len(resolutions), codebook.shape[1]
+    if zero_from_col is None:
+        zero_from_col = L * F
+    res_arr, res_ptr = _host_i32(resolutions)
+    feats = torch.empty(n, L * F, dtype=codebook.dtype, device=coords.device)
+    with _timed("hashgrid_fwd", n):
+        _check(lib.wisp_hashgrid_interpolate_fwd(_p(coords), n, dim, _p(codebook), _DTYPE_CODE[codebook.dtype], F,
+                                                 _p(first_idx), res_ptr, L, codebook_bitwidth, zero_from_col, _p(feats),
+                                                 _stream()), "hashgrid_interpolate_fwd")
+    return feats
+
+
+def hashgrid_interpolate_backward(coords, grad_feats, codebook_shape, first_idx, resolutions, codebook_bitwidth,
+                                  zero_from_col=None, out=None):
+    """fp32 grad_codebook - wisp._C.ops.hashgrid_interpolate_backward_cuda (hashgrid_interpolate.cpp:71-105).
+    `out` (fp32, same shape) is accumulated into when given."""
+    coords = _need(coords, torch.float32, "coords")
+    grad_feats = _need(grad_feats, None, "grad_feats")
+    first_idx = _need(first_idx, torch.int64, "codebook_first_idx")
+    n, dim = coords.shape
+    L, F = len(resolutions), codebook_shape[1]
+    if zero_from_col is None:
+        zero_from_col = L * F
+    res_arr, res_ptr = _host_i32(resolutions)
+    grad = out if out is not None else torch.zeros(tuple(codebook_shape), dtype=torch.float32, device=coords.device)
+    assert grad.dtype == torch.float32 and grad.is_contiguous()
+    with _timed("hashgrid_bwd", n):
+        _check(lib.wisp_hashgrid_interpolate_bwd(_p(coords), n, dim, _p(grad_feats), _DTYPE_CODE[grad_feats.dtype], F,
+                                                 _p(first_idx), res_ptr, L, codebook_bitwidth, zero_from_col, _p(grad),
+                                                 _stream()), "hashgrid_interpolate_bwd")
+    return grad
+
+
+# ------------------------------------------------------------------------------------------------ scans / packs
+def exclusive_scan(counts):
+    """int32 counts [n] -> int64 offsets [n+1] (offsets[n] = total)."""
+    counts = _need(counts, torch.int32, "counts")
+    n = counts.shape[0]
+    offsets = torch.empty(n + 1, dtype=torch.int64, device=counts.device)
+    ws = torch.empty(int(lib.wisp_scan_workspace_bytes(n)), dtype=torch.uint8, device=counts.device)
+    _check(lib.wisp_exclusive_scan_i32(_p(counts), n, _p(offsets), _p(ws), _stream()), "exclusive_scan")
+    return offsets
+
+
+def inclusive_scan(values):
+    """kaolin._C.render.spc.inclusive_sum_cuda (octree_as.py:351): int32 -> int32 inclusive prefix sum."""
+    values = _need(values, torch.int32, "values")
+    n = values.shape[0]
+    out = torch.empty_like(values)
+    ws = torch.empty(int(lib.wisp_scan_workspace_bytes(n)), dtype=torch.uint8, device=values.device)
+    _check(lib.wisp_inclusive_scan_i32(_p(values), n, _p(out), _p(ws), _stream()), "inclusive_scan")
+    return out
+
+
+def mark_pack_boundaries(ids):
+    """kaolin mark_pack_boundaries / mark_first_hit (octree_as.py:300, :228): bool [n]."""
+    ids = _need(ids, None, "ids")
+    n = ids.shape[0]
+    out = torch.empty(n, dtype=torch.bool, device=ids.device)
+    if ids.dtype == torch.int64:
+        _check(lib.wisp_mark_pack_boundaries_i64(_p(ids), n, _p(out), _stream()), "mark_pack_boundaries")
+    elif ids.dtype == torch.int32:
+        _check(lib.wisp_mark_pack_boundaries_i32(_p(ids), n, _p(out), _stream()), "mark_pack_boundaries")
+    else:
+        raise TypeError(f"mark_pack_boundaries expects int32/int64 ids, got {ids.dtype}")
+    return out
+
+
+def pack_starts(boundary):
+    """boundary bool [S] -> int64 [P] start index of every pack (== boundary.nonzero()[:,0])."""
+    boundary = _need(boundary, torch.bool, "boundary")
+    n = boundary.shape[0]
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=boundary.device)
+    ntiles = (n + 2047) // 2048
+    counts = torch.empty(ntiles, dtype=torch.int32, device=boundary.device)
+    _check(lib.wisp_boundary_tile_counts(_p(boundary), n, _p(counts), _stream()), "boundary_tile_counts")
+    offsets = exclusive_scan(counts)
+    num_packs = int(offsets[-1].item())
+    starts = torch.empty(num_packs, dtype=torch.int64, device=boundary.device)
+    _check(lib.wisp_boundary_pack_starts(_p(boundary), n, _p(offsets), _p(starts), _stream()), "boundary_pack_starts")
+    return starts
+
+
+# ------------------------------------------------------------------------------------------------ SPC
+def spc_query(octree, exsum, coords, level, with_parents=False):
+    """kaolin.ops.spc.unbatched_query (octree_as.py:162): int64 [Q] or [Q, level+1]."""
+    coords = _need(coords, torch.float32, "coords").reshape(-1, 3)
+    octree = _need(octree, torch.uint8, "octree")
+    exsum = _need(exsum, torch.int32, "exsum")
+    n = coords.shape[0]
+    shape = (n, level + 1) if with_parents else (n,)
+    pidx = torch.empty(shape, dtype=torch.int64, device=coords.device)
+    _check(lib.wisp_spc_query(_p(octree), _p(exsum), _p(coords), n, level, int(with_parents), _p(pidx), _stream()),
+           "spc_query")
+    return pidx
+
+
+def spc_bitfield(level_points, level):
+    """Morton-ordered occupancy bits of `level` (uint32 words viewed as int32 storage)."""
+    level_points = _need(level_points, torch.int16, "level_points")
+    words = max((8 ** level + 31) // 32, 1)
+    bits = torch.empty(words, dtype=torch.int32, device=level_points.device)
+    _check(lib.wisp_spc_build_bitfield(_p(level_points), level_points.shape[0], level, _p(bits), _stream()),
+           "spc_build_bitfield")
+    return bits
+
+
+def spc_raytrace(octree, points, exsum, origins, dirs, level, with_exit=False):
+    """kaolin.render.spc.unbatched_raytrace (octree_as.py:183-185).
+    Returns (ridx i32 [M], pidx i32 [M], depth f32 [M,1|2], ray_offsets i64 [R+1])."""
+    origins = _need(origins, torch.float32, "origins").reshape(-1, 3)
+    dirs = _need(dirs, torch.float32, "dirs").reshape(-1, 3)
+    octree = _need(octree, torch.uint8, "octree")
+    points = _need(points, torch.int16, "points")
+    exsum = _need(exsum, torch.int32, "exsum")
+    R = origins.shape[0]
+    dev = origins.device
+    counts = torch.empty(R, dtype=torch.int32, device=dev)
+    _check(lib.wisp_spc_raytrace_count(_p(octree), _p(points), _p(exsum), _p(origins), _p(dirs), R, level, _p(counts),
+                                       _stream()), "spc_raytrace_count")
+    offsets = exclusive_scan(counts)
+    M = int(offsets[-1].item())                      # size read-back, as the reference's kaolin op does
+    ridx = torch.empty(M, dtype=torch.int32, device=dev)
+    pidx = torch.empty(M, dtype=torch.int32, device=dev)
+    depth = torch.empty(M, 2 if with_exit else 1, dtype=torch.float32, device=dev)
+    if M:
+        _check(lib.wisp_spc_raytrace_emit(_p(octree), _p(points), _p(exsum), _p(origins), _p(dirs), R, level,
+                                          _p(offsets), int(with_exit), _p(ridx), _p(pidx), _p(depth), _stream()),
+               "spc_raytrace_emit")
+    return ridx, pidx, depth, offsets
+
+
+# ------------------------------------------------------------------------------------------------ raymarch
+def _alloc_samples(S, dev):
+    return (torch.empty(S, dtype=torch.int64, device=dev), torch.empty(S, 3, dtype=torch.float32, device=dev),
+            torch.empty(S, 1, dtype=torch.float32, device=dev), torch.empty(S, 1, dtype=torch.float32, device=dev),
+            torch.empty(S, dtype=torch.bool, device=dev))
+
+
+def raymarch_ray(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level, jitter=None, seed=0):
+    """OctreeAS._raymarch_ray (octree_as.py:247-309).  Returns (ridx, samples, depth, deltas, boundary, ray_offsets)."""
+    origins = _need(origins, torch.float32, "origins").reshape(-1, 3)
+    dirs = _need(dirs, torch.float32, "dirs").reshape(-1, 3)
+    R, dev = origins.shape[0], origins.device
+    if jitter is not None:
+        jitter = _need(jitter, torch.float32, "jitter")
+        assert jitter.numel() == R * num_samples, "jitter must be [num_rays, num_samples]"
+    near32 = float(np.float32(near))
+    range32 = float(np.float32(float(far) - float(near)))      # depth *= (dist_max - dist_min), python double -> f32
+    words = (num_samples + 31) // 32
+    hitmask = torch.empty(R, words, dtype=torch.int32, device=dev)
+    counts = torch.empty(R, dtype=torch.int32, device=dev)
+    _check(lib.wisp_raymarch_ray_count(_p(occ_bits), _p(octree), _p(exsum), _p(origins), _p(dirs), R, near32, range32,
+                                       num_samples, level, _p(jitter), seed, _p(hitmask), _p(counts), _stream()),
+           "raymarch_ray_count")
+    offsets = exclusive_scan(counts)
+    S = int(offsets[-1].item())                      # the reference syncs here too (nonzero, octree_as.py:288)
+    ridx, samples, depth, deltas, boundary = _alloc_samples(S, dev)
+    if S:
+        _check(lib.wisp_raymarch_ray_emit(_p(origins), _p(dirs), R, near32, range32, num_samples, _p(jitter), seed,
+                                          _p(hitmask), _p(offsets), _p(ridx), _p(samples), _p(depth), _p(deltas),
+                                          _p(boundary), _stream()), "raymarch_ray_emit")
+    return ridx, samples, depth, deltas, boundary, offsets
+
+
+def raymarch_voxel(origins, dirs, nug_ridx, nug_depth, num_samples, jitter=None, seed=0):
+    """OctreeAS._raymarch_voxel after the raytrace (octree_as.py:213-245)."""
+    origins = _need(origins, torch.float32, "origins").reshape(-1, 3)
+    dirs = _need(dirs, torch.float32, "dirs").reshape(-1, 3)
+    nug_ridx = _need(nug_ridx, torch.int32, "nug_ridx")
+    nug_depth = _need(nug_depth, torch.float32, "nug_depth")
+    M = nug_ridx.shape[0]
+    if jitter is not None:
+        jitter = _need(jitter, torch.float32, "jitter")
+        assert jitter.numel() == M * num_samples, "jitter must be [num_nuggets, num_samples]"
+    ridx, samples, depth, deltas, boundary = _alloc_samples(M * num_samples, origins.device)
+    if M:
+        _check(lib.wisp_raymarch_voxel_emit(_p(origins), _p(dirs), _p(nug_ridx), _p(nug_depth), M, num_samples,
+                                            _p(jitter), seed, _p(ridx), _p(samples), _p(depth), _p(deltas),
+                                            _p(boundary), _stream()), "raymarch_voxel_emit")
+    return ridx, samples, depth, deltas, boundary
+
+
+def raymarch_uniform(origins, dirs, nug_ridx, nug_depth, ray_offsets, scale):
+    """OctreeAS._raymarch_uniform after the raytrace (octree_as.py:336-372) + uniform_sample_cuda."""
+    origins = _need(origins, torch.float32, "origins").reshape(-1, 3)
+    dirs = _need(dirs, torch.float32, "dirs").reshape(-1, 3)
+    nug_ridx = _need(nug_ridx, torch.int32, "nug_ridx")
+    nug_depth = _need(nug_depth, torch.float32, "nug_depth")
+    M, dev = nug_ridx.shape[0], origins.device
+    counts = torch.empty(M, dtype=torch.int32, device=dev)
+    if M:
+        _check(lib.wisp_raymarch_uniform_count(_p(nug_depth), M, float(scale), _p(counts), _stream()),
+               "raymarch_uniform_count")
+    offsets = exclusive_scan(counts)
+    S = int(offsets[-1].item())                      # blocking read-back as in uniform_sample_cuda.cu:76
+    ridx, samples, depth, _, boundary = _alloc_samples(S, dev)
+    if S:
+        _check(lib.wisp_raymarch_uniform_emit(_p(origins), _p(dirs), _p(nug_ridx), _p(nug_depth), M, float(scale),
+                                              _p(offsets), _p(ray_offsets), _p(ridx), _p(samples), _p(depth),
+                                              _p(boundary), _stream()), "raymarch_uniform_emit")
+    return ridx, samples, depth, boundary
+
+
+# ------------------------------------------------------------------------------------------------ packed integration
+def packed_sum_reduce(feats, starts):
+    feats = _need(feats, torch.float32, "feats")
+    S, C = feats.shape
+    P = starts.shape[0]
+    out = torch.empty(P, C, dtype=torch.float32, device=feats.device)
+    _check(lib.wisp_packed_sum_reduce(_p(feats), S, C, _p(starts), P, _p(out), _stream()), "packed_sum_reduce")
+    return out
+
+
+def packed_cumsum(feats, starts, exclusive=False, reverse=False):
+    feats = _need(feats, torch.float32, "feats")
+    S, C = feats.shape
+    out = torch.empty_like(feats)
+    _check(lib.wisp_packed_cumsum(_p(feats), S, C, _p(starts), starts.shape[0], int(exclusive), int(reverse), _p(out),
+                                  _stream()), "packed_cumsum")
+    return out
+
+
+def composite_fwd(color, density, deltas, depths, ridx, starts, num_rays, bg):
+    color = _need(color, torch.float32, "color")
+    density = _need(density, torch.float32, "density")
+    deltas = _need(deltas, torch.float32, "deltas")
+    depths = None if depths is None else _need(depths, torch.float32, "depths")
+    S, dev = color.shape[0], color.device
+    rgb = torch.empty(num_rays, 3, dtype=torch.float32, device=dev)
+    alpha = torch.empty(num_rays, 1, dtype=torch.float32, device=dev)
+    depth = None if depths is None else torch.empty(num_rays, 1, dtype=torch.float32, device=dev)
+    hit = torch.empty(num_rays, dtype=torch.bool, device=dev)
+    weights = torch.empty(S, 1, dtype=torch.float32, device=dev)
+    bg_arr, bg_ptr = _host_f32(bg)
+    _check(lib.wisp_composite_fwd(_p(color), _p(density), _p(deltas), _p(depths), _p(ridx), _p(starts), starts.shape[0],
+                                  S, num_rays, bg_ptr, _p(rgb), _p(alpha), _p(depth), _p(hit), _p(weights), _stream()),
+           "composite_fwd")
+    return rgb, alpha, depth, hit, weights
+
+
+def composite_bwd(grad_rgb, grad_alpha, grad_depth, color, density, deltas, depths, ridx, starts, bg):
+    S, dev = color.shape[0], color.device
+    grad_rgb = _need(grad_rgb, torch.float32, "grad_rgb")
+    grad_alpha = None if grad_alpha is None else _need(grad_alpha, torch.float32, "grad_alpha")
+    grad_depth = None if grad_depth is None else _need(grad_depth, torch.float32, "grad_depth")
+    g_color = torch.empty(S, 3, dtype=torch.float32, device=dev)
+    g_density = torch.empty(S, 1, dtype=torch.float32, device=dev)
+    bg_arr, bg_ptr = _host_f32(bg)
+    _check(lib.wisp_composite_bwd(_p(grad_rgb), _p(grad_alpha), _p(grad_depth), _p(color), _p(density), _p(deltas),
+                                  _p(depths), _p(ridx), _p(starts), starts.shape[0], S, bg_ptr, _p(g_color),
+                                  _p(g_density), _stream()), "composite_bwd")
+    return g_color, g_density
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0,
+               zero_grad=False):
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    _check(lib.wisp_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2, eps,
+                               weight_decay, step, grad_scale, int(zero_grad), _stream()), "adamw_step")

@@ -1,0 +1,159 @@
+"""OctreeAS: sparse-octree (SPC) occupancy structure; query / raytrace / raymarch run as HIP kernels.
+
+Drop-in for wisp/accelstructs/octree_as.py:37-437: same constructors, attributes (octree, points, pyramid,
+prefix, max_level, extent) and result layouts.  Differences that matter on MI355X:
+  * 'ray' raymarch never materialises the R x N candidate tensors (octree_as.py:272-298): a count kernel keeps a
+    1-bit-per-candidate mask, a scan turns per-ray counts into offsets, an emit kernel writes only survivors;
+  * the occupancy test is a lookup in a Morton-ordered bitfield of the marching level, built once per structure;
+  * `raymarch(..., jitter=...)` optionally injects the stratification jitter so identical ray batches give
+    identical samples (the reference is unseeded).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+import torch
+
+import wisp.ops.spc as wisp_spc_ops
+from wisp.accelstructs.base_as import BaseAS, ASQueryResults, ASRaytraceResults, ASRaymarchResults
+
+
+def _hip():
+    import wisp._C as _C      # raises ImportError when libwisp_hip.so is not built: no fallback
+    return _C
+
+
+class OctreeAS(BaseAS):
+    """Bottom-level acceleration structure over a Structured Point Cloud octree."""
+
+    def __init__(self, octree):
+        """octree (torch.ByteTensor): one occupancy byte per non-leaf node, breadth first, Morton order."""
+        super().__init__()
+        self.octree = octree
+        self.points, self.pyramid, self.prefix = wisp_spc_ops.octree_to_spc(octree)
+        self.max_level = self.pyramid.shape[-1] - 2
+        self.extent = dict()
+        self._occ_bits = {}          # level -> Morton bitfield (device tensor), built lazily
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_mesh(cls, mesh_path: str, level: int, sample_tex: bool = False,
+                  num_samples_on_mesh: int = 100000000) -> OctreeAS:
+        """Mesh ingestion (OBJ load + surface sampling) is dataset preparation, outside the hot path."""
+        raise NotImplementedError("OctreeAS.from_mesh: mesh ingestion is out of scope of this backend; "
+                                  "sample the surface offline and use OctreeAS.from_pointcloud.")
+
+    @classmethod
+    def from_pointcloud(cls, pointcloud: torch.FloatTensor, level: int) -> OctreeAS:
+        """Cells of `level` containing at least one point of `pointcloud` ([N,3] in [-1,1]) are occupied."""
+        return cls(wisp_spc_ops.pointcloud_to_octree(pointcloud, level, dilate=0))
+
+    @classmethod
+    def from_quantized_points(cls, quantized_points: torch.LongTensor, level: int) -> OctreeAS:
+        """quantized_points: integer cell coordinates [N,3] in [0, 2**level)."""
+        return cls(wisp_spc_ops.unbatched_points_to_octree(quantized_points, level, sorted=False))
+
+    @classmethod
+    def make_dense(cls, level: int) -> OctreeAS:
+        """Fully occupied octree of depth `level`."""
+        return cls(wisp_spc_ops.create_dense_octree(level))
+
+    # ------------------------------------------------------------------ state helpers
+    def _to_device(self, device):
+        if self.octree.device != device:
+            self.octree = self.octree.to(device)
+            self.points = self.points.to(device)
+            self.prefix = self.prefix.to(device)
+            self._occ_bits = {}
+
+    def _bitfield(self, level):
+        bits = self._occ_bits.get(level)
+        if bits is None and level <= 10:
+            pts = wisp_spc_ops.unbatched_get_level_points(self.points, self.pyramid, level)
+            bits = _hip().spc_bitfield(pts, level)
+            self._occ_bits[level] = bits
+        return bits
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_occ_bits'] = {}
+        return state
+
+    # ------------------------------------------------------------------ queries
+    def query(self, coords, level=None, with_parents=False) -> ASQueryResults:
+        """Cell index of `level` containing each coordinate ([N,3] in [-1,1]), -1 if empty / outside."""
+        if level is None:
+            level = self.max_level
+        self._to_device(coords.device)
+        return ASQueryResults(pidx=_hip().spc_query(self.octree, self.prefix, coords, level, with_parents))
+
+    def raytrace(self, rays, level=None, with_exit=False) -> ASRaytraceResults:
+        """All ray / cell intersections at `level`, sorted by ray then front to back."""
+        if level is None:
+            level = self.max_level
+        self._to_device(rays.origins.device)
+        ridx, pidx, depth, offsets = _hip().spc_raytrace(self.octree, self.points, self.prefix, rays.origins,
+                                                         rays.dirs, level, with_exit)
+        res = ASRaytraceResults(ridx=ridx, pidx=pidx, depth=depth)
+        res.ray_offsets = offsets     # nugget range of every ray; used by 'uniform' raymarch
+        return res
+
+    # ------------------------------------------------------------------ raymarch
+    @staticmethod
+    def _draw_seed():
+        return int(torch.randint(0, 2 ** 62, (1,)).item())   # follows torch.manual_seed
+
+    def _raymarch_voxel(self, rays, num_samples, level=None, jitter=None) -> ASRaymarchResults:
+        """num_samples jittered samples inside every intersected cell (S = nuggets * num_samples)."""
+        rt = self.raytrace(rays, level, with_exit=True)
+        ridx, samples, depth, deltas, boundary = _hip().raymarch_voxel(
+            rays.origins, rays.dirs, rt.ridx, rt.depth, num_samples, jitter, self._draw_seed())
+        return ASRaymarchResults(ridx=ridx, samples=samples, depth_samples=depth, deltas=deltas, boundary=boundary,
+                                 pack_info=None)
+
+    def _raymarch_ray(self, rays, num_samples, level=None, jitter=None) -> ASRaymarchResults:
+        """num_samples stratified samples between dist_min and dist_max, keeping those inside occupied cells."""
+        if torch.is_tensor(rays.dist_min) or torch.is_tensor(rays.dist_max):
+            raise TypeError("'ray' raymarch needs scalar Rays.dist_min / dist_max (as the reference, octree_as.py:276-277)")
+        self._to_device(rays.origins.device)
+        ridx, samples, depth, deltas, boundary, offsets = _hip().raymarch_ray(
+            self._bitfield(level), self.octree, self.prefix, rays.origins, rays.dirs, rays.dist_min, rays.dist_max,
+            num_samples, level, jitter, self._draw_seed())
+        res = ASRaymarchResults(ridx=ridx, samples=samples, depth_samples=depth, deltas=deltas, boundary=boundary,
+                                pack_info=None)
+        res.ray_offsets = offsets
+        return res
+
+    def _raymarch_uniform(self, rays, num_samples, level=None) -> ASRaymarchResults:
+        """Fixed world-space lattice of spacing ~2*sqrt(3)/num_samples clipped to the intersected cells."""
+        rt = self.raytrace(rays, level, with_exit=True)
+        step_size = 2 * np.sqrt(3) / num_samples
+        scale = int(np.ceil(1.0 / step_size))
+        step_size = 1.0 / float(scale)
+        ridx, samples, depth, boundary = _hip().raymarch_uniform(rays.origins, rays.dirs, rt.ridx, rt.depth,
+                                                                 rt.ray_offsets, scale)
+        deltas = torch.full((ridx.shape[0], 1), step_size, dtype=torch.float32, device=depth.device)
+        return ASRaymarchResults(ridx=ridx, samples=samples, depth_samples=depth, deltas=deltas, boundary=boundary)
+
+    def raymarch(self, rays, raymarch_type, num_samples, level=None, jitter=None) -> ASRaymarchResults:
+        """Generate packed samples along `rays`; raymarch_type in {'voxel', 'ray', 'uniform'}."""
+        if level is None:
+            level = self.max_level
+        if raymarch_type == 'voxel':
+            return self._raymarch_voxel(rays=rays, num_samples=num_samples, level=level, jitter=jitter)
+        elif raymarch_type == 'ray':
+            return self._raymarch_ray(rays=rays, num_samples=num_samples, level=level, jitter=jitter)
+        elif raymarch_type == 'uniform':
+            return self._raymarch_uniform(rays=rays, num_samples=num_samples, level=level)
+        raise TypeError(f"Raymarch sampler type: {raymarch_type} is not supported by OctreeAS.")
+
+    # ------------------------------------------------------------------ stats
+    def occupancy(self) -> List[int]:
+        return self.pyramid[0, :-2].cpu().numpy().tolist()
+
+    def capacity(self) -> List[int]:
+        return [8 ** lod for lod in range(self.max_level)]
+
+    def name(self) -> str:
+        return "Octree"

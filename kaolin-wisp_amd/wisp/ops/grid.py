@@ -1,0 +1,75 @@
+"""Grid interpolation ops: autograd front of the HIP hash-grid kernels.
+
+Counterpart of wisp/ops/grid.py:16-144.  `hashgrid` / `HashGridInterpolate` keep the reference signature;
+forward and backward are single launches over all levels (csrc/hashgrid.hip).  Differences: the gradient table
+is accumulated in fp32 (the reference adds __half2 atomics in the table dtype), bf16 tables are accepted, and
+the 'cat' zeroing of HashGrid.interpolate can be fused through `zero_from_col`.
+"""
+import torch
+
+PRIMES = [1, 2654435761, 805459861]
+
+
+def _hip():
+    import wisp._C as _C
+    return _C
+
+
+def _as_int_list(resolutions):
+    if torch.is_tensor(resolutions):
+        return [int(r) for r in resolutions.reshape(-1).tolist()]
+    return [int(r) for r in resolutions]
+
+
+class HashGridInterpolate(torch.autograd.Function):
+    """feats[N, L*F] = multi-resolution (dense or hashed) trilinear / bilinear lookup of `codebook`."""
+
+    @staticmethod
+    def forward(ctx, coords, resolutions, codebook_bitwidth, lod_idx, codebook, codebook_first_idx, zero_from_col=None):
+        if codebook.shape[-1] % 2 == 1:
+            raise Exception("The codebook feature dimension needs to be a multiple of 2.")
+        assert coords.shape[-1] in [2, 3]
+        table = codebook
+        if torch.is_autocast_enabled():
+            # the reference casts to fp16 under autocast (grid.py:88-89); follow the active autocast dtype (bf16 on MI355X)
+            table = codebook.to(torch.get_autocast_gpu_dtype())
+        res = _as_int_list(resolutions)
+        feats = _hip().hashgrid_interpolate(coords.detach(), table.detach(), codebook_first_idx, res, codebook_bitwidth,
+                                            zero_from_col)
+        ctx.save_for_backward(coords, codebook_first_idx)
+        ctx.meta = (res, codebook_bitwidth, tuple(codebook.shape), codebook.dtype, zero_from_col)
+        # a trainer may pre-allocate the fp32 gradient buffer of the table (flat-parameter layout): scatter into it
+        ctx.grad_buffer = getattr(codebook, '_wisp_grad_buffer', None)
+        return feats
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        coords, first_idx = ctx.saved_tensors
+        res, bitwidth, shape, dtype, zero_from_col = ctx.meta
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradients w.r.t. hash-grid coordinates are not provided (the reference's are "
+                                      "known-broken, hashgrid_interpolate_cuda.cu:165-166; no in-scope caller needs them)")
+        buf = ctx.grad_buffer
+        grad = _hip().hashgrid_interpolate_backward(coords.detach().float(), grad_output.contiguous(), shape, first_idx,
+                                                    res, bitwidth, zero_from_col, out=buf)
+        if buf is not None:
+            return None, None, None, None, None, None, None      # accumulated in place, nothing for autograd to add
+        return None, None, None, None, grad.to(dtype), None, None
+
+
+def hashgrid(coords, codebook_bitwidth, lod_idx, codebook, zero_from_col=None):
+    """Hash-grid query + interpolation.
+
+    Args:
+        coords (torch.FloatTensor): [batch, 2 or 3] in [-1, 1]
+        codebook_bitwidth (int): the hashed levels have 2^bitwidth entries
+        lod_idx (int): unused by the kernel (all levels are evaluated, as in the reference)
+        codebook (wisp.models.grids.utils.MultiTable): stacked per-level tables
+    Returns:
+        (torch.Tensor): [batch, num_lods * feature_dim]
+    """
+    batch, dim = coords.shape
+    feats = HashGridInterpolate.apply(coords.contiguous(), codebook.resolutions, codebook_bitwidth, lod_idx,
+                                      codebook.feats, codebook.begin_idxes, zero_from_col)
+    feature_dim = codebook.feats.shape[1] * len(codebook.resolutions)
+    return feats.reshape(batch, feature_dim)

@@ -1,0 +1,2 @@
+from .base_tracer import BaseTracer
+from .packed_rf_tracer import PackedRFTracer

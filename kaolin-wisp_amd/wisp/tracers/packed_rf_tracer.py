@@ -1,0 +1,83 @@
+"""PackedRFTracer: differentiable volumetric tracer over packed (ragged) per-ray samples.
+
+Drop-in for wisp/tracers/packed_rf_tracer.py:17-181.  The reference strings together ~15 torch / Kaolin kernels
+for compositing (exp, packed cumsum, three atomic segmented sums, four index_put); here the whole block
+(:143-165) is one fused HIP kernel with a hand-written backward (csrc/render.hip), wrapped as an autograd op.
+"""
+from typing import Tuple
+
+import torch
+
+from wisp.core import RenderBuffer
+from wisp.tracers.base_tracer import BaseTracer
+import wisp.ops.render as render_ops
+
+
+class PackedRFTracer(BaseTracer):
+    def __init__(self,
+        raymarch_type : str = 'ray',  # options: 'voxel', 'ray'
+        num_steps     : int = 1024,
+        step_size     : float = 1.0,
+        bg_color      : Tuple[float, float, float] = (1.0, 1.0, 1.0)):
+        """
+        Args:
+            raymarch_type (str): 'voxel' samples every intersected cell num_steps times; 'ray' draws num_steps
+                stratified samples per ray and keeps those inside occupied cells; 'uniform' uses a fixed lattice.
+            num_steps (int): see raymarch_type.
+            step_size (float): unused (kept for config compatibility).
+            bg_color (Tuple[float, float, float]): background colour.
+        """
+        super().__init__(bg_color=bg_color)
+        self.raymarch_type = raymarch_type
+        self.num_steps = num_steps
+        self.step_size = step_size
+        self.bg_color = torch.tensor(bg_color, dtype=torch.float32)
+        self.prev_num_samples = None
+
+    def get_prev_num_samples(self):
+        """Number of packed samples of the last trace() (None before the first)."""
+        return self.prev_num_samples
+
+    def get_supported_channels(self):
+        return {"depth", "hit", "rgb", "alpha"}
+
+    def get_required_nef_channels(self):
+        return {"rgb", "density"}
+
+    def trace(self, nef, rays, channels, extra_channels,
+              lod_idx=None, raymarch_type='voxel', num_steps=64, step_size=1.0, bg_color='white', jitter=None):
+        """Raymarch -> field query -> fused compositing.  Returns RenderBuffer(depth, hit, rgb, alpha, extras)."""
+        assert nef.grid is not None and "this tracer requires a grid"
+        N = rays.origins.shape[0]
+        if lod_idx is None:
+            lod_idx = nef.grid.num_lods - 1
+        march_kwargs = {} if jitter is None else {"jitter": jitter}
+        rm = nef.grid.raymarch(rays, level=nef.grid.active_lods[lod_idx], num_samples=num_steps,
+                               raymarch_type=raymarch_type, **march_kwargs)
+        ridx, samples, deltas, depths, boundary = rm.ridx, rm.samples, rm.deltas, rm.depth_samples, rm.boundary
+        num_samples = samples.shape[0]
+        self.prev_num_samples = num_samples
+
+        hit_ray_d = rays.dirs.index_select(0, ridx)
+        color, density = nef(coords=samples, ray_d=hit_ray_d, lod_idx=lod_idx, channels=["rgb", "density"])
+        density = density.reshape(num_samples, 1)
+        self.bg_color = self.bg_color.to(rays.origins.device)
+        bg = [float(x) for x in self.bg_color.detach().cpu().reshape(-1).tolist()]
+
+        starts = rm.pack_info if rm.pack_info is not None else render_ops.pack_starts_of(rm)
+        want_depth = "depth" in channels
+        rgb, alpha, depth, hit = render_ops.composite(color, density, deltas, depths if want_depth else None, ridx,
+                                                      starts, N, bg)
+        extra_outputs = {}
+        if extra_channels:
+            tau = density.float() * deltas
+            for channel in extra_channels:
+                feats = nef(coords=samples, ray_d=hit_ray_d, lod_idx=lod_idx, channels=channel)
+                feats = feats.view(num_samples, feats.shape[-1]).float()
+                ray_feats, _ = render_ops.exponential_integration(feats, tau, boundary, exclusive=True, starts=starts)
+                out = torch.zeros(N, feats.shape[-1], device=feats.device)
+                if starts.shape[0]:
+                    rh = ridx.index_select(0, starts)
+                    out[rh] = alpha[rh] * ray_feats
+                extra_outputs[channel] = out
+        return RenderBuffer(depth=depth, hit=hit, rgb=rgb, alpha=alpha, **extra_outputs)

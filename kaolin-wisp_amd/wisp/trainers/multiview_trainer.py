@@ -1,0 +1,139 @@
+"""MultiviewTrainStep: the optimisation step of the reference's MultiviewTrainer, without its app plumbing.
+
+Semantics follow wisp/trainers/multiview_trainer.py:85-180 (pre_step pruning, warm-up raymarch, loss over rays,
+adaptive ray count) and wisp/trainers/base_trainer.py:205-246 (parameter groups: names containing 'decoder' get
+weight decay, names containing 'grid' get lr * grid_lr_weight; MultiStepLR).  MI355X-specific choices:
+  * all trainable parameters live in ONE flat fp32 buffer (views keep their reference names), so the optimizer is a
+    single fused AdamW launch per group (csrc/misc.hip) that also zeroes the gradients, and
+  * data-parallel training is one RCCL all-reduce of the flat gradient buffer per step (the reference has no
+    distributed path at all); rays are sharded across ranks, parameters and the occupancy octree are replicated;
+  * bf16 autocast replaces the reference's fp16 autocast + GradScaler (no loss scaling needed).
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from wisp.core import Rays
+
+
+def _hip():
+    import wisp._C as _C
+    return _C
+
+
+class FlatParams:
+    """Re-homes the trainable parameters of `module` into one flat buffer, grouped like init_optimizer does."""
+
+    def __init__(self, module: torch.nn.Module):
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        groups = {"decoder": [], "grid": [], "rest": []}
+        for n, p in named:
+            groups["decoder" if "decoder" in n else "grid" if "grid" in n else "rest"].append((n, p))
+        device = named[0][1].device
+        total = sum(((p.numel() + 3) // 4) * 4 for _, p in named)          # 16-byte aligned segments
+        self.data = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.ranges = {}
+        off = 0
+        for g in ("decoder", "grid", "rest"):
+            start = off
+            for n, p in groups[g]:
+                k = p.numel()
+                self.data[off:off + k].copy_(p.detach().reshape(-1).float())
+                p.data = self.data[off:off + k].view(p.shape)
+                p.grad = self.grad[off:off + k].view(p.shape)
+                if "grid" in n:
+                    p._wisp_grad_buffer = p.grad        # hash-grid backward scatters straight into the flat buffer
+                off += ((k + 3) // 4) * 4
+            self.ranges[g] = (start, off)
+        self.exp_avg = torch.zeros_like(self.data)
+        self.exp_avg_sq = torch.zeros_like(self.data)
+
+
+class MultiviewTrainStep:
+    def __init__(self, pipeline, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, betas=(0.9, 0.999),
+                 rgb_loss_type='huber', prune_every=100, target_sample_size=2 ** 18, max_rays=2 ** 18,
+                 enable_amp=False, scheduler_milestones=None, scheduler_gamma=0.333, process_group=None, seed=0):
+        self.pipeline = pipeline
+        self.flat = FlatParams(pipeline.nef)
+        self.lr, self.eps, self.weight_decay, self.grid_lr_weight, self.betas = lr, eps, weight_decay, grid_lr_weight, betas
+        self.rgb_loss_type = rgb_loss_type
+        self.prune_every = prune_every
+        self.target_sample_size = target_sample_size
+        self.max_rays = max_rays
+        self.enable_amp = enable_amp
+        self.milestones = sorted(scheduler_milestones or [])
+        self.gamma = scheduler_gamma
+        self.total_iterations = 0
+        self.opt_steps = 0
+        self.num_rays = None
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.group = process_group
+        # prune draws must be identical on every rank so the replicated octrees stay identical
+        self._prune_gen = torch.Generator().manual_seed(seed)
+
+    # -------------------------------------------------------------------------------------------- schedule / groups
+    def _lr_scale(self):
+        k = sum(1 for m in self.milestones if self.opt_steps >= m)       # MultiStepLR
+        return self.gamma ** k
+
+    def optimizer_step(self):
+        C = _hip()
+        self.opt_steps += 1
+        s = self._lr_scale()
+        f = self.flat
+        gs = 1.0 / self.world
+        for g, lr in (("decoder", self.lr), ("grid", self.lr * self.grid_lr_weight), ("rest", self.lr)):
+            a, b = f.ranges[g]
+            if b > a:
+                C.adamw_step(f.data[a:b], f.grad[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], lr * s, self.betas[0],
+                             self.betas[1], self.eps, self.weight_decay, self.opt_steps, grad_scale=gs, zero_grad=True)
+
+    def allreduce_grads(self):
+        if self.world > 1:
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)     # RCCL over xGMI
+
+    # -------------------------------------------------------------------------------------------- reference hooks
+    def pre_step(self):
+        """multiview_trainer.py:85-93."""
+        if self.prune_every > -1 and self.total_iterations > 1 and self.total_iterations % self.prune_every == 0:
+            self.prune()
+
+    def prune(self):
+        nef = self.pipeline.nef
+        cells = nef.grid.dense_points.shape[0]
+        unit = torch.rand(cells, 3, generator=self._prune_gen)
+        views = torch.nn.functional.normalize(torch.randn(cells, 3, generator=self._prune_gen), dim=1)
+        nef.prune(unit_samples=unit, view_dirs=views)
+
+    def calc_adaptive_rays(self, num_rays_in_batch):
+        """multiview_trainer.py:95-109: rays for the next step so that ~target_sample_size samples are produced."""
+        spr = self.pipeline.tracer.get_prev_num_samples() / max(num_rays_in_batch, 1)
+        n = self.target_sample_size / max(spr, 1)
+        self.num_rays = int(math.floor(min(n, self.max_rays)))
+        return self.num_rays
+
+    def loss_fn(self, rgb, gts):
+        if self.rgb_loss_type == 'l2':
+            return torch.nn.functional.mse_loss(rgb, gts, reduction='none').mean()
+        if self.rgb_loss_type == 'l1':
+            return torch.abs(rgb - gts).mean()
+        if self.rgb_loss_type == 'huber':
+            return torch.nn.functional.smooth_l1_loss(rgb, gts, reduction='none').mean()
+        raise NotImplementedError
+
+    def step(self, rays: Rays, img_gts, jitter=None):
+        """One optimisation step on this rank's ray shard.  Returns (loss tensor, num_samples)."""
+        self.pre_step()
+        self.total_iterations += 1
+        kw = {} if jitter is None else {"jitter": jitter}
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.enable_amp):
+            rb = self.pipeline(rays=rays, lod_idx=None, channels=["rgb"], **kw)
+            loss = self.loss_fn(rb.rgb.float(), img_gts)
+        loss.backward()
+        self.allreduce_grads()
+        self.optimizer_step()
+        self.calc_adaptive_rays(rays.origins.shape[0])
+        return loss.detach(), self.pipeline.tracer.get_prev_num_samples()

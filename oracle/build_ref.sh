@@ -1,0 +1,18 @@
+#!/bin/bash
+# Test infrastructure: builds oracle/_ref/libwisp_ref.so from the reference's own kernel sources where they lie
+# (only possible where /root/reference exists; the .so then travels to the GPU box with the repo snapshot).
+# Nothing from the reference is copied into tracked files: the extracted fragments live in the git-ignored oracle/_ref/.
+set -e
+REF=${WISP_REFERENCE:-/root/reference}
+HERE="$(cd "$(dirname "$0")" && pwd)"
+SRC="$REF/wisp/csrc/ops"
+[ -f "$SRC/hashgrid_interpolate_cuda.cu" ] || { echo "reference sources not present at $REF - skipping"; exit 0; }
+mkdir -p "$HERE/_ref"
+# kernels only: stop before the ATen launcher functions (which need CUDA's <<<>>> syntax)
+awk '/^void hashgrid_interpolate_cuda_impl\(/{exit} {print}' "$SRC/hashgrid_interpolate_cuda.cu" > "$HERE/_ref/hashgrid_kernels.inc"
+# uniform sampler: kernel only; give the per-thread body an explicit thread index (tidx is the kernel's only use of the grid)
+awk '/^std::vector<at::Tensor> uniform_sample_cuda_impl\(/{exit} {print}' "$SRC/uniform_sample_cuda.cu" \
+  | sed -e 's/^uniform_sample_cuda_kernel(/uniform_sample_cuda_kernel_at(uint tidx_in,/' \
+        -e 's/uint tidx = blockDim.x \* blockIdx.x + threadIdx.x;/uint tidx = tidx_in;/' > "$HERE/_ref/uniform_kernels.inc"
+g++ -O2 -std=c++17 -shared -fPIC -ffp-contract=off -I "$HERE/ref_shim" -I "$SRC" "$HERE/ref_wrap.cpp" -o "$HERE/_ref/libwisp_ref.so"
+echo "built $HERE/_ref/libwisp_ref.so"

@@ -1,0 +1,88 @@
+"""Test infrastructure: ctypes access to oracle/_ref/libwisp_ref.so - the REFERENCE's own kernel bodies
+(wisp/csrc/ops/hashgrid_interpolate_cuda.cu:19-339, hash_utils.cuh:17-112, uniform_sample_cuda.cu:18-59)
+compiled for the host by oracle/build_ref.sh.  Used to pin oracle/hashgrid.py and oracle/raymarch.uniform_sample
+against the real reference arithmetic and to generate tests/golden/*.npz.  Absent => `available()` is False."""
+import ctypes
+import os
+
+import numpy as np
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libwisp_ref.so")
+_lib = None
+
+
+def available():
+    return os.path.exists(_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(_PATH)
+        _lib.ref_hash_index_3d.restype = ctypes.c_int32
+        _lib.ref_hash_index_2d.restype = ctypes.c_int32
+        _lib.ref_clamp.restype = ctypes.c_float
+        _lib.ref_clamp.argtypes = [ctypes.c_float] * 3
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def hash_index_3d(x, y, z, res, T):
+    return int(lib().ref_hash_index_3d(int(x), int(y), int(z), int(res), int(T)))
+
+
+def hash_index_2d(x, y, res, T):
+    return int(lib().ref_hash_index_2d(int(x), int(y), int(res), int(T)))
+
+
+def clamp(x, a, b):
+    return float(lib().ref_clamp(x, a, b))
+
+
+def hashgrid_forward(coords, table, begin_idxes, resolutions, codebook_bitwidth):
+    """hashgrid_interpolate_cuda (hashgrid_interpolate.cpp:46-69) with the reference kernels, float32 tables."""
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    begin = np.ascontiguousarray(begin_idxes, dtype=np.int64)
+    n, dim = coords.shape
+    L, F = len(resolutions), table.shape[1]
+    feats = np.zeros((n, L * F), dtype=np.float32)
+    for l, r in enumerate(resolutions):
+        lib().ref_hashgrid_fwd_level(ctypes.c_int64(n), ctypes.c_int32(2 ** codebook_bitwidth), ctypes.c_int64(F),
+                                     ctypes.c_int32(int(r)), ctypes.c_int32(l), ctypes.c_int32(L), ctypes.c_int(dim),
+                                     _p(coords), _p(table), _p(begin), _p(feats))
+    return feats
+
+
+def hashgrid_backward(coords, grad_out, table, begin_idxes, resolutions, codebook_bitwidth):
+    """hashgrid_interpolate_backward_cuda (hashgrid_interpolate.cpp:71-105), float32, sequential adds."""
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    grad_out = np.ascontiguousarray(grad_out, dtype=np.float32)
+    begin = np.ascontiguousarray(begin_idxes, dtype=np.int64)
+    n, dim = coords.shape
+    L, F = len(resolutions), table.shape[1]
+    grad = np.zeros_like(table)
+    for l, r in enumerate(resolutions):
+        lib().ref_hashgrid_bwd_level(ctypes.c_int64(n), ctypes.c_int32(2 ** codebook_bitwidth), ctypes.c_int64(F),
+                                     ctypes.c_int32(int(r)), ctypes.c_int32(l), ctypes.c_int32(L), ctypes.c_int(dim),
+                                     _p(coords), _p(table), _p(begin), _p(grad_out), _p(grad))
+    return grad
+
+
+def uniform_sample(scale, ridx, depth, insum):
+    ridx = np.ascontiguousarray(ridx, dtype=np.int32)
+    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    insum = np.ascontiguousarray(insum, dtype=np.int32)
+    V = ridx.shape[0]
+    total = int(insum[-1]) if V else 0
+    new_ridx = np.zeros(total, dtype=np.int64)
+    ds = np.zeros((total, 1), dtype=np.float32)
+    boundary = np.zeros(total, dtype=np.bool_)
+    if V:
+        lib().ref_uniform_sample(ctypes.c_int32(V), ctypes.c_float(scale), _p(ridx), _p(depth), _p(insum), _p(new_ridx),
+                                 _p(ds), _p(boundary))
+    return dict(ridx=new_ridx, depth_samples=ds, boundary=boundary)

@@ -1,0 +1,56 @@
+// Test infrastructure: C entry points over the REFERENCE's own kernel bodies, compiled for the host.
+// build_ref.sh extracts the kernel part (everything before the ATen launchers) of
+//   /root/reference/wisp/csrc/ops/hashgrid_interpolate_cuda.cu  and  .../uniform_sample_cuda.cu
+// into oracle/_ref/*.inc (git-ignored; reference sources are never committed) and compiles this file against
+// them and against /root/reference/wisp/csrc/ops/hash_utils.cuh where it lies.
+#include <ATen/ATen.h>
+#include "_ref/hashgrid_kernels.inc"
+}   // closes `namespace wisp` left open by the extracted fragment
+#include "_ref/uniform_kernels.inc"
+}   // closes `namespace wisp`
+
+extern "C" {
+
+int32_t ref_hash_index_3d(int x, int y, int z, int32_t resolution, int32_t codebook_size) {
+    return wisp::hash_index_3d(make_int3(x, y, z), resolution, codebook_size);
+}
+int32_t ref_hash_index_2d(int x, int y, int32_t resolution, int32_t codebook_size) {
+    return wisp::hash_index_2d(make_int2(x, y), resolution, resolution, codebook_size);
+}
+float ref_clamp(float x, float a, float b) { return wisp::clamp(x, a, b); }
+
+// one level, float tables: mirrors hashgrid_interpolate_cuda_impl's per-level launch (hashgrid_interpolate_cuda.cu:341-390)
+void ref_hashgrid_fwd_level(int64_t n, int32_t codebook_size, int64_t feature_dim, int32_t resolution, int32_t lod_idx,
+                            int32_t num_lods, int coord_dim, const float* coords, const float* codebook,
+                            const int64_t* first_idx, float* feats) {
+    if (coord_dim == 3)
+        wisp::hashgrid_interpolate_3d_cuda_kernel<float>(n, codebook_size, feature_dim, resolution, lod_idx, num_lods,
+                                                         coords, codebook, first_idx, feats);
+    else
+        wisp::hashgrid_interpolate_2d_cuda_kernel<float>(n, codebook_size, feature_dim, resolution, lod_idx, num_lods,
+                                                         coords, codebook, first_idx, feats);
+}
+
+void ref_hashgrid_bwd_level(int64_t n, int32_t codebook_size, int64_t feature_dim, int32_t resolution, int32_t lod_idx,
+                            int32_t num_lods, int coord_dim, const float* coords, const float* codebook,
+                            const int64_t* first_idx, const float* grad_output, float* grad_codebook) {
+    if (coord_dim == 3)
+        wisp::hashgrid_interpolate_3d_backward_cuda_kernel<float>(n, codebook_size, feature_dim, resolution, lod_idx,
+                                                                  num_lods, false, coords, codebook, first_idx,
+                                                                  grad_output, grad_codebook, nullptr);
+    else
+        wisp::hashgrid_interpolate_2d_backward_cuda_kernel<float>(n, codebook_size, feature_dim, resolution, lod_idx,
+                                                                  num_lods, false, coords, codebook, first_idx,
+                                                                  grad_output, grad_codebook, nullptr);
+}
+
+// uniform_sample_cuda_kernel (uniform_sample_cuda.cu:18-59) over all nuggets
+void ref_uniform_sample(int32_t num_voxels, float scale, const int32_t* ridx, const float* depth, const int32_t* insum,
+                        int64_t* new_ridx, float* depth_samples, bool* boundary) {
+    for (int32_t t = 0; t < num_voxels; ++t) {
+        // the kernel has no grid-stride loop: emulate one thread per voxel by shifting the base pointers
+        wisp::uniform_sample_cuda_kernel_at(t, num_voxels, scale, 1.0f / scale, ridx, reinterpret_cast<const float2*>(depth),
+                                            insum, new_ridx, depth_samples, boundary);
+    }
+}
+}

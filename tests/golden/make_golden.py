@@ -1,0 +1,122 @@
+"""Generates the committed golden vectors.  Run from the repo root in the build container (needs /root/reference
+for the hash-grid / lattice-sampler vectors, which come from the REFERENCE's own kernel bodies compiled for the host
+by oracle/build_ref.sh):
+
+    python tests/golden/make_golden.py
+
+Outputs (small, committed):
+  hashgrid_ref.npz   - inputs + outputs of the reference hashgrid forward/backward kernels (3-D and 2-D, float32),
+                       hash-index known answers, the clamp bound probes of SURVEY.md Appendix B
+  uniform_ref.npz    - inputs + outputs of the reference uniform_sample kernel
+  spc_kats.npz       - hand-checkable SPC cases (dense level-2 tree, 3-point sparse tree, query / raytrace answers)
+                       produced by oracle/spc.py and verified inside this script against brute force in float64
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import hashgrid, raymarch, ref_lib, spc  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def hashgrid_vectors():
+    assert ref_lib.available(), "run oracle/build_ref.sh first"
+    rng = np.random.default_rng(1234)
+    out = {}
+    # ---- 3-D: 4 dense + 4 hashed levels, T = 2^10, F = 2
+    res3, bw3 = [4, 6, 8, 10, 13, 16, 23, 32], 10
+    _, begin3 = hashgrid.table_layout(res3, 2 ** bw3, 3)
+    table3 = rng.uniform(-0.5, 0.5, (int(begin3[-1]), 2)).astype(np.float32)
+    coords3 = rng.uniform(-1, 1, (512, 3)).astype(np.float32)
+    coords3[:6] = [[1, 1, 1], [-1, -1, -1], [0, 0, 0], [1, -1, 0.5], [0.999999, -0.999999, 0.25], [1.25, -3.0, 0.1]]
+    grad3 = rng.normal(size=(512, len(res3) * 2)).astype(np.float32)
+    out.update(res3=np.array(res3), bw3=bw3, begin3=begin3, table3=table3, coords3=coords3, grad3=grad3,
+               feats3=ref_lib.hashgrid_forward(coords3, table3, begin3, res3, bw3),
+               gtable3=ref_lib.hashgrid_backward(coords3, grad3, table3, begin3, res3, bw3))
+    # ---- 2-D (image app): table sized with coord_dim = 3 (main_image.py:63), F = 4
+    res2, bw2 = [4, 8, 16, 32, 64, 128], 9
+    _, begin2 = hashgrid.table_layout(res2, 2 ** bw2, 3)
+    table2 = rng.uniform(-0.5, 0.5, (int(begin2[-1]), 4)).astype(np.float32)
+    coords2 = rng.uniform(-1, 1, (256, 2)).astype(np.float32)
+    grad2 = rng.normal(size=(256, len(res2) * 4)).astype(np.float32)
+    out.update(res2=np.array(res2), bw2=bw2, begin2=begin2, table2=table2, coords2=coords2, grad2=grad2,
+               feats2=ref_lib.hashgrid_forward(coords2, table2, begin2, res2, bw2),
+               gtable2=ref_lib.hashgrid_backward(coords2, grad2, table2, begin2, res2, bw2))
+    # ---- index KATs at the nerf_hash.yaml sizes (T = 2^19): dense levels, first hashed level, finest level
+    kat_in = np.array([[1, 2, 3, 16], [15, 15, 15, 16], [79, 79, 79, 80], [1, 2, 3, 80], [1, 2, 3, 101], [100, 100, 100, 101],
+                       [1, 2, 3, 128], [511, 0, 255, 512], [512, 512, 512, 512], [0, 0, 0, 512], [321, 5, 77, 322]],
+                      dtype=np.int64)
+    kat_out = np.array([ref_lib.hash_index_3d(x, y, z, r, 2 ** 19) for x, y, z, r in kat_in], dtype=np.int64)
+    kat2_in = np.array([[1, 2, 16], [100, 7, 128], [700, 700, 724], [723, 1, 724]], dtype=np.int64)
+    kat2_out = np.array([ref_lib.hash_index_2d(x, y, r, 2 ** 19) for x, y, r in kat2_in], dtype=np.int64)
+    # clamp bound: float32(res - 1 - 1e-5) probes (Appendix B)
+    probe_res = np.array([80, 101, 257, 258, 322, 406, 512], dtype=np.int64)
+    probe = np.array([ref_lib.clamp(1e9, 0, r - 1 - 1e-5) for r in probe_res], dtype=np.float32)
+    out.update(kat_in=kat_in, kat_out=kat_out, kat2_in=kat2_in, kat2_out=kat2_out, probe_res=probe_res, probe=probe)
+    np.savez_compressed(os.path.join(OUT, "hashgrid_ref.npz"), **out)
+
+
+def uniform_vectors():
+    rng = np.random.default_rng(7)
+    V = 300
+    ridx = np.sort(rng.integers(0, 40, V)).astype(np.int32)
+    entry = rng.uniform(0, 3, V).astype(np.float32)
+    depth = np.stack([entry, entry + rng.uniform(0, 0.2, V).astype(np.float32)], 1)
+    scale = 37
+    ia = np.ceil(np.float32(scale) * depth[:, 0]).astype(np.int32)
+    ib = np.ceil(np.float32(scale) * depth[:, 1]).astype(np.int32)
+    cnt = ib - ia
+    keep = cnt != 0
+    insum = spc.inclusive_sum(cnt[keep])
+    got = ref_lib.uniform_sample(scale, ridx[keep], depth[keep], insum)
+    np.savez_compressed(os.path.join(OUT, "uniform_ref.npz"), scale=scale, ridx=ridx[keep], depth=depth[keep],
+                        insum=insum, out_ridx=got["ridx"], out_depth=got["depth_samples"], out_boundary=got["boundary"])
+
+
+def spc_vectors():
+    out = {}
+    # sparse 3-point tree at level 2: points (0,0,0), (3,3,3), (2,1,0)
+    pts = np.array([[0, 0, 0], [3, 3, 3], [2, 1, 0]])
+    oc = spc.points_to_octree(pts, 2)
+    points, pyr, ex = spc.octree_to_spc(oc)
+    # hand check: root byte has children 0 (000), 7 (111) and 4 (x=1,y=0,z=0 -> 100b) set = 1 + 128 + 16 = 145
+    assert oc[0] == 145 and len(oc) == 4, oc
+    # level-1 nodes in morton order: child 0, child 4, child 7.  (0,0,0)->child 0 of node(0,0,0): byte 1;
+    # (2,1,0): parent (1,0,0), local (0,1,0) -> slot 2 -> byte 4; (3,3,3): parent (1,1,1), local (1,1,1) -> slot 7 -> byte 128
+    assert list(oc[1:]) == [1, 4, 128], oc
+    assert pyr.tolist() == [[1, 3, 3, 0], [0, 1, 4, 7]]
+    q = np.array([[-0.9, -0.9, -0.9], [0.9, 0.9, 0.9], [0.1, -0.4, -0.9], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1.01, 0, 0]],
+                 dtype=np.float32)
+    qa = spc.query(oc, ex, q, 2, with_parents=True)
+    assert qa[:, 2].tolist() == [4, 6, 5, -1, 6, -1], qa
+    rng = np.random.default_rng(3)
+    o = rng.normal(size=(64, 3)).astype(np.float32)
+    o = (3 * o / np.linalg.norm(o, axis=1, keepdims=True)).astype(np.float32)
+    d = (rng.uniform(-0.6, 0.6, (64, 3)) - o).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rt = spc.raytrace(oc, points, pyr, ex, o, d, 2, with_exit=True)
+    out.update(sp_octree=oc, sp_points=points, sp_pyramid=pyr, sp_exsum=ex, sp_q=q, sp_q_pidx=qa,
+               rt_o=o, rt_d=d, rt_ridx=rt[0], rt_pidx=rt[1], rt_depth=rt[2])
+    # dense level-2 tree, one axis-aligned ray through the row y=z=-0.75 (cells (k,0,0), k=0..3), origin outside
+    ocd = spc.create_dense_octree(2)
+    pd, pyd, exd = spc.octree_to_spc(ocd)
+    o1 = np.array([[-2.0, -0.75, -0.75]], dtype=np.float32)
+    d1 = np.array([[1.0, 0.0, 0.0]], dtype=np.float32)
+    r1 = spc.raytrace(ocd, pd, pyd, exd, o1, d1, 2, with_exit=True)
+    cells = pd[r1[1]].tolist()
+    assert cells == [[0, 0, 0], [1, 0, 0], [2, 0, 0], [3, 0, 0]], cells
+    assert np.allclose(r1[2], [[1.0, 1.5], [1.5, 2.0], [2.0, 2.5], [2.5, 3.0]])
+    out.update(dn_octree=ocd, dn_points=pd, dn_pyramid=pyd, dn_exsum=exd, dn_o=o1, dn_d=d1, dn_pidx=r1[1], dn_depth=r1[2])
+    np.savez_compressed(os.path.join(OUT, "spc_kats.npz"), **out)
+
+
+if __name__ == "__main__":
+    hashgrid_vectors()
+    uniform_vectors()
+    spc_vectors()
+    print("golden vectors written to", OUT)

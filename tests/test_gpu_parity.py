@@ -1,0 +1,374 @@
+"""GPU (MI355X): every HIP entry point against the CPU oracle on identical inputs, through the C ABI
+(wisp._C -> libwisp_hip.so).  Integer outputs must be bit-exact; float outputs within the stated tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hashgrid as ohash, nerf as onerf, raymarch as omarch, render as orender, spc as ospc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+NGP_RES = [16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406, 512]
+
+
+def _C():
+    import wisp._C as C
+    return C
+
+
+def cuda(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x
+    t = t.to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def make_rays(n, seed, radius=3.0, spread=0.6):
+    rng = np.random.default_rng(seed)
+    o = rng.normal(size=(n, 3))
+    o = (radius * o / np.linalg.norm(o, axis=1, keepdims=True)).astype(np.float32)
+    d = rng.uniform(-spread, spread, (n, 3)) - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o, d
+
+
+def sparse_tree(level, n, seed):
+    rng = np.random.default_rng(seed)
+    oc = ospc.points_to_octree(rng.integers(0, 2 ** level, size=(n, 3)), level)
+    pts, pyr, ex = ospc.octree_to_spc(oc)
+    return oc, pts, pyr, ex
+
+
+# ------------------------------------------------------------------------------------------------ hash grid
+@pytest.mark.parametrize("dim", [3, 2])
+def test_hashgrid_golden_reference_vectors(golden_dir, dim):
+    g = np.load(os.path.join(golden_dir, "hashgrid_ref.npz"))
+    s = str(dim)
+    res, bw = [int(r) for r in g["res" + s]], int(g["bw" + s])
+    feats = _C().hashgrid_interpolate(cuda(g["coords" + s]), cuda(g["table" + s]), cuda(g["begin" + s]), res, bw)
+    np.testing.assert_allclose(feats.cpu().numpy(), g["feats" + s], rtol=0, atol=1e-6)   # fp32; FMA contraction only
+    grad = _C().hashgrid_interpolate_backward(cuda(g["coords" + s]), cuda(g["grad" + s]), g["table" + s].shape,
+                                              cuda(g["begin" + s]), res, bw)
+    np.testing.assert_allclose(grad.cpu().numpy(), g["gtable" + s], rtol=0, atol=5e-5)   # atomic order
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float32, 2e-7), (torch.float16, 2e-4), (torch.bfloat16, 1.5e-3)])
+def test_hashgrid_forward_nerf_hash_shape(dtype, atol):
+    rng = np.random.default_rng(11)
+    _, begin = ohash.table_layout(NGP_RES, 2 ** 19)
+    table = torch.from_numpy(rng.uniform(-0.1, 0.1, (int(begin[-1]), 2)).astype(np.float32)).to(dtype)
+    coords = rng.uniform(-1, 1, (30000, 3)).astype(np.float32)
+    coords[:5] = [[1, 1, 1], [-1, -1, -1], [0, 0, 0], [1, -1, 0.3], [1.7, 0, -4]]
+    want = ohash.hashgrid_forward(torch.from_numpy(coords), table, torch.from_numpy(begin), NGP_RES, 19)
+    got = _C().hashgrid_interpolate(cuda(coords), table.to(DEV), cuda(begin), NGP_RES, 19)
+    assert got.dtype == dtype and got.shape == (30000, 32)
+    np.testing.assert_allclose(got.float().cpu().numpy(), want.float().numpy(), rtol=0, atol=atol)
+    # 'cat' quirk fused: columns >= zero_from_col are exactly zero, the others unchanged
+    got_z = _C().hashgrid_interpolate(cuda(coords), table.to(DEV), cuda(begin), NGP_RES, 19, zero_from_col=30)
+    assert torch.equal(got_z[:, :30], got[:, :30]) and float(got_z[:, 30:].abs().max()) == 0.0
+
+
+def test_hashgrid_backward_nerf_hash_shape_and_adjoint():
+    rng = np.random.default_rng(12)
+    _, begin = ohash.table_layout(NGP_RES, 2 ** 19)
+    shape = (int(begin[-1]), 2)
+    coords = rng.uniform(-1, 1, (20000, 3)).astype(np.float32)
+    go = rng.normal(size=(20000, 32)).astype(np.float32)
+    want = ohash.hashgrid_backward(torch.from_numpy(coords), torch.from_numpy(go), shape, torch.from_numpy(begin), NGP_RES, 19,
+                                   torch.float64)
+    got = _C().hashgrid_interpolate_backward(cuda(coords), cuda(go), shape, cuda(begin), NGP_RES, 19)
+    scale = float(want.abs().max())
+    assert float((got.double().cpu() - want).abs().max()) <= 2e-6 * max(scale, 1.0) * 8
+    # bf16 upstream gradient, zeroed columns get no gradient
+    got_b = _C().hashgrid_interpolate_backward(cuda(coords), cuda(go).bfloat16(), shape, cuda(begin), NGP_RES, 19, zero_from_col=30)
+    assert float(got_b[int(begin[15]):].abs().max()) == 0.0
+    want_b = ohash.hashgrid_backward(torch.from_numpy(coords), torch.from_numpy(go).bfloat16().float(), shape,
+                                     torch.from_numpy(begin), NGP_RES, 19, torch.float64)
+    assert float((got_b[:int(begin[15])].double().cpu() - want_b[:int(begin[15])]).abs().max()) <= 1e-4 * scale
+    # full-size adjoint property: <fwd(table), g> == <table, bwd(g)>  at S = 2^20
+    S = 1 << 20
+    c = torch.rand(S, 3, device=DEV) * 2 - 1
+    table = torch.randn(shape, device=DEV) * 0.1
+    g = torch.randn(S, 32, device=DEV)
+    lhs = (_C().hashgrid_interpolate(c, table, cuda(begin), NGP_RES, 19).double() * g.double()).sum()
+    rhs = (_C().hashgrid_interpolate_backward(c, g, shape, cuda(begin), NGP_RES, 19).double() * table.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-5 * abs(float(lhs)) + 1e-3
+
+
+def test_hashgrid_autograd_module_cat_and_sum():
+    from wisp.accelstructs import OctreeAS
+    from wisp.models.grids import HashGrid
+    torch.manual_seed(0)
+    for mtype in ("cat", "sum"):
+        grid = HashGrid.from_geometric(OctreeAS.make_dense(2), feature_dim=2, num_lods=8, multiscale_type=mtype,
+                                       feature_std=0.1, codebook_bitwidth=12, min_grid_res=4, max_grid_res=64).to(DEV)
+        coords = (torch.rand(5000, 3, device=DEV) * 2 - 1)
+        out = grid.interpolate(coords, 7)
+        w = torch.randn_like(out)
+        (out * w).sum().backward()
+        table = grid.codebook.feats.detach().cpu().clone().requires_grad_(True)
+        ref = ohash.grid_interpolate(coords.cpu(), 7, mtype, 2, grid.resolutions, 12, table, grid.codebook.begin_idxes.cpu())
+        (ref * w.cpu()).sum().backward()
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=1e-6)
+        np.testing.assert_allclose(grid.codebook.feats.grad.cpu().numpy(), table.grad.numpy(), atol=2e-5)
+        if mtype == "cat":
+            assert float(out[:, 14:].abs().max()) == 0.0        # finest LOD zeroed (hash_grid.py:226-229)
+    with pytest.raises(Exception, match="multiple of 2"):
+        import wisp.ops.grid as G
+        G.HashGridInterpolate.apply(coords, [4], 4, 0, torch.zeros(64, 3, device=DEV), torch.zeros(2, dtype=torch.int64, device=DEV))
+    # empty input
+    assert _C().hashgrid_interpolate(torch.zeros(0, 3, device=DEV), grid.codebook.feats, grid.codebook.begin_idxes,
+                                     grid.resolutions, 12).shape == (0, 16)
+
+
+# ------------------------------------------------------------------------------------------------ SPC
+def test_query_bit_exact():
+    oc, pts, pyr, ex = sparse_tree(6, 3000, 21)
+    rng = np.random.default_rng(22)
+    x = rng.uniform(-1.05, 1.05, (50000, 3)).astype(np.float32)
+    x[:6] = [[1, 1, 1], [-1, -1, -1], [0, 0, 0], [np.nan, 0, 0], [1.0000001, 0, 0], [-0.0, 0.5, -0.5]]
+    # points exactly on cell boundaries
+    x[6:1006] = (rng.integers(-64, 65, (1000, 3)) / 64.0).astype(np.float32)
+    for level in (6, 3):
+        for wp in (False, True):
+            want = ospc.query(oc, ex, x, level, with_parents=wp)
+            got = _C().spc_query(cuda(oc), cuda(ex), cuda(x), level, wp)
+            assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), want)
+
+
+def test_raytrace_bit_exact_sparse_and_dense():
+    for (oc, pts, pyr, ex), level in ((sparse_tree(5, 2500, 31), 5), (sparse_tree(7, 40000, 32), 7),
+                                      ((ospc.create_dense_octree(3),) + ospc.octree_to_spc(ospc.create_dense_octree(3)), 3)):
+        o, d = make_rays(700, 33)
+        d[:3] = [[1, 0, 0], [0, -1, 0], [0, 0, 1]]           # axis-aligned: zero components -> inf inverses
+        o[:3] = [[-3, 0.13, 0.27], [0.4, 3, -0.2], [0.05, 0.05, -3]]
+        o[3] = [0.01, 0.02, 0.03]                              # origin inside the volume
+        for with_exit in (True, False):
+            want = ospc.raytrace(oc, pts, pyr, ex, o, d, level, with_exit=with_exit)
+            ridx, pidx, depth, offsets = _C().spc_raytrace(cuda(oc), cuda(pts), cuda(ex), cuda(o), cuda(d), level, with_exit)
+            assert ridx.dtype == torch.int32 and np.array_equal(ridx.cpu().numpy(), want[0])
+            assert np.array_equal(pidx.cpu().numpy(), want[1])
+            assert np.array_equal(depth.cpu().numpy(), want[2])
+            assert int(offsets[-1]) == want[0].shape[0]
+    # no hits at all
+    ridx, pidx, depth, _ = _C().spc_raytrace(cuda(oc), cuda(pts), cuda(ex), cuda(np.full((4, 3), 5, np.float32)),
+                                             cuda(np.tile(np.float32([1, 0, 0]), (4, 1))), 3, True)
+    assert ridx.shape[0] == 0 and depth.shape == (0, 2)
+
+
+def test_scans_boundaries_and_pack_starts():
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 63, 2048, 2049, 300001):
+        c = torch.randint(0, 9, (n,), generator=g, dtype=torch.int32)
+        off = _C().exclusive_scan(c.to(DEV)).cpu()
+        assert torch.equal(off[1:], torch.cumsum(c.long(), 0)) and int(off[0]) == 0
+        assert torch.equal(_C().inclusive_scan(c.to(DEV)).cpu(), torch.cumsum(c, 0).int())
+        ids = torch.sort(torch.randint(0, max(n // 7, 1), (n,), generator=g))[0]
+        b = _C().mark_pack_boundaries(ids.to(DEV))
+        want = torch.from_numpy(ospc.mark_pack_boundaries(ids.numpy()))
+        assert torch.equal(b.cpu(), want)
+        assert torch.equal(_C().mark_pack_boundaries(ids.int().to(DEV)).cpu(), want)
+        assert torch.equal(_C().pack_starts(b).cpu(), torch.nonzero(want)[:, 0])
+    assert int(_C().exclusive_scan(torch.zeros(0, dtype=torch.int32, device=DEV))[0]) == 0
+
+
+# ------------------------------------------------------------------------------------------------ raymarch
+@pytest.mark.parametrize("tree,level", [("sparse", 6), ("dense", 4), ("sparse", 11)])
+def test_raymarch_ray_bit_exact(tree, level):
+    if tree == "dense":
+        oc = ospc.create_dense_octree(level); pts, pyr, ex = ospc.octree_to_spc(oc)
+    else:
+        oc, pts, pyr, ex = sparse_tree(level, 20000, 41)
+    o, d = make_rays(257, 42)
+    N = 200 if level != 11 else 64
+    jit = np.random.default_rng(43).uniform(size=(257, N)).astype(np.float32)
+    want = omarch.raymarch_ray(oc, ex, o, d, 1.0, 5.0, N, level, jit)
+    lvl_pts = pts[pyr[1, level]:pyr[1, level] + pyr[0, level]]
+    bits = _C().spc_bitfield(cuda(lvl_pts), level) if level <= 10 else None
+    for occ in ((bits, None) if bits is not None else (None,)):
+        ridx, samples, depth, deltas, boundary, off = _C().raymarch_ray(occ, cuda(oc), cuda(ex), cuda(o), cuda(d), 1.0, 5.0,
+                                                                        N, level, cuda(jit))
+        assert ridx.dtype == torch.int64 and np.array_equal(ridx.cpu().numpy(), want["ridx"])
+        assert np.array_equal(boundary.cpu().numpy(), want["boundary"])
+        assert np.array_equal(samples.cpu().numpy(), want["samples"])
+        assert np.array_equal(depth.cpu().numpy(), want["depth_samples"])
+        assert np.array_equal(deltas.cpu().numpy(), want["deltas"])
+    # in-kernel jitter: same structure invariants, reproducible for a fixed seed, different across seeds
+    a = _C().raymarch_ray(bits, cuda(oc), cuda(ex), cuda(o), cuda(d), 1.0, 5.0, N, level, None, seed=7)
+    b = _C().raymarch_ray(bits, cuda(oc), cuda(ex), cuda(o), cuda(d), 1.0, 5.0, N, level, None, seed=7)
+    c = _C().raymarch_ray(bits, cuda(oc), cuda(ex), cuda(o), cuda(d), 1.0, 5.0, N, level, None, seed=8)
+    assert torch.equal(a[1], b[1]) and (a[1].shape != c[1].shape or not torch.equal(a[1], c[1]))
+    assert bool((ospc.query(oc, ex, a[1].cpu().numpy(), level) >= 0).all())
+
+
+def test_raymarch_voxel_and_uniform_bit_exact():
+    oc, pts, pyr, ex = sparse_tree(5, 1500, 51)
+    o, d = make_rays(300, 52)
+    N = 8
+    nug = ospc.raytrace(oc, pts, pyr, ex, o, d, 5, with_exit=True)
+    jit = np.random.default_rng(53).uniform(size=(nug[0].shape[0], N)).astype(np.float32)
+    want = omarch.raymarch_voxel(oc, pts, pyr, ex, o, d, N, 5, jit)
+    ridx, pidx, depth, offsets = _C().spc_raytrace(cuda(oc), cuda(pts), cuda(ex), cuda(o), cuda(d), 5, True)
+    got = _C().raymarch_voxel(cuda(o), cuda(d), ridx, depth, N, cuda(jit))
+    for g, k in zip(got, ("ridx", "samples", "depth_samples", "deltas", "boundary")):
+        assert np.array_equal(g.cpu().numpy(), want[k]), k
+    wantu = omarch.raymarch_uniform(oc, pts, pyr, ex, o, d, 96, 5)
+    scale, _ = omarch.uniform_scale(96)
+    gotu = _C().raymarch_uniform(cuda(o), cuda(d), ridx, depth, offsets, scale)
+    for g, k in zip(gotu, ("ridx", "samples", "depth_samples", "boundary")):
+        assert np.array_equal(g.cpu().numpy(), wantu[k]), k
+
+
+def test_octree_as_class_api_matches_oracle():
+    from wisp.accelstructs import OctreeAS
+    from wisp.core import Rays
+    rng = np.random.default_rng(61)
+    P = rng.integers(0, 32, size=(3000, 3))
+    blas = OctreeAS.from_quantized_points(torch.from_numpy(P).short().to(DEV), 5)
+    oc = ospc.points_to_octree(P, 5); pts, pyr, ex = ospc.octree_to_spc(oc)
+    assert np.array_equal(blas.octree.cpu().numpy(), oc) and np.array_equal(blas.points.cpu().numpy(), pts)
+    o, d = make_rays(100, 62)
+    rays = Rays(cuda(o), cuda(d), dist_min=0.5, dist_max=4.5)
+    jit = rng.uniform(size=(100, 96)).astype(np.float32)
+    rm = blas.raymarch(rays, 'ray', 96, jitter=cuda(jit))
+    want = omarch.raymarch_ray(oc, ex, o, d, 0.5, 4.5, 96, 5, jit)
+    assert np.array_equal(rm.ridx.cpu().numpy(), want["ridx"]) and rm.samples.shape == (want["ridx"].shape[0], 3)
+    assert rm.depth_samples.shape[1] == 1 and rm.deltas.shape[1] == 1 and rm.boundary.dtype == torch.bool
+    wu = omarch.raymarch_uniform(oc, pts, pyr, ex, o, d, 64, 5)
+    ru = blas.raymarch(rays, 'uniform', 64)
+    assert np.array_equal(ru.ridx.cpu().numpy(), wu["ridx"]) and np.array_equal(ru.deltas.cpu().numpy(), wu["deltas"])
+    q = blas.query(cuda(rng.uniform(-1, 1, (1000, 3)).astype(np.float32)), with_parents=True)
+    assert q.pidx.shape == (1000, 6)
+    # empty result
+    far_rays = Rays(cuda(np.full((3, 3), 9, np.float32)), cuda(np.tile(np.float32([1, 0, 0]), (3, 1))), 1.0, 2.0)
+    e = blas.raymarch(far_rays, 'ray', 16)
+    assert e.ridx.shape[0] == 0 and e.samples.shape == (0, 3)
+
+
+# ------------------------------------------------------------------------------------------------ compositing
+def _packs(lens, seed):
+    rng = np.random.default_rng(seed)
+    ridx = np.concatenate([np.full(n, r) for r, n in enumerate(lens) if n]).astype(np.int64)
+    S = ridx.shape[0]
+    return (ridx, rng.uniform(size=(S, 3)).astype(np.float32), rng.uniform(0, 40, size=(S, 1)).astype(np.float32),
+            rng.uniform(1e-3, 0.05, size=(S, 1)).astype(np.float32), rng.uniform(1, 5, size=(S, 1)).astype(np.float32))
+
+
+@pytest.mark.parametrize("lens", [[5, 1, 0, 64, 65, 3, 0, 200, 1, 1], list(np.random.default_rng(1).integers(0, 130, 3000))])
+def test_composite_forward_backward(lens):
+    import wisp.ops.render as R
+    ridx, color, dens, delt, dep = _packs(lens, 71)
+    nr = len(lens)
+    bg = (0.2, 0.5, 0.9)
+    c64 = torch.from_numpy(color).double().requires_grad_(True); d64 = torch.from_numpy(dens).double().requires_grad_(True)
+    b = torch.from_numpy(ospc.mark_pack_boundaries(ridx))
+    want = orender.composite(c64, d64, torch.from_numpy(delt), torch.from_numpy(dep), torch.from_numpy(ridx), b, nr, bg)
+    gr, ga, gd = torch.randn(nr, 3).double(), torch.randn(nr, 1).double(), torch.randn(nr, 1).double()
+    ((want["rgb"] * gr).sum() + (want["alpha"] * ga).sum() + (want["depth"] * gd).sum()).backward()
+
+    cg = cuda(color).requires_grad_(True); dg = cuda(dens).requires_grad_(True)
+    starts = R.pack_starts(b.to(DEV))
+    rgb, alpha, depth, hit = R.composite(cg, dg, cuda(delt), cuda(dep), cuda(ridx), starts, nr, bg)
+    ((rgb * gr.float().to(DEV)).sum() + (alpha * ga.float().to(DEV)).sum() + (depth * gd.float().to(DEV)).sum()).backward()
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), want["rgb"].detach().numpy(), atol=1e-5)     # contract: 1e-4
+    np.testing.assert_allclose(alpha.detach().cpu().numpy(), want["alpha"].detach().numpy(), atol=1e-5)
+    np.testing.assert_allclose(depth.detach().cpu().numpy(), want["depth"].detach().numpy(), atol=5e-5)
+    assert torch.equal(hit.cpu(), want["hit"])
+    np.testing.assert_allclose(cg.grad.cpu().numpy(), c64.grad.numpy(), atol=1e-5)
+    gscale = float(d64.grad.abs().max())
+    np.testing.assert_allclose(dg.grad.cpu().numpy(), d64.grad.numpy(), atol=2e-5 * max(gscale, 1.0))
+    # kaolin-compatible pieces
+    f = torch.randn(ridx.shape[0], 4, device=DEV)
+    np.testing.assert_allclose(R.sum_reduce(f, b.to(DEV)).cpu().numpy(), orender.sum_reduce(f.cpu().double(), b).numpy(), atol=1e-4)
+    np.testing.assert_allclose(R.cumsum(f, b.to(DEV), exclusive=True).cpu().numpy(),
+                               orender.cumsum(f.cpu().double(), b, exclusive=True).numpy(), atol=1e-4)
+    ei, w = R.exponential_integration(cuda(color), cuda(dens * delt), b.to(DEV))
+    wi, ww = orender.exponential_integration(torch.from_numpy(color).double(), torch.from_numpy(dens * delt).double(), b)
+    np.testing.assert_allclose(ei.cpu().numpy(), wi.numpy(), atol=1e-5); np.testing.assert_allclose(w.cpu().numpy(), ww.numpy(), atol=1e-6)
+
+
+def test_adamw_matches_torch():
+    torch.manual_seed(3)
+    n = 100003
+    p = torch.randn(n, device=DEV); g = torch.randn(n, device=DEV)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-2, betas=(0.9, 0.999), eps=1e-15, weight_decay=1e-3)
+    m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for step in range(1, 4):
+        ref.grad = g.clone() * step
+        opt.step()
+        gg = (g * step * 2).contiguous()
+        _C().adamw_step(p, gg, m, v, 1e-2, 0.9, 0.999, 1e-15, 1e-3, step, grad_scale=0.5, zero_grad=True)
+        assert float(gg.abs().max()) == 0.0
+    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().cpu().numpy(), atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------ end to end
+def _build_pair(level=4, bitwidth=12, lods=8, hidden=64):
+    from wisp.accelstructs import OctreeAS
+    from wisp.models.grids import HashGrid
+    from wisp.models.nefs import NeuralRadianceField
+    torch.manual_seed(0)
+    rng = np.random.default_rng(81)
+    P = rng.integers(0, 2 ** level, size=(1500, 3))
+    blas = OctreeAS.from_quantized_points(torch.from_numpy(P).short().to(DEV), level)
+    grid = HashGrid.from_geometric(blas, feature_dim=2, num_lods=lods, multiscale_type='cat', feature_std=0.2,
+                                   codebook_bitwidth=bitwidth, min_grid_res=4, max_grid_res=64)
+    nef = NeuralRadianceField(grid, view_embedder='positional', view_multires=4, hidden_dim=hidden, num_layers=1, bias=True,
+                              prune_density_decay=0.95, prune_min_density=0.5).to(DEV)
+    onef = onerf.OracleNeRF(grid.resolutions, 2, bitwidth, 'cat', 0.2, hidden, 1, True, 4)
+    sd = {k: v.detach().cpu() for k, v in nef.state_dict().items() if k in onef.state_dict()}
+    onef.load_state_dict(sd, strict=False)
+    oblas = onerf.OracleBLAS(ospc.points_to_octree(P, level))
+    return nef, onef, oblas
+
+
+@pytest.mark.parametrize("rtype,steps", [("ray", 128), ("voxel", 4), ("uniform", 64)])
+def test_tracer_end_to_end_matches_oracle(rtype, steps):
+    from wisp.core import Rays
+    from wisp.tracers import PackedRFTracer
+    from wisp.models import Pipeline
+    nef, onef, oblas = _build_pair()
+    o, d = make_rays(300, 82)
+    rng = np.random.default_rng(83)
+    if rtype == "voxel":
+        nn = ospc.raytrace(oblas.octree, oblas.points, oblas.pyramid, oblas.exsum, o, d, oblas.max_level, True)[0].shape[0]
+        jit = rng.uniform(size=(nn, steps)).astype(np.float32)
+    else:
+        jit = rng.uniform(size=(300, steps)).astype(np.float32)
+    tracer = PackedRFTracer(raymarch_type=rtype, num_steps=steps, bg_color=(0.1, 0.2, 0.3))
+    pipe = Pipeline(nef, tracer)
+    rays = Rays(cuda(o), cuda(d), dist_min=1.0, dist_max=5.0)
+    kw = {} if rtype == "uniform" else {"jitter": cuda(jit)}
+    rb = pipe(rays=rays, channels=["rgb", "depth", "alpha", "hit"], **kw)
+    want = onerf.trace(onef, oblas, torch.from_numpy(o), torch.from_numpy(d), 1.0, 5.0, steps, jit, (0.1, 0.2, 0.3), rtype)
+    assert tracer.get_prev_num_samples() == want["raymarch"]["ridx"].shape[0]
+    np.testing.assert_allclose(rb.rgb.detach().cpu().numpy(), want["rgb"].detach().numpy(), atol=1e-4)     # north-star bound
+    np.testing.assert_allclose(rb.alpha.detach().cpu().numpy(), want["alpha"].detach().numpy(), atol=1e-4)
+    np.testing.assert_allclose(rb.depth.detach().cpu().numpy(), want["depth"].detach().numpy(), atol=5e-4)
+    assert torch.equal(rb.hit.cpu(), want["hit"])
+    gts = torch.from_numpy(rng.uniform(size=(300, 3)).astype(np.float32))
+    torch.nn.functional.smooth_l1_loss(rb.rgb, gts.to(DEV)).backward()
+    torch.nn.functional.smooth_l1_loss(want["rgb"], gts).backward()
+    for (n1, p1), (n2, p2) in zip(sorted((n, p) for n, p in nef.named_parameters() if p.grad is not None),
+                                  sorted((n, p) for n, p in onef.named_parameters() if p.grad is not None)):
+        assert n1 == n2
+        scale = max(float(p2.grad.abs().max()), 1e-6)
+        assert float((p1.grad.cpu() - p2.grad).abs().max()) <= 2e-4 * scale + 1e-7, n1
+
+
+def test_prune_rebuilds_identical_octree():
+    nef, onef, oblas = _build_pair()
+    cells = nef.grid.dense_points.shape[0]
+    g = torch.Generator().manual_seed(9)
+    unit = torch.rand(cells, 3, generator=g); views = torch.nn.functional.normalize(torch.randn(cells, 3, generator=g), dim=1)
+    occ0 = torch.zeros(cells)
+    nb, occ = onerf.prune(onef, oblas, occ0, oblas.level_points(), 0.95, 0.5, unit, views)
+    nef.prune(unit_samples=unit, view_dirs=views)
+    np.testing.assert_allclose(nef.grid.occupancy.cpu().numpy(), occ.numpy(), atol=1e-4)
+    margin = (occ - 0.5).abs() > 1e-3               # cells whose keep/drop decision is not at the float threshold
+    if bool(margin.all()):
+        assert np.array_equal(nef.grid.blas.octree.cpu().numpy(), nb.octree)
+    assert nef.grid.blas.max_level == oblas.max_level

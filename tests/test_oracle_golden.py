@@ -1,0 +1,163 @@
+"""CPU: pins the oracle restatement against the committed golden vectors (tests/golden/make_golden.py).
+hashgrid_ref.npz / uniform_ref.npz come from the reference's own kernel bodies compiled for the host."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hashgrid, raymarch, render, spc, ref_lib
+
+
+@pytest.fixture(scope="module")
+def hg(golden_dir):
+    return np.load(os.path.join(golden_dir, "hashgrid_ref.npz"))
+
+
+def test_hash_index_kats(hg):
+    for (x, y, z, r), want in zip(hg["kat_in"], hg["kat_out"]):
+        c = torch.tensor([[0.0, 0.0, 0.0]])
+        dense = hashgrid.level_is_dense(int(r), 2 ** 19, 3)
+        if dense:
+            got = x + y * r + z * r * r
+        else:
+            got = ((x * 1) & 0xFFFFFFFF ^ (y * 2654435761) & 0xFFFFFFFF ^ (z * 805459861) & 0xFFFFFFFF) % 2 ** 19
+        assert int(got) == int(want), (x, y, z, r)
+    # dense iff res^3 < T with strict '<' : 80 dense (512000 < 524288), 101 hashed
+    assert hashgrid.level_is_dense(80, 2 ** 19) and not hashgrid.level_is_dense(101, 2 ** 19)
+    for (x, y, r), want in zip(hg["kat2_in"], hg["kat2_out"]):
+        dense = hashgrid.level_is_dense(int(r), 2 ** 19, 2)
+        got = x + y * r if dense else (((x * 1) & 0xFFFFFFFF) ^ ((y * 2654435761) & 0xFFFFFFFF)) % 2 ** 19
+        assert int(got) == int(want)
+
+
+def test_clamp_bound_rounding(hg):
+    # float32(res-1-1e-5) == res-1 exactly for res >= 258
+    for r, p in zip(hg["probe_res"], hg["probe"]):
+        assert np.float32(r - 1 - 1e-5) == p
+        assert (p == r - 1) == (r >= 258)
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_hashgrid_forward_matches_reference_kernels(hg, dim):
+    s = str(dim)
+    res, bw = [int(r) for r in hg["res" + s]], int(hg["bw" + s])
+    out = hashgrid.hashgrid_forward(torch.from_numpy(hg["coords" + s]), torch.from_numpy(hg["table" + s]),
+                                    torch.from_numpy(hg["begin" + s]), res, bw).numpy()
+    assert np.array_equal(out, hg["feats" + s])          # bit-exact against the reference kernel
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_hashgrid_backward_matches_reference_kernels(hg, dim):
+    s = str(dim)
+    res, bw = [int(r) for r in hg["res" + s]], int(hg["bw" + s])
+    g = hashgrid.hashgrid_backward(torch.from_numpy(hg["coords" + s]), torch.from_numpy(hg["grad" + s]),
+                                   hg["table" + s].shape, torch.from_numpy(hg["begin" + s]), res, bw, torch.float64).numpy()
+    np.testing.assert_allclose(g, hg["gtable" + s], rtol=0, atol=2e-5)   # reference adds sequentially in fp32
+
+
+def test_uniform_sampler_matches_reference_kernel(golden_dir):
+    u = np.load(os.path.join(golden_dir, "uniform_ref.npz"))
+    got = raymarch.uniform_sample(int(u["scale"]), u["ridx"], u["depth"], u["insum"])
+    assert np.array_equal(got["ridx"], u["out_ridx"])
+    assert np.array_equal(got["depth_samples"], u["out_depth"])
+    assert np.array_equal(got["boundary"], u["out_boundary"])
+
+
+@pytest.mark.skipif(not ref_lib.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_vs_live_reference_kernels_nerf_hash_shape():
+    """nerf_hash.yaml shape (L=16, T=2^19, res 16..512) on fresh random inputs, forward bit-exact."""
+    res = [16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406, 512]
+    rng = np.random.default_rng(5)
+    _, begin = hashgrid.table_layout(res, 2 ** 19)
+    table = rng.uniform(-0.1, 0.1, (int(begin[-1]), 2)).astype(np.float32)
+    coords = rng.uniform(-1, 1, (2000, 3)).astype(np.float32)
+    want = ref_lib.hashgrid_forward(coords, table, begin, res, 19)
+    got = hashgrid.hashgrid_forward(torch.from_numpy(coords), torch.from_numpy(table), torch.from_numpy(begin), res, 19)
+    assert np.array_equal(got.numpy(), want)
+
+
+def test_spc_kats(golden_dir):
+    k = np.load(os.path.join(golden_dir, "spc_kats.npz"))
+    oc = spc.points_to_octree(np.array([[0, 0, 0], [3, 3, 3], [2, 1, 0]]), 2)
+    assert np.array_equal(oc, k["sp_octree"]) and oc.tolist() == [145, 1, 4, 128]
+    pts, pyr, ex = spc.octree_to_spc(oc)
+    assert np.array_equal(pts, k["sp_points"]) and np.array_equal(pyr, k["sp_pyramid"]) and np.array_equal(ex, k["sp_exsum"])
+    assert np.array_equal(spc.query(oc, ex, k["sp_q"], 2, with_parents=True), k["sp_q_pidx"])
+    r = spc.raytrace(oc, pts, pyr, ex, k["rt_o"], k["rt_d"], 2, with_exit=True)
+    assert np.array_equal(r[0], k["rt_ridx"]) and np.array_equal(r[1], k["rt_pidx"]) and np.array_equal(r[2], k["rt_depth"])
+    rd = spc.raytrace(k["dn_octree"], k["dn_points"], k["dn_pyramid"], k["dn_exsum"], k["dn_o"], k["dn_d"], 2, with_exit=True)
+    assert np.array_equal(rd[1], k["dn_pidx"]) and np.allclose(rd[2], k["dn_depth"])
+
+
+def test_query_is_membership_and_morton_rank():
+    rng = np.random.default_rng(0)
+    P = rng.integers(0, 32, size=(300, 3))
+    oc = spc.points_to_octree(P, 5)
+    pts, pyr, ex = spc.octree_to_spc(oc)
+    leaf = pts[pyr[1, 5]:pyr[1, 5] + pyr[0, 5]]
+    assert (np.diff(spc.points_to_morton(leaf)) > 0).all()
+    x = rng.uniform(-1, 1, (4000, 3)).astype(np.float32)
+    q = spc.quantize_points(x, 5)
+    rank = {tuple(p): i for i, p in enumerate(leaf.tolist())}
+    pid = spc.query(oc, ex, x, 5)
+    for i in range(x.shape[0]):
+        want = rank.get(tuple(q[i].tolist()), None)
+        assert pid[i] == (-1 if want is None else pyr[1, 5] + want)
+
+
+def test_raytrace_equals_bruteforce_slab_float64():
+    rng = np.random.default_rng(2)
+    P = rng.integers(0, 16, size=(60, 3))
+    oc = spc.points_to_octree(P, 4)
+    pts, pyr, ex = spc.octree_to_spc(oc)
+    leaf = pts[pyr[1, 4]:pyr[1, 4] + pyr[0, 4]].astype(np.float64)
+    o = rng.normal(size=(150, 3)); o = (3 * o / np.linalg.norm(o, axis=1, keepdims=True)).astype(np.float32)
+    d = rng.uniform(-0.5, 0.5, (150, 3)) - o; d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    ridx, pidx, depth = spc.raytrace(oc, pts, pyr, ex, o, d, 4, with_exit=True)
+    for r in range(150):
+        lo = -1 + 2 * leaf / 16; hi = lo + 2 / 16
+        t0 = (lo - o[r].astype(np.float64)) / d[r].astype(np.float64); t1 = (hi - o[r].astype(np.float64)) / d[r].astype(np.float64)
+        tn = np.minimum(t0, t1).max(1); tf = np.maximum(t0, t1).min(1)
+        solid = tf > np.maximum(tn, 0) + 1e-6          # exclude grazing hits
+        graze = np.abs(tf - np.maximum(tn, 0)) <= 1e-6
+        want = [pyr[1, 4] + k for k in np.argsort(np.maximum(tn, 0)) if solid[k]]
+        mine = [p for p in pidx[ridx == r].tolist() if not graze[p - pyr[1, 4]]]
+        assert mine == want
+
+
+def test_raymarch_ray_properties():
+    rng = np.random.default_rng(4)
+    blas_oct = spc.points_to_octree(rng.integers(0, 16, size=(500, 3)), 4)
+    pts, pyr, ex = spc.octree_to_spc(blas_oct)
+    o = rng.normal(size=(50, 3)); o = (3 * o / np.linalg.norm(o, axis=1, keepdims=True)).astype(np.float32)
+    d = rng.uniform(-0.5, 0.5, (50, 3)) - o; d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    jit = rng.uniform(size=(50, 128)).astype(np.float32)
+    rm = raymarch.raymarch_ray(blas_oct, ex, o, d, 1.0, 5.0, 128, 4, jit)
+    assert (np.diff(rm["ridx"]) >= 0).all()
+    assert np.array_equal(rm["boundary"], spc.mark_pack_boundaries(rm["ridx"]))
+    assert (spc.query(blas_oct, ex, rm["samples"], 4) >= 0).all()
+    assert (rm["deltas"] > 0).all() and (rm["depth_samples"] >= 1.0).all() and (rm["depth_samples"] <= 5.0 + 4.0 / 128).all()
+    # linspace emulation equals torch.linspace to 1 ulp
+    assert np.abs(raymarch.linspace01(128) - torch.linspace(0, 1, 128).numpy()).max() < 1e-7
+
+
+def test_composite_matches_python_loop_float64():
+    rng = np.random.default_rng(9)
+    lens = [5, 1, 0, 17, 3]
+    ridx = np.concatenate([np.full(n, r) for r, n in enumerate(lens)]).astype(np.int64)
+    S = ridx.shape[0]
+    color = torch.from_numpy(rng.uniform(size=(S, 3))); dens = torch.from_numpy(rng.uniform(0, 30, size=(S, 1)))
+    delt = torch.from_numpy(rng.uniform(0.001, 0.1, size=(S, 1))); dep = torch.from_numpy(rng.uniform(1, 5, size=(S, 1)))
+    b = torch.from_numpy(spc.mark_pack_boundaries(ridx))
+    out = render.composite(color, dens, delt, dep, torch.from_numpy(ridx), b, 5, (0.2, 0.3, 0.4))
+    for r, n in enumerate(lens):
+        T, acc, A, D = 1.0, np.zeros(3), 0.0, 0.0
+        for i in np.nonzero(ridx == r)[0]:
+            tau = float(dens[i] * delt[i]); w = T * (1 - np.exp(-tau)); T *= np.exp(-tau)
+            acc += w * color[i].numpy(); A += w; D += w * float(dep[i])
+        want = np.array([0.2, 0.3, 0.4]) * (1 - A) + acc
+        np.testing.assert_allclose(out["rgb"][r].numpy(), want, atol=1e-12)
+        np.testing.assert_allclose(out["alpha"][r].item(), A, atol=1e-12)
+        np.testing.assert_allclose(out["depth"][r].item(), D, atol=1e-12)
+        assert bool(out["hit"][r]) == (A > 0)
