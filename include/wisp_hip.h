@@ -125,11 +125,11 @@ int wisp_boundary_pack_starts(const uint8_t* boundary, int64_t n, const int64_t*
  */
 int wisp_raymarch_ray_count(const uint32_t* occ_bits, const uint8_t* octree, const int32_t* exsum,
                             const float* origins, const float* dirs, int64_t num_rays,
-                            float near, float far, int num_samples, int level,
+                            float near, float range /* fl32(dist_max - dist_min) */, int num_samples, int level,
                             const float* jitter, uint64_t seed,
                             uint32_t* hitmask, int32_t* counts, wisp_stream_t stream);
 int wisp_raymarch_ray_emit(const float* origins, const float* dirs, int64_t num_rays,
-                           float near, float far, int num_samples,
+                           float near, float range, int num_samples,
                            const float* jitter, uint64_t seed,
                            const uint32_t* hitmask, const int64_t* offsets,
                            int64_t* ridx, float* samples, float* depth_samples, float* deltas,

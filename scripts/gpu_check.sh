@@ -1,0 +1,15 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): parity tests, smoke, a short bench in both precisions, and a rocprofv3 kernel trace.
+# Everything is logged under gpurun_out/.
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
+rocm-smi --showproductname 2>/dev/null | head -5 > gpurun_out/device.txt
+timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest exit: $?" >> gpurun_out/pytest_gpu.log
+tail -40 gpurun_out/pytest_gpu.log
+timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log; tail -3 gpurun_out/smoke.log
+timeout 600 python bench.py --steps 20 --warmup 3 --precision fp32 --no-cpu-baseline > gpurun_out/bench_fp32.log 2>&1; tail -2 gpurun_out/bench_fp32.log
+timeout 900 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_bf16.log 2>&1; tail -2 gpurun_out/bench_bf16.log
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof.log" 2>&1)
+ls -R gpurun_out/prof | head -20
