@@ -190,7 +190,6 @@ int wisp_composite_bwd(const float* grad_rgb /* [R,3] */, const float* grad_alph
  * wisp/models/nefs/nerf.py:245-264: decoder_density (Linear-ReLU-Linear) -> relu density + 15 geometry
  * features -> cat positional-encoded view dir (wisp/models/embedders/positional_embedder.py:51-66)
  * -> decoder_color (Linear-ReLU x2, Linear) -> sigmoid)
- * See wisp_nerf_mlp.h section below; declared in this header so the loader sees one ABI.
  *
  *  feats   dtype_io [S, in_dim]          (in_dim <= 64)
  *  dirs    f32 [S,3]
@@ -200,6 +199,8 @@ int wisp_composite_bwd(const float* grad_rgb /* [R,3] */, const float* grad_alph
  *  compute_dtype: WISP_F32 (exact fp32 MFMA) or WISP_BF16 (bf16 MFMA, fp32 accumulate)
  */
 int64_t wisp_nerf_mlp_param_count(int in_dim, int hidden, int view_freqs);
+/* floats of device scratch wisp_nerf_mlp_bwd needs (per-wave partial weight gradients). */
+int64_t wisp_nerf_mlp_workspace_floats(void);
 int wisp_nerf_mlp_fwd(const void* feats, int dtype_io, const float* dirs, int64_t num_samples,
                       int in_dim, int hidden, int view_freqs, const float* params, int compute_dtype,
                       float* rgb /* [S,3] */, float* density /* [S] */, wisp_stream_t stream);
@@ -207,7 +208,7 @@ int wisp_nerf_mlp_bwd(const void* feats, int dtype_io, const float* dirs, int64_
                       int in_dim, int hidden, int view_freqs, const float* params, int compute_dtype,
                       const float* grad_rgb /* [S,3] */, const float* grad_density /* [S] */,
                       void* grad_feats /* dtype_io [S,in_dim] */, float* grad_params /* accumulated */,
-                      wisp_stream_t stream);
+                      float* workspace /* wisp_nerf_mlp_workspace_floats() floats */, wisp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer  (replaces torch.optim.AdamW / apex FusedAdam over the flat parameter buffer,

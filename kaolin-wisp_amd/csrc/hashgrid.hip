@@ -15,6 +15,7 @@
 // Numerics contract: SURVEY.md Appendix B (double-then-float coordinate scaling, float32 clamp bound,
 // uint32 hash with the reference's primes, float32 blend in corner order).
 #include "wisp_common.h"
+#include <stdlib.h>
 
 #define HG_MAX_LODS 32
 #define HG_TILE 64
@@ -148,7 +149,13 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
     }
 }
 
-template <typename T, int F, int DIM>
+// Backward.  Global fp32 atomics on MI355X execute memory-side at ~1.4e10 /s no matter the scope bits, so the
+// lever is the NUMBER of atomics, not their placement.  Consecutive samples of a ray are consecutive lanes and on
+// every level several of them fall into the same grid cell (from ~2 per cell at res 512 to the whole wave at res
+// 16 for the 2048-step march), and a cell fixes all 2^DIM corner indices.  Each wave therefore runs a segmented
+// (by cell id) inclusive scan over its 64 lanes for the 2^DIM x F corner contributions and only the LAST lane of
+// every run issues atomics: ~38 instead of 256 atomics per sample for the nerf_hash.yaml configuration.
+template <typename T, int F, int DIM, bool MERGE>
 __global__ void __launch_bounds__(1024)
 hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ grad_feats,
                     const int64_t* __restrict__ first_idx, HashLevels lv, int num_lods, uint32_t tsize,
@@ -159,26 +166,71 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
     const int64_t ntiles = (n + HG_TILE - 1) / HG_TILE;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t i = tile * HG_TILE + lane;
-        if (i >= n) continue;
+        const bool live = i < n;
         float c[DIM];
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) c[a] = coords[i * DIM + a];
+        for (int a = 0; a < DIM; ++a) c[a] = live ? coords[i * DIM + a] : 0.0f;
         for (int l = wave; l < num_lods; l += nwaves) {
             if (l * F >= zero_from_col) continue;
             const int32_t res = __builtin_amdgcn_readfirstlane(lv.res[l]);
             const bool dense = __builtin_amdgcn_readfirstlane(lv.dense[l]) != 0;
             float g[F];
-            const T* gp = grad_feats + (i * num_lods + l) * F;
 #pragma unroll
-            for (int k = 0; k < F; ++k) g[k] = (l * F + k < zero_from_col) ? Cvt<T>::to_f(gp[k]) : 0.0f;
+            for (int k = 0; k < F; ++k) g[k] = 0.0f;
+            if (live) {
+                const T* gp = grad_feats + (i * num_lods + l) * F;
+#pragma unroll
+                for (int k = 0; k < F; ++k) g[k] = (l * F + k < zero_from_col) ? Cvt<T>::to_f(gp[k]) : 0.0f;
+            }
             CornerSetup<DIM> cs;
             corner_setup<DIM>(c, res, dense, tsize, tsize_pow2 != 0, cs);
-            float* __restrict__ gt = grad_codebook + first_idx[l] * F;
+            float v[1 << DIM][F];
 #pragma unroll
-            for (int j = 0; j < (1 << DIM); ++j) {
-                float* p = gt + (int64_t)cs.idx[j] * F;
+            for (int j = 0; j < (1 << DIM); ++j)
 #pragma unroll
-                for (int k = 0; k < F; ++k) atomicAdd(p + k, g[k] * cs.coef[j]);   // global_atomic_add_f32
+                for (int k = 0; k < F; ++k) v[j][k] = g[k] * cs.coef[j];
+            bool issue = live;
+            if (MERGE) {
+                // cell id = the (dense-style) linear index of corner 0; unique per cell for res^DIM < 2^31
+                int32_t key;
+                {
+                    const float hi = (float)((double)(res - 1) - 1e-5);
+                    int32_t lin = 0, mul = 1;
+#pragma unroll
+                    for (int a = 0; a < DIM; ++a) {
+                        float x = (float)((double)res * ((double)c[a] * 0.5 + 0.5));
+                        x = fmaxf(0.0f, fminf(hi, x));
+                        lin += (int32_t)floorf(x) * mul;
+                        mul *= res;
+                    }
+                    key = live ? lin : (-2 - lane);
+                }
+                const int32_t prevk = __shfl_up(key, 1, 64);
+                int f = (lane == 0 || key != prevk) ? 1 : 0;          // run-head flag
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int fp = __shfl_up(f, d, 64);
+                    const bool take = (lane >= d) && !f;
+#pragma unroll
+                    for (int j = 0; j < (1 << DIM); ++j)
+#pragma unroll
+                        for (int k = 0; k < F; ++k) {
+                            const float vp = __shfl_up(v[j][k], d, 64);
+                            if (take) v[j][k] += vp;
+                        }
+                    if (take) f |= fp;
+                }
+                const int32_t nextk = __shfl_down(key, 1, 64);
+                issue = live && (lane == 63 || key != nextk);         // run tail holds the run total
+            }
+            if (issue) {
+                float* __restrict__ gt = grad_codebook + first_idx[l] * F;
+#pragma unroll
+                for (int j = 0; j < (1 << DIM); ++j) {
+                    float* p = gt + (int64_t)cs.idx[j] * F;
+#pragma unroll
+                    for (int k = 0; k < F; ++k) atomicAdd(p + k, v[j][k]);   // global_atomic_add_f32
+                }
             }
         }
     }
@@ -220,14 +272,30 @@ static int launch_fwd(const float* coords, int64_t n, const void* codebook, cons
     return 0;
 }
 
+static bool bwd_merge_enabled() {
+    static const int v = [] { const char* e = getenv("WISP_HG_BWD_MERGE"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v != 0;
+}
+
 template <typename T, int F, int DIM>
 static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, const int64_t* first_idx,
                       const HashLevels& lv, int num_lods, uint32_t tsize, int zero_from_col, float* grad_codebook,
                       hipStream_t s) {
     const int nw = num_lods < 16 ? num_lods : 16;
     const int pow2 = (tsize & (tsize - 1)) == 0;
-    hipLaunchKernelGGL((hashgrid_bwd_kernel<T, F, DIM>), dim3(hg_grid(n)), dim3(64 * nw), 0, s, coords, n,
-                       (const T*)grad_feats, first_idx, lv, num_lods, tsize, pow2, zero_from_col, grad_codebook);
+    // the run merge keys cells by a 32-bit linear id: fall back to plain scatter for absurd resolutions / wide features
+    bool merge = bwd_merge_enabled() && (F * (1 << DIM) <= 32);
+    for (int l = 0; l < num_lods; ++l) {
+        double cells = 1.0;
+        for (int a = 0; a < DIM; ++a) cells *= (double)lv.res[l];
+        if (cells >= 2147483648.0) merge = false;
+    }
+    if (merge)
+        hipLaunchKernelGGL((hashgrid_bwd_kernel<T, F, DIM, true>), dim3(hg_grid(n)), dim3(64 * nw), 0, s, coords, n,
+                           (const T*)grad_feats, first_idx, lv, num_lods, tsize, pow2, zero_from_col, grad_codebook);
+    else
+        hipLaunchKernelGGL((hashgrid_bwd_kernel<T, F, DIM, false>), dim3(hg_grid(n)), dim3(64 * nw), 0, s, coords, n,
+                           (const T*)grad_feats, first_idx, lv, num_lods, tsize, pow2, zero_from_col, grad_codebook);
     return 0;
 }
 

@@ -54,12 +54,14 @@ SIGNATURES = {
     "wisp_composite_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_nerf_mlp_param_count": [c_i32, c_i32, c_i32],
     "wisp_nerf_mlp_fwd": [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp],
-    "wisp_nerf_mlp_bwd": [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_nerf_mlp_bwd": [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_nerf_mlp_workspace_floats": [],
     "wisp_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp],
     "wisp_last_error": [],
     "wisp_abi_version": [],
 }
-_RESTYPES = {"wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_last_error": ctypes.c_char_p}
+_RESTYPES = {"wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_nerf_mlp_workspace_floats": c_i64,
+             "wisp_last_error": ctypes.c_char_p}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here == header/library mismatch: fail loudly
@@ -397,3 +399,43 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_d
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
     _check(lib.wisp_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2, eps,
                                weight_decay, step, grad_scale, int(zero_grad), _stream()), "adamw_step")
+
+
+# ------------------------------------------------------------------------------------------------ fused NeRF decoder
+def nerf_mlp_forward(feats, dirs, params, in_dim, hidden, view_freqs, compute_bf16):
+    """(rgb [S,3], density [S,1]) = fused density + colour decoders (nerf.py:245-264)."""
+    feats = _need(feats, None, "feats")
+    dirs = _need(dirs, torch.float32, "dirs")
+    params = _need(params, torch.float32, "params")
+    S = feats.shape[0]
+    rgb = torch.empty(S, 3, dtype=torch.float32, device=feats.device)
+    density = torch.empty(S, 1, dtype=torch.float32, device=feats.device)
+    with _timed("nerf_mlp_fwd", S):
+        _check(lib.wisp_nerf_mlp_fwd(_p(feats), _DTYPE_CODE[feats.dtype], _p(dirs), S, in_dim, hidden, view_freqs, _p(params),
+                                     BF16 if compute_bf16 else F32, _p(rgb), _p(density), _stream()), "nerf_mlp_fwd")
+    return rgb, density
+
+
+_mlp_workspace = {}
+
+
+def nerf_mlp_backward(feats, dirs, params, grad_rgb, grad_density, in_dim, hidden, view_freqs, compute_bf16, grad_params=None):
+    """(grad_feats [S,in_dim] in feats.dtype, grad_params fp32 - accumulated into `grad_params` when given)."""
+    feats = _need(feats, None, "feats")
+    dirs = _need(dirs, torch.float32, "dirs")
+    params = _need(params, torch.float32, "params")
+    grad_rgb = _need(grad_rgb, torch.float32, "grad_rgb")
+    grad_density = _need(grad_density, torch.float32, "grad_density")
+    S, dev = feats.shape[0], feats.device
+    grad_feats = torch.empty_like(feats)
+    if grad_params is None:
+        grad_params = torch.zeros_like(params)
+    ws = _mlp_workspace.get(dev)
+    if ws is None:
+        ws = torch.empty(int(lib.wisp_nerf_mlp_workspace_floats()), dtype=torch.float32, device=dev)
+        _mlp_workspace[dev] = ws
+    with _timed("nerf_mlp_bwd", S):
+        _check(lib.wisp_nerf_mlp_bwd(_p(feats), _DTYPE_CODE[feats.dtype], _p(dirs), S, in_dim, hidden, view_freqs, _p(params),
+                                     BF16 if compute_bf16 else F32, _p(grad_rgb), _p(grad_density), _p(grad_feats),
+                                     _p(grad_params), _p(ws), _stream()), "nerf_mlp_bwd")
+    return grad_feats, grad_params

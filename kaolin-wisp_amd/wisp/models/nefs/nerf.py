@@ -75,7 +75,7 @@ class NeuralRadianceField(BaseNeuralField):
         self.prune_density_decay = prune_density_decay
         self.prune_min_density = prune_min_density
         # MI355X backend knobs (not part of the reference schema)
-        self.fused_decoder = False           # use csrc/nerf_mlp.hip when the configuration allows it
+        self.fused_decoder = True            # use csrc/nerf_mlp.hip when the configuration allows it
         self.decoder_compute = 'auto'        # 'fp32' | 'bf16' | 'auto' (bf16 under autocast, else fp32)
 
     def init_embedder(self, embedder_type, frequencies=None, include_input=False):
@@ -131,10 +131,10 @@ class NeuralRadianceField(BaseNeuralField):
         self._register_forward_function(self.rgba, ["density", "rgb"])
 
     def _can_fuse(self, feats):
-        return (self.fused_decoder and feats.is_cuda and self.pos_embedder is None
-                and self.view_embedder_type == 'positional' and self.activation_type == 'relu'
-                and self.layer_type in ('linear', 'none') and self.num_layers == 1
-                and feats.shape[-1] <= 64 and self.hidden_dim in (64, 128) and feats.shape[-1] % 2 == 0)
+        if not self.fused_decoder:
+            return False
+        from wisp.ops.nerf_mlp import supports
+        return supports(self, feats)
 
     def rgba(self, coords, ray_d, lod_idx=None):
         """coords [batch,3], ray_d [batch,3] -> dict(rgb [batch,3] in [0,1], density [batch,1])."""
