@@ -171,18 +171,29 @@ def main():
         units = [u for _, _, u in evs]
         kern[name] = dict(avg_ms=float(np.mean(ms)), launches=len(ms), avg_units=float(np.mean(units)), total_ms=float(np.sum(ms)))
     b = 2 if amp else 4
-    bytes_per_sample = {"hashgrid_fwd": 12 + 16 * 8 * 2 * b + 16 * 2 * b,            # coords + 128 gathered entries + 32 outputs
-                        "hashgrid_bwd": 12 + 16 * 2 * b + 2 * 16 * 8 * 2 * 4}       # coords + grads + fp32 RMW on 128 entries
+    # algorithmic work per packed sample (SURVEY.md 8d / DESIGN.md): bytes for the HBM-bound kernels, flops for the MLP
+    work = {"hashgrid_fwd": ("hbm", 12 + 16 * 8 * 2 * b + 16 * 2 * b),        # coords + 128 gathered entries + 32 outputs
+            "hashgrid_bwd": ("hbm", 12 + 16 * 2 * b + 2 * 16 * 8 * 2 * 4),     # coords + grads + fp32 RMW on 128 entries
+            "nerf_mlp_fwd": ("mfma", 20096), "nerf_mlp_bwd": ("mfma", 3 * 20096)}
+    peaks = {"hbm": (HBM_PEAK_GBS, "GB/s"), "mfma": (2500.0 if amp else 157.3, "TFLOP/s")}
+
+    def rate(name, v):
+        bound, per = work[name]
+        r = per * v["avg_units"] / (v["avg_ms"] * 1e-3)
+        return bound, (r / 1e9 if bound == "hbm" else r / 1e12)
+
+    kern = {n: v for n, v in kern.items() if n in work}
     dominant = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
     roofline = None
     if dominant:
         k = kern[dominant]
-        achieved = bytes_per_sample[dominant] * k["avg_units"] / (k["avg_ms"] * 1e-3) / 1e9
-        roofline = dict(bound="hbm", kernel=dominant, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, avg_launch_ms=k["avg_ms"],
-                        units_per_launch=k["avg_units"], bytes_per_unit=bytes_per_sample[dominant],
-                        all_kernels={n: dict(avg_ms=v["avg_ms"], gbps=bytes_per_sample[n] * v["avg_units"] / (v["avg_ms"] * 1e-3) / 1e9)
-                                     for n, v in kern.items()})
+        bound, achieved = rate(dominant, k)
+        peak, unit = peaks[bound]
+        roofline = dict(bound=bound, kernel=dominant, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
+                        traffic=None, avg_launch_ms=k["avg_ms"], units_per_launch=k["avg_units"],
+                        work_per_unit=work[dominant][1],
+                        all_kernels={n: dict(avg_ms=v["avg_ms"], bound=rate(n, v)[0], achieved=rate(n, v)[1],
+                                             frac=rate(n, v)[1] / peaks[rate(n, v)[0]][0]) for n, v in kern.items()})
 
     out = None
     if rank == 0:

@@ -425,13 +425,23 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
     }
 }
 
-__global__ void __launch_bounds__(256)
+// grad_params[j] += sum over partial rows.  Block = 64 parameters x 16 row groups (row-strided partial sums, then LDS).
+__global__ void __launch_bounds__(1024)
 nerf_mlp_reduce_kernel(const float* __restrict__ partials, int rows, float* __restrict__ grad_params) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= NPARAM) return;
+    __shared__ float s[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tx;
     float a = 0.0f;
-    for (int r = 0; r < rows; ++r) a += partials[(int64_t)r * NPARAM_PAD + j];
-    grad_params[j] += a;
+    if (j < NPARAM)
+        for (int r = ty; r < rows; r += 16) a += partials[(int64_t)r * NPARAM_PAD + j];
+    s[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && j < NPARAM) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s[k][tx];
+        grad_params[j] += t;
+    }
 }
 
 int cu_count() {
@@ -452,7 +462,7 @@ int launch(const void* feats, const float* dirs, int64_t s_total, const float* p
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, (const TIO*)feats, dirs, s_total, params, rgb, density,
                        grad_rgb, grad_density, (TIO*)grad_feats, workspace);
     if (BWD)
-        hipLaunchKernelGGL(nerf_mlp_reduce_kernel, dim3((NPARAM + 255) / 256), dim3(256), 0, st, workspace, grid * WAVES,
+        hipLaunchKernelGGL(nerf_mlp_reduce_kernel, dim3((NPARAM + 63) / 64), dim3(1024), 0, st, workspace, grid * WAVES,
                            grad_params);
     return 0;
 }

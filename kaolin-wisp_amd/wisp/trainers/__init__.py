@@ -1,1 +1,1 @@
-from .multiview_trainer import MultiviewTrainStep, FlatParams
+from .multiview_trainer import MultiviewTrainStep, FlatParams, shard_rays

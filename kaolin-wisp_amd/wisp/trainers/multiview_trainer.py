@@ -137,3 +137,11 @@ class MultiviewTrainStep:
         self.optimizer_step()
         self.calc_adaptive_rays(rays.origins.shape[0])
         return loss.detach(), self.pipeline.tracer.get_prev_num_samples()
+
+
+def shard_rays(num_rays: int, rank: int, world: int):
+    """Contiguous, disjoint, exhaustive ray shards: rank r gets rays [lo, hi).  Rays are independent (each ray's samples,
+    field queries and compositing touch no other ray), so this is the only data-path partitioning the method needs."""
+    base, rem = divmod(num_rays, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

@@ -415,6 +415,16 @@ def test_fused_decoder_matches_torch_fp32_modules(mode, io_dtype, tol, bias):
     ((rgb_ref * w_rgb).sum() + (den_ref * w_den).sum()).backward()
     ref_grads = {n: p.grad.clone() for n, p in nef.named_parameters() if p.grad is not None}
     nef.zero_grad()
+    # what plain torch bf16 autocast of the same modules loses against fp32 - the yardstick for the bf16 kernel
+    f_amp = feats.clone().requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        dfa = nef.decoder_density(f_amp)
+        fda = torch.cat([dfa, nef.view_embedder(dirs)], dim=-1)
+        rgb_a = torch.sigmoid(nef.decoder_color(fda[..., 1:])); den_a = torch.relu(dfa[..., 0:1])
+    ((rgb_a.float() * w_rgb).sum() + (den_a.float() * w_den).sum()).backward()
+    amp_err_feats = float((f_amp.grad - f_ref.grad).norm() / f_ref.grad.norm())
+    amp_err = {n: float((p.grad - ref_grads[n]).norm() / ref_grads[n].norm()) for n, p in nef.named_parameters() if n in ref_grads}
+    nef.zero_grad()
 
     f_in = feats.to(io_dtype).requires_grad_(True)
     rgb, den = fused_nerf_decoder(nef, f_in, dirs)
@@ -423,12 +433,22 @@ def test_fused_decoder_matches_torch_fp32_modules(mode, io_dtype, tol, bias):
     np.testing.assert_allclose(rgb.detach().cpu().numpy(), rgb_ref.detach().cpu().numpy(), atol=tol)       # fp32: 1e-4 contract
     np.testing.assert_allclose(den.detach().cpu().numpy(), den_ref.detach().cpu().numpy(), atol=tol * 10, rtol=tol)
     gs = float(f_ref.grad.abs().max())
-    assert float((f_in.grad.float() - f_ref.grad).abs().max()) <= (2e-4 if mode == "fp32" else 6e-2) * gs
+    if mode == "fp32":
+        assert float((f_in.grad.float() - f_ref.grad).abs().max()) <= 2e-4 * gs
+    else:
+        # bf16 activations flip a few relu masks near zero, which changes single gradient rows entirely: judge the
+        # tensor by its relative L2 error and the bulk of its entries, not by the worst entry
+        diff = (f_in.grad.float() - f_ref.grad)
+        assert float(diff.norm() / f_ref.grad.norm()) <= 1.5 * amp_err_feats + 1e-2, (float(diff.norm() / f_ref.grad.norm()), amp_err_feats)
     for n, p in nef.named_parameters():
         if n in ref_grads:
-            scale = max(float(ref_grads[n].abs().max()), 1e-6)
-            err = float((p.grad - ref_grads[n]).abs().max())
-            assert err <= (3e-4 if mode == "fp32" else 6e-2) * scale, (n, err, scale)
+            if mode == "fp32":
+                scale = max(float(ref_grads[n].abs().max()), 1e-6)
+                err = float((p.grad - ref_grads[n]).abs().max())
+                assert err <= 3e-4 * scale, (n, err, scale)
+            else:
+                rel = float((p.grad - ref_grads[n]).norm() / ref_grads[n].norm())
+                assert rel <= 1.5 * amp_err[n] + 1e-2, (n, rel, amp_err[n])
     r0, d0 = fused_nerf_decoder(nef, torch.zeros(0, 32, device=DEV), torch.zeros(0, 3, device=DEV))
     assert r0.shape == (0, 3) and d0.shape == (0, 1)
 
@@ -461,3 +481,45 @@ def test_trainer_flat_params_step_matches_unfused_torch_path():
     for (n1, p1), (n2, p2) in zip(nef.named_parameters(), nef2.named_parameters()):
         assert n1 == n2
         np.testing.assert_allclose(p1.detach().cpu().numpy(), p2.detach().cpu().numpy(), atol=3e-4, err_msg=n1)
+
+
+def test_training_psnr_parity_with_oracle():
+    """Same initial weights, same ray batches, same jitter: after 120 AdamW steps the HIP path and the CPU oracle reach
+    the same PSNR on the training rays within 0.1 dB (north-star bound)."""
+    import synlego
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.tracers import PackedRFTracer
+    from wisp.trainers import MultiviewTrainStep
+    level, steps_per_ray, R, iters = 5, 96, 384, 120
+    cells = synlego.occupied_cells(level, device='cpu')
+    from wisp.accelstructs import OctreeAS
+    from wisp.models.grids import HashGrid
+    from wisp.models.nefs import NeuralRadianceField
+    torch.manual_seed(0)
+    blas = OctreeAS.from_quantized_points(cells.to(DEV), level)
+    grid = HashGrid.from_geometric(blas, feature_dim=2, num_lods=16, multiscale_type='cat', feature_std=1e-4,
+                                   codebook_bitwidth=12, min_grid_res=4, max_grid_res=96)
+    nef = NeuralRadianceField(grid, view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1, bias=True).to(DEV)
+    onef = onerf.OracleNeRF(grid.resolutions, 2, 12, 'cat', 1e-4, 64, 1, True, 4)
+    onef.load_state_dict({k: v.detach().cpu() for k, v in nef.state_dict().items() if k in onef.state_dict()}, strict=False)
+    oblas = onerf.OracleBLAS(ospc.points_to_octree(cells.numpy(), level))
+    o, d, _ = synlego.ray_bank(3072, num_views=8, seed=3, device='cpu', with_gt=False)
+    gt = synlego.render_gt(o, d, steps=192)
+    pipe = Pipeline(nef, PackedRFTracer(raymarch_type='ray', num_steps=steps_per_ray, bg_color=(0.0, 0.0, 0.0)))
+    tr = MultiviewTrainStep(pipe, prune_every=-1, lr=1e-3, grid_lr_weight=100.0)
+    opt = onerf.make_optimizer(onef, lr=1e-3, grid_lr_weight=100.0)
+    rng = np.random.default_rng(17)
+    for it in range(iters):
+        idx = torch.from_numpy(rng.integers(0, o.shape[0], R))
+        jit = rng.uniform(size=(R, steps_per_ray)).astype(np.float32)
+        tr.step(Rays(o[idx].to(DEV), d[idx].to(DEV), dist_min=1.0, dist_max=5.0), gt[idx].to(DEV), jitter=cuda(jit))
+        onerf.train_step(onef, oblas, opt, o[idx], d[idx], gt[idx], 1.0, 5.0, steps_per_ray, jit)
+    jit = rng.uniform(size=(o.shape[0], steps_per_ray)).astype(np.float32)
+    with torch.no_grad():
+        rb = pipe(rays=Rays(o.to(DEV), d.to(DEV), dist_min=1.0, dist_max=5.0), channels=["rgb"], jitter=cuda(jit))
+        want = onerf.trace(onef, oblas, o, d, 1.0, 5.0, steps_per_ray, jit, (0.0, 0.0, 0.0), 'ray', with_depth=False)
+    p_hip, p_cpu = onerf.psnr(rb.rgb.cpu(), gt), onerf.psnr(want["rgb"], gt)
+    base = onerf.psnr(torch.zeros_like(gt), gt)
+    assert p_cpu > base + 3.0, (p_cpu, base)          # it actually learned something
+    assert abs(p_hip - p_cpu) <= 0.1, (p_hip, p_cpu)
