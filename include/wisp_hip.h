@@ -65,7 +65,13 @@ int wisp_hashgrid_interpolate_bwd(const float* coords, int64_t n, int coord_dim,
                                   const void* grad_feats, int dtype, int feature_dim,
                                   const int64_t* first_idx, const int32_t* resolutions, int num_lods,
                                   int codebook_bitwidth, int zero_from_col,
-                                  float* grad_codebook, wisp_stream_t stream);
+                                  float* grad_codebook, void* workspace, int64_t workspace_bytes,
+                                  wisp_stream_t stream);
+/* Optional device scratch for the backward: with at least this many bytes the hashed levels are reduced through
+ * binned (index, value) records + LDS accumulation instead of memory-side atomics (0 = binning not applicable). */
+int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, int feature_dim,
+                                          const int32_t* resolutions /* host */, int num_lods,
+                                          int codebook_bitwidth);
 
 /* ------------------------------------------------------------------------------------------------
  * SPC octree queries  (replace kaolin.ops.spc.unbatched_query at wisp/accelstructs/octree_as.py:162,

@@ -149,16 +149,82 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
     }
 }
 
-// Backward.  Global fp32 atomics on MI355X execute memory-side at ~1.4e10 /s no matter the scope bits, so the
-// lever is the NUMBER of atomics, not their placement.  Consecutive samples of a ray are consecutive lanes and on
-// every level several of them fall into the same grid cell (from ~2 per cell at res 512 to the whole wave at res
-// 16 for the 2048-step march), and a cell fixes all 2^DIM corner indices.  Each wave therefore runs a segmented
-// (by cell id) inclusive scan over its 64 lanes for the 2^DIM x F corner contributions and only the LAST lane of
-// every run issues atomics: ~38 instead of 256 atomics per sample for the nerf_hash.yaml configuration.
+// Backward.  Global fp32 atomics on MI355X execute memory-side at ~1.8e10 /s no matter the scope bits
+// (PMC: TCC_EA0_ATOMIC == number of atomic instructions), so the levers are (1) the NUMBER of atomics and (2) not using
+// them at all where a table slice fits in LDS.
+//  (1) Run merge.  Consecutive samples of a ray are consecutive lanes and on every level several of them fall into the
+//      same grid cell (~2 per cell at res 512, the whole wave at res 16 for the 2048-step march), and a cell fixes all
+//      2^DIM corner indices.  Each wave runs a segmented (by cell id) inclusive scan over its 64 lanes for the
+//      2^DIM x F corner contributions; only the LAST lane of every run emits: 36.5 instead of 256 per sample.
+//  (2) Binned LDS reduction for the hashed levels (they carry ~85 % of the remaining traffic and have no locality):
+//      the emit kernel appends (index, values) records to one of T/CHUNK buckets per level; a second kernel gives every
+//      (level, chunk) to ONE workgroup, which accumulates its bucket in LDS (ds_add_f32) and adds the finished slice to
+//      the gradient table with plain coalesced stores.  Records cost 12 B of streamed traffic instead of a memory-side
+//      atomic; bucket overflow (never observed: capacity is 1.25x the no-merge worst case) falls back to an atomic.
+struct LevelList { int32_t n; int32_t lv[HG_MAX_LODS]; };
+// per binned level: #chunks, bucket capacity (records), first cursor slot, first record slot, table entries, split factor
+struct BinLevels {
+    int32_t chunks[HG_MAX_LODS]; uint32_t cap[HG_MAX_LODS]; int32_t cur_base[HG_MAX_LODS]; int64_t rec_base[HG_MAX_LODS];
+    uint32_t entries[HG_MAX_LODS]; int32_t splits[HG_MAX_LODS];
+};
+
+template <typename T, int F, int DIM, bool MERGE>
+static __device__ __forceinline__ bool tail_compute(const float* c, bool live, int64_t i, int l, int num_lods, int32_t res,
+                                                    bool dense, uint32_t tsize, bool pow2, int zero_from_col,
+                                                    const T* __restrict__ grad_feats, int lane, CornerSetup<DIM>& cs,
+                                                    float (&v)[1 << DIM][F]) {
+    float g[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) g[k] = 0.0f;
+    if (live) {
+        const T* gp = grad_feats + (i * num_lods + l) * F;
+#pragma unroll
+        for (int k = 0; k < F; ++k) g[k] = (l * F + k < zero_from_col) ? Cvt<T>::to_f(gp[k]) : 0.0f;
+    }
+    corner_setup<DIM>(c, res, dense, tsize, pow2, cs);
+#pragma unroll
+    for (int j = 0; j < (1 << DIM); ++j)
+#pragma unroll
+        for (int k = 0; k < F; ++k) v[j][k] = g[k] * cs.coef[j];
+    if (!MERGE) return live;
+    // cell id = the (dense-style) linear index of corner 0; unique per cell for res^DIM < 2^31
+    int32_t key;
+    {
+        const float hi = (float)((double)(res - 1) - 1e-5);
+        int32_t lin = 0, mul = 1;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+            float x = (float)((double)res * ((double)c[a] * 0.5 + 0.5));
+            x = fmaxf(0.0f, fminf(hi, x));
+            lin += (int32_t)floorf(x) * mul;
+            mul *= res;
+        }
+        key = live ? lin : (-2 - lane);
+    }
+    const int32_t prevk = __shfl_up(key, 1, 64);
+    int f = (lane == 0 || key != prevk) ? 1 : 0;          // run-head flag
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int fp = __shfl_up(f, d, 64);
+        const bool take = (lane >= d) && !f;
+#pragma unroll
+        for (int j = 0; j < (1 << DIM); ++j)
+#pragma unroll
+            for (int k = 0; k < F; ++k) {
+                const float vp = __shfl_up(v[j][k], d, 64);
+                if (take) v[j][k] += vp;
+            }
+        if (take) f |= fp;
+    }
+    const int32_t nextk = __shfl_down(key, 1, 64);
+    return live && (lane == 63 || key != nextk);          // run tail holds the run total
+}
+
+// direct-atomic path: wave w of a workgroup handles level levels.lv[w] for a tile of 64 samples
 template <typename T, int F, int DIM, bool MERGE>
 __global__ void __launch_bounds__(1024)
 hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ grad_feats,
-                    const int64_t* __restrict__ first_idx, HashLevels lv, int num_lods, uint32_t tsize,
+                    const int64_t* __restrict__ first_idx, HashLevels lv, LevelList levels, int num_lods, uint32_t tsize,
                     int tsize_pow2, int zero_from_col, float* __restrict__ grad_codebook) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -170,59 +236,14 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
         float c[DIM];
 #pragma unroll
         for (int a = 0; a < DIM; ++a) c[a] = live ? coords[i * DIM + a] : 0.0f;
-        for (int l = wave; l < num_lods; l += nwaves) {
-            if (l * F >= zero_from_col) continue;
+        for (int li = wave; li < levels.n; li += nwaves) {
+            const int l = __builtin_amdgcn_readfirstlane(levels.lv[li]);
             const int32_t res = __builtin_amdgcn_readfirstlane(lv.res[l]);
             const bool dense = __builtin_amdgcn_readfirstlane(lv.dense[l]) != 0;
-            float g[F];
-#pragma unroll
-            for (int k = 0; k < F; ++k) g[k] = 0.0f;
-            if (live) {
-                const T* gp = grad_feats + (i * num_lods + l) * F;
-#pragma unroll
-                for (int k = 0; k < F; ++k) g[k] = (l * F + k < zero_from_col) ? Cvt<T>::to_f(gp[k]) : 0.0f;
-            }
             CornerSetup<DIM> cs;
-            corner_setup<DIM>(c, res, dense, tsize, tsize_pow2 != 0, cs);
             float v[1 << DIM][F];
-#pragma unroll
-            for (int j = 0; j < (1 << DIM); ++j)
-#pragma unroll
-                for (int k = 0; k < F; ++k) v[j][k] = g[k] * cs.coef[j];
-            bool issue = live;
-            if (MERGE) {
-                // cell id = the (dense-style) linear index of corner 0; unique per cell for res^DIM < 2^31
-                int32_t key;
-                {
-                    const float hi = (float)((double)(res - 1) - 1e-5);
-                    int32_t lin = 0, mul = 1;
-#pragma unroll
-                    for (int a = 0; a < DIM; ++a) {
-                        float x = (float)((double)res * ((double)c[a] * 0.5 + 0.5));
-                        x = fmaxf(0.0f, fminf(hi, x));
-                        lin += (int32_t)floorf(x) * mul;
-                        mul *= res;
-                    }
-                    key = live ? lin : (-2 - lane);
-                }
-                const int32_t prevk = __shfl_up(key, 1, 64);
-                int f = (lane == 0 || key != prevk) ? 1 : 0;          // run-head flag
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int fp = __shfl_up(f, d, 64);
-                    const bool take = (lane >= d) && !f;
-#pragma unroll
-                    for (int j = 0; j < (1 << DIM); ++j)
-#pragma unroll
-                        for (int k = 0; k < F; ++k) {
-                            const float vp = __shfl_up(v[j][k], d, 64);
-                            if (take) v[j][k] += vp;
-                        }
-                    if (take) f |= fp;
-                }
-                const int32_t nextk = __shfl_down(key, 1, 64);
-                issue = live && (lane == 63 || key != nextk);         // run tail holds the run total
-            }
+            const bool issue = tail_compute<T, F, DIM, MERGE>(c, live, i, l, num_lods, res, dense, tsize, tsize_pow2 != 0,
+                                                              zero_from_col, grad_feats, lane, cs, v);
             if (issue) {
                 float* __restrict__ gt = grad_codebook + first_idx[l] * F;
 #pragma unroll
@@ -232,6 +253,134 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
                     for (int k = 0; k < F; ++k) atomicAdd(p + k, v[j][k]);   // global_atomic_add_f32
                 }
             }
+        }
+    }
+}
+
+// ---- binned path for hashed levels -----------------------------------------------------------------------------------
+#define EM_TILE 512          // samples per emit workgroup
+#define EM_THREADS 256
+#define RD_THREADS 1024
+#define BIN_MAX_CHUNKS 1024
+
+// record = { index within the level table, F gradient values }, (1 + F) dwords
+template <typename T, int F, int DIM>
+__global__ void __launch_bounds__(EM_THREADS)
+hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ grad_feats,
+                         const int64_t* __restrict__ first_idx, HashLevels lv, LevelList levels, int num_lods,
+                         uint32_t tsize, int tsize_pow2, int zero_from_col, int chunk_shift, BinLevels bins,
+                         uint32_t* __restrict__ cursors, uint32_t* __restrict__ records, float* __restrict__ grad_codebook) {
+    constexpr int NC = 1 << DIM;
+    constexpr int RW = 1 + F;
+    extern __shared__ __attribute__((aligned(16))) uint32_t em_smem[];
+    uint32_t* s_hist = em_smem;                          // [chunks]   records of this tile per bucket
+    uint32_t* s_base = em_smem + BIN_MAX_CHUNKS;         // [chunks]   reserved global offset per bucket
+    uint32_t* s_stage = em_smem + 2 * BIN_MAX_CHUNKS;    // [EM_TILE * NC][RW]
+    __shared__ uint32_t s_count;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = blockIdx.y;
+    const int l = levels.lv[li];
+    const int32_t res = lv.res[l];
+    const bool dense = lv.dense[l] != 0;
+    const int chunks = bins.chunks[li];
+    const uint32_t cap = bins.cap[li];
+    for (int b = threadIdx.x; b < chunks; b += EM_THREADS) s_hist[b] = 0;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    const int64_t tile0 = (int64_t)blockIdx.x * EM_TILE;
+    for (int grp = wave; grp < EM_TILE / 64; grp += EM_THREADS / 64) {
+        const int64_t i = tile0 + grp * 64 + lane;
+        const bool live = i < n;
+        float c[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) c[a] = live ? coords[i * DIM + a] : 0.0f;
+        CornerSetup<DIM> cs;
+        float v[NC][F];
+        const bool issue = tail_compute<T, F, DIM, true>(c, live, i, l, num_lods, res, dense, tsize, tsize_pow2 != 0,
+                                                         zero_from_col, grad_feats, lane, cs, v);
+        const unsigned long long m = __ballot(issue);
+        if (m == 0ull) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s_count, (uint32_t)__popcll(m) * NC);
+        base = __shfl(base, 0, 64);
+        if (issue) {
+            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) * NC;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                uint32_t* r = s_stage + (slot + j) * RW;
+                r[0] = (uint32_t)cs.idx[j];
+#pragma unroll
+                for (int k = 0; k < F; ++k) r[1 + k] = __float_as_uint(v[j][k]);
+                atomicAdd(&s_hist[(uint32_t)cs.idx[j] >> chunk_shift], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t total = s_count;
+    uint32_t* cur = cursors + bins.cur_base[li];
+    for (int b = threadIdx.x; b < chunks; b += EM_THREADS) {
+        const uint32_t h = s_hist[b];
+        s_base[b] = h ? atomicAdd(cur + b, h) : 0u;      // reserve [base, base + h) in bucket b
+        s_hist[b] = 0;                                    // reused as the running rank inside the reservation
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < total; r += EM_THREADS) {
+        const uint32_t* rec = s_stage + r * RW;
+        const uint32_t idx = rec[0];
+        const uint32_t b = idx >> chunk_shift;
+        const uint32_t pos = s_base[b] + atomicAdd(&s_hist[b], 1u);
+        if (pos < cap) {
+            uint32_t* dst = records + ((size_t)bins.rec_base[li] + (size_t)b * cap + pos) * RW;
+#pragma unroll
+            for (int w = 0; w < RW; ++w) dst[w] = rec[w];
+        } else {                                          // bucket full: fall back to the memory-side atomic
+            float* p = grad_codebook + (first_idx[l] + (int64_t)idx) * F;
+#pragma unroll
+            for (int k = 0; k < F; ++k) atomicAdd(p + k, __uint_as_float(rec[1 + k]));
+        }
+    }
+}
+
+template <int F>
+__global__ void __launch_bounds__(RD_THREADS)
+hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList levels, int chunk_shift, BinLevels bins,
+                           const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ records,
+                           float* __restrict__ grad_codebook) {
+    constexpr int RW = 1 + F;
+    extern __shared__ __attribute__((aligned(16))) float rd_acc[];      // [chunk entries * F]
+    const int b = blockIdx.x, li = blockIdx.y, z = blockIdx.z;
+    const int splits = bins.splits[li];
+    if (b >= bins.chunks[li] || z >= splits) return;
+    const int l = levels.lv[li];
+    const uint32_t csize = 1u << chunk_shift;
+    const uint32_t cap = bins.cap[li];
+    uint32_t cnt = cursors[bins.cur_base[li] + b];
+    if (cnt > cap) cnt = cap;
+    if (cnt <= (uint32_t)z) return;
+    const uint32_t first = (uint32_t)b << chunk_shift;
+    const uint32_t entries = bins.entries[li];
+    const uint32_t lim = (entries > first ? min(entries - first, csize) : 0u) * F;
+    for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) rd_acc[e] = 0.0f;
+    __syncthreads();
+    const uint32_t* src = records + ((size_t)bins.rec_base[li] + (size_t)b * cap) * RW;
+    for (uint32_t r = z + threadIdx.x * splits; r < cnt; r += RD_THREADS * splits) {
+        const uint32_t* rec = src + (size_t)r * RW;
+        const uint32_t e = rec[0] - first;
+#pragma unroll
+        for (int k = 0; k < F; ++k) atomicAdd(&rd_acc[e * F + k], __uint_as_float(rec[1 + k]));     // ds_add_f32
+    }
+    __syncthreads();
+    float* __restrict__ dst = grad_codebook + (first_idx[l] + (int64_t)first) * F;
+    if (splits == 1) {
+        for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
+            const float a = rd_acc[e];
+            if (a != 0.0f) dst[e] += a;                   // this workgroup owns the slice: plain read-modify-write
+        }
+    } else {
+        for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
+            const float a = rd_acc[e];
+            if (a != 0.0f) atomicAdd(dst + e, a);         // coarse levels are split over several workgroups
         }
     }
 }
@@ -272,16 +421,53 @@ static int launch_fwd(const float* coords, int64_t n, const void* codebook, cons
     return 0;
 }
 
-static bool bwd_merge_enabled() {
-    static const int v = [] { const char* e = getenv("WISP_HG_BWD_MERGE"); return (e && e[0] == '0') ? 0 : 1; }();
-    return v != 0;
+static bool env_flag(const char* name, bool dflt) {
+    const char* e = getenv(name);
+    if (!e || !e[0]) return dflt;
+    return e[0] != '0';
+}
+static bool bwd_merge_enabled() { static const bool v = env_flag("WISP_HG_BWD_MERGE", true); return v; }
+static bool bwd_bin_enabled() { static const bool v = env_flag("WISP_HG_BWD_BIN", true); return v; }
+
+// bin geometry shared by the workspace query and the launcher
+struct BinPlan { int chunk_shift, max_chunks, max_splits; BinLevels bins; int64_t cursor_bytes, record_bytes; bool ok; };
+static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels, int feature_dim, int64_t tsize, int dim) {
+    BinPlan p{};
+    const int corners = 1 << dim;
+    int64_t centries = 16384 / feature_dim;               // 64 KiB of fp32 accumulators per workgroup
+    while (((int64_t)1 << (p.chunk_shift + 1)) <= centries) ++p.chunk_shift;
+    int64_t cur = 0, rec = 0;
+    p.ok = true;
+    for (int li = 0; li < levels.n; ++li) {
+        const int l = levels.lv[li];
+        int64_t entries = tsize;
+        if (lv.dense[l]) { entries = 1; for (int a = 0; a < dim; ++a) entries *= (int64_t)(lv.res[l] + 1); }   // corner index < (res+1)^dim
+        if (entries > tsize && !lv.dense[l]) entries = tsize;
+        const int64_t chunks = (entries + ((int64_t)1 << p.chunk_shift) - 1) >> p.chunk_shift;
+        int64_t cap = (n * corners + chunks - 1) / chunks;    // no-merge worst case under a uniform spread ...
+        cap = cap + cap / 4 + 4096;                           // ... + 25 % skew margin (overflow falls back to atomics)
+        if (chunks > BIN_MAX_CHUNKS || cap > 0x7fffffff || entries > 0xffffffffLL) p.ok = false;
+        p.bins.chunks[li] = (int32_t)chunks;
+        p.bins.cap[li] = (uint32_t)cap;
+        p.bins.cur_base[li] = (int32_t)cur;
+        p.bins.rec_base[li] = rec;
+        p.bins.entries[li] = (uint32_t)entries;
+        int splits = (int)(64 / chunks);                      // ~64 reduce workgroups per level
+        p.bins.splits[li] = splits < 1 ? 1 : splits;
+        if (chunks > p.max_chunks) p.max_chunks = (int)chunks;
+        if (p.bins.splits[li] > p.max_splits) p.max_splits = p.bins.splits[li];
+        cur += chunks;
+        rec += chunks * cap;
+    }
+    p.cursor_bytes = (cur * 4 + 255) / 256 * 256;
+    p.record_bytes = rec * (1 + feature_dim) * 4;
+    return p;
 }
 
 template <typename T, int F, int DIM>
 static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, const int64_t* first_idx,
                       const HashLevels& lv, int num_lods, uint32_t tsize, int zero_from_col, float* grad_codebook,
-                      hipStream_t s) {
-    const int nw = num_lods < 16 ? num_lods : 16;
+                      void* workspace, int64_t workspace_bytes, hipStream_t s) {
     const int pow2 = (tsize & (tsize - 1)) == 0;
     // the run merge keys cells by a 32-bit linear id: fall back to plain scatter for absurd resolutions / wide features
     bool merge = bwd_merge_enabled() && (F * (1 << DIM) <= 32);
@@ -290,12 +476,37 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
         for (int a = 0; a < DIM; ++a) cells *= (double)lv.res[l];
         if (cells >= 2147483648.0) merge = false;
     }
-    if (merge)
-        hipLaunchKernelGGL((hashgrid_bwd_kernel<T, F, DIM, true>), dim3(hg_grid(n)), dim3(64 * nw), 0, s, coords, n,
-                           (const T*)grad_feats, first_idx, lv, num_lods, tsize, pow2, zero_from_col, grad_codebook);
-    else
-        hipLaunchKernelGGL((hashgrid_bwd_kernel<T, F, DIM, false>), dim3(hg_grid(n)), dim3(64 * nw), 0, s, coords, n,
-                           (const T*)grad_feats, first_idx, lv, num_lods, tsize, pow2, zero_from_col, grad_codebook);
+    LevelList active{0, {0}};
+    for (int l = 0; l < num_lods; ++l)
+        if (l * F < zero_from_col) active.lv[active.n++] = l;
+    if (active.n == 0) return 0;
+    const BinPlan plan = bin_plan(n, lv, active, F, (int64_t)tsize, DIM);
+    const bool can_bin = merge && bwd_bin_enabled() && workspace && plan.ok &&
+                         plan.cursor_bytes + plan.record_bytes <= workspace_bytes && n >= 4096;
+    if (!can_bin) {
+        const int nw = active.n < 16 ? active.n : 16;
+        if (merge)
+            hipLaunchKernelGGL((hashgrid_bwd_kernel<T, F, DIM, true>), dim3(hg_grid(n)), dim3(64 * nw), 0, s, coords, n,
+                               (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col, grad_codebook);
+        else
+            hipLaunchKernelGGL((hashgrid_bwd_kernel<T, F, DIM, false>), dim3(hg_grid(n)), dim3(64 * nw), 0, s, coords, n,
+                               (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col, grad_codebook);
+        return 0;
+    }
+    uint32_t* cursors = (uint32_t*)workspace;
+    uint32_t* records = (uint32_t*)((char*)workspace + plan.cursor_bytes);
+    if (hipMemsetAsync(cursors, 0, plan.cursor_bytes, s) != hipSuccess) return -1;
+    const size_t em_lds = (size_t)(2 * BIN_MAX_CHUNKS + EM_TILE * (1 << DIM) * (1 + F)) * 4;
+    auto em = hashgrid_bwd_emit_kernel<T, F, DIM>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)em_lds);
+    hipLaunchKernelGGL(em, dim3((unsigned)ceil_div64(n, EM_TILE), active.n), dim3(EM_THREADS), em_lds, s, coords, n,
+                       (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
+                       plan.chunk_shift, plan.bins, cursors, records, grad_codebook);
+    const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 4;
+    auto rd = hashgrid_bwd_reduce_kernel<F>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
+    hipLaunchKernelGGL(rd, dim3(plan.max_chunks, active.n, plan.max_splits), dim3(RD_THREADS), rd_lds, s, first_idx, active,
+                       plan.chunk_shift, plan.bins, cursors, records, grad_codebook);
     return 0;
 }
 
@@ -342,7 +553,8 @@ extern "C" int wisp_hashgrid_interpolate_fwd(const float* coords, int64_t n, int
 extern "C" int wisp_hashgrid_interpolate_bwd(const float* coords, int64_t n, int coord_dim, const void* grad_feats,
                                              int dtype, int feature_dim, const int64_t* first_idx,
                                              const int32_t* resolutions, int num_lods, int codebook_bitwidth,
-                                             int zero_from_col, float* grad_codebook, wisp_stream_t stream) {
+                                             int zero_from_col, float* grad_codebook, void* workspace,
+                                             int64_t workspace_bytes, wisp_stream_t stream) {
     WISP_REQUIRE(n >= 0, "negative n");
     if (n == 0) return WISP_OK;
     WISP_REQUIRE(coords && grad_feats && first_idx && resolutions && grad_codebook, "null pointer");
@@ -355,7 +567,20 @@ extern "C" int wisp_hashgrid_interpolate_bwd(const float* coords, int64_t n, int
     WISP_REQUIRE(fill_levels(resolutions, num_lods, coord_dim, tsize, lv) == 0, "bad resolution");
     hipStream_t s = (hipStream_t)stream;
     HG_DISPATCH(launch_bwd, coords, n, grad_feats, first_idx, lv, num_lods, (uint32_t)tsize, zero_from_col,
-                grad_codebook, s)
+                grad_codebook, workspace, workspace_bytes, s)
     WISP_CHECK_LAUNCH();
     return WISP_OK;
+}
+
+extern "C" int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, int feature_dim,
+                                                     const int32_t* resolutions, int num_lods, int codebook_bitwidth) {
+    if (n <= 0 || num_lods <= 0 || num_lods > HG_MAX_LODS || feature_dim <= 0 || !resolutions) return 0;
+    if (coord_dim != 2 && coord_dim != 3) return 0;
+    HashLevels lv;
+    const int64_t tsize = (int64_t)1 << codebook_bitwidth;
+    if (fill_levels(resolutions, num_lods, coord_dim, tsize, lv) != 0) return 0;
+    LevelList all{0, {0}};
+    for (int l = 0; l < num_lods; ++l) all.lv[all.n++] = l;
+    const BinPlan p = bin_plan(n, lv, all, feature_dim, tsize, coord_dim);
+    return p.ok ? p.cursor_bytes + p.record_bytes : 0;
 }

@@ -126,15 +126,29 @@ template <> struct MMA<__bf16> {
     }
 };
 
-// dW[i0 + r][k0 + c] += sum_n dY[n][i0 + r] * X[n][k0 + c]   (always fp32 MFMA, reduction over the 32 samples)
-template <typename TC>
-static __device__ __forceinline__ void dw_acc(const TC* dY, int ldy, int i0, const TC* X, int ldx, int k0, floatx16& acc,
-                                              int lane) {
-    const TC* pa = dY + (lane >> 5) * ldy + i0 + (lane & 31);
-    const TC* pb = X + (lane >> 5) * ldx + k0 + (lane & 31);
+// dW[i0 + r][k0 + c] += sum_n dY[n][i0 + r] * X[n][k0 + c]   (reduction over the wave's 32 samples).
+// fp32 tiles: exact fp32 MFMA, one sample pair per step.  bf16 tiles: two v_mfma_f32_32x32x16_bf16 per 32x32 block of
+// dW; both operands are COLUMNS of the [sample][feature] LDS tiles, gathered with strided 2-byte reads (the K slots of
+// A and B only have to agree with each other, so sample 8*half + j of each 16-sample step goes to slot j).
+static __device__ __forceinline__ void dw_acc(const float* dY, int ldy, int i0, const float* X, int ldx, int k0,
+                                              floatx16& acc, int lane) {
+    const float* pa = dY + (lane >> 5) * ldy + i0 + (lane & 31);
+    const float* pb = X + (lane >> 5) * ldx + k0 + (lane & 31);
 #pragma unroll
-    for (int n = 0; n < TS; n += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Traits<TC>::to_f(pa[n * ldy]), Traits<TC>::to_f(pb[n * ldx]), acc, 0, 0, 0);
+    for (int n = 0; n < TS; n += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[n * ldy], pb[n * ldx], acc, 0, 0, 0);
+}
+
+static __device__ __forceinline__ void dw_acc(const __bf16* dY, int ldy, int i0, const __bf16* X, int ldx, int k0,
+                                              floatx16& acc, int lane) {
+    const __bf16* pa = dY + 8 * (lane >> 5) * ldy + i0 + (lane & 31);
+    const __bf16* pb = X + 8 * (lane >> 5) * ldx + k0 + (lane & 31);
+#pragma unroll
+    for (int n = 0; n < TS; n += 16) {
+        bf16x8 a, b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = pa[(n + j) * ldy]; b[j] = pb[(n + j) * ldx]; }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
 }
 
 // row of accumulator register `reg` for this lane (C/D layout of the 32x32 MFMA shapes)
@@ -312,7 +326,7 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
         }
         // dW5 += dY5^T h3 ; db5 ; dH3 = (W5^T dY5) * (h3 > 0) -> dyb
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) dw_acc<TC>(dya, G::LDH, 0, h3, G::LDH, kt * 32, dW5[kt], lane);
+        for (int kt = 0; kt < 2; ++kt) dw_acc(dya, G::LDH, 0, h3, G::LDH, kt * 32, dW5[kt], lane);
         if (lane < 3) { float a = 0.f; for (int m = 0; m < TS; ++m) a += Tr::to_f(dya[m * G::LDH + lane]); db5 += a; }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -330,7 +344,7 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) dw_acc<TC>(dyb, G::LDH, it * 32, h2, G::LDH, kt * 32, dW4[it * 2 + kt], lane);
+            for (int kt = 0; kt < 2; ++kt) dw_acc(dyb, G::LDH, it * 32, h2, G::LDH, kt * 32, dW4[it * 2 + kt], lane);
         { float a = 0.f; for (int m = 0; m < TS; ++m) a += Tr::to_f(dyb[m * G::LDH + lane]); db4 += a; }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -348,7 +362,7 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) dw_acc<TC>(dya, G::LDH, it * 32, x2, G::LDH, kt * 32, dW3[it * 2 + kt], lane);
+            for (int kt = 0; kt < 2; ++kt) dw_acc(dya, G::LDH, it * 32, x2, G::LDH, kt * 32, dW3[it * 2 + kt], lane);
         { float a = 0.f; for (int m = 0; m < TS; ++m) a += Tr::to_f(dya[m * G::LDH + lane]); db3 += a; }
         {
             floatx16 acc = zero16();
@@ -368,7 +382,7 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
         __builtin_amdgcn_wave_barrier();
         // dW2 += dY2^T h1 ; db2 ; dH1 = (W2^T dY2) * (h1 > 0) -> dya
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) dw_acc<TC>(dyb, G::LDH, 0, h1, G::LDH, kt * 32, dW2[kt], lane);
+        for (int kt = 0; kt < 2; ++kt) dw_acc(dyb, G::LDH, 0, h1, G::LDH, kt * 32, dW2[kt], lane);
         if (lane < 16) { float a = 0.f; for (int m = 0; m < TS; ++m) a += Tr::to_f(dyb[m * G::LDH + lane]); db2 += a; }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -384,7 +398,7 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
         __builtin_amdgcn_wave_barrier();
         // dW1 += dH1^T x0 ; db1 ; dX0 = W1^T dH1 -> grad_feats
 #pragma unroll
-        for (int it = 0; it < 2; ++it) dw_acc<TC>(dya, G::LDH, it * 32, x0, G::LDI, 0, dW1[it], lane);
+        for (int it = 0; it < 2; ++it) dw_acc(dya, G::LDH, it * 32, x0, G::LDI, 0, dW1[it], lane);
         { float a = 0.f; for (int m = 0; m < TS; ++m) a += Tr::to_f(dya[m * G::LDH + lane]); db1 += a; }
         {
             floatx16 acc = zero16();

@@ -31,7 +31,8 @@ c_vp, c_i64, c_i32, c_f32, c_u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 # name -> argtypes (restype int unless listed in _RESTYPES); mirrors include/wisp_hip.h one to one
 SIGNATURES = {
     "wisp_hashgrid_interpolate_fwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
-    "wisp_hashgrid_interpolate_bwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
+    "wisp_hashgrid_interpolate_bwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp],
+    "wisp_hashgrid_bwd_workspace_bytes": [c_i64, c_i32, c_i32, c_vp, c_i32, c_i32],
     "wisp_spc_query": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_build_bitfield": [c_vp, c_i64, c_i32, c_vp, c_vp],
     "wisp_spc_raytrace_count": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp],
@@ -60,7 +61,7 @@ SIGNATURES = {
     "wisp_last_error": [],
     "wisp_abi_version": [],
 }
-_RESTYPES = {"wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_nerf_mlp_workspace_floats": c_i64,
+_RESTYPES = {"wisp_hashgrid_bwd_workspace_bytes": c_i64, "wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_nerf_mlp_workspace_floats": c_i64,
              "wisp_last_error": ctypes.c_char_p}
 
 for _name, _args in SIGNATURES.items():
@@ -162,11 +163,29 @@ def hashgrid_interpolate_backward(coords, grad_feats, codebook_shape, first_idx,
     res_arr, res_ptr = _host_i32(resolutions)
     grad = out if out is not None else torch.zeros(tuple(codebook_shape), dtype=torch.float32, device=coords.device)
     assert grad.dtype == torch.float32 and grad.is_contiguous()
+    # scratch for the binned reduction of the hashed levels (sized for the levels that are actually hashed)
+    ws_bytes = int(lib.wisp_hashgrid_bwd_workspace_bytes(n, dim, F, res_ptr, L, codebook_bitwidth))
+    ws = _bwd_workspace(coords.device, ws_bytes) if 0 < ws_bytes <= HASHGRID_BWD_WORKSPACE_LIMIT else None
     with _timed("hashgrid_bwd", n):
         _check(lib.wisp_hashgrid_interpolate_bwd(_p(coords), n, dim, _p(grad_feats), _DTYPE_CODE[grad_feats.dtype], F,
                                                  _p(first_idx), res_ptr, L, codebook_bitwidth, zero_from_col, _p(grad),
-                                                 _stream()), "hashgrid_interpolate_bwd")
+                                                 _p(ws), ws.numel() if ws is not None else 0, _stream()),
+               "hashgrid_interpolate_bwd")
     return grad
+
+
+HASHGRID_BWD_WORKSPACE_LIMIT = 24 << 30          # bytes; 288 GB of HBM makes a multi-GB scratch a fair trade
+_bwd_ws = {}
+
+
+def _bwd_workspace(device, nbytes):
+    buf = _bwd_ws.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _bwd_ws[device] = None
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _bwd_ws[device] = buf
+    return buf
 
 
 # ------------------------------------------------------------------------------------------------ scans / packs
