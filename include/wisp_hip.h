@@ -119,6 +119,28 @@ int wisp_boundary_pack_starts(const uint8_t* boundary, int64_t n, const int64_t*
                               int64_t* starts, wisp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Dual-octree trilinear interpolation  (replace kaolin.ops.spc.unbatched_interpolate_trilinear at
+ * wisp/models/grids/octree_grid.py:147-149 and kaolin.ops.spc.coords_to_trilinear_coeffs at
+ * wisp/models/grids/codebook_grid.py:164)
+ *
+ *  coords   f32 [V, S, 3]      S samples inside each of V voxels
+ *  pidx     i32 or i64 [V]     point-hierarchy index of the voxel (-1: outside -> zeros)
+ *  trinkets i32 [P, 8]         per-voxel indices of its 8 corners, local to the level's feature tensor
+ *  feats    dtype [Fn, C]      level-local corner features; out / grad_out f32 [V, S, C]
+ *  half_round != 0 reproduces the reference's `feats.half() ... .float()` rounding in registers.
+ */
+int wisp_spc_trilinear_coeffs(const float* coords, const int16_t* voxel_points /* [V,3] */, int64_t num_voxels,
+                              int samples_per_voxel, int level, float* coeffs /* [V,S,8] */, wisp_stream_t stream);
+int wisp_spc_trilinear_fwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
+                           const int32_t* trinkets, const void* feats, int dtype, int64_t num_voxels,
+                           int samples_per_voxel, int channels, int level, int half_round, float* out,
+                           wisp_stream_t stream);
+int wisp_spc_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
+                           const int32_t* trinkets, const float* grad_out, int64_t num_voxels,
+                           int samples_per_voxel, int channels, int level, float* grad_feats /* f32, accumulated */,
+                           wisp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Raymarch sample generation  (replace OctreeAS._raymarch_ray / _raymarch_voxel / _raymarch_uniform,
  * wisp/accelstructs/octree_as.py:188-374, wisp/ops/spc/sampling.py:35-71 and
  * wisp._C.ops.uniform_sample_cuda, wisp/csrc/ops/uniform_sample_cuda.cu:18-98)

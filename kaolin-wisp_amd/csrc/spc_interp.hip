@@ -1,0 +1,158 @@
+// Trilinear interpolation over the dual octree (SPC "trinkets") for gfx950.
+//
+// Replaces kaolin.ops.spc.unbatched_interpolate_trilinear (wisp/models/grids/octree_grid.py:147-149) and
+// kaolin.ops.spc.coords_to_trilinear_coeffs (wisp/models/grids/codebook_grid.py:164, octree_grid.py:157);
+// semantics SURVEY.md Appendix A.6:
+//     x = 2^level (0.5 c + 0.5) - point[pidx] ;  coeff_j = prod_axis (bit_j ? x : 1 - x), j = dx<<2 | dy<<1 | dz
+//     out = sum_j feats[trinkets[pidx, j]] * coeff_j ;  pidx == -1 -> 0
+// Layout: one workgroup row per (voxel, sample); consecutive lanes own consecutive feature channels, so the 8 corner
+// rows are read as contiguous segments (C = 16 floats = one 64-B line per corner) and the output row is written
+// contiguously.  `half_round` reproduces the reference call `feats.half() ... .float()` (octree_grid.py:147-149)
+// without materialising a half copy of the feature tensor: features and the result are rounded through fp16 in
+// registers.
+#include "wisp_common.h"
+
+static __device__ __forceinline__ void trilinear_coeffs(const float* __restrict__ c, const int16_t* __restrict__ pt,
+                                                        int level, float (&w)[8]) {
+    const float res = (float)(1 << level);
+    float f[3], g[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        f[a] = res * (0.5f * c[a] + 0.5f) - (float)pt[a];
+        g[a] = 1.0f - f[a];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = ((j & 4) ? f[0] : g[0]) * ((j & 2) ? f[1] : g[1]) * ((j & 1) ? f[2] : g[2]);
+}
+
+__global__ void __launch_bounds__(256)
+spc_trilinear_coeffs_kernel(const float* __restrict__ coords, const int16_t* __restrict__ pts, int64_t n, int spv,
+                            int level, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (voxel, sample) flattened
+    if (i >= n * spv) return;
+    const int64_t v = i / spv;
+    float w[8];
+    trilinear_coeffs(coords + i * 3, pts + v * 3, level, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[i * 8 + j] = w[j];
+}
+
+template <typename T, typename I>
+__global__ void __launch_bounds__(256)
+spc_trilinear_fwd_kernel(const float* __restrict__ coords, const I* __restrict__ pidx, const int16_t* __restrict__ points,
+                         const int32_t* __restrict__ trinkets, const T* __restrict__ feats, int64_t n, int spv, int channels,
+                         int level, int half_round, float* __restrict__ out) {
+    const int cpt = channels <= 64 ? channels : 64;                  // lanes cooperating on one row
+    const int rows_per_block = blockDim.x / cpt;
+    const int ch0 = threadIdx.x % cpt;
+    const int64_t stride = (int64_t)gridDim.x * rows_per_block;
+    for (int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cpt; i < n * spv; i += stride) {
+        if (threadIdx.x / cpt >= rows_per_block) break;
+        const int64_t v = i / spv;
+        const int64_t p = (int64_t)pidx[v];
+        if (p < 0) {
+            for (int ch = ch0; ch < channels; ch += cpt) out[i * channels + ch] = 0.0f;
+            continue;
+        }
+        float w[8];
+        trilinear_coeffs(coords + i * 3, points + p * 3, level, w);
+        const int32_t* tr = trinkets + p * 8;
+        for (int ch = ch0; ch < channels; ch += cpt) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float fv = Cvt<T>::to_f(feats[(int64_t)tr[j] * channels + ch]);
+                if (half_round) fv = __half2float(__float2half_rn(fv));
+                acc += fv * w[j];
+            }
+            out[i * channels + ch] = half_round ? __half2float(__float2half_rn(acc)) : acc;
+        }
+    }
+}
+
+template <typename I>
+__global__ void __launch_bounds__(256)
+spc_trilinear_bwd_kernel(const float* __restrict__ coords, const I* __restrict__ pidx, const int16_t* __restrict__ points,
+                         const int32_t* __restrict__ trinkets, const float* __restrict__ grad_out, int64_t n, int spv,
+                         int channels, int level, float* __restrict__ grad_feats) {
+    const int cpt = channels <= 64 ? channels : 64;
+    const int rows_per_block = blockDim.x / cpt;
+    const int ch0 = threadIdx.x % cpt;
+    const int64_t stride = (int64_t)gridDim.x * rows_per_block;
+    for (int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cpt; i < n * spv; i += stride) {
+        if (threadIdx.x / cpt >= rows_per_block) break;
+        const int64_t v = i / spv;
+        const int64_t p = (int64_t)pidx[v];
+        if (p < 0) continue;
+        float w[8];
+        trilinear_coeffs(coords + i * 3, points + p * 3, level, w);
+        const int32_t* tr = trinkets + p * 8;
+        for (int ch = ch0; ch < channels; ch += cpt) {
+            const float g = grad_out[i * channels + ch];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(grad_feats + (int64_t)tr[j] * channels + ch, g * w[j]);
+        }
+    }
+}
+
+static inline int interp_grid(int64_t rows, int channels) {
+    const int cpt = channels <= 64 ? channels : 64;
+    const int rpb = 256 / cpt;
+    return (int)min64(ceil_div64(rows, rpb), 16384);
+}
+
+extern "C" int wisp_spc_trilinear_coeffs(const float* coords, const int16_t* voxel_points, int64_t num_voxels,
+                                         int samples_per_voxel, int level, float* coeffs, wisp_stream_t stream) {
+    WISP_REQUIRE(num_voxels >= 0 && samples_per_voxel >= 1 && level >= 0 && level <= 15, "bad sizes");
+    if (num_voxels == 0) return WISP_OK;
+    WISP_REQUIRE(coords && voxel_points && coeffs, "null pointer");
+    const int64_t rows = num_voxels * samples_per_voxel;
+    hipLaunchKernelGGL(spc_trilinear_coeffs_kernel, dim3((unsigned)ceil_div64(rows, 256)), dim3(256), 0, (hipStream_t)stream,
+                       coords, voxel_points, num_voxels, samples_per_voxel, level, coeffs);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_spc_trilinear_fwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
+                                      const int32_t* trinkets, const void* feats, int dtype, int64_t num_voxels,
+                                      int samples_per_voxel, int channels, int level, int half_round, float* out,
+                                      wisp_stream_t stream) {
+    WISP_REQUIRE(num_voxels >= 0 && samples_per_voxel >= 1 && channels >= 1 && level >= 0 && level <= 15, "bad sizes");
+    if (num_voxels == 0) return WISP_OK;
+    WISP_REQUIRE(coords && pidx && points && trinkets && feats && out, "null pointer");
+    WISP_REQUIRE(channels <= 64 ? (256 % channels == 0 || true) : true, "channels");
+    const int64_t rows = num_voxels * samples_per_voxel;
+    const dim3 grid(interp_grid(rows, channels)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define TRI_FWD(T, I)                                                                                              \
+    hipLaunchKernelGGL((spc_trilinear_fwd_kernel<T, I>), grid, block, 0, s, coords, (const I*)pidx, points, trinkets, \
+                       (const T*)feats, num_voxels, samples_per_voxel, channels, level, half_round, out)
+    if (pidx_is_i64) {
+        if (dtype == WISP_F32) TRI_FWD(float, int64_t); else if (dtype == WISP_F16) TRI_FWD(__half, int64_t); else TRI_FWD(__hip_bfloat16, int64_t);
+    } else {
+        if (dtype == WISP_F32) TRI_FWD(float, int32_t); else if (dtype == WISP_F16) TRI_FWD(__half, int32_t); else TRI_FWD(__hip_bfloat16, int32_t);
+    }
+#undef TRI_FWD
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_spc_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
+                                      const int32_t* trinkets, const float* grad_out, int64_t num_voxels,
+                                      int samples_per_voxel, int channels, int level, float* grad_feats,
+                                      wisp_stream_t stream) {
+    WISP_REQUIRE(num_voxels >= 0 && samples_per_voxel >= 1 && channels >= 1 && level >= 0 && level <= 15, "bad sizes");
+    if (num_voxels == 0) return WISP_OK;
+    WISP_REQUIRE(coords && pidx && points && trinkets && grad_out && grad_feats, "null pointer");
+    const int64_t rows = num_voxels * samples_per_voxel;
+    const dim3 grid(interp_grid(rows, channels)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (pidx_is_i64)
+        hipLaunchKernelGGL(spc_trilinear_bwd_kernel<int64_t>, grid, block, 0, s, coords, (const int64_t*)pidx, points, trinkets,
+                           grad_out, num_voxels, samples_per_voxel, channels, level, grad_feats);
+    else
+        hipLaunchKernelGGL(spc_trilinear_bwd_kernel<int32_t>, grid, block, 0, s, coords, (const int32_t*)pidx, points, trinkets,
+                           grad_out, num_voxels, samples_per_voxel, channels, level, grad_feats);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

@@ -37,6 +37,9 @@ SIGNATURES = {
     "wisp_spc_build_bitfield": [c_vp, c_i64, c_i32, c_vp, c_vp],
     "wisp_spc_raytrace_count": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp],
     "wisp_spc_raytrace_emit": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "wisp_spc_trilinear_coeffs": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
+    "wisp_spc_trilinear_fwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
+    "wisp_spc_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_mark_pack_boundaries_i64": [c_vp, c_i64, c_vp, c_vp],
     "wisp_mark_pack_boundaries_i32": [c_vp, c_i64, c_vp, c_vp],
     "wisp_scan_workspace_bytes": [c_i64],
@@ -286,6 +289,47 @@ def spc_raytrace(octree, points, exsum, origins, dirs, level, with_exit=False):
                                           _p(offsets), int(with_exit), _p(ridx), _p(pidx), _p(depth), _stream()),
                "spc_raytrace_emit")
     return ridx, pidx, depth, offsets
+
+
+def spc_trilinear_coeffs(coords, voxel_points, level):
+    """kaolin coords_to_trilinear_coeffs (codebook_grid.py:164): coords [V,S,3], voxel_points i16 [V,3] -> [V,S,8]."""
+    coords = _need(coords, torch.float32, "coords")
+    voxel_points = _need(voxel_points, torch.int16, "points").reshape(-1, 3)
+    V, S = coords.shape[0], coords.shape[1]
+    out = torch.empty(V, S, 8, dtype=torch.float32, device=coords.device)
+    _check(lib.wisp_spc_trilinear_coeffs(_p(coords), _p(voxel_points), V, S, level, _p(out), _stream()), "spc_trilinear_coeffs")
+    return out
+
+
+def _pidx_arg(pidx):
+    if pidx.dtype not in (torch.int32, torch.int64):
+        raise TypeError(f"pidx must be int32 or int64, got {pidx.dtype}")
+    return _need(pidx, None, "pidx"), int(pidx.dtype == torch.int64)
+
+
+def spc_trilinear_forward(coords, pidx, points, trinkets, feats, level, half_round=False):
+    """kaolin unbatched_interpolate_trilinear (octree_grid.py:147-149): coords [V,S,3] -> f32 [V,S,C]."""
+    coords = _need(coords, torch.float32, "coords")
+    pidx, is64 = _pidx_arg(pidx)
+    points = _need(points, torch.int16, "points")
+    trinkets = _need(trinkets, torch.int32, "trinkets")
+    feats = _need(feats, None, "feats")
+    V, S, C = coords.shape[0], coords.shape[1], feats.shape[1]
+    out = torch.empty(V, S, C, dtype=torch.float32, device=coords.device)
+    _check(lib.wisp_spc_trilinear_fwd(_p(coords), _p(pidx), is64, _p(points), _p(trinkets), _p(feats), _DTYPE_CODE[feats.dtype],
+                                      V, S, C, level, int(half_round), _p(out), _stream()), "spc_trilinear_fwd")
+    return out
+
+
+def spc_trilinear_backward(coords, pidx, points, trinkets, grad_out, feats_shape, level):
+    coords = _need(coords, torch.float32, "coords")
+    pidx, is64 = _pidx_arg(pidx)
+    grad_out = _need(grad_out, torch.float32, "grad_out")
+    V, S, C = coords.shape[0], coords.shape[1], feats_shape[1]
+    grad = torch.zeros(tuple(feats_shape), dtype=torch.float32, device=coords.device)
+    _check(lib.wisp_spc_trilinear_bwd(_p(coords), _p(pidx), is64, _p(points), _p(trinkets), _p(grad_out), V, S, C, level,
+                                      _p(grad), _stream()), "spc_trilinear_bwd")
+    return grad
 
 
 # ------------------------------------------------------------------------------------------------ raymarch

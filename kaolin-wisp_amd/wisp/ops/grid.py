@@ -73,3 +73,33 @@ def hashgrid(coords, codebook_bitwidth, lod_idx, codebook, zero_from_col=None):
                                       codebook.feats, codebook.begin_idxes, zero_from_col)
     feature_dim = codebook.feats.shape[1] * len(codebook.resolutions)
     return feats.reshape(batch, feature_dim)
+
+
+class SPCTrilinear(torch.autograd.Function):
+    """Differentiable (w.r.t. the features) dual-octree trilinear interpolation - the Kaolin-Core leaf
+    unbatched_interpolate_trilinear that OctreeGrid._interpolate calls (wisp/models/grids/octree_grid.py:147-149)."""
+
+    @staticmethod
+    def forward(ctx, coords, pidx, points, trinkets, feats, level, half_round):
+        out = _hip().spc_trilinear_forward(coords.detach(), pidx, points, trinkets, feats.detach(), level, half_round)
+        ctx.save_for_backward(coords.detach(), pidx, points, trinkets)
+        ctx.meta = (tuple(feats.shape), feats.dtype, level)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        coords, pidx, points, trinkets = ctx.saved_tensors
+        shape, dtype, level = ctx.meta
+        grad = _hip().spc_trilinear_backward(coords, pidx, points, trinkets, grad_out.contiguous().float(), shape, level)
+        return None, None, None, None, grad.to(dtype), None, None
+
+
+def spc_interpolate_trilinear(coords, pidx, points, trinkets, feats, level, half_round=False):
+    """coords [V,S,3], pidx [V] (-1 = outside), feats [Fn,C] -> [V,S,C] float32."""
+    return SPCTrilinear.apply(coords.contiguous(), pidx, points, trinkets, feats, level, half_round)
+
+
+def coords_to_trilinear_coeffs(coords, points, level):
+    """coords [V,S,3] + the quantised voxel origin of every row ([V,3] or [V,S,3] repeated) -> [V,S,8]."""
+    pts = points[:, 0] if points.ndim == 3 else points
+    return _hip().spc_trilinear_coeffs(coords.contiguous(), pts.contiguous(), level)

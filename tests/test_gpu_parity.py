@@ -523,3 +523,82 @@ def test_training_psnr_parity_with_oracle():
     base = onerf.psnr(torch.zeros_like(gt), gt)
     assert p_cpu > base + 3.0, (p_cpu, base)          # it actually learned something
     assert abs(p_hip - p_cpu) <= 0.1, (p_hip, p_cpu)
+
+
+# ------------------------------------------------------------------------------------------------ octree / codebook grids
+def _sparse_blas(level, n, seed):
+    from wisp.accelstructs import OctreeAS
+    rng = np.random.default_rng(seed)
+    P = rng.integers(0, 2 ** level, size=(n, 3))
+    blas = OctreeAS.from_quantized_points(torch.from_numpy(P).short().to(DEV), level)
+    oblas = onerf.OracleBLAS(ospc.points_to_octree(P, level))
+    return blas, oblas
+
+
+@pytest.mark.parametrize("mtype,half", [("sum", True), ("cat", True), ("sum", False)])
+def test_octree_grid_interpolate_matches_oracle(mtype, half):
+    from oracle import octree_grid as og
+    from wisp.models.grids import OctreeGrid
+    blas, oblas = _sparse_blas(5, 4000, 101)
+    torch.manual_seed(1)
+    grid = OctreeGrid(blas, feature_dim=16, num_lods=4, multiscale_type=mtype, feature_std=0.5).to(DEV)
+    grid.half_features = half
+    pd, pyd = ospc.make_dual(oblas.points, oblas.pyramid)
+    tr, _ = ospc.make_trinkets(oblas.points, oblas.pyramid, pd, pyd)
+    assert np.array_equal(grid.trinkets.cpu().numpy(), tr) and np.array_equal(grid.pyramid_dual.numpy(), pyd)
+    rng = np.random.default_rng(102)
+    # half the coords inside occupied cells, half anywhere
+    leaf = oblas.level_points().astype(np.float32)
+    inside = (leaf[rng.integers(0, leaf.shape[0], 3000)] + rng.uniform(0, 1, (3000, 3))) / 32.0 * 2 - 1
+    coords = np.concatenate([inside, rng.uniform(-1, 1, (3000, 3))]).astype(np.float32)
+    for lod_idx in (3, 0):
+        out = grid.interpolate(cuda(coords), lod_idx)
+        w = torch.randn_like(out)
+        grid.zero_grad(); (out * w).sum().backward()
+        feats_cpu = [f.detach().cpu().clone().requires_grad_(True) for f in grid.features]
+        ref = og.octree_grid_interpolate(oblas, tr, feats_cpu, torch.from_numpy(coords), lod_idx, grid.base_lod,
+                                         grid.active_lods, mtype, 16, half_round=half)
+        (ref * w.cpu()).sum().backward()
+        tol = 2e-3 if half else 1e-5       # half: results are fp16-rounded, accumulation order may flip the last bit
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=tol * (4 if mtype == "sum" else 1))
+        for i in range(lod_idx + 1):
+            np.testing.assert_allclose(grid.features[i].grad.cpu().numpy(), feats_cpu[i].grad.numpy(), rtol=1e-4, atol=1e-4)
+    # [batch, num_samples, 3] input at the base level, kaolin-style leaf call, coefficient helper
+    import wisp.ops.grid as G
+    c3 = cuda(inside[:64].reshape(16, 4, 3).astype(np.float32))
+    pid = blas.query(c3[:, 0], grid.active_lods[0]).pidx
+    f3 = grid._interpolate(c3, grid.features[0], pid, 0)
+    assert f3.shape == (16, 4, 16)
+    vp = pid.clamp(min=0)
+    co = G.coords_to_trilinear_coeffs(c3, blas.points.index_select(0, vp)[:, None].repeat(1, 4, 1), grid.active_lods[0])
+    want = og.trilinear_coeffs(c3.cpu(), blas.points.index_select(0, vp).cpu()[:, None].long().expand(16, 4, 3), grid.active_lods[0])
+    np.testing.assert_allclose(co.cpu().numpy(), want.numpy(), atol=1e-6)
+    rm = grid.raymarch(__import__("wisp.core", fromlist=["Rays"]).Rays(cuda(make_rays(8, 1)[0]), cuda(make_rays(8, 1)[1]), 0.5, 5.0), 'voxel', 2)
+    assert rm.samples.shape[1] == 3
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_codebook_grid_matches_oracle(training):
+    from oracle import octree_grid as og
+    from wisp.models.grids import CodebookOctreeGrid
+    blas, oblas = _sparse_blas(5, 3000, 111)
+    torch.manual_seed(2)
+    grid = CodebookOctreeGrid(blas, feature_dim=5, num_lods=4, multiscale_type='sum', feature_std=0.7, codebook_bitwidth=4).to(DEV)
+    grid.train(training)
+    pd, pyd = ospc.make_dual(oblas.points, oblas.pyramid)
+    tr, _ = ospc.make_trinkets(oblas.points, oblas.pyramid, pd, pyd)
+    rng = np.random.default_rng(112)
+    leaf = oblas.level_points().astype(np.float32)
+    coords = ((leaf[rng.integers(0, leaf.shape[0], 2000)] + rng.uniform(0, 1, (2000, 3))) / 32.0 * 2 - 1).astype(np.float32)
+    coords[:50] = rng.uniform(-1, 1, (50, 3))
+    out = grid.interpolate(cuda(coords), 3)
+    feats_cpu = [f.detach().cpu().clone().requires_grad_(True) for f in grid.features]
+    dict_cpu = [d.detach().cpu().clone().requires_grad_(True) for d in grid.dictionary]
+    ref = og.codebook_grid_interpolate(oblas, tr, feats_cpu, dict_cpu, torch.from_numpy(coords), 3, grid.active_lods, 'sum', 5, training)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=1e-5)
+    if training:
+        w = torch.randn_like(out)
+        (out * w).sum().backward(); (ref * w.cpu()).sum().backward()
+        for i in range(4):
+            np.testing.assert_allclose(grid.features[i].grad.cpu().numpy(), feats_cpu[i].grad.numpy(), rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(grid.dictionary[i].grad.cpu().numpy(), dict_cpu[i].grad.numpy(), rtol=1e-4, atol=1e-4)

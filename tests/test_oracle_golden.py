@@ -161,3 +161,30 @@ def test_composite_matches_python_loop_float64():
         np.testing.assert_allclose(out["alpha"][r].item(), A, atol=1e-12)
         np.testing.assert_allclose(out["depth"][r].item(), D, atol=1e-12)
         assert bool(out["hit"][r]) == (A > 0)
+
+
+def test_octree_grid_oracle_properties():
+    """Trilinear coefficients are a partition of unity; sampling exactly at a voxel corner returns that corner's
+    feature; samples outside the tree give zeros; trinkets index the per-level dual block."""
+    from oracle import octree_grid as og
+    rng = np.random.default_rng(3)
+    P = rng.integers(0, 8, size=(60, 3))
+    oc = spc.points_to_octree(P, 3)
+    pts, pyr, ex = spc.octree_to_spc(oc)
+    pd, pyd = spc.make_dual(pts, pyr)
+    tr, par = spc.make_trinkets(pts, pyr, pd, pyd)
+    level = 3
+    feats = torch.randn(int(pyd[0, level]) + 1, 4)
+    leaf = pts[pyr[1, level]:pyr[1, level] + pyr[0, level]]
+    x = torch.from_numpy(rng.uniform(-1, 1, (500, 3)).astype(np.float32))
+    pidx = torch.from_numpy(spc.query(oc, ex, x.numpy(), level))
+    w = og.trilinear_coeffs(x, torch.from_numpy(pts)[pidx.clamp(min=0)].long(), level)
+    assert torch.allclose(w.sum(-1)[pidx >= 0], torch.ones(int((pidx >= 0).sum())), atol=1e-5)
+    out = og.interpolate_trilinear(x[:, None], pidx, pts, tr, feats, level)
+    assert float(out[pidx < 0].abs().max()) == 0.0 and (pidx < 0).any()
+    # exactly at the min corner of a voxel: coefficient 0 is 1 -> corner feature 0 of that voxel
+    k = 7
+    c = torch.from_numpy((leaf[k].astype(np.float32) / 8.0) * 2 - 1)[None, None]
+    got = og.interpolate_trilinear(c, torch.tensor([pyr[1, level] + k]), pts, tr, feats, level)
+    assert torch.allclose(got[0, 0], feats[tr[pyr[1, level] + k, 0]], atol=1e-6)
+    assert tr.max() <= pyd[0, 1:].max() and par[0] == -1
