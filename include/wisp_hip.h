@@ -213,6 +213,12 @@ int wisp_composite_bwd(const float* grad_rgb /* [R,3] */, const float* grad_alph
                        float* grad_color /* [S,3] */, float* grad_density /* [S] */,
                        wisp_stream_t stream);
 
+/* Sphere-tracing helper (replaces wisp._C.render.find_depth_bound_cuda, wisp/csrc/render/find_depth_bound.cpp:23-36,
+ * kernel find_depth_bound_cuda.cu:16-45): out[i] = first nugget index >= curr_idxes[i] whose [entry, exit] contains or
+ * lies beyond query[i], or -1.  nug_depth f32 [M,2]. */
+int wisp_find_depth_bound(const float* query /* [P] */, const int32_t* curr_idxes /* [P] */, const float* nug_depth,
+                          int64_t num_packs, int64_t num_nugs, int32_t* out /* [P] */, wisp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused radiance-field decoder  (replaces NeuralRadianceField.rgba after grid.interpolate,
  * wisp/models/nefs/nerf.py:245-264: decoder_density (Linear-ReLU-Linear) -> relu density + 15 geometry

@@ -239,3 +239,40 @@ extern "C" int wisp_composite_bwd(const float* grad_rgb, const float* grad_alpha
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- sphere-tracing helper
+// find_depth_bound (wisp/csrc/render/find_depth_bound_cuda.cu:16-45): for every ray (pack) advance its current nugget
+// index to the first nugget whose [entry, exit] contains, or lies beyond, the query depth; -1 when there is none.
+// Bug-compatible with the reference on purpose: the search of pack i is bounded by the CURRENT index of pack i+1
+// (not that pack's first nugget), and the last pack is bounded by num_packs rather than num_nugs (.cu:29).
+__global__ void __launch_bounds__(256)
+find_depth_bound_kernel(int64_t num_packs, int64_t num_nugs, const float* __restrict__ query,
+                        const int32_t* __restrict__ curr_in, int32_t* __restrict__ curr_out,
+                        const float* __restrict__ depth) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= num_packs) return;
+    int32_t result = -1;
+    const int32_t start = curr_in[t];
+    if (start > -1) {
+        uint32_t i = (uint32_t)start;
+        const uint32_t stop = (t == num_packs - 1) ? (uint32_t)num_packs : (uint32_t)curr_in[t + 1];
+        const float q = query[t];
+        while (i < stop) {
+            const float entry = depth[2 * (int64_t)i], exit_ = depth[2 * (int64_t)i + 1];
+            if ((q >= entry && q <= exit_) || q < entry) { result = (int32_t)i; break; }
+            ++i;
+        }
+    }
+    curr_out[t] = result;
+}
+
+extern "C" int wisp_find_depth_bound(const float* query, const int32_t* curr_idxes, const float* nug_depth,
+                                     int64_t num_packs, int64_t num_nugs, int32_t* out, wisp_stream_t stream) {
+    WISP_REQUIRE(num_packs >= 0 && num_nugs >= 0, "bad sizes");
+    if (num_packs == 0) return WISP_OK;
+    WISP_REQUIRE(query && curr_idxes && nug_depth && out, "null pointer");
+    hipLaunchKernelGGL(find_depth_bound_kernel, dim3((unsigned)ceil_div64(num_packs, 256)), dim3(256), 0, (hipStream_t)stream,
+                       num_packs, num_nugs, query, curr_idxes, out, nug_depth);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

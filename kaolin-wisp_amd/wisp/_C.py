@@ -54,6 +54,7 @@ SIGNATURES = {
     "wisp_raymarch_uniform_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_packed_sum_reduce": [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
     "wisp_packed_cumsum": [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
+    "wisp_find_depth_bound": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp],
     "wisp_composite_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_composite_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_nerf_mlp_param_count": [c_i32, c_i32, c_i32],
@@ -453,6 +454,18 @@ def composite_bwd(grad_rgb, grad_alpha, grad_depth, color, density, deltas, dept
                                   _p(depths), _p(ridx), _p(starts), starts.shape[0], S, bg_ptr, _p(g_color),
                                   _p(g_density), _stream()), "composite_bwd")
     return g_color, g_density
+
+
+def find_depth_bound(query, curr_idxes, nug_depth):
+    """wisp._C.render.find_depth_bound_cuda (find_depth_bound.cpp:23-36): int32 [P]."""
+    query = _need(query, torch.float32, "query")
+    curr_idxes = _need(curr_idxes, torch.int32, "curr_idxes")
+    nug_depth = _need(nug_depth, torch.float32, "nug_depth")
+    P = query.shape[0]
+    out = torch.empty(P, dtype=torch.int32, device=query.device)
+    _check(lib.wisp_find_depth_bound(_p(query), _p(curr_idxes), _p(nug_depth), P, nug_depth.shape[0], _p(out), _stream()),
+           "find_depth_bound")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ optimizer

@@ -1,2 +1,3 @@
 from .base_nef import *
 from .nerf import *
+from .neural_sdf import *

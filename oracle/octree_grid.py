@@ -36,9 +36,10 @@ def interpolate_trilinear(coords, pidx, points, trinkets, feats, level, half_rou
     for j in range(8):                                                                    # corner order accumulation
         term = corner[:, None, j, :] * w[..., j:j + 1]
         acc = term if acc is None else acc + term
+    acc = torch.where(valid[:, None, None], acc, torch.zeros_like(acc))     # pidx == -1 -> exact zeros
     if half_round:
         acc = _ste_half(acc)
-    return acc * valid[:, None, None].float()
+    return acc
 
 
 class _HalfRound(torch.autograd.Function):

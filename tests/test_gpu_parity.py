@@ -562,7 +562,9 @@ def test_octree_grid_interpolate_matches_oracle(mtype, half):
         tol = 2e-3 if half else 1e-5       # half: results are fp16-rounded, accumulation order may flip the last bit
         np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=tol * (4 if mtype == "sum" else 1))
         for i in range(lod_idx + 1):
-            np.testing.assert_allclose(grid.features[i].grad.cpu().numpy(), feats_cpu[i].grad.numpy(), rtol=1e-4, atol=1e-4)
+            # reference-style half path: autograd through feats.half() rounds the gradient to fp16; the kernel keeps fp32
+            gt = dict(rtol=2e-3, atol=2e-3) if half else dict(rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(grid.features[i].grad.cpu().numpy(), feats_cpu[i].grad.numpy(), **gt)
     # [batch, num_samples, 3] input at the base level, kaolin-style leaf call, coefficient helper
     import wisp.ops.grid as G
     c3 = cuda(inside[:64].reshape(16, 4, 3).astype(np.float32))
@@ -602,3 +604,72 @@ def test_codebook_grid_matches_oracle(training):
         for i in range(4):
             np.testing.assert_allclose(grid.features[i].grad.cpu().numpy(), feats_cpu[i].grad.numpy(), rtol=1e-4, atol=1e-5)
             np.testing.assert_allclose(grid.dictionary[i].grad.cpu().numpy(), dict_cpu[i].grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ SDF path (NGLOD)
+def test_find_depth_bound_bit_exact():
+    from oracle import sdf as osdf
+    rng = np.random.default_rng(121)
+    P = 500
+    counts = rng.integers(1, 9, P)
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int32)
+    M = int(counts.sum())
+    entry = np.concatenate([np.sort(rng.uniform(0.5, 4.0, c)) for c in counts]).astype(np.float32)
+    depth = np.stack([entry, entry + rng.uniform(0.01, 0.2, M).astype(np.float32)], 1)
+    cur = (starts + rng.integers(0, 2, P).astype(np.int32) * (counts > 1)).astype(np.int32)
+    cur[rng.integers(0, P, 20)] = -1
+    q = rng.uniform(0.3, 4.5, P).astype(np.float32)
+    want = osdf.find_depth_bound(q, cur, depth)
+    got = _C().find_depth_bound(cuda(q), cuda(cur), cuda(depth))
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_neural_sdf_and_sdf_tracer_match_oracle():
+    from oracle import octree_grid as og, sdf as osdf
+    from wisp.core import Rays
+    from wisp.models.grids import OctreeGrid
+    from wisp.models.nefs import NeuralSDF
+    from wisp.tracers import PackedSDFTracer
+    # shell of occupied cells around a sphere of radius 0.55 at level 5
+    level = 5
+    idx = np.stack(np.meshgrid(*[np.arange(32)] * 3, indexing='ij'), -1).reshape(-1, 3)
+    ctr = (idx + 0.5) / 16 - 1
+    P = idx[np.abs(np.linalg.norm(ctr, axis=1) - 0.55) < 0.12]
+    from wisp.accelstructs import OctreeAS
+    blas = OctreeAS.from_quantized_points(torch.from_numpy(P).short().to(DEV), level)
+    oblas = onerf.OracleBLAS(ospc.points_to_octree(P, level))
+    torch.manual_seed(3)
+    grid = OctreeGrid(blas, feature_dim=16, num_lods=3, multiscale_type='sum', feature_std=0.05).to(DEV)
+    nef = NeuralSDF(grid, pos_embedder='none', position_input=True, hidden_dim=128, num_layers=1).to(DEV)
+    # --- field parity (C3 shape: 16 feats + 3 pos -> 128 -> 1) incl. gradients
+    pd, pyd = ospc.make_dual(oblas.points, oblas.pyramid); tr, _ = ospc.make_trinkets(oblas.points, oblas.pyramid, pd, pyd)
+    rng = np.random.default_rng(122)
+    c = ctr[np.abs(np.linalg.norm(ctr, axis=1) - 0.55) < 0.12][rng.integers(0, P.shape[0], 512)].astype(np.float32)
+    pred = nef(coords=cuda(c), lod_idx=2, channels="sdf")
+    feats_cpu = [f.detach().cpu().clone().requires_grad_(True) for f in grid.features]
+    dec = onerf.OracleDecoder(19, 1, 128, 1, True)
+    dec.load_state_dict({k: v.detach().cpu() for k, v in nef.decoder.state_dict().items()})
+    f = og.octree_grid_interpolate(oblas, tr, feats_cpu, torch.from_numpy(c), 2, grid.base_lod, grid.active_lods, 'sum', 16, True)
+    want = dec(torch.cat([torch.from_numpy(c), f], -1))
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), want.detach().numpy(), atol=2e-4)
+    gt = torch.from_numpy(rng.normal(size=(512, 1)).astype(np.float32))
+    ((pred - gt.to(DEV)) ** 2).sum().backward(); ((want - gt) ** 2).sum().backward()
+    for p1, p2 in zip(nef.decoder.parameters(), dec.parameters()):
+        np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.numpy(), rtol=2e-3, atol=2e-3)
+    # --- tracer parity on an analytic field (sphere r = 0.55) so both sides evaluate the same SDF
+    def sdf_cpu(x):
+        return x.norm(dim=-1, keepdim=True) - 0.55
+
+    class Analytic(NeuralSDF):
+        def sdf(self, coords, lod_idx=None):
+            return dict(sdf=coords.norm(dim=-1, keepdim=True) - 0.55)
+    anef = Analytic(grid, pos_embedder='none', position_input=True, hidden_dim=8).to(DEV)
+    o, d = make_rays(400, 123, radius=2.5, spread=0.8)
+    tracer = PackedSDFTracer(num_steps=48, step_size=0.8, min_dis=0.0003)
+    rb = tracer(anef, rays=Rays(cuda(o), cuda(d), dist_min=0.0, dist_max=6.0), channels=["depth", "hit", "normal", "rgb"], lod_idx=2)
+    want = osdf.sphere_trace(sdf_cpu, oblas, torch.from_numpy(o), torch.from_numpy(d), 6.0, grid.active_lods[2], 48, 0.8, 0.0003)
+    assert torch.equal(rb.hit.cpu(), want["hit"]) and int(want["hit"].sum()) > 50
+    np.testing.assert_allclose(rb.depth.cpu().numpy(), want["depth"].numpy(), atol=1e-5)
+    np.testing.assert_allclose(rb.xyz.cpu().numpy(), want["xyz"].numpy(), atol=1e-5)
+    np.testing.assert_allclose(rb.normal.cpu().numpy(), want["normal"].numpy(), atol=1e-4)
+    np.testing.assert_allclose(rb.alpha.cpu().numpy(), want["alpha"].numpy())
