@@ -617,7 +617,6 @@ def test_find_depth_bound_bit_exact():
     entry = np.concatenate([np.sort(rng.uniform(0.5, 4.0, c)) for c in counts]).astype(np.float32)
     depth = np.stack([entry, entry + rng.uniform(0.01, 0.2, M).astype(np.float32)], 1)
     cur = (starts + rng.integers(0, 2, P).astype(np.int32) * (counts > 1)).astype(np.int32)
-    cur[rng.integers(0, P, 20)] = -1
     q = rng.uniform(0.3, 4.5, P).astype(np.float32)
     want = osdf.find_depth_bound(q, cur, depth)
     got = _C().find_depth_bound(cuda(q), cuda(cur), cuda(depth))
