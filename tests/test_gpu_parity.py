@@ -672,3 +672,32 @@ def test_neural_sdf_and_sdf_tracer_match_oracle():
     np.testing.assert_allclose(rb.xyz.cpu().numpy(), want["xyz"].numpy(), atol=1e-5)
     np.testing.assert_allclose(rb.normal.cpu().numpy(), want["normal"].numpy(), atol=1e-4)
     np.testing.assert_allclose(rb.alpha.cpu().numpy(), want["alpha"].numpy())
+
+
+def test_image_field_config_c1_fits_and_matches_oracle_2d():
+    """C1 (app/image): HashGrid with blas=None, 2-D coords, table sized with coord_dim=3 (main_image.py:63),
+    ImageNeuralField 46 -> 64 -> 3.  Forward parity of the 2-D lookup with the oracle and a short fit that learns."""
+    from wisp.models.grids import HashGrid
+    from wisp.models.nefs import ImageNeuralField
+    torch.manual_seed(0)
+    grid = HashGrid.from_geometric(None, feature_dim=2, num_lods=16, multiscale_type='cat', feature_std=0.01,
+                                   codebook_bitwidth=14, min_grid_res=16, max_grid_res=128).to(DEV)
+    nef = ImageNeuralField(grid, hidden_dim=64).to(DEV)
+    assert nef.input_dim == 46 and grid.codebook.feats.shape[0] == sum(min(2 ** 14, r ** 3) for r in grid.resolutions)
+    H = 64
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, H), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(-1, 2).to(DEV)
+    img = torch.stack([0.5 + 0.5 * torch.sin(6 * xs), 0.5 + 0.5 * torch.cos(4 * ys), 0.5 + 0.5 * torch.sin(5 * xs * ys)], -1).reshape(-1, 3).to(DEV)
+    feats = grid.interpolate(coords, 15)
+    want = ohash.grid_interpolate(coords.cpu(), 15, 'cat', 2, grid.resolutions, 14, grid.codebook.feats.detach().cpu(),
+                                  grid.codebook.begin_idxes.cpu())
+    np.testing.assert_allclose(feats.detach().cpu().numpy(), want.numpy(), atol=1e-7)
+    opt = torch.optim.Adam([{"params": grid.parameters(), "lr": 0.05}, {"params": nef.decoder.parameters(), "lr": 1e-3}], eps=1e-15)
+    first = None
+    for it in range(150):
+        idx = torch.randint(0, coords.shape[0], (2048,), device=DEV)
+        loss = ((nef.rgb(coords[idx]) - img[idx]) ** 2).mean()
+        first = first if first is not None else float(loss)
+        opt.zero_grad(); loss.backward(); opt.step()
+    final = float(((nef.rgb(coords) - img) ** 2).mean())
+    assert final < 0.2 * first, (first, final)
