@@ -166,6 +166,7 @@ struct LevelList { int32_t n; int32_t lv[HG_MAX_LODS]; };
 struct BinLevels {
     int32_t chunks[HG_MAX_LODS]; uint32_t cap[HG_MAX_LODS]; int32_t cur_base[HG_MAX_LODS]; int64_t rec_base[HG_MAX_LODS];
     uint32_t entries[HG_MAX_LODS]; int32_t splits[HG_MAX_LODS];
+    int32_t blk_base[HG_MAX_LODS + 1];      // reduce kernel: first workgroup of every level in the flattened 1-D grid
 };
 
 template <typename T, int F, int DIM, bool MERGE>
@@ -203,19 +204,28 @@ static __device__ __forceinline__ bool tail_compute(const float* c, bool live, i
     }
     const int32_t prevk = __shfl_up(key, 1, 64);
     int f = (lane == 0 || key != prevk) ? 1 : 0;          // run-head flag
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int fp = __shfl_up(f, d, 64);
-        const bool take = (lane >= d) && !f;
-#pragma unroll
-        for (int j = 0; j < (1 << DIM); ++j)
-#pragma unroll
-            for (int k = 0; k < F; ++k) {
-                const float vp = __shfl_up(v[j][k], d, 64);
-                if (take) v[j][k] += vp;
-            }
-        if (take) f |= fp;
+    // Segmented inclusive scan on the VALU (DPP), no LDS traffic: four row_shr steps inside each 16-lane row, then the
+    // row totals are carried across rows with row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3).  (v, f) pairs
+    // combine as (v1,f1)+(v2,f2) = (f2 ? v2 : v1+v2, f1|f2), which is associative, so the row carries compose.
+#define HG_SEG_STEP(CTRL, RMASK, VALID)                                                                   \
+    {                                                                                                      \
+        const int fp = __builtin_amdgcn_update_dpp(1, f, CTRL, RMASK, 0xf, false);                         \
+        const bool take = (VALID) && !f;                                                                   \
+        _Pragma("unroll") for (int j = 0; j < (1 << DIM); ++j)                                             \
+            _Pragma("unroll") for (int k = 0; k < F; ++k) {                                                \
+                const float vp = __builtin_bit_cast(                                                       \
+                    float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[j][k]), CTRL, RMASK, 0xf, false)); \
+                if (take) v[j][k] += vp;                                                                   \
+            }                                                                                              \
+        if (take) f |= fp;                                                                                 \
     }
+    HG_SEG_STEP(0x111, 0xf, (lane & 15) >= 1)             // row_shr:1
+    HG_SEG_STEP(0x112, 0xf, (lane & 15) >= 2)             // row_shr:2
+    HG_SEG_STEP(0x114, 0xf, (lane & 15) >= 4)             // row_shr:4
+    HG_SEG_STEP(0x118, 0xf, (lane & 15) >= 8)             // row_shr:8
+    HG_SEG_STEP(0x142, 0xa, (lane >> 4) & 1)              // row_bcast:15 -> rows 1 and 3
+    HG_SEG_STEP(0x143, 0xc, lane >= 32)                   // row_bcast:31 -> rows 2 and 3
+#undef HG_SEG_STEP
     const int32_t nextk = __shfl_down(key, 1, 64);
     return live && (lane == 63 || key != nextk);          // run tail holds the run total
 }
@@ -349,9 +359,12 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
                            float* __restrict__ grad_codebook) {
     constexpr int RW = 1 + F;
     extern __shared__ __attribute__((aligned(16))) float rd_acc[];      // [chunk entries * F]
-    const int b = blockIdx.x, li = blockIdx.y, z = blockIdx.z;
+    // flattened (level, chunk, split) grid: only workgroups that have work are launched
+    int li = 0;
+    while (li + 1 < levels.n && (int)blockIdx.x >= bins.blk_base[li + 1]) ++li;
     const int splits = bins.splits[li];
-    if (b >= bins.chunks[li] || z >= splits) return;
+    const int local = (int)blockIdx.x - bins.blk_base[li];
+    const int b = local / splits, z = local - b * splits;
     const int l = levels.lv[li];
     const uint32_t csize = 1u << chunk_shift;
     const uint32_t cap = bins.cap[li];
@@ -430,7 +443,7 @@ static bool bwd_merge_enabled() { static const bool v = env_flag("WISP_HG_BWD_ME
 static bool bwd_bin_enabled() { static const bool v = env_flag("WISP_HG_BWD_BIN", true); return v; }
 
 // bin geometry shared by the workspace query and the launcher
-struct BinPlan { int chunk_shift, max_chunks, max_splits; BinLevels bins; int64_t cursor_bytes, record_bytes; bool ok; };
+struct BinPlan { int chunk_shift, max_chunks, max_splits, total_blocks; BinLevels bins; int64_t cursor_bytes, record_bytes; bool ok; };
 static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels, int feature_dim, int64_t tsize, int dim) {
     BinPlan p{};
     const int corners = 1 << dim;
@@ -456,9 +469,12 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         p.bins.splits[li] = splits < 1 ? 1 : splits;
         if (chunks > p.max_chunks) p.max_chunks = (int)chunks;
         if (p.bins.splits[li] > p.max_splits) p.max_splits = p.bins.splits[li];
+        p.bins.blk_base[li] = p.total_blocks;
+        p.total_blocks += (int)chunks * p.bins.splits[li];
         cur += chunks;
         rec += chunks * cap;
     }
+    p.bins.blk_base[levels.n] = p.total_blocks;
     p.cursor_bytes = (cur * 4 + 255) / 256 * 256;
     p.record_bytes = rec * (1 + feature_dim) * 4;
     return p;
@@ -505,7 +521,7 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 4;
     auto rd = hashgrid_bwd_reduce_kernel<F>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
-    hipLaunchKernelGGL(rd, dim3(plan.max_chunks, active.n, plan.max_splits), dim3(RD_THREADS), rd_lds, s, first_idx, active,
+    hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active,
                        plan.chunk_shift, plan.bins, cursors, records, grad_codebook);
     return 0;
 }
