@@ -273,7 +273,10 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #define RD_THREADS 1024
 #define BIN_MAX_CHUNKS 1024
 
-// record = { index within the level table, F gradient values }, (1 + F) dwords
+// record = { index within the level table, F gradient values }, (1 + F) dwords.
+// A workgroup handles EM_TILE samples of one level.  The run tails stay in registers across the two phases
+// (count per bucket -> one reservation per non-empty bucket -> scatter), so the only LDS use is 2 x chunks counters and
+// occupancy is bounded by registers, not by a staging buffer.
 template <typename T, int F, int DIM>
 __global__ void __launch_bounds__(EM_THREADS)
 hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ grad_feats,
@@ -282,52 +285,39 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
                          uint32_t* __restrict__ cursors, uint32_t* __restrict__ records, float* __restrict__ grad_codebook) {
     constexpr int NC = 1 << DIM;
     constexpr int RW = 1 + F;
+    constexpr int GROUPS = EM_TILE / EM_THREADS;         // 64-sample groups per wave
     extern __shared__ __attribute__((aligned(16))) uint32_t em_smem[];
-    uint32_t* s_hist = em_smem;                          // [chunks]   records of this tile per bucket
-    uint32_t* s_base = em_smem + BIN_MAX_CHUNKS;         // [chunks]   reserved global offset per bucket
-    uint32_t* s_stage = em_smem + 2 * BIN_MAX_CHUNKS;    // [EM_TILE * NC][RW]
-    __shared__ uint32_t s_count;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
     const int li = blockIdx.y;
     const int l = levels.lv[li];
+    const int chunks = bins.chunks[li];
+    uint32_t* s_hist = em_smem;                          // [chunks] records of this tile per bucket, then running rank
+    uint32_t* s_base = em_smem + chunks;                 // [chunks] reserved global offset per bucket
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int32_t res = lv.res[l];
     const bool dense = lv.dense[l] != 0;
-    const int chunks = bins.chunks[li];
     const uint32_t cap = bins.cap[li];
     for (int b = threadIdx.x; b < chunks; b += EM_THREADS) s_hist[b] = 0;
-    if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
     const int64_t tile0 = (int64_t)blockIdx.x * EM_TILE;
-    for (int grp = wave; grp < EM_TILE / 64; grp += EM_THREADS / 64) {
-        const int64_t i = tile0 + grp * 64 + lane;
+    CornerSetup<DIM> cs[GROUPS];
+    float v[GROUPS][NC][F];
+    bool issue[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+        const int64_t i = tile0 + (int64_t)(wave * GROUPS + g) * 64 + lane;
         const bool live = i < n;
         float c[DIM];
 #pragma unroll
         for (int a = 0; a < DIM; ++a) c[a] = live ? coords[i * DIM + a] : 0.0f;
-        CornerSetup<DIM> cs;
-        float v[NC][F];
-        const bool issue = tail_compute<T, F, DIM, true>(c, live, i, l, num_lods, res, dense, tsize, tsize_pow2 != 0,
-                                                         zero_from_col, grad_feats, lane, cs, v);
-        const unsigned long long m = __ballot(issue);
-        if (m == 0ull) continue;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&s_count, (uint32_t)__popcll(m) * NC);
-        base = __shfl(base, 0, 64);
-        if (issue) {
-            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) * NC;
+        issue[g] = tail_compute<T, F, DIM, true>(c, live, i, l, num_lods, res, dense, tsize, tsize_pow2 != 0, zero_from_col,
+                                                 grad_feats, lane, cs[g], v[g]);
+        if (issue[g]) {
 #pragma unroll
-            for (int j = 0; j < NC; ++j) {
-                uint32_t* r = s_stage + (slot + j) * RW;
-                r[0] = (uint32_t)cs.idx[j];
-#pragma unroll
-                for (int k = 0; k < F; ++k) r[1 + k] = __float_as_uint(v[j][k]);
-                atomicAdd(&s_hist[(uint32_t)cs.idx[j] >> chunk_shift], 1u);
-            }
+            for (int j = 0; j < NC; ++j) atomicAdd(&s_hist[(uint32_t)cs[g].idx[j] >> chunk_shift], 1u);
         }
     }
     __syncthreads();
-    const uint32_t total = s_count;
     uint32_t* cur = cursors + bins.cur_base[li];
     for (int b = threadIdx.x; b < chunks; b += EM_THREADS) {
         const uint32_t h = s_hist[b];
@@ -335,19 +325,25 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
         s_hist[b] = 0;                                    // reused as the running rank inside the reservation
     }
     __syncthreads();
-    for (uint32_t r = threadIdx.x; r < total; r += EM_THREADS) {
-        const uint32_t* rec = s_stage + r * RW;
-        const uint32_t idx = rec[0];
-        const uint32_t b = idx >> chunk_shift;
-        const uint32_t pos = s_base[b] + atomicAdd(&s_hist[b], 1u);
-        if (pos < cap) {
-            uint32_t* dst = records + ((size_t)bins.rec_base[li] + (size_t)b * cap + pos) * RW;
+    uint32_t* __restrict__ rec_l = records + (size_t)bins.rec_base[li] * RW;
 #pragma unroll
-            for (int w = 0; w < RW; ++w) dst[w] = rec[w];
-        } else {                                          // bucket full: fall back to the memory-side atomic
-            float* p = grad_codebook + (first_idx[l] + (int64_t)idx) * F;
+    for (int g = 0; g < GROUPS; ++g) {
+        if (!issue[g]) continue;
 #pragma unroll
-            for (int k = 0; k < F; ++k) atomicAdd(p + k, __uint_as_float(rec[1 + k]));
+        for (int j = 0; j < NC; ++j) {
+            const uint32_t idx = (uint32_t)cs[g].idx[j];
+            const uint32_t b = idx >> chunk_shift;
+            const uint32_t pos = s_base[b] + atomicAdd(&s_hist[b], 1u);
+            if (pos < cap) {
+                uint32_t* dst = rec_l + ((size_t)b * cap + pos) * RW;
+                dst[0] = idx;
+#pragma unroll
+                for (int k = 0; k < F; ++k) dst[1 + k] = __float_as_uint(v[g][j][k]);
+            } else {                                      // bucket full: fall back to the memory-side atomic
+                float* p = grad_codebook + (first_idx[l] + (int64_t)idx) * F;
+#pragma unroll
+                for (int k = 0; k < F; ++k) atomicAdd(p + k, v[g][j][k]);
+            }
         }
     }
 }
@@ -377,11 +373,25 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
     for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) rd_acc[e] = 0.0f;
     __syncthreads();
     const uint32_t* src = records + ((size_t)bins.rec_base[li] + (size_t)b * cap) * RW;
-    for (uint32_t r = z + threadIdx.x * splits; r < cnt; r += RD_THREADS * splits) {
-        const uint32_t* rec = src + (size_t)r * RW;
-        const uint32_t e = rec[0] - first;
+    // 4 independent record loads in flight per thread before the LDS adds (the loop is latency-, not bandwidth-bound)
+    const uint32_t step = RD_THREADS * splits;
+    for (uint32_t r0 = z + threadIdx.x * splits; r0 < cnt; r0 += 4 * step) {
+        uint32_t w[4][RW];
 #pragma unroll
-        for (int k = 0; k < F; ++k) atomicAdd(&rd_acc[e * F + k], __uint_as_float(rec[1 + k]));     // ds_add_f32
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t r = r0 + u * step;
+            const uint32_t* rec = src + (size_t)(r < cnt ? r : r0) * RW;
+#pragma unroll
+            for (int q = 0; q < RW; ++q) w[u][q] = rec[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r0 + u * step < cnt) {
+                const uint32_t e = w[u][0] - first;
+#pragma unroll
+                for (int k = 0; k < F; ++k) atomicAdd(&rd_acc[e * F + k], __uint_as_float(w[u][1 + k]));     // ds_add_f32
+            }
+        }
     }
     __syncthreads();
     float* __restrict__ dst = grad_codebook + (first_idx[l] + (int64_t)first) * F;
@@ -465,7 +475,7 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         p.bins.cur_base[li] = (int32_t)cur;
         p.bins.rec_base[li] = rec;
         p.bins.entries[li] = (uint32_t)entries;
-        int splits = (int)(64 / chunks);                      // ~64 reduce workgroups per level
+        int splits = (int)(8 / chunks);                       // >= 8 reduce workgroups per level; split slices are flushed with atomics
         p.bins.splits[li] = splits < 1 ? 1 : splits;
         if (chunks > p.max_chunks) p.max_chunks = (int)chunks;
         if (p.bins.splits[li] > p.max_splits) p.max_splits = p.bins.splits[li];
@@ -512,7 +522,7 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     uint32_t* cursors = (uint32_t*)workspace;
     uint32_t* records = (uint32_t*)((char*)workspace + plan.cursor_bytes);
     if (hipMemsetAsync(cursors, 0, plan.cursor_bytes, s) != hipSuccess) return -1;
-    const size_t em_lds = (size_t)(2 * BIN_MAX_CHUNKS + EM_TILE * (1 << DIM) * (1 + F)) * 4;
+    const size_t em_lds = (size_t)(2 * plan.max_chunks) * 4;
     auto em = hashgrid_bwd_emit_kernel<T, F, DIM>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)em_lds);
     hipLaunchKernelGGL(em, dim3((unsigned)ceil_div64(n, EM_TILE), active.n), dim3(EM_THREADS), em_lds, s, coords, n,
