@@ -348,13 +348,35 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
     }
 }
 
-template <int F>
+// Accumulator flavours of the reduce kernel.  LDS *float* atomics (ds_add_f32) turned out to retire roughly one lane per
+// ~3 clocks per CU on gfx950 (measured: 67 M lane-adds -> 0.6 ms), i.e. they are the reduce kernel's bottleneck.
+// Integer LDS atomics do not have that problem, so the default accumulates in 64-bit fixed point (2^-44 resolution,
+// +-5e5 range): exact, order-independent (bitwise reproducible gradients) and converted to fp32 once per table entry.
+struct AccF32 {
+    typedef float type;
+    static __device__ __forceinline__ void add(float* acc, uint32_t i, float v) { atomicAdd(acc + i, v); }   // ds_add_f32
+    static __device__ __forceinline__ float get(const float* acc, uint32_t i) { return acc[i]; }
+};
+struct AccFix64 {
+    typedef unsigned long long type;
+    static __device__ __forceinline__ void add(type* acc, uint32_t i, float v) {
+        const long long q = (long long)((double)v * 17592186044416.0);                                      // 2^44
+        atomicAdd(acc + i, (unsigned long long)q);                                                           // ds_add_u64
+    }
+    static __device__ __forceinline__ float get(const type* acc, uint32_t i) {
+        return (float)((double)(long long)acc[i] * (1.0 / 17592186044416.0));
+    }
+};
+
+template <int F, typename ACC>
 __global__ void __launch_bounds__(RD_THREADS)
 hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList levels, int chunk_shift, BinLevels bins,
                            const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ records,
-                           float* __restrict__ grad_codebook) {
+                           float* __restrict__ grad_codebook, int dbg) {
     constexpr int RW = 1 + F;
-    extern __shared__ __attribute__((aligned(16))) float rd_acc[];      // [chunk entries * F]
+    typedef typename ACC::type acc_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char rd_smem[];
+    acc_t* rd_acc = reinterpret_cast<acc_t*>(rd_smem);                  // [chunk entries * F]
     // flattened (level, chunk, split) grid: only workgroups that have work are launched
     int li = 0;
     while (li + 1 < levels.n && (int)blockIdx.x >= bins.blk_base[li + 1]) ++li;
@@ -370,10 +392,10 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
     const uint32_t first = (uint32_t)b << chunk_shift;
     const uint32_t entries = bins.entries[li];
     const uint32_t lim = (entries > first ? min(entries - first, csize) : 0u) * F;
-    for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) rd_acc[e] = 0.0f;
+    for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) rd_acc[e] = (acc_t)0;
     __syncthreads();
     const uint32_t* src = records + ((size_t)bins.rec_base[li] + (size_t)b * cap) * RW;
-    // 4 independent record loads in flight per thread before the LDS adds (the loop is latency-, not bandwidth-bound)
+    // 4 independent record loads in flight per thread before the LDS adds
     const uint32_t step = RD_THREADS * splits;
     for (uint32_t r0 = z + threadIdx.x * splits; r0 < cnt; r0 += 4 * step) {
         uint32_t w[4][RW];
@@ -386,23 +408,24 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (r0 + u * step < cnt) {
+            if (r0 + u * step < cnt && !(dbg & 1)) {
                 const uint32_t e = w[u][0] - first;
 #pragma unroll
-                for (int k = 0; k < F; ++k) atomicAdd(&rd_acc[e * F + k], __uint_as_float(w[u][1 + k]));     // ds_add_f32
+                for (int k = 0; k < F; ++k) ACC::add(rd_acc, e * F + k, __uint_as_float(w[u][1 + k]));
             }
         }
     }
     __syncthreads();
     float* __restrict__ dst = grad_codebook + (first_idx[l] + (int64_t)first) * F;
+    if (dbg & 2) return;
     if (splits == 1) {
         for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
-            const float a = rd_acc[e];
+            const float a = ACC::get(rd_acc, e);
             if (a != 0.0f) dst[e] += a;                   // this workgroup owns the slice: plain read-modify-write
         }
     } else {
         for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
-            const float a = rd_acc[e];
+            const float a = ACC::get(rd_acc, e);
             if (a != 0.0f) atomicAdd(dst + e, a);         // coarse levels are split over several workgroups
         }
     }
@@ -457,7 +480,7 @@ struct BinPlan { int chunk_shift, max_chunks, max_splits, total_blocks; BinLevel
 static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels, int feature_dim, int64_t tsize, int dim) {
     BinPlan p{};
     const int corners = 1 << dim;
-    int64_t centries = 16384 / feature_dim;               // 64 KiB of fp32 accumulators per workgroup
+    int64_t centries = 16384 / feature_dim;               // chunk entries: 64 KiB as fp32, 128 KiB as 64-bit fixed point
     while (((int64_t)1 << (p.chunk_shift + 1)) <= centries) ++p.chunk_shift;
     int64_t cur = 0, rec = 0;
     p.ok = true;
@@ -475,7 +498,8 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         p.bins.cur_base[li] = (int32_t)cur;
         p.bins.rec_base[li] = rec;
         p.bins.entries[li] = (uint32_t)entries;
-        int splits = (int)(8 / chunks);                       // >= 8 reduce workgroups per level; split slices are flushed with atomics
+        static const int split_target = [] { const char* e = getenv("WISP_RD_SPLITS"); return e ? atoi(e) : 64; }();
+        int splits = (int)(split_target / chunks);            // ~split_target reduce workgroups per coarse level (atomic flush)
         p.bins.splits[li] = splits < 1 ? 1 : splits;
         if (chunks > p.max_chunks) p.max_chunks = (int)chunks;
         if (p.bins.splits[li] > p.max_splits) p.max_splits = p.bins.splits[li];
@@ -528,11 +552,21 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     hipLaunchKernelGGL(em, dim3((unsigned)ceil_div64(n, EM_TILE), active.n), dim3(EM_THREADS), em_lds, s, coords, n,
                        (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
                        plan.chunk_shift, plan.bins, cursors, records, grad_codebook);
-    const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 4;
-    auto rd = hashgrid_bwd_reduce_kernel<F>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
-    hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active,
-                       plan.chunk_shift, plan.bins, cursors, records, grad_codebook);
+    static const int rd_dbg = [] { const char* e = getenv("WISP_RD_DBG"); return e ? atoi(e) : 0; }();
+    static const bool rd_f32 = env_flag("WISP_RD_F32", false);
+    if (rd_f32) {
+        const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 4;
+        auto rd = hashgrid_bwd_reduce_kernel<F, AccF32>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
+        hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
+                           plan.bins, cursors, records, grad_codebook, rd_dbg);
+    } else {
+        const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 8;
+        auto rd = hashgrid_bwd_reduce_kernel<F, AccFix64>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
+        hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
+                           plan.bins, cursors, records, grad_codebook, rd_dbg);
+    }
     return 0;
 }
 
