@@ -270,6 +270,9 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 // ---- binned path for hashed levels -----------------------------------------------------------------------------------
 #define EM_TILE 512          // samples per emit workgroup
 #define EM_THREADS 256
+#ifndef EM_MIN_WAVES
+#define EM_MIN_WAVES 4          // waves per SIMD the emit kernel is register-budgeted for
+#endif
 #define RD_THREADS 1024
 #define BIN_MAX_CHUNKS 1024
 
@@ -278,7 +281,7 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 // (count per bucket -> one reservation per non-empty bucket -> scatter), so the only LDS use is 2 x chunks counters and
 // occupancy is bounded by registers, not by a staging buffer.
 template <typename T, int F, int DIM>
-__global__ void __launch_bounds__(EM_THREADS)
+__global__ void __launch_bounds__(EM_THREADS, EM_MIN_WAVES)
 hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ grad_feats,
                          const int64_t* __restrict__ first_idx, HashLevels lv, LevelList levels, int num_lods,
                          uint32_t tsize, int tsize_pow2, int zero_from_col, int chunk_shift, BinLevels bins,

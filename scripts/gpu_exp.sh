@@ -11,7 +11,7 @@ for r in csv.DictReader(open(f)):
     if "hashgrid_bwd" in r["Name"]: print("   $1", r["Calls"], round(float(r["AverageNs"])/1e3,1), "us", r["Name"][:40])
 PY
 }
-prof fix64_s8
-WISP_RD_SPLITS=64 prof fix64_s64
-WISP_RD_SPLITS=1 prof fix64_s1
-WISP_RD_F32=1 WISP_RD_SPLITS=64 prof f32_s64
+cp kaolin-wisp_amd/csrc/libwisp_hip.so /tmp/keep.so
+prof w4
+for w in 5 6 8; do cp kaolin-wisp_amd/csrc/libwisp_hip_w$w.so kaolin-wisp_amd/csrc/libwisp_hip.so; prof w$w; done
+cp /tmp/keep.so kaolin-wisp_amd/csrc/libwisp_hip.so
