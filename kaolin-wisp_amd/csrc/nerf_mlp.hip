@@ -130,24 +130,47 @@ template <> struct MMA<__bf16> {
 // fp32 tiles: exact fp32 MFMA, one sample pair per step.  bf16 tiles: two v_mfma_f32_32x32x16_bf16 per 32x32 block of
 // dW; both operands are COLUMNS of the [sample][feature] LDS tiles, gathered with strided 2-byte reads (the K slots of
 // A and B only have to agree with each other, so sample 8*half + j of each 16-sample step goes to slot j).
-static __device__ __forceinline__ void dw_acc(const float* dY, int ldy, int i0, const float* X, int ldx, int k0,
-                                              floatx16& acc, int lane) {
-    const float* pa = dY + (lane >> 5) * ldy + i0 + (lane & 31);
-    const float* pb = X + (lane >> 5) * ldx + k0 + (lane & 31);
+// One whole layer: acc[it * KT + kt] += dY[:, it-th 32 columns]^T  X[:, kt-th 32 columns]; every operand column block
+// is gathered from LDS once per sample step and reused by all the MFMAs that need it.
+template <int IT, int KT>
+static __device__ __forceinline__ void dw_layer(const float* dY, int ldy, const float* X, int ldx, floatx16* acc, int lane) {
+    const float* pa = dY + (lane >> 5) * ldy + (lane & 31);
+    const float* pb = X + (lane >> 5) * ldx + (lane & 31);
 #pragma unroll
-    for (int n = 0; n < TS; n += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[n * ldy], pb[n * ldx], acc, 0, 0, 0);
+    for (int n = 0; n < TS; n += 2) {
+        float a[IT], b[KT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) a[it] = pa[n * ldy + it * 32];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) b[kt] = pb[n * ldx + kt * 32];
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+                acc[it * KT + kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it], b[kt], acc[it * KT + kt], 0, 0, 0);
+    }
 }
 
-static __device__ __forceinline__ void dw_acc(const __bf16* dY, int ldy, int i0, const __bf16* X, int ldx, int k0,
-                                              floatx16& acc, int lane) {
-    const __bf16* pa = dY + 8 * (lane >> 5) * ldy + i0 + (lane & 31);
-    const __bf16* pb = X + 8 * (lane >> 5) * ldx + k0 + (lane & 31);
+template <int IT, int KT>
+static __device__ __forceinline__ void dw_layer(const __bf16* dY, int ldy, const __bf16* X, int ldx, floatx16* acc, int lane) {
+    const __bf16* pa = dY + 8 * (lane >> 5) * ldy + (lane & 31);
+    const __bf16* pb = X + 8 * (lane >> 5) * ldx + (lane & 31);
 #pragma unroll
     for (int n = 0; n < TS; n += 16) {
-        bf16x8 a, b;
+        bf16x8 a[IT], b[KT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { a[j] = pa[(n + j) * ldy]; b[j] = pb[(n + j) * ldx]; }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[it][j] = pa[(n + j) * ldy + it * 32];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[kt][j] = pb[(n + j) * ldx + kt * 32];
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+                acc[it * KT + kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[it], b[kt], acc[it * KT + kt], 0, 0, 0);
     }
 }
 
@@ -223,31 +246,53 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
         const int64_t s = tile * TS + n;
         const bool live = s < num_samples;
 
-        // ---- load the input tile: lane (n, half) copies 16 of the 32 features of sample n
+        // ---- load the input tile: lane (n, half) copies 16 of the 32 features of sample n (vector loads)
         {
-            const TIO* src = feats + s * IN + half * 16;
+            TIO buf[16];
+            if (live) {
+                const uint4* src = reinterpret_cast<const uint4*>(feats + s * IN + half * 16);
+                uint4* dstv = reinterpret_cast<uint4*>(buf);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) x0[n * G::LDI + half * 16 + k] = Tr::from_f(live ? io_to_f<TIO>(src[k]) : 0.0f);
+                for (int q = 0; q < (int)(16 * sizeof(TIO) / 16); ++q) dstv[q] = src[q];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x0[n * G::LDI + half * 16 + k] = Tr::from_f(live ? io_to_f<TIO>(buf[k]) : 0.0f);
         }
-        // ---- positional encoding of the view direction -> x2[:, 15..41]; zero the K padding 42..63
-        if (half == 0) {
+        // ---- positional encoding of the view direction -> x2[:, 15..41]; zero the K padding 42..63.
+        // layout [d ; sin(2^k d) k-major ; cos(2^k d) k-major] (positional_embedder.py:61-65).  The two half-waves split the
+        // work: half 0 writes d and the sines, half 1 the cosines and the padding.  fp32 path: one accurate sincosf per
+        // band (bit-compatible with torch.sin / torch.cos to ~1 ulp); bf16 path: one sincos + double-angle recurrences.
+        {
             float d[3] = {0.f, 0.f, 0.f};
             if (live) { d[0] = dirs[s * 3]; d[1] = dirs[s * 3 + 1]; d[2] = dirs[s * 3 + 2]; }
             TC* row = x2 + n * G::LDH + 15;
+            if (half == 0) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) row[a] = Tr::from_f(d[a]);
+                for (int a = 0; a < 3; ++a) row[a] = Tr::from_f(d[a]);
+            } else {
 #pragma unroll
-            for (int k = 0; k < NF; ++k)
+                for (int k = X2; k < 64; ++k) x2[n * G::LDH + k] = Tr::from_f(0.0f);
+            }
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
+            for (int a = 0; a < 3; ++a) {
+                if (sizeof(TC) == 4) {
+#pragma unroll
+                    for (int k = 0; k < NF; ++k) {
+                        const float arg = (float)(1 << k) * d[a];
+                        const float val = half == 0 ? sinf(arg) : cosf(arg);
+                        row[3 + half * 3 * NF + k * 3 + a] = Tr::from_f(val);
+                    }
+                } else {
                     float sv, cv;
-                    sincosf((float)(1 << k) * d[a], &sv, &cv);          // bands 2^k, layout [x ; sin k-major ; cos k-major]
-                    row[3 + k * 3 + a] = Tr::from_f(sv);
-                    row[3 + 3 * NF + k * 3 + a] = Tr::from_f(cv);
-                }
-        } else {
+                    __sincosf(d[a], &sv, &cv);
 #pragma unroll
-            for (int k = X2; k < 64; ++k) x2[n * G::LDH + k] = Tr::from_f(0.0f);
+                    for (int k = 0; k < NF; ++k) {
+                        row[3 + half * 3 * NF + k * 3 + a] = Tr::from_f(half == 0 ? sv : cv);
+                        const float s2 = 2.0f * sv * cv, c2 = 1.0f - 2.0f * sv * sv;      // angle doubling
+                        sv = s2; cv = c2;
+                    }
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -325,8 +370,7 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
             __builtin_amdgcn_wave_barrier();
         }
         // dW5 += dY5^T h3 ; db5 ; dH3 = (W5^T dY5) * (h3 > 0) -> dyb
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) dw_acc(dya, G::LDH, 0, h3, G::LDH, kt * 32, dW5[kt], lane);
+        dw_layer<1, 2>(dya, G::LDH, h3, G::LDH, dW5, lane);
         if (lane < 3) { float a = 0.f; for (int m = 0; m < TS; ++m) a += Tr::to_f(dya[m * G::LDH + lane]); db5 += a; }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -341,10 +385,7 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
         }
         __builtin_amdgcn_wave_barrier();
         // dW4 += dH3^T h2 ; db4 ; dH2 = (W4^T dH3) * (h2 > 0) -> dya
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) dw_acc(dyb, G::LDH, it * 32, h2, G::LDH, kt * 32, dW4[it * 2 + kt], lane);
+        dw_layer<2, 2>(dyb, G::LDH, h2, G::LDH, dW4, lane);
         { float a = 0.f; for (int m = 0; m < TS; ++m) a += Tr::to_f(dyb[m * G::LDH + lane]); db4 += a; }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -359,10 +400,7 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
         }
         __builtin_amdgcn_wave_barrier();
         // dW3 += dH2^T x2 ; db3 ; dX2 = W3^T dH2 (only the 15 geometry columns carry gradient further)
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) dw_acc(dya, G::LDH, it * 32, x2, G::LDH, kt * 32, dW3[it * 2 + kt], lane);
+        dw_layer<2, 2>(dya, G::LDH, x2, G::LDH, dW3, lane);
         { float a = 0.f; for (int m = 0; m < TS; ++m) a += Tr::to_f(dya[m * G::LDH + lane]); db3 += a; }
         {
             floatx16 acc = zero16();
@@ -381,8 +419,7 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
         }
         __builtin_amdgcn_wave_barrier();
         // dW2 += dY2^T h1 ; db2 ; dH1 = (W2^T dY2) * (h1 > 0) -> dya
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) dw_acc(dyb, G::LDH, 0, h1, G::LDH, kt * 32, dW2[kt], lane);
+        dw_layer<1, 2>(dyb, G::LDH, h1, G::LDH, dW2, lane);
         if (lane < 16) { float a = 0.f; for (int m = 0; m < TS; ++m) a += Tr::to_f(dyb[m * G::LDH + lane]); db2 += a; }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -397,8 +434,7 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
         }
         __builtin_amdgcn_wave_barrier();
         // dW1 += dH1^T x0 ; db1 ; dX0 = W1^T dH1 -> grad_feats
-#pragma unroll
-        for (int it = 0; it < 2; ++it) dw_acc(dya, G::LDH, it * 32, x0, G::LDI, 0, dW1[it], lane);
+        dw_layer<2, 1>(dya, G::LDH, x0, G::LDI, dW1, lane);
         { float a = 0.f; for (int m = 0; m < TS; ++m) a += Tr::to_f(dya[m * G::LDH + lane]); db1 += a; }
         {
             floatx16 acc = zero16();
