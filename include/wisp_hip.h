@@ -197,7 +197,9 @@ int wisp_packed_cumsum(const float* feats, int64_t num_samples, int channels,
 /* Fused tracer compositing: tau = density*delta; w_i = exp(-sum_{j<i} tau_j)(1-exp(-tau_i));
  * rgb[r] = bg*(1-sum w) + sum w*c ; alpha[r] = sum w ; depth[r] = sum w*t ; hit[r] = alpha > 0.
  * Rays without samples get bg / 0 / 0 / false.  weights f32 [S] is an output (kaolin returns it).
- * depths / out_depth may be NULL together. */
+ * depths / out_depth may be NULL together.
+ * Ray-offset mode: pass ridx = NULL, pack_starts = per-ray sample offsets i64 [R+1] and num_packs = num_rays; packs are
+ * then addressed by ray (every ray is its own, possibly empty, pack) and no boundary compaction is needed. */
 int wisp_composite_fwd(const float* color /* [S,3] */, const float* density /* [S] */,
                        const float* deltas /* [S] */, const float* depths /* [S] or NULL */,
                        const int64_t* ridx /* [S] */, const int64_t* pack_starts, int64_t num_packs,

@@ -98,6 +98,11 @@ composite_init_kernel(int64_t num_rays, Bg bg, float* __restrict__ rgb, float* _
     hit[r] = 0;
 }
 
+// BY_RAY = false: pack p covers samples [pack_starts[p], pack_starts[p+1]) and its ray is ridx[first sample].
+// BY_RAY = true : `pack_starts` is the per-ray offset table [R+1]; wave r handles ray r and also writes the
+//                 background for rays without samples, so no init pass, no boundary->starts compaction and no
+//                 device->host read of the pack count are needed.
+template <bool BY_RAY>
 __global__ void __launch_bounds__(256)
 composite_fwd_kernel(const float* __restrict__ color, const float* __restrict__ density,
                      const float* __restrict__ deltas, const float* __restrict__ depths,
@@ -107,7 +112,15 @@ composite_fwd_kernel(const float* __restrict__ color, const float* __restrict__ 
     const int lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= num_packs) return;
-    const int64_t b = pack_starts[p], e = (p + 1 < num_packs) ? pack_starts[p + 1] : s_total;
+    const int64_t b = pack_starts[p], e = (BY_RAY || p + 1 < num_packs) ? pack_starts[p + 1] : s_total;
+    if (BY_RAY && b == e) {
+        if (lane == 0) {
+            out_alpha[p] = 0.0f; out_hit[p] = 0;
+            out_rgb[p * 3] = bg.r; out_rgb[p * 3 + 1] = bg.g; out_rgb[p * 3 + 2] = bg.b;
+            if (out_depth) out_depth[p] = 0.0f;
+        }
+        return;
+    }
     float carry = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f, sa = 0.0f, sd = 0.0f;
     for (int64_t k0 = b; k0 < e; k0 += 64) {
         const int64_t i = k0 + lane;
@@ -128,7 +141,7 @@ composite_fwd_kernel(const float* __restrict__ color, const float* __restrict__ 
     sr = wave_sum_f(sr); sg = wave_sum_f(sg); sb = wave_sum_f(sb); sa = wave_sum_f(sa);
     if (depths) sd = wave_sum_f(sd);
     if (lane == 0) {
-        const int64_t r = ridx[b];
+        const int64_t r = BY_RAY ? p : ridx[b];
         out_alpha[r] = sa;                                                // :160-161
         out_hit[r] = sa > 0.0f ? 1 : 0;                                   // :162
         const float om = 1.0f - sa;
@@ -139,6 +152,7 @@ composite_fwd_kernel(const float* __restrict__ color, const float* __restrict__ 
 
 // dL/dc_i = w_i g_rgb ; G_i = g_rgb.(c_i - bg) + g_alpha + g_depth t_i ;
 // dL/dtau_i = G_i T_i exp(-tau_i) - sum_{k>i} G_k w_k ; dL/dsigma_i = dL/dtau_i * delta_i
+template <bool BY_RAY>
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(const float* __restrict__ grad_rgb, const float* __restrict__ grad_alpha,
                      const float* __restrict__ grad_depth, const float* __restrict__ color,
@@ -149,8 +163,9 @@ composite_bwd_kernel(const float* __restrict__ grad_rgb, const float* __restrict
     const int lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= num_packs) return;
-    const int64_t b = pack_starts[p], e = (p + 1 < num_packs) ? pack_starts[p + 1] : s_total;
-    const int64_t r = ridx[b];
+    const int64_t b = pack_starts[p], e = (BY_RAY || p + 1 < num_packs) ? pack_starts[p + 1] : s_total;
+    if (BY_RAY && b == e) return;
+    const int64_t r = BY_RAY ? p : ridx[b];
     const float gr = grad_rgb[r * 3], gg = grad_rgb[r * 3 + 1], gb = grad_rgb[r * 3 + 2];
     const float ga = grad_alpha ? grad_alpha[r] : 0.0f;
     const float gd = (grad_depth && depths) ? grad_depth[r] : 0.0f;
@@ -211,11 +226,20 @@ extern "C" int wisp_composite_fwd(const float* color, const float* density, cons
     WISP_REQUIRE(out_depth == nullptr || depths != nullptr, "out_depth needs depths");
     hipStream_t s = (hipStream_t)stream;
     const Bg b{bg[0], bg[1], bg[2]};
+    if (ridx == nullptr) {      // per-ray offsets mode: pack_starts = ray_offsets [num_rays + 1], num_packs must equal num_rays
+        WISP_REQUIRE(pack_starts && num_packs == num_rays, "ray-offset mode needs offsets[R+1] and num_packs == num_rays");
+        WISP_REQUIRE(num_samples == 0 || (color && density && deltas && weights), "null pointer");
+        hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3((unsigned)ceil_div64(num_rays, 4)), dim3(256), 0, s, color,
+                           density, deltas, out_depth ? depths : nullptr, ridx, pack_starts, num_rays, num_samples, b,
+                           out_rgb, out_alpha, out_depth, out_hit, weights);
+        WISP_CHECK_LAUNCH();
+        return WISP_OK;
+    }
     hipLaunchKernelGGL(composite_init_kernel, dim3((unsigned)ceil_div64(num_rays, 256)), dim3(256), 0, s, num_rays, b,
                        out_rgb, out_alpha, out_depth, out_hit);
     if (num_packs > 0) {
         WISP_REQUIRE(color && density && deltas && ridx && pack_starts && weights, "null pointer");
-        hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)ceil_div64(num_packs, 4)), dim3(256), 0, s, color,
+        hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3((unsigned)ceil_div64(num_packs, 4)), dim3(256), 0, s, color,
                            density, deltas, out_depth ? depths : nullptr, ridx, pack_starts, num_packs, num_samples, b,
                            out_rgb, out_alpha, out_depth, out_hit, weights);
     }
@@ -230,12 +254,16 @@ extern "C" int wisp_composite_bwd(const float* grad_rgb, const float* grad_alpha
                                   wisp_stream_t stream) {
     WISP_REQUIRE(num_packs >= 0 && num_samples >= 0 && bg, "bad sizes");
     if (num_packs == 0) return WISP_OK;
-    WISP_REQUIRE(grad_rgb && color && density && deltas && ridx && pack_starts && grad_color && grad_density,
-                 "null pointer");
+    WISP_REQUIRE(grad_rgb && color && density && deltas && pack_starts && grad_color && grad_density, "null pointer");
     const Bg b{bg[0], bg[1], bg[2]};
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)ceil_div64(num_packs, 4)), dim3(256), 0,
-                       (hipStream_t)stream, grad_rgb, grad_alpha, grad_depth, color, density, deltas, depths, ridx,
-                       pack_starts, num_packs, num_samples, b, grad_color, grad_density);
+    if (ridx == nullptr)        // per-ray offsets mode (see wisp_composite_fwd): num_packs = number of rays
+        hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3((unsigned)ceil_div64(num_packs, 4)), dim3(256), 0,
+                           (hipStream_t)stream, grad_rgb, grad_alpha, grad_depth, color, density, deltas, depths, ridx,
+                           pack_starts, num_packs, num_samples, b, grad_color, grad_density);
+    else
+        hipLaunchKernelGGL(composite_bwd_kernel<false>, dim3((unsigned)ceil_div64(num_packs, 4)), dim3(256), 0,
+                           (hipStream_t)stream, grad_rgb, grad_alpha, grad_depth, color, density, deltas, depths, ridx,
+                           pack_starts, num_packs, num_samples, b, grad_color, grad_density);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }

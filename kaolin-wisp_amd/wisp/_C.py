@@ -402,7 +402,7 @@ def raymarch_uniform(origins, dirs, nug_ridx, nug_depth, ray_offsets, scale):
         _check(lib.wisp_raymarch_uniform_emit(_p(origins), _p(dirs), _p(nug_ridx), _p(nug_depth), M, float(scale),
                                               _p(offsets), _p(ray_offsets), _p(ridx), _p(samples), _p(depth),
                                               _p(boundary), _stream()), "raymarch_uniform_emit")
-    return ridx, samples, depth, boundary
+    return ridx, samples, depth, boundary, offsets
 
 
 # ------------------------------------------------------------------------------------------------ packed integration
@@ -436,7 +436,10 @@ def composite_fwd(color, density, deltas, depths, ridx, starts, num_rays, bg):
     hit = torch.empty(num_rays, dtype=torch.bool, device=dev)
     weights = torch.empty(S, 1, dtype=torch.float32, device=dev)
     bg_arr, bg_ptr = _host_f32(bg)
-    _check(lib.wisp_composite_fwd(_p(color), _p(density), _p(deltas), _p(depths), _p(ridx), _p(starts), starts.shape[0],
+    num_packs = num_rays if ridx is None else starts.shape[0]
+    if ridx is None:
+        assert starts.shape[0] == num_rays + 1, "ray-offset mode needs offsets [num_rays + 1]"
+    _check(lib.wisp_composite_fwd(_p(color), _p(density), _p(deltas), _p(depths), _p(ridx), _p(starts), num_packs,
                                   S, num_rays, bg_ptr, _p(rgb), _p(alpha), _p(depth), _p(hit), _p(weights), _stream()),
            "composite_fwd")
     return rgb, alpha, depth, hit, weights
@@ -450,8 +453,9 @@ def composite_bwd(grad_rgb, grad_alpha, grad_depth, color, density, deltas, dept
     g_color = torch.empty(S, 3, dtype=torch.float32, device=dev)
     g_density = torch.empty(S, 1, dtype=torch.float32, device=dev)
     bg_arr, bg_ptr = _host_f32(bg)
+    num_packs = starts.shape[0] - 1 if ridx is None else starts.shape[0]
     _check(lib.wisp_composite_bwd(_p(grad_rgb), _p(grad_alpha), _p(grad_depth), _p(color), _p(density), _p(deltas),
-                                  _p(depths), _p(ridx), _p(starts), starts.shape[0], S, bg_ptr, _p(g_color),
+                                  _p(depths), _p(ridx), _p(starts), num_packs, S, bg_ptr, _p(g_color),
                                   _p(g_density), _stream()), "composite_bwd")
     return g_color, g_density
 

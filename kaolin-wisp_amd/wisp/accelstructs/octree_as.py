@@ -109,8 +109,10 @@ class OctreeAS(BaseAS):
         rt = self.raytrace(rays, level, with_exit=True)
         ridx, samples, depth, deltas, boundary = _hip().raymarch_voxel(
             rays.origins, rays.dirs, rt.ridx, rt.depth, num_samples, jitter, self._draw_seed())
-        return ASRaymarchResults(ridx=ridx, samples=samples, depth_samples=depth, deltas=deltas, boundary=boundary,
-                                 pack_info=None)
+        res = ASRaymarchResults(ridx=ridx, samples=samples, depth_samples=depth, deltas=deltas, boundary=boundary,
+                                pack_info=None)
+        res.ray_offsets = rt.ray_offsets * num_samples        # every nugget contributes exactly num_samples samples
+        return res
 
     def _raymarch_ray(self, rays, num_samples, level=None, jitter=None) -> ASRaymarchResults:
         """num_samples stratified samples between dist_min and dist_max, keeping those inside occupied cells."""
@@ -131,10 +133,12 @@ class OctreeAS(BaseAS):
         step_size = 2 * np.sqrt(3) / num_samples
         scale = int(np.ceil(1.0 / step_size))
         step_size = 1.0 / float(scale)
-        ridx, samples, depth, boundary = _hip().raymarch_uniform(rays.origins, rays.dirs, rt.ridx, rt.depth,
-                                                                 rt.ray_offsets, scale)
+        ridx, samples, depth, boundary, sample_offsets = _hip().raymarch_uniform(rays.origins, rays.dirs, rt.ridx, rt.depth,
+                                                                                 rt.ray_offsets, scale)
         deltas = torch.full((ridx.shape[0], 1), step_size, dtype=torch.float32, device=depth.device)
-        return ASRaymarchResults(ridx=ridx, samples=samples, depth_samples=depth, deltas=deltas, boundary=boundary)
+        res = ASRaymarchResults(ridx=ridx, samples=samples, depth_samples=depth, deltas=deltas, boundary=boundary)
+        res.ray_offsets = sample_offsets.index_select(0, rt.ray_offsets)    # per-nugget sample offsets at each ray's first nugget
+        return res
 
     def raymarch(self, rays, raymarch_type, num_samples, level=None, jitter=None) -> ASRaymarchResults:
         """Generate packed samples along `rays`; raymarch_type in {'voxel', 'ray', 'uniform'}."""

@@ -93,7 +93,9 @@ class _Composite(torch.autograd.Function):
         color32 = color.detach().float().contiguous()
         dens32 = density.detach().float().contiguous()
         rgb, alpha, depth, hit, _w = C.composite_fwd(color32, dens32, deltas, depths, ridx, starts, num_rays, bg)
-        ctx.save_for_backward(color32, dens32, deltas, depths if depths is not None else torch.empty(0), ridx, starts)
+        ctx.by_ray = ridx is None
+        ctx.save_for_backward(color32, dens32, deltas, depths if depths is not None else torch.empty(0),
+                              ridx if ridx is not None else torch.empty(0), starts)
         ctx.has_depth = depths is not None
         ctx.bg = bg
         ctx.in_dtypes = (color.dtype, density.dtype)
@@ -106,6 +108,7 @@ class _Composite(torch.autograd.Function):
     def backward(ctx, g_rgb, g_alpha, g_depth, _g_hit):
         color, density, deltas, depths, ridx, starts = ctx.saved_tensors
         depths = depths if ctx.has_depth else None
+        ridx = None if ctx.by_ray else ridx
         C = _hip()
         if g_rgb is None:
             g_rgb = torch.zeros(g_alpha.shape[0], 3, device=color.device)
@@ -116,6 +119,7 @@ class _Composite(torch.autograd.Function):
 
 
 def composite(color, density, deltas, depths, ridx, starts, num_rays, bg):
-    """-> (rgb [R,3], alpha [R,1], depth [R,1] or None, hit bool [R]); differentiable w.r.t. color and density."""
+    """-> (rgb [R,3], alpha [R,1], depth [R,1] or None, hit bool [R]); differentiable w.r.t. color and density.
+    `starts` = pack starts [P] with `ridx` given, or per-ray sample offsets [R+1] with ridx=None (no compaction needed)."""
     rgb, alpha, depth, hit = _Composite.apply(color, density.reshape(-1, 1), deltas, depths, ridx, starts, num_rays, bg)
     return rgb, alpha, (depth if depths is not None else None), hit

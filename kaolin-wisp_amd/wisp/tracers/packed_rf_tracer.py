@@ -34,6 +34,14 @@ class PackedRFTracer(BaseTracer):
         self.bg_color = torch.tensor(bg_color, dtype=torch.float32)
         self.prev_num_samples = None
 
+    def _bg_host(self):
+        """background colour as python floats, cached (reading the device tensor every call would sync)."""
+        cached = getattr(self, "_bg_cache", None)
+        if cached is None or cached[0] is not self.bg_color:
+            cached = (self.bg_color, [float(x) for x in self.bg_color.detach().cpu().reshape(-1).tolist()])
+            self._bg_cache = cached
+        return cached[1]
+
     def get_prev_num_samples(self):
         """Number of packed samples of the last trace() (None before the first)."""
         return self.prev_num_samples
@@ -61,13 +69,21 @@ class PackedRFTracer(BaseTracer):
         hit_ray_d = rays.dirs.index_select(0, ridx)
         color, density = nef(coords=samples, ray_d=hit_ray_d, lod_idx=lod_idx, channels=["rgb", "density"])
         density = density.reshape(num_samples, 1)
-        self.bg_color = self.bg_color.to(rays.origins.device)
-        bg = [float(x) for x in self.bg_color.detach().cpu().reshape(-1).tolist()]
+        if self.bg_color.device != rays.origins.device:
+            self.bg_color = self.bg_color.to(rays.origins.device)
+        bg = self._bg_host()
 
-        starts = rm.pack_info if rm.pack_info is not None else render_ops.pack_starts_of(rm)
         want_depth = "depth" in channels
-        rgb, alpha, depth, hit = render_ops.composite(color, density, deltas, depths if want_depth else None, ridx,
-                                                      starts, N, bg)
+        ray_offsets = getattr(rm, "ray_offsets", None)
+        if ray_offsets is not None and not extra_channels:
+            # every ray is its own (possibly empty) pack: no boundary compaction, no host read of the pack count
+            rgb, alpha, depth, hit = render_ops.composite(color, density, deltas, depths if want_depth else None, None,
+                                                          ray_offsets, N, bg)
+            starts = None
+        else:
+            starts = rm.pack_info if rm.pack_info is not None else render_ops.pack_starts_of(rm)
+            rgb, alpha, depth, hit = render_ops.composite(color, density, deltas, depths if want_depth else None, ridx,
+                                                          starts, N, bg)
         extra_outputs = {}
         if extra_channels:
             tau = density.float() * deltas

@@ -222,7 +222,7 @@ def test_raymarch_voxel_and_uniform_bit_exact():
     wantu = omarch.raymarch_uniform(oc, pts, pyr, ex, o, d, 96, 5)
     scale, _ = omarch.uniform_scale(96)
     gotu = _C().raymarch_uniform(cuda(o), cuda(d), ridx, depth, offsets, scale)
-    for g, k in zip(gotu, ("ridx", "samples", "depth_samples", "boundary")):
+    for g, k in zip(gotu[:4], ("ridx", "samples", "depth_samples", "boundary")):
         assert np.array_equal(g.cpu().numpy(), wantu[k]), k
 
 
