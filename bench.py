@@ -182,6 +182,24 @@ def main():
         r = per * v["avg_units"] / (v["avg_ms"] * 1e-3)
         return bound, (r / 1e9 if bound == "hbm" else r / 1e12)
 
+    def pmc_traffic(kernel_prefixes):
+        """HBM-side bytes per launch from the committed rocprofv3 PMC summaries of this same command (profiles/r01_pmc_*):
+        FETCH_SIZE (KiB, doubled per MI355X_MICROARCH.md: it counts 128-B requests as 64 B) + WRITE_SIZE (KiB)."""
+        import csv
+        tot = 0.0
+        try:
+            for fname, mult in (("r01_pmc_FETCH_SIZE.csv", 2.0), ("r01_pmc_WRITE_SIZE.csv", 1.0)):
+                with open(os.path.join(ROOT, "profiles", fname)) as f:
+                    for row in csv.DictReader(f):
+                        if any(k in row["kernel"] for k in kernel_prefixes):
+                            tot += float(row["mean_per_dispatch"]) * 1024.0 * mult
+        except (OSError, KeyError, ValueError):
+            return None
+        return tot or None
+
+    pmc_names = {"hashgrid_fwd": ["hashgrid_fwd_kernel"], "hashgrid_bwd": ["hashgrid_bwd_emit_kernel", "hashgrid_bwd_reduce_kernel",
+                                                                           "hashgrid_bwd_kernel"],
+                 "nerf_mlp_fwd": ["Lb0EEE"], "nerf_mlp_bwd": ["Lb1EEE"]}
     kern = {n: v for n, v in kern.items() if n in work}
     dominant = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
     roofline = None
@@ -190,7 +208,10 @@ def main():
         bound, achieved = rate(dominant, k)
         peak, unit = peaks[bound]
         roofline = dict(bound=bound, kernel=dominant, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
-                        traffic=None, avg_launch_ms=k["avg_ms"], units_per_launch=k["avg_units"],
+                        traffic=pmc_traffic(pmc_names[dominant]) if (amp and world == 1) else None,
+                        traffic_note="bytes/launch from profiles/r01_pmc_{FETCH,WRITE}_SIZE.csv (rocprofv3 --pmc, same command, "
+                                     "FETCH_SIZE x2); hashgrid_bwd = memset + emit + reduce kernels",
+                        avg_launch_ms=k["avg_ms"], units_per_launch=k["avg_units"],
                         work_per_unit=work[dominant][1],
                         all_kernels={n: dict(avg_ms=v["avg_ms"], bound=rate(n, v)[0], achieved=rate(n, v)[1],
                                              frac=rate(n, v)[1] / peaks[rate(n, v)[0]][0]) for n, v in kern.items()})
