@@ -1,0 +1,3 @@
+from .batch import Batch, MultiviewBatch, SDFBatch
+from .transforms import SampleRays
+from .multiview_tensor_dataset import MultiviewTensorDataset

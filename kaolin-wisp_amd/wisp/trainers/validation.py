@@ -1,0 +1,69 @@
+"""Validation / offline rendering and checkpoint helpers (the caller side right after the hot path).
+
+render()            - OfflineRenderer.render (wisp/trainers/tracker/offline_renderer.py:170-191): chunked no-grad tracing.
+evaluate_psnr()     - the PSNR loop of MultiviewTrainer.evaluate_metrics (wisp/trainers/multiview_trainer.py:191-255),
+                      returning the same log line the reference prints and its tests scrape (tests/test_utils.py:55-92).
+save/load_pipeline  - BaseTrainer.save_model (wisp/trainers/base_trainer.py:344-359).  'state_dict' mode additionally
+                      stores the occupancy octree, which the reference silently drops (its OctreeAS tensors are plain
+                      attributes, not buffers) so that a pruned model can actually be restored.
+"""
+import torch
+
+from wisp.core import Rays, RenderBuffer
+from wisp.ops.image import psnr
+
+
+def render(pipeline, rays: Rays, lod_idx=None, render_batch=10000, channels=None, amp=False):
+    """Full-resolution inference in chunks of `render_batch` rays; RenderBuffer channels concatenated along dim 0."""
+    kw = {} if channels is None else {"channels": channels}
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+        if render_batch > 0:
+            rb = RenderBuffer()
+            for pack in rays.split(render_batch):
+                rb += pipeline.tracer(pipeline.nef, rays=pack, lod_idx=lod_idx, **kw)
+            return rb
+        return pipeline.tracer(pipeline.nef, rays=rays, lod_idx=lod_idx, **kw)
+
+
+def evaluate_psnr(pipeline, views, epoch=0, max_epochs=0, name=None, lod_idx=None, render_batch=10000, amp=False):
+    """views: iterable of (Rays [H*W,3], rgb [H*W,3]).  Returns (mean psnr, log line)."""
+    pipeline.eval()
+    total, n = 0.0, 0
+    for rays, gts in views:
+        rb = render(pipeline, rays.reshape(-1, 3), lod_idx=lod_idx, render_batch=render_batch, channels=["rgb"], amp=amp)
+        total += psnr(rb.rgb[..., :3].float(), gts.reshape(-1, 3)[..., :3])
+        n += 1
+    pipeline.train()
+    mean = total / max(n, 1)
+    if name is None:
+        name = f"lod{pipeline.nef.grid.num_lods - 1}" if lod_idx is None else f"lod{lod_idx}"
+    return mean, 'EPOCH {}/{} | {}: {:.2f}'.format(epoch, max_epochs, f"{name} psnr", mean)
+
+
+def save_pipeline(pipeline, path, model_format="full"):
+    if model_format == "full":
+        torch.save(pipeline, path)
+        return
+    state = {"state_dict": pipeline.state_dict()}
+    blas = getattr(getattr(pipeline.nef, "grid", None), "blas", None)
+    if blas is not None:
+        state["blas_octree"] = blas.octree.detach().cpu()
+        occ = getattr(pipeline.nef.grid, "occupancy", None)
+        state["grid_occupancy"] = None if occ is None else occ.detach().cpu()
+    torch.save(state, path)
+
+
+def load_pipeline(path, pipeline=None, map_location=None):
+    """'full' checkpoints return the pickled pipeline; 'state_dict' checkpoints are loaded into `pipeline`."""
+    obj = torch.load(path, map_location=map_location, weights_only=False)
+    if not isinstance(obj, dict) or "state_dict" not in obj:
+        return obj
+    assert pipeline is not None, "a state_dict checkpoint needs the pipeline to load into"
+    pipeline.load_state_dict(obj["state_dict"])
+    if obj.get("blas_octree") is not None:
+        grid = pipeline.nef.grid
+        dev = grid.blas.octree.device
+        grid.blas = grid.blas.__class__(obj["blas_octree"].to(dev))
+        if obj.get("grid_occupancy") is not None:
+            grid.occupancy = obj["grid_occupancy"]
+    return pipeline

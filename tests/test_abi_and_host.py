@@ -186,3 +186,50 @@ def test_tracer_fills_trace_kwargs_from_attributes():
     assert seen["num_steps"] == 7
     with pytest.raises(Exception, match="not supported"):
         t(Nef(), rays=None, channels=["normal"])
+
+
+def test_dataset_batch_and_ray_sampler_contract():
+    from wisp.core import Rays
+    from wisp.datasets import MultiviewBatch, SampleRays, MultiviewTensorDataset
+    V, P = 3, 50
+    o, d, rgb = torch.rand(V, P, 3), torch.rand(V, P, 3), torch.rand(V, P, 3)
+    tf = SampleRays(num_samples=16)
+    ds = MultiviewTensorDataset(o, d, rgb, dist_min=1.0, dist_max=5.0, transform=tf)
+    assert len(ds) == V
+    item = ds[1]
+    assert item['rays'].origins.shape == (16, 3) and item['rgb'].shape == (16, 3) and item['rays'].dist_max == 5.0
+    tf.set_num_samples(7)                      # what calc_adaptive_rays does every step
+    assert ds[0]['rays'].origins.shape == (7, 3)
+    b = MultiviewBatch(rays=Rays(o[0], d[0]), rgb=rgb[0], mask=torch.ones(P, 1))
+    assert set(b.fields) == {"rays", "cameras", "rgb", "mask"} and set(b.ray_values()) == {"rgb", "mask"}
+    g = torch.Generator().manual_seed(1)
+    a1 = SampleRays(8)(b, generator=g)['rgb']
+    g = torch.Generator().manual_seed(1)
+    a2 = SampleRays(8)(b, generator=g)['rgb']
+    assert torch.equal(a1, a2)
+    # a row of a picked ray stays aligned with its colour
+    idx = (b['rgb'][:, None, :] == a1[None]).all(-1).float().argmax(0)
+    assert torch.equal(b['rays'].origins[idx], SampleRays(8)(b, generator=torch.Generator().manual_seed(1))['rays'].origins)
+
+
+def test_checkpoint_roundtrip_keeps_pruned_octree(tmp_path):
+    from wisp.accelstructs import OctreeAS
+    from wisp.models import Pipeline
+    from wisp.models.grids import HashGrid
+    from wisp.models.nefs import NeuralRadianceField
+    from wisp.tracers import PackedRFTracer
+    from wisp.trainers import save_pipeline, load_pipeline
+
+    def make(points):
+        blas = OctreeAS.from_quantized_points(points, 3)
+        grid = HashGrid.from_geometric(blas, feature_dim=2, num_lods=4, multiscale_type='cat', feature_std=0.1,
+                                       codebook_bitwidth=8, min_grid_res=4, max_grid_res=16)
+        return Pipeline(NeuralRadianceField(grid, view_embedder='positional', hidden_dim=16, bias=True), PackedRFTracer())
+    pts = torch.tensor([[0, 0, 0], [7, 7, 7], [3, 4, 5]], dtype=torch.int16)
+    p1 = make(pts)
+    for fmt in ("full", "state_dict"):
+        path = str(tmp_path / f"m_{fmt}.pth")
+        save_pipeline(p1, path, fmt)
+        p2 = load_pipeline(path, pipeline=make(torch.tensor([[1, 1, 1]], dtype=torch.int16)))
+        assert torch.equal(p2.nef.grid.blas.octree.cpu(), p1.nef.grid.blas.octree.cpu())
+        assert torch.equal(p2.nef.grid.codebook.feats.cpu(), p1.nef.grid.codebook.feats.cpu())

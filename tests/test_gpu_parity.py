@@ -701,3 +701,23 @@ def test_image_field_config_c1_fits_and_matches_oracle_2d():
         opt.zero_grad(); loss.backward(); opt.step()
     final = float(((nef.rgb(coords) - img) ** 2).mean())
     assert final < 0.2 * first, (first, final)
+
+
+def test_validation_render_and_psnr_log_line():
+    """Chunked offline render == single-shot render; the PSNR log line has the format the reference's tests scrape."""
+    import re
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.tracers import PackedRFTracer
+    from wisp.trainers import render, evaluate_psnr
+    nef, onef, oblas = _build_pair()
+    pipe = Pipeline(nef, PackedRFTracer(raymarch_type='uniform', num_steps=64, bg_color=(0.0, 0.0, 0.0)))   # deterministic march
+    o, d = make_rays(1000, 131)
+    rays = Rays(cuda(o), cuda(d), dist_min=1.0, dist_max=5.0)
+    whole = render(pipe, rays, render_batch=0, channels=["rgb", "depth"])
+    parts = render(pipe, rays, render_batch=300, channels=["rgb", "depth"])
+    assert parts.rgb.shape == (1000, 3) and parts.hit.shape == (1000,)
+    np.testing.assert_allclose(parts.rgb.cpu().numpy(), whole.rgb.cpu().numpy(), atol=1e-6)
+    gts = whole.rgb.clamp(0, 1)
+    val, line = evaluate_psnr(pipe, [(rays, gts)], epoch=3, max_epochs=10, render_batch=256)
+    assert re.search(r"EPOCH 3/10 \| lod15 psnr: (\d+\.\d\d)$", line) and val > 60
