@@ -140,6 +140,20 @@ int wisp_spc_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i6
                            int samples_per_voxel, int channels, int level, float* grad_feats /* f32, accumulated */,
                            wisp_stream_t stream);
 
+/* VQAD codebook lookup fused with the trilinear blend (replaces CodebookOctreeGrid._index_features + _interpolate,
+ * wisp/models/grids/codebook_grid.py:103-172): logits f32 [Fn, dict_size], dictionary f32 [dict_size, feature_dim]
+ * (dict_size <= 256, feature_dim <= 16).  training != 0: straight-through softmax one-hot; else argmax lookup.
+ * Backward (training semantics) accumulates into grad_logits [Fn, dict_size] and grad_dictionary. */
+int wisp_codebook_trilinear_fwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
+                                const int32_t* trinkets, const float* logits, const float* dictionary,
+                                int64_t num_voxels, int samples_per_voxel, int dict_size, int feature_dim, int level,
+                                int training, float* out /* [V,S,feature_dim] */, wisp_stream_t stream);
+int wisp_codebook_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
+                                const int32_t* trinkets, const float* logits, const float* dictionary,
+                                const float* grad_out, int64_t num_voxels, int samples_per_voxel, int dict_size,
+                                int feature_dim, int level, float* grad_logits, float* grad_dictionary,
+                                wisp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Raymarch sample generation  (replace OctreeAS._raymarch_ray / _raymarch_voxel / _raymarch_uniform,
  * wisp/accelstructs/octree_as.py:188-374, wisp/ops/spc/sampling.py:35-71 and

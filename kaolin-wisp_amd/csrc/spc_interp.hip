@@ -156,3 +156,140 @@ extern "C" int wisp_spc_trilinear_bwd(const float* coords, const void* pidx, int
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- VQAD codebook lookup
+// Fused CodebookOctreeGrid._index_features + trilinear blend (wisp/models/grids/codebook_grid.py:103-172).  The
+// reference materialises logits[S, 8, 2^bw], a softmax, a one-hot and a [S, 8, 2^bw, F] product per level; here one
+// thread owns one (voxel, sample): for each of the 8 corners it reads the 2^bw logits row, finds the argmax, and blends
+// the selected dictionary rows.  Training mode reproduces the straight-through estimator
+//     keys = y_hard - stopgrad(y_soft) + y_soft        (forward value: one-hot up to one rounding of (1 - p) + p)
+// and its backward: d logits = softmax-Jacobian^T (dictionary . g), d dictionary[argmax] += g.
+#define CB_MAX_K 256
+#define CB_MAX_F 16
+
+template <typename I>
+__global__ void __launch_bounds__(128)
+codebook_trilinear_fwd_kernel(const float* __restrict__ coords, const I* __restrict__ pidx, const int16_t* __restrict__ points,
+                              const int32_t* __restrict__ trinkets, const float* __restrict__ logits,
+                              const float* __restrict__ dictionary, int64_t n, int spv, int K, int F, int level, int training,
+                              float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * spv) return;
+    const int64_t p = (int64_t)pidx[i / spv];
+    float acc[CB_MAX_F];
+    for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+    if (p >= 0) {
+        float w[8];
+        trilinear_coeffs(coords + i * 3, points + p * 3, level, w);
+        for (int j = 0; j < 8; ++j) {
+            const float* row = logits + (int64_t)trinkets[p * 8 + j] * K;
+            int best = 0;
+            float mx = row[0];
+            for (int k = 1; k < K; ++k) { const float v = row[k]; if (v > mx) { mx = v; best = k; } }   // first max wins (torch.max)
+            float scale = 1.0f;
+            if (training) {
+                float denom = 0.0f;
+                for (int k = 0; k < K; ++k) denom += expf(row[k] - mx);
+                const float pb = 1.0f / denom;                    // softmax probability of the argmax
+                scale = (1.0f - pb) + pb;
+            }
+            const float* drow = dictionary + (int64_t)best * F;
+            for (int f = 0; f < F; ++f) acc[f] += drow[f] * scale * w[j];
+        }
+    }
+    for (int f = 0; f < F; ++f) out[i * F + f] = acc[f];
+}
+
+template <typename I>
+__global__ void __launch_bounds__(128)
+codebook_trilinear_bwd_kernel(const float* __restrict__ coords, const I* __restrict__ pidx, const int16_t* __restrict__ points,
+                              const int32_t* __restrict__ trinkets, const float* __restrict__ logits,
+                              const float* __restrict__ dictionary, const float* __restrict__ grad_out, int64_t n, int spv,
+                              int K, int F, int level, float* __restrict__ grad_logits, float* __restrict__ grad_dict) {
+    extern __shared__ float s_gdict[];                                 // [K * F] workgroup-private dictionary gradient
+    for (int e = threadIdx.x; e < K * F; e += blockDim.x) s_gdict[e] = 0.0f;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = (i < n * spv) ? (int64_t)pidx[i / spv] : -1;
+    if (p >= 0) {
+        float w[8], g[CB_MAX_F];
+        trilinear_coeffs(coords + i * 3, points + p * 3, level, w);
+        for (int f = 0; f < F; ++f) g[f] = grad_out[i * F + f];
+        for (int j = 0; j < 8; ++j) {
+            const int64_t r = trinkets[p * 8 + j];
+            const float* row = logits + r * K;
+            int best = 0;
+            float mx = row[0];
+            for (int k = 1; k < K; ++k) { const float v = row[k]; if (v > mx) { mx = v; best = k; } }
+            float denom = 0.0f;
+            for (int k = 0; k < K; ++k) denom += expf(row[k] - mx);
+            const float inv = 1.0f / denom;
+            // dkey_k = dictionary[k] . (w_j g) ;  dlogit_k = p_k (dkey_k - sum_m p_m dkey_m)
+            float dot = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                float dk = 0.0f;
+                for (int f = 0; f < F; ++f) dk += dictionary[(int64_t)k * F + f] * g[f];
+                dot += expf(row[k] - mx) * inv * dk * w[j];
+            }
+            for (int k = 0; k < K; ++k) {
+                float dk = 0.0f;
+                for (int f = 0; f < F; ++f) dk += dictionary[(int64_t)k * F + f] * g[f];
+                const float pk = expf(row[k] - mx) * inv;
+                atomicAdd(grad_logits + r * K + k, pk * (dk * w[j] - dot));
+            }
+            const float scale = (1.0f - inv) + inv;                    // forward value of the argmax key
+            for (int f = 0; f < F; ++f) atomicAdd(&s_gdict[best * F + f], g[f] * w[j] * scale);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * F; e += blockDim.x) {
+        const float v = s_gdict[e];
+        if (v != 0.0f) atomicAdd(grad_dict + e, v);
+    }
+}
+
+extern "C" int wisp_codebook_trilinear_fwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
+                                           const int32_t* trinkets, const float* logits, const float* dictionary,
+                                           int64_t num_voxels, int samples_per_voxel, int dict_size, int feature_dim, int level,
+                                           int training, float* out, wisp_stream_t stream) {
+    WISP_REQUIRE(num_voxels >= 0 && samples_per_voxel >= 1 && level >= 0 && level <= 15, "bad sizes");
+    WISP_REQUIRE(dict_size >= 1 && dict_size <= CB_MAX_K && feature_dim >= 1 && feature_dim <= CB_MAX_F, "dictionary too large for the fused kernel");
+    if (num_voxels == 0) return WISP_OK;
+    WISP_REQUIRE(coords && pidx && points && trinkets && logits && dictionary && out, "null pointer");
+    const int64_t rows = num_voxels * samples_per_voxel;
+    const dim3 grid((unsigned)ceil_div64(rows, 128)), block(128);
+    hipStream_t s = (hipStream_t)stream;
+    if (pidx_is_i64)
+        hipLaunchKernelGGL(codebook_trilinear_fwd_kernel<int64_t>, grid, block, 0, s, coords, (const int64_t*)pidx, points, trinkets,
+                           logits, dictionary, num_voxels, samples_per_voxel, dict_size, feature_dim, level, training, out);
+    else
+        hipLaunchKernelGGL(codebook_trilinear_fwd_kernel<int32_t>, grid, block, 0, s, coords, (const int32_t*)pidx, points, trinkets,
+                           logits, dictionary, num_voxels, samples_per_voxel, dict_size, feature_dim, level, training, out);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_codebook_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
+                                           const int32_t* trinkets, const float* logits, const float* dictionary,
+                                           const float* grad_out, int64_t num_voxels, int samples_per_voxel, int dict_size,
+                                           int feature_dim, int level, float* grad_logits, float* grad_dictionary,
+                                           wisp_stream_t stream) {
+    WISP_REQUIRE(num_voxels >= 0 && samples_per_voxel >= 1 && level >= 0 && level <= 15, "bad sizes");
+    WISP_REQUIRE(dict_size >= 1 && dict_size <= CB_MAX_K && feature_dim >= 1 && feature_dim <= CB_MAX_F, "dictionary too large for the fused kernel");
+    if (num_voxels == 0) return WISP_OK;
+    WISP_REQUIRE(coords && pidx && points && trinkets && logits && dictionary && grad_out && grad_logits && grad_dictionary, "null pointer");
+    const int64_t rows = num_voxels * samples_per_voxel;
+    const dim3 grid((unsigned)ceil_div64(rows, 128)), block(128);
+    const size_t lds = (size_t)dict_size * feature_dim * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (pidx_is_i64)
+        hipLaunchKernelGGL(codebook_trilinear_bwd_kernel<int64_t>, grid, block, lds, s, coords, (const int64_t*)pidx, points, trinkets,
+                           logits, dictionary, grad_out, num_voxels, samples_per_voxel, dict_size, feature_dim, level, grad_logits,
+                           grad_dictionary);
+    else
+        hipLaunchKernelGGL(codebook_trilinear_bwd_kernel<int32_t>, grid, block, lds, s, coords, (const int32_t*)pidx, points, trinkets,
+                           logits, dictionary, grad_out, num_voxels, samples_per_voxel, dict_size, feature_dim, level, grad_logits,
+                           grad_dictionary);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

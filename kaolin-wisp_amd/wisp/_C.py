@@ -40,6 +40,8 @@ SIGNATURES = {
     "wisp_spc_trilinear_coeffs": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_trilinear_fwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp],
+    "wisp_codebook_trilinear_fwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
+    "wisp_codebook_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "wisp_mark_pack_boundaries_i64": [c_vp, c_i64, c_vp, c_vp],
     "wisp_mark_pack_boundaries_i32": [c_vp, c_i64, c_vp, c_vp],
     "wisp_scan_workspace_bytes": [c_i64],
@@ -331,6 +333,37 @@ def spc_trilinear_backward(coords, pidx, points, trinkets, grad_out, feats_shape
     _check(lib.wisp_spc_trilinear_bwd(_p(coords), _p(pidx), is64, _p(points), _p(trinkets), _p(grad_out), V, S, C, level,
                                       _p(grad), _stream()), "spc_trilinear_bwd")
     return grad
+
+
+def codebook_trilinear_forward(coords, pidx, points, trinkets, logits, dictionary, level, training):
+    """Fused VQAD lookup + trilinear blend: coords [V,S,3] -> f32 [V,S,F]."""
+    coords = _need(coords, torch.float32, "coords")
+    pidx, is64 = _pidx_arg(pidx)
+    logits = _need(logits, torch.float32, "logits")
+    dictionary = _need(dictionary, torch.float32, "dictionary")
+    V, S = coords.shape[0], coords.shape[1]
+    K, F = dictionary.shape
+    out = torch.empty(V, S, F, dtype=torch.float32, device=coords.device)
+    _check(lib.wisp_codebook_trilinear_fwd(_p(coords), _p(pidx), is64, _p(_need(points, torch.int16, "points")),
+                                           _p(_need(trinkets, torch.int32, "trinkets")), _p(logits), _p(dictionary), V, S, K, F,
+                                           level, int(training), _p(out), _stream()), "codebook_trilinear_fwd")
+    return out
+
+
+def codebook_trilinear_backward(coords, pidx, points, trinkets, logits, dictionary, grad_out, level):
+    coords = _need(coords, torch.float32, "coords")
+    pidx, is64 = _pidx_arg(pidx)
+    logits = _need(logits, torch.float32, "logits")
+    dictionary = _need(dictionary, torch.float32, "dictionary")
+    grad_out = _need(grad_out, torch.float32, "grad_out")
+    V, S = coords.shape[0], coords.shape[1]
+    K, F = dictionary.shape
+    g_logits = torch.zeros_like(logits)
+    g_dict = torch.zeros_like(dictionary)
+    _check(lib.wisp_codebook_trilinear_bwd(_p(coords), _p(pidx), is64, _p(_need(points, torch.int16, "points")),
+                                           _p(_need(trinkets, torch.int32, "trinkets")), _p(logits), _p(dictionary), _p(grad_out),
+                                           V, S, K, F, level, _p(g_logits), _p(g_dict), _stream()), "codebook_trilinear_bwd")
+    return g_logits, g_dict
 
 
 # ------------------------------------------------------------------------------------------------ raymarch

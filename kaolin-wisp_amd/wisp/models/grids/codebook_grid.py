@@ -1,7 +1,7 @@
 """CodebookOctreeGrid (VQAD): octree corners store logits over a small dictionary of feature vectors.
-Surface of wisp/models/grids/codebook_grid.py:21-200.  The trilinear coefficients come from the HIP kernel; the
-softmax / straight-through selection is plain tensor algebra on the gathered [corners, 2^bitwidth] logits (a fused
-kernel is the next step for this row)."""
+Surface of wisp/models/grids/codebook_grid.py:21-200.  Selection (straight-through softmax one-hot / argmax) and the
+trilinear blend run as ONE fused HIP kernel per level (csrc/spc_interp.hip) when the dictionary is small enough
+(<= 256 entries, <= 16 features, fp32); otherwise the reference formulation on gathered logits is used."""
 from typing import Any, Dict
 
 import torch
@@ -27,6 +27,7 @@ class CodebookOctreeGrid(OctreeGrid):
     ):
         """Same arguments as OctreeGrid plus codebook_bitwidth: every level has a dictionary of 2**bitwidth vectors."""
         self.bitwidth = codebook_bitwidth
+        self.fused = True             # fused selection + blend kernel (csrc/spc_interp.hip)
         super().__init__(blas=blas, feature_dim=feature_dim, num_lods=num_lods, interpolation_type=interpolation_type,
                          multiscale_type=multiscale_type, feature_std=feature_std, feature_bias=feature_bias)
 
@@ -64,6 +65,11 @@ class CodebookOctreeGrid(OctreeGrid):
             if self.interpolation_type == 'closest':
                 raise NotImplementedError
             raise Exception(f"Interpolation mode {self.interpolation_type} is not supported.")
+        dictionary = self.dictionary[lod_idx]
+        if (self.fused and coords.is_cuda and feats.dtype == torch.float32 and feats.ndim == 2
+                and dictionary.shape[0] <= 256 and dictionary.shape[1] <= 16 and not torch.is_autocast_enabled()):
+            return grid_ops.codebook_interpolate_trilinear(coords, pidx, self.blas.points, self.trinkets.int(), feats,
+                                                           dictionary, self.active_lods[lod_idx], self.training)
         fs = torch.zeros(batch, num_samples, self.feature_dim, device=coords.device)
         valid = pidx > -1
         vp = pidx[valid].long()

@@ -103,3 +103,30 @@ def coords_to_trilinear_coeffs(coords, points, level):
     """coords [V,S,3] + the quantised voxel origin of every row ([V,3] or [V,S,3] repeated) -> [V,S,8]."""
     pts = points[:, 0] if points.ndim == 3 else points
     return _hip().spc_trilinear_coeffs(coords.contiguous(), pts.contiguous(), level)
+
+
+class CodebookTrilinear(torch.autograd.Function):
+    """Fused VQAD dictionary selection (straight-through softmax one-hot in training, argmax in eval) + trilinear blend;
+    what CodebookOctreeGrid._index_features / _interpolate compute (wisp/models/grids/codebook_grid.py:103-172)."""
+
+    @staticmethod
+    def forward(ctx, coords, pidx, points, trinkets, logits, dictionary, level, training):
+        out = _hip().codebook_trilinear_forward(coords.detach(), pidx, points, trinkets, logits.detach(), dictionary.detach(),
+                                                level, training)
+        ctx.save_for_backward(coords.detach(), pidx, points, trinkets, logits.detach(), dictionary.detach())
+        ctx.level, ctx.training = level, training
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        coords, pidx, points, trinkets, logits, dictionary = ctx.saved_tensors
+        if not ctx.training:
+            return (None,) * 8          # eval-mode lookup is a hard argmax: no gradient path (as in the reference)
+        gl, gd = _hip().codebook_trilinear_backward(coords, pidx, points, trinkets, logits, dictionary,
+                                                    grad_out.contiguous().float(), ctx.level)
+        return None, None, None, None, gl, gd, None, None
+
+
+def codebook_interpolate_trilinear(coords, pidx, points, trinkets, logits, dictionary, level, training):
+    """coords [V,S,3], pidx [V] -> [V,S,F] float32."""
+    return CodebookTrilinear.apply(coords.contiguous(), pidx, points, trinkets, logits, dictionary, level, training)

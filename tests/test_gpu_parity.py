@@ -579,14 +579,16 @@ def test_octree_grid_interpolate_matches_oracle(mtype, half):
     assert rm.samples.shape[1] == 3
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("training", [True, False])
-def test_codebook_grid_matches_oracle(training):
+def test_codebook_grid_matches_oracle(training, fused):
     from oracle import octree_grid as og
     from wisp.models.grids import CodebookOctreeGrid
     blas, oblas = _sparse_blas(5, 3000, 111)
     torch.manual_seed(2)
     grid = CodebookOctreeGrid(blas, feature_dim=5, num_lods=4, multiscale_type='sum', feature_std=0.7, codebook_bitwidth=4).to(DEV)
     grid.train(training)
+    grid.fused = fused
     pd, pyd = ospc.make_dual(oblas.points, oblas.pyramid)
     tr, _ = ospc.make_trinkets(oblas.points, oblas.pyramid, pd, pyd)
     rng = np.random.default_rng(112)
