@@ -720,6 +720,6 @@ def test_validation_render_and_psnr_log_line():
     parts = render(pipe, rays, render_batch=300, channels=["rgb", "depth"])
     assert parts.rgb.shape == (1000, 3) and parts.hit.shape == (1000,)
     np.testing.assert_allclose(parts.rgb.cpu().numpy(), whole.rgb.cpu().numpy(), atol=1e-6)
-    gts = whole.rgb.clamp(0, 1)
+    gts = (whole.rgb + 0.01).clamp(0, 1)             # uniform 0.01 error -> 40 dB
     val, line = evaluate_psnr(pipe, [(rays, gts)], epoch=3, max_epochs=10, render_batch=256)
-    assert re.search(r"EPOCH 3/10 \| lod15 psnr: (\d+\.\d\d)$", line) and val > 60
+    assert re.search(r"EPOCH 3/10 \| lod15 psnr: (\d+\.\d\d)$", line) and 39.0 < val < 41.5
