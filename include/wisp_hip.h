@@ -264,11 +264,13 @@ int wisp_nerf_mlp_bwd(const void* feats, int dtype_io, const float* dirs, int64_
  * Optimizer  (replaces torch.optim.AdamW / apex FusedAdam over the flat parameter buffer,
  * wisp/trainers/base_trainer.py:205-235, wisp/config/presets/torch.py:22-58)
  * One launch over n contiguous fp32 parameters; grad_scale multiplies the gradient first
- * (1/world_size for data-parallel mean).  step is the 1-based step count.
+ * (1/world_size for data-parallel mean).  step is the 1-based step count.  bf16_shadow (optional, bf16 [n]) receives a
+ * bf16 copy of the updated parameters so that the bf16 forward does not need a separate cast pass over the table.
  */
 int wisp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                    float grad_scale, int zero_grad /* also zero grad[] */, wisp_stream_t stream);
+                    float grad_scale, int zero_grad /* also zero grad[] */, void* bf16_shadow,
+                    wisp_stream_t stream);
 
 #ifdef __cplusplus
 }

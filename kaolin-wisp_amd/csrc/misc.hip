@@ -13,7 +13,8 @@ extern "C" int wisp_abi_version(void) { return 1; }
 
 __global__ void __launch_bounds__(256)
 adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale, int zero_grad) {
+             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale, int zero_grad,
+             __hip_bfloat16* __restrict__ shadow) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
@@ -33,6 +34,10 @@ adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m
             *reinterpret_cast<float4*>(m + i) = mv;
             *reinterpret_cast<float4*>(v + i) = vv;
             if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (shadow) {                                                // bf16 copy of the updated parameters
+#pragma unroll
+                for (int k = 0; k < 4; ++k) shadow[i + k] = __float2bfloat16(pp[k]);
+            }
         } else {
             for (int64_t j = i; j < n; ++j) {
                 const float gr = g[j] * gscale;
@@ -43,6 +48,7 @@ adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m
                 pj -= (lr / bc1) * (mj / denom);
                 p[j] = pj; m[j] = mj; v[j] = vj;
                 if (zero_grad) g[j] = 0.0f;
+                if (shadow) shadow[j] = __float2bfloat16(pj);
             }
         }
     }
@@ -50,7 +56,7 @@ adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m
 
 extern "C" int wisp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                                float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
-                               int zero_grad, wisp_stream_t stream) {
+                               int zero_grad, void* bf16_shadow, wisp_stream_t stream) {
     WISP_REQUIRE(n >= 0 && step >= 1, "bad n / step");
     if (n == 0) return WISP_OK;
     WISP_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null pointer");
@@ -61,7 +67,8 @@ extern "C" int wisp_adamw_step(float* param, const float* grad, float* exp_avg, 
     const int64_t groups = ceil_div64(n, 4);
     const int grid = (int)min64(ceil_div64(groups, 256), 4096);
     hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, const_cast<float*>(grad),
-                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale, zero_grad);
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale, zero_grad,
+                       (__hip_bfloat16*)bf16_shadow);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }

@@ -63,7 +63,7 @@ SIGNATURES = {
     "wisp_nerf_mlp_fwd": [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp],
     "wisp_nerf_mlp_bwd": [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_nerf_mlp_workspace_floats": [],
-    "wisp_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp],
+    "wisp_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp, c_vp],
     "wisp_last_error": [],
     "wisp_abi_version": [],
 }
@@ -108,7 +108,16 @@ def _check(rc, what):
         raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
 
 
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream          # ~0.3 us; torch.cuda.current_stream() costs ~12 us per call
+except AttributeError:                                         # pragma: no cover
+    _raw_stream = None
+
+
 def _stream():
+    """the HIP stream torch is currently launching on (the kernels must be ordered with torch's own work)."""
+    if _raw_stream is not None:
+        return c_vp(_raw_stream(torch.cuda.current_device()))
     return c_vp(torch.cuda.current_stream().cuda_stream)
 
 
@@ -507,11 +516,13 @@ def find_depth_bound(query, curr_idxes, nug_depth):
 
 # ------------------------------------------------------------------------------------------------ optimizer
 def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0,
-               zero_grad=False):
+               zero_grad=False, bf16_shadow=None):
     for t in (param, grad, exp_avg, exp_avg_sq):
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    if bf16_shadow is not None:
+        assert bf16_shadow.dtype == torch.bfloat16 and bf16_shadow.numel() == param.numel() and bf16_shadow.is_contiguous()
     _check(lib.wisp_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2, eps,
-                               weight_decay, step, grad_scale, int(zero_grad), _stream()), "adamw_step")
+                               weight_decay, step, grad_scale, int(zero_grad), _p(bf16_shadow), _stream()), "adamw_step")
 
 
 # ------------------------------------------------------------------------------------------------ fused NeRF decoder

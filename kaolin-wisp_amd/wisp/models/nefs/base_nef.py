@@ -68,11 +68,7 @@ class BaseNeuralField(WispModule):
             if not provides:
                 continue
             torch.cuda.nvtx.range_push(f"{fn.__name__}")
-            spec = inspect.getfullargspec(fn)
-            n_opt = len(spec.defaults) if spec.defaults else 0
-            names = spec.args[1:]                                   # drop self
-            required = names[:len(names) - n_opt] if n_opt else names
-            optional = names[len(names) - n_opt:] if n_opt else []
+            required, optional = self._fn_args(fn)
             call = {}
             for a in required:
                 if a not in kwargs:
@@ -91,6 +87,21 @@ class BaseNeuralField(WispModule):
         if isinstance(channels, list):
             return [results[c] for c in channels]
         return results
+
+    _ARGSPEC_CACHE = {}
+
+    @staticmethod
+    def _fn_args(fn):
+        """(required, optional) argument names of a registered forward function, introspected once."""
+        key = getattr(fn, "__func__", fn)
+        hit = BaseNeuralField._ARGSPEC_CACHE.get(key)
+        if hit is None:
+            spec = inspect.getfullargspec(fn)
+            n_opt = len(spec.defaults) if spec.defaults else 0
+            names = spec.args[1:]                                   # drop self
+            hit = (names[:len(names) - n_opt] if n_opt else names, names[len(names) - n_opt:] if n_opt else [])
+            BaseNeuralField._ARGSPEC_CACHE[key] = hit
+        return hit
 
     def public_properties(self) -> Dict[str, Any]:
         return dict()

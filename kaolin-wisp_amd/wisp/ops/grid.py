@@ -31,8 +31,11 @@ class HashGridInterpolate(torch.autograd.Function):
         assert coords.shape[-1] in [2, 3]
         table = codebook
         if torch.is_autocast_enabled():
-            # the reference casts to fp16 under autocast (grid.py:88-89); follow the active autocast dtype (bf16 on MI355X)
-            table = codebook.to(torch.get_autocast_gpu_dtype())
+            # the reference casts to fp16 under autocast (grid.py:88-89); follow the active autocast dtype (bf16 on MI355X).
+            # A trainer may keep an up-to-date low-precision copy next to the master weights (refreshed by the fused AdamW).
+            dt = torch.get_autocast_gpu_dtype()
+            shadow = getattr(codebook, '_wisp_shadow', None)
+            table = shadow if (shadow is not None and shadow.dtype == dt) else codebook.to(dt)
         res = _as_int_list(resolutions)
         feats = _hip().hashgrid_interpolate(coords.detach(), table.detach(), codebook_first_idx, res, codebook_bitwidth,
                                             zero_from_col)

@@ -47,8 +47,7 @@ class BaseTracer(WispModule):
         if unsupported:
             raise Exception(f"Channels {unsupported} are not supported in the tracer {type(self)} or neural field {type(nef)}.")
 
-        base_args = set(inspect.signature(BaseTracer.trace).parameters) - {"self", "args", "kwargs"}
-        own_args = [a for a in inspect.signature(self.trace).parameters if a not in base_args | {"self", "args", "kwargs"}]
+        own_args = self._trace_arg_names()
         call = {}
         for a in own_args:
             if a in kwargs:
@@ -59,6 +58,17 @@ class BaseTracer(WispModule):
                     call[a] = default
         with torch.cuda.nvtx.range("Tracer.trace"):
             return self.trace(nef, rays, requested, extra, **call)
+
+    def _trace_arg_names(self):
+        """names of trace()'s tracer-specific keyword arguments (introspected once per class, not per call)."""
+        cache = BaseTracer._ARG_CACHE
+        key = type(self).trace
+        if key not in cache:
+            base_args = set(inspect.signature(BaseTracer.trace).parameters) - {"self", "args", "kwargs"}
+            cache[key] = [a for a in inspect.signature(key).parameters if a not in base_args | {"self", "args", "kwargs"}]
+        return cache[key]
+
+    _ARG_CACHE = {}
 
     def public_properties(self) -> Dict[str, Any]:
         return dict()

@@ -50,6 +50,18 @@ class FlatParams:
             self.ranges[g] = (start, off)
         self.exp_avg = torch.zeros_like(self.data)
         self.exp_avg_sq = torch.zeros_like(self.data)
+        self.shadow = None
+        self._grid_params = [(p, (p.data_ptr() - self.data.data_ptr()) // 4) for n, p in groups["grid"]]
+
+    def enable_bf16_shadow(self):
+        """Keep a bf16 copy of the grid parameters, refreshed by the fused AdamW kernel, and hand it to the hash-grid op
+        (attribute `_wisp_shadow`), so that the bf16 forward needs no cast pass over the 41.7 MB table."""
+        a, b = self.ranges["grid"]
+        if b <= a:
+            return
+        self.shadow = self.data[a:b].to(torch.bfloat16)
+        for p, off in self._grid_params:
+            p._wisp_shadow = self.shadow[off - a:off - a + p.numel()].view(p.shape)
 
 
 class MultiviewTrainStep:
@@ -64,6 +76,8 @@ class MultiviewTrainStep:
         self.target_sample_size = target_sample_size
         self.max_rays = max_rays
         self.enable_amp = enable_amp
+        if enable_amp:
+            self.flat.enable_bf16_shadow()
         self.milestones = sorted(scheduler_milestones or [])
         self.gamma = scheduler_gamma
         self.total_iterations = 0
@@ -89,7 +103,8 @@ class MultiviewTrainStep:
             a, b = f.ranges[g]
             if b > a:
                 C.adamw_step(f.data[a:b], f.grad[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], lr * s, self.betas[0],
-                             self.betas[1], self.eps, self.weight_decay, self.opt_steps, grad_scale=gs, zero_grad=True)
+                             self.betas[1], self.eps, self.weight_decay, self.opt_steps, grad_scale=gs, zero_grad=True,
+                             bf16_shadow=f.shadow if g == "grid" else None)
 
     def allreduce_grads(self):
         if self.world > 1:

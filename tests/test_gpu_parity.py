@@ -305,8 +305,9 @@ def test_adamw_matches_torch():
         ref.grad = g.clone() * step
         opt.step()
         gg = (g * step * 2).contiguous()
-        _C().adamw_step(p, gg, m, v, 1e-2, 0.9, 0.999, 1e-15, 1e-3, step, grad_scale=0.5, zero_grad=True)
-        assert float(gg.abs().max()) == 0.0
+        shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        _C().adamw_step(p, gg, m, v, 1e-2, 0.9, 0.999, 1e-15, 1e-3, step, grad_scale=0.5, zero_grad=True, bf16_shadow=shadow)
+        assert float(gg.abs().max()) == 0.0 and torch.equal(shadow, p.bfloat16())
     np.testing.assert_allclose(p.cpu().numpy(), ref.detach().cpu().numpy(), atol=2e-6)
 
 
