@@ -85,6 +85,10 @@ class MultiviewTrainStep:
         self.num_rays = None
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.group = process_group
+        # WISP_FORCE_ALLREDUCE=1 runs the collective even with one rank (exercises the RCCL path on a single-GPU box)
+        import os
+        self.force_allreduce = (os.environ.get("WISP_FORCE_ALLREDUCE", "0") == "1" and dist.is_available()
+                                and dist.is_initialized())
         # prune draws must be identical on every rank so the replicated octrees stay identical
         self._prune_gen = torch.Generator().manual_seed(seed)
 
@@ -107,7 +111,7 @@ class MultiviewTrainStep:
                              bf16_shadow=f.shadow if g == "grid" else None)
 
     def allreduce_grads(self):
-        if self.world > 1:
+        if self.world > 1 or self.force_allreduce:
             dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)     # RCCL over xGMI
 
     # -------------------------------------------------------------------------------------------- reference hooks

@@ -47,7 +47,7 @@ def _worker(rank, world, port, out):
     lo, hi = shard_rays(100, rank, world)
     torch.nn.functional.smooth_l1_loss(model(O[lo:hi], D[lo:hi]), T[lo:hi], reduction='none').mean().backward()
     step = MultiviewTrainStep.__new__(MultiviewTrainStep)
-    step.flat, step.world, step.group = flat, world, None
+    step.flat, step.world, step.group, step.force_allreduce = flat, world, None, False
     step.allreduce_grads()
     avg = flat.grad / world                                   # what adamw_step's grad_scale = 1/world applies
     ref100 = TinyField()
