@@ -235,6 +235,15 @@ int wisp_composite_bwd(const float* grad_rgb /* [R,3] */, const float* grad_alph
 int wisp_find_depth_bound(const float* query /* [P] */, const int32_t* curr_idxes /* [P] */, const float* nug_depth,
                           int64_t num_packs, int64_t num_nugs, int32_t* out /* [P] */, wisp_stream_t stream);
 
+/* One iteration of the sphere-tracing loop of PackedSDFTracer.trace (wisp/tracers/packed_sdf_tracer.py:118-146) for all
+ * rays that own nuggets ("packs"): t += dist; convergence (|dist| < thr_close or |dist + dist_prev| / 2 < thr_avg);
+ * far plane; nugget search as wisp_find_depth_bound; jump to the next cell; new query point x.  All state arrays are
+ * [P] (x is [P,3]) and updated in place; curr_in / curr_out double-buffer the current nugget index. */
+int wisp_sphere_trace_step(int64_t num_packs, const float* nug_o, const float* nug_d, const float* nug_depth,
+                           const int32_t* nug_pidx, float dist_max, float thr_close, float thr_avg, float* t,
+                           const float* dist, float* dist_prev, uint8_t* mask, uint8_t* hit, const int32_t* curr_in,
+                           int32_t* curr_out, int64_t* curr_pidx, float* x, wisp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused radiance-field decoder  (replaces NeuralRadianceField.rgba after grid.interpolate,
  * wisp/models/nefs/nerf.py:245-264: decoder_density (Linear-ReLU-Linear) -> relu density + 15 geometry

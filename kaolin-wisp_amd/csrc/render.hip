@@ -304,3 +304,80 @@ extern "C" int wisp_find_depth_bound(const float* query, const int32_t* curr_idx
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- fused sphere-trace step
+// One iteration of PackedSDFTracer.trace's marching loop (wisp/tracers/packed_sdf_tracer.py:118-146) for every active
+// ray in ONE launch: advance t by the last distance, convergence tests, far-plane test, nugget search
+// (find_depth_bound, same bounds quirks as above), jump to the next cell's entry, and the new query position.
+// The reference issues ~25 masked torch kernels per iteration for this.
+// State per pack p (= ray with at least one nugget), all updated in place except curr_idx which is double-buffered
+// because pack p reads pack p+1's PREVIOUS index as its search bound:
+//   t, dist, dist_prev f32 ; mask, hit u8 ; curr_in/curr_out i32 ; curr_pidx i64 ; x f32[3]
+__global__ void __launch_bounds__(256)
+sphere_trace_step_kernel(int64_t num_packs, const float* __restrict__ nug_o, const float* __restrict__ nug_d,
+                         const float* __restrict__ nug_depth, const int32_t* __restrict__ nug_pidx, float dist_max,
+                         float thr_close, float thr_avg, float* __restrict__ t, const float* __restrict__ dist, float* __restrict__ dist_prev,
+                         uint8_t* __restrict__ mask, uint8_t* __restrict__ hit, const int32_t* __restrict__ curr_in,
+                         int32_t* __restrict__ curr_out, int64_t* __restrict__ curr_pidx, float* __restrict__ x) {
+#pragma clang fp contract(off)
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= num_packs) return;
+    const int32_t cur = curr_in[p];
+    bool m = mask[p] != 0;
+    bool h = hit[p] != 0;
+    const float dd = dist[p];
+    float tt = t[p] + dd;                                                        // t += dist          (:120)
+    if (m) {
+        h = fabsf(dd) < thr_close;                                               // :122   thr_close = min_dis
+        h = h || (fabsf(dd + dist_prev[p]) * 0.5f < thr_avg);                    // :123-124 thr_avg = 5 min_dis
+        m = tt < dist_max;                                                       // :125
+    }
+    m = m && !h;                                                                 // :126
+    if (m) dist_prev[p] = dd;                                                    // :129
+    // find_depth_bound (:131) - evaluated for every pack with a valid index, exactly like the reference kernel
+    int32_t nxt = -1;
+    if (cur > -1) {
+        uint32_t i = (uint32_t)cur;
+        const uint32_t stop = (p == num_packs - 1) ? (uint32_t)num_packs : (uint32_t)curr_in[p + 1];
+        while (i < stop) {
+            const float entry = nug_depth[2 * (int64_t)i], exit_ = nug_depth[2 * (int64_t)i + 1];
+            if ((tt >= entry && tt <= exit_) || tt < entry) { nxt = (int32_t)i; break; }
+            ++i;
+        }
+    }
+    m = m && (nxt != -1);                                                        // :132
+    const bool jumped = nxt != cur;                                              // :133
+    const int32_t now = m ? nxt : cur;                                           // :134
+    if (m && jumped) tt = nug_depth[2 * (int64_t)now];                           // :136
+    if (m) {                                                                     // :137-139
+        x[p * 3 + 0] = nug_o[p * 3 + 0] + nug_d[p * 3 + 0] * tt;
+        x[p * 3 + 1] = nug_o[p * 3 + 1] + nug_d[p * 3 + 1] * tt;
+        x[p * 3 + 2] = nug_o[p * 3 + 2] + nug_d[p * 3 + 2] * tt;
+        curr_pidx[p] = (int64_t)nug_pidx[now];
+    } else if (mask[p] != 0) {
+        // ray deactivated in this step: x still has to be refreshed with the advanced t (:121 ran before the tests)
+        x[p * 3 + 0] = nug_o[p * 3 + 0] + nug_d[p * 3 + 0] * tt;
+        x[p * 3 + 1] = nug_o[p * 3 + 1] + nug_d[p * 3 + 1] * tt;
+        x[p * 3 + 2] = nug_o[p * 3 + 2] + nug_d[p * 3 + 2] * tt;
+    }
+    t[p] = tt;
+    mask[p] = m ? 1 : 0;
+    hit[p] = h ? 1 : 0;
+    curr_out[p] = now;
+}
+
+extern "C" int wisp_sphere_trace_step(int64_t num_packs, const float* nug_o, const float* nug_d, const float* nug_depth,
+                                      const int32_t* nug_pidx, float dist_max, float thr_close, float thr_avg, float* t,
+                                      const float* dist,
+                                      float* dist_prev, uint8_t* mask, uint8_t* hit, const int32_t* curr_in,
+                                      int32_t* curr_out, int64_t* curr_pidx, float* x, wisp_stream_t stream) {
+    WISP_REQUIRE(num_packs >= 0, "negative count");
+    if (num_packs == 0) return WISP_OK;
+    WISP_REQUIRE(nug_o && nug_d && nug_depth && nug_pidx && t && dist && dist_prev && mask && hit && curr_in && curr_out &&
+                 curr_pidx && x, "null pointer");
+    hipLaunchKernelGGL(sphere_trace_step_kernel, dim3((unsigned)ceil_div64(num_packs, 256)), dim3(256), 0, (hipStream_t)stream,
+                       num_packs, nug_o, nug_d, nug_depth, nug_pidx, dist_max, thr_close, thr_avg, t, dist, dist_prev, mask, hit, curr_in,
+                       curr_out, curr_pidx, x);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

@@ -57,6 +57,7 @@ SIGNATURES = {
     "wisp_packed_sum_reduce": [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
     "wisp_packed_cumsum": [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "wisp_find_depth_bound": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp],
+    "wisp_sphere_trace_step": [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_composite_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_composite_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_nerf_mlp_param_count": [c_i32, c_i32, c_i32],
@@ -512,6 +513,16 @@ def find_depth_bound(query, curr_idxes, nug_depth):
     _check(lib.wisp_find_depth_bound(_p(query), _p(curr_idxes), _p(nug_depth), P, nug_depth.shape[0], _p(out), _stream()),
            "find_depth_bound")
     return out
+
+
+def sphere_trace_step(nug_o, nug_d, nug_depth, nug_pidx, dist_max, thr_close, thr_avg, t, dist, dist_prev, mask, hit,
+                      curr_in, curr_out, curr_pidx, x):
+    """One fused marching iteration (packed_sdf_tracer.py:118-146); all state tensors are updated in place."""
+    P = t.shape[0]
+    _check(lib.wisp_sphere_trace_step(P, _p(nug_o), _p(nug_d), _p(nug_depth), _p(nug_pidx), float(np.float32(dist_max)),
+                                      float(np.float32(thr_close)), float(np.float32(thr_avg)), _p(t), _p(dist), _p(dist_prev),
+                                      _p(mask), _p(hit), _p(curr_in), _p(curr_out), _p(curr_pidx), _p(x), _stream()),
+           "sphere_trace_step")
 
 
 # ------------------------------------------------------------------------------------------------ optimizer
