@@ -21,24 +21,16 @@
 //     atomics are used at all.
 // Fixed shape of this build: IN = 32 grid features, H = 64 hidden, 4 view frequencies (nerf_hash.yaml).
 #include "wisp_common.h"
+#include "nerf_mlp_shape.h"
+#include <cstdlib>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int IN = 32;        // grid feature width
-constexpr int H = 64;         // hidden width
-constexpr int NF = 4;         // view-direction frequencies
-constexpr int PE = 3 + 6 * NF;            // 27
-constexpr int X2 = 15 + PE;               // 42 real colour-MLP inputs
+using namespace wisp_mlp;
 constexpr int K3 = 48;                    // X2 padded to the MFMA K granularity
-constexpr int TS = 32;                    // samples per wave tile
-
-// packed parameter offsets (floats): W1[H,IN] b1[H] W2[16,H] b2[16] W3[H,X2] b3[H] W4[H,H] b4[H] W5[3,H] b5[3]
-constexpr int OW1 = 0, OB1 = OW1 + H * IN, OW2 = OB1 + H, OB2 = OW2 + 16 * H, OW3 = OB2 + 16, OB3 = OW3 + H * X2,
-              OW4 = OB3 + H, OB4 = OW4 + H * H, OW5 = OB4 + H, OB5 = OW5 + 3 * H, NPARAM = OB5 + 3;
-constexpr int NPARAM_PAD = (NPARAM + 63) / 64 * 64;
 
 template <typename TC> struct Traits;
 template <> struct Traits<float> {
@@ -527,7 +519,20 @@ int dispatch(const void* feats, int dtype_io, const float* dirs, int64_t s_total
         case WISP_F16: return launch<TC, __half, W, BWD>(feats, dirs, s_total, params, rgb, density, grad_rgb, grad_density, grad_feats, grad_params, workspace, st); \
         default: return launch<TC, __hip_bfloat16, W, BWD>(feats, dirs, s_total, params, rgb, density, grad_rgb, grad_density, grad_feats, grad_params, workspace, st); \
     }
-    if (compute == WISP_BF16) { WISP_MLP_GO(__bf16, 4) }
+    if (compute == WISP_BF16) {
+        // register-chained bf16 kernels (nerf_mlp_bf16.hip); WISP_MLP_V1=1 selects the LDS-staged version below
+        static const bool v1 = [] { const char* e = getenv("WISP_MLP_V1"); return e && e[0] == '1'; }();
+        if (!v1) {
+            if (!BWD) return wisp_mlp::bf16_forward(feats, dtype_io, dirs, s_total, params, rgb, density, st);
+            int rows = 0;
+            if (int rc = wisp_mlp::bf16_backward(feats, dtype_io, dirs, s_total, params, grad_rgb, grad_density, grad_feats,
+                                                 workspace, &rows, st))
+                return rc;
+            hipLaunchKernelGGL(nerf_mlp_reduce_kernel, dim3((NPARAM + 63) / 64), dim3(1024), 0, st, workspace, rows, grad_params);
+            return 0;
+        }
+        WISP_MLP_GO(__bf16, 4)
+    }
     if (BWD) { WISP_MLP_GO(float, 1) }
     WISP_MLP_GO(float, 2)
 #undef WISP_MLP_GO

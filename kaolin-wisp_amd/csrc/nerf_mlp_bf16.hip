@@ -1,0 +1,607 @@
+// bf16 matrix-core path of the fused radiance-field decoder (see nerf_mlp.hip for what it replaces in the reference).
+//
+// Design: activations never leave registers between layers.
+//   * One wave = one tile of 32 samples; sample n = lane & 31 sits on the N side of v_mfma_f32_32x32x16_bf16, the layer's
+//     weights are the A operand (LDS, rows padded for conflict-free ds_read_b128), so after a layer lane (n, g = lane >> 5)
+//     holds 16 output neurons of ITS sample per 32-row block: accumulator register r <-> neuron 8 (r / 4) + 4 g + r % 4.
+//   * The B operand of the next layer wants 8 K-values per lane.  The order of K inside a contraction is free as long as
+//     A and B agree, so accumulator registers 8 h .. 8 h + 7 of block t ARE K-block 2 t + h of the next layer after a
+//     v_cvt_pk_bf16_f32; the weights are stored in LDS with their columns permuted to match
+//     (slot 16 kb + 8 g + j  <->  neuron phi = 16 kb + 8 (j / 4) + 4 g + j % 4).  No LDS round trip, no shuffles.
+//   * relu is one v_pk_max_i16 per two values on the packed bf16; hidden biases enter as the MFMA C operand (free); the
+//     bias of the first colour layer rides on a constant-one slot of the view-encoding block.
+//   * backward recomputes the forward, keeps the packed activations in registers for the relu masks, back-propagates
+//     through the transposed (also column-permuted) weights with the same chaining, and forms dW = dY^T X with
+//     v_mfma_f32_16x16x32_bf16 whose K dimension is the tile's 32 samples.  For that both operands have to be
+//     transposed (samples from lanes to registers): the packed registers are written to a per-wave LDS image made of
+//     8-byte chunks (sample, 4 features) and read back with ds_read_b64_tr_b16.  Chunk address =
+//     (fq >> 1) * 640 + (2 n + (fq & 1)) * 8 with fq = feature / 4: both the writes and the transposing reads are
+//     bank-conflict free.  dW accumulates in 216 VGPRs for the whole launch; per-wave partials are reduced afterwards.
+//   * bias gradients: one extra MFMA per 16 rows against a constant-ones operand (db3 comes with dW3's ones column).
+#include "wisp_common.h"
+#include "nerf_mlp_shape.h"
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define DEV static __device__ __forceinline__
+
+namespace {
+using namespace wisp_mlp;
+
+// ---------------------------------------------------------------------------------------------- LDS image of the weights
+// slot p = 8 g + j of a chained 16-block <-> neuron offset
+__host__ __device__ constexpr int phi16(int p) { return 8 * ((p & 7) >> 2) + 4 * (p >> 3) + (p & 3); }
+__host__ __device__ constexpr int phi(int s) { return (s & ~15) + phi16(s & 15); }
+
+// forward operands  [out row][K slots], row stride = K + 8 elements
+constexpr int LD1 = 40, LD2 = 72, LD3 = 56, LD4 = 72, LD5 = 72;
+constexpr int L_W1 = 0;                     // [64][32]  natural K (the grid features come straight from HBM)
+constexpr int L_W2 = L_W1 + 64 * LD1;       // [16][64]  chained K
+constexpr int L_W3 = L_W2 + 16 * LD2;       // [64][48]  block 0 chained (density-MLP outputs), blocks 1-2 view encoding
+constexpr int L_W4 = L_W3 + 64 * LD3;       // [64][64]  chained
+constexpr int L_W5 = L_W4 + 64 * LD4;       // [ 4][64]  chained (3 real rows)
+constexpr int L_FWD_END = L_W5 + 4 * LD5;
+// backward operands [in row][out-neuron slots]
+constexpr int LT5 = 24, LT4 = 72, LT3 = 72, LT2 = 24, LT1 = 72;
+constexpr int L_W5T = L_FWD_END;            // [64][16]  slot p < 3 <-> colour channel p
+constexpr int L_W4T = L_W5T + 64 * LT5;     // [64][64]
+constexpr int L_W3T = L_W4T + 64 * LT4;     // [16][64]  row m <-> density-MLP output m (row 0 unused)
+constexpr int L_W2T = L_W3T + 16 * LT3;     // [64][16]
+constexpr int L_W1T = L_W2T + 64 * LT2;     // [32][64]
+constexpr int L_BWD_END = L_W1T + 32 * LT1;
+
+constexpr int TILE_REGION = 640;            // bytes between feature-octet regions of a transposition image
+constexpr int TILE_BYTES = 8 * TILE_REGION; // 64 features x 32 samples
+constexpr int ONES_SLOT = 16 + PE;          // = 43: feature index (within the 48-wide colour input) that holds 1.0
+
+// Prologue: the packed fp32 parameters are first copied to an LDS staging area with coalesced loads (one global
+// round trip), then scattered into the permuted bf16 operand images from there.
+DEV void stage_params(float* stg, const float* __restrict__ P, int tid, int nthreads) {
+    for (int e = tid; e < NPARAM; e += nthreads) stg[e] = P[e];
+}
+template <bool BWD>
+DEV void stage_weights(__bf16* sw, const float* P, int tid, int nthreads) {
+    for (int e = tid; e < 64 * 32; e += nthreads) { const int r = e >> 5, c = e & 31; sw[L_W1 + r * LD1 + c] = (__bf16)P[OW1 + r * IN + c]; }
+    for (int e = tid; e < 16 * 64; e += nthreads) { const int r = e >> 6, s = e & 63; sw[L_W2 + r * LD2 + s] = (__bf16)P[OW2 + r * H + phi(s)]; }
+    for (int e = tid; e < 64 * 48; e += nthreads) {
+        const int r = e / 48, s = e % 48;
+        float v = 0.0f;
+        if (s < 16) { const int m = phi16(s); if (m) v = P[OW3 + r * X2 + m - 1]; }
+        else if (s < ONES_SLOT) v = P[OW3 + r * X2 + s - 1];          // encoding element s - 16 <-> column 15 + (s - 16)
+        else if (s == ONES_SLOT) v = P[OB3 + r];
+        sw[L_W3 + r * LD3 + s] = (__bf16)v;
+    }
+    for (int e = tid; e < 64 * 64; e += nthreads) { const int r = e >> 6, s = e & 63; sw[L_W4 + r * LD4 + s] = (__bf16)P[OW4 + r * H + phi(s)]; }
+    for (int e = tid; e < 4 * 64; e += nthreads) { const int r = e >> 6, s = e & 63; sw[L_W5 + r * LD5 + s] = (__bf16)(r < 3 ? P[OW5 + r * H + phi(s)] : 0.0f); }
+    if (BWD) {
+        for (int e = tid; e < 64 * 16; e += nthreads) { const int k = e >> 4, p = e & 15; sw[L_W5T + k * LT5 + p] = (__bf16)(p < 3 ? P[OW5 + p * H + k] : 0.0f); }
+        for (int e = tid; e < 64 * 64; e += nthreads) { const int k = e >> 6, s = e & 63; sw[L_W4T + k * LT4 + s] = (__bf16)P[OW4 + phi(s) * H + k]; }
+        for (int e = tid; e < 16 * 64; e += nthreads) { const int m = e >> 6, s = e & 63; sw[L_W3T + m * LT3 + s] = (__bf16)(m ? P[OW3 + phi(s) * X2 + m - 1] : 0.0f); }
+        for (int e = tid; e < 64 * 16; e += nthreads) { const int k = e >> 4, p = e & 15; sw[L_W2T + k * LT2 + p] = (__bf16)P[OW2 + phi16(p) * H + k]; }
+        for (int e = tid; e < 32 * 64; e += nthreads) { const int k = e >> 6, s = e & 63; sw[L_W1T + k * LT1 + s] = (__bf16)P[OW1 + phi(s) * IN + k]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- register helpers
+DEV int acc_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+
+DEV floatx16 zero16() { floatx16 z; _Pragma("unroll") for (int r = 0; r < 16; ++r) z[r] = 0.0f; return z; }
+DEV floatx4 zero4() { floatx4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+// two floats -> one dword of two bf16 (v_cvt_pk_bf16_f32); the explicit pair keeps the compiler from converting singly
+DEV unsigned cvt2(float a, float b) {
+    const floatx2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+// NOTE: every 16-bit lane operation below is written on the WHOLE 8-element vector.  Bit-casting one extracted dword to
+// a 2 x i16 vector (u32x4 -> [j] -> s16x2) is mis-folded by this compiler: all four dwords end up using dword 0.
+template <int BASE, bool RELU> DEV bf16x8 pack8(const floatx16& a) {
+    u32x4 w;
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) w[j] = cvt2(a[BASE + 2 * j], a[BASE + 2 * j + 1]);
+    if (RELU) {                                  // sign bit set <=> negative: integer max with 0 on the bit patterns
+        const s16x8 s = __builtin_elementwise_max(__builtin_bit_cast(s16x8, w), (s16x8)(0));
+        return __builtin_bit_cast(bf16x8, s);
+    }
+    return __builtin_bit_cast(bf16x8, w);
+}
+DEV bf16x8 pack8f(const float v[8]) {
+    u32x4 w;
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) w[j] = cvt2(v[2 * j], v[2 * j + 1]);
+    return __builtin_bit_cast(bf16x8, w);
+}
+// BASE.. of `a` as bf16 where the relu output h is positive (bit pattern 0 or positive), else 0
+template <int BASE> DEV bf16x8 pack8_masked(const floatx16& a, bf16x8 h) {
+    // mask = (0 - h) >> 15 per 16-bit lane = 0xffff where h > 0.  Spelled as two packed instructions: left to itself the
+    // compiler rewrites the expression into two compares, two selects and a permute per dword.
+    const u32x4 hw = __builtin_bit_cast(u32x4, h);
+    u32x4 w;
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {
+        unsigned m;
+        asm("v_pk_sub_i16 %0, 0, %1\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=v"(m) : "v"(hw[j]));
+        w[j] = cvt2(a[BASE + 2 * j], a[BASE + 2 * j + 1]) & m;
+    }
+    return __builtin_bit_cast(bf16x8, w);
+}
+DEV floatx16 mma32(bf16x8 a, bf16x8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+DEV floatx4 mma16(bf16x8 a, bf16x8 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// A operand: 8 consecutive slots of one LDS row
+DEV bf16x8 lds_a(const __bf16* lane_row, int elem_off) { return *reinterpret_cast<const bf16x8*>(lane_row + elem_off); }
+
+// transposition image: per-lane write pointers  wc = img + (2 n + g) * 8  (chained halves), wn = img + g * 640 + n * 16
+DEV void store_chained(unsigned char* wc, int kb, bf16x8 p) {
+    bf16x4 lo = {p[0], p[1], p[2], p[3]}, hi = {p[4], p[5], p[6], p[7]};
+    *reinterpret_cast<bf16x4*>(wc + (2 * kb) * TILE_REGION) = lo;
+    *reinterpret_cast<bf16x4*>(wc + (2 * kb + 1) * TILE_REGION) = hi;
+}
+DEV void store_natural(unsigned char* wn, int kb, bf16x8 p) { *reinterpret_cast<bf16x8*>(wn + 2 * kb * TILE_REGION) = p; }
+// operand of the 16x16x32 MFMA for feature block fb: lane (feature l & 15, kg = l >> 4) gets samples 4 kg + {0..3} and
+// 16 + 4 kg + {0..3};  tr = img + ((l >> 1) & 1) * 640 + (8 kg + 2 ((l >> 2) & 3) + (l & 1)) * 8
+DEV bf16x8 load_transposed(const unsigned char* tr, int fb) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tr + fb * 2 * TILE_REGION));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tr + fb * 2 * TILE_REGION + 256));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename T> DEV float io_to_f(T v);
+template <> __device__ __forceinline__ float io_to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float io_to_f<__half>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ float io_to_f<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+
+// 8 consecutive input features as a bf16 operand
+template <typename TIO> DEV bf16x8 load_feats8(const TIO* p, bool live) {
+    bf16x8 v;
+    if (!live) { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.0f; return v; }
+    if (sizeof(TIO) == 2 && !__is_same(TIO, __half)) return *reinterpret_cast<const bf16x8*>(p);
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = (__bf16)io_to_f<TIO>(p[j]);
+    return v;
+}
+template <typename TIO> DEV void store_grad4(TIO* p, float a, float b, float c, float d) {
+    if (sizeof(TIO) == 2 && !__is_same(TIO, __half)) {
+        bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+        *reinterpret_cast<bf16x4*>(p) = v;
+    } else if (sizeof(TIO) == 2) {
+        __half2* q = reinterpret_cast<__half2*>(p);
+        q[0] = __floats2half2_rn(a, b); q[1] = __floats2half2_rn(c, d);
+    } else {
+        float4 v = {a, b, c, d};
+        *reinterpret_cast<float4*>(p) = v;
+    }
+}
+
+// view-direction encoding [d ; sin(2^k d) k-major ; cos(2^k d) k-major] (positional_embedder.py:61-65) + the ones slot, as the
+// two natural-order K blocks of the colour input: element e = 16 (kb - 1) + 8 g + j
+DEV void encode_dir(const float d[3], int g, bf16x8& k1, bf16x8& k2) {
+    float S[NF][3], C[NF][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float sv, cv;
+        __sincosf(d[a], &sv, &cv);
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            S[k][a] = sv; C[k][a] = cv;
+            const float s2 = 2.0f * sv * cv, c2 = 1.0f - 2.0f * sv * sv;      // angle doubling
+            sv = s2; cv = c2;
+        }
+    }
+    const float a1[8] = {d[0], d[1], d[2], S[0][0], S[0][1], S[0][2], S[1][0], S[1][1]};
+    const float b1[8] = {S[1][2], S[2][0], S[2][1], S[2][2], S[3][0], S[3][1], S[3][2], C[0][0]};
+    const float a2[8] = {C[0][1], C[0][2], C[1][0], C[1][1], C[1][2], C[2][0], C[2][1], C[2][2]};
+    const float b2[8] = {C[3][0], C[3][1], C[3][2], 1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float v1[8], v2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v1[j] = g ? b1[j] : a1[j]; v2[j] = g ? b2[j] : a2[j]; }
+    k1 = pack8f(v1); k2 = pack8f(v2);
+}
+
+// everything of one tile that the backward pass needs again
+struct Acts {
+    bf16x8 x0[2], h1[4], x2[3], h2[4], h3[4];
+    float y0, sg[3];
+};
+
+struct LaneConst {
+    int n, g;
+    const __bf16 *w1, *w2, *w3, *w4, *w5;          // this lane's row of each forward operand (+ 8 g)
+    floatx16 b1[2], b4[2];                          // hidden biases in accumulator layout
+    float b2[8], b5[3];
+};
+
+DEV void lane_const(LaneConst& L, const __bf16* sw, const float* P, int lane) {
+    L.n = lane & 31; L.g = lane >> 5;
+    L.w1 = sw + L_W1 + L.n * LD1 + 8 * L.g;
+    L.w2 = sw + L_W2 + (L.n & 15) * LD2 + 8 * L.g;
+    L.w3 = sw + L_W3 + L.n * LD3 + 8 * L.g;
+    L.w4 = sw + L_W4 + L.n * LD4 + 8 * L.g;
+    L.w5 = sw + L_W5 + (L.n < 3 ? L.n : 3) * LD5 + 8 * L.g;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            L.b1[t][r] = P[OB1 + 32 * t + acc_row(r, L.g)];
+            L.b4[t][r] = P[OB4 + 32 * t + acc_row(r, L.g)];
+        }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) L.b2[r] = P[OB2 + acc_row(r, L.g)];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) L.b5[c] = P[OB5 + c];
+}
+
+// forward of one tile; x0 and the view direction are already in registers
+DEV void forward_tile(const LaneConst& L, const float d[3], Acts& A) {
+    // L1: h1 = relu(W1 x0 + b1)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        floatx16 acc = L.b1[t];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) acc = mma32(lds_a(L.w1, t * 32 * LD1 + 16 * kb), A.x0[kb], acc);
+        A.h1[2 * t] = pack8<0, true>(acc);
+        A.h1[2 * t + 1] = pack8<8, true>(acc);
+    }
+    // L2: y = W2 h1 + b2 (16 rows = accumulator registers 0..7); density = relu(y0); y[1..15] feed the colour MLP
+    {
+        floatx16 acc = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) acc = mma32(lds_a(L.w2, 16 * kb), A.h1[kb], acc);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] += L.b2[r];
+        A.y0 = acc[0];                                   // row 0 on the g = 0 lanes
+        if (L.g == 0) acc[0] = 0.0f;                     // slot of y0 in the colour input (its weight column is zero)
+        A.x2[0] = pack8<0, false>(acc);
+    }
+    encode_dir(d, L.g, A.x2[1], A.x2[2]);
+    // L3: h2 = relu(W3 x2 + b3)   (b3 rides on the ones slot)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        floatx16 acc = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) acc = mma32(lds_a(L.w3, t * 32 * LD3 + 16 * kb), A.x2[kb], acc);
+        A.h2[2 * t] = pack8<0, true>(acc);
+        A.h2[2 * t + 1] = pack8<8, true>(acc);
+    }
+    // L4: h3 = relu(W4 h2 + b4)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        floatx16 acc = L.b4[t];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) acc = mma32(lds_a(L.w4, t * 32 * LD4 + 16 * kb), A.h2[kb], acc);
+        A.h3[2 * t] = pack8<0, true>(acc);
+        A.h3[2 * t + 1] = pack8<8, true>(acc);
+    }
+    // L5: rgb = sigmoid(W5 h3 + b5)  (rows 0..2 = registers 0..2 of the g = 0 lanes)
+    {
+        floatx16 acc = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) acc = mma32(lds_a(L.w5, 16 * kb), A.h3[kb], acc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) A.sg[c] = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[c] + L.b5[c])));
+    }
+}
+
+template <typename TIO>
+DEV void fetch_inputs(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t s, bool live, int g, bf16x8 x0[2],
+                      float d[3]) {
+    x0[0] = load_feats8<TIO>(feats + s * IN + 8 * g, live);
+    x0[1] = load_feats8<TIO>(feats + s * IN + 16 + 8 * g, live);
+    d[0] = live ? dirs[s * 3] : 0.0f; d[1] = live ? dirs[s * 3 + 1] : 0.0f; d[2] = live ? dirs[s * 3 + 2] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------- forward kernel
+constexpr int FWD_WAVES = 8;
+
+template <typename TIO>
+__global__ void __launch_bounds__(FWD_WAVES * 64)
+mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples,
+               const float* __restrict__ params, float* __restrict__ out_rgb, float* __restrict__ out_density) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* sw = reinterpret_cast<__bf16*>(smem);
+    float* stg = reinterpret_cast<float*>(smem + (size_t)L_FWD_END * 2);
+    stage_params(stg, params, threadIdx.x, FWD_WAVES * 64);
+    __syncthreads();
+    stage_weights<false>(sw, stg, threadIdx.x, FWD_WAVES * 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LaneConst L;
+    lane_const(L, sw, stg, lane);
+    __syncthreads();
+
+    const int64_t ntiles = (num_samples + TS - 1) / TS;
+    const int64_t stride = (int64_t)gridDim.x * FWD_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * FWD_WAVES + wave;
+    Acts A;
+    float d[3];
+    if (tile < ntiles) fetch_inputs<TIO>(feats, dirs, tile * TS + L.n, tile * TS + L.n < num_samples, L.g, A.x0, d);
+    for (; tile < ntiles; tile += stride) {
+        const int64_t s = tile * TS + L.n;
+        const bool live = s < num_samples;
+        // prefetch the next tile's inputs behind this tile's arithmetic
+        bf16x8 nx0[2];
+        float nd[3];
+        const int64_t ns = (tile + stride) * TS + L.n;
+        const bool more = tile + stride < ntiles;
+        if (more) fetch_inputs<TIO>(feats, dirs, ns, ns < num_samples, L.g, nx0, nd);
+        forward_tile(L, d, A);
+        if (L.g == 0 && live) {
+            out_density[s] = fmaxf(A.y0, 0.0f);
+            out_rgb[s * 3] = A.sg[0]; out_rgb[s * 3 + 1] = A.sg[1]; out_rgb[s * 3 + 2] = A.sg[2];
+        }
+        if (more) { A.x0[0] = nx0[0]; A.x0[1] = nx0[1]; d[0] = nd[0]; d[1] = nd[1]; d[2] = nd[2]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward kernel
+constexpr int BWD_WAVES = 4;
+constexpr int BWD_WAVE_LDS = 4 * TILE_BYTES;        // two (dY, X) image pairs, alternated between stages
+
+// dX block: acc[k][n] = sum over NKB chained K blocks of  WT[k][.] dY[n][.]
+template <int NKB> DEV floatx16 back_block(const __bf16* wt_lane_row, const bf16x8* dy) {
+    floatx16 acc = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) acc = mma32(lds_a(wt_lane_row, 16 * kb), dy[kb], acc);
+    return acc;
+}
+
+template <typename TIO>
+__global__ void __launch_bounds__(BWD_WAVES * 64)
+mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples,
+               const float* __restrict__ params, const float* __restrict__ grad_rgb, const float* __restrict__ grad_density,
+               TIO* __restrict__ grad_feats, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* sw = reinterpret_cast<__bf16*>(smem);
+    float* stg = reinterpret_cast<float*>(smem + (size_t)L_BWD_END * 2);       // aliases the transposition images
+    stage_params(stg, params, threadIdx.x, BWD_WAVES * 64);
+    __syncthreads();
+    stage_weights<true>(sw, stg, threadIdx.x, BWD_WAVES * 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LaneConst L;
+    lane_const(L, sw, stg, lane);
+    __syncthreads();
+    const int n = L.n, g = L.g;
+    // this lane's rows of the transposed operands
+    const __bf16* w5t = sw + L_W5T + n * LT5 + 8 * g;               // + 32 rows for the second block
+    const __bf16* w4t = sw + L_W4T + n * LT4 + 8 * g;
+    const __bf16* w3t = sw + L_W3T + (n & 15) * LT3 + 8 * g;
+    const __bf16* w2t = sw + L_W2T + n * LT2 + 8 * g;
+    const __bf16* w1t = sw + L_W1T + n * LT1 + 8 * g;
+    // transposition images of this wave
+    unsigned char* img = smem + (size_t)L_BWD_END * 2 + (size_t)wave * BWD_WAVE_LDS;
+    const int wc_off = (2 * n + g) * 8, wn_off = g * TILE_REGION + n * 16;
+    const int tr_off = ((lane >> 1) & 1) * TILE_REGION + (8 * (lane >> 4) + 2 * ((lane >> 2) & 3) + (lane & 1)) * 8;
+
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    floatx4 dW5[4], dW4[16], dW3[12], dW2[4], dW1[8], db5, db4[4], db2, db1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { dW5[t] = zero4(); dW2[t] = zero4(); db4[t] = zero4(); db1[t] = zero4(); }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dW4[t] = zero4();
+#pragma unroll
+    for (int t = 0; t < 12; ++t) dW3[t] = zero4();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dW1[t] = zero4();
+    db5 = zero4(); db2 = zero4();
+
+    const int64_t ntiles = (num_samples + TS - 1) / TS;
+    const int64_t stride = (int64_t)gridDim.x * BWD_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * BWD_WAVES + wave;
+    Acts A;
+    float d[3];
+    if (tile < ntiles) fetch_inputs<TIO>(feats, dirs, tile * TS + n, tile * TS + n < num_samples, g, A.x0, d);
+    for (; tile < ntiles; tile += stride) {
+        const int64_t s = tile * TS + n;
+        const bool live = s < num_samples;
+        float gr[3] = {0.f, 0.f, 0.f}, gd = 0.0f;
+        if (live && g == 0) { gr[0] = grad_rgb[s * 3]; gr[1] = grad_rgb[s * 3 + 1]; gr[2] = grad_rgb[s * 3 + 2]; gd = grad_density[s]; }
+        bf16x8 nx0[2];
+        float nd[3];
+        const int64_t ns = (tile + stride) * TS + n;
+        const bool more = tile + stride < ntiles;
+        if (more) fetch_inputs<TIO>(feats, dirs, ns, ns < num_samples, g, nx0, nd);
+
+        forward_tile(L, d, A);
+
+        unsigned char* imgA = img;                       // stage images alternate: (dY, X) = (A0, A1) / (B0, B1)
+        unsigned char* imgB = img + 2 * TILE_BYTES;
+
+        // ---- stage 5: dY5 = g_rgb * s (1 - s) (3 channels, natural slots 0..2 of the g = 0 lanes)
+        float g5[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // the g = 1 lanes hold other rows in sg: keep them 0
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g5[c] = g == 0 ? gr[c] * A.sg[c] * (1.0f - A.sg[c]) : 0.0f;
+        const bf16x8 dy5 = pack8f(g5);
+        store_natural(imgA + wn_off, 0, dy5);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) store_chained(imgA + TILE_BYTES + wc_off, kb, A.h3[kb]);
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 dh3[4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                    // dH3 = (W5^T dY5) * (h3 > 0)
+            const floatx16 acc = back_block<1>(w5t + t * 32 * LT5, &dy5);
+            dh3[2 * t] = pack8_masked<0>(acc, A.h3[2 * t]);
+            dh3[2 * t + 1] = pack8_masked<8>(acc, A.h3[2 * t + 1]);
+        }
+        {                                                // dW5 += dY5^T h3 ; db5
+            const bf16x8 a = load_transposed(imgA + tr_off, 0);
+            db5 = mma16(a, ones, db5);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) dW5[kt] = mma16(a, load_transposed(imgA + TILE_BYTES + tr_off, kt), dW5[kt]);
+        }
+        // ---- stage 4
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) { store_chained(imgB + wc_off, kb, dh3[kb]); store_chained(imgB + TILE_BYTES + wc_off, kb, A.h2[kb]); }
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 dh2[4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                    // dH2 = (W4^T dH3) * (h2 > 0)
+            const floatx16 acc = back_block<4>(w4t + t * 32 * LT4, dh3);
+            dh2[2 * t] = pack8_masked<0>(acc, A.h2[2 * t]);
+            dh2[2 * t + 1] = pack8_masked<8>(acc, A.h2[2 * t + 1]);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                 // dW4 += dH3^T h2 ; db4
+            const bf16x8 a = load_transposed(imgB + tr_off, it);
+            db4[it] = mma16(a, ones, db4[it]);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) dW4[it * 4 + kt] = mma16(a, load_transposed(imgB + TILE_BYTES + tr_off, kt), dW4[it * 4 + kt]);
+        }
+        // ---- stage 3
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) store_chained(imgA + wc_off, kb, dh2[kb]);
+        store_chained(imgA + TILE_BYTES + wc_off, 0, A.x2[0]);
+        store_natural(imgA + TILE_BYTES + wn_off, 1, A.x2[1]);
+        store_natural(imgA + TILE_BYTES + wn_off, 2, A.x2[2]);
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 dy2;
+        {                                                // dY2[m] = W3^T dH2 (m = 1..15), dY2[0] = g_density * (y0 > 0)
+            floatx16 acc = back_block<4>(w3t, dh2);
+            if (g == 0) acc[0] = A.y0 > 0.0f ? gd : 0.0f;
+            dy2 = pack8<0, false>(acc);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                 // dW3 += dH2^T x2 (column ONES_SLOT = db3)
+            const bf16x8 a = load_transposed(imgA + tr_off, it);
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) dW3[it * 3 + kt] = mma16(a, load_transposed(imgA + TILE_BYTES + tr_off, kt), dW3[it * 3 + kt]);
+        }
+        // ---- stage 2
+        store_chained(imgB + wc_off, 0, dy2);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) store_chained(imgB + TILE_BYTES + wc_off, kb, A.h1[kb]);
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 dh1[4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                    // dH1 = (W2^T dY2) * (h1 > 0)
+            const floatx16 acc = back_block<1>(w2t + t * 32 * LT2, &dy2);
+            dh1[2 * t] = pack8_masked<0>(acc, A.h1[2 * t]);
+            dh1[2 * t + 1] = pack8_masked<8>(acc, A.h1[2 * t + 1]);
+        }
+        {                                                // dW2 += dY2^T h1 ; db2
+            const bf16x8 a = load_transposed(imgB + tr_off, 0);
+            db2 = mma16(a, ones, db2);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) dW2[kt] = mma16(a, load_transposed(imgB + TILE_BYTES + tr_off, kt), dW2[kt]);
+        }
+        // ---- stage 1
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) store_chained(imgA + wc_off, kb, dh1[kb]);
+        store_natural(imgA + TILE_BYTES + wn_off, 0, A.x0[0]);
+        store_natural(imgA + TILE_BYTES + wn_off, 1, A.x0[1]);
+        __builtin_amdgcn_wave_barrier();
+        {                                                // dX0 = W1^T dH1 -> grad_feats
+            const floatx16 acc = back_block<4>(w1t, dh1);
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    store_grad4<TIO>(grad_feats + s * IN + 8 * q + 4 * g, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                 // dW1 += dH1^T x0 ; db1
+            const bf16x8 a = load_transposed(imgA + tr_off, it);
+            db1[it] = mma16(a, ones, db1[it]);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) dW1[it * 2 + kt] = mma16(a, load_transposed(imgA + TILE_BYTES + tr_off, kt), dW1[it * 2 + kt]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (more) { A.x0[0] = nx0[0]; A.x0[1] = nx0[1]; d[0] = nd[0]; d[1] = nd[1]; d[2] = nd[2]; }
+    }
+
+    // ---- per-wave partial gradients -> workspace row [block * WAVES + wave][NPARAM_PAD]
+    float* out = partials + ((int64_t)blockIdx.x * BWD_WAVES + wave) * NPARAM_PAD;
+    const int col = lane & 15, rg = lane >> 4;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = 4 * rg + rr;                     // row inside a 16-row block
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (row < 3) out[OW5 + row * H + 16 * kt + col] = dW5[kt][rr];
+            out[OW2 + row * H + 16 * kt + col] = dW2[kt][rr];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int R = 16 * it + row;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) out[OW4 + R * H + 16 * kt + col] = dW4[it * 4 + kt][rr];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) out[OW1 + R * IN + 16 * kt + col] = dW1[it * 2 + kt][rr];
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                const int u = 16 * kt + col;             // feature index inside the 48-wide colour input
+                const float v = dW3[it * 3 + kt][rr];
+                if (kt == 0) { if (u >= 1) out[OW3 + R * X2 + u - 1] = v; }
+                else if (u < ONES_SLOT) out[OW3 + R * X2 + u - 1] = v;
+                else if (u == ONES_SLOT) out[OB3 + R] = v;
+            }
+            if (col == 0) { out[OB4 + R] = db4[it][rr]; out[OB1 + R] = db1[it][rr]; }
+        }
+        if (col == 0) { out[OB2 + row] = db2[rr]; if (row < 3) out[OB5 + row] = db5[rr]; }
+    }
+}
+
+int cu_count() {
+    static int n = [] { int d = 0, c = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d); return c > 0 ? c : 256; }();
+    return n;
+}
+
+template <typename TIO>
+int launch_fwd(const void* feats, const float* dirs, int64_t S, const float* params, float* rgb, float* density, hipStream_t st) {
+    const size_t lds = (size_t)L_FWD_END * 2 + (size_t)NPARAM_PAD * 4;
+    auto kern = mlp_fwd_kernel<TIO>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
+    const int64_t ntiles = (S + TS - 1) / TS;
+    const int grid = (int)min64(ceil_div64(ntiles, FWD_WAVES), cu_count());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, S, params, rgb, density);
+    return 0;
+}
+
+template <typename TIO>
+int launch_bwd(const void* feats, const float* dirs, int64_t S, const float* params, const float* grad_rgb,
+               const float* grad_density, void* grad_feats, float* partials, int* partial_rows, hipStream_t st) {
+    const size_t lds = (size_t)L_BWD_END * 2 + (size_t)BWD_WAVES * BWD_WAVE_LDS;
+    auto kern = mlp_bwd_kernel<TIO>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
+    const int64_t ntiles = (S + TS - 1) / TS;
+    const int grid = (int)min64(ceil_div64(ntiles, BWD_WAVES), cu_count());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, S, params, grad_rgb,
+                       grad_density, (TIO*)grad_feats, partials);
+    *partial_rows = grid * BWD_WAVES;
+    return 0;
+}
+
+}  // namespace
+
+namespace wisp_mlp {
+
+int bf16_forward(const void* feats, int dtype_io, const float* dirs, int64_t S, const float* params, float* rgb,
+                 float* density, hipStream_t st) {
+    switch (dtype_io) {
+        case WISP_F32: return launch_fwd<float>(feats, dirs, S, params, rgb, density, st);
+        case WISP_F16: return launch_fwd<__half>(feats, dirs, S, params, rgb, density, st);
+        default: return launch_fwd<__hip_bfloat16>(feats, dirs, S, params, rgb, density, st);
+    }
+}
+
+int bf16_backward(const void* feats, int dtype_io, const float* dirs, int64_t S, const float* params, const float* grad_rgb,
+                  const float* grad_density, void* grad_feats, float* partials, int* partial_rows, hipStream_t st) {
+    switch (dtype_io) {
+        case WISP_F32: return launch_bwd<float>(feats, dirs, S, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st);
+        case WISP_F16: return launch_bwd<__half>(feats, dirs, S, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st);
+        default: return launch_bwd<__hip_bfloat16>(feats, dirs, S, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st);
+    }
+}
+
+}  // namespace wisp_mlp

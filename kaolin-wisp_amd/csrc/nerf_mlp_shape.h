@@ -1,0 +1,29 @@
+// Shape constants of the fused radiance-field decoder build (nerf_hash.yaml: 32 grid features, hidden 64, 4 view octaves)
+// and the packed parameter order  W1[H,IN] b1[H] W2[16,H] b2[16] W3[H,X2] b3[H] W4[H,H] b4[H] W5[3,H] b5[3]
+// (wisp/models/nefs/nerf.py:151-173 in nn.Module order).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace wisp_mlp {
+
+constexpr int IN = 32;                    // grid feature width
+constexpr int H = 64;                     // hidden width
+constexpr int NF = 4;                     // view-direction octaves
+constexpr int PE = 3 + 6 * NF;            // 27
+constexpr int X2 = 15 + PE;               // 42 real colour-MLP inputs
+constexpr int TS = 32;                    // samples per wave tile
+
+constexpr int OW1 = 0, OB1 = OW1 + H * IN, OW2 = OB1 + H, OB2 = OW2 + 16 * H, OW3 = OB2 + 16, OB3 = OW3 + H * X2,
+              OW4 = OB3 + H, OB4 = OW4 + H * H, OW5 = OB4 + H, OB5 = OW5 + 3 * H, NPARAM = OB5 + 3;
+constexpr int NPARAM_PAD = (NPARAM + 63) / 64 * 64;
+
+// bf16 matrix-core path (nerf_mlp_bf16.hip); feats/grad_feats element type: 0 f32, 1 f16, 2 bf16 (wisp_hip.h dtype codes).
+// Both return 0 or a wisp error code.  `partials` = workspace of wisp_nerf_mlp_workspace_floats() floats.
+int bf16_forward(const void* feats, int dtype_io, const float* dirs, int64_t num_samples, const float* params, float* rgb,
+                 float* density, hipStream_t st);
+int bf16_backward(const void* feats, int dtype_io, const float* dirs, int64_t num_samples, const float* params,
+                  const float* grad_rgb, const float* grad_density, void* grad_feats, float* partials, int* partial_rows,
+                  hipStream_t st);
+
+}  // namespace wisp_mlp
