@@ -16,10 +16,11 @@
 //     transposed (samples from lanes to registers): the packed registers are written to a per-wave LDS image made of
 //     8-byte chunks (sample, 4 features) and read back with ds_read_b64_tr_b16.  Chunk address =
 //     (fq >> 1) * 640 + (2 n + (fq & 1)) * 8 with fq = feature / 4: both the writes and the transposing reads are
-//     bank-conflict free.  dW accumulates in 216 VGPRs for the whole launch; per-wave partials are reduced afterwards.
+//     bank-conflict free.  dW accumulates in 180 VGPRs for the whole launch; per-wave partials are reduced afterwards.
 //   * bias gradients: one extra MFMA per 16 rows against a constant-ones operand (db3 comes with dW3's ones column).
 #include "wisp_common.h"
 #include "nerf_mlp_shape.h"
+#include <cstdlib>
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -66,14 +67,20 @@ constexpr int ONES_SLOT = 16 + PE;          // = 43: feature index (within the 4
 
 // Prologue: the packed fp32 parameters are first copied to an LDS staging area with coalesced loads (one global
 // round trip), then scattered into the permuted bf16 operand images from there.
-DEV void stage_params(float* stg, const float* __restrict__ P, int tid, int nthreads) {
-    for (int e = tid; e < NPARAM; e += nthreads) stg[e] = P[e];
+template <int THREADS>
+DEV void stage_params(float* stg, const float* __restrict__ P, int tid) {
+    constexpr int PER = (NPARAM + THREADS - 1) / THREADS;
+    float v[PER];                                    // all loads in flight before the first LDS write
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int e = tid + k * THREADS; v[k] = e < NPARAM ? P[e] : 0.0f; }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int e = tid + k * THREADS; if (e < NPARAM) stg[e] = v[k]; }
 }
 template <bool BWD>
 DEV void stage_weights(__bf16* sw, const float* P, int tid, int nthreads) {
-    for (int e = tid; e < 64 * 32; e += nthreads) { const int r = e >> 5, c = e & 31; sw[L_W1 + r * LD1 + c] = (__bf16)P[OW1 + r * IN + c]; }
-    for (int e = tid; e < 16 * 64; e += nthreads) { const int r = e >> 6, s = e & 63; sw[L_W2 + r * LD2 + s] = (__bf16)P[OW2 + r * H + phi(s)]; }
-    for (int e = tid; e < 64 * 48; e += nthreads) {
+    _Pragma("unroll 4") for (int e = tid; e < 64 * 32; e += nthreads) { const int r = e >> 5, c = e & 31; sw[L_W1 + r * LD1 + c] = (__bf16)P[OW1 + r * IN + c]; }
+    _Pragma("unroll 4") for (int e = tid; e < 16 * 64; e += nthreads) { const int r = e >> 6, s = e & 63; sw[L_W2 + r * LD2 + s] = (__bf16)P[OW2 + r * H + phi(s)]; }
+    _Pragma("unroll 4") for (int e = tid; e < 64 * 48; e += nthreads) {
         const int r = e / 48, s = e % 48;
         float v = 0.0f;
         if (s < 16) { const int m = phi16(s); if (m) v = P[OW3 + r * X2 + m - 1]; }
@@ -81,14 +88,14 @@ DEV void stage_weights(__bf16* sw, const float* P, int tid, int nthreads) {
         else if (s == ONES_SLOT) v = P[OB3 + r];
         sw[L_W3 + r * LD3 + s] = (__bf16)v;
     }
-    for (int e = tid; e < 64 * 64; e += nthreads) { const int r = e >> 6, s = e & 63; sw[L_W4 + r * LD4 + s] = (__bf16)P[OW4 + r * H + phi(s)]; }
-    for (int e = tid; e < 4 * 64; e += nthreads) { const int r = e >> 6, s = e & 63; sw[L_W5 + r * LD5 + s] = (__bf16)(r < 3 ? P[OW5 + r * H + phi(s)] : 0.0f); }
+    _Pragma("unroll 4") for (int e = tid; e < 64 * 64; e += nthreads) { const int r = e >> 6, s = e & 63; sw[L_W4 + r * LD4 + s] = (__bf16)P[OW4 + r * H + phi(s)]; }
+    _Pragma("unroll 4") for (int e = tid; e < 4 * 64; e += nthreads) { const int r = e >> 6, s = e & 63; sw[L_W5 + r * LD5 + s] = (__bf16)(r < 3 ? P[OW5 + r * H + phi(s)] : 0.0f); }
     if (BWD) {
-        for (int e = tid; e < 64 * 16; e += nthreads) { const int k = e >> 4, p = e & 15; sw[L_W5T + k * LT5 + p] = (__bf16)(p < 3 ? P[OW5 + p * H + k] : 0.0f); }
-        for (int e = tid; e < 64 * 64; e += nthreads) { const int k = e >> 6, s = e & 63; sw[L_W4T + k * LT4 + s] = (__bf16)P[OW4 + phi(s) * H + k]; }
-        for (int e = tid; e < 16 * 64; e += nthreads) { const int m = e >> 6, s = e & 63; sw[L_W3T + m * LT3 + s] = (__bf16)(m ? P[OW3 + phi(s) * X2 + m - 1] : 0.0f); }
-        for (int e = tid; e < 64 * 16; e += nthreads) { const int k = e >> 4, p = e & 15; sw[L_W2T + k * LT2 + p] = (__bf16)P[OW2 + phi16(p) * H + k]; }
-        for (int e = tid; e < 32 * 64; e += nthreads) { const int k = e >> 6, s = e & 63; sw[L_W1T + k * LT1 + s] = (__bf16)P[OW1 + phi(s) * IN + k]; }
+        _Pragma("unroll 4") for (int e = tid; e < 64 * 16; e += nthreads) { const int k = e >> 4, p = e & 15; sw[L_W5T + k * LT5 + p] = (__bf16)(p < 3 ? P[OW5 + p * H + k] : 0.0f); }
+        _Pragma("unroll 4") for (int e = tid; e < 64 * 64; e += nthreads) { const int k = e >> 6, s = e & 63; sw[L_W4T + k * LT4 + s] = (__bf16)P[OW4 + phi(s) * H + k]; }
+        _Pragma("unroll 4") for (int e = tid; e < 16 * 64; e += nthreads) { const int m = e >> 6, s = e & 63; sw[L_W3T + m * LT3 + s] = (__bf16)(m ? P[OW3 + phi(s) * X2 + m - 1] : 0.0f); }
+        _Pragma("unroll 4") for (int e = tid; e < 64 * 16; e += nthreads) { const int k = e >> 4, p = e & 15; sw[L_W2T + k * LT2 + p] = (__bf16)P[OW2 + phi16(p) * H + k]; }
+        _Pragma("unroll 4") for (int e = tid; e < 32 * 64; e += nthreads) { const int k = e >> 6, s = e & 63; sw[L_W1T + k * LT1 + s] = (__bf16)P[OW1 + phi(s) * IN + k]; }
     }
 }
 
@@ -121,14 +128,13 @@ DEV bf16x8 pack8f(const float v[8]) {
 }
 // BASE.. of `a` as bf16 where the relu output h is positive (bit pattern 0 or positive), else 0
 template <int BASE> DEV bf16x8 pack8_masked(const floatx16& a, bf16x8 h) {
-    // mask = (0 - h) >> 15 per 16-bit lane = 0xffff where h > 0.  Spelled as two packed instructions: left to itself the
-    // compiler rewrites the expression into two compares, two selects and a permute per dword.
+    // per 16-bit lane: d * min(h, 1) (h is 0 or a positive bit pattern), i.e. d where h > 0 else 0.  Spelled as two packed
+    // instructions: left to itself the compiler turns any such expression into compares, selects and a permute per dword.
     const u32x4 hw = __builtin_bit_cast(u32x4, h);
     u32x4 w;
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {
-        unsigned m;
-        asm("v_pk_sub_i16 %0, 0, %1\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=v"(m) : "v"(hw[j]));
-        w[j] = cvt2(a[BASE + 2 * j], a[BASE + 2 * j + 1]) & m;
+        const unsigned d = cvt2(a[BASE + 2 * j], a[BASE + 2 * j + 1]);
+        asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_mul_lo_u16 %0, %0, %2" : "=&v"(w[j]) : "v"(hw[j]), "v"(d));
     }
     return __builtin_bit_cast(bf16x8, w);
 }
@@ -215,24 +221,37 @@ struct Acts {
 struct LaneConst {
     int n, g;
     const __bf16 *w1, *w2, *w3, *w4, *w5;          // this lane's row of each forward operand (+ 8 g)
-    floatx16 b1[2], b4[2];                          // hidden biases in accumulator layout
+    floatx16 b1[2], b4[2];                          // hidden biases in accumulator layout (register-resident variant)
+    const float* bias_lds;                          // ... or their LDS copy [layer][t][g][16] (+ 16 g)
     float b2[8], b5[3];
 };
 
-DEV void lane_const(LaneConst& L, const __bf16* sw, const float* P, int lane) {
+constexpr int BIASV_FLOATS = 2 * 2 * 2 * 16;
+DEV void stage_bias_vectors(float* biasv, const float* P, int tid, int nthreads) {
+    for (int e = tid; e < BIASV_FLOATS; e += nthreads) {
+        const int r = e & 15, g = (e >> 4) & 1, t = (e >> 5) & 1, layer = e >> 6;
+        biasv[e] = P[(layer ? OB4 : OB1) + 32 * t + acc_row(r, g)];
+    }
+}
+
+template <bool BIAS_LDS>
+DEV void lane_const(LaneConst& L, const __bf16* sw, const float* P, int lane, const float* biasv = nullptr) {
     L.n = lane & 31; L.g = lane >> 5;
     L.w1 = sw + L_W1 + L.n * LD1 + 8 * L.g;
     L.w2 = sw + L_W2 + (L.n & 15) * LD2 + 8 * L.g;
     L.w3 = sw + L_W3 + L.n * LD3 + 8 * L.g;
     L.w4 = sw + L_W4 + L.n * LD4 + 8 * L.g;
     L.w5 = sw + L_W5 + (L.n < 3 ? L.n : 3) * LD5 + 8 * L.g;
+    L.bias_lds = BIAS_LDS ? biasv + 16 * L.g : nullptr;
+    if (!BIAS_LDS) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            L.b1[t][r] = P[OB1 + 32 * t + acc_row(r, L.g)];
-            L.b4[t][r] = P[OB4 + 32 * t + acc_row(r, L.g)];
-        }
+            for (int r = 0; r < 16; ++r) {
+                L.b1[t][r] = P[OB1 + 32 * t + acc_row(r, L.g)];
+                L.b4[t][r] = P[OB4 + 32 * t + acc_row(r, L.g)];
+            }
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) L.b2[r] = P[OB2 + acc_row(r, L.g)];
 #pragma unroll
@@ -240,11 +259,12 @@ DEV void lane_const(LaneConst& L, const __bf16* sw, const float* P, int lane) {
 }
 
 // forward of one tile; x0 and the view direction are already in registers
+template <bool BIAS_LDS>
 DEV void forward_tile(const LaneConst& L, const float d[3], Acts& A) {
     // L1: h1 = relu(W1 x0 + b1)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        floatx16 acc = L.b1[t];
+        floatx16 acc = BIAS_LDS ? *reinterpret_cast<const floatx16*>(L.bias_lds + t * 32) : L.b1[t];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) acc = mma32(lds_a(L.w1, t * 32 * LD1 + 16 * kb), A.x0[kb], acc);
         A.h1[2 * t] = pack8<0, true>(acc);
@@ -274,7 +294,7 @@ DEV void forward_tile(const LaneConst& L, const float d[3], Acts& A) {
     // L4: h3 = relu(W4 h2 + b4)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        floatx16 acc = L.b4[t];
+        floatx16 acc = BIAS_LDS ? *reinterpret_cast<const floatx16*>(L.bias_lds + 64 + t * 32) : L.b4[t];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) acc = mma32(lds_a(L.w4, t * 32 * LD4 + 16 * kb), A.h2[kb], acc);
         A.h3[2 * t] = pack8<0, true>(acc);
@@ -308,12 +328,12 @@ mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16* sw = reinterpret_cast<__bf16*>(smem);
     float* stg = reinterpret_cast<float*>(smem + (size_t)L_FWD_END * 2);
-    stage_params(stg, params, threadIdx.x, FWD_WAVES * 64);
+    stage_params<FWD_WAVES * 64>(stg, params, threadIdx.x);
     __syncthreads();
     stage_weights<false>(sw, stg, threadIdx.x, FWD_WAVES * 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LaneConst L;
-    lane_const(L, sw, stg, lane);
+    lane_const<false>(L, sw, stg, lane);
     __syncthreads();
 
     const int64_t ntiles = (num_samples + TS - 1) / TS;
@@ -331,7 +351,7 @@ mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
         const int64_t ns = (tile + stride) * TS + L.n;
         const bool more = tile + stride < ntiles;
         if (more) fetch_inputs<TIO>(feats, dirs, ns, ns < num_samples, L.g, nx0, nd);
-        forward_tile(L, d, A);
+        forward_tile<false>(L, d, A);
         if (L.g == 0 && live) {
             out_density[s] = fmaxf(A.y0, 0.0f);
             out_rgb[s * 3] = A.sg[0]; out_rgb[s * 3 + 1] = A.sg[1]; out_rgb[s * 3 + 2] = A.sg[2];
@@ -341,8 +361,27 @@ mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
 }
 
 // ---------------------------------------------------------------------------------------------- backward kernel
-constexpr int BWD_WAVES = 4;
-constexpr int BWD_WAVE_LDS = 4 * TILE_BYTES;        // two (dY, X) image pairs, alternated between stages
+// Eight waves per workgroup in two roles, one of each per SIMD:
+//   * chain waves 0..3 own a tile each: forward recompute, back-propagation through the transposed weights, grad_feats;
+//     they publish the (dY, X) transposition images of every layer in LDS;
+//   * accumulator waves 4..7 (partner of chain wave w is wave w + 4) read the images back transposed and keep
+//     dW += dY^T X in registers for the whole launch (180 VGPRs).
+// Splitting the roles keeps every wave at <= 256 registers: two waves per SIMD (the chain wave's conversions overlap
+// the partner's MFMAs) and all MFMAs in VGPR form, where one combined wave needed ~480 registers, ran alone on its SIMD
+// and paid a v_accvgpr_read for every accumulator value it converted.
+// Each pair hands images over through a two-slot ring in LDS guarded by two counters (ready / done); no workgroup
+// barrier in the main loop.
+constexpr int BWD_PAIRS = 4;
+constexpr int BWD_THREADS = 2 * BWD_PAIRS * 64;
+constexpr int BWD_PAIR_LDS = 4 * TILE_BYTES;        // two slots x (dY image, X image)
+constexpr int BWD_OFF_BIASV = L_BWD_END * 2;
+constexpr int BWD_OFF_FLAGS = BWD_OFF_BIASV + BIASV_FLOATS * 4;
+constexpr int BWD_OFF_IMG = BWD_OFF_FLAGS + 64;
+constexpr int BWD_LDS_MAIN = BWD_OFF_IMG + BWD_PAIRS * BWD_PAIR_LDS;
+constexpr int BWD_LDS_REDUCE = BWD_OFF_IMG + 2 * NPARAM_PAD * 4;      // 4 rows x half the parameters      // epilogue scratch aliases the images
+constexpr int BWD_LDS = BWD_LDS_MAIN > BWD_LDS_REDUCE ? BWD_LDS_MAIN : BWD_LDS_REDUCE;
+static_assert(BWD_LDS <= 160 * 1024, "LDS budget");
+static_assert(NPARAM_PAD * 4 <= BWD_PAIRS * BWD_PAIR_LDS, "parameter staging aliases the images");
 
 // dX block: acc[k][n] = sum over NKB chained K blocks of  WT[k][.] dY[n][.]
 template <int NKB> DEV floatx16 back_block(const __bf16* wt_lane_row, const bf16x8* dy) {
@@ -352,201 +391,263 @@ template <int NKB> DEV floatx16 back_block(const __bf16* wt_lane_row, const bf16
     return acc;
 }
 
-template <typename TIO>
-__global__ void __launch_bounds__(BWD_WAVES * 64)
-mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples,
-               const float* __restrict__ params, const float* __restrict__ grad_rgb, const float* __restrict__ grad_density,
-               TIO* __restrict__ grad_feats, float* __restrict__ partials) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __bf16* sw = reinterpret_cast<__bf16*>(smem);
-    float* stg = reinterpret_cast<float*>(smem + (size_t)L_BWD_END * 2);       // aliases the transposition images
-    stage_params(stg, params, threadIdx.x, BWD_WAVES * 64);
-    __syncthreads();
-    stage_weights<true>(sw, stg, threadIdx.x, BWD_WAVES * 64);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    LaneConst L;
-    lane_const(L, sw, stg, lane);
-    __syncthreads();
-    const int n = L.n, g = L.g;
-    // this lane's rows of the transposed operands
-    const __bf16* w5t = sw + L_W5T + n * LT5 + 8 * g;               // + 32 rows for the second block
-    const __bf16* w4t = sw + L_W4T + n * LT4 + 8 * g;
-    const __bf16* w3t = sw + L_W3T + (n & 15) * LT3 + 8 * g;
-    const __bf16* w2t = sw + L_W2T + n * LT2 + 8 * g;
-    const __bf16* w1t = sw + L_W1T + n * LT1 + 8 * g;
-    // transposition images of this wave
-    unsigned char* img = smem + (size_t)L_BWD_END * 2 + (size_t)wave * BWD_WAVE_LDS;
-    const int wc_off = (2 * n + g) * 8, wn_off = g * TILE_REGION + n * 16;
-    const int tr_off = ((lane >> 1) & 1) * TILE_REGION + (8 * (lane >> 4) + 2 * ((lane >> 2) & 3) + (lane & 1)) * 8;
+DEV void wait_at_least(int* counter, int target) {
+    // the spin is bounded (~tens of ms) so that a protocol error shows up as wrong numbers in the tests, not as a hung GPU
+    int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < (1 << 20))
+        __builtin_amdgcn_s_sleep(1);
+}
+DEV void publish(int* counter, int value) { __hip_atomic_store(counter, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-    bf16x8 ones;
+// weight-gradient accumulators of one accumulator wave
+struct GradAcc {
+    floatx4 dW5[4], dW4[16], dW3[12], dW2[4], dW1[8];
+    floatx4 db;      // all bias gradients share ONE 16x16 block: row c = "combo" c (a 16-neuron block of one layer), see DB_*
+};
+constexpr int DB_L4 = 0, DB_L1 = 4, DB_L2 = 8, DB_L5 = 9;      // first combo row of each layer (b3 comes with dW3)
+DEV void grad_zero(GradAcc& G) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-
-    floatx4 dW5[4], dW4[16], dW3[12], dW2[4], dW1[8], db5, db4[4], db2, db1[4];
+    for (int t = 0; t < 4; ++t) { G.dW5[t] = zero4(); G.dW2[t] = zero4(); }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { dW5[t] = zero4(); dW2[t] = zero4(); db4[t] = zero4(); db1[t] = zero4(); }
+    for (int t = 0; t < 16; ++t) G.dW4[t] = zero4();
 #pragma unroll
-    for (int t = 0; t < 16; ++t) dW4[t] = zero4();
+    for (int t = 0; t < 12; ++t) G.dW3[t] = zero4();
 #pragma unroll
-    for (int t = 0; t < 12; ++t) dW3[t] = zero4();
-#pragma unroll
-    for (int t = 0; t < 8; ++t) dW1[t] = zero4();
-    db5 = zero4(); db2 = zero4();
-
-    const int64_t ntiles = (num_samples + TS - 1) / TS;
-    const int64_t stride = (int64_t)gridDim.x * BWD_WAVES;
-    int64_t tile = (int64_t)blockIdx.x * BWD_WAVES + wave;
-    Acts A;
-    float d[3];
-    if (tile < ntiles) fetch_inputs<TIO>(feats, dirs, tile * TS + n, tile * TS + n < num_samples, g, A.x0, d);
-    for (; tile < ntiles; tile += stride) {
-        const int64_t s = tile * TS + n;
-        const bool live = s < num_samples;
-        float gr[3] = {0.f, 0.f, 0.f}, gd = 0.0f;
-        if (live && g == 0) { gr[0] = grad_rgb[s * 3]; gr[1] = grad_rgb[s * 3 + 1]; gr[2] = grad_rgb[s * 3 + 2]; gd = grad_density[s]; }
-        bf16x8 nx0[2];
-        float nd[3];
-        const int64_t ns = (tile + stride) * TS + n;
-        const bool more = tile + stride < ntiles;
-        if (more) fetch_inputs<TIO>(feats, dirs, ns, ns < num_samples, g, nx0, nd);
-
-        forward_tile(L, d, A);
-
-        unsigned char* imgA = img;                       // stage images alternate: (dY, X) = (A0, A1) / (B0, B1)
-        unsigned char* imgB = img + 2 * TILE_BYTES;
-
-        // ---- stage 5: dY5 = g_rgb * s (1 - s) (3 channels, natural slots 0..2 of the g = 0 lanes)
-        float g5[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // the g = 1 lanes hold other rows in sg: keep them 0
-#pragma unroll
-        for (int c = 0; c < 3; ++c) g5[c] = g == 0 ? gr[c] * A.sg[c] * (1.0f - A.sg[c]) : 0.0f;
-        const bf16x8 dy5 = pack8f(g5);
-        store_natural(imgA + wn_off, 0, dy5);
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) store_chained(imgA + TILE_BYTES + wc_off, kb, A.h3[kb]);
-        __builtin_amdgcn_wave_barrier();
-        bf16x8 dh3[4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {                    // dH3 = (W5^T dY5) * (h3 > 0)
-            const floatx16 acc = back_block<1>(w5t + t * 32 * LT5, &dy5);
-            dh3[2 * t] = pack8_masked<0>(acc, A.h3[2 * t]);
-            dh3[2 * t + 1] = pack8_masked<8>(acc, A.h3[2 * t + 1]);
-        }
-        {                                                // dW5 += dY5^T h3 ; db5
-            const bf16x8 a = load_transposed(imgA + tr_off, 0);
-            db5 = mma16(a, ones, db5);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) dW5[kt] = mma16(a, load_transposed(imgA + TILE_BYTES + tr_off, kt), dW5[kt]);
-        }
-        // ---- stage 4
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) { store_chained(imgB + wc_off, kb, dh3[kb]); store_chained(imgB + TILE_BYTES + wc_off, kb, A.h2[kb]); }
-        __builtin_amdgcn_wave_barrier();
-        bf16x8 dh2[4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {                    // dH2 = (W4^T dH3) * (h2 > 0)
-            const floatx16 acc = back_block<4>(w4t + t * 32 * LT4, dh3);
-            dh2[2 * t] = pack8_masked<0>(acc, A.h2[2 * t]);
-            dh2[2 * t + 1] = pack8_masked<8>(acc, A.h2[2 * t + 1]);
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {                 // dW4 += dH3^T h2 ; db4
-            const bf16x8 a = load_transposed(imgB + tr_off, it);
-            db4[it] = mma16(a, ones, db4[it]);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) dW4[it * 4 + kt] = mma16(a, load_transposed(imgB + TILE_BYTES + tr_off, kt), dW4[it * 4 + kt]);
-        }
-        // ---- stage 3
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) store_chained(imgA + wc_off, kb, dh2[kb]);
-        store_chained(imgA + TILE_BYTES + wc_off, 0, A.x2[0]);
-        store_natural(imgA + TILE_BYTES + wn_off, 1, A.x2[1]);
-        store_natural(imgA + TILE_BYTES + wn_off, 2, A.x2[2]);
-        __builtin_amdgcn_wave_barrier();
-        bf16x8 dy2;
-        {                                                // dY2[m] = W3^T dH2 (m = 1..15), dY2[0] = g_density * (y0 > 0)
-            floatx16 acc = back_block<4>(w3t, dh2);
-            if (g == 0) acc[0] = A.y0 > 0.0f ? gd : 0.0f;
-            dy2 = pack8<0, false>(acc);
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {                 // dW3 += dH2^T x2 (column ONES_SLOT = db3)
-            const bf16x8 a = load_transposed(imgA + tr_off, it);
-#pragma unroll
-            for (int kt = 0; kt < 3; ++kt) dW3[it * 3 + kt] = mma16(a, load_transposed(imgA + TILE_BYTES + tr_off, kt), dW3[it * 3 + kt]);
-        }
-        // ---- stage 2
-        store_chained(imgB + wc_off, 0, dy2);
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) store_chained(imgB + TILE_BYTES + wc_off, kb, A.h1[kb]);
-        __builtin_amdgcn_wave_barrier();
-        bf16x8 dh1[4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {                    // dH1 = (W2^T dY2) * (h1 > 0)
-            const floatx16 acc = back_block<1>(w2t + t * 32 * LT2, &dy2);
-            dh1[2 * t] = pack8_masked<0>(acc, A.h1[2 * t]);
-            dh1[2 * t + 1] = pack8_masked<8>(acc, A.h1[2 * t + 1]);
-        }
-        {                                                // dW2 += dY2^T h1 ; db2
-            const bf16x8 a = load_transposed(imgB + tr_off, 0);
-            db2 = mma16(a, ones, db2);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) dW2[kt] = mma16(a, load_transposed(imgB + TILE_BYTES + tr_off, kt), dW2[kt]);
-        }
-        // ---- stage 1
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) store_chained(imgA + wc_off, kb, dh1[kb]);
-        store_natural(imgA + TILE_BYTES + wn_off, 0, A.x0[0]);
-        store_natural(imgA + TILE_BYTES + wn_off, 1, A.x0[1]);
-        __builtin_amdgcn_wave_barrier();
-        {                                                // dX0 = W1^T dH1 -> grad_feats
-            const floatx16 acc = back_block<4>(w1t, dh1);
-            if (live) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    store_grad4<TIO>(grad_feats + s * IN + 8 * q + 4 * g, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {                 // dW1 += dH1^T x0 ; db1
-            const bf16x8 a = load_transposed(imgA + tr_off, it);
-            db1[it] = mma16(a, ones, db1[it]);
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) dW1[it * 2 + kt] = mma16(a, load_transposed(imgA + TILE_BYTES + tr_off, kt), dW1[it * 2 + kt]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (more) { A.x0[0] = nx0[0]; A.x0[1] = nx0[1]; d[0] = nd[0]; d[1] = nd[1]; d[2] = nd[2]; }
-    }
-
-    // ---- per-wave partial gradients -> workspace row [block * WAVES + wave][NPARAM_PAD]
-    float* out = partials + ((int64_t)blockIdx.x * BWD_WAVES + wave) * NPARAM_PAD;
+    for (int t = 0; t < 8; ++t) G.dW1[t] = zero4();
+    G.db = zero4();
+}
+// visit every (packed parameter index, accumulator element) pair this lane owns: f(index, value)
+template <typename F> DEV void grad_visit(const GradAcc& G, int lane, F f) {
     const int col = lane & 15, rg = lane >> 4;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int row = 4 * rg + rr;                     // row inside a 16-row block
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if (row < 3) out[OW5 + row * H + 16 * kt + col] = dW5[kt][rr];
-            out[OW2 + row * H + 16 * kt + col] = dW2[kt][rr];
+            if (row < 3) f(OW5 + row * H + 16 * kt + col, G.dW5[kt][rr]);
+            f(OW2 + row * H + 16 * kt + col, G.dW2[kt][rr]);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int R = 16 * it + row;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) out[OW4 + R * H + 16 * kt + col] = dW4[it * 4 + kt][rr];
+            for (int kt = 0; kt < 4; ++kt) f(OW4 + R * H + 16 * kt + col, G.dW4[it * 4 + kt][rr]);
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) out[OW1 + R * IN + 16 * kt + col] = dW1[it * 2 + kt][rr];
+            for (int kt = 0; kt < 2; ++kt) f(OW1 + R * IN + 16 * kt + col, G.dW1[it * 2 + kt][rr]);
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
                 const int u = 16 * kt + col;             // feature index inside the 48-wide colour input
-                const float v = dW3[it * 3 + kt][rr];
-                if (kt == 0) { if (u >= 1) out[OW3 + R * X2 + u - 1] = v; }
-                else if (u < ONES_SLOT) out[OW3 + R * X2 + u - 1] = v;
-                else if (u == ONES_SLOT) out[OB3 + R] = v;
+                if (kt == 0) { if (u >= 1) f(OW3 + R * X2 + u - 1, G.dW3[it * 3 + kt][rr]); }
+                else if (u < ONES_SLOT) f(OW3 + R * X2 + u - 1, G.dW3[it * 3 + kt][rr]);
+                else if (u == ONES_SLOT) f(OB3 + R, G.dW3[it * 3 + kt][rr]);
             }
-            if (col == 0) { out[OB4 + R] = db4[it][rr]; out[OB1 + R] = db1[it][rr]; }
         }
-        if (col == 0) { out[OB2 + row] = db2[rr]; if (row < 3) out[OB5 + row] = db5[rr]; }
+        {                                                // shared bias block: row = combo, column = neuron inside its block
+            const int c = row;
+            if (c < DB_L1) f(OB4 + 16 * (c - DB_L4) + col, G.db[rr]);
+            else if (c < DB_L2) f(OB1 + 16 * (c - DB_L1) + col, G.db[rr]);
+            else if (c == DB_L2) f(OB2 + col, G.db[rr]);
+            else if (c == DB_L5 && col < 3) f(OB5 + col, G.db[rr]);
+        }
+    }
+}
+
+// one stage of an accumulator wave: dW[it][kt] += dY_it^T X_kt for the published images.  DB >= 0: the bias gradient
+// sum_n dY[n][.] of block `it` is accumulated into row DB + it of the shared block by an MFMA whose A operand is all ones in
+// that row and zero elsewhere (the transposed dY image is the B operand there).
+template <int NIT, int NKT, int DB>
+DEV void accumulate_stage(const unsigned char* imgY, const unsigned char* imgX, floatx4 (&dW)[NIT * NKT], floatx4& db, int lane) {
+    bf16x8 xb[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) xb[kt] = load_transposed(imgX, kt);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const bf16x8 a = load_transposed(imgY, it);
+        if (DB >= 0) {
+            const unsigned one2 = (lane & 15) == DB + it ? 0x3f803f80u : 0u;      // two bf16 1.0
+            const u32x4 row_of_ones = {one2, one2, one2, one2};
+            db = mma16(__builtin_bit_cast(bf16x8, row_of_ones), a, db);
+        }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) dW[it * NKT + kt] = mma16(a, xb[kt], dW[it * NKT + kt]);
+    }
+}
+
+template <typename TIO>
+__global__ void __launch_bounds__(BWD_THREADS)
+mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples,
+               const float* __restrict__ params, const float* __restrict__ grad_rgb, const float* __restrict__ grad_density,
+               TIO* __restrict__ grad_feats, float* __restrict__ partials, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* sw = reinterpret_cast<__bf16*>(smem);
+    float* biasv = reinterpret_cast<float*>(smem + BWD_OFF_BIASV);
+    int* flags = reinterpret_cast<int*>(smem + BWD_OFF_FLAGS);              // ready[4], done[4]
+    float* stg = reinterpret_cast<float*>(smem + BWD_OFF_IMG);              // aliases the images
+    stage_params<BWD_THREADS>(stg, params, threadIdx.x);
+    if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+    __syncthreads();
+    stage_weights<true>(sw, stg, threadIdx.x, BWD_THREADS);
+    stage_bias_vectors(biasv, stg, threadIdx.x, BWD_THREADS);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = wave & (BWD_PAIRS - 1);
+    const bool chain_role = wave < BWD_PAIRS;
+    LaneConst L;
+    lane_const<true>(L, sw, stg, lane, biasv);
+    __syncthreads();
+
+    unsigned char* ring = smem + BWD_OFF_IMG + (size_t)pair * BWD_PAIR_LDS;
+    int* ready = flags + pair;
+    int* done = flags + BWD_PAIRS + pair;
+    const int64_t ntiles = dbg & 1 ? 0 : (num_samples + TS - 1) / TS;         // dbg bit 0: prologue + epilogue only
+    const int64_t stride = (int64_t)gridDim.x * BWD_PAIRS;
+    int64_t tile = (int64_t)blockIdx.x * BWD_PAIRS + pair;
+    int seq = 0;                                                             // stages handed over so far
+    GradAcc G;
+
+    if (chain_role) {
+        const int n = L.n, g = L.g;
+        const __bf16* w5t = sw + L_W5T + n * LT5 + 8 * g;                   // this lane's rows of the transposed operands
+        const __bf16* w4t = sw + L_W4T + n * LT4 + 8 * g;
+        const __bf16* w3t = sw + L_W3T + (n & 15) * LT3 + 8 * g;
+        const __bf16* w2t = sw + L_W2T + n * LT2 + 8 * g;
+        const __bf16* w1t = sw + L_W1T + n * LT1 + 8 * g;
+        const int wc_off = (2 * n + g) * 8, wn_off = g * TILE_REGION + n * 16;
+        Acts A;
+        float d[3];
+        if (tile < ntiles) fetch_inputs<TIO>(feats, dirs, tile * TS + n, tile * TS + n < num_samples, g, A.x0, d);
+        for (; tile < ntiles; tile += stride) {
+            const int64_t s = tile * TS + n;
+            const bool live = s < num_samples;
+            float gr[3] = {0.f, 0.f, 0.f}, gd = 0.0f;
+            if (live && g == 0) { gr[0] = grad_rgb[s * 3]; gr[1] = grad_rgb[s * 3 + 1]; gr[2] = grad_rgb[s * 3 + 2]; gd = grad_density[s]; }
+            bf16x8 nx0[2];
+            float nd[3];
+            const int64_t ns = (tile + stride) * TS + n;
+            const bool more = tile + stride < ntiles;
+            if (more) fetch_inputs<TIO>(feats, dirs, ns, ns < num_samples, g, nx0, nd);
+
+            forward_tile<true>(L, d, A);
+
+            // ---- stage 5: dY5 = g_rgb * s (1 - s) (3 channels, natural slots 0..2 of the g = 0 lanes)
+            float g5[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // the g = 1 lanes hold other rows in sg: keep them 0
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g5[c] = g == 0 ? gr[c] * A.sg[c] * (1.0f - A.sg[c]) : 0.0f;
+            const bf16x8 dy5 = pack8f(g5);
+            {
+                unsigned char* slot = ring + (seq & 1) * 2 * TILE_BYTES;
+                wait_at_least(done, seq - 1);
+                store_natural(slot + wn_off, 0, dy5);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) store_chained(slot + TILE_BYTES + wc_off, kb, A.h3[kb]);
+                publish(ready, ++seq);
+            }
+            bf16x8 dh3[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                    // dH3 = (W5^T dY5) * (h3 > 0)
+                const floatx16 acc = back_block<1>(w5t + t * 32 * LT5, &dy5);
+                dh3[2 * t] = pack8_masked<0>(acc, A.h3[2 * t]);
+                dh3[2 * t + 1] = pack8_masked<8>(acc, A.h3[2 * t + 1]);
+            }
+            // ---- stage 4
+            {
+                unsigned char* slot = ring + (seq & 1) * 2 * TILE_BYTES;
+                wait_at_least(done, seq - 1);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) { store_chained(slot + wc_off, kb, dh3[kb]); store_chained(slot + TILE_BYTES + wc_off, kb, A.h2[kb]); }
+                publish(ready, ++seq);
+            }
+            bf16x8 dh2[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                    // dH2 = (W4^T dH3) * (h2 > 0)
+                const floatx16 acc = back_block<4>(w4t + t * 32 * LT4, dh3);
+                dh2[2 * t] = pack8_masked<0>(acc, A.h2[2 * t]);
+                dh2[2 * t + 1] = pack8_masked<8>(acc, A.h2[2 * t + 1]);
+            }
+            // ---- stage 3
+            {
+                unsigned char* slot = ring + (seq & 1) * 2 * TILE_BYTES;
+                wait_at_least(done, seq - 1);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) store_chained(slot + wc_off, kb, dh2[kb]);
+                store_chained(slot + TILE_BYTES + wc_off, 0, A.x2[0]);
+                store_natural(slot + TILE_BYTES + wn_off, 1, A.x2[1]);
+                store_natural(slot + TILE_BYTES + wn_off, 2, A.x2[2]);
+                publish(ready, ++seq);
+            }
+            bf16x8 dy2;
+            {                                                // dY2[m] = W3^T dH2 (m = 1..15), dY2[0] = g_density * (y0 > 0)
+                floatx16 acc = back_block<4>(w3t, dh2);
+                if (g == 0) acc[0] = A.y0 > 0.0f ? gd : 0.0f;
+                dy2 = pack8<0, false>(acc);
+            }
+            // ---- stage 2
+            {
+                unsigned char* slot = ring + (seq & 1) * 2 * TILE_BYTES;
+                wait_at_least(done, seq - 1);
+                store_chained(slot + wc_off, 0, dy2);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) store_chained(slot + TILE_BYTES + wc_off, kb, A.h1[kb]);
+                publish(ready, ++seq);
+            }
+            bf16x8 dh1[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                    // dH1 = (W2^T dY2) * (h1 > 0)
+                const floatx16 acc = back_block<1>(w2t + t * 32 * LT2, &dy2);
+                dh1[2 * t] = pack8_masked<0>(acc, A.h1[2 * t]);
+                dh1[2 * t + 1] = pack8_masked<8>(acc, A.h1[2 * t + 1]);
+            }
+            // ---- stage 1
+            {
+                unsigned char* slot = ring + (seq & 1) * 2 * TILE_BYTES;
+                wait_at_least(done, seq - 1);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) store_chained(slot + wc_off, kb, dh1[kb]);
+                store_natural(slot + TILE_BYTES + wn_off, 0, A.x0[0]);
+                store_natural(slot + TILE_BYTES + wn_off, 1, A.x0[1]);
+                publish(ready, ++seq);
+            }
+            {                                                // dX0 = W1^T dH1 -> grad_feats
+                const floatx16 acc = back_block<4>(w1t, dh1);
+                if (live) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        store_grad4<TIO>(grad_feats + s * IN + 8 * q + 4 * g, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                }
+            }
+            if (more) { A.x0[0] = nx0[0]; A.x0[1] = nx0[1]; d[0] = nd[0]; d[1] = nd[1]; d[2] = nd[2]; }
+        }
+    } else {
+        grad_zero(G);
+        const int tr_off = ((lane >> 1) & 1) * TILE_REGION + (8 * (lane >> 4) + 2 * ((lane >> 2) & 3) + (lane & 1)) * 8;
+        for (; tile < ntiles; tile += stride) {
+            const unsigned char* slot;
+#define WISP_NEXT_STAGE()  slot = ring + (seq & 1) * 2 * TILE_BYTES + tr_off; wait_at_least(ready, seq + 1)
+            WISP_NEXT_STAGE(); accumulate_stage<1, 4, DB_L5>(slot, slot + TILE_BYTES, G.dW5, G.db, lane); publish(done, ++seq);
+            WISP_NEXT_STAGE(); accumulate_stage<4, 4, DB_L4>(slot, slot + TILE_BYTES, G.dW4, G.db, lane); publish(done, ++seq);
+            WISP_NEXT_STAGE(); accumulate_stage<4, 3, -1>(slot, slot + TILE_BYTES, G.dW3, G.db, lane); publish(done, ++seq);
+            WISP_NEXT_STAGE(); accumulate_stage<1, 4, DB_L2>(slot, slot + TILE_BYTES, G.dW2, G.db, lane); publish(done, ++seq);
+            WISP_NEXT_STAGE(); accumulate_stage<4, 2, DB_L1>(slot, slot + TILE_BYTES, G.dW1, G.db, lane); publish(done, ++seq);
+#undef WISP_NEXT_STAGE
+        }
+    }
+
+    if (dbg & 2) return;                                                     // dbg bit 1: no epilogue
+    // ---- epilogue: one partial row per workgroup.  In two halves of the parameter range (four full rows do not fit in
+    // LDS next to the weights) the accumulator waves park their registers in LDS, then all threads sum the four rows
+    // and write the result with coalesced stores.
+    constexpr int HALF = NPARAM_PAD / 2;
+    float* red = reinterpret_cast<float*>(smem + BWD_OFF_IMG);              // [4][HALF], aliases the images
+    float* out = partials + (int64_t)blockIdx.x * NPARAM_PAD;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if (!chain_role) {
+            float* r = red + pair * HALF - h * HALF;
+            grad_visit(G, lane, [&](int idx, float v) { if ((idx >= HALF) == (h == 1)) r[idx] = v; });
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < HALF; j += BWD_THREADS)
+            out[h * HALF + j] = (red[j] + red[HALF + j]) + (red[2 * HALF + j] + red[3 * HALF + j]);
     }
 }
 
@@ -559,7 +660,7 @@ template <typename TIO>
 int launch_fwd(const void* feats, const float* dirs, int64_t S, const float* params, float* rgb, float* density, hipStream_t st) {
     const size_t lds = (size_t)L_FWD_END * 2 + (size_t)NPARAM_PAD * 4;
     auto kern = mlp_fwd_kernel<TIO>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
     const int64_t ntiles = (S + TS - 1) / TS;
     const int grid = (int)min64(ceil_div64(ntiles, FWD_WAVES), cu_count());
@@ -570,15 +671,16 @@ int launch_fwd(const void* feats, const float* dirs, int64_t S, const float* par
 template <typename TIO>
 int launch_bwd(const void* feats, const float* dirs, int64_t S, const float* params, const float* grad_rgb,
                const float* grad_density, void* grad_feats, float* partials, int* partial_rows, hipStream_t st) {
-    const size_t lds = (size_t)L_BWD_END * 2 + (size_t)BWD_WAVES * BWD_WAVE_LDS;
+    const size_t lds = BWD_LDS;
     auto kern = mlp_bwd_kernel<TIO>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
     const int64_t ntiles = (S + TS - 1) / TS;
-    const int grid = (int)min64(ceil_div64(ntiles, BWD_WAVES), cu_count());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, S, params, grad_rgb,
-                       grad_density, (TIO*)grad_feats, partials);
-    *partial_rows = grid * BWD_WAVES;
+    const int grid = (int)min64(ceil_div64(ntiles, BWD_PAIRS), cu_count());
+    static const int dbg = [] { const char* e = getenv("WISP_MLP_DBG"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), lds, st, (const TIO*)feats, dirs, S, params, grad_rgb,
+                       grad_density, (TIO*)grad_feats, partials, dbg);
+    *partial_rows = grid;
     return 0;
 }
 
