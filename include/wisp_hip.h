@@ -86,8 +86,8 @@ int wisp_spc_query(const uint8_t* octree, const int32_t* exsum, const float* coo
                    int level, int with_parents, int64_t* pidx /* [n] or [n, level+1] */,
                    wisp_stream_t stream);
 
-/* Morton-ordered occupancy bitfield of one level: bit m of bits[] is set iff the level-`level` cell with
- * Morton code m exists.  bits: u32 [ceil(8^level / 32)], zeroed by the call. */
+/* Occupancy bitfield of one level: bit  x | y << level | z << 2 level  of bits[] is set iff the level-`level` cell
+ * (x, y, z) exists.  bits: u32 [ceil(8^level / 32)], zeroed by the call. */
 int wisp_spc_build_bitfield(const int16_t* level_points, int64_t n_points, int level, uint32_t* bits,
                             wisp_stream_t stream);
 
@@ -163,7 +163,7 @@ int wisp_codebook_trilinear_bwd(const float* coords, const void* pidx, int pidx_
  * occupancy and stores a hit mask (u32 [R, ceil(N/32)]) plus the per-ray hit count.  emit: expands the
  * mask into the packed outputs at offsets[r].  jitter: f32 [R,N] in [0,1) or NULL, in which case a
  * counter-based generator keyed by (seed, ray, step) is used (the reference uses torch.rand, unseeded).
- * occ_bits: Morton bitfield of `level` (wisp_spc_build_bitfield) - or NULL to walk octree/exsum.
+ * occ_bits: bitfield of `level` (wisp_spc_build_bitfield) - or NULL to walk octree/exsum.
  */
 int wisp_raymarch_ray_count(const uint32_t* occ_bits, const uint8_t* octree, const int32_t* exsum,
                             const float* origins, const float* dirs, int64_t num_rays,

@@ -39,13 +39,6 @@ static __device__ __forceinline__ float axpy_unfused(float o, float d, float t) 
     return o + p;
 }
 
-static __device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z, int level) {
-    uint32_t m = 0;
-    for (int b = 0; b < level; ++b)
-        m |= (((x >> b) & 1u) << (3 * b + 2)) | (((y >> b) & 1u) << (3 * b + 1)) | (((z >> b) & 1u) << (3 * b));
-    return m;
-}
-
 static __device__ __forceinline__ bool occupied(const uint32_t* __restrict__ occ_bits, const uint8_t* __restrict__ octree,
                                                 const int32_t* __restrict__ exsum, float x, float y, float z, int level) {
     const bool inside = (fabsf(x) <= 1.0f) && (fabsf(y) <= 1.0f) && (fabsf(z) <= 1.0f);
@@ -56,7 +49,7 @@ static __device__ __forceinline__ bool occupied(const uint32_t* __restrict__ occ
     const int qy = min((int)floorf(res * (0.5f * y + 0.5f)), top);
     const int qz = min((int)floorf(res * (0.5f * z + 0.5f)), top);
     if (occ_bits) {
-        const uint32_t m = morton3((uint32_t)qx, (uint32_t)qy, (uint32_t)qz, level);
+        const uint32_t m = wisp_cell_bit((uint32_t)qx, (uint32_t)qy, (uint32_t)qz, level);
         return (occ_bits[m >> 5] >> (m & 31u)) & 1u;
     }
     int32_t node = 0;

@@ -59,18 +59,11 @@ extern "C" int wisp_spc_query(const uint8_t* octree, const int32_t* exsum, const
 }
 
 // ---------------------------------------------------------------------------------------------- bitfield
-static __device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z, int level) {
-    uint32_t m = 0;
-    for (int b = 0; b < level; ++b)
-        m |= (((x >> b) & 1u) << (3 * b + 2)) | (((y >> b) & 1u) << (3 * b + 1)) | (((z >> b) & 1u) << (3 * b));
-    return m;
-}
-
 __global__ void __launch_bounds__(256)
 spc_bitfield_kernel(const int16_t* __restrict__ pts, int64_t n, int level, uint32_t* __restrict__ bits) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t m = morton3((uint32_t)pts[i * 3], (uint32_t)pts[i * 3 + 1], (uint32_t)pts[i * 3 + 2], level);
+    const uint32_t m = wisp_cell_bit((uint32_t)pts[i * 3], (uint32_t)pts[i * 3 + 1], (uint32_t)pts[i * 3 + 2], level);
     atomicOr(bits + (m >> 5), 1u << (m & 31u));
 }
 

@@ -270,7 +270,7 @@ def spc_query(octree, exsum, coords, level, with_parents=False):
 
 
 def spc_bitfield(level_points, level):
-    """Morton-ordered occupancy bits of `level` (uint32 words viewed as int32 storage)."""
+    """Occupancy bits of `level`, row-major cell order (uint32 words viewed as int32 storage)."""
     level_points = _need(level_points, torch.int16, "level_points")
     words = max((8 ** level + 31) // 32, 1)
     bits = torch.empty(words, dtype=torch.int32, device=level_points.device)

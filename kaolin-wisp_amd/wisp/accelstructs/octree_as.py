@@ -4,7 +4,7 @@ Drop-in for wisp/accelstructs/octree_as.py:37-437: same constructors, attributes
 prefix, max_level, extent) and result layouts.  Differences that matter on MI355X:
   * 'ray' raymarch never materialises the R x N candidate tensors (octree_as.py:272-298): a count kernel keeps a
     1-bit-per-candidate mask, a scan turns per-ray counts into offsets, an emit kernel writes only survivors;
-  * the occupancy test is a lookup in a Morton-ordered bitfield of the marching level, built once per structure;
+  * the occupancy test is a lookup in a one-bit-per-cell field of the marching level, built once per structure;
   * `raymarch(..., jitter=...)` optionally injects the stratification jitter so identical ray batches give
     identical samples (the reference is unseeded).
 """
@@ -34,7 +34,7 @@ class OctreeAS(BaseAS):
         self.points, self.pyramid, self.prefix = wisp_spc_ops.octree_to_spc(octree)
         self.max_level = self.pyramid.shape[-1] - 2
         self.extent = dict()
-        self._occ_bits = {}          # level -> Morton bitfield (device tensor), built lazily
+        self._occ_bits = {}          # level -> occupancy bitfield (device tensor), built lazily
 
     # ------------------------------------------------------------------ constructors
     @classmethod
