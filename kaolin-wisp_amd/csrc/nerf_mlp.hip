@@ -6,26 +6,25 @@
 // round-trip HBM in the reference), PositionalEmbedder.forward (wisp/models/embedders/positional_embedder.py:51-66)
 // and the relu / sigmoid epilogues.
 //
-// Structure (persistent kernel, one wave = one tile of 32 samples, no inter-wave sync in the main loop):
-//   * all weights live in LDS for the whole launch (row-major [out][K], row stride padded so that the MFMA
-//     operand reads are bank-conflict free: +8 elements for bf16 ds_read_b128, +1 for fp32 ds_read_b32);
-//   * a layer is D[out][sample] = W[out][k] . X[sample][k]: weights are the MFMA A operand, the wave's activation
-//     tile (LDS, [sample][k]) is the B operand, so each lane ends up holding 16 output neurons of ONE sample
-//     (column = lane & 31).  Bias + relu are applied in registers and the result is written back to LDS as the
-//     next layer's [sample][k] tile - activations never touch HBM;
-//   * compute type TC = bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate) for the timed path, or fp32
-//     (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain) for the 1e-4 parity path;
+// This file holds the C entry points and the EXACT fp32 path (compute_dtype = f32, the 1e-4 parity contract); the bf16
+// path that training runs on is nerf_mlp_bf16.hip (register-chained layers, different kernel design).
+//
+// fp32 kernel (persistent, one wave = one tile of 32 samples, no inter-wave sync in the main loop):
+//   * all weights live in LDS for the whole launch (row-major [out][K], row stride + 1 so that the MFMA operand reads are
+//     bank-conflict free);
+//   * a layer is D[out][sample] = W[out][k] . X[sample][k] with v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain):
+//     weights are the A operand, the wave's activation tile (LDS, [sample][k]) is the B operand, so each lane ends up
+//     holding 16 output neurons of ONE sample (column = lane & 31).  Bias + relu are applied in registers and the result
+//     is written back to LDS as the next layer's [sample][k] tile - activations never touch HBM;
 //   * backward recomputes the forward into LDS, back-propagates dY through W^T with the same MFMA shape and
-//     accumulates dW += dY^T X over the whole launch in 224 accumulator VGPRs per lane (fp32 MFMA on the
-//     LDS-resident tiles); per-wave partial dW go to a workspace and a second tiny kernel reduces them, so no
-//     atomics are used at all.
+//     accumulates dW += dY^T X over the whole launch in 224 accumulator VGPRs per lane; per-wave partial dW go to a
+//     workspace and a second tiny kernel reduces them, so no atomics are used at all.
 // Fixed shape of this build: IN = 32 grid features, H = 64 hidden, 4 view frequencies (nerf_hash.yaml).
 #include "wisp_common.h"
 #include "nerf_mlp_shape.h"
 #include <cstdlib>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -38,12 +37,6 @@ template <> struct Traits<float> {
     static __device__ __forceinline__ float to_f(float v) { return v; }
     static __device__ __forceinline__ float from_f(float v) { return v; }
 };
-template <> struct Traits<__bf16> {
-    static constexpr int PAD = 8;
-    static __device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
-    static __device__ __forceinline__ __bf16 from_f(float v) { return (__bf16)v; }
-};
-
 // LDS geometry for compute type TC
 template <typename TC> struct Geo {
     static constexpr int P = Traits<TC>::PAD;
@@ -90,38 +83,8 @@ template <> struct MMA<float> {
     }
 };
 
-template <> struct MMA<__bf16> {
-    template <int K>
-    static __device__ __forceinline__ void nt(const __bf16* A, int lda, const __bf16* B, int ldb, floatx16& acc, int lane) {
-        const __bf16* pa = A + (lane & 31) * lda + 8 * (lane >> 5);
-        const __bf16* pb = B + (lane & 31) * ldb + 8 * (lane >> 5);
-#pragma unroll
-        for (int k = 0; k < K; k += 16) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(pa + k);
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(pb + k);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-        }
-    }
-    template <int M>
-    static __device__ __forceinline__ void tn(const __bf16* W, int ldw, int krow0, const __bf16* dY, int ldy, floatx16& acc,
-                                              int lane) {
-        const __bf16* pa = W + 8 * (lane >> 5) * ldw + krow0 + (lane & 31);
-        const __bf16* pb = dY + (lane & 31) * ldy + 8 * (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < M; i += 16) {
-            bf16x8 a;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = pa[(i + j) * ldw];           // column of W: strided 2-byte reads
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(pb + i);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-        }
-    }
-};
-
 // dW[i0 + r][k0 + c] += sum_n dY[n][i0 + r] * X[n][k0 + c]   (reduction over the wave's 32 samples).
-// fp32 tiles: exact fp32 MFMA, one sample pair per step.  bf16 tiles: two v_mfma_f32_32x32x16_bf16 per 32x32 block of
-// dW; both operands are COLUMNS of the [sample][feature] LDS tiles, gathered with strided 2-byte reads (the K slots of
-// A and B only have to agree with each other, so sample 8*half + j of each 16-sample step goes to slot j).
+// Exact fp32 MFMA, one sample pair per step; both operands are COLUMNS of the [sample][feature] LDS tiles.
 // One whole layer: acc[it * KT + kt] += dY[:, it-th 32 columns]^T  X[:, kt-th 32 columns]; every operand column block
 // is gathered from LDS once per sample step and reused by all the MFMAs that need it.
 template <int IT, int KT>
@@ -140,29 +103,6 @@ static __device__ __forceinline__ void dw_layer(const float* dY, int ldy, const 
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
                 acc[it * KT + kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it], b[kt], acc[it * KT + kt], 0, 0, 0);
-    }
-}
-
-template <int IT, int KT>
-static __device__ __forceinline__ void dw_layer(const __bf16* dY, int ldy, const __bf16* X, int ldx, floatx16* acc, int lane) {
-    const __bf16* pa = dY + 8 * (lane >> 5) * ldy + (lane & 31);
-    const __bf16* pb = X + 8 * (lane >> 5) * ldx + (lane & 31);
-#pragma unroll
-    for (int n = 0; n < TS; n += 16) {
-        bf16x8 a[IT], b[KT];
-#pragma unroll
-        for (int it = 0; it < IT; ++it)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[it][j] = pa[(n + j) * ldy + it * 32];
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) b[kt][j] = pb[(n + j) * ldx + kt * 32];
-#pragma unroll
-        for (int it = 0; it < IT; ++it)
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-                acc[it * KT + kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[it], b[kt], acc[it * KT + kt], 0, 0, 0);
     }
 }
 
@@ -252,8 +192,8 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
         }
         // ---- positional encoding of the view direction -> x2[:, 15..41]; zero the K padding 42..63.
         // layout [d ; sin(2^k d) k-major ; cos(2^k d) k-major] (positional_embedder.py:61-65).  The two half-waves split the
-        // work: half 0 writes d and the sines, half 1 the cosines and the padding.  fp32 path: one accurate sincosf per
-        // band (bit-compatible with torch.sin / torch.cos to ~1 ulp); bf16 path: one sincos + double-angle recurrences.
+        // work: half 0 writes d and the sines, half 1 the cosines and the padding; one accurate sinf / cosf per band
+        // (bit-compatible with torch.sin / torch.cos to ~1 ulp).
         {
             float d[3] = {0.f, 0.f, 0.f};
             if (live) { d[0] = dirs[s * 3]; d[1] = dirs[s * 3 + 1]; d[2] = dirs[s * 3 + 2]; }
@@ -267,22 +207,11 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
             }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                if (sizeof(TC) == 4) {
 #pragma unroll
-                    for (int k = 0; k < NF; ++k) {
-                        const float arg = (float)(1 << k) * d[a];
-                        const float val = half == 0 ? sinf(arg) : cosf(arg);
-                        row[3 + half * 3 * NF + k * 3 + a] = Tr::from_f(val);
-                    }
-                } else {
-                    float sv, cv;
-                    __sincosf(d[a], &sv, &cv);
-#pragma unroll
-                    for (int k = 0; k < NF; ++k) {
-                        row[3 + half * 3 * NF + k * 3 + a] = Tr::from_f(half == 0 ? sv : cv);
-                        const float s2 = 2.0f * sv * cv, c2 = 1.0f - 2.0f * sv * sv;      // angle doubling
-                        sv = s2; cv = c2;
-                    }
+                for (int k = 0; k < NF; ++k) {
+                    const float arg = (float)(1 << k) * d[a];
+                    const float val = half == 0 ? sinf(arg) : cosf(arg);
+                    row[3 + half * 3 * NF + k * 3 + a] = Tr::from_f(val);
                 }
             }
         }
@@ -519,19 +448,14 @@ int dispatch(const void* feats, int dtype_io, const float* dirs, int64_t s_total
         case WISP_F16: return launch<TC, __half, W, BWD>(feats, dirs, s_total, params, rgb, density, grad_rgb, grad_density, grad_feats, grad_params, workspace, st); \
         default: return launch<TC, __hip_bfloat16, W, BWD>(feats, dirs, s_total, params, rgb, density, grad_rgb, grad_density, grad_feats, grad_params, workspace, st); \
     }
-    if (compute == WISP_BF16) {
-        // register-chained bf16 kernels (nerf_mlp_bf16.hip); WISP_MLP_V1=1 selects the LDS-staged version below
-        static const bool v1 = [] { const char* e = getenv("WISP_MLP_V1"); return e && e[0] == '1'; }();
-        if (!v1) {
-            if (!BWD) return wisp_mlp::bf16_forward(feats, dtype_io, dirs, s_total, params, rgb, density, st);
-            int rows = 0;
-            if (int rc = wisp_mlp::bf16_backward(feats, dtype_io, dirs, s_total, params, grad_rgb, grad_density, grad_feats,
-                                                 workspace, &rows, st))
-                return rc;
-            hipLaunchKernelGGL(nerf_mlp_reduce_kernel, dim3((NPARAM + 63) / 64), dim3(1024), 0, st, workspace, rows, grad_params);
-            return 0;
-        }
-        WISP_MLP_GO(__bf16, 4)
+    if (compute == WISP_BF16) {                      // register-chained matrix-core kernels, nerf_mlp_bf16.hip
+        if (!BWD) return wisp_mlp::bf16_forward(feats, dtype_io, dirs, s_total, params, rgb, density, st);
+        int rows = 0;
+        if (int rc = wisp_mlp::bf16_backward(feats, dtype_io, dirs, s_total, params, grad_rgb, grad_density, grad_feats,
+                                             workspace, &rows, st))
+            return rc;
+        hipLaunchKernelGGL(nerf_mlp_reduce_kernel, dim3((NPARAM + 63) / 64), dim3(1024), 0, st, workspace, rows, grad_params);
+        return 0;
     }
     if (BWD) { WISP_MLP_GO(float, 1) }
     WISP_MLP_GO(float, 2)

@@ -477,7 +477,7 @@ template <typename TIO>
 __global__ void __launch_bounds__(BWD_THREADS)
 mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples,
                const float* __restrict__ params, const float* __restrict__ grad_rgb, const float* __restrict__ grad_density,
-               TIO* __restrict__ grad_feats, float* __restrict__ partials, int dbg) {
+               TIO* __restrict__ grad_feats, float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16* sw = reinterpret_cast<__bf16*>(smem);
     float* biasv = reinterpret_cast<float*>(smem + BWD_OFF_BIASV);
@@ -498,7 +498,7 @@ mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
     unsigned char* ring = smem + BWD_OFF_IMG + (size_t)pair * BWD_PAIR_LDS;
     int* ready = flags + pair;
     int* done = flags + BWD_PAIRS + pair;
-    const int64_t ntiles = dbg & 1 ? 0 : (num_samples + TS - 1) / TS;         // dbg bit 0: prologue + epilogue only
+    const int64_t ntiles = (num_samples + TS - 1) / TS;
     const int64_t stride = (int64_t)gridDim.x * BWD_PAIRS;
     int64_t tile = (int64_t)blockIdx.x * BWD_PAIRS + pair;
     int seq = 0;                                                             // stages handed over so far
@@ -631,7 +631,6 @@ mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
         }
     }
 
-    if (dbg & 2) return;                                                     // dbg bit 1: no epilogue
     // ---- epilogue: one partial row per workgroup.  In two halves of the parameter range (four full rows do not fit in
     // LDS next to the weights) the accumulator waves park their registers in LDS, then all threads sum the four rows
     // and write the result with coalesced stores.
@@ -677,9 +676,8 @@ int launch_bwd(const void* feats, const float* dirs, int64_t S, const float* par
     if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
     const int64_t ntiles = (S + TS - 1) / TS;
     const int grid = (int)min64(ceil_div64(ntiles, BWD_PAIRS), cu_count());
-    static const int dbg = [] { const char* e = getenv("WISP_MLP_DBG"); return e ? atoi(e) : 0; }();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), lds, st, (const TIO*)feats, dirs, S, params, grad_rgb,
-                       grad_density, (TIO*)grad_feats, partials, dbg);
+                       grad_density, (TIO*)grad_feats, partials);
     *partial_rows = grid;
     return 0;
 }
