@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc
 REPO="$PWD"
-RX="hashgrid|nerf_mlp|raymarch|composite|adamw"
+RX="hashgrid|mlp_|raymarch|composite|adamw"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum"; do
   tag=$(echo $grp | tr ' ' '_')
   (cd /tmp && rm -rf /tmp/pmc_$tag && timeout 600 rocprofv3 --pmc $grp --kernel-trace --kernel-include-regex "$RX" --output-format csv -d /tmp/pmc_$tag -o p -- python "$REPO/bench.py" --steps 6 --warmup 2 --no-cpu-baseline > "$REPO/gpurun_out/pmc/$tag.log" 2>&1)
