@@ -10,6 +10,7 @@ weight decay, names containing 'grid' get lr * grid_lr_weight; MultiStepLR).  MI
   * bf16 autocast replaces the reference's fp16 autocast + GradScaler (no loss scaling needed).
 """
 import math
+import os
 from typing import Optional
 
 import torch
@@ -64,6 +65,111 @@ class FlatParams:
             p._wisp_shadow = self.shadow[off - a:off - a + p.numel()].view(p.shape)
 
 
+class _DirectHashNeRFStep:
+    """The forward + loss + backward of MultiviewTrainStep.step for the nerf_hash.yaml pipeline shape (OctreeAS 'ray' march,
+    'cat' HashGrid, the fused 64-wide decoder, PackedRFTracer without extra channels), issued as the same HIP launches in the
+    same order as Pipeline.forward + autograd would issue them - minus the nn.Module / channel-negotiation / autograd-engine
+    plumbing, which costs more host time per step than the GPU needs for a 2^18-sample batch.  Results are identical to the
+    modular path (tests/test_gpu_parity.py::test_direct_step_equals_modular_step)."""
+
+    @staticmethod
+    def supports(pipeline):
+        from wisp.accelstructs import OctreeAS
+        from wisp.models.grids import HashGrid
+        from wisp.models.nefs import NeuralRadianceField
+        from wisp.tracers import PackedRFTracer
+        from wisp.ops.nerf_mlp import SUPPORTED
+        nef, tracer = pipeline.nef, pipeline.tracer
+        if type(nef) is not NeuralRadianceField or type(tracer) is not PackedRFTracer:
+            return False
+        grid = nef.grid
+        if type(grid) is not HashGrid or grid.multiscale_type != 'cat' or type(grid.blas) is not OctreeAS:
+            return False
+        if getattr(tracer, 'raymarch_type', None) != 'ray' or grid.blas.max_level > 10:
+            return False
+        return (nef.fused_decoder and nef.hidden_dim == SUPPORTED["hidden"] and nef.num_layers == 1
+                and nef.view_multires == SUPPORTED["view_freqs"] and nef.pos_embedder is None
+                and nef.view_embedder_type == 'positional' and nef.activation_type == 'relu'
+                and nef.layer_type in ('linear', 'none') and nef.effective_feature_dim() == SUPPORTED["in_dim"]
+                and all(t is not None for t in _decoder_tensors(nef))
+                and getattr(nef, 'decoder_compute', 'auto') == 'auto')
+
+    def __init__(self, trainer):
+        from wisp.ops.nerf_mlp import _flat_view, SUPPORTED
+        self.t = trainer
+        nef = trainer.pipeline.nef
+        grid = nef.grid
+        self.shape = (SUPPORTED["in_dim"], SUPPORTED["hidden"], SUPPORTED["view_freqs"])
+        dec = _decoder_tensors(nef)
+        self.packed = _flat_view([p.detach() for p in dec])                  # zero-copy views of the flat buffers
+        self.packed_grad = _flat_view([p.grad for p in dec])
+        cb = grid.codebook
+        self.table = cb.feats
+        self.first_idx = cb.begin_idxes
+        self.res = [int(r) for r in cb.resolutions.reshape(-1).tolist()]
+        self.bitwidth = grid.codebook_bitwidth
+        # the tracer queries lod_idx = num_lods - 1 and 'cat' zeroes the columns from lod_idx * feature_dim on
+        # (reference hash_grid.py:226-229): the finest level's columns are zero, exactly as in the modular path
+        self.zero_from_col = (grid.num_lods - 1) * grid.feature_dim
+        self.ok = self.packed is not None and self.packed_grad is not None
+
+    def run(self, rays, img_gts, jitter=None):
+        """-> (loss tensor, num_samples); gradients are left accumulated in the flat gradient buffer."""
+        C = _hip()
+        t = self.t
+        pipe = t.pipeline
+        nef, tracer = pipe.nef, pipe.tracer
+        blas = nef.grid.blas
+        if torch.is_tensor(rays.dist_min) or torch.is_tensor(rays.dist_max):
+            raise TypeError("'ray' raymarch needs scalar Rays.dist_min / dist_max (as the reference, octree_as.py:276-277)")
+        dev = rays.origins.device
+        blas._to_device(dev)
+        level = blas.max_level
+        N = rays.origins.shape[0]
+        ridx, samples, depths, deltas, boundary, offsets = C.raymarch_ray(
+            blas._bitfield(level), blas.octree, blas.prefix, rays.origins, rays.dirs, rays.dist_min, rays.dist_max,
+            tracer.num_steps, level, jitter, blas._draw_seed())
+        S = samples.shape[0]
+        tracer.prev_num_samples = S
+        dirs = rays.dirs.index_select(0, ridx)
+        table = self.table
+        if t.enable_amp:
+            shadow = getattr(table, '_wisp_shadow', None)
+            table = shadow if shadow is not None else table.to(torch.bfloat16)
+        feats = C.hashgrid_interpolate(samples, table.detach(), self.first_idx, self.res, self.bitwidth, self.zero_from_col)
+        i, h, f = self.shape
+        color, density = C.nerf_mlp_forward(feats, dirs, self.packed, i, h, f, t.enable_amp)
+        if tracer.bg_color.device != dev:
+            tracer.bg_color = tracer.bg_color.to(dev)
+        bg = tracer._bg_host()
+        rgb, _alpha, _depth, _hit, _w = C.composite_fwd(color, density, deltas, None, None, offsets, N, bg)
+        # loss and its gradient w.r.t. the composited colours (what autograd derives for loss_fn(...).mean())
+        diff = rgb - img_gts
+        inv = 1.0 / diff.numel()
+        if t.rgb_loss_type == 'huber':
+            loss = torch.nn.functional.smooth_l1_loss(rgb, img_gts, reduction='none').mean()
+            g_rgb = torch.clamp(diff, -1.0, 1.0) * inv
+        elif t.rgb_loss_type == 'l2':
+            loss = (diff * diff).mean()
+            g_rgb = diff * (2.0 * inv)
+        elif t.rgb_loss_type == 'l1':
+            loss = diff.abs().mean()
+            g_rgb = torch.sign(diff) * inv
+        else:
+            raise NotImplementedError
+        g_color, g_density = C.composite_bwd(g_rgb, None, None, color, density, deltas, None, None, offsets, bg)
+        g_feats, _ = C.nerf_mlp_backward(feats, dirs, self.packed, g_color, g_density, i, h, f, t.enable_amp,
+                                         grad_params=self.packed_grad)
+        C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res, self.bitwidth,
+                                        self.zero_from_col, out=self.table.grad)
+        return loss, S
+
+
+def _decoder_tensors(nef):
+    from wisp.ops.nerf_mlp import _decoder_tensors as dt
+    return dt(nef)
+
+
 class MultiviewTrainStep:
     def __init__(self, pipeline, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, betas=(0.9, 0.999),
                  rgb_loss_type='huber', prune_every=100, target_sample_size=2 ** 18, max_rays=2 ** 18,
@@ -86,11 +192,15 @@ class MultiviewTrainStep:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.group = process_group
         # WISP_FORCE_ALLREDUCE=1 runs the collective even with one rank (exercises the RCCL path on a single-GPU box)
-        import os
         self.force_allreduce = (os.environ.get("WISP_FORCE_ALLREDUCE", "0") == "1" and dist.is_available()
                                 and dist.is_initialized())
         # prune draws must be identical on every rank so the replicated octrees stay identical
         self._prune_gen = torch.Generator().manual_seed(seed)
+        # specialised issue order for the flagship pipeline shape (WISP_DIRECT_STEP=0 keeps the modular path)
+        self._direct = None
+        if os.environ.get("WISP_DIRECT_STEP", "1") != "0" and _DirectHashNeRFStep.supports(pipeline):
+            d = _DirectHashNeRFStep(self)
+            self._direct = d if d.ok else None
 
     # -------------------------------------------------------------------------------------------- schedule / groups
     def _lr_scale(self):
@@ -147,11 +257,15 @@ class MultiviewTrainStep:
         """One optimisation step on this rank's ray shard.  Returns (loss tensor, num_samples)."""
         self.pre_step()
         self.total_iterations += 1
-        kw = {} if jitter is None else {"jitter": jitter}
-        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.enable_amp):
-            rb = self.pipeline(rays=rays, lod_idx=None, channels=["rgb"], **kw)
-            loss = self.loss_fn(rb.rgb.float(), img_gts)
-        loss.backward()
+        if self._direct is not None and self.pipeline.nef.training:
+            with torch.no_grad():
+                loss, _ = self._direct.run(rays, img_gts, jitter)
+        else:
+            kw = {} if jitter is None else {"jitter": jitter}
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.enable_amp):
+                rb = self.pipeline(rays=rays, lod_idx=None, channels=["rgb"], **kw)
+                loss = self.loss_fn(rb.rgb.float(), img_gts)
+            loss.backward()
         self.allreduce_grads()
         self.optimizer_step()
         self.calc_adaptive_rays(rays.origins.shape[0])

@@ -10,7 +10,7 @@ for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=Tru
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row.get("Kernel_Name", "")
-            short = name.split("(")[0][-90:]
+            short = name.replace("(anonymous namespace)::", "").split("(")[0][-90:]
             out[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 w = csv.writer(sys.stdout)
 w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch", "sum"])
