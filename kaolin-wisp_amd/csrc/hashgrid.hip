@@ -156,15 +156,18 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 //      same grid cell (~2 per cell at res 512, the whole wave at res 16 for the 2048-step march), and a cell fixes all
 //      2^DIM corner indices.  Each wave runs a segmented (by cell id) inclusive scan over its 64 lanes for the
 //      2^DIM x F corner contributions; only the LAST lane of every run emits: 36.5 instead of 256 per sample.
-//  (2) Binned LDS reduction for the hashed levels (they carry ~85 % of the remaining traffic and have no locality):
-//      the emit kernel appends (index, values) records to one of T/CHUNK buckets per level; a second kernel gives every
-//      (level, chunk) to ONE workgroup, which accumulates its bucket in LDS (ds_add_f32) and adds the finished slice to
-//      the gradient table with plain coalesced stores.  Records cost 12 B of streamed traffic instead of a memory-side
-//      atomic; bucket overflow (never observed: capacity is 1.25x the no-merge worst case) falls back to an atomic.
+//  (2) Binned LDS reduction: the emit kernel writes (index, values) records into buckets of 8192 table entries per level;
+//      a second kernel gives every (level, bucket) to ONE workgroup, which accumulates the bucket in LDS and adds the
+//      finished slice to the gradient table with plain coalesced stores.  A bucket is stored as one fixed-capacity SLOT per
+//      emitting workgroup ([bucket][tile][slot_cap] records + a count): the emitter needs no histogram pass, no global
+//      reservation atomics (they are memory-side too: 2 M of them cost 0.1 ms) and no second pass over its registers - it
+//      ranks a record inside its slot with one LDS counter and writes it straight away.  Records cost 12 B of streamed
+//      traffic instead of a memory-side atomic; a full slot (capacity = 1.5 x / 4 x the no-merge expectation on hashed / dense levels, at least 128)
+//      falls back to the atomic.
 struct LevelList { int32_t n; int32_t lv[HG_MAX_LODS]; };
-// per binned level: #chunks, bucket capacity (records), first cursor slot, first record slot, table entries, split factor
+// per binned level: #buckets, slot capacity (records), first count cell, first record, table entries, split factor
 struct BinLevels {
-    int32_t chunks[HG_MAX_LODS]; uint32_t cap[HG_MAX_LODS]; int32_t cur_base[HG_MAX_LODS]; int64_t rec_base[HG_MAX_LODS];
+    int32_t chunks[HG_MAX_LODS]; uint32_t cap[HG_MAX_LODS]; int64_t cnt_base[HG_MAX_LODS]; int64_t rec_base[HG_MAX_LODS];
     uint32_t entries[HG_MAX_LODS]; int32_t splits[HG_MAX_LODS];
     int32_t blk_base[HG_MAX_LODS + 1];      // reduce kernel: first workgroup of every level in the flattened 1-D grid
 };
@@ -269,10 +272,10 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 
 // ---- binned path for hashed levels -----------------------------------------------------------------------------------
 #ifndef EM_THREADS
-#define EM_THREADS 512         // 512 threads x 2 groups = 1024-sample tiles: halves the bucket reservations (measured best)
+#define EM_THREADS 512
 #endif
 #ifndef EM_GROUPS
-#define EM_GROUPS 2           // 64-sample groups per wave
+#define EM_GROUPS 2           // 64-sample groups per wave (1024-sample tiles; 4096 measured slower in the reduce)
 #endif
 #define EM_TILE (EM_THREADS * EM_GROUPS)     // samples per emit workgroup
 #ifndef EM_MIN_WAVES
@@ -282,16 +285,13 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #define BIN_MAX_CHUNKS 1024
 
 // record = { index within the level table, F gradient values }, (1 + F) dwords.
-// A workgroup handles EM_TILE samples of one level.  The run tails stay in registers across the two phases
-// (count per bucket -> one reservation per non-empty bucket -> scatter), so the only LDS use is 2 x chunks counters and
-// occupancy is bounded by registers, not by a staging buffer.
+// A workgroup handles EM_TILE samples of one level and owns slot [bucket][blockIdx.x] of every bucket of that level.
 template <typename T, int F, int DIM>
 __global__ void __launch_bounds__(EM_THREADS, EM_MIN_WAVES)
 hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ grad_feats,
                          const int64_t* __restrict__ first_idx, HashLevels lv, LevelList levels, int num_lods,
                          uint32_t tsize, int tsize_pow2, int zero_from_col, int chunk_shift, BinLevels bins,
-                         uint32_t* __restrict__ cursors, uint32_t* __restrict__ records, float* __restrict__ grad_codebook,
-                         int dbg) {
+                         uint32_t* __restrict__ counts, uint32_t* __restrict__ records, float* __restrict__ grad_codebook) {
     constexpr int NC = 1 << DIM;
     constexpr int RW = 1 + F;
     constexpr int GROUPS = EM_TILE / EM_THREADS;         // 64-sample groups per wave
@@ -299,19 +299,17 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
     const int li = blockIdx.y;
     const int l = levels.lv[li];
     const int chunks = bins.chunks[li];
-    uint32_t* s_hist = em_smem;                          // [chunks] records of this tile per bucket, then running rank
-    uint32_t* s_base = em_smem + chunks;                 // [chunks] reserved global offset per bucket
+    uint32_t* s_rank = em_smem;                          // [chunks] records written so far per bucket
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int32_t res = lv.res[l];
     const bool dense = lv.dense[l] != 0;
     const uint32_t cap = bins.cap[li];
-    for (int b = threadIdx.x; b < chunks; b += EM_THREADS) s_hist[b] = 0;
+    const uint32_t ntiles = gridDim.x;
+    for (int b = threadIdx.x; b < chunks; b += EM_THREADS) s_rank[b] = 0;
     __syncthreads();
     const int64_t tile0 = (int64_t)blockIdx.x * EM_TILE;
-    CornerSetup<DIM> cs[GROUPS];
-    float v[GROUPS][NC][F];
-    bool issue[GROUPS];
+    uint32_t* __restrict__ rec_l = records + (size_t)bins.rec_base[li] * RW;
 #pragma unroll
     for (int g = 0; g < GROUPS; ++g) {
         const int64_t i = tile0 + (int64_t)(wave * GROUPS + g) * 64 + lane;
@@ -319,50 +317,33 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
         float c[DIM];
 #pragma unroll
         for (int a = 0; a < DIM; ++a) c[a] = live ? coords[i * DIM + a] : 0.0f;
-        issue[g] = tail_compute<T, F, DIM, true>(c, live, i, l, num_lods, res, dense, tsize, tsize_pow2 != 0, zero_from_col,
-                                                 grad_feats, lane, cs[g], v[g]);
-        if (issue[g] && !(dbg & 1)) {
-#pragma unroll
-            for (int j = 0; j < NC; ++j) atomicAdd(&s_hist[(uint32_t)cs[g].idx[j] >> chunk_shift], 1u);
-        }
-    }
-    if (dbg & 1) {          // experiment: tail computation only
-        float chk = 0.f;
-#pragma unroll
-        for (int g = 0; g < GROUPS; ++g) chk += v[g][0][0] + (float)cs[g].idx[NC - 1] + (issue[g] ? 1.f : 0.f);
-        if (chk == 1.2345e30f) grad_codebook[0] = chk;
-        return;
-    }
-    __syncthreads();
-    if (dbg & 2) return;    // experiment: + bucket histogram
-    uint32_t* cur = cursors + bins.cur_base[li];
-    for (int b = threadIdx.x; b < chunks; b += EM_THREADS) {
-        const uint32_t h = s_hist[b];
-        s_base[b] = h ? atomicAdd(cur + b, h) : 0u;      // reserve [base, base + h) in bucket b
-        s_hist[b] = 0;                                    // reused as the running rank inside the reservation
-    }
-    __syncthreads();
-    if (dbg & 4) return;    // experiment: + reservations
-    uint32_t* __restrict__ rec_l = records + (size_t)bins.rec_base[li] * RW;
-#pragma unroll
-    for (int g = 0; g < GROUPS; ++g) {
-        if (!issue[g]) continue;
+        CornerSetup<DIM> cs;
+        float v[NC][F];
+        const bool issue = tail_compute<T, F, DIM, true>(c, live, i, l, num_lods, res, dense, tsize, tsize_pow2 != 0,
+                                                         zero_from_col, grad_feats, lane, cs, v);
+        if (!issue) continue;
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
-            const uint32_t idx = (uint32_t)cs[g].idx[j];
+            const uint32_t idx = (uint32_t)cs.idx[j];
             const uint32_t b = idx >> chunk_shift;
-            const uint32_t pos = s_base[b] + atomicAdd(&s_hist[b], 1u);
+            const uint32_t pos = atomicAdd(&s_rank[b], 1u);
             if (pos < cap) {
-                uint32_t* dst = rec_l + ((size_t)b * cap + pos) * RW;
+                uint32_t* dst = rec_l + (((size_t)b * ntiles + blockIdx.x) * cap + pos) * RW;
                 dst[0] = idx;
 #pragma unroll
-                for (int k = 0; k < F; ++k) dst[1 + k] = __float_as_uint(v[g][j][k]);
-            } else {                                      // bucket full: fall back to the memory-side atomic
+                for (int k = 0; k < F; ++k) dst[1 + k] = __float_as_uint(v[j][k]);
+            } else {                                      // slot full: fall back to the memory-side atomic
                 float* p = grad_codebook + (first_idx[l] + (int64_t)idx) * F;
 #pragma unroll
-                for (int k = 0; k < F; ++k) atomicAdd(p + k, v[g][j][k]);
+                for (int k = 0; k < F; ++k) atomicAdd(p + k, v[j][k]);
             }
         }
+    }
+    __syncthreads();
+    uint32_t* __restrict__ cnt_l = counts + bins.cnt_base[li];
+    for (int b = threadIdx.x; b < chunks; b += EM_THREADS) {
+        const uint32_t c = s_rank[b];
+        cnt_l[(size_t)b * ntiles + blockIdx.x] = c < cap ? c : cap;
     }
 }
 
@@ -389,13 +370,13 @@ struct AccFix64 {
 template <int F, typename ACC>
 __global__ void __launch_bounds__(RD_THREADS)
 hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList levels, int chunk_shift, BinLevels bins,
-                           const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ records,
-                           float* __restrict__ grad_codebook, int dbg) {
+                           uint32_t ntiles, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ records,
+                           float* __restrict__ grad_codebook) {
     constexpr int RW = 1 + F;
     typedef typename ACC::type acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char rd_smem[];
     acc_t* rd_acc = reinterpret_cast<acc_t*>(rd_smem);                  // [chunk entries * F]
-    // flattened (level, chunk, split) grid: only workgroups that have work are launched
+    // flattened (level, bucket, split) grid
     int li = 0;
     while (li + 1 < levels.n && (int)blockIdx.x >= bins.blk_base[li + 1]) ++li;
     const int splits = bins.splits[li];
@@ -404,38 +385,60 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
     const int l = levels.lv[li];
     const uint32_t csize = 1u << chunk_shift;
     const uint32_t cap = bins.cap[li];
-    uint32_t cnt = cursors[bins.cur_base[li] + b];
-    if (cnt > cap) cnt = cap;
-    if (cnt <= (uint32_t)z) return;
     const uint32_t first = (uint32_t)b << chunk_shift;
     const uint32_t entries = bins.entries[li];
     const uint32_t lim = (entries > first ? min(entries - first, csize) : 0u) * F;
     for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) rd_acc[e] = (acc_t)0;
     __syncthreads();
-    const uint32_t* src = records + ((size_t)bins.rec_base[li] + (size_t)b * cap) * RW;
-    // 4 independent record loads in flight per thread before the LDS adds
-    const uint32_t step = RD_THREADS * splits;
-    for (uint32_t r0 = z + threadIdx.x * splits; r0 < cnt; r0 += 4 * step) {
-        uint32_t w[4][RW];
+    const uint32_t* __restrict__ cnt = counts + bins.cnt_base[li] + (size_t)b * ntiles;
+    const uint32_t* __restrict__ src = records + ((size_t)bins.rec_base[li] + (size_t)b * ntiles * cap) * RW;
+    // This workgroup takes the emitting tiles z, z + splits, ...; its waves take them 64 at a time.  A wave fetches the
+    // 64 counts with one load, enumerates the (slot, 64-record chunk) pairs through a prefix sum over the lanes and walks
+    // them with eight record loads in flight per lane (lane = record inside the chunk).
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = RD_THREADS / 64;
+    constexpr int INFLIGHT = 8;
+    const uint32_t my_tiles = ntiles > (uint32_t)z ? (ntiles - z + splits - 1) / splits : 0u;   // tiles of this workgroup
+    for (uint32_t base = wave * 64; base < my_tiles; base += NW * 64) {
+        const uint32_t k = base + lane;
+        const uint32_t cnt_of_lane = k < my_tiles ? cnt[z + k * splits] : 0u;
+        const uint32_t cc = (cnt_of_lane + 63u) >> 6;     // chunks of this lane's slot
+        uint32_t inc = cc;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t r = r0 + u * step;
-            const uint32_t* rec = src + (size_t)(r < cnt ? r : r0) * RW;
-#pragma unroll
-            for (int q = 0; q < RW; ++q) w[u][q] = rec[q];
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, d, 64);
+            if (lane >= d) inc += t;
         }
+        const uint32_t exc = inc - cc;
+        const uint32_t pairs = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        for (uint32_t p0 = 0; p0 < pairs; p0 += INFLIGHT) {
+            uint32_t w[INFLIGHT][RW];
+            bool act[INFLIGHT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (r0 + u * step < cnt && !(dbg & 1)) {
-                const uint32_t e = w[u][0] - first;
+            for (int u = 0; u < INFLIGHT; ++u) {
+                const uint32_t pr = p0 + u < pairs ? p0 + u : p0;
+                const int t = __popcll(__ballot(exc <= pr)) - 1;                     // slot that owns pair pr (wave-uniform)
+                const uint32_t chunk = pr - (uint32_t)__builtin_amdgcn_readlane((int)exc, t);
+                const uint32_t n_t = (uint32_t)__builtin_amdgcn_readlane((int)cnt_of_lane, t);
+                const uint32_t r = chunk * 64 + lane;
+                act[u] = (p0 + u < pairs) && r < n_t;
+                const uint32_t tile = z + (base + t) * splits;
+                const uint32_t* rec = src + ((size_t)tile * cap + (act[u] ? r : 0u)) * RW;
 #pragma unroll
-                for (int k = 0; k < F; ++k) ACC::add(rd_acc, e * F + k, __uint_as_float(w[u][1 + k]));
+                for (int q = 0; q < RW; ++q) w[u][q] = rec[q];
+            }
+#pragma unroll
+            for (int u = 0; u < INFLIGHT; ++u) {
+                if (act[u]) {
+                    const uint32_t e = w[u][0] - first;
+#pragma unroll
+                    for (int kk = 0; kk < F; ++kk) ACC::add(rd_acc, e * F + kk, __uint_as_float(w[u][1 + kk]));
+                }
             }
         }
     }
     __syncthreads();
     float* __restrict__ dst = grad_codebook + (first_idx[l] + (int64_t)first) * F;
-    if (dbg & 2) return;
     if (splits == 1) {
         for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
             const float a = ACC::get(rd_acc, e);
@@ -494,13 +497,14 @@ static bool bwd_merge_enabled() { static const bool v = env_flag("WISP_HG_BWD_ME
 static bool bwd_bin_enabled() { static const bool v = env_flag("WISP_HG_BWD_BIN", true); return v; }
 
 // bin geometry shared by the workspace query and the launcher
-struct BinPlan { int chunk_shift, max_chunks, max_splits, total_blocks; BinLevels bins; int64_t cursor_bytes, record_bytes; bool ok; };
+struct BinPlan { int chunk_shift, max_chunks, max_splits, total_blocks; int64_t ntiles; BinLevels bins; int64_t count_bytes, record_bytes; bool ok; };
 static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels, int feature_dim, int64_t tsize, int dim) {
     BinPlan p{};
     const int corners = 1 << dim;
     int64_t centries = 16384 / feature_dim;               // chunk entries: 64 KiB as fp32, 128 KiB as 64-bit fixed point
     while (((int64_t)1 << (p.chunk_shift + 1)) <= centries) ++p.chunk_shift;
-    int64_t cur = 0, rec = 0;
+    p.ntiles = ceil_div64(n, EM_TILE);
+    int64_t cnt = 0, rec = 0;
     p.ok = true;
     for (int li = 0; li < levels.n; ++li) {
         const int l = levels.lv[li];
@@ -508,26 +512,33 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         if (lv.dense[l]) { entries = 1; for (int a = 0; a < dim; ++a) entries *= (int64_t)(lv.res[l] + 1); }   // corner index < (res+1)^dim
         if (entries > tsize && !lv.dense[l]) entries = tsize;
         const int64_t chunks = (entries + ((int64_t)1 << p.chunk_shift) - 1) >> p.chunk_shift;
-        int64_t cap = (n * corners + chunks - 1) / chunks;    // no-merge worst case under a uniform spread ...
-        cap = cap + cap / 4 + 4096;                           // ... + 25 % skew margin (overflow falls back to atomics)
-        if (chunks > BIN_MAX_CHUNKS || cap > 0x7fffffff || entries > 0xffffffffLL) p.ok = false;
+        // slot = the records one emitting tile sends to one bucket: no-merge expectation under a uniform spread x 1.5,
+        // at least 128 (overflow falls back to atomics, so the bound only has to be a good guess)
+        int64_t cap = ((int64_t)EM_TILE * corners + chunks - 1) / chunks;
+        // a hash spreads a tile's records evenly over the buckets (x 1.5 covers the Poisson tail); on a dense level a
+        // bucket is a slab of space and a tile's rays may favour some slabs (x 4)
+        cap = lv.dense[l] ? cap * 4 : cap + cap / 2;
+        if (cap < 128) cap = 128;
+        if (cap > (int64_t)EM_TILE * corners) cap = (int64_t)EM_TILE * corners;
+        if (chunks > BIN_MAX_CHUNKS || entries > 0xffffffffLL) p.ok = false;
         p.bins.chunks[li] = (int32_t)chunks;
         p.bins.cap[li] = (uint32_t)cap;
-        p.bins.cur_base[li] = (int32_t)cur;
+        p.bins.cnt_base[li] = cnt;
         p.bins.rec_base[li] = rec;
         p.bins.entries[li] = (uint32_t)entries;
         static const int split_target = [] { const char* e = getenv("WISP_RD_SPLITS"); return e ? atoi(e) : 64; }();
         int splits = (int)(split_target / chunks);            // ~split_target reduce workgroups per coarse level (atomic flush)
+        if (splits > p.ntiles) splits = (int)p.ntiles;
         p.bins.splits[li] = splits < 1 ? 1 : splits;
         if (chunks > p.max_chunks) p.max_chunks = (int)chunks;
         if (p.bins.splits[li] > p.max_splits) p.max_splits = p.bins.splits[li];
         p.bins.blk_base[li] = p.total_blocks;
         p.total_blocks += (int)chunks * p.bins.splits[li];
-        cur += chunks;
-        rec += chunks * cap;
+        cnt += chunks * p.ntiles;
+        rec += chunks * p.ntiles * cap;
     }
     p.bins.blk_base[levels.n] = p.total_blocks;
-    p.cursor_bytes = (cur * 4 + 255) / 256 * 256;
+    p.count_bytes = (cnt * 4 + 255) / 256 * 256;
     p.record_bytes = rec * (1 + feature_dim) * 4;
     return p;
 }
@@ -550,7 +561,7 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     if (active.n == 0) return 0;
     const BinPlan plan = bin_plan(n, lv, active, F, (int64_t)tsize, DIM);
     const bool can_bin = merge && bwd_bin_enabled() && workspace && plan.ok &&
-                         plan.cursor_bytes + plan.record_bytes <= workspace_bytes && n >= 4096;
+                         plan.count_bytes + plan.record_bytes <= workspace_bytes && n >= 4096;
     if (!can_bin) {
         const int nw = active.n < 16 ? active.n : 16;
         if (merge)
@@ -561,30 +572,25 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
                                (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col, grad_codebook);
         return 0;
     }
-    uint32_t* cursors = (uint32_t*)workspace;
-    uint32_t* records = (uint32_t*)((char*)workspace + plan.cursor_bytes);
-    if (hipMemsetAsync(cursors, 0, plan.cursor_bytes, s) != hipSuccess) return -1;
-    const size_t em_lds = (size_t)(2 * plan.max_chunks) * 4;
-    auto em = hashgrid_bwd_emit_kernel<T, F, DIM>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)em_lds);
-    hipLaunchKernelGGL(em, dim3((unsigned)ceil_div64(n, EM_TILE), active.n), dim3(EM_THREADS), em_lds, s, coords, n,
-                       (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
-                       plan.chunk_shift, plan.bins, cursors, records, grad_codebook,
-                       [] { const char* e = getenv("WISP_EM_DBG"); return e ? atoi(e) : 0; }());
-    static const int rd_dbg = [] { const char* e = getenv("WISP_RD_DBG"); return e ? atoi(e) : 0; }();
+    uint32_t* counts = (uint32_t*)workspace;              // every count cell is written by the emit kernel: no memset
+    uint32_t* records = (uint32_t*)((char*)workspace + plan.count_bytes);
+    const size_t em_lds = (size_t)plan.max_chunks * 4;
+    hipLaunchKernelGGL((hashgrid_bwd_emit_kernel<T, F, DIM>), dim3((unsigned)plan.ntiles, active.n), dim3(EM_THREADS), em_lds, s,
+                       coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
+                       plan.chunk_shift, plan.bins, counts, records, grad_codebook);
     static const bool rd_f32 = env_flag("WISP_RD_F32", false);
     if (rd_f32) {
         const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 4;
         auto rd = hashgrid_bwd_reduce_kernel<F, AccF32>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
         hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
-                           plan.bins, cursors, records, grad_codebook, rd_dbg);
+                           plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook);
     } else {
         const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 8;
         auto rd = hashgrid_bwd_reduce_kernel<F, AccFix64>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
         hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
-                           plan.bins, cursors, records, grad_codebook, rd_dbg);
+                           plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook);
     }
     return 0;
 }
@@ -661,5 +667,5 @@ extern "C" int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, i
     LevelList all{0, {0}};
     for (int l = 0; l < num_lods; ++l) all.lv[all.n++] = l;
     const BinPlan p = bin_plan(n, lv, all, feature_dim, tsize, coord_dim);
-    return p.ok ? p.cursor_bytes + p.record_bytes : 0;
+    return p.ok ? p.count_bytes + p.record_bytes : 0;
 }

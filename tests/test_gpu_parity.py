@@ -487,7 +487,7 @@ def test_trainer_flat_params_step_matches_unfused_torch_path():
 @pytest.mark.parametrize("amp", [False, True])
 def test_direct_step_equals_modular_step(amp, monkeypatch):
     """The direct-issue step of MultiviewTrainStep (same launches, no module / autograd plumbing) against the modular
-    Pipeline.forward + autograd step: identical losses and parameters after a few optimisation steps."""
+    Pipeline.forward + autograd step: same loss and same gradients, and the same training trajectory."""
     from wisp.core import Rays
     from wisp.models import Pipeline
     from wisp.tracers import PackedRFTracer
@@ -506,16 +506,28 @@ def test_direct_step_equals_modular_step(amp, monkeypatch):
     tr2 = MultiviewTrainStep(Pipeline(nef2, PackedRFTracer(raymarch_type='ray', num_steps=96, bg_color=(0, 0, 0))),
                              prune_every=-1, enable_amp=amp)
     assert tr2._direct is None
-    for _ in range(4):
+    # 1. same gradients: run one step with the optimizer replaced by a snapshot of the flat gradient buffer
+    grads = {}
+    for name, tr in (("direct", tr1), ("modular", tr2)):
+        def snap(tr=tr, name=name):
+            grads[name] = tr.flat.grad.clone()
+            tr.flat.grad.zero_()
+        tr.optimizer_step = snap
+    l1, s1 = tr1.step(rays, gts, jitter=jit)
+    l2, s2 = tr2.step(rays, gts, jitter=jit)
+    assert s1 == s2 and abs(float(l1) - float(l2)) <= 1e-7 * max(1.0, abs(float(l2)))
+    g1, g2 = grads["direct"].cpu().numpy(), grads["modular"].cpu().numpy()
+    scale = float(np.abs(g2).max())
+    # (this small batch takes the float-atomic scatter path, whose add order varies from run to run)
+    np.testing.assert_allclose(g1, g2, rtol=0, atol=(2e-6 if not amp else 1e-5) * scale)
+    # 2. same trajectory: real optimisation steps, losses stay together
+    del tr1.optimizer_step, tr2.optimizer_step
+    for _ in range(3):
         l1, s1 = tr1.step(rays, gts, jitter=jit)
         l2, s2 = tr2.step(rays, gts, jitter=jit)
         assert s1 == s2 and tr1.num_rays == tr2.num_rays
-        assert abs(float(l1) - float(l2)) <= 1e-7 * max(1.0, abs(float(l2)))
-    for (n1, p1), (n2, p2) in zip(nef.named_parameters(), nef2.named_parameters()):
-        assert n1 == n2
-        # (the table gradient of this small batch goes through float atomics, whose order varies from run to run, and Adam
-        # normalises the update: parameters agree to a few ulp, not bitwise)
-        np.testing.assert_allclose(p1.detach().cpu().numpy(), p2.detach().cpu().numpy(), rtol=0, atol=5e-6, err_msg=n1)
+        # (Adam with eps = 1e-16 turns add-order noise on near-zero gradient entries into O(lr) parameter differences)
+        assert abs(float(l1) - float(l2)) <= 1e-3 * max(1.0, abs(float(l2)))
 
 
 def test_training_psnr_parity_with_oracle():
