@@ -392,15 +392,16 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
     __syncthreads();
     const uint32_t* __restrict__ cnt = counts + bins.cnt_base[li] + (size_t)b * ntiles;
     const uint32_t* __restrict__ src = records + ((size_t)bins.rec_base[li] + (size_t)b * ntiles * cap) * RW;
-    // This workgroup takes the emitting tiles z, z + splits, ...; its waves take them 64 at a time.  A wave fetches the
+    // This workgroup takes the emitting tiles z, z + splits, ...; its waves take them 64 at a time.  A wave fetches
     // 64 counts with one load, enumerates the (slot, 64-record chunk) pairs through a prefix sum over the lanes and walks
     // them with eight record loads in flight per lane (lane = record inside the chunk).
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = RD_THREADS / 64;
     constexpr int INFLIGHT = 8;
     const uint32_t my_tiles = ntiles > (uint32_t)z ? (ntiles - z + splits - 1) / splits : 0u;   // tiles of this workgroup
-    for (uint32_t base = wave * 64; base < my_tiles; base += NW * 64) {
-        const uint32_t k = base + lane;
+    // tile number k of this workgroup goes to wave k % NW, so that all waves have work even when there are few tiles
+    for (uint32_t base = 0; base * NW + wave < my_tiles; base += 64) {
+        const uint32_t k = (base + lane) * NW + wave;
         const uint32_t cnt_of_lane = k < my_tiles ? cnt[z + k * splits] : 0u;
         const uint32_t cc = (cnt_of_lane + 63u) >> 6;     // chunks of this lane's slot
         uint32_t inc = cc;
@@ -422,7 +423,7 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
                 const uint32_t n_t = (uint32_t)__builtin_amdgcn_readlane((int)cnt_of_lane, t);
                 const uint32_t r = chunk * 64 + lane;
                 act[u] = (p0 + u < pairs) && r < n_t;
-                const uint32_t tile = z + (base + t) * splits;
+                const uint32_t tile = z + ((base + t) * NW + wave) * splits;
                 const uint32_t* rec = src + ((size_t)tile * cap + (act[u] ? r : 0u)) * RW;
 #pragma unroll
                 for (int q = 0; q < RW; ++q) w[u][q] = rec[q];
