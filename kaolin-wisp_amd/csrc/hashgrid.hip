@@ -48,28 +48,38 @@ static __device__ __forceinline__ void corner_setup(const float* __restrict__ c,
         f[a] = x - p;
         g[a] = 1.0f - f[a];
     }
+    // Per-axis partial terms, shared by the corners: index terms for (pos, pos + 1) - (p + 1) * k == p * k + k in uint32
+    // arithmetic, so one multiply per axis serves both - and the blend factors (g, f).
+    uint32_t term[DIM][2];
+    if (dense) {                                                  // hash_utils.cuh:27-32: x + y * res + z * res * res
+        uint32_t mul = 1u;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+            term[a][0] = (uint32_t)pos[a] * mul;
+            term[a][1] = term[a][0] + mul;
+            mul *= (uint32_t)res;
+        }
+    } else {                                                      // hash_utils.cuh:34-36 (uint32 wrap-around)
+        const uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+            term[a][0] = (uint32_t)pos[a] * primes[a];
+            term[a][1] = term[a][0] + primes[a];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < (1 << DIM); ++j) {
         float w = 1.0f;
-        int32_t corner[DIM];
+        uint32_t h = 0u;
 #pragma unroll
         for (int a = 0; a < DIM; ++a) {
             const int bit = (j >> (DIM - 1 - a)) & 1;
             const float t = bit ? f[a] : g[a];
             w = (a == 0) ? t : w * t;                             // left-to-right product, .cu:49-56
-            corner[a] = pos[a] + bit;
+            h = dense ? h + term[a][bit] : h ^ term[a][bit];
         }
         cs.coef[j] = w;
-        int32_t idx;
-        if (dense) {                                              // hash_utils.cuh:27-32
-            idx = corner[0] + corner[1] * res;
-            if (DIM == 3) idx += corner[2] * res * res;
-        } else {                                                  // hash_utils.cuh:34-36 (uint32 wrap-around)
-            uint32_t h = (uint32_t)corner[0] * 1u ^ (uint32_t)corner[1] * 2654435761u;
-            if (DIM == 3) h ^= (uint32_t)corner[2] * 805459861u;
-            idx = (int32_t)(tsize_pow2 ? (h & (tsize - 1u)) : (h % tsize));
-        }
-        cs.idx[j] = idx;
+        cs.idx[j] = dense ? (int32_t)h : (int32_t)(tsize_pow2 ? (h & (tsize - 1u)) : (h % tsize));
     }
 }
 
@@ -210,24 +220,28 @@ static __device__ __forceinline__ bool tail_compute(const float* c, bool live, i
     // Segmented inclusive scan on the VALU (DPP), no LDS traffic: four row_shr steps inside each 16-lane row, then the
     // row totals are carried across rows with row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3).  (v, f) pairs
     // combine as (v1,f1)+(v2,f2) = (f2 ? v2 : v1+v2, f1|f2), which is associative, so the row carries compose.
-#define HG_SEG_STEP(CTRL, RMASK, VALID)                                                                   \
+    // One step: v += shifted(v) * tk with tk = 1 where the lane takes its predecessor's partial sum, else 0 - a single
+    // v_fmac_f32 with the DPP shift on its first source per value (lanes whose source is outside the row / row mask keep v).
+    // Written as inline asm because the compiler otherwise splits it into v_mov_dpp + packed fma + register shuffles; the
+    // leading s_nop covers the VALU-write -> DPP-read hazard the assembler does not see.  (A non-finite gradient would
+    // leak into neighbouring runs through 0 * inf - gradients that far gone are lost anyway.)
+#define HG_SEG_STEP(CTRL, RMASK, DPPSTR, VALID)                                                            \
     {                                                                                                      \
         const int fp = __builtin_amdgcn_update_dpp(1, f, CTRL, RMASK, 0xf, false);                         \
         const bool take = (VALID) && !f;                                                                   \
+        const float tk = take ? 1.0f : 0.0f;                                                               \
+        asm volatile("s_nop 1");                                                                           \
         _Pragma("unroll") for (int j = 0; j < (1 << DIM); ++j)                                             \
-            _Pragma("unroll") for (int k = 0; k < F; ++k) {                                                \
-                const float vp = __builtin_bit_cast(                                                       \
-                    float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[j][k]), CTRL, RMASK, 0xf, false)); \
-                if (take) v[j][k] += vp;                                                                   \
-            }                                                                                              \
+            _Pragma("unroll") for (int k = 0; k < F; ++k)                                                  \
+                asm volatile("v_fmac_f32_dpp %0, %0, %1 " DPPSTR : "+v"(v[j][k]) : "v"(tk));                 \
         if (take) f |= fp;                                                                                 \
     }
-    HG_SEG_STEP(0x111, 0xf, (lane & 15) >= 1)             // row_shr:1
-    HG_SEG_STEP(0x112, 0xf, (lane & 15) >= 2)             // row_shr:2
-    HG_SEG_STEP(0x114, 0xf, (lane & 15) >= 4)             // row_shr:4
-    HG_SEG_STEP(0x118, 0xf, (lane & 15) >= 8)             // row_shr:8
-    HG_SEG_STEP(0x142, 0xa, (lane >> 4) & 1)              // row_bcast:15 -> rows 1 and 3
-    HG_SEG_STEP(0x143, 0xc, lane >= 32)                   // row_bcast:31 -> rows 2 and 3
+    HG_SEG_STEP(0x111, 0xf, "row_shr:1 row_mask:0xf bank_mask:0xf", (lane & 15) >= 1)
+    HG_SEG_STEP(0x112, 0xf, "row_shr:2 row_mask:0xf bank_mask:0xf", (lane & 15) >= 2)
+    HG_SEG_STEP(0x114, 0xf, "row_shr:4 row_mask:0xf bank_mask:0xf", (lane & 15) >= 4)
+    HG_SEG_STEP(0x118, 0xf, "row_shr:8 row_mask:0xf bank_mask:0xf", (lane & 15) >= 8)
+    HG_SEG_STEP(0x142, 0xa, "row_bcast:15 row_mask:0xa bank_mask:0xf", (lane >> 4) & 1)      // rows 1 and 3
+    HG_SEG_STEP(0x143, 0xc, "row_bcast:31 row_mask:0xc bank_mask:0xf", lane >= 32)           // rows 2 and 3
 #undef HG_SEG_STEP
     const int32_t nextk = __shfl_down(key, 1, 64);
     return live && (lane == 63 || key != nextk);          // run tail holds the run total
@@ -310,6 +324,7 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
     __syncthreads();
     const int64_t tile0 = (int64_t)blockIdx.x * EM_TILE;
     uint32_t* __restrict__ rec_l = records + (size_t)bins.rec_base[li] * RW;
+    const uint32_t bucket_stride = ntiles * cap, slot0 = blockIdx.x * cap;      // record offsets inside the level, 32-bit
 #pragma unroll
     for (int g = 0; g < GROUPS; ++g) {
         const int64_t i = tile0 + (int64_t)(wave * GROUPS + g) * 64 + lane;
@@ -328,7 +343,7 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
             const uint32_t b = idx >> chunk_shift;
             const uint32_t pos = atomicAdd(&s_rank[b], 1u);
             if (pos < cap) {
-                uint32_t* dst = rec_l + (((size_t)b * ntiles + blockIdx.x) * cap + pos) * RW;
+                uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos) * RW);   // < 2^32 dwords (bin_plan)
                 dst[0] = idx;
 #pragma unroll
                 for (int k = 0; k < F; ++k) dst[1 + k] = __float_as_uint(v[j][k]);
@@ -521,7 +536,7 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         cap = lv.dense[l] ? cap * 4 : cap + cap / 2;
         if (cap < 128) cap = 128;
         if (cap > (int64_t)EM_TILE * corners) cap = (int64_t)EM_TILE * corners;
-        if (chunks > BIN_MAX_CHUNKS || entries > 0xffffffffLL) p.ok = false;
+        if (chunks > BIN_MAX_CHUNKS || entries > 0xffffffffLL || chunks * p.ntiles * cap * (1 + feature_dim) > 0xffffffffLL) p.ok = false;
         p.bins.chunks[li] = (int32_t)chunks;
         p.bins.cap[li] = (uint32_t)cap;
         p.bins.cnt_base[li] = cnt;
