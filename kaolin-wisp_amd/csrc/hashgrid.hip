@@ -180,18 +180,18 @@ struct BinLevels {
     int32_t chunks[HG_MAX_LODS]; uint32_t cap[HG_MAX_LODS]; int64_t cnt_base[HG_MAX_LODS]; int64_t rec_base[HG_MAX_LODS];
     uint32_t entries[HG_MAX_LODS]; int32_t splits[HG_MAX_LODS];
     int32_t blk_base[HG_MAX_LODS + 1];      // reduce kernel: first workgroup of every level in the flattened 1-D grid
+    int32_t rank_base[HG_MAX_LODS + 1];     // emit kernel: first LDS rank counter of every level
 };
 
 template <typename T, int F, int DIM, bool MERGE>
-static __device__ __forceinline__ bool tail_compute(const float* c, bool live, int64_t i, int l, int num_lods, int32_t res,
-                                                    bool dense, uint32_t tsize, bool pow2, int zero_from_col,
-                                                    const T* __restrict__ grad_feats, int lane, CornerSetup<DIM>& cs,
-                                                    float (&v)[1 << DIM][F]) {
+static __device__ __forceinline__ bool tail_compute(const float* c, bool live, int l, int32_t res, bool dense, uint32_t tsize,
+                                                    bool pow2, int zero_from_col, const T* gp, int lane,
+                                                    CornerSetup<DIM>& cs, float (&v)[1 << DIM][F]) {
+    // gp -> the F gradient values of this (sample, level) (global memory or an LDS copy); read only for live samples
     float g[F];
 #pragma unroll
     for (int k = 0; k < F; ++k) g[k] = 0.0f;
     if (live) {
-        const T* gp = grad_feats + (i * num_lods + l) * F;
 #pragma unroll
         for (int k = 0; k < F; ++k) g[k] = (l * F + k < zero_from_col) ? Cvt<T>::to_f(gp[k]) : 0.0f;
     }
@@ -269,8 +269,8 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
             const bool dense = __builtin_amdgcn_readfirstlane(lv.dense[l]) != 0;
             CornerSetup<DIM> cs;
             float v[1 << DIM][F];
-            const bool issue = tail_compute<T, F, DIM, MERGE>(c, live, i, l, num_lods, res, dense, tsize, tsize_pow2 != 0,
-                                                              zero_from_col, grad_feats, lane, cs, v);
+            const bool issue = tail_compute<T, F, DIM, MERGE>(c, live, l, res, dense, tsize, tsize_pow2 != 0, zero_from_col,
+                                                              grad_feats + (i * num_lods + l) * F, lane, cs, v);
             if (issue) {
                 float* __restrict__ gt = grad_codebook + first_idx[l] * F;
 #pragma unroll
@@ -299,7 +299,11 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #define BIN_MAX_CHUNKS 1024
 
 // record = { index within the level table, F gradient values }, (1 + F) dwords.
-// A workgroup handles EM_TILE samples of one level and owns slot [bucket][blockIdx.x] of every bucket of that level.
+// A workgroup owns EM_TILE consecutive samples for ALL levels and slot [bucket][blockIdx.x] of every bucket.  The
+// [EM_TILE x L*F] gradient rows are read from HBM once, fully coalesced, into LDS (row stride padded to an odd dword
+// count: the per-level column reads are conflict free) - a (tile, level) grid re-reads every 64-byte row once per level
+// (PMC: 2.3 GB fetched for 0.13 GB of gradients), which is what bounded this kernel.  After the staging barrier the waves
+// run independently: every level has its own LDS rank counters, so there is no barrier inside the level loop.
 template <typename T, int F, int DIM>
 __global__ void __launch_bounds__(EM_THREADS, EM_MIN_WAVES)
 hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ grad_feats,
@@ -309,56 +313,82 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
     constexpr int NC = 1 << DIM;
     constexpr int RW = 1 + F;
     constexpr int GROUPS = EM_TILE / EM_THREADS;         // 64-sample groups per wave
+    static_assert((F * sizeof(T)) % 4 == 0, "a (sample, level) gradient is a whole number of dwords");
+    constexpr int W = (F * (int)sizeof(T)) / 4;
     extern __shared__ __attribute__((aligned(16))) uint32_t em_smem[];
-    const int li = blockIdx.y;
-    const int l = levels.lv[li];
-    const int chunks = bins.chunks[li];
-    uint32_t* s_rank = em_smem;                          // [chunks] records written so far per bucket
+    const int total_ranks = bins.rank_base[levels.n];
+    uint32_t* s_rank = em_smem;                          // [total_ranks] records written so far per (level, bucket)
+    uint32_t* s_grad = em_smem + total_ranks;            // [EM_TILE][rowp] gradient rows of this tile
+    const int row_dw = num_lods * W;
+    const int rowp = row_dw | 1;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int32_t res = lv.res[l];
-    const bool dense = lv.dense[l] != 0;
-    const uint32_t cap = bins.cap[li];
     const uint32_t ntiles = gridDim.x;
-    for (int b = threadIdx.x; b < chunks; b += EM_THREADS) s_rank[b] = 0;
-    __syncthreads();
     const int64_t tile0 = (int64_t)blockIdx.x * EM_TILE;
-    uint32_t* __restrict__ rec_l = records + (size_t)bins.rec_base[li] * RW;
-    const uint32_t bucket_stride = ntiles * cap, slot0 = blockIdx.x * cap;      // record offsets inside the level, 32-bit
+    for (int b = threadIdx.x; b < total_ranks; b += EM_THREADS) s_rank[b] = 0;
+    {
+        const int64_t rows = (n - tile0) < (int64_t)EM_TILE ? (n - tile0) : (int64_t)EM_TILE;
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(grad_feats) + tile0 * row_dw;
+        const int total = (int)rows * row_dw;
+        for (int e = threadIdx.x; e < total; e += EM_THREADS) {
+            const int r = e / row_dw;
+            s_grad[r * rowp + (e - r * row_dw)] = src[e];
+        }
+    }
+    float c[GROUPS][DIM];
+    bool live[GROUPS];
 #pragma unroll
     for (int g = 0; g < GROUPS; ++g) {
         const int64_t i = tile0 + (int64_t)(wave * GROUPS + g) * 64 + lane;
-        const bool live = i < n;
-        float c[DIM];
+        live[g] = i < n;
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) c[a] = live ? coords[i * DIM + a] : 0.0f;
-        CornerSetup<DIM> cs;
-        float v[NC][F];
-        const bool issue = tail_compute<T, F, DIM, true>(c, live, i, l, num_lods, res, dense, tsize, tsize_pow2 != 0,
-                                                         zero_from_col, grad_feats, lane, cs, v);
-        if (!issue) continue;
+        for (int a = 0; a < DIM; ++a) c[g][a] = live[g] ? coords[i * DIM + a] : 0.0f;
+    }
+    __syncthreads();
+    for (int li = 0; li < levels.n; ++li) {
+        const int l = levels.lv[li];
+        const int32_t res = lv.res[l];
+        const bool dense = lv.dense[l] != 0;
+        const uint32_t cap = bins.cap[li];
+        uint32_t* rank_l = s_rank + bins.rank_base[li];
+        uint32_t* __restrict__ rec_l = records + (size_t)bins.rec_base[li] * RW;
+        const uint32_t bucket_stride = ntiles * cap, slot0 = blockIdx.x * cap;  // record offsets inside the level, 32-bit
 #pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            const uint32_t idx = (uint32_t)cs.idx[j];
-            const uint32_t b = idx >> chunk_shift;
-            const uint32_t pos = atomicAdd(&s_rank[b], 1u);
-            if (pos < cap) {
-                uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos) * RW);   // < 2^32 dwords (bin_plan)
-                dst[0] = idx;
+        for (int g = 0; g < GROUPS; ++g) {
+            const int sl = (wave * GROUPS + g) * 64 + lane;
+            CornerSetup<DIM> cs;
+            float v[NC][F];
+            const bool issue = tail_compute<T, F, DIM, true>(c[g], live[g], l, res, dense, tsize, tsize_pow2 != 0, zero_from_col,
+                                                             reinterpret_cast<const T*>(s_grad + sl * rowp + l * W), lane, cs, v);
+            if (!issue) continue;
 #pragma unroll
-                for (int k = 0; k < F; ++k) dst[1 + k] = __float_as_uint(v[j][k]);
-            } else {                                      // slot full: fall back to the memory-side atomic
-                float* p = grad_codebook + (first_idx[l] + (int64_t)idx) * F;
+            for (int j = 0; j < NC; ++j) {
+                const uint32_t idx = (uint32_t)cs.idx[j];
+                const uint32_t b = idx >> chunk_shift;
+                const uint32_t pos = atomicAdd(&rank_l[b], 1u);
+                if (pos < cap) {
+                    uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos) * RW);   // < 2^32 dwords (bin_plan)
+                    dst[0] = idx;
 #pragma unroll
-                for (int k = 0; k < F; ++k) atomicAdd(p + k, v[j][k]);
+                    for (int k = 0; k < F; ++k) dst[1 + k] = __float_as_uint(v[j][k]);
+                } else {                                  // slot full: fall back to the memory-side atomic
+                    float* p = grad_codebook + (first_idx[l] + (int64_t)idx) * F;
+#pragma unroll
+                    for (int k = 0; k < F; ++k) atomicAdd(p + k, v[j][k]);
+                }
             }
         }
     }
     __syncthreads();
-    uint32_t* __restrict__ cnt_l = counts + bins.cnt_base[li];
-    for (int b = threadIdx.x; b < chunks; b += EM_THREADS) {
-        const uint32_t c = s_rank[b];
-        cnt_l[(size_t)b * ntiles + blockIdx.x] = c < cap ? c : cap;
+    for (int li = 0; li < levels.n; ++li) {
+        const int chunks = bins.chunks[li];
+        const uint32_t cap = bins.cap[li];
+        const uint32_t* rank_l = s_rank + bins.rank_base[li];
+        uint32_t* __restrict__ cnt_l = counts + bins.cnt_base[li];
+        for (int b = threadIdx.x; b < chunks; b += EM_THREADS) {
+            const uint32_t cn = rank_l[b];
+            cnt_l[(size_t)b * ntiles + blockIdx.x] = cn < cap ? cn : cap;
+        }
     }
 }
 
@@ -513,7 +543,7 @@ static bool bwd_merge_enabled() { static const bool v = env_flag("WISP_HG_BWD_ME
 static bool bwd_bin_enabled() { static const bool v = env_flag("WISP_HG_BWD_BIN", true); return v; }
 
 // bin geometry shared by the workspace query and the launcher
-struct BinPlan { int chunk_shift, max_chunks, max_splits, total_blocks; int64_t ntiles; BinLevels bins; int64_t count_bytes, record_bytes; bool ok; };
+struct BinPlan { int chunk_shift, max_chunks, max_splits, total_blocks, total_ranks; int64_t ntiles; BinLevels bins; int64_t count_bytes, record_bytes; bool ok; };
 static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels, int feature_dim, int64_t tsize, int dim) {
     BinPlan p{};
     const int corners = 1 << dim;
@@ -550,10 +580,13 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         if (p.bins.splits[li] > p.max_splits) p.max_splits = p.bins.splits[li];
         p.bins.blk_base[li] = p.total_blocks;
         p.total_blocks += (int)chunks * p.bins.splits[li];
+        p.bins.rank_base[li] = p.total_ranks;
+        p.total_ranks += (int)chunks;
         cnt += chunks * p.ntiles;
         rec += chunks * p.ntiles * cap;
     }
     p.bins.blk_base[levels.n] = p.total_blocks;
+    p.bins.rank_base[levels.n] = p.total_ranks;
     p.count_bytes = (cnt * 4 + 255) / 256 * 256;
     p.record_bytes = rec * (1 + feature_dim) * 4;
     return p;
@@ -576,7 +609,9 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
         if (l * F < zero_from_col) active.lv[active.n++] = l;
     if (active.n == 0) return 0;
     const BinPlan plan = bin_plan(n, lv, active, F, (int64_t)tsize, DIM);
-    const bool can_bin = merge && bwd_bin_enabled() && workspace && plan.ok &&
+    // emit kernel LDS: rank counters of every (level, bucket) + the tile's gradient rows
+    const size_t em_lds = ((size_t)plan.total_ranks + (size_t)EM_TILE * ((num_lods * ((F * (int)sizeof(T)) / 4)) | 1)) * 4;
+    const bool can_bin = merge && bwd_bin_enabled() && workspace && plan.ok && em_lds <= 150 * 1024 &&
                          plan.count_bytes + plan.record_bytes <= workspace_bytes && n >= 4096;
     if (!can_bin) {
         const int nw = active.n < 16 ? active.n : 16;
@@ -590,8 +625,9 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     }
     uint32_t* counts = (uint32_t*)workspace;              // every count cell is written by the emit kernel: no memset
     uint32_t* records = (uint32_t*)((char*)workspace + plan.count_bytes);
-    const size_t em_lds = (size_t)plan.max_chunks * 4;
-    hipLaunchKernelGGL((hashgrid_bwd_emit_kernel<T, F, DIM>), dim3((unsigned)plan.ntiles, active.n), dim3(EM_THREADS), em_lds, s,
+    auto em = hashgrid_bwd_emit_kernel<T, F, DIM>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)em_lds);
+    hipLaunchKernelGGL(em, dim3((unsigned)plan.ntiles), dim3(EM_THREADS), em_lds, s,
                        coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
                        plan.chunk_shift, plan.bins, counts, records, grad_codebook);
     static const bool rd_f32 = env_flag("WISP_RD_F32", false);
