@@ -74,17 +74,36 @@ static __device__ __forceinline__ void corner_setup(const float* __restrict__ c,
 #pragma unroll
     for (int j = 0; j < (1 << DIM); ++j) {
         float w = 1.0f;
-        uint32_t h = 0u;
 #pragma unroll
         for (int a = 0; a < DIM; ++a) {
-            const int bit = (j >> (DIM - 1 - a)) & 1;
-            const float t = bit ? f[a] : g[a];
+            const float t = ((j >> (DIM - 1 - a)) & 1) ? f[a] : g[a];
             w = (a == 0) ? t : w * t;                             // left-to-right product, .cu:49-56
-            h = dense ? h + term[a][bit] : h ^ term[a][bit];
         }
         cs.coef[j] = w;
-        cs.idx[j] = dense ? (int32_t)h : (int32_t)(tsize_pow2 ? (h & (tsize - 1u)) : (h % tsize));
     }
+    // the index flavour is uniform for the whole wave: branch once, not per corner
+#define HG_CORNER_TERMS(OP)                                                                               \
+    _Pragma("unroll") for (int j = 0; j < (1 << DIM); ++j) {                                              \
+        uint32_t h = term[0][(j >> (DIM - 1)) & 1];                                                       \
+        _Pragma("unroll") for (int a = 1; a < DIM; ++a) h = h OP term[a][(j >> (DIM - 1 - a)) & 1];       \
+        hh[j] = h;                                                                                        \
+    }
+    uint32_t hh[1 << DIM];
+    if (dense) {
+        HG_CORNER_TERMS(+)
+#pragma unroll
+        for (int j = 0; j < (1 << DIM); ++j) cs.idx[j] = (int32_t)hh[j];
+    } else {
+        HG_CORNER_TERMS(^)
+        if (tsize_pow2) {
+#pragma unroll
+            for (int j = 0; j < (1 << DIM); ++j) cs.idx[j] = (int32_t)(hh[j] & (tsize - 1u));
+        } else {
+#pragma unroll
+            for (int j = 0; j < (1 << DIM); ++j) cs.idx[j] = (int32_t)(hh[j] % tsize);
+        }
+    }
+#undef HG_CORNER_TERMS
 }
 
 template <typename T, int F, int DIM>
@@ -100,6 +119,21 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
     const int64_t ntiles = (n + HG_TILE - 1) / HG_TILE;
     const int row_dw = num_lods * W;                                   // dwords per output row
 
+    // the levels of this wave (wave, wave + nwaves) and their constants, fetched once: indexing the by-value level table
+    // with a per-wave level inside the tile loop costs a dependent memory round trip per tile
+    constexpr int MAXW = 2;
+    int32_t w_res[MAXW];
+    bool w_dense[MAXW];
+    const T* w_table[MAXW];
+#pragma unroll
+    for (int q = 0; q < MAXW; ++q) {
+        const int l = wave + q * nwaves;
+        const bool ok = l < num_lods;
+        w_res[q] = __builtin_amdgcn_readfirstlane(ok ? lv.res[l] : 1);
+        w_dense[q] = __builtin_amdgcn_readfirstlane(ok ? lv.dense[l] : 1) != 0;
+        w_table[q] = codebook + (ok ? first_idx[l] : 0) * F;
+    }
+
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t i = tile * HG_TILE + lane;
         const bool live = i < n;
@@ -107,14 +141,17 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #pragma unroll
         for (int a = 0; a < DIM; ++a) c[a] = live ? coords[i * DIM + a] : 0.0f;
 
-        for (int l = wave; l < num_lods; l += nwaves) {
-            const int32_t res = __builtin_amdgcn_readfirstlane(lv.res[l]);
-            const bool dense = __builtin_amdgcn_readfirstlane(lv.dense[l]) != 0;
+#pragma unroll
+        for (int q = 0; q < MAXW; ++q) {
+            const int l = wave + q * nwaves;
+            if (l >= num_lods) break;
+            const int32_t res = w_res[q];
+            const bool dense = w_dense[q];
             float acc[F];
 #pragma unroll
             for (int k = 0; k < F; ++k) acc[k] = 0.0f;
             if (live && l * F < zero_from_col) {
-                const T* __restrict__ table = codebook + first_idx[l] * F;
+                const T* __restrict__ table = w_table[q];
                 CornerSetup<DIM> cs;
                 corner_setup<DIM>(c, res, dense, tsize, tsize_pow2 != 0, cs);
                 T v[1 << DIM][F];
