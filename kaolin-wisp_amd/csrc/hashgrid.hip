@@ -339,7 +339,42 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #define RD_THREADS 1024
 #define BIN_MAX_CHUNKS 1024
 
-// record = { index within the level table, F gradient values }, (1 + F) dwords.
+// Records.  Generic form: { index within the level table, F fp32 gradient values } = 1 + F dwords.  For two features coming
+// from a 16-bit gradient tensor (the bf16 / fp16 training path) the record is packed into TWO dwords: each value keeps
+// sign, exponent and 16 mantissa bits (rounded; 2^-17 relative - the values were products of a 16-bit gradient already)
+// and donates its low 7 bits to the index INSIDE the bucket (14 bits; a bucket has at most 8192 entries).  A third less
+// record traffic in both kernels.
+template <typename T, int F> struct RecordCodec {
+    static constexpr bool COMPACT = (sizeof(T) == 2 && F == 2);
+    static constexpr int RW = COMPACT ? 2 : 1 + F;
+    static __device__ __forceinline__ void store(uint32_t* dst, uint32_t idx, uint32_t local_mask, const float (&v)[F]) {
+        if constexpr (COMPACT) {
+            const uint32_t loc = idx & local_mask;
+            uint2 w;
+            w.x = ((__float_as_uint(v[0]) + 0x40u) & ~0x7fu) | (loc & 0x7fu);
+            w.y = ((__float_as_uint(v[1]) + 0x40u) & ~0x7fu) | (loc >> 7);
+            *reinterpret_cast<uint2*>(dst) = w;
+        } else {
+            dst[0] = idx;
+#pragma unroll
+            for (int k = 0; k < F; ++k) dst[1 + k] = __float_as_uint(v[k]);
+        }
+    }
+    // -> entry index inside the bucket, values
+    static __device__ __forceinline__ uint32_t load(const uint32_t (&w)[RW], uint32_t first, float (&v)[F]) {
+        if constexpr (COMPACT) {
+            v[0] = __uint_as_float(w[0] & ~0x7fu);
+            v[1] = __uint_as_float(w[1] & ~0x7fu);
+            return (w[0] & 0x7fu) | ((w[1] & 0x7fu) << 7);
+        } else {
+#pragma unroll
+            for (int k = 0; k < F; ++k) v[k] = __uint_as_float(w[1 + k]);
+            return w[0] - first;
+        }
+    }
+};
+
+// (records: see RecordCodec)
 // A workgroup owns EM_TILE consecutive samples for ALL levels and slot [bucket][blockIdx.x] of every bucket.  The
 // [EM_TILE x L*F] gradient rows are read from HBM once, fully coalesced, into LDS (row stride padded to an odd dword
 // count: the per-level column reads are conflict free) - a (tile, level) grid re-reads every 64-byte row once per level
@@ -352,7 +387,8 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
                          uint32_t tsize, int tsize_pow2, int zero_from_col, int chunk_shift, BinLevels bins,
                          uint32_t* __restrict__ counts, uint32_t* __restrict__ records, float* __restrict__ grad_codebook) {
     constexpr int NC = 1 << DIM;
-    constexpr int RW = 1 + F;
+    typedef RecordCodec<T, F> Codec;
+    constexpr int RW = Codec::RW;
     constexpr int GROUPS = EM_TILE / EM_THREADS;         // 64-sample groups per wave
     static_assert((F * sizeof(T)) % 4 == 0, "a (sample, level) gradient is a whole number of dwords");
     constexpr int W = (F * (int)sizeof(T)) / 4;
@@ -409,9 +445,7 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
                 const uint32_t pos = atomicAdd(&rank_l[b], 1u);
                 if (pos < cap) {
                     uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos) * RW);   // < 2^32 dwords (bin_plan)
-                    dst[0] = idx;
-#pragma unroll
-                    for (int k = 0; k < F; ++k) dst[1 + k] = __float_as_uint(v[j][k]);
+                    Codec::store(dst, idx, (1u << chunk_shift) - 1u, v[j]);
                 } else {                                  // slot full: fall back to the memory-side atomic
                     float* p = grad_codebook + (first_idx[l] + (int64_t)idx) * F;
 #pragma unroll
@@ -453,12 +487,13 @@ struct AccFix64 {
     }
 };
 
-template <int F, typename ACC>
+template <typename T, int F, typename ACC>
 __global__ void __launch_bounds__(RD_THREADS)
 hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList levels, int chunk_shift, BinLevels bins,
                            uint32_t ntiles, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ records,
                            float* __restrict__ grad_codebook) {
-    constexpr int RW = 1 + F;
+    typedef RecordCodec<T, F> Codec;
+    constexpr int RW = Codec::RW;
     typedef typename ACC::type acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char rd_smem[];
     acc_t* rd_acc = reinterpret_cast<acc_t*>(rd_smem);                  // [chunk entries * F]
@@ -517,9 +552,10 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
 #pragma unroll
             for (int u = 0; u < INFLIGHT; ++u) {
                 if (act[u]) {
-                    const uint32_t e = w[u][0] - first;
+                    float val[F];
+                    const uint32_t e = Codec::load(w[u], first, val);
 #pragma unroll
-                    for (int kk = 0; kk < F; ++kk) ACC::add(rd_acc, e * F + kk, __uint_as_float(w[u][1 + kk]));
+                    for (int kk = 0; kk < F; ++kk) ACC::add(rd_acc, e * F + kk, val[kk]);
                 }
             }
         }
@@ -585,7 +621,8 @@ static bool bwd_bin_enabled() { static const bool v = env_flag("WISP_HG_BWD_BIN"
 
 // bin geometry shared by the workspace query and the launcher
 struct BinPlan { int chunk_shift, max_chunks, max_splits, total_blocks, total_ranks; int64_t ntiles; BinLevels bins; int64_t count_bytes, record_bytes; bool ok; };
-static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels, int feature_dim, int64_t tsize, int dim) {
+static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels, int feature_dim, int64_t tsize, int dim,
+                        int rec_dwords) {
     BinPlan p{};
     const int corners = 1 << dim;
     int64_t centries = 16384 / feature_dim;               // chunk entries: 64 KiB as fp32, 128 KiB as 64-bit fixed point
@@ -607,7 +644,7 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         cap = lv.dense[l] ? cap * 4 : cap + cap / 2;
         if (cap < 128) cap = 128;
         if (cap > (int64_t)EM_TILE * corners) cap = (int64_t)EM_TILE * corners;
-        if (chunks > BIN_MAX_CHUNKS || entries > 0xffffffffLL || chunks * p.ntiles * cap * (1 + feature_dim) > 0xffffffffLL) p.ok = false;
+        if (chunks > BIN_MAX_CHUNKS || entries > 0xffffffffLL || chunks * p.ntiles * cap * rec_dwords > 0xffffffffLL) p.ok = false;
         p.bins.chunks[li] = (int32_t)chunks;
         p.bins.cap[li] = (uint32_t)cap;
         p.bins.cnt_base[li] = cnt;
@@ -629,7 +666,7 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
     p.bins.blk_base[levels.n] = p.total_blocks;
     p.bins.rank_base[levels.n] = p.total_ranks;
     p.count_bytes = (cnt * 4 + 255) / 256 * 256;
-    p.record_bytes = rec * (1 + feature_dim) * 4;
+    p.record_bytes = rec * rec_dwords * 4;
     return p;
 }
 
@@ -649,7 +686,7 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     for (int l = 0; l < num_lods; ++l)
         if (l * F < zero_from_col) active.lv[active.n++] = l;
     if (active.n == 0) return 0;
-    const BinPlan plan = bin_plan(n, lv, active, F, (int64_t)tsize, DIM);
+    const BinPlan plan = bin_plan(n, lv, active, F, (int64_t)tsize, DIM, RecordCodec<T, F>::RW);
     // emit kernel LDS: rank counters of every (level, bucket) + the tile's gradient rows
     const size_t em_lds = ((size_t)plan.total_ranks + (size_t)EM_TILE * ((num_lods * ((F * (int)sizeof(T)) / 4)) | 1)) * 4;
     const bool can_bin = merge && bwd_bin_enabled() && workspace && plan.ok && em_lds <= 150 * 1024 &&
@@ -674,13 +711,13 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     static const bool rd_f32 = env_flag("WISP_RD_F32", false);
     if (rd_f32) {
         const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 4;
-        auto rd = hashgrid_bwd_reduce_kernel<F, AccF32>;
+        auto rd = hashgrid_bwd_reduce_kernel<T, F, AccF32>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
         hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
                            plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook);
     } else {
         const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 8;
-        auto rd = hashgrid_bwd_reduce_kernel<F, AccFix64>;
+        auto rd = hashgrid_bwd_reduce_kernel<T, F, AccFix64>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
         hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
                            plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook);
@@ -759,6 +796,6 @@ extern "C" int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, i
     if (fill_levels(resolutions, num_lods, coord_dim, tsize, lv) != 0) return 0;
     LevelList all{0, {0}};
     for (int l = 0; l < num_lods; ++l) all.lv[all.n++] = l;
-    const BinPlan p = bin_plan(n, lv, all, feature_dim, tsize, coord_dim);
+    const BinPlan p = bin_plan(n, lv, all, feature_dim, tsize, coord_dim, 1 + feature_dim);   // widest record form
     return p.ok ? p.count_bytes + p.record_bytes : 0;
 }
