@@ -174,7 +174,9 @@ def main():
     b = 2 if amp else 4
     # algorithmic work per packed sample (SURVEY.md 8d / DESIGN.md): bytes for the HBM-bound kernels, flops for the MLP
     work = {"hashgrid_fwd": ("hbm", 12 + 16 * 8 * 2 * b + 16 * 2 * b),        # coords + 128 gathered entries + 32 outputs
-            "hashgrid_bwd": ("hbm", 12 + 16 * 2 * b + 2 * 16 * 8 * 2 * 4),     # coords + grads + fp32 RMW on 128 entries
+            # 12 + L*F*b + 2*L*2^d*F*b_acc with b_acc = the table element size (1100 B for 16-bit tables).
+            # The kernels accumulate in fp32 / 64-bit fixed point and merge runs, so what they actually move is `traffic`.
+            "hashgrid_bwd": ("hbm", 12 + 16 * 2 * b + 2 * 16 * 8 * 2 * b),
             "nerf_mlp_fwd": ("mfma", 20096), "nerf_mlp_bwd": ("mfma", 3 * 20096)}
     peaks = {"hbm": (HBM_PEAK_GBS, "GB/s"), "mfma": (2500.0 if amp else 157.3, "TFLOP/s")}
 
@@ -200,7 +202,7 @@ def main():
 
     pmc_names = {"hashgrid_fwd": ["hashgrid_fwd_kernel"], "hashgrid_bwd": ["hashgrid_bwd_emit_kernel", "hashgrid_bwd_reduce_kernel",
                                                                            "hashgrid_bwd_kernel"],
-                 "nerf_mlp_fwd": ["Lb0EEE"], "nerf_mlp_bwd": ["Lb1EEE"]}
+                 "nerf_mlp_fwd": ["mlp_fwd_kernel"], "nerf_mlp_bwd": ["mlp_bwd_kernel", "nerf_mlp_reduce_kernel"]}
     kern = {n: v for n, v in kern.items() if n in work}
     dominant = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
     roofline = None
@@ -211,7 +213,7 @@ def main():
         roofline = dict(bound=bound, kernel=dominant, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
                         traffic=pmc_traffic(pmc_names[dominant]) if (amp and world == 1) else None,
                         traffic_note="bytes/launch from profiles/r01_pmc_{FETCH,WRITE}_SIZE.csv (rocprofv3 --pmc, same command, "
-                                     "FETCH_SIZE x2); hashgrid_bwd = memset + emit + reduce kernels",
+                                     "FETCH_SIZE x2); hashgrid_bwd = emit + reduce kernels",
                         avg_launch_ms=k["avg_ms"], units_per_launch=k["avg_units"],
                         work_per_unit=work[dominant][1],
                         all_kernels={n: dict(avg_ms=v["avg_ms"], bound=rate(n, v)[0], achieved=rate(n, v)[1],
