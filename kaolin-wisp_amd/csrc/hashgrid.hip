@@ -11,9 +11,10 @@
 //   * the [64 x L*F] output tile is staged through LDS and written back as whole rows: every global
 //     store instruction writes 256 contiguous bytes per wave (the reference scatters 4-byte pieces at a
 //     64-byte stride).
-//   * backward accumulates into an fp32 gradient table with hardware global_atomic_add_f32.
-// Numerics contract: SURVEY.md Appendix B (double-then-float coordinate scaling, float32 clamp bound,
-// uint32 hash with the reference's primes, float32 blend in corner order).
+//   * backward (second half of this file): run merge inside the wave, records binned per 8192 table entries, one
+//     workgroup per bin accumulating in LDS - atomics only as the overflow / tiny-batch path.
+// Numerics contract: SURVEY.md Appendix B (coordinate scaling rounded once from the exact value like the reference's
+// double expression, float32 clamp bound, uint32 hash with the reference's primes, float32 blend in corner order).
 #include "wisp_common.h"
 #include <stdlib.h>
 
@@ -212,9 +213,9 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 //      finished slice to the gradient table with plain coalesced stores.  A bucket is stored as one fixed-capacity SLOT per
 //      emitting workgroup ([bucket][tile][slot_cap] records + a count): the emitter needs no histogram pass, no global
 //      reservation atomics (they are memory-side too: 2 M of them cost 0.1 ms) and no second pass over its registers - it
-//      ranks a record inside its slot with one LDS counter and writes it straight away.  Records cost 12 B of streamed
-//      traffic instead of a memory-side atomic; a full slot (capacity = 1.5 x / 4 x the no-merge expectation on hashed / dense levels, at least 128)
-//      falls back to the atomic.
+//      ranks a record inside its slot with one LDS counter and writes it straight away.  Records cost 8-12 B of
+//      streamed traffic instead of a memory-side atomic; a full slot (capacity = 1.5 x / 4 x the no-merge expectation on
+//      hashed / dense levels, at least 128) falls back to the atomic.
 struct LevelList { int32_t n; int32_t lv[HG_MAX_LODS]; };
 // per binned level: #buckets, slot capacity (records), first count cell, first record, table entries, split factor
 struct BinLevels {
