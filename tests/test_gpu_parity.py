@@ -97,6 +97,28 @@ def test_hashgrid_backward_nerf_hash_shape_and_adjoint():
     assert abs(float(lhs - rhs)) <= 1e-5 * abs(float(lhs)) + 1e-3
 
 
+def test_hashgrid_backward_slot_overflow_falls_back_to_atomics():
+    """Adversarial batch for the binned backward: consecutive samples jump between 97 points of one small region, so there
+    are no runs to merge and every tile sends its 8192 records per level to one or two buckets - far beyond the slot
+    capacity.  The overflow path (memory-side atomics) must still give the oracle's gradient."""
+    rng = np.random.default_rng(14)
+    _, begin = ohash.table_layout(NGP_RES, 2 ** 19)
+    shape = (int(begin[-1]), 2)
+    pts = rng.uniform(0.30, 0.34, (97, 3)).astype(np.float32)
+    n = 12288
+    coords = pts[(np.arange(n) * 41) % 97]
+    go = rng.normal(size=(n, 32)).astype(np.float32)
+    want = ohash.hashgrid_backward(torch.from_numpy(coords), torch.from_numpy(go), shape, torch.from_numpy(begin), NGP_RES, 19,
+                                   torch.float64)
+    for dt, tol in ((torch.float32, 3e-6), (torch.bfloat16, 1e-4)):
+        g = torch.from_numpy(go).to(dt)
+        want_d = want if dt == torch.float32 else ohash.hashgrid_backward(
+            torch.from_numpy(coords), g.float(), shape, torch.from_numpy(begin), NGP_RES, 19, torch.float64)
+        got = _C().hashgrid_interpolate_backward(cuda(coords), g.to(DEV), shape, cuda(begin), NGP_RES, 19)
+        scale = float(want_d.abs().max())
+        assert float((got.double().cpu() - want_d).abs().max()) <= tol * scale, dt
+
+
 def test_hashgrid_autograd_module_cat_and_sum():
     from wisp.accelstructs import OctreeAS
     from wisp.models.grids import HashGrid
