@@ -244,6 +244,15 @@ int wisp_sphere_trace_step(int64_t num_packs, const float* nug_o, const float* n
                            const float* dist, float* dist_prev, uint8_t* mask, uint8_t* hit, const int32_t* curr_in,
                            int32_t* curr_out, int64_t* curr_pidx, float* x, wisp_stream_t stream);
 
+/* Rays of one camera through the given pixel coordinates - generate_pinhole_rays / generate_ortho_rays
+ * (wisp/ops/raygen/raygen.py:40-119).  pixel_x / pixel_y: f32 [num_pixels] (device); the camera is passed by value from
+ * the host: principal-point offset (x0, y0) in pixels from the image centre, image size, scale_x / scale_y =
+ * tan(fov/2) per axis (pinhole) or fov_distance * aspect, fov_distance (ortho), and the world -> camera view transform
+ * as rotation R[9] (row major) + translation t[3] (HOST pointers).  Out: origins, dirs f32 [num_pixels, 3], dirs normalised. */
+int wisp_generate_rays(const float* pixel_x, const float* pixel_y, int64_t num_pixels, int ortho, float x0, float y0,
+                       float width, float height, float scale_x, float scale_y, const float* view_rotation,
+                       const float* view_translation, float* origins, float* dirs, wisp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused radiance-field decoder  (replaces NeuralRadianceField.rgba after grid.interpolate,
  * wisp/models/nefs/nerf.py:245-264: decoder_density (Linear-ReLU-Linear) -> relu density + 15 geometry

@@ -381,3 +381,70 @@ extern "C" int wisp_sphere_trace_step(int64_t num_packs, const float* nug_o, con
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- ray generation
+// generate_pinhole_rays / generate_ortho_rays (wisp/ops/raygen/raygen.py:40-119) for one camera: pixel coordinates ->
+// principal-point shift -> NDC -> camera-space ray -> world space (inverse of the view transform: R^T (p - t)) ->
+// normalised direction.  Every step is a separately rounded fp32 operation, in the reference's order.
+struct RayCam {
+    float x0, y0, width, height;      // principal point offset (pixels from the image centre), image size
+    float sx, sy;                     // pinhole: tan(fov_x / 2), tan(fov_y / 2); ortho: fov_distance * aspect, fov_distance
+    float r[9];                       // view rotation R (row major), world -> camera
+    float t[3];                       // view translation
+};
+
+template <bool ORTHO>
+__global__ void __launch_bounds__(256)
+raygen_kernel(const float* __restrict__ pixel_x, const float* __restrict__ pixel_y, int64_t n, RayCam cam,
+              float* __restrict__ origins, float* __restrict__ dirs) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float px = pixel_x[i], py = pixel_y[i];
+    if (!ORTHO) { px = px - cam.x0; py = py + cam.y0; }                  // raygen.py:66-67
+    px = 2.0f * (px / cam.width) - 1.0f;                                  // _to_ndc_coords, :34-37
+    py = 2.0f * (py / cam.height) - 1.0f;
+    float o[3], d[3];
+    if (ORTHO) {                                                          // :100-107
+        o[0] = px * cam.sx; o[1] = -(py * cam.sy); o[2] = 0.0f;
+        d[0] = 0.0f; d[1] = 0.0f; d[2] = -1.0f;
+    } else {                                                              // :72-77
+        o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
+        d[0] = px * cam.sx; d[1] = -py * cam.sy; d[2] = -1.0f;
+    }
+    // inv_transform_rays: origin' = R^T (o - t), dir' = R^T d  (sums accumulated left to right)
+    const float q[3] = {o[0] - cam.t[0], o[1] - cam.t[1], o[2] - cam.t[2]};
+    float ow[3], dw[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ow[c] = (cam.r[0 + c] * q[0] + cam.r[3 + c] * q[1]) + cam.r[6 + c] * q[2];
+        dw[c] = (cam.r[0 + c] * d[0] + cam.r[3 + c] * d[1]) + cam.r[6 + c] * d[2];
+    }
+    const float nrm = sqrtf((dw[0] * dw[0] + dw[1] * dw[1]) + dw[2] * dw[2]);        // torch.linalg.norm
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        origins[i * 3 + c] = ow[c];
+        dirs[i * 3 + c] = dw[c] / nrm;
+    }
+}
+
+extern "C" int wisp_generate_rays(const float* pixel_x, const float* pixel_y, int64_t num_pixels, int ortho, float x0,
+                                  float y0, float width, float height, float scale_x, float scale_y,
+                                  const float* view_rotation, const float* view_translation, float* origins, float* dirs,
+                                  wisp_stream_t stream) {
+    WISP_REQUIRE(num_pixels >= 0, "negative count");
+    if (num_pixels == 0) return WISP_OK;
+    WISP_REQUIRE(pixel_x && pixel_y && view_rotation && view_translation && origins && dirs, "null pointer");
+    WISP_REQUIRE(width > 0.0f && height > 0.0f, "bad image size");
+    RayCam cam;
+    cam.x0 = x0; cam.y0 = y0; cam.width = width; cam.height = height; cam.sx = scale_x; cam.sy = scale_y;
+    for (int k = 0; k < 9; ++k) cam.r[k] = view_rotation[k];             // host arrays
+    for (int k = 0; k < 3; ++k) cam.t[k] = view_translation[k];
+    const dim3 grid((unsigned)ceil_div64(num_pixels, 256));
+    if (ortho)
+        hipLaunchKernelGGL(raygen_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, pixel_x, pixel_y, num_pixels, cam, origins, dirs);
+    else
+        hipLaunchKernelGGL(raygen_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, pixel_x, pixel_y, num_pixels, cam, origins, dirs);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

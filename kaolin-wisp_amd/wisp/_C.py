@@ -58,6 +58,7 @@ SIGNATURES = {
     "wisp_packed_cumsum": [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "wisp_find_depth_bound": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp],
     "wisp_sphere_trace_step": [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_generate_rays": [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_composite_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_composite_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_nerf_mlp_param_count": [c_i32, c_i32, c_i32],
@@ -523,6 +524,24 @@ def sphere_trace_step(nug_o, nug_d, nug_depth, nug_pidx, dist_max, thr_close, th
                                       float(np.float32(thr_close)), float(np.float32(thr_avg)), _p(t), _p(dist), _p(dist_prev),
                                       _p(mask), _p(hit), _p(curr_in), _p(curr_out), _p(curr_pidx), _p(x), _stream()),
            "sphere_trace_step")
+
+
+def generate_rays(pixel_x, pixel_y, ortho, x0, y0, width, height, scale_x, scale_y, view_rotation, view_translation):
+    """(origins [N,3], dirs [N,3]) for pixel coordinates [N] of one camera (raygen.py:40-119)."""
+    pixel_x = _need(pixel_x, torch.float32, "pixel_x").reshape(-1)
+    pixel_y = _need(pixel_y, torch.float32, "pixel_y").reshape(-1)
+    n, dev = pixel_x.shape[0], pixel_x.device
+    assert pixel_y.shape[0] == n
+    origins = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    dirs = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    r_arr, r_ptr = _host_f32(view_rotation)
+    t_arr, t_ptr = _host_f32(view_translation)
+    assert r_arr.size == 9 and t_arr.size == 3
+    f32 = lambda v: float(np.float32(v))
+    _check(lib.wisp_generate_rays(_p(pixel_x), _p(pixel_y), n, int(bool(ortho)), f32(x0), f32(y0), f32(width), f32(height),
+                                  f32(scale_x), f32(scale_y), r_ptr, t_ptr, _p(origins), _p(dirs), _stream()),
+           "generate_rays")
+    return origins, dirs
 
 
 # ------------------------------------------------------------------------------------------------ optimizer

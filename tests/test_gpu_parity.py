@@ -792,3 +792,36 @@ def test_validation_render_and_psnr_log_line():
     gts = (whole.rgb + 0.01).clamp(0, 1)             # uniform 0.01 error -> 40 dB
     val, line = evaluate_psnr(pipe, [(rays, gts)], epoch=3, max_epochs=10, render_batch=256)
     assert re.search(r"EPOCH 3/10 \| lod15 psnr: (\d+\.\d\d)$", line) and 39.0 < val < 41.5
+
+
+def test_ray_generation_matches_oracle():
+    """generate_pinhole_rays / generate_ortho_rays (wisp/ops/raygen) against the numpy restatement, plus the geometric
+    facts that do not depend on any float ordering: unit directions, the centre ray looks at `at`, all pinhole rays start
+    at the eye."""
+    from oracle import raygen as oray
+    from wisp.ops.raygen import generate_centered_pixel_coords, generate_pinhole_rays, generate_ortho_rays, LookAtCamera
+    cam = LookAtCamera(eye=(2.1, 1.3, -2.4), at=(0.1, -0.05, 0.2), up=(0, 1, 0), fov=0.6911112, width=96, height=64,
+                       near=1.0, far=5.0, x0=1.5, y0=-0.75, fov_distance=1.7)
+    grid = generate_centered_pixel_coords(cam.width, cam.height, cam.width, cam.height, device=DEV)
+    opy, opx = oray.centered_pixel_coords(cam.width, cam.height)
+    np.testing.assert_array_equal(grid[0].cpu().numpy(), opy)
+    np.testing.assert_array_equal(grid[1].cpu().numpy(), opx)
+    m = cam.view_matrix()[0].numpy()
+    for ortho, gen in ((False, generate_pinhole_rays), (True, generate_ortho_rays)):
+        rays = gen(cam, grid)
+        if ortho:
+            sx, sy, x0, y0 = np.float32(cam.fov_distance) * np.float32(cam.width / cam.height), cam.fov_distance, 0.0, 0.0
+        else:
+            sx, sy, x0, y0 = cam.tan_half_fov('horizontal'), cam.tan_half_fov('vertical'), cam.x0, cam.y0
+        wo, wd = oray.generate_rays(opx, opy, ortho, x0, y0, cam.width, cam.height, sx, sy, m[:3, :3], m[:3, 3])
+        assert rays.origins.shape == (cam.width * cam.height, 3) and rays.dist_min == 1.0 and rays.dist_max == 5.0
+        np.testing.assert_allclose(rays.origins.cpu().numpy(), wo, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(rays.dirs.cpu().numpy(), wd, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(np.linalg.norm(rays.dirs.cpu().numpy(), axis=1), 1.0, atol=1e-6)
+    # geometry (no principal-point shift): the ray through the image centre points from the eye to `at`
+    cam0 = LookAtCamera(eye=(2.1, 1.3, -2.4), at=(0.1, -0.05, 0.2), up=(0, 1, 0), fov=0.9, width=64, height=64)
+    c = (torch.full((1, 1), 32.0, device=DEV), torch.full((1, 1), 32.0, device=DEV))
+    r = generate_pinhole_rays(cam0, c)
+    want = np.array(cam0.at) - np.array(cam0.eye); want /= np.linalg.norm(want)
+    np.testing.assert_allclose(r.dirs[0].cpu().numpy(), want, atol=2e-6)
+    np.testing.assert_allclose(r.origins[0].cpu().numpy(), np.array(cam0.eye), atol=2e-6)

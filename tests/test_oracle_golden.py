@@ -188,3 +188,24 @@ def test_octree_grid_oracle_properties():
     got = og.interpolate_trilinear(c, torch.tensor([pyr[1, level] + k]), pts, tr, feats, level)
     assert torch.allclose(got[0, 0], feats[tr[pyr[1, level] + k, 0]], atol=1e-6)
     assert tr.max() <= pyd[0, 1:].max() and par[0] == -1
+
+
+def test_raygen_oracle_geometry():
+    """The ray-generation restatement on a look-at camera: unit directions, the image-centre ray runs from the eye to the
+    look-at point, and pixel (0.5, 0.5) of a 90-degree camera sits at the (-1, +1) corner of the image plane."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kaolin-wisp_amd"))
+    from oracle import raygen as oray
+    from wisp.ops.raygen import LookAtCamera
+    cam = LookAtCamera(eye=(0.0, 0.0, 3.0), at=(0.0, 0.0, 0.0), up=(0, 1, 0), fov=np.pi / 2, width=64, height=64)
+    m = cam.view_matrix()[0].numpy()
+    py, px = oray.centered_pixel_coords(64, 64)
+    o, d = oray.generate_rays(px, py, False, 0.0, 0.0, 64, 64, cam.tan_half_fov('horizontal'), cam.tan_half_fov('vertical'),
+                              m[:3, :3], m[:3, 3])
+    np.testing.assert_allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-6)
+    np.testing.assert_allclose(o, np.tile(np.array([[0, 0, 3.0]], np.float32), (64 * 64, 1)), atol=1e-6)
+    corner = d[0] / -d[0, 2]                                   # pixel (0.5, 0.5): top-left
+    np.testing.assert_allclose(corner[:2], [-(1 - 1 / 64), (1 - 1 / 64)], atol=1e-6)
+    oc, dc = oray.generate_rays(np.array([32.0], np.float32), np.array([32.0], np.float32), False, 0.0, 0.0, 64, 64, 1.0, 1.0,
+                                m[:3, :3], m[:3, 3])
+    np.testing.assert_allclose(dc[0], [0, 0, -1], atol=1e-6)
