@@ -24,4 +24,4 @@ for S in [32, 32 * 1024, 262144, 1 << 20, 1 << 21, 1 << 22]:
     gr = torch.randn(S, 3, device=dev); gd = torch.randn(S, 1, device=dev)
     f = timeit(lambda: C.nerf_mlp_forward(feats, dirs, params, 32, 64, 4, True))
     b = timeit(lambda: C.nerf_mlp_backward(feats, dirs, params, gr, gd, 32, 64, 4, True, grad_params=gp))
-    print(f"S={S:8d}  fwd {f:8.1f} us   bwd {b:8.1f} us   (WISP_MLP_DBG={os.environ.get('WISP_MLP_DBG', '0')})", flush=True)
+    print(f"S={S:8d}  fwd {f:8.1f} us   bwd {b:8.1f} us", flush=True)
