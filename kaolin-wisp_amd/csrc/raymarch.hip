@@ -77,8 +77,38 @@ raymarch_ray_count_kernel(const uint32_t* __restrict__ occ_bits, const uint8_t* 
     const float step = n > 1 ? __fdiv_rn(1.0f, (float)(n - 1)) : 0.0f;
     const float fn = (float)n;
     const int words = (n + 31) >> 5;
+    // Conservative depth interval in which this ray can be inside the (slightly inflated) cube: 64-candidate chunks that lie
+    // entirely outside it cannot contain a hit and are skipped without evaluating jitter / position / occupancy.  The
+    // inflation (1e-4 in space) is far above the rounding of o + d*t (|x| < 8 -> 1e-6), so no candidate the exact test
+    // would accept is ever skipped; the per-candidate test itself is unchanged.
+    float t_in = -INFINITY, t_out = INFINITY;
+    {
+        const float o3[3] = {ox, oy, oz}, d3[3] = {dx, dy, dz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (fabsf(d3[a]) > 1e-12f) {
+                const float ta = (-1.0001f - o3[a]) / d3[a], tb = (1.0001f - o3[a]) / d3[a];
+                t_in = fmaxf(t_in, fminf(ta, tb));
+                t_out = fminf(t_out, fmaxf(ta, tb));
+            } else if (fabsf(o3[a]) > 1.0001f) {
+                t_out = -INFINITY;                       // parallel to the slab and outside it: never inside
+            }
+        }
+    }
+    const float pad = 1e-3f * fabsf(range) + 1e-6f;
     int cnt = 0;
     for (int base = 0; base < n; base += 64) {
+        // depths of candidates base .. base+63 lie in [near + range*base/n, near + range*((base+64)/(n-1) + 1/n)] (range >= 0)
+        const float c_lo = near + range * ((float)base / fn) - pad;
+        const float c_hi = near + range * ((float)(base + 64) / (float)(n > 1 ? n - 1 : 1) + 1.0f / fn) + pad;
+        if (range >= 0.0f && (c_hi < t_in || c_lo > t_out)) {
+            if (lane == 0) {
+                const int w = base >> 5;
+                hitmask[r * words + w] = 0u;
+                if (w + 1 < words) hitmask[r * words + w + 1] = 0u;
+            }
+            continue;
+        }
         const int s = base + lane;
         bool hit = false;
         if (s < n) {
