@@ -119,6 +119,28 @@ def test_hashgrid_backward_slot_overflow_falls_back_to_atomics():
         assert float((got.double().cpu() - want_d).abs().max()) <= tol * scale, dt
 
 
+@pytest.mark.parametrize("dim,F,bitwidth,res", [(2, 2, 14, [16, 40, 101, 256, 512]), (3, 4, 15, [8, 20, 50, 128]),
+                                                (3, 8, 14, [8, 32, 64])])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hashgrid_backward_other_shapes(dim, F, bitwidth, res, dtype):
+    """Binned backward away from the flagship shape: 2-D coordinates (image fit), 4 features (generic record form) and
+    8 features (gradient rows too wide for the LDS staging: the launcher must pick the atomic path by itself)."""
+    rng = np.random.default_rng(21 + dim + F)
+    _, begin = ohash.table_layout(res, 2 ** bitwidth, coord_dim=dim)
+    shape = (int(begin[-1]), F)
+    n = 8192
+    # ray-like ordering (runs of nearby samples) so that the run merge has something to do
+    start = rng.uniform(-1, 1, (n // 32, 1, dim))
+    step = rng.normal(size=(n // 32, 1, dim)) * 0.004
+    coords = np.clip(start + step * np.arange(32)[None, :, None], -1, 1).reshape(n, dim).astype(np.float32)
+    go = torch.from_numpy(rng.normal(size=(n, len(res) * F)).astype(np.float32)).to(dtype)
+    want = ohash.hashgrid_backward(torch.from_numpy(coords), go.float(), shape, torch.from_numpy(begin), res, bitwidth,
+                                   torch.float64)
+    got = _C().hashgrid_interpolate_backward(cuda(coords), go.to(DEV), shape, cuda(begin), res, bitwidth)
+    scale = float(want.abs().max())
+    assert float((got.double().cpu() - want).abs().max()) <= (4e-6 if dtype == torch.float32 else 3e-5) * scale
+
+
 def test_hashgrid_autograd_module_cat_and_sum():
     from wisp.accelstructs import OctreeAS
     from wisp.models.grids import HashGrid
