@@ -2,15 +2,14 @@
 //
 // Replaces wisp/csrc/ops/hashgrid_interpolate_cuda.cu:19-339 + hash_utils.cuh:17-112 (reference design:
 // one launch per level, one thread per sample, uncoalesced 4-byte stores).  Design here:
-//   * ONE launch for all levels.  A workgroup owns a tile of 64 consecutive samples; wave w of the
-//     workgroup owns level w (w, w+16, ... when there are more than 16 levels).  All per-level state
-//     (resolution, dense-vs-hash, table base) is therefore wave-uniform: it lives in SGPRs and the
-//     dense/hash branch never diverges.
+//   * ONE launch for all levels.  A wave owns a tile of 64 consecutive samples and walks the levels; all per-level
+//     state (resolution, dense-vs-hash, table base) is wave-uniform: it lives in SGPRs and the dense/hash branch
+//     never diverges.  Waves are independent - no workgroup barrier anywhere.
 //   * consecutive samples of a ray are consecutive lanes, so on the coarse (dense) levels a wave's 8x64
 //     corner reads fall into a handful of cache lines.
-//   * the [64 x L*F] output tile is staged through LDS and written back as whole rows: every global
-//     store instruction writes 256 contiguous bytes per wave (the reference scatters 4-byte pieces at a
-//     64-byte stride).
+//   * the [64 x L*F] output tile is staged through the wave's LDS slice and written back as one contiguous block:
+//     every global store instruction writes 256 contiguous bytes per wave (the reference scatters 4-byte pieces
+//     at a 64-byte stride).
 //   * backward (second half of this file): run merge inside the wave, records binned per 8192 table entries, one
 //     workgroup per bin accumulating in LDS - atomics only as the overflow / tiny-batch path.
 // Numerics contract: SURVEY.md Appendix B (coordinate scaling rounded once from the exact value like the reference's
@@ -107,52 +106,40 @@ static __device__ __forceinline__ void corner_setup(const float* __restrict__ c,
 #undef HG_CORNER_TERMS
 }
 
+// Forward.  One WAVE owns 64 consecutive samples and walks all levels for them: the level is wave-uniform (resolution,
+// dense-vs-hash and table base are scalar loads, the index flavour never diverges), the waves are independent (no
+// workgroup barrier: a wave of a cheap coarse level never waits for a wave of an expensive hashed one) and the tile's
+// [64 x L*F] output is collected in the wave's LDS slice and written back as one contiguous block.
+#define FW_WAVES 4
 template <typename T, int F, int DIM>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(FW_WAVES * 64)
 hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ codebook,
                     const int64_t* __restrict__ first_idx, HashLevels lv, int num_lods, uint32_t tsize,
-                    int tsize_pow2, int zero_from_col, T* __restrict__ feats) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t stage[];   // [num_lods][65][W] dwords
-    constexpr int W = (F * (int)sizeof(T)) / 4;                        // payload dwords per (sample, level)
+                    int tsize_pow2, int zero_from_col, int row_shift, T* __restrict__ feats) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t stage_all[];   // per wave: [num_lods][65][W] dwords
+    constexpr int W = (F * (int)sizeof(T)) / 4;                            // payload dwords per (sample, level)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int nwaves = blockDim.x >> 6;
+    uint32_t* stage = stage_all + (size_t)wave * num_lods * 65 * W;
     const int64_t ntiles = (n + HG_TILE - 1) / HG_TILE;
-    const int row_dw = num_lods * W;                                   // dwords per output row
+    const int row_dw = num_lods * W;                                       // dwords per output row
 
-    // the levels of this wave (wave, wave + nwaves) and their constants, fetched once: indexing the by-value level table
-    // with a per-wave level inside the tile loop costs a dependent memory round trip per tile
-    constexpr int MAXW = 2;
-    int32_t w_res[MAXW];
-    bool w_dense[MAXW];
-    const T* w_table[MAXW];
-#pragma unroll
-    for (int q = 0; q < MAXW; ++q) {
-        const int l = wave + q * nwaves;
-        const bool ok = l < num_lods;
-        w_res[q] = __builtin_amdgcn_readfirstlane(ok ? lv.res[l] : 1);
-        w_dense[q] = __builtin_amdgcn_readfirstlane(ok ? lv.dense[l] : 1) != 0;
-        w_table[q] = codebook + (ok ? first_idx[l] : 0) * F;
-    }
-
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int nwaves = blockDim.x >> 6;                                    // 4, fewer when the rows are wide (LDS)
+    for (int64_t tile = (int64_t)blockIdx.x * nwaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * nwaves) {
         const int64_t i = tile * HG_TILE + lane;
         const bool live = i < n;
         float c[DIM];
 #pragma unroll
         for (int a = 0; a < DIM; ++a) c[a] = live ? coords[i * DIM + a] : 0.0f;
 
-#pragma unroll
-        for (int q = 0; q < MAXW; ++q) {
-            const int l = wave + q * nwaves;
-            if (l >= num_lods) break;
-            const int32_t res = w_res[q];
-            const bool dense = w_dense[q];
+        for (int l = 0; l < num_lods; ++l) {
+            const int32_t res = lv.res[l];
+            const bool dense = lv.dense[l] != 0;
             float acc[F];
 #pragma unroll
             for (int k = 0; k < F; ++k) acc[k] = 0.0f;
             if (live && l * F < zero_from_col) {
-                const T* __restrict__ table = w_table[q];
+                const T* __restrict__ table = codebook + first_idx[l] * F;
                 CornerSetup<DIM> cs;
                 corner_setup<DIM>(c, res, dense, tsize, tsize_pow2 != 0, cs);
                 T v[1 << DIM][F];
@@ -185,19 +172,19 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #pragma unroll
             for (int w = 0; w < W; ++w) dst[w] = reinterpret_cast<const uint32_t*>(o)[w];
         }
-        __syncthreads();
-        // write the tile back as full rows: consecutive threads -> consecutive dwords of feats
+        __builtin_amdgcn_wave_barrier();
+        // write the tile back as one contiguous block: consecutive lanes -> consecutive dwords of feats
         const int64_t rows = (n - tile * HG_TILE) < HG_TILE ? (n - tile * HG_TILE) : HG_TILE;
         const int total = (int)rows * row_dw;
         uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(feats) + tile * HG_TILE * row_dw;
-        for (int gidx = threadIdx.x; gidx < total; gidx += blockDim.x) {
-            const int s = gidx / row_dw;
+        for (int gidx = lane; gidx < total; gidx += 64) {
+            const int s = row_shift >= 0 ? gidx >> row_shift : gidx / row_dw;
             const int rem = gidx - s * row_dw;
             const int l = rem / W;
             const int w = rem - l * W;
             out[gidx] = stage[(l * 65 + s) * W + w];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -604,11 +591,21 @@ static int launch_fwd(const float* coords, int64_t n, const void* codebook, cons
                       const HashLevels& lv, int num_lods, uint32_t tsize, int zero_from_col, void* feats,
                       hipStream_t s) {
     constexpr int W = (F * (int)sizeof(T)) / 4;
-    const int nw = num_lods < 16 ? num_lods : 16;
-    const size_t lds = (size_t)num_lods * 65 * W * 4;
+    const size_t wave_lds = (size_t)num_lods * 65 * W * 4;
+    int waves = FW_WAVES;
+    while (waves > 1 && waves * wave_lds > 64 * 1024) --waves;
+    const size_t lds = waves * wave_lds;
     const int pow2 = (tsize & (tsize - 1)) == 0;
-    hipLaunchKernelGGL((hashgrid_fwd_kernel<T, F, DIM>), dim3(hg_grid(n)), dim3(64 * nw), lds, s, coords, n,
-                       (const T*)codebook, first_idx, lv, num_lods, tsize, pow2, zero_from_col, (T*)feats);
+    const int row_dw = num_lods * W;
+    int row_shift = -1;
+    if ((row_dw & (row_dw - 1)) == 0) { row_shift = 0; while ((1 << row_shift) < row_dw) ++row_shift; }
+    auto kern = hashgrid_fwd_kernel<T, F, DIM>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t tiles = ceil_div64(n, HG_TILE);
+    int64_t g = ceil_div64(tiles, waves);
+    if (g > 8192) g = 8192;                               // 256 CUs x 32; grid-stride beyond that
+    hipLaunchKernelGGL(kern, dim3((unsigned)(g < 1 ? 1 : g)), dim3(waves * 64), lds, s, coords, n, (const T*)codebook,
+                       first_idx, lv, num_lods, tsize, pow2, zero_from_col, row_shift, (T*)feats);
     return 0;
 }
 
