@@ -244,6 +244,12 @@ int wisp_sphere_trace_step(int64_t num_packs, const float* nug_o, const float* n
                            const float* dist, float* dist_prev, uint8_t* mask, uint8_t* hit, const int32_t* curr_in,
                            int32_t* curr_out, int64_t* curr_pidx, float* x, wisp_stream_t stream);
 
+/* Photometric loss of MultiviewTrainer.step (wisp/trainers/multiview_trainer.py:140-154) and its gradient in one launch:
+ * loss[0] = mean over the num_elements entries of huber(beta = 1) (kind 0) / squared (1) / absolute (2) error of rgb
+ * against gt; grad[i] = d loss / d rgb[i].  rgb, gt, grad: f32 [num_elements]; loss: f32 [1]; workspace: f32 [256]. */
+int wisp_rgb_loss(const float* rgb, const float* gt, int64_t num_elements, int kind, float* grad, float* loss,
+                  float* workspace, wisp_stream_t stream);
+
 /* Rays of one camera through the given pixel coordinates - generate_pinhole_rays / generate_ortho_rays
  * (wisp/ops/raygen/raygen.py:40-119).  pixel_x / pixel_y: f32 [num_pixels] (device); the camera is passed by value from
  * the host: principal-point offset (x0, y0) in pixels from the image centre, image size, scale_x / scale_y =

@@ -58,6 +58,7 @@ SIGNATURES = {
     "wisp_packed_cumsum": [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "wisp_find_depth_bound": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp],
     "wisp_sphere_trace_step": [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_rgb_loss": [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
     "wisp_generate_rays": [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_composite_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_composite_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp],
@@ -524,6 +525,21 @@ def sphere_trace_step(nug_o, nug_d, nug_depth, nug_pidx, dist_max, thr_close, th
                                       float(np.float32(thr_close)), float(np.float32(thr_avg)), _p(t), _p(dist), _p(dist_prev),
                                       _p(mask), _p(hit), _p(curr_in), _p(curr_out), _p(curr_pidx), _p(x), _stream()),
            "sphere_trace_step")
+
+
+_LOSS_KIND = {"huber": 0, "l2": 1, "l1": 2}
+
+
+def rgb_loss(rgb, gts, kind):
+    """(loss [1], d loss / d rgb) for the mean huber / l2 / l1 error (multiview_trainer.py:140-154)."""
+    rgb = _need(rgb, torch.float32, "rgb")
+    gts = _need(gts, torch.float32, "gts")
+    assert rgb.shape == gts.shape
+    grad = torch.empty_like(rgb)
+    buf = torch.empty(257, dtype=torch.float32, device=rgb.device)          # [0] loss, [1:] per-workgroup partials
+    _check(lib.wisp_rgb_loss(_p(rgb), _p(gts), rgb.numel(), _LOSS_KIND[kind], _p(grad), _p(buf), c_vp(buf.data_ptr() + 4),
+                             _stream()), "rgb_loss")
+    return buf[:1], grad
 
 
 def generate_rays(pixel_x, pixel_y, ortho, x0, y0, width, height, scale_x, scale_y, view_rotation, view_translation):

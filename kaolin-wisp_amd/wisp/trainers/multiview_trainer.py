@@ -143,20 +143,11 @@ class _DirectHashNeRFStep:
             tracer.bg_color = tracer.bg_color.to(dev)
         bg = tracer._bg_host()
         rgb, _alpha, _depth, _hit, _w = C.composite_fwd(color, density, deltas, None, None, offsets, N, bg)
-        # loss and its gradient w.r.t. the composited colours (what autograd derives for loss_fn(...).mean())
-        diff = rgb - img_gts
-        inv = 1.0 / diff.numel()
-        if t.rgb_loss_type == 'huber':
-            loss = torch.nn.functional.smooth_l1_loss(rgb, img_gts, reduction='none').mean()
-            g_rgb = torch.clamp(diff, -1.0, 1.0) * inv
-        elif t.rgb_loss_type == 'l2':
-            loss = (diff * diff).mean()
-            g_rgb = diff * (2.0 * inv)
-        elif t.rgb_loss_type == 'l1':
-            loss = diff.abs().mean()
-            g_rgb = torch.sign(diff) * inv
-        else:
+        # loss and its gradient w.r.t. the composited colours (what autograd derives for loss_fn(...).mean()), one launch
+        if t.rgb_loss_type not in ('huber', 'l2', 'l1'):
             raise NotImplementedError
+        loss, g_rgb = C.rgb_loss(rgb, img_gts, t.rgb_loss_type)
+        loss = loss[0]
         g_color, g_density = C.composite_bwd(g_rgb, None, None, color, density, deltas, None, None, offsets, bg)
         g_feats, _ = C.nerf_mlp_backward(feats, dirs, self.packed, g_color, g_density, i, h, f, t.enable_amp,
                                          grad_params=self.packed_grad)

@@ -559,7 +559,7 @@ def test_direct_step_equals_modular_step(amp, monkeypatch):
         tr.optimizer_step = snap
     l1, s1 = tr1.step(rays, gts, jitter=jit)
     l2, s2 = tr2.step(rays, gts, jitter=jit)
-    assert s1 == s2 and abs(float(l1) - float(l2)) <= 1e-7 * max(1.0, abs(float(l2)))
+    assert s1 == s2 and abs(float(l1) - float(l2)) <= 1e-6 * max(1.0, abs(float(l2)))      # different summation order
     g1, g2 = grads["direct"].cpu().numpy(), grads["modular"].cpu().numpy()
     scale = float(np.abs(g2).max())
     # (this small batch takes the float-atomic scatter path, whose add order varies from run to run)
