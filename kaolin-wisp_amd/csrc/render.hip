@@ -452,13 +452,16 @@ extern "C" int wisp_generate_rays(const float* pixel_x, const float* pixel_y, in
 // ---------------------------------------------------------------------------------------------- photometric loss
 // mean over all elements of huber (smooth-L1, beta = 1) / L2 / L1 between the composited colours and the ground truth
 // (MultiviewTrainer.step, wisp/trainers/multiview_trainer.py:140-154) together with its gradient w.r.t. the colours:
-// d loss / d rgb = clamp(x, -1, 1) / N, 2 x / N, sign(x) / N for x = rgb - gt.  Grid-stride pass that writes the gradient
-// and one partial sum per workgroup, then a single-wave pass over the partials: fixed summation order, reproducible value.
+// d loss / d rgb = clamp(x, -1, 1) / N, 2 x / N, sign(x) / N for x = rgb - gt.  ONE launch: a grid-stride pass writes the
+// gradient and one partial sum per workgroup; the workgroup that finishes last (ticket counter in the workspace, which it
+// resets for the next call) adds the partials in index order - reproducible value, no second kernel.
 #define LOSS_BLOCKS 256
 __global__ void __launch_bounds__(256)
 rgb_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ gt, int64_t n, int kind, float inv_n,
-                float* __restrict__ grad, float* __restrict__ partial) {
+                float* __restrict__ grad, float* __restrict__ partial, unsigned int* __restrict__ ticket,
+                float* __restrict__ loss) {
     __shared__ float part[4];
+    __shared__ bool last;
     float acc = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float x = rgb[i] - gt[i];
@@ -473,16 +476,19 @@ rgb_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ gt, int
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
-}
-
-__global__ void __launch_bounds__(64)
-rgb_loss_final_kernel(const float* __restrict__ partial, int blocks, float inv_n, float* __restrict__ loss) {
-    float acc = 0.0f;
-    for (int b = threadIdx.x; b < blocks; b += 64) acc += partial[b];
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+        __threadfence();                                               // partial visible before the ticket is taken
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    __threadfence();
+    float t = 0.0f;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 64) t += __hip_atomic_load(partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (threadIdx.x == 0) loss[0] = acc * inv_n;
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (threadIdx.x == 0) { loss[0] = t * inv_n; *ticket = 0u; }
 }
 
 extern "C" int wisp_rgb_loss(const float* rgb, const float* gt, int64_t num_elements, int kind, float* grad, float* loss,
@@ -490,10 +496,8 @@ extern "C" int wisp_rgb_loss(const float* rgb, const float* gt, int64_t num_elem
     WISP_REQUIRE(num_elements > 0 && rgb && gt && grad && loss && workspace, "bad arguments");
     WISP_REQUIRE(kind >= 0 && kind <= 2, "kind: 0 huber, 1 l2, 2 l1");
     const int blocks = (int)min64(ceil_div64(num_elements, 256), LOSS_BLOCKS);
-    const float inv_n = 1.0f / (float)num_elements;
-    hipLaunchKernelGGL(rgb_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rgb, gt, num_elements, kind, inv_n,
-                       grad, workspace);
-    hipLaunchKernelGGL(rgb_loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, blocks, inv_n, loss);
+    hipLaunchKernelGGL(rgb_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rgb, gt, num_elements, kind,
+                       1.0f / (float)num_elements, grad, workspace + 1, reinterpret_cast<unsigned int*>(workspace), loss);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }

@@ -316,6 +316,34 @@ extern "C" int64_t wisp_scan_workspace_bytes(int64_t n) {
     return (nt + 8) * 8;
 }
 
+// Up to 64 K values (the per-ray sample counts of one training batch): ONE workgroup, one launch - every thread sums a
+// contiguous run, the 1024 run totals are scanned with wave shuffles + 16 LDS cells, then the runs are re-walked.  The
+// three-kernel tile scan below takes over for longer inputs; a launch costs ~5 us of timeline here, the scan itself ~2.
+#define SC1_MAX (64 * 1024)
+__global__ void __launch_bounds__(1024)
+scan_single_block_kernel(const int32_t* __restrict__ in, int n, int64_t* __restrict__ out) {
+    __shared__ int64_t wave_tot[16];
+    const int per = (n + 1023) / 1024;
+    const int lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
+    int64_t run = 0;
+    for (int i = lo; i < hi; ++i) run += in[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t inc = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int64_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int64_t t = wave_tot[w]; if (w < wave) base += t; total += t; }
+    int64_t acc = base + inc - run;                      // exclusive prefix of this thread's run
+    for (int i = lo; i < hi; ++i) { out[i] = acc; acc += in[i]; }
+    if (threadIdx.x == 0) out[n] = total;
+}
+
 extern "C" int wisp_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* offsets, void* workspace,
                                        wisp_stream_t stream) {
     WISP_REQUIRE(n >= 0 && offsets, "bad args");
@@ -325,6 +353,11 @@ extern "C" int wisp_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t
         return WISP_OK;
     }
     WISP_REQUIRE(counts && workspace, "null pointer");
+    if (n <= SC1_MAX) {
+        hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(1024), 0, s, counts, (int)n, offsets);
+        WISP_CHECK_LAUNCH();
+        return WISP_OK;
+    }
     int64_t* tiles = (int64_t*)workspace;
     const int64_t nt = ceil_div64(n, SC_TILE);
     hipLaunchKernelGGL(scan_tile_sums_kernel<int32_t>, dim3((unsigned)nt), dim3(SC_THREADS), 0, s, counts, n, tiles);

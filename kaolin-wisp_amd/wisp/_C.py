@@ -528,6 +528,7 @@ def sphere_trace_step(nug_o, nug_d, nug_depth, nug_pidx, dist_max, thr_close, th
 
 
 _LOSS_KIND = {"huber": 0, "l2": 1, "l1": 2}
+_loss_ws = {}
 
 
 def rgb_loss(rgb, gts, kind):
@@ -536,10 +537,13 @@ def rgb_loss(rgb, gts, kind):
     gts = _need(gts, torch.float32, "gts")
     assert rgb.shape == gts.shape
     grad = torch.empty_like(rgb)
-    buf = torch.empty(257, dtype=torch.float32, device=rgb.device)          # [0] loss, [1:] per-workgroup partials
-    _check(lib.wisp_rgb_loss(_p(rgb), _p(gts), rgb.numel(), _LOSS_KIND[kind], _p(grad), _p(buf), c_vp(buf.data_ptr() + 4),
-                             _stream()), "rgb_loss")
-    return buf[:1], grad
+    ws = _loss_ws.get(rgb.device)
+    if ws is None:
+        ws = _loss_ws[rgb.device] = torch.zeros(257, dtype=torch.float32, device=rgb.device)   # ticket + partials
+    loss = torch.empty(1, dtype=torch.float32, device=rgb.device)
+    _check(lib.wisp_rgb_loss(_p(rgb), _p(gts), rgb.numel(), _LOSS_KIND[kind], _p(grad), _p(loss), _p(ws), _stream()),
+           "rgb_loss")
+    return loss, grad
 
 
 def generate_rays(pixel_x, pixel_y, ortho, x0, y0, width, height, scale_x, scale_y, view_rotation, view_translation):

@@ -204,7 +204,7 @@ def test_raytrace_bit_exact_sparse_and_dense():
 
 def test_scans_boundaries_and_pack_starts():
     g = torch.Generator().manual_seed(5)
-    for n in (1, 63, 2048, 2049, 300001):
+    for n in (1, 63, 2048, 2049, 65536, 65537, 300001):      # single-workgroup scan up to 64 K, tile scan above
         c = torch.randint(0, 9, (n,), generator=g, dtype=torch.int32)
         off = _C().exclusive_scan(c.to(DEV)).cpu()
         assert torch.equal(off[1:], torch.cumsum(c.long(), 0)) and int(off[0]) == 0
