@@ -551,9 +551,32 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
     __syncthreads();
     float* __restrict__ dst = grad_codebook + (first_idx[l] + (int64_t)first) * F;
     if (splits == 1) {
-        for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
-            const float a = ACC::get(rd_acc, e);
-            if (a != 0.0f) dst[e] += a;                   // this workgroup owns the slice: plain read-modify-write
+        // this workgroup owns the slice: plain read-modify-write, four floats per thread and ALL of a thread's loads issued
+        // before its first store (one memory round trip per workgroup instead of one per element)
+        constexpr int MAXQ = 4;                           // 16384 floats / (1024 threads x 4)
+        const uint32_t quads = lim >> 2;
+        if (quads <= MAXQ * RD_THREADS && (lim & 3u) == 0 && ((uintptr_t)dst & 15u) == 0) {
+            float4 cur[MAXQ];
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+                const uint32_t i = threadIdx.x + q * RD_THREADS;
+                if (i < quads) cur[q] = reinterpret_cast<const float4*>(dst)[i];
+            }
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+                const uint32_t i = threadIdx.x + q * RD_THREADS;
+                if (i < quads) {
+                    float4 t = cur[q];
+                    t.x += ACC::get(rd_acc, 4 * i); t.y += ACC::get(rd_acc, 4 * i + 1);
+                    t.z += ACC::get(rd_acc, 4 * i + 2); t.w += ACC::get(rd_acc, 4 * i + 3);
+                    reinterpret_cast<float4*>(dst)[i] = t;
+                }
+            }
+        } else {
+            for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
+                const float a = ACC::get(rd_acc, e);
+                if (a != 0.0f) dst[e] += a;
+            }
         }
     } else {
         for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
