@@ -847,3 +847,21 @@ def test_ray_generation_matches_oracle():
     want = np.array(cam0.at) - np.array(cam0.eye); want /= np.linalg.norm(want)
     np.testing.assert_allclose(r.dirs[0].cpu().numpy(), want, atol=2e-6)
     np.testing.assert_allclose(r.origins[0].cpu().numpy(), np.array(cam0.eye), atol=2e-6)
+
+
+@pytest.mark.parametrize("kind", ["huber", "l2", "l1"])
+def test_rgb_loss_matches_torch_autograd(kind):
+    """wisp_rgb_loss (loss + gradient in one launch) against torch's loss functions and their autograd backward,
+    at a size that needs several workgroups and at a tiny one."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for n in (7, 49623):
+        rgb = (torch.rand(n, 3, device=DEV, generator=g) * 3 - 1).requires_grad_(True)      # |x| > 1 occurs (huber knee)
+        gt = torch.rand(n, 3, device=DEV, generator=g)
+        ref = {"huber": torch.nn.functional.smooth_l1_loss(rgb, gt, reduction='none').mean(),
+               "l2": torch.nn.functional.mse_loss(rgb, gt, reduction='none').mean(),
+               "l1": torch.abs(rgb - gt).mean()}[kind]
+        ref.backward()
+        for _ in range(2):                                   # twice: the ticket counter must have reset itself
+            loss, grad = _C().rgb_loss(rgb.detach(), gt, kind)
+            assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+            np.testing.assert_allclose(grad.cpu().numpy(), rgb.grad.cpu().numpy(), rtol=1e-6, atol=1e-9)
