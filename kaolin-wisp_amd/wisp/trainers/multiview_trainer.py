@@ -132,6 +132,7 @@ class _DirectHashNeRFStep:
         S = samples.shape[0]
         tracer.prev_num_samples = S
         dirs = rays.dirs.index_select(0, ridx)
+        t.wait_for_parameters()                 # everything above overlapped the previous step's all-reduce + update
         table = self.table
         if t.enable_amp:
             shadow = getattr(table, '_wisp_shadow', None)
@@ -187,6 +188,8 @@ class MultiviewTrainStep:
                                 and dist.is_initialized())
         # prune draws must be identical on every rank so the replicated octrees stay identical
         self._prune_gen = torch.Generator().manual_seed(seed)
+        self._side_stream = None
+        self._params_ready = None
         # specialised issue order for the flagship pipeline shape (WISP_DIRECT_STEP=0 keeps the modular path)
         self._direct = None
         if os.environ.get("WISP_DIRECT_STEP", "1") != "0" and _DirectHashNeRFStep.supports(pipeline):
@@ -215,6 +218,31 @@ class MultiviewTrainStep:
         if self.world > 1 or self.force_allreduce:
             dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)     # RCCL over xGMI
 
+    def reduce_and_update(self):
+        """Gradient all-reduce + optimizer.  With more than one rank both run on a side stream, so that the part of the
+        NEXT step that does not read parameters (ray gathering, raymarch against the occupancy structure, its size
+        read-back) overlaps the collective; whoever reads parameters next calls wait_for_parameters() first."""
+        if not (self.world > 1 or self.force_allreduce) or not self.flat.data.is_cuda:
+            self.allreduce_grads()
+            self.optimizer_step()
+            return
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        self._side_stream.wait_stream(main)
+        with torch.cuda.stream(self._side_stream):
+            self.allreduce_grads()
+            self.optimizer_step()
+            self._params_ready = torch.cuda.Event()
+            self._params_ready.record()
+
+    def wait_for_parameters(self):
+        """Order the current stream after the last reduce_and_update()."""
+        ev = self._params_ready
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._params_ready = None
+
     # -------------------------------------------------------------------------------------------- reference hooks
     def pre_step(self):
         """multiview_trainer.py:85-93."""
@@ -222,6 +250,7 @@ class MultiviewTrainStep:
             self.prune()
 
     def prune(self):
+        self.wait_for_parameters()
         nef = self.pipeline.nef
         cells = nef.grid.dense_points.shape[0]
         unit = torch.rand(cells, 3, generator=self._prune_gen)
@@ -252,13 +281,13 @@ class MultiviewTrainStep:
             with torch.no_grad():
                 loss, _ = self._direct.run(rays, img_gts, jitter)
         else:
+            self.wait_for_parameters()
             kw = {} if jitter is None else {"jitter": jitter}
             with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.enable_amp):
                 rb = self.pipeline(rays=rays, lod_idx=None, channels=["rgb"], **kw)
                 loss = self.loss_fn(rb.rgb.float(), img_gts)
             loss.backward()
-        self.allreduce_grads()
-        self.optimizer_step()
+        self.reduce_and_update()
         self.calc_adaptive_rays(rays.origins.shape[0])
         return loss.detach(), self.pipeline.tracer.get_prev_num_samples()
 
