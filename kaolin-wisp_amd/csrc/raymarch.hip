@@ -77,6 +77,7 @@ raymarch_ray_count_kernel(const uint32_t* __restrict__ occ_bits, const uint8_t* 
     const float step = n > 1 ? __fdiv_rn(1.0f, (float)(n - 1)) : 0.0f;
     const float fn = (float)n;
     const int words = (n + 31) >> 5;
+    const uint32_t key = wisp_stream_key(seed, (uint64_t)r);            // wave-uniform
     // Conservative depth interval in which this ray can be inside the (slightly inflated) cube: 64-candidate chunks that lie
     // entirely outside it cannot contain a hit and are skipped without evaluating jitter / position / occupancy.  The
     // inflation (1e-4 in space) is far above the rounding of o + d*t (|x| < 8 -> 1e-6), so no candidate the exact test
@@ -112,7 +113,7 @@ raymarch_ray_count_kernel(const uint32_t* __restrict__ occ_bits, const uint8_t* 
         const int s = base + lane;
         bool hit = false;
         if (s < n) {
-            const float u = jitter ? jitter[r * n + s] : wisp_uniform01(seed, (uint64_t)r, (uint64_t)s);
+            const float u = jitter ? jitter[r * n + s] : wisp_uniform01_keyed(key, (uint32_t)s);
             const float t = ray_depth(s, n, step, u, fn, range, near);
             hit = occupied(occ_bits, octree, exsum, axpy_unfused(ox, dx, t), axpy_unfused(oy, dy, t),
                            axpy_unfused(oz, dz, t), level);
@@ -144,6 +145,7 @@ raymarch_ray_emit_kernel(const float* __restrict__ origins, const float* __restr
     const float step = n > 1 ? __fdiv_rn(1.0f, (float)(n - 1)) : 0.0f;
     const float fn = (float)n;
     const int words = (n + 31) >> 5;
+    const uint32_t key = wisp_stream_key(seed, (uint64_t)r);            // wave-uniform, same stream as the count kernel
     int64_t wr = begin;
     for (int base = 0; base < n; base += 64) {
         const int w = base >> 5;
@@ -153,11 +155,11 @@ raymarch_ray_emit_kernel(const float* __restrict__ origins, const float* __restr
         if ((m >> lane) & 1ull) {
             const int s = base + lane;
             const int64_t o = wr + __popcll(m & ((1ull << lane) - 1ull));
-            const float u = jitter ? jitter[r * n + s] : wisp_uniform01(seed, (uint64_t)r, (uint64_t)s);
+            const float u = jitter ? jitter[r * n + s] : wisp_uniform01_keyed(key, (uint32_t)s);
             const float t = ray_depth(s, n, step, u, fn, range, near);
             float prev = near;                                   // depth.diff(prepend=near), octree_as.py:290-291
             if (s > 0) {
-                const float up = jitter ? jitter[r * n + s - 1] : wisp_uniform01(seed, (uint64_t)r, (uint64_t)(s - 1));
+                const float up = jitter ? jitter[r * n + s - 1] : wisp_uniform01_keyed(key, (uint32_t)(s - 1));
                 prev = ray_depth(s - 1, n, step, up, fn, range, near);
             }
             ridx[o] = r;

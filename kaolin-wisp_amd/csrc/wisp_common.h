@@ -46,14 +46,27 @@ template <> struct Cvt<__hip_bfloat16> {
     static __device__ __forceinline__ __hip_bfloat16 from_f(float v) { return __float2bfloat16(v); }
 };
 
-// Counter-based uniform [0,1) generator keyed by (seed, a, b): two rounds of a 64-bit mix
-// (splitmix64 finaliser).  Used only when the caller does not inject a jitter tensor.
-static __device__ __forceinline__ float wisp_uniform01(uint64_t seed, uint64_t a, uint64_t b) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (a + 1) + 0xD1B54A32D192ED03ull * (b + 1);
+// Counter-based uniform [0,1) generator keyed by (seed, a, b); used only when the caller does not inject a jitter tensor.
+// The (seed, a) part - a = the ray / nugget - goes through a 64-bit splitmix finaliser ONCE (in the marching kernels it is
+// wave-uniform, i.e. scalar-unit work); the per-candidate part b is a 32-bit Weyl step + the lowbias32 finaliser: two
+// 32-bit multiplies instead of the four 64-bit ones (quarter-rate v_mul_lo/hi_u32 chains) of a full 64-bit mix, which
+// were ~40 % of the candidate loop.
+static __host__ __device__ __forceinline__ uint32_t wisp_stream_key(uint64_t seed, uint64_t a) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (a + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z = z ^ (z >> 31);
-    return (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0,1)
+    return (uint32_t)(z ^ (z >> 32));
+}
+static __host__ __device__ __forceinline__ float wisp_uniform01_keyed(uint32_t key, uint32_t b) {
+    uint32_t x = key + 0x9E3779B9u * (b + 1u);
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return (float)(x >> 8) * (1.0f / 16777216.0f);    // 24 random bits -> [0,1)
+}
+static __host__ __device__ __forceinline__ float wisp_uniform01(uint64_t seed, uint64_t a, uint64_t b) {
+    return wisp_uniform01_keyed(wisp_stream_key(seed, a), (uint32_t)b);
 }
 
 // Bit position of level-`level` cell (x, y, z) inside the occupancy bitfield (wisp_spc_build_bitfield): plain row-major
