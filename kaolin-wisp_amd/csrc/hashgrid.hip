@@ -455,15 +455,10 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
     }
 }
 
-// Accumulator flavours of the reduce kernel.  LDS *float* atomics (ds_add_f32) turned out to retire roughly one lane per
-// ~3 clocks per CU on gfx950 (measured: 67 M lane-adds -> 0.6 ms), i.e. they are the reduce kernel's bottleneck.
-// Integer LDS atomics do not have that problem, so the default accumulates in 64-bit fixed point (2^-44 resolution,
-// +-5e5 range): exact, order-independent (bitwise reproducible gradients) and converted to fp32 once per table entry.
-struct AccF32 {
-    typedef float type;
-    static __device__ __forceinline__ void add(float* acc, uint32_t i, float v) { atomicAdd(acc + i, v); }   // ds_add_f32
-    static __device__ __forceinline__ float get(const float* acc, uint32_t i) { return acc[i]; }
-};
+// LDS accumulator of the reduce kernel.  LDS *float* atomics (ds_add_f32) turned out to retire roughly one lane per
+// ~3 clocks per CU on gfx950 (measured: 67 M lane-adds -> 0.6 ms); integer LDS atomics do not have that problem, so the
+// bucket is accumulated in 64-bit fixed point (2^-44 resolution, +-5e5 range): exact, order-independent (bitwise
+// reproducible gradients) and converted to fp32 once per table entry.
 struct AccFix64 {
     typedef unsigned long long type;
     static __device__ __forceinline__ void add(type* acc, uint32_t i, float v) {
@@ -672,8 +667,7 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         p.bins.cnt_base[li] = cnt;
         p.bins.rec_base[li] = rec;
         p.bins.entries[li] = (uint32_t)entries;
-        static const int split_target = [] { const char* e = getenv("WISP_RD_SPLITS"); return e ? atoi(e) : 64; }();
-        int splits = (int)(split_target / chunks);            // ~split_target reduce workgroups per coarse level (atomic flush)
+        int splits = (int)(64 / chunks);                      // ~64 reduce workgroups per coarse level (atomic flush)
         if (splits > p.ntiles) splits = (int)p.ntiles;
         p.bins.splits[li] = splits < 1 ? 1 : splits;
         if (chunks > p.max_chunks) p.max_chunks = (int)chunks;
@@ -730,20 +724,11 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     hipLaunchKernelGGL(em, dim3((unsigned)plan.ntiles), dim3(EM_THREADS), em_lds, s,
                        coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
                        plan.chunk_shift, plan.bins, counts, records, grad_codebook);
-    static const bool rd_f32 = env_flag("WISP_RD_F32", false);
-    if (rd_f32) {
-        const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 4;
-        auto rd = hashgrid_bwd_reduce_kernel<T, F, AccF32>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
-        hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
-                           plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook);
-    } else {
-        const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 8;
-        auto rd = hashgrid_bwd_reduce_kernel<T, F, AccFix64>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
-        hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
-                           plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook);
-    }
+    const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 8;
+    auto rd = hashgrid_bwd_reduce_kernel<T, F, AccFix64>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
+    hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
+                       plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook);
     return 0;
 }
 
