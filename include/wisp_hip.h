@@ -140,6 +140,20 @@ int wisp_spc_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i6
                            int samples_per_voxel, int channels, int level, float* grad_feats /* f32, accumulated */,
                            wisp_stream_t stream);
 
+/* All active levels of an OctreeGrid in one launch (wisp/models/grids/octree_grid.py:183-219: one trilinear lookup per
+ * level, then cat or sum).  coords f32 [N,3]; chain i64 [N, chain_stride], column l = voxel (point-hierarchy index, -1 =
+ * outside) of the sample on level levels[l]; feats / grad_feats: HOST arrays of num_lods device pointers ([corners_l,
+ * channels] each, dtype as given / f32); levels: HOST i32 [num_lods].  out f32 [N, num_lods*channels] (sum = 0) or
+ * [N, channels] (sum = 1).  Same per-level arithmetic (and half_round meaning) as wisp_spc_trilinear_fwd/_bwd. */
+int wisp_spc_trilinear_multi_fwd(const float* coords, const int64_t* chain, int64_t chain_stride, const int16_t* points,
+                                 const int32_t* trinkets, const void* const* feats, int dtype, int64_t num_samples,
+                                 int num_lods, const int32_t* levels, int channels, int half_round, int sum, float* out,
+                                 wisp_stream_t stream);
+int wisp_spc_trilinear_multi_bwd(const float* coords, const int64_t* chain, int64_t chain_stride, const int16_t* points,
+                                 const int32_t* trinkets, const float* grad_out, int64_t num_samples, int num_lods,
+                                 const int32_t* levels, int channels, int sum, float* const* grad_feats,
+                                 wisp_stream_t stream);
+
 /* VQAD codebook lookup fused with the trilinear blend (replaces CodebookOctreeGrid._index_features + _interpolate,
  * wisp/models/grids/codebook_grid.py:103-172): logits f32 [Fn, dict_size], dictionary f32 [dict_size, feature_dim]
  * (dict_size <= 256, feature_dim <= 16).  training != 0: straight-through softmax one-hot; else argmax lookup.

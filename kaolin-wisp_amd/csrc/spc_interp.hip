@@ -157,6 +157,123 @@ extern "C" int wisp_spc_trilinear_bwd(const float* coords, const void* pidx, int
     return WISP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- all LODs in one launch
+// OctreeGrid.interpolate (wisp/models/grids/octree_grid.py:183-219) evaluates one trilinear lookup per active level and
+// concatenates or sums the results; here one launch walks the levels for every sample (the level loop is uniform, the
+// per-level feature pointer and octree level are scalar loads) and writes the 'cat' row or the 'sum' directly - no
+// per-level output tensors, no cat / reshape / sum kernels.  Same arithmetic per level as spc_trilinear_fwd_kernel.
+#define SPC_MAX_LODS 16
+struct MultiLod { const void* feats[SPC_MAX_LODS]; float* grad[SPC_MAX_LODS]; int32_t level[SPC_MAX_LODS]; };
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+spc_trilinear_multi_fwd_kernel(const float* __restrict__ coords, const int64_t* __restrict__ chain, int64_t chain_stride,
+                               const int16_t* __restrict__ points, const int32_t* __restrict__ trinkets, MultiLod ml,
+                               int64_t n, int num_lods, int channels, int half_round, int sum, float* __restrict__ out) {
+    const int cpt = channels <= 64 ? channels : 64;
+    const int rows_per_block = blockDim.x / cpt;
+    const int ch0 = threadIdx.x % cpt;
+    const int64_t stride = (int64_t)gridDim.x * rows_per_block;
+    const int out_row = sum ? channels : num_lods * channels;
+    for (int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cpt; i < n; i += stride) {
+        if (threadIdx.x / cpt >= rows_per_block) break;
+        for (int ch = ch0; ch < channels; ch += cpt) {
+            float total = 0.0f;
+            for (int l = 0; l < num_lods; ++l) {
+                const int64_t p = chain[i * chain_stride + l];
+                float acc = 0.0f;
+                if (p >= 0) {
+                    float w[8];
+                    trilinear_coeffs(coords + i * 3, points + p * 3, ml.level[l], w);
+                    const int32_t* tr = trinkets + p * 8;
+                    const T* feats = reinterpret_cast<const T*>(ml.feats[l]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float fv = Cvt<T>::to_f(feats[(int64_t)tr[j] * channels + ch]);
+                        if (half_round) fv = __half2float(__float2half_rn(fv));
+                        acc += fv * w[j];
+                    }
+                    if (half_round) acc = __half2float(__float2half_rn(acc));
+                }
+                if (sum) total += acc; else out[i * out_row + l * channels + ch] = acc;
+            }
+            if (sum) out[i * out_row + ch] = total;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+spc_trilinear_multi_bwd_kernel(const float* __restrict__ coords, const int64_t* __restrict__ chain, int64_t chain_stride,
+                               const int16_t* __restrict__ points, const int32_t* __restrict__ trinkets, MultiLod ml,
+                               const float* __restrict__ grad_out, int64_t n, int num_lods, int channels, int sum) {
+    const int cpt = channels <= 64 ? channels : 64;
+    const int rows_per_block = blockDim.x / cpt;
+    const int ch0 = threadIdx.x % cpt;
+    const int64_t stride = (int64_t)gridDim.x * rows_per_block;
+    const int out_row = sum ? channels : num_lods * channels;
+    for (int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cpt; i < n; i += stride) {
+        if (threadIdx.x / cpt >= rows_per_block) break;
+        for (int l = 0; l < num_lods; ++l) {
+            const int64_t p = chain[i * chain_stride + l];
+            if (p < 0) continue;
+            float w[8];
+            trilinear_coeffs(coords + i * 3, points + p * 3, ml.level[l], w);
+            const int32_t* tr = trinkets + p * 8;
+            float* gf = ml.grad[l];
+            for (int ch = ch0; ch < channels; ch += cpt) {
+                const float g = grad_out[i * out_row + (sum ? 0 : l * channels) + ch];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(gf + (int64_t)tr[j] * channels + ch, g * w[j]);
+            }
+        }
+    }
+}
+
+static int fill_multi(MultiLod& ml, const void* const* feats, float* const* grads, const int32_t* levels, int num_lods) {
+    for (int l = 0; l < SPC_MAX_LODS; ++l) { ml.feats[l] = nullptr; ml.grad[l] = nullptr; ml.level[l] = 0; }
+    for (int l = 0; l < num_lods; ++l) {
+        if (levels[l] < 0 || levels[l] > 15) return -1;
+        ml.level[l] = levels[l];
+        if (feats) { if (!feats[l]) return -1; ml.feats[l] = feats[l]; }
+        if (grads) { if (!grads[l]) return -1; ml.grad[l] = grads[l]; }
+    }
+    return 0;
+}
+
+extern "C" int wisp_spc_trilinear_multi_fwd(const float* coords, const int64_t* chain, int64_t chain_stride,
+                                            const int16_t* points, const int32_t* trinkets, const void* const* feats,
+                                            int dtype, int64_t num_samples, int num_lods, const int32_t* levels,
+                                            int channels, int half_round, int sum, float* out, wisp_stream_t stream) {
+    WISP_REQUIRE(num_samples >= 0 && num_lods >= 1 && num_lods <= SPC_MAX_LODS && channels >= 1 && chain_stride >= num_lods, "bad sizes");
+    if (num_samples == 0) return WISP_OK;
+    WISP_REQUIRE(coords && chain && points && trinkets && feats && levels && out, "null pointer");
+    MultiLod ml;
+    WISP_REQUIRE(fill_multi(ml, feats, nullptr, levels, num_lods) == 0, "bad level or null feature pointer");
+    const dim3 grid(interp_grid(num_samples, channels)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define TRI_MULTI(T) hipLaunchKernelGGL((spc_trilinear_multi_fwd_kernel<T>), grid, block, 0, s, coords, chain, chain_stride, points, \
+                                         trinkets, ml, num_samples, num_lods, channels, half_round, sum, out)
+    if (dtype == WISP_F32) TRI_MULTI(float); else if (dtype == WISP_F16) TRI_MULTI(__half); else TRI_MULTI(__hip_bfloat16);
+#undef TRI_MULTI
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_spc_trilinear_multi_bwd(const float* coords, const int64_t* chain, int64_t chain_stride,
+                                            const int16_t* points, const int32_t* trinkets, const float* grad_out,
+                                            int64_t num_samples, int num_lods, const int32_t* levels, int channels, int sum,
+                                            float* const* grad_feats, wisp_stream_t stream) {
+    WISP_REQUIRE(num_samples >= 0 && num_lods >= 1 && num_lods <= SPC_MAX_LODS && channels >= 1 && chain_stride >= num_lods, "bad sizes");
+    if (num_samples == 0) return WISP_OK;
+    WISP_REQUIRE(coords && chain && points && trinkets && grad_out && levels && grad_feats, "null pointer");
+    MultiLod ml;
+    WISP_REQUIRE(fill_multi(ml, nullptr, grad_feats, levels, num_lods) == 0, "bad level or null gradient pointer");
+    hipLaunchKernelGGL(spc_trilinear_multi_bwd_kernel, dim3(interp_grid(num_samples, channels)), dim3(256), 0, (hipStream_t)stream,
+                       coords, chain, chain_stride, points, trinkets, ml, grad_out, num_samples, num_lods, channels, sum);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- VQAD codebook lookup
 // Fused CodebookOctreeGrid._index_features + trilinear blend (wisp/models/grids/codebook_grid.py:103-172).  The
 // reference materialises logits[S, 8, 2^bw], a softmax, a one-hot and a [S, 8, 2^bw, F] product per level; here one

@@ -40,6 +40,8 @@ SIGNATURES = {
     "wisp_spc_trilinear_coeffs": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_trilinear_fwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp],
+    "wisp_spc_trilinear_multi_fwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
+    "wisp_spc_trilinear_multi_bwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp],
     "wisp_codebook_trilinear_fwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_codebook_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "wisp_mark_pack_boundaries_i64": [c_vp, c_i64, c_vp, c_vp],
@@ -345,6 +347,41 @@ def spc_trilinear_backward(coords, pidx, points, trinkets, grad_out, feats_shape
     _check(lib.wisp_spc_trilinear_bwd(_p(coords), _p(pidx), is64, _p(points), _p(trinkets), _p(grad_out), V, S, C, level,
                                       _p(grad), _stream()), "spc_trilinear_bwd")
     return grad
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr, ctypes.cast(arr, c_vp)
+
+
+def spc_trilinear_multi_forward(coords, chain, points, trinkets, feats_list, levels, half_round, sum_lods):
+    """All LODs of an OctreeGrid in one launch: coords [N,3], chain i64 [N,L] -> f32 [N, L*C] ('cat') or [N, C] ('sum')."""
+    coords = _need(coords, torch.float32, "coords")
+    assert chain.is_cuda and chain.dtype == torch.int64 and chain.stride(-1) == 1
+    points = _need(points, torch.int16, "points")
+    trinkets = _need(trinkets, torch.int32, "trinkets")
+    feats_list = [_need(f, None, "feats") for f in feats_list]
+    N, L, C = coords.shape[0], len(feats_list), feats_list[0].shape[1]
+    assert chain.shape[0] == N and chain.shape[1] >= L and all(f.shape[1] == C and f.dtype == feats_list[0].dtype for f in feats_list)
+    out = torch.empty(N, C if sum_lods else L * C, dtype=torch.float32, device=coords.device)
+    farr, fptr = _ptr_array(feats_list)
+    larr, lptr = _host_i32(levels)
+    _check(lib.wisp_spc_trilinear_multi_fwd(_p(coords), _p(chain), chain.stride(0), _p(points), _p(trinkets), fptr,
+                                            _DTYPE_CODE[feats_list[0].dtype], N, L, lptr, C, int(half_round), int(sum_lods),
+                                            _p(out), _stream()), "spc_trilinear_multi_fwd")
+    return out
+
+
+def spc_trilinear_multi_backward(coords, chain, points, trinkets, grad_out, feats_shapes, levels, sum_lods):
+    coords = _need(coords, torch.float32, "coords")
+    grad_out = _need(grad_out, torch.float32, "grad_out")
+    N, L, C = coords.shape[0], len(feats_shapes), feats_shapes[0][1]
+    grads = [torch.zeros(tuple(sh), dtype=torch.float32, device=coords.device) for sh in feats_shapes]
+    garr, gptr = _ptr_array(grads)
+    larr, lptr = _host_i32(levels)
+    _check(lib.wisp_spc_trilinear_multi_bwd(_p(coords), _p(chain), chain.stride(0), _p(points), _p(trinkets), _p(grad_out), N, L,
+                                            lptr, C, int(sum_lods), gptr, _stream()), "spc_trilinear_multi_bwd")
+    return grads
 
 
 def codebook_trilinear_forward(coords, pidx, points, trinkets, logits, dictionary, level, training):

@@ -76,6 +76,13 @@ class OctreeGrid(BLASGrid):
         """Feature rows for corner indices (overridden by codebook grids)."""
         return feats[idx.long()]
 
+    def _fusable(self):
+        """The one-launch multi-level lookup covers plain trilinear feature tables (subclasses that re-index their
+        features, e.g. the codebook grid, keep the per-level path)."""
+        return (self.interpolation_type == 'linear' and type(self)._index_features is OctreeGrid._index_features
+                and type(self)._interpolate is OctreeGrid._interpolate and self.multiscale_type in ('cat', 'sum')
+                and len(self.active_lods) <= 16 and self.features[0].is_cuda)
+
     def _sync_device(self, device):
         if self.interpolation_type == 'linear' and self.trinkets.device != device:
             self.trinkets = self.trinkets.to(device)
@@ -106,6 +113,13 @@ class OctreeGrid(BLASGrid):
         num_feats = lod_idx + 1
         flat = coords.reshape(-1, 3)
         chain = self.blas.query(flat, self.active_lods[lod_idx], with_parents=True).pidx[..., self.base_lod:]
+        if self._fusable():
+            # all levels in one launch ('cat' row or the 'sum' written directly)
+            self._sync_device(flat.device)
+            feats = grid_ops.spc_interpolate_trilinear_multi(
+                flat, chain, self.blas.points, self.trinkets.int(), [self.features[i] for i in range(num_feats)],
+                self.active_lods[:num_feats], half_round=self.half_features, sum_lods=self.multiscale_type == 'sum')
+            return feats.reshape(*output_shape, feats.shape[-1])
         feats = [self._interpolate(flat.reshape(-1, 1, 3), self.features[i], chain[:, i].contiguous(), i)[:, 0]
                  for i in range(num_feats)]
         feats = torch.cat(feats, dim=-1)

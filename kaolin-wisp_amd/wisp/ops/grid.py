@@ -102,6 +102,33 @@ def spc_interpolate_trilinear(coords, pidx, points, trinkets, feats, level, half
     return SPCTrilinear.apply(coords.contiguous(), pidx, points, trinkets, feats, level, half_round)
 
 
+class SPCTrilinearMulti(torch.autograd.Function):
+    """Every active level of an OctreeGrid at once (octree_grid.py:183-219): per-level trilinear lookups written straight
+    into the concatenated row or summed, one launch forward and one backward."""
+
+    @staticmethod
+    def forward(ctx, coords, chain, points, trinkets, levels, half_round, sum_lods, *feats):
+        out = _hip().spc_trilinear_multi_forward(coords.detach(), chain, points, trinkets, [f.detach() for f in feats], levels,
+                                                 half_round, sum_lods)
+        ctx.save_for_backward(coords.detach(), chain, points, trinkets)
+        ctx.meta = ([tuple(f.shape) for f in feats], [f.dtype for f in feats], list(levels), sum_lods)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        coords, chain, points, trinkets = ctx.saved_tensors
+        shapes, dtypes, levels, sum_lods = ctx.meta
+        grads = _hip().spc_trilinear_multi_backward(coords, chain, points, trinkets, grad_out.contiguous().float(), shapes,
+                                                    levels, sum_lods)
+        return (None,) * 7 + tuple(g.to(dt) for g, dt in zip(grads, dtypes))
+
+
+def spc_interpolate_trilinear_multi(coords, chain, points, trinkets, feats, levels, half_round=False, sum_lods=False):
+    """coords [N,3], chain i64 [N, >= len(feats)] (voxel per level, -1 = outside) -> [N, L*C] or (sum_lods) [N, C]."""
+    return SPCTrilinearMulti.apply(coords.contiguous(), chain, points, trinkets, tuple(int(l) for l in levels), half_round,
+                                   sum_lods, *feats)
+
+
 def coords_to_trilinear_coeffs(coords, points, level):
     """coords [V,S,3] + the quantised voxel origin of every row ([V,3] or [V,S,3] repeated) -> [V,S,8]."""
     pts = points[:, 0] if points.ndim == 3 else points

@@ -643,9 +643,19 @@ def test_octree_grid_interpolate_matches_oracle(mtype, half):
     inside = (leaf[rng.integers(0, leaf.shape[0], 3000)] + rng.uniform(0, 1, (3000, 3))) / 32.0 * 2 - 1
     coords = np.concatenate([inside, rng.uniform(-1, 1, (3000, 3))]).astype(np.float32)
     for lod_idx in (3, 0):
-        out = grid.interpolate(cuda(coords), lod_idx)
+        out = grid.interpolate(cuda(coords), lod_idx)            # lod_idx > 0: the one-launch multi-level lookup
         w = torch.randn_like(out)
         grid.zero_grad(); (out * w).sum().backward()
+        if lod_idx > 0:
+            # ... which must agree with the per-level kernels it replaces
+            fused_grads = [f.grad.clone() for f in grid.features[:lod_idx + 1]]
+            grid._fusable = lambda: False
+            out_pl = grid.interpolate(cuda(coords), lod_idx)
+            grid.zero_grad(); (out_pl * w).sum().backward()
+            del grid._fusable
+            np.testing.assert_allclose(out.detach().cpu().numpy(), out_pl.detach().cpu().numpy(), atol=1e-6)
+            for i, g in enumerate(fused_grads):
+                np.testing.assert_allclose(g.cpu().numpy(), grid.features[i].grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
         feats_cpu = [f.detach().cpu().clone().requires_grad_(True) for f in grid.features]
         ref = og.octree_grid_interpolate(oblas, tr, feats_cpu, torch.from_numpy(coords), lod_idx, grid.base_lod,
                                          grid.active_lods, mtype, 16, half_round=half)
