@@ -432,7 +432,7 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
                 const uint32_t b = idx >> chunk_shift;
                 const uint32_t pos = atomicAdd(&rank_l[b], 1u);
                 if (pos < cap) {
-                    uint32_t* dst = rec_l + (size_t)((__umul24(b, bucket_stride) + slot0 + pos) * RW);   // 24-bit operands, < 2^32 dwords (bin_plan)
+                    uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos) * RW);   // < 2^32 dwords (bin_plan)
                     Codec::store(dst, idx, (1u << chunk_shift) - 1u, v[j]);
                 } else {                                  // slot full: fall back to the memory-side atomic
                     float* p = grad_codebook + (first_idx[l] + (int64_t)idx) * F;
@@ -660,8 +660,7 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         cap = lv.dense[l] ? cap * 4 : cap + cap / 2;
         if (cap < 128) cap = 128;
         if (cap > (int64_t)EM_TILE * corners) cap = (int64_t)EM_TILE * corners;
-        if (chunks > BIN_MAX_CHUNKS || entries > 0xffffffffLL || chunks * p.ntiles * cap * rec_dwords > 0xffffffffLL ||
-            p.ntiles * cap >= (1 << 24)) p.ok = false;
+        if (chunks > BIN_MAX_CHUNKS || entries > 0xffffffffLL || chunks * p.ntiles * cap * rec_dwords > 0xffffffffLL) p.ok = false;
         p.bins.chunks[li] = (int32_t)chunks;
         p.bins.cap[li] = (uint32_t)cap;
         p.bins.cnt_base[li] = cnt;
