@@ -10,14 +10,17 @@
 //     (slot 16 kb + 8 g + j  <->  neuron phi = 16 kb + 8 (j / 4) + 4 g + j % 4).  No LDS round trip, no shuffles.
 //   * relu is one v_pk_max_i16 per two values on the packed bf16; hidden biases enter as the MFMA C operand (free); the
 //     bias of the first colour layer rides on a constant-one slot of the view-encoding block.
-//   * backward recomputes the forward, keeps the packed activations in registers for the relu masks, back-propagates
-//     through the transposed (also column-permuted) weights with the same chaining, and forms dW = dY^T X with
+//   * backward (two wave roles per workgroup, see the comment at mlp_bwd_kernel): the chain wave recomputes the forward,
+//     keeps the packed activations in registers for the relu masks and back-propagates through the transposed (also
+//     column-permuted) weights with the same chaining; dW = dY^T X is formed by its partner wave with
 //     v_mfma_f32_16x16x32_bf16 whose K dimension is the tile's 32 samples.  For that both operands have to be
-//     transposed (samples from lanes to registers): the packed registers are written to a per-wave LDS image made of
+//     transposed (samples from lanes to registers): the packed registers are written to an LDS image made of
 //     8-byte chunks (sample, 4 features) and read back with ds_read_b64_tr_b16.  Chunk address =
 //     (fq >> 1) * 640 + (2 n + (fq & 1)) * 8 with fq = feature / 4: both the writes and the transposing reads are
-//     bank-conflict free.  dW accumulates in 180 VGPRs for the whole launch; per-wave partials are reduced afterwards.
-//   * bias gradients: one extra MFMA per 16 rows against a constant-ones operand (db3 comes with dW3's ones column).
+//     bank-conflict free.  dW accumulates in 180 VGPRs for the whole launch; one partial row per workgroup is reduced
+//     afterwards.
+//   * bias gradients: one extra MFMA per 16 neurons whose A operand is all ones in ONE row - all of them land in one
+//     shared 16x16 accumulator block (db3 comes with dW3's ones column).
 #include "wisp_common.h"
 #include "nerf_mlp_shape.h"
 #include <cstdlib>
@@ -28,8 +31,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
