@@ -136,9 +136,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         R = int(t.item())
 
+    # the loop hands the trainer the NEXT batch's rays as well (a one-batch look-ahead, like a prefetching data loader):
+    # their occupancy test is issued early and the next step does not stall on its sample-count read-back
+    rays, gts = batch(R)
     for _ in range(args.warmup):
-        rays, gts = batch(R)
-        trainer.step(rays, gts)
+        nrays, ngts = batch(R)
+        trainer.step(rays, gts, prefetch=nrays)
+        rays, gts = nrays, ngts
 
     C.TIMING = {}                                         # HIP-event timing of the hash-grid kernels, live
     if world > 1:
@@ -147,9 +151,10 @@ def main():
     t0 = time.perf_counter()
     total_samples = 0
     for _ in range(args.steps):
-        rays, gts = batch(R)
-        _, ns = trainer.step(rays, gts)
+        nrays, ngts = batch(R)
+        _, ns = trainer.step(rays, gts, prefetch=nrays)
         total_samples += ns
+        rays, gts = nrays, ngts
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -422,8 +422,10 @@ def _alloc_samples(S, dev):
             torch.empty(S, dtype=torch.bool, device=dev))
 
 
-def raymarch_ray(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level, jitter=None, seed=0):
-    """OctreeAS._raymarch_ray (octree_as.py:247-309).  Returns (ridx, samples, depth, deltas, boundary, ray_offsets)."""
+def raymarch_ray_count(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level, jitter=None, seed=0):
+    """First half of OctreeAS._raymarch_ray (octree_as.py:247-309): occupancy test of every candidate + per-ray offsets.
+    Needs no field parameters and no host read-back, so a trainer can issue it for the NEXT batch early.  Returns the state
+    raymarch_ray_finish() expands into packed samples."""
     origins = _need(origins, torch.float32, "origins").reshape(-1, 3)
     dirs = _need(dirs, torch.float32, "dirs").reshape(-1, 3)
     R, dev = origins.shape[0], origins.device
@@ -439,13 +441,28 @@ def raymarch_ray(occ_bits, octree, exsum, origins, dirs, near, far, num_samples,
                                        num_samples, level, _p(jitter), seed, _p(hitmask), _p(counts), _stream()),
            "raymarch_ray_count")
     offsets = exclusive_scan(counts)
-    S = int(offsets[-1].item())                      # the reference syncs here too (nonzero, octree_as.py:288)
+    return dict(origins=origins, dirs=dirs, near32=near32, range32=range32, num_samples=num_samples, jitter=jitter, seed=seed,
+                hitmask=hitmask, offsets=offsets)
+
+
+def raymarch_ray_finish(st):
+    """Second half: read the sample count back (the reference syncs here too: nonzero, octree_as.py:288), allocate and
+    emit.  Returns (ridx, samples, depth, deltas, boundary, ray_offsets)."""
+    origins, offsets = st["origins"], st["offsets"]
+    R, dev = origins.shape[0], origins.device
+    S = int(offsets[-1].item())
     ridx, samples, depth, deltas, boundary = _alloc_samples(S, dev)
     if S:
-        _check(lib.wisp_raymarch_ray_emit(_p(origins), _p(dirs), R, near32, range32, num_samples, _p(jitter), seed,
-                                          _p(hitmask), _p(offsets), _p(ridx), _p(samples), _p(depth), _p(deltas),
-                                          _p(boundary), _stream()), "raymarch_ray_emit")
+        _check(lib.wisp_raymarch_ray_emit(_p(origins), _p(st["dirs"]), R, st["near32"], st["range32"], st["num_samples"],
+                                          _p(st["jitter"]), st["seed"], _p(st["hitmask"]), _p(offsets), _p(ridx), _p(samples),
+                                          _p(depth), _p(deltas), _p(boundary), _stream()), "raymarch_ray_emit")
     return ridx, samples, depth, deltas, boundary, offsets
+
+
+def raymarch_ray(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level, jitter=None, seed=0):
+    """OctreeAS._raymarch_ray (octree_as.py:247-309).  Returns (ridx, samples, depth, deltas, boundary, ray_offsets)."""
+    return raymarch_ray_finish(raymarch_ray_count(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level,
+                                                  jitter, seed))
 
 
 def raymarch_voxel(origins, dirs, nug_ridx, nug_depth, num_samples, jitter=None, seed=0):

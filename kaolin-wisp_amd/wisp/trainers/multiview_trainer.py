@@ -112,23 +112,42 @@ class _DirectHashNeRFStep:
         # (reference hash_grid.py:226-229): the finest level's columns are zero, exactly as in the modular path
         self.zero_from_col = (grid.num_lods - 1) * grid.feature_dim
         self.ok = self.packed is not None and self.packed_grad is not None
+        self._pending = None
 
-    def run(self, rays, img_gts, jitter=None):
-        """-> (loss tensor, num_samples); gradients are left accumulated in the flat gradient buffer."""
+    def _count(self, rays, jitter, seed=None):
+        C = _hip()
+        pipe = self.t.pipeline
+        blas = pipe.nef.grid.blas
+        if torch.is_tensor(rays.dist_min) or torch.is_tensor(rays.dist_max):
+            raise TypeError("'ray' raymarch needs scalar Rays.dist_min / dist_max (as the reference, octree_as.py:276-277)")
+        blas._to_device(rays.origins.device)
+        level = blas.max_level
+        st = C.raymarch_ray_count(blas._bitfield(level), blas.octree, blas.prefix, rays.origins, rays.dirs, rays.dist_min,
+                                  rays.dist_max, pipe.tracer.num_steps, level, jitter,
+                                  blas._draw_seed() if seed is None else seed)
+        st["rays"], st["blas"] = rays, blas
+        return st
+
+    def run(self, rays, img_gts, jitter=None, prefetch=None):
+        """-> (loss tensor, num_samples); gradients are left accumulated in the flat gradient buffer.
+        `prefetch`: the Rays of the NEXT step; their parameter-free prefix (occupancy test + offsets) is issued now, behind
+        this step's own raymarch, so that the next step finds its sample count already computed instead of stalling the GPU
+        on the size read-back."""
         C = _hip()
         t = self.t
         pipe = t.pipeline
         nef, tracer = pipe.nef, pipe.tracer
         blas = nef.grid.blas
-        if torch.is_tensor(rays.dist_min) or torch.is_tensor(rays.dist_max):
-            raise TypeError("'ray' raymarch needs scalar Rays.dist_min / dist_max (as the reference, octree_as.py:276-277)")
         dev = rays.origins.device
-        blas._to_device(dev)
-        level = blas.max_level
         N = rays.origins.shape[0]
-        ridx, samples, depths, deltas, boundary, offsets = C.raymarch_ray(
-            blas._bitfield(level), blas.octree, blas.prefix, rays.origins, rays.dirs, rays.dist_min, rays.dist_max,
-            tracer.num_steps, level, jitter, blas._draw_seed())
+        st, self._pending = self._pending, None
+        if st is None or st["rays"] is not rays or jitter is not None:
+            st = self._count(rays, jitter)                # nothing was prefetched for this batch
+        elif st["blas"] is not blas:
+            st = self._count(rays, None, seed=st["seed"])  # the octree was pruned since: redo it (same jitter stream)
+        ridx, samples, depths, deltas, boundary, offsets = C.raymarch_ray_finish(st)
+        if prefetch is not None:
+            self._pending = self._count(prefetch, None)
         S = samples.shape[0]
         tracer.prev_num_samples = S
         dirs = rays.dirs.index_select(0, ridx)
@@ -273,13 +292,15 @@ class MultiviewTrainStep:
             return torch.nn.functional.smooth_l1_loss(rgb, gts, reduction='none').mean()
         raise NotImplementedError
 
-    def step(self, rays: Rays, img_gts, jitter=None):
-        """One optimisation step on this rank's ray shard.  Returns (loss tensor, num_samples)."""
+    def step(self, rays: Rays, img_gts, jitter=None, prefetch: Optional[Rays] = None):
+        """One optimisation step on this rank's ray shard.  Returns (loss tensor, num_samples).
+        `prefetch` (optional): the Rays object the NEXT call will be given - the direct-issue path then runs their
+        occupancy test early (a data-loader style look-ahead; results are the same with or without it)."""
         self.pre_step()
         self.total_iterations += 1
         if self._direct is not None and self.pipeline.nef.training:
             with torch.no_grad():
-                loss, _ = self._direct.run(rays, img_gts, jitter)
+                loss, _ = self._direct.run(rays, img_gts, jitter, prefetch)
         else:
             self.wait_for_parameters()
             kw = {} if jitter is None else {"jitter": jitter}

@@ -875,3 +875,35 @@ def test_rgb_loss_matches_torch_autograd(kind):
             loss, grad = _C().rgb_loss(rgb.detach(), gt, kind)
             assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
             np.testing.assert_allclose(grad.cpu().numpy(), rgb.grad.cpu().numpy(), rtol=1e-6, atol=1e-9)
+
+
+def test_step_with_prefetched_next_batch_is_the_same_step():
+    """The one-batch look-ahead of MultiviewTrainStep.step (next batch's occupancy test issued early) changes the issue order
+    only: same sample counts and the same loss trajectory as without it - also across a prune, which invalidates the
+    look-ahead (the octree it was computed against is gone)."""
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.tracers import PackedRFTracer
+    from wisp.trainers import MultiviewTrainStep
+    import copy
+    nef0, _, _ = _build_pair(lods=16)
+    batches = []
+    for k in range(6):
+        o, d = make_rays(600, 300 + k)
+        gts = cuda(np.random.default_rng(400 + k).uniform(size=(600, 3)).astype(np.float32))
+        batches.append((Rays(cuda(o), cuda(d), dist_min=1.0, dist_max=5.0), gts))
+    logs = []
+    for look_ahead in (False, True):
+        nef = copy.deepcopy(nef0)
+        tr = MultiviewTrainStep(Pipeline(nef, PackedRFTracer(raymarch_type='ray', num_steps=96, bg_color=(0, 0, 0))),
+                                prune_every=3, enable_amp=False)
+        assert tr._direct is not None
+        torch.manual_seed(11)                              # the in-kernel jitter seeds come from torch's CPU generator
+        log = []
+        for k, (rays, gts) in enumerate(batches):
+            nxt = batches[k + 1][0] if (look_ahead and k + 1 < len(batches)) else None
+            loss, ns = tr.step(rays, gts, prefetch=nxt)
+            log.append((ns, float(loss)))
+        logs.append(log)
+    for (n0, l0), (n1, l1) in zip(*logs):
+        assert n0 == n1 and abs(l0 - l1) <= 1e-4 * max(1.0, abs(l0))
