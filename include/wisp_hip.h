@@ -154,6 +154,17 @@ int wisp_spc_trilinear_multi_bwd(const float* coords, const int64_t* chain, int6
                                  const int32_t* levels, int channels, int sum, float* const* grad_feats,
                                  wisp_stream_t stream);
 
+/* TriplanarGrid.interpolate (wisp/models/grids/triplanar_grid.py:97-146, TriplanarFeatureVolume.forward :205-233): per
+ * level three bilinear plane lookups with torch.nn.functional.grid_sample semantics (align_corners=True, reflection
+ * padding) - plane x sampled at (y, z), plane y at (x, z), plane z at (x, y) - laid out [x | y | z] per level, then cat
+ * (sum = 0: out f32 [N, num_lods*3*feature_dim]) or sum (sum = 1: [N, 3*feature_dim]) over levels.
+ * planes / grad_planes: HOST arrays of num_lods*3 device pointers (x, y, z of level 0, then level 1, ...), each plane f32
+ * [feature_dim, size_l, size_l] as the reference stores it; sizes: HOST i32 [num_lods].  The backward accumulates. */
+int wisp_triplane_fwd(const float* coords, int64_t num_samples, const float* const* planes, const int32_t* sizes,
+                      int num_lods, int feature_dim, int sum, float* out, wisp_stream_t stream);
+int wisp_triplane_bwd(const float* coords, int64_t num_samples, const float* grad_out, const int32_t* sizes, int num_lods,
+                      int feature_dim, int sum, float* const* grad_planes, wisp_stream_t stream);
+
 /* VQAD codebook lookup fused with the trilinear blend (replaces CodebookOctreeGrid._index_features + _interpolate,
  * wisp/models/grids/codebook_grid.py:103-172): logits f32 [Fn, dict_size], dictionary f32 [dict_size, feature_dim]
  * (dict_size <= 256, feature_dim <= 16).  training != 0: straight-through softmax one-hot; else argmax lookup.

@@ -410,3 +410,108 @@ extern "C" int wisp_codebook_trilinear_bwd(const float* coords, const void* pidx
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- triplanar feature pyramid
+// TriplanarGrid.interpolate (wisp/models/grids/triplanar_grid.py:97-146) + TriplanarFeatureVolume.forward (:205-233): per
+// level three F.grid_sample(bilinear, align_corners=True, padding_mode='reflection') lookups - plane x with (y, z), plane
+// y with (x, z), plane z with (x, y); grid[..., 0] indexes the LAST (width) dimension - stacked as [x | y | z] features,
+// then cat / sum over levels.  One launch for all levels and planes; planes keep torch's [fdim, R, R] parameter layout.
+#define TRI_MAX_LODS 16
+struct TriPlanes { const float* fm[TRI_MAX_LODS * 3]; float* grad[TRI_MAX_LODS * 3]; int32_t size[TRI_MAX_LODS]; };
+
+// grid_sample's coordinate pipeline for align_corners=True + reflection padding: unnormalise, reflect into [0, size-1], clip
+static __device__ __forceinline__ float tri_source_index(float g, int size) {
+    float x = (g + 1.0f) * 0.5f * (float)(size - 1);
+    const float span = (float)(size - 1);
+    if (span <= 0.0f) return 0.0f;
+    x = fabsf(x);
+    const float flips = floorf(x / span);
+    const float extra = x - flips * span;                 // fmod(x, span)
+    x = (((int)flips) & 1) ? span - extra : extra;
+    return fminf(fmaxf(x, 0.0f), span);
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+triplane_kernel(const float* __restrict__ coords, int64_t n, TriPlanes tp, int num_lods, int fdim, int sum,
+                float* __restrict__ out, const float* __restrict__ grad_out) {
+    const int row = sum ? 3 * fdim : num_lods * 3 * fdim;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float c[3] = {coords[i * 3], coords[i * 3 + 1], coords[i * 3 + 2]};
+        if (!BWD && sum)
+            for (int k = 0; k < row; ++k) out[i * row + k] = 0.0f;
+        for (int l = 0; l < num_lods; ++l) {
+            const int R = tp.size[l];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const float gx = c[p == 0 ? 1 : 0];       // grid[..., 0] -> width:  x-plane y, y-plane x, z-plane x
+                const float gy = c[p == 2 ? 1 : 2];       // grid[..., 1] -> height: x-plane z, y-plane z, z-plane y
+                const float ix = tri_source_index(gx, R), iy = tri_source_index(gy, R);
+                const float fx = floorf(ix), fy = floorf(iy);
+                const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+                const float tx = ix - fx, ty = iy - fy;
+                const float w00 = (1.0f - tx) * (1.0f - ty), w01 = tx * (1.0f - ty), w10 = (1.0f - tx) * ty, w11 = tx * ty;
+                const bool vx1 = x1 < R, vy1 = y1 < R;    // grid_sample drops out-of-bounds corners (their weight is 0 here)
+                const int col = (sum ? 0 : l * 3 * fdim) + p * fdim;
+                for (int ch = 0; ch < fdim; ++ch) {
+                    const int64_t base = (int64_t)ch * R * R;
+                    if (!BWD) {
+                        const float* fm = tp.fm[l * 3 + p] + base;
+                        float v = fm[y0 * R + x0] * w00;
+                        if (vx1) v += fm[y0 * R + x1] * w01;
+                        if (vy1) v += fm[y1 * R + x0] * w10;
+                        if (vx1 && vy1) v += fm[y1 * R + x1] * w11;
+                        if (sum) out[i * row + col + ch] += v; else out[i * row + col + ch] = v;
+                    } else {
+                        float* gm = tp.grad[l * 3 + p] + base;
+                        const float g = grad_out[i * row + col + ch];
+                        atomicAdd(gm + y0 * R + x0, g * w00);
+                        if (vx1) atomicAdd(gm + y0 * R + x1, g * w01);
+                        if (vy1) atomicAdd(gm + y1 * R + x0, g * w10);
+                        if (vx1 && vy1) atomicAdd(gm + y1 * R + x1, g * w11);
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int fill_planes(TriPlanes& tp, const float* const* planes, float* const* grads, const int32_t* sizes, int num_lods) {
+    for (int k = 0; k < TRI_MAX_LODS * 3; ++k) { tp.fm[k] = nullptr; tp.grad[k] = nullptr; }
+    for (int l = 0; l < TRI_MAX_LODS; ++l) tp.size[l] = 1;
+    for (int l = 0; l < num_lods; ++l) {
+        if (sizes[l] < 1) return -1;
+        tp.size[l] = sizes[l];
+        for (int p = 0; p < 3; ++p) {
+            if (planes) { if (!planes[l * 3 + p]) return -1; tp.fm[l * 3 + p] = planes[l * 3 + p]; }
+            if (grads) { if (!grads[l * 3 + p]) return -1; tp.grad[l * 3 + p] = grads[l * 3 + p]; }
+        }
+    }
+    return 0;
+}
+
+extern "C" int wisp_triplane_fwd(const float* coords, int64_t num_samples, const float* const* planes, const int32_t* sizes,
+                                 int num_lods, int feature_dim, int sum, float* out, wisp_stream_t stream) {
+    WISP_REQUIRE(num_samples >= 0 && num_lods >= 1 && num_lods <= TRI_MAX_LODS && feature_dim >= 1, "bad sizes");
+    if (num_samples == 0) return WISP_OK;
+    WISP_REQUIRE(coords && planes && sizes && out, "null pointer");
+    TriPlanes tp;
+    WISP_REQUIRE(fill_planes(tp, planes, nullptr, sizes, num_lods) == 0, "bad plane size or null plane pointer");
+    hipLaunchKernelGGL(triplane_kernel<false>, dim3((unsigned)min64(ceil_div64(num_samples, 256), 16384)), dim3(256), 0,
+                       (hipStream_t)stream, coords, num_samples, tp, num_lods, feature_dim, sum, out, (const float*)nullptr);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_triplane_bwd(const float* coords, int64_t num_samples, const float* grad_out, const int32_t* sizes,
+                                 int num_lods, int feature_dim, int sum, float* const* grad_planes, wisp_stream_t stream) {
+    WISP_REQUIRE(num_samples >= 0 && num_lods >= 1 && num_lods <= TRI_MAX_LODS && feature_dim >= 1, "bad sizes");
+    if (num_samples == 0) return WISP_OK;
+    WISP_REQUIRE(coords && grad_out && sizes && grad_planes, "null pointer");
+    TriPlanes tp;
+    WISP_REQUIRE(fill_planes(tp, nullptr, grad_planes, sizes, num_lods) == 0, "bad plane size or null gradient pointer");
+    hipLaunchKernelGGL(triplane_kernel<true>, dim3((unsigned)min64(ceil_div64(num_samples, 256), 16384)), dim3(256), 0,
+                       (hipStream_t)stream, coords, num_samples, tp, num_lods, feature_dim, sum, (float*)nullptr, grad_out);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

@@ -42,6 +42,8 @@ SIGNATURES = {
     "wisp_spc_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_trilinear_multi_fwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_trilinear_multi_bwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp],
+    "wisp_triplane_fwd": [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
+    "wisp_triplane_bwd": [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_codebook_trilinear_fwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_codebook_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "wisp_mark_pack_boundaries_i64": [c_vp, c_i64, c_vp, c_vp],
@@ -381,6 +383,35 @@ def spc_trilinear_multi_backward(coords, chain, points, trinkets, grad_out, feat
     larr, lptr = _host_i32(levels)
     _check(lib.wisp_spc_trilinear_multi_bwd(_p(coords), _p(chain), chain.stride(0), _p(points), _p(trinkets), _p(grad_out), N, L,
                                             lptr, C, int(sum_lods), gptr, _stream()), "spc_trilinear_multi_bwd")
+    return grads
+
+
+def triplane_forward(coords, planes, sum_lods):
+    """TriplanarGrid lookup of all levels: coords [N,3], planes = [x0, y0, z0, x1, ...] each [1 or -, fdim, R, R] -> f32
+    [N, L*3*fdim] ('cat') or [N, 3*fdim] ('sum')."""
+    coords = _need(coords, torch.float32, "coords")
+    planes = [_need(p, torch.float32, "plane") for p in planes]
+    L = len(planes) // 3
+    fdim, sizes = planes[0].shape[-3], [int(planes[3 * l].shape[-1]) for l in range(L)]
+    assert len(planes) == 3 * L and all(p.shape[-3] == fdim and p.shape[-1] == p.shape[-2] for p in planes)
+    N = coords.shape[0]
+    out = torch.empty(N, (1 if sum_lods else L) * 3 * fdim, dtype=torch.float32, device=coords.device)
+    parr, pptr = _ptr_array(planes)
+    sarr, sptr = _host_i32(sizes)
+    _check(lib.wisp_triplane_fwd(_p(coords), N, pptr, sptr, L, fdim, int(sum_lods), _p(out), _stream()), "triplane_fwd")
+    return out
+
+
+def triplane_backward(coords, grad_out, plane_shapes, sum_lods):
+    coords = _need(coords, torch.float32, "coords")
+    grad_out = _need(grad_out, torch.float32, "grad_out")
+    L = len(plane_shapes) // 3
+    fdim, sizes = plane_shapes[0][-3], [int(plane_shapes[3 * l][-1]) for l in range(L)]
+    grads = [torch.zeros(tuple(sh), dtype=torch.float32, device=coords.device) for sh in plane_shapes]
+    garr, gptr = _ptr_array(grads)
+    sarr, sptr = _host_i32(sizes)
+    _check(lib.wisp_triplane_bwd(_p(coords), coords.shape[0], _p(grad_out), sptr, L, fdim, int(sum_lods), gptr, _stream()),
+           "triplane_bwd")
     return grads
 
 

@@ -907,3 +907,44 @@ def test_step_with_prefetched_next_batch_is_the_same_step():
         logs.append(log)
     for (n0, l0), (n1, l1) in zip(*logs):
         assert n0 == n1 and abs(l0 - l1) <= 1e-4 * max(1.0, abs(l0))
+
+
+@pytest.mark.parametrize("mtype", ["sum", "cat"])
+def test_triplanar_grid_matches_grid_sample(mtype):
+    """TriplanarGrid (one HIP launch for all levels and planes) against torch's CPU grid_sample, which is what the
+    reference calls: forward and plane gradients, coordinates slightly outside [-1, 1] included (reflection padding)."""
+    from oracle import triplanar as otri
+    from wisp.accelstructs import AxisAlignedBBoxAS
+    from wisp.models.grids import TriplanarGrid
+    torch.manual_seed(4)
+    grid = TriplanarGrid(AxisAlignedBBoxAS(), feature_dim=4, log_base_resolution=3, num_lods=3, multiscale_type=mtype,
+                         feature_std=0.5).to(DEV)
+    assert grid.feature_dim == 12 and [v.fmx.shape[-1] for v in grid.features] == [9, 17, 33]
+    rng = np.random.default_rng(5)
+    coords = np.concatenate([rng.uniform(-1, 1, (4000, 3)), rng.uniform(-1.3, 1.3, (500, 3)),
+                             np.array([[1, 1, 1], [-1, -1, -1], [1, -1, 0.0]])]).astype(np.float32)
+    for lod_idx in (2, 0):
+        out = grid.interpolate(cuda(coords), lod_idx)
+        w = torch.randn_like(out)
+        grid.zero_grad(); (out * w).sum().backward()
+        vols = [tuple(p.detach().cpu().clone().requires_grad_(True) for p in (v.fmx, v.fmy, v.fmz)) for v in grid.features]
+        ref = otri.interpolate(vols, torch.from_numpy(coords), lod_idx, mtype)
+        (ref * w.cpu()).sum().backward()
+        assert out.shape == ref.shape == (coords.shape[0], 12 if mtype == "sum" else 12 * (lod_idx + 1))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-6)
+        for i in range(lod_idx + 1):
+            for mine, theirs in zip((grid.features[i].fmx, grid.features[i].fmy, grid.features[i].fmz), vols[i]):
+                np.testing.assert_allclose(mine.grad.cpu().numpy(), theirs.grad.numpy(), rtol=1e-4, atol=1e-4)
+    # [batch, num_samples, 3] input, the per-level interface and the volume's own forward layout
+    c3 = cuda(coords[:60].reshape(15, 4, 3))
+    assert grid.interpolate(c3, 1).shape[:2] == (15, 4)
+    f1 = grid._interpolate(c3, grid.features[1], 1)
+    np.testing.assert_allclose(f1.reshape(60, -1).detach().cpu().numpy(),
+                               otri.volume_forward(*[p.detach().cpu() for p in (grid.features[1].fmx, grid.features[1].fmy,
+                                                                                   grid.features[1].fmz)],
+                                                   torch.from_numpy(coords[:60])).reshape(60, -1).numpy(), atol=2e-6)
+    assert grid.features[0](c3).shape == (15, 3, 4, 4) and grid.features[0](c3[:, 0]).shape == (15, 3, 4)
+    from wisp.core import Rays
+    o, d = make_rays(16, 9)
+    rm = grid.raymarch(Rays(cuda(o), cuda(d), 0.5, 6.0), 'voxel', 8)
+    assert rm.samples.shape[1] == 3 and rm.samples.shape[0] % 8 == 0
