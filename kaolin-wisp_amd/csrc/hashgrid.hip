@@ -29,6 +29,7 @@ template <int DIM>
 struct CornerSetup {
     int32_t idx[1 << DIM];
     float coef[1 << DIM];
+    int32_t cell[DIM];          // integer coordinates of corner 0
 };
 
 // Position / coefficient / index computation shared by forward and backward.
@@ -49,6 +50,7 @@ static __device__ __forceinline__ void corner_setup(const float* __restrict__ c,
         x = fmaxf(0.0f, fminf(hi, x));
         float p = floorf(x);
         pos[a] = (int32_t)p;
+        cs.cell[a] = pos[a];
         f[a] = x - p;
         g[a] = 1.0f - f[a];
     }
@@ -230,22 +232,21 @@ static __device__ __forceinline__ bool tail_compute(const float* c, bool live, i
 #pragma unroll
         for (int k = 0; k < F; ++k) v[j][k] = g[k] * cs.coef[j];
     if (!MERGE) return live;
-    // cell id = the (dense-style) linear index of corner 0; unique per cell for res^DIM < 2^31
-    int32_t key;
-    {
-        const float hi = (float)((double)(res - 1) - 1e-5);
-        int32_t lin = 0, mul = 1;
-#pragma unroll
-        for (int a = 0; a < DIM; ++a) {
-            float x = __builtin_fmaf(0.5f * (float)res, c[a], 0.5f * (float)res);     // same value as corner_setup
-            x = fmaxf(0.0f, fminf(hi, x));
-            lin += (int32_t)floorf(x) * mul;
-            mul *= res;
-        }
-        key = live ? lin : (-2 - lane);
-    }
-    const int32_t prevk = __shfl_up(key, 1, 64);
-    int f = (lane == 0 || key != prevk) ? 1 : 0;          // run-head flag
+    // Two samples belong to one run iff they sit in the same cell.  Only NEIGHBOURING lanes are ever compared, so the cell
+    // is carried as (x | y << 16, z) - exact for res <= 65536 (checked on the host), no integer multiplies.
+    int32_t key_xy = cs.cell[0], key_z = 0;
+    if (DIM > 1) key_xy |= cs.cell[1] << 16;
+    if (DIM > 2) key_z = cs.cell[2];
+    if (!live) key_z = -1 - lane;                          // never equal to a neighbour
+    // wave_shr:1 / wave_shl:1 DPP moves (lane 0 / lane 63 keep their own value; both are forced below).  All four are
+    // evaluated unconditionally: a cross-lane read under a short-circuited '&&' would run with a partial exec mask.
+    const int32_t prev_xy = __builtin_amdgcn_update_dpp(key_xy, key_xy, 0x138, 0xf, 0xf, false);
+    const int32_t prev_z = __builtin_amdgcn_update_dpp(key_z, key_z, 0x138, 0xf, 0xf, false);
+    const int32_t next_xy = __builtin_amdgcn_update_dpp(key_xy, key_xy, 0x130, 0xf, 0xf, false);
+    const int32_t next_z = __builtin_amdgcn_update_dpp(key_z, key_z, 0x130, 0xf, 0xf, false);
+    const bool same_as_prev = (key_xy == prev_xy) & (key_z == prev_z);
+    const bool same_as_next = (key_xy == next_xy) & (key_z == next_z);
+    int f = (lane == 0 || !same_as_prev) ? 1 : 0;          // run-head flag
     // Segmented inclusive scan on the VALU (DPP), no LDS traffic: four row_shr steps inside each 16-lane row, then the
     // row totals are carried across rows with row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3).  (v, f) pairs
     // combine as (v1,f1)+(v2,f2) = (f2 ? v2 : v1+v2, f1|f2), which is associative, so the row carries compose.
@@ -272,8 +273,7 @@ static __device__ __forceinline__ bool tail_compute(const float* c, bool live, i
     HG_SEG_STEP(0x142, 0xa, "row_bcast:15 row_mask:0xa bank_mask:0xf", (lane >> 4) & 1)      // rows 1 and 3
     HG_SEG_STEP(0x143, 0xc, "row_bcast:31 row_mask:0xc bank_mask:0xf", lane >= 32)           // rows 2 and 3
 #undef HG_SEG_STEP
-    const int32_t nextk = __shfl_down(key, 1, 64);
-    return live && (lane == 63 || key != nextk);          // run tail holds the run total
+    return live && (lane == 63 || !same_as_next);         // run tail holds the run total
 }
 
 // direct-atomic path: wave w of a workgroup handles level levels.lv[w] for a tile of 64 samples
@@ -417,7 +417,10 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
         const uint32_t cap = bins.cap[li];
         uint32_t* rank_l = s_rank + bins.rank_base[li];
         uint32_t* __restrict__ rec_l = records + (size_t)bins.rec_base[li] * RW;
-        const uint32_t bucket_stride = ntiles * cap, slot0 = blockIdx.x * cap;  // record offsets inside the level, 32-bit
+        // record offsets inside the level, 32-bit; kept opaque so that the address is ONE vector multiply per record
+        // (the compiler otherwise re-associates it into (b * ntiles + blockIdx) * cap: two quarter-rate multiplies)
+        const uint32_t bucket_stride = __builtin_amdgcn_readfirstlane(ntiles * cap);
+        const uint32_t slot0 = __builtin_amdgcn_readfirstlane(blockIdx.x * cap);
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             const int sl = (wave * GROUPS + g) * 64 + lane;
@@ -426,13 +429,17 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
             const bool issue = tail_compute<T, F, DIM, true>(c[g], live[g], l, res, dense, tsize, tsize_pow2 != 0, zero_from_col,
                                                              reinterpret_cast<const T*>(s_grad + sl * rowp + l * W), lane, cs, v);
             if (!issue) continue;
+            // Rank all corners first - eight independent LDS atomics in flight - and only then write: ranking and
+            // writing corner by corner put a full LDS round trip in front of every record.
+            uint32_t pos[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) pos[j] = atomicAdd(&rank_l[(uint32_t)cs.idx[j] >> chunk_shift], 1u);
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const uint32_t idx = (uint32_t)cs.idx[j];
                 const uint32_t b = idx >> chunk_shift;
-                const uint32_t pos = atomicAdd(&rank_l[b], 1u);
-                if (pos < cap) {
-                    uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos) * RW);   // < 2^32 dwords (bin_plan)
+                if (pos[j] < cap) {
+                    uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos[j]) * RW);   // < 2^32 dwords (bin_plan)
                     Codec::store(dst, idx, (1u << chunk_shift) - 1u, v[j]);
                 } else {                                  // slot full: fall back to the memory-side atomic
                     float* p = grad_codebook + (first_idx[l] + (int64_t)idx) * F;
@@ -690,13 +697,10 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
                       const HashLevels& lv, int num_lods, uint32_t tsize, int zero_from_col, float* grad_codebook,
                       void* workspace, int64_t workspace_bytes, hipStream_t s) {
     const int pow2 = (tsize & (tsize - 1)) == 0;
-    // the run merge keys cells by a 32-bit linear id: fall back to plain scatter for absurd resolutions / wide features
+    // the run merge carries 16 bits per cell coordinate (tail_compute); wide features would not fit the register budget
     bool merge = bwd_merge_enabled() && (F * (1 << DIM) <= 32);
-    for (int l = 0; l < num_lods; ++l) {
-        double cells = 1.0;
-        for (int a = 0; a < DIM; ++a) cells *= (double)lv.res[l];
-        if (cells >= 2147483648.0) merge = false;
-    }
+    for (int l = 0; l < num_lods; ++l)
+        if (lv.res[l] > 65536) merge = false;
     LevelList active{0, {0}};
     for (int l = 0; l < num_lods; ++l)
         if (l * F < zero_from_col) active.lv[active.n++] = l;

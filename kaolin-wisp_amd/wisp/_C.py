@@ -13,7 +13,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libwisp_hip.so"))
+# WISP_HIP_LIB points at another build of the same C ABI (an installed copy, or an A/B variant while tuning kernels)
+LIB_PATH = os.environ.get("WISP_HIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "csrc", "libwisp_hip.so"))
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -120,11 +120,13 @@ def test_hashgrid_backward_slot_overflow_falls_back_to_atomics():
 
 
 @pytest.mark.parametrize("dim,F,bitwidth,res", [(2, 2, 14, [16, 40, 101, 256, 512]), (3, 4, 15, [8, 20, 50, 128]),
-                                                (3, 8, 14, [8, 32, 64])])
+                                                (3, 8, 14, [8, 32, 64]),
+                                                (3, 2, 19, [16, 64, 300, 1024, 2048, 8192])])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_hashgrid_backward_other_shapes(dim, F, bitwidth, res, dtype):
-    """Binned backward away from the flagship shape: 2-D coordinates (image fit), 4 features (generic record form) and
-    8 features (gradient rows too wide for the LDS staging: the launcher must pick the atomic path by itself)."""
+    """Binned backward away from the flagship shape: 2-D coordinates (image fit), 4 features (generic record form),
+    8 features (gradient rows too wide for the LDS staging: the launcher must pick the atomic path by itself) and
+    resolutions whose cell count exceeds 32 bits (instant-ngp's max_res 2048 and beyond: the run key is per axis)."""
     rng = np.random.default_rng(21 + dim + F)
     _, begin = ohash.table_layout(res, 2 ** bitwidth, coord_dim=dim)
     shape = (int(begin[-1]), F)
