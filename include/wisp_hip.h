@@ -292,7 +292,9 @@ int wisp_generate_rays(const float* pixel_x, const float* pixel_y, int64_t num_p
  * features -> cat positional-encoded view dir (wisp/models/embedders/positional_embedder.py:51-66)
  * -> decoder_color (Linear-ReLU x2, Linear) -> sigmoid)
  *
- *  feats   dtype_io [S, in_dim]          (in_dim <= 64)
+ *  feats   dtype_io [S, in_dim], rows packed (stride in_dim).  This build: 1 <= in_dim <= 32, hidden = 64,
+ *          view_freqs = 4 - the decoders of every app/nerf config (in_dim 32 nerf_hash, 5 nerf_octree /
+ *          nerf_codebook, 12 nerf_triplanar); other shapes return WISP_ERR_UNSUPPORTED
  *  dirs    f32 [S,3]
  *  params  f32 packed, layout given by wisp_nerf_mlp_param_count(): W1[hid,in], b1[hid], W2[16,hid],
  *          b2[16], W3[hid, 15+pe], b3[hid], W4[hid,hid], b4[hid], W5[3,hid], b5[3]   (row-major

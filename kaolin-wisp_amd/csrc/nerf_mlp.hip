@@ -128,7 +128,7 @@ template <> __device__ __forceinline__ __hip_bfloat16 io_from_f<__hip_bfloat16>(
 // ------------------------------------------------------------------------------------------------ the kernel
 template <typename TC, typename TIO, int WAVES, bool BWD>
 __global__ void __launch_bounds__(WAVES * 64, 1)
-nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples,
+nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples, int in_dim,
                 const float* __restrict__ params, float* __restrict__ out_rgb, float* __restrict__ out_density,
                 const float* __restrict__ grad_rgb, const float* __restrict__ grad_density,
                 TIO* __restrict__ grad_feats, float* __restrict__ partials) {
@@ -147,16 +147,16 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
     for (int e = threadIdx.x; e < G::WEND; e += WAVES * 64) sw[e] = Tr::from_f(0.0f);
     for (int e = threadIdx.x; e < G::NBIAS; e += WAVES * 64) sb[e] = 0.0f;
     __syncthreads();
-    for (int e = threadIdx.x; e < H * IN; e += WAVES * 64) sw[G::W1 + (e / IN) * G::LDI + e % IN] = Tr::from_f(params[OW1 + e]);
-    for (int e = threadIdx.x; e < 16 * H; e += WAVES * 64) sw[G::W2 + (e / H) * G::LDH + e % H] = Tr::from_f(params[OW2 + e]);
-    for (int e = threadIdx.x; e < H * X2; e += WAVES * 64) sw[G::W3 + (e / X2) * G::LDH + e % X2] = Tr::from_f(params[OW3 + e]);
-    for (int e = threadIdx.x; e < H * H; e += WAVES * 64) sw[G::W4 + (e / H) * G::LDH + e % H] = Tr::from_f(params[OW4 + e]);
-    for (int e = threadIdx.x; e < 3 * H; e += WAVES * 64) sw[G::W5 + (e / H) * G::LDH + e % H] = Tr::from_f(params[OW5 + e]);
+    for (int e = threadIdx.x; e < H * IN; e += WAVES * 64) sw[G::W1 + (e / IN) * G::LDI + e % IN] = Tr::from_f(packed_param(params, OW1 + e, in_dim));
+    for (int e = threadIdx.x; e < 16 * H; e += WAVES * 64) sw[G::W2 + (e / H) * G::LDH + e % H] = Tr::from_f(packed_param(params, OW2 + e, in_dim));
+    for (int e = threadIdx.x; e < H * X2; e += WAVES * 64) sw[G::W3 + (e / X2) * G::LDH + e % X2] = Tr::from_f(packed_param(params, OW3 + e, in_dim));
+    for (int e = threadIdx.x; e < H * H; e += WAVES * 64) sw[G::W4 + (e / H) * G::LDH + e % H] = Tr::from_f(packed_param(params, OW4 + e, in_dim));
+    for (int e = threadIdx.x; e < 3 * H; e += WAVES * 64) sw[G::W5 + (e / H) * G::LDH + e % H] = Tr::from_f(packed_param(params, OW5 + e, in_dim));
     for (int e = threadIdx.x; e < H; e += WAVES * 64) {
-        sb[G::B1 + e] = params[OB1 + e]; sb[G::B3 + e] = params[OB3 + e]; sb[G::B4 + e] = params[OB4 + e];
+        sb[G::B1 + e] = packed_param(params, OB1 + e, in_dim); sb[G::B3 + e] = packed_param(params, OB3 + e, in_dim); sb[G::B4 + e] = packed_param(params, OB4 + e, in_dim);
     }
-    if (threadIdx.x < 16) sb[G::B2 + threadIdx.x] = params[OB2 + threadIdx.x];
-    if (threadIdx.x < 3) sb[G::B5 + threadIdx.x] = params[OB5 + threadIdx.x];
+    if (threadIdx.x < 16) sb[G::B2 + threadIdx.x] = packed_param(params, OB2 + threadIdx.x, in_dim);
+    if (threadIdx.x < 3) sb[G::B5 + threadIdx.x] = packed_param(params, OB5 + threadIdx.x, in_dim);
     __syncthreads();
 
     TC* x0 = act + G::A_X0; TC* h1 = act + G::A_H1; TC* x2 = act + G::A_X2; TC* h2 = act + G::A_H2; TC* h3 = act + G::A_H3;
@@ -181,11 +181,14 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
         // ---- load the input tile: lane (n, half) copies 16 of the 32 features of sample n (vector loads)
         {
             TIO buf[16];
-            if (live) {
+            if (live && in_dim == IN) {
                 const uint4* src = reinterpret_cast<const uint4*>(feats + s * IN + half * 16);
                 uint4* dstv = reinterpret_cast<uint4*>(buf);
 #pragma unroll
                 for (int q = 0; q < (int)(16 * sizeof(TIO) / 16); ++q) dstv[q] = src[q];
+            } else if (live) {                      // narrow rows: in_dim elements, no alignment, zero padded
+#pragma unroll
+                for (int k = 0; k < 16; ++k) buf[k] = half * 16 + k < in_dim ? feats[s * in_dim + half * 16 + k] : io_from_f<TIO>(0.0f);
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) x0[n * G::LDI + half * 16 + k] = Tr::from_f(live ? io_to_f<TIO>(buf[k]) : 0.0f);
@@ -362,7 +365,8 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
             MMA<TC>::template tn<H>(sw + G::W1, G::LDI, 0, dya, G::LDH, acc, lane);
             if (live) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) grad_feats[s * IN + acc_row(r, lane)] = io_from_f<TIO>(acc[r]);
+                for (int r = 0; r < 16; ++r)
+                    if (acc_row(r, lane) < in_dim) grad_feats[s * in_dim + acc_row(r, lane)] = io_from_f<TIO>(acc[r]);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -396,9 +400,10 @@ nerf_mlp_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
     }
 }
 
-// grad_params[j] += sum over partial rows.  Block = 64 parameters x 16 row groups (row-strided partial sums, then LDS).
+// grad_params[packed(j)] += sum over partial rows (rows are in canonical order, nerf_mlp_shape.h).
+// Block = 64 parameters x 16 row groups (row-strided partial sums, then LDS).
 __global__ void __launch_bounds__(1024)
-nerf_mlp_reduce_kernel(const float* __restrict__ partials, int rows, float* __restrict__ grad_params) {
+nerf_mlp_reduce_kernel(const float* __restrict__ partials, int rows, int in_dim, float* __restrict__ grad_params) {
     __shared__ float s[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + tx;
@@ -411,7 +416,8 @@ nerf_mlp_reduce_kernel(const float* __restrict__ partials, int rows, float* __re
         float t = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += s[k][tx];
-        grad_params[j] += t;
+        const int dst = packed_index(j, in_dim);
+        if (dst >= 0) grad_params[dst] += t;
     }
 }
 
@@ -421,7 +427,7 @@ int cu_count() {
 }
 
 template <typename TC, typename TIO, int WAVES, bool BWD>
-int launch(const void* feats, const float* dirs, int64_t s_total, const float* params, float* rgb, float* density,
+int launch(const void* feats, const float* dirs, int64_t s_total, int in_dim, const float* params, float* rgb, float* density,
            const float* grad_rgb, const float* grad_density, void* grad_feats, float* grad_params, float* workspace,
            hipStream_t st) {
     const size_t lds = lds_bytes<TC>(WAVES, BWD);
@@ -430,31 +436,31 @@ int launch(const void* feats, const float* dirs, int64_t s_total, const float* p
     if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp", hipGetErrorString(e));
     const int64_t ntiles = (s_total + TS - 1) / TS;
     int grid = (int)min64(ceil_div64(ntiles, WAVES), cu_count());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, (const TIO*)feats, dirs, s_total, params, rgb, density,
-                       grad_rgb, grad_density, (TIO*)grad_feats, workspace);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, (const TIO*)feats, dirs, s_total, in_dim, params, rgb,
+                       density, grad_rgb, grad_density, (TIO*)grad_feats, workspace);
     if (BWD)
         hipLaunchKernelGGL(nerf_mlp_reduce_kernel, dim3((NPARAM + 63) / 64), dim3(1024), 0, st, workspace, grid * WAVES,
-                           grad_params);
+                           in_dim, grad_params);
     return 0;
 }
 
 template <bool BWD>
-int dispatch(const void* feats, int dtype_io, const float* dirs, int64_t s_total, const float* params, int compute,
+int dispatch(const void* feats, int dtype_io, const float* dirs, int64_t s_total, int in_dim, const float* params, int compute,
              float* rgb, float* density, const float* grad_rgb, const float* grad_density, void* grad_feats,
              float* grad_params, float* workspace, hipStream_t st) {
 #define WISP_MLP_GO(TC, W)                                                                                             \
     switch (dtype_io) {                                                                                                \
-        case WISP_F32: return launch<TC, float, W, BWD>(feats, dirs, s_total, params, rgb, density, grad_rgb, grad_density, grad_feats, grad_params, workspace, st); \
-        case WISP_F16: return launch<TC, __half, W, BWD>(feats, dirs, s_total, params, rgb, density, grad_rgb, grad_density, grad_feats, grad_params, workspace, st); \
-        default: return launch<TC, __hip_bfloat16, W, BWD>(feats, dirs, s_total, params, rgb, density, grad_rgb, grad_density, grad_feats, grad_params, workspace, st); \
+        case WISP_F32: return launch<TC, float, W, BWD>(feats, dirs, s_total, in_dim, params, rgb, density, grad_rgb, grad_density, grad_feats, grad_params, workspace, st); \
+        case WISP_F16: return launch<TC, __half, W, BWD>(feats, dirs, s_total, in_dim, params, rgb, density, grad_rgb, grad_density, grad_feats, grad_params, workspace, st); \
+        default: return launch<TC, __hip_bfloat16, W, BWD>(feats, dirs, s_total, in_dim, params, rgb, density, grad_rgb, grad_density, grad_feats, grad_params, workspace, st); \
     }
     if (compute == WISP_BF16) {                      // register-chained matrix-core kernels, nerf_mlp_bf16.hip
-        if (!BWD) return wisp_mlp::bf16_forward(feats, dtype_io, dirs, s_total, params, rgb, density, st);
+        if (!BWD) return wisp_mlp::bf16_forward(feats, dtype_io, dirs, s_total, in_dim, params, rgb, density, st);
         int rows = 0;
-        if (int rc = wisp_mlp::bf16_backward(feats, dtype_io, dirs, s_total, params, grad_rgb, grad_density, grad_feats,
+        if (int rc = wisp_mlp::bf16_backward(feats, dtype_io, dirs, s_total, in_dim, params, grad_rgb, grad_density, grad_feats,
                                              workspace, &rows, st))
             return rc;
-        hipLaunchKernelGGL(nerf_mlp_reduce_kernel, dim3((NPARAM + 63) / 64), dim3(1024), 0, st, workspace, rows, grad_params);
+        hipLaunchKernelGGL(nerf_mlp_reduce_kernel, dim3((NPARAM + 63) / 64), dim3(1024), 0, st, workspace, rows, in_dim, grad_params);
         return 0;
     }
     if (BWD) { WISP_MLP_GO(float, 1) }
@@ -473,8 +479,8 @@ extern "C" int64_t wisp_nerf_mlp_param_count(int in_dim, int hidden, int view_fr
 extern "C" int64_t wisp_nerf_mlp_workspace_floats(void) { return (int64_t)cu_count() * 4 * NPARAM_PAD; }
 
 static int check_shape(int in_dim, int hidden, int view_freqs, int dtype_io, int compute) {
-    if (in_dim != IN || hidden != H || view_freqs != NF)
-        return wisp_fail(WISP_ERR_UNSUPPORTED, "nerf_mlp", "this build supports in_dim=32, hidden=64, view_freqs=4");
+    if (in_dim < 1 || in_dim > IN || hidden != H || view_freqs != NF)
+        return wisp_fail(WISP_ERR_UNSUPPORTED, "nerf_mlp", "this build supports 1 <= in_dim <= 32, hidden=64, view_freqs=4");
     if (dtype_io != WISP_F32 && dtype_io != WISP_F16 && dtype_io != WISP_BF16) return wisp_fail(WISP_ERR_INVALID, "nerf_mlp", "bad dtype_io");
     if (compute != WISP_F32 && compute != WISP_BF16) return wisp_fail(WISP_ERR_INVALID, "nerf_mlp", "compute must be f32 or bf16");
     return 0;
@@ -487,7 +493,7 @@ extern "C" int wisp_nerf_mlp_fwd(const void* feats, int dtype_io, const float* d
     if (int rc = check_shape(in_dim, hidden, view_freqs, dtype_io, compute_dtype)) return rc;
     if (num_samples == 0) return WISP_OK;
     WISP_REQUIRE(feats && dirs && params && rgb && density, "null pointer");
-    if (int rc = dispatch<false>(feats, dtype_io, dirs, num_samples, params, compute_dtype, rgb, density, nullptr, nullptr,
+    if (int rc = dispatch<false>(feats, dtype_io, dirs, num_samples, in_dim, params, compute_dtype, rgb, density, nullptr, nullptr,
                                  nullptr, nullptr, nullptr, (hipStream_t)stream))
         return rc;
     WISP_CHECK_LAUNCH();
@@ -502,7 +508,7 @@ extern "C" int wisp_nerf_mlp_bwd(const void* feats, int dtype_io, const float* d
     if (int rc = check_shape(in_dim, hidden, view_freqs, dtype_io, compute_dtype)) return rc;
     if (num_samples == 0) return WISP_OK;
     WISP_REQUIRE(feats && dirs && params && grad_rgb && grad_density && grad_feats && grad_params && workspace, "null pointer");
-    if (int rc = dispatch<true>(feats, dtype_io, dirs, num_samples, params, compute_dtype, nullptr, nullptr, grad_rgb,
+    if (int rc = dispatch<true>(feats, dtype_io, dirs, num_samples, in_dim, params, compute_dtype, nullptr, nullptr, grad_rgb,
                                 grad_density, grad_feats, grad_params, workspace, (hipStream_t)stream))
         return rc;
     WISP_CHECK_LAUNCH();

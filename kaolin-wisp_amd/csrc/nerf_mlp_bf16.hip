@@ -69,11 +69,11 @@ constexpr int ONES_SLOT = 16 + PE;          // = 43: feature index (within the 4
 // Prologue: the packed fp32 parameters are first copied to an LDS staging area with coalesced loads (one global
 // round trip), then scattered into the permuted bf16 operand images from there.
 template <int THREADS>
-DEV void stage_params(float* stg, const float* __restrict__ P, int tid) {
+DEV void stage_params(float* stg, const float* __restrict__ P, int tid, int in_dim) {
     constexpr int PER = (NPARAM + THREADS - 1) / THREADS;
     float v[PER];                                    // all loads in flight before the first LDS write
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { const int e = tid + k * THREADS; v[k] = e < NPARAM ? P[e] : 0.0f; }
+    for (int k = 0; k < PER; ++k) { const int e = tid + k * THREADS; v[k] = e < NPARAM ? packed_param(P, e, in_dim) : 0.0f; }
 #pragma unroll
     for (int k = 0; k < PER; ++k) { const int e = tid + k * THREADS; if (e < NPARAM) stg[e] = v[k]; }
 }
@@ -174,6 +174,20 @@ template <typename TIO> DEV bf16x8 load_feats8(const TIO* p, bool live) {
     if (sizeof(TIO) == 2 && !__is_same(TIO, __half)) return *reinterpret_cast<const bf16x8*>(p);
     _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = (__bf16)io_to_f<TIO>(p[j]);
     return v;
+}
+// in_dim < 32: rows are in_dim elements long and carry no alignment; columns >= in_dim read as zero / are not written
+template <typename TIO> DEV bf16x8 load_feats8_narrow(const TIO* row, int col0, int in_dim, bool live) {
+    bf16x8 v;
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = (__bf16)((live && col0 + j < in_dim) ? io_to_f<TIO>(row[col0 + j]) : 0.0f);
+    return v;
+}
+template <typename T> DEV T io_from_f(float v);
+template <> __device__ __forceinline__ float io_from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half io_from_f<__half>(float v) { return __float2half_rn(v); }
+template <> __device__ __forceinline__ __hip_bfloat16 io_from_f<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+template <typename TIO> DEV void store_grad4_narrow(TIO* row, int col0, int in_dim, float a, float b, float c, float d) {
+    const float v[4] = {a, b, c, d};
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) if (col0 + j < in_dim) row[col0 + j] = io_from_f<TIO>(v[j]);
 }
 template <typename TIO> DEV void store_grad4(TIO* p, float a, float b, float c, float d) {
     if (sizeof(TIO) == 2 && !__is_same(TIO, __half)) {
@@ -311,25 +325,30 @@ DEV void forward_tile(const LaneConst& L, const float d[3], Acts& A) {
     }
 }
 
-template <typename TIO>
-DEV void fetch_inputs(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t s, bool live, int g, bf16x8 x0[2],
-                      float d[3]) {
-    x0[0] = load_feats8<TIO>(feats + s * IN + 8 * g, live);
-    x0[1] = load_feats8<TIO>(feats + s * IN + 16 + 8 * g, live);
+template <typename TIO, bool NARROW>
+DEV void fetch_inputs(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t s, bool live, int g, int in_dim,
+                      bf16x8 x0[2], float d[3]) {
+    if (NARROW) {
+        x0[0] = load_feats8_narrow<TIO>(feats + s * in_dim, 8 * g, in_dim, live);
+        x0[1] = load_feats8_narrow<TIO>(feats + s * in_dim, 16 + 8 * g, in_dim, live);
+    } else {
+        x0[0] = load_feats8<TIO>(feats + s * IN + 8 * g, live);
+        x0[1] = load_feats8<TIO>(feats + s * IN + 16 + 8 * g, live);
+    }
     d[0] = live ? dirs[s * 3] : 0.0f; d[1] = live ? dirs[s * 3 + 1] : 0.0f; d[2] = live ? dirs[s * 3 + 2] : 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------- forward kernel
 constexpr int FWD_WAVES = 8;
 
-template <typename TIO>
+template <typename TIO, bool NARROW>
 __global__ void __launch_bounds__(FWD_WAVES * 64)
-mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples,
+mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples, int in_dim,
                const float* __restrict__ params, float* __restrict__ out_rgb, float* __restrict__ out_density) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16* sw = reinterpret_cast<__bf16*>(smem);
     float* stg = reinterpret_cast<float*>(smem + (size_t)L_FWD_END * 2);
-    stage_params<FWD_WAVES * 64>(stg, params, threadIdx.x);
+    stage_params<FWD_WAVES * 64>(stg, params, threadIdx.x, NARROW ? in_dim : IN);
     __syncthreads();
     stage_weights<false>(sw, stg, threadIdx.x, FWD_WAVES * 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -342,7 +361,7 @@ mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
     int64_t tile = (int64_t)blockIdx.x * FWD_WAVES + wave;
     Acts A;
     float d[3];
-    if (tile < ntiles) fetch_inputs<TIO>(feats, dirs, tile * TS + L.n, tile * TS + L.n < num_samples, L.g, A.x0, d);
+    if (tile < ntiles) fetch_inputs<TIO, NARROW>(feats, dirs, tile * TS + L.n, tile * TS + L.n < num_samples, L.g, in_dim, A.x0, d);
     for (; tile < ntiles; tile += stride) {
         const int64_t s = tile * TS + L.n;
         const bool live = s < num_samples;
@@ -351,7 +370,7 @@ mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
         float nd[3];
         const int64_t ns = (tile + stride) * TS + L.n;
         const bool more = tile + stride < ntiles;
-        if (more) fetch_inputs<TIO>(feats, dirs, ns, ns < num_samples, L.g, nx0, nd);
+        if (more) fetch_inputs<TIO, NARROW>(feats, dirs, ns, ns < num_samples, L.g, in_dim, nx0, nd);
         forward_tile<false>(L, d, A);
         if (L.g == 0 && live) {
             out_density[s] = fmaxf(A.y0, 0.0f);
@@ -474,9 +493,9 @@ DEV void accumulate_stage(const unsigned char* imgY, const unsigned char* imgX, 
     }
 }
 
-template <typename TIO>
+template <typename TIO, bool NARROW>
 __global__ void __launch_bounds__(BWD_THREADS)
-mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples,
+mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples, int in_dim,
                const float* __restrict__ params, const float* __restrict__ grad_rgb, const float* __restrict__ grad_density,
                TIO* __restrict__ grad_feats, float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -484,7 +503,7 @@ mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
     float* biasv = reinterpret_cast<float*>(smem + BWD_OFF_BIASV);
     int* flags = reinterpret_cast<int*>(smem + BWD_OFF_FLAGS);              // ready[4], done[4]
     float* stg = reinterpret_cast<float*>(smem + BWD_OFF_IMG);              // aliases the images
-    stage_params<BWD_THREADS>(stg, params, threadIdx.x);
+    stage_params<BWD_THREADS>(stg, params, threadIdx.x, NARROW ? in_dim : IN);
     if (threadIdx.x < 16) flags[threadIdx.x] = 0;
     __syncthreads();
     stage_weights<true>(sw, stg, threadIdx.x, BWD_THREADS);
@@ -515,7 +534,7 @@ mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
         const int wc_off = (2 * n + g) * 8, wn_off = g * TILE_REGION + n * 16;
         Acts A;
         float d[3];
-        if (tile < ntiles) fetch_inputs<TIO>(feats, dirs, tile * TS + n, tile * TS + n < num_samples, g, A.x0, d);
+        if (tile < ntiles) fetch_inputs<TIO, NARROW>(feats, dirs, tile * TS + n, tile * TS + n < num_samples, g, in_dim, A.x0, d);
         for (; tile < ntiles; tile += stride) {
             const int64_t s = tile * TS + n;
             const bool live = s < num_samples;
@@ -525,7 +544,7 @@ mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
             float nd[3];
             const int64_t ns = (tile + stride) * TS + n;
             const bool more = tile + stride < ntiles;
-            if (more) fetch_inputs<TIO>(feats, dirs, ns, ns < num_samples, g, nx0, nd);
+            if (more) fetch_inputs<TIO, NARROW>(feats, dirs, ns, ns < num_samples, g, in_dim, nx0, nd);
 
             forward_tile<true>(L, d, A);
 
@@ -611,8 +630,12 @@ mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
                 const floatx16 acc = back_block<4>(w1t, dh1);
                 if (live) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        store_grad4<TIO>(grad_feats + s * IN + 8 * q + 4 * g, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                    for (int q = 0; q < 4; ++q) {
+                        if (NARROW)
+                            store_grad4_narrow<TIO>(grad_feats + s * in_dim, 8 * q + 4 * g, in_dim, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                        else
+                            store_grad4<TIO>(grad_feats + s * IN + 8 * q + 4 * g, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                    }
                 }
             }
             if (more) { A.x0[0] = nx0[0]; A.x0[1] = nx0[1]; d[0] = nd[0]; d[1] = nd[1]; d[2] = nd[2]; }
@@ -656,28 +679,29 @@ int cu_count() {
     return n;
 }
 
-template <typename TIO>
-int launch_fwd(const void* feats, const float* dirs, int64_t S, const float* params, float* rgb, float* density, hipStream_t st) {
+template <typename TIO, bool NARROW>
+int launch_fwd(const void* feats, const float* dirs, int64_t S, int in_dim, const float* params, float* rgb, float* density,
+               hipStream_t st) {
     const size_t lds = (size_t)L_FWD_END * 2 + (size_t)NPARAM_PAD * 4;
-    auto kern = mlp_fwd_kernel<TIO>;
+    auto kern = mlp_fwd_kernel<TIO, NARROW>;
     static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
     const int64_t ntiles = (S + TS - 1) / TS;
     const int grid = (int)min64(ceil_div64(ntiles, FWD_WAVES), cu_count());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, S, params, rgb, density);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, S, in_dim, params, rgb, density);
     return 0;
 }
 
-template <typename TIO>
-int launch_bwd(const void* feats, const float* dirs, int64_t S, const float* params, const float* grad_rgb,
+template <typename TIO, bool NARROW>
+int launch_bwd(const void* feats, const float* dirs, int64_t S, int in_dim, const float* params, const float* grad_rgb,
                const float* grad_density, void* grad_feats, float* partials, int* partial_rows, hipStream_t st) {
     const size_t lds = BWD_LDS;
-    auto kern = mlp_bwd_kernel<TIO>;
+    auto kern = mlp_bwd_kernel<TIO, NARROW>;
     static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
     const int64_t ntiles = (S + TS - 1) / TS;
     const int grid = (int)min64(ceil_div64(ntiles, BWD_PAIRS), cu_count());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), lds, st, (const TIO*)feats, dirs, S, params, grad_rgb,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), lds, st, (const TIO*)feats, dirs, S, in_dim, params, grad_rgb,
                        grad_density, (TIO*)grad_feats, partials);
     *partial_rows = grid;
     return 0;
@@ -687,22 +711,28 @@ int launch_bwd(const void* feats, const float* dirs, int64_t S, const float* par
 
 namespace wisp_mlp {
 
-int bf16_forward(const void* feats, int dtype_io, const float* dirs, int64_t S, const float* params, float* rgb,
-                 float* density, hipStream_t st) {
-    switch (dtype_io) {
-        case WISP_F32: return launch_fwd<float>(feats, dirs, S, params, rgb, density, st);
-        case WISP_F16: return launch_fwd<__half>(feats, dirs, S, params, rgb, density, st);
-        default: return launch_fwd<__hip_bfloat16>(feats, dirs, S, params, rgb, density, st);
+#define WISP_MLP_IO(FN, ...)                                                                        \
+    if (in_dim == IN) switch (dtype_io) {                                                           \
+        case WISP_F32: return FN<float, false>(__VA_ARGS__);                                        \
+        case WISP_F16: return FN<__half, false>(__VA_ARGS__);                                       \
+        default: return FN<__hip_bfloat16, false>(__VA_ARGS__);                                     \
+    }                                                                                               \
+    switch (dtype_io) {                                                                             \
+        case WISP_F32: return FN<float, true>(__VA_ARGS__);                                         \
+        case WISP_F16: return FN<__half, true>(__VA_ARGS__);                                        \
+        default: return FN<__hip_bfloat16, true>(__VA_ARGS__);                                      \
     }
+
+int bf16_forward(const void* feats, int dtype_io, const float* dirs, int64_t S, int in_dim, const float* params, float* rgb,
+                 float* density, hipStream_t st) {
+    WISP_MLP_IO(launch_fwd, feats, dirs, S, in_dim, params, rgb, density, st)
 }
 
-int bf16_backward(const void* feats, int dtype_io, const float* dirs, int64_t S, const float* params, const float* grad_rgb,
-                  const float* grad_density, void* grad_feats, float* partials, int* partial_rows, hipStream_t st) {
-    switch (dtype_io) {
-        case WISP_F32: return launch_bwd<float>(feats, dirs, S, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st);
-        case WISP_F16: return launch_bwd<__half>(feats, dirs, S, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st);
-        default: return launch_bwd<__hip_bfloat16>(feats, dirs, S, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st);
-    }
+int bf16_backward(const void* feats, int dtype_io, const float* dirs, int64_t S, int in_dim, const float* params,
+                  const float* grad_rgb, const float* grad_density, void* grad_feats, float* partials, int* partial_rows,
+                  hipStream_t st) {
+    WISP_MLP_IO(launch_bwd, feats, dirs, S, in_dim, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st)
 }
+#undef WISP_MLP_IO
 
 }  // namespace wisp_mlp

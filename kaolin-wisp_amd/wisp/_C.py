@@ -662,11 +662,20 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_d
 
 
 # ------------------------------------------------------------------------------------------------ fused NeRF decoder
+def _check_decoder_shapes(feats, params, in_dim, hidden, view_freqs):
+    if feats.dim() != 2 or feats.shape[1] != in_dim:
+        raise ValueError(f"feats must be [S, {in_dim}], got {tuple(feats.shape)}")
+    want = int(lib.wisp_nerf_mlp_param_count(in_dim, hidden, view_freqs))
+    if params.numel() != want:
+        raise ValueError(f"packed decoder parameters: expected {want} floats for in_dim={in_dim}, got {params.numel()}")
+
+
 def nerf_mlp_forward(feats, dirs, params, in_dim, hidden, view_freqs, compute_bf16):
     """(rgb [S,3], density [S,1]) = fused density + colour decoders (nerf.py:245-264)."""
     feats = _need(feats, None, "feats")
     dirs = _need(dirs, torch.float32, "dirs")
     params = _need(params, torch.float32, "params")
+    _check_decoder_shapes(feats, params, in_dim, hidden, view_freqs)
     S = feats.shape[0]
     rgb = torch.empty(S, 3, dtype=torch.float32, device=feats.device)
     density = torch.empty(S, 1, dtype=torch.float32, device=feats.device)
@@ -686,6 +695,7 @@ def nerf_mlp_backward(feats, dirs, params, grad_rgb, grad_density, in_dim, hidde
     params = _need(params, torch.float32, "params")
     grad_rgb = _need(grad_rgb, torch.float32, "grad_rgb")
     grad_density = _need(grad_density, torch.float32, "grad_density")
+    _check_decoder_shapes(feats, params, in_dim, hidden, view_freqs)
     S, dev = feats.shape[0], feats.device
     grad_feats = torch.empty_like(feats)
     if grad_params is None:

@@ -33,7 +33,7 @@ class HashGridInterpolate(torch.autograd.Function):
         if torch.is_autocast_enabled():
             # the reference casts to fp16 under autocast (grid.py:88-89); follow the active autocast dtype (bf16 on MI355X).
             # A trainer may keep an up-to-date low-precision copy next to the master weights (refreshed by the fused AdamW).
-            dt = torch.get_autocast_gpu_dtype()
+            dt = torch.get_autocast_dtype('cuda')
             shadow = getattr(codebook, '_wisp_shadow', None)
             table = shadow if (shadow is not None and shadow.dtype == dt) else codebook.to(dt)
         res = _as_int_list(resolutions)

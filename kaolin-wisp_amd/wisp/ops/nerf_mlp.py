@@ -7,7 +7,9 @@ vector in nn.Module order (W1 b1 W2 b2 W3 b3 W4 b4 W5 b5); when the trainer keep
 """
 import torch
 
-SUPPORTED = dict(in_dim=32, hidden=64, view_freqs=4)
+# decoder shapes the kernels are built for: every app/nerf config of the reference (grid feature width 32 for nerf_hash,
+# 5 for nerf_octree / nerf_codebook, 12 for nerf_triplanar; hidden 64, one hidden layer, 4 view octaves)
+SUPPORTED = dict(max_in_dim=32, hidden=64, view_freqs=4)
 
 
 def _hip():
@@ -53,7 +55,7 @@ class _FusedDecoder(torch.autograd.Function):
         C = _hip()
         flat = _flat_view([p.detach() if p is not None else None for p in params])
         packed = flat if flat is not None else _pack(params, shapes)
-        rgb, density = C.nerf_mlp_forward(feats.detach(), dirs, packed, SUPPORTED["in_dim"], SUPPORTED["hidden"],
+        rgb, density = C.nerf_mlp_forward(feats.detach(), dirs, packed, feats.shape[-1], SUPPORTED["hidden"],
                                           SUPPORTED["view_freqs"], compute_bf16)
         ctx.save_for_backward(feats.detach(), dirs, packed)
         ctx.compute_bf16, ctx.shapes = compute_bf16, shapes
@@ -72,7 +74,7 @@ class _FusedDecoder(torch.autograd.Function):
         if g_density is None:
             g_density = torch.zeros(feats.shape[0], 1, device=feats.device)
         g_feats, g_params = C.nerf_mlp_backward(feats, dirs, packed, g_rgb.contiguous().float(), g_density.contiguous().float(),
-                                                SUPPORTED["in_dim"], SUPPORTED["hidden"], SUPPORTED["view_freqs"],
+                                                feats.shape[-1], SUPPORTED["hidden"], SUPPORTED["view_freqs"],
                                                 ctx.compute_bf16, grad_params=ctx.grad_flat)
         if ctx.grad_flat is not None:
             return (g_feats, None, None, None) + tuple(None for _ in ctx.present)
@@ -87,17 +89,17 @@ class _FusedDecoder(torch.autograd.Function):
 
 
 def supports(nef, feats):
-    return (feats.is_cuda and feats.shape[-1] == SUPPORTED["in_dim"] and nef.hidden_dim == SUPPORTED["hidden"]
+    return (feats.is_cuda and 1 <= feats.shape[-1] <= SUPPORTED["max_in_dim"] and nef.hidden_dim == SUPPORTED["hidden"]
             and nef.view_multires == SUPPORTED["view_freqs"] and nef.num_layers == 1 and nef.pos_embedder is None
             and nef.view_embedder_type == 'positional' and nef.activation_type == 'relu'
             and nef.layer_type in ('linear', 'none') and feats.dtype in (torch.float32, torch.float16, torch.bfloat16))
 
 
 def fused_nerf_decoder(nef, feats, ray_d):
-    """(rgb [S,3] fp32, density [S,1] fp32) for nerf_hash.yaml-shaped decoders."""
+    """(rgb [S,3] fp32, density [S,1] fp32) for the decoder shapes of the reference's app/nerf configs (see SUPPORTED)."""
     mode = getattr(nef, 'decoder_compute', 'auto')
     compute_bf16 = (mode == 'bf16') or (mode == 'auto' and torch.is_autocast_enabled())
     params = _decoder_tensors(nef)
-    H, I = SUPPORTED["hidden"], SUPPORTED["in_dim"]
+    H, I = SUPPORTED["hidden"], feats.shape[-1]
     shapes = ((H, I), (H,), (16, H), (16,), (H, 42), (H,), (H, H), (H,), (3, H), (3,))
     return _FusedDecoder.apply(feats.contiguous(), ray_d.contiguous().float(), compute_bf16, shapes, *params)

@@ -90,7 +90,7 @@ class _DirectHashNeRFStep:
         return (nef.fused_decoder and nef.hidden_dim == SUPPORTED["hidden"] and nef.num_layers == 1
                 and nef.view_multires == SUPPORTED["view_freqs"] and nef.pos_embedder is None
                 and nef.view_embedder_type == 'positional' and nef.activation_type == 'relu'
-                and nef.layer_type in ('linear', 'none') and nef.effective_feature_dim() == SUPPORTED["in_dim"]
+                and nef.layer_type in ('linear', 'none') and 1 <= nef.effective_feature_dim() <= SUPPORTED["max_in_dim"]
                 and all(t is not None for t in _decoder_tensors(nef))
                 and getattr(nef, 'decoder_compute', 'auto') == 'auto')
 
@@ -99,7 +99,7 @@ class _DirectHashNeRFStep:
         self.t = trainer
         nef = trainer.pipeline.nef
         grid = nef.grid
-        self.shape = (SUPPORTED["in_dim"], SUPPORTED["hidden"], SUPPORTED["view_freqs"])
+        self.shape = (nef.effective_feature_dim(), SUPPORTED["hidden"], SUPPORTED["view_freqs"])
         dec = _decoder_tensors(nef)
         self.packed = _flat_view([p.detach() for p in dec])                  # zero-copy views of the flat buffers
         self.packed_grad = _flat_view([p.grad for p in dec])

@@ -427,14 +427,20 @@ def test_prune_rebuilds_identical_octree():
 
 
 # ------------------------------------------------------------------------------------------------ fused decoder
-def _decoder_pair(bias=True):
+def _decoder_pair(bias=True, in_dim=32):
+    """A NeuralRadianceField whose decoders take `in_dim` grid features: the widths of the reference's app/nerf configs
+    (32 = nerf_hash 'cat' 16x2, 12 = a 6-level 'cat' hash grid / the triplanar width, 5 = nerf_octree / nerf_codebook)."""
     from wisp.accelstructs import OctreeAS
-    from wisp.models.grids import HashGrid
+    from wisp.models.grids import HashGrid, OctreeGrid
     from wisp.models.nefs import NeuralRadianceField
     torch.manual_seed(5)
-    grid = HashGrid.from_geometric(OctreeAS.make_dense(2), feature_dim=2, num_lods=16, multiscale_type='cat', feature_std=0.1,
-                                   codebook_bitwidth=10, min_grid_res=4, max_grid_res=64)
+    if in_dim == 5:
+        grid = OctreeGrid(OctreeAS.make_dense(2), feature_dim=5, num_lods=2, multiscale_type='sum', feature_std=0.1)
+    else:
+        grid = HashGrid.from_geometric(OctreeAS.make_dense(2), feature_dim=2, num_lods=in_dim // 2, multiscale_type='cat',
+                                       feature_std=0.1, codebook_bitwidth=10, min_grid_res=4, max_grid_res=64)
     nef = NeuralRadianceField(grid, view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1, bias=bias).to(DEV)
+    assert nef.effective_feature_dim() == in_dim
     with torch.no_grad():
         for n, p in nef.named_parameters():
             if 'decoder' in n:
@@ -442,16 +448,20 @@ def _decoder_pair(bias=True):
     return nef
 
 
-@pytest.mark.parametrize("mode,io_dtype,tol", [("fp32", torch.float32, 3e-5), ("bf16", torch.float32, 4e-2),
-                                               ("bf16", torch.bfloat16, 4e-2)])
-@pytest.mark.parametrize("bias", [True, False])
-def test_fused_decoder_matches_torch_fp32_modules(mode, io_dtype, tol, bias):
-    from wisp.ops.nerf_mlp import fused_nerf_decoder
-    nef = _decoder_pair(bias)
+@pytest.mark.parametrize("mode,io_dtype,tol,bias,in_dim", [
+    ("fp32", torch.float32, 3e-5, True, 32), ("bf16", torch.float32, 4e-2, True, 32), ("bf16", torch.bfloat16, 4e-2, True, 32),
+    ("fp32", torch.float32, 3e-5, False, 32), ("bf16", torch.float32, 4e-2, False, 32), ("bf16", torch.bfloat16, 4e-2, False, 32),
+    # narrower grid features: rows without alignment, W1 zero-padded inside the kernel, gradients un-padded on the way out
+    ("fp32", torch.float32, 3e-5, False, 5), ("bf16", torch.bfloat16, 4e-2, False, 5), ("bf16", torch.float16, 4e-2, True, 5),
+    ("fp32", torch.float32, 3e-5, True, 12), ("bf16", torch.float32, 4e-2, True, 12), ("bf16", torch.bfloat16, 4e-2, False, 12)])
+def test_fused_decoder_matches_torch_fp32_modules(mode, io_dtype, tol, bias, in_dim):
+    from wisp.ops.nerf_mlp import fused_nerf_decoder, supports
+    nef = _decoder_pair(bias, in_dim)
     nef.decoder_compute = mode
     S = 5003                                       # not a multiple of the 32-sample tile
     g = torch.Generator(device=DEV).manual_seed(1)
-    feats = torch.randn(S, 32, device=DEV, generator=g)
+    feats = torch.randn(S, in_dim, device=DEV, generator=g)
+    assert supports(nef, feats)
     dirs = torch.nn.functional.normalize(torch.randn(S, 3, device=DEV, generator=g), dim=1)
     w_rgb = torch.randn(S, 3, device=DEV, generator=g); w_den = torch.randn(S, 1, device=DEV, generator=g)
 
@@ -496,7 +506,8 @@ def test_fused_decoder_matches_torch_fp32_modules(mode, io_dtype, tol, bias):
             else:
                 rel = float((p.grad - ref_grads[n]).norm() / ref_grads[n].norm())
                 assert rel <= 1.5 * amp_err[n] + 1e-2, (n, rel, amp_err[n])
-    r0, d0 = fused_nerf_decoder(nef, torch.zeros(0, 32, device=DEV), torch.zeros(0, 3, device=DEV))
+    assert f_in.grad.shape == (S, in_dim)
+    r0, d0 = fused_nerf_decoder(nef, torch.zeros(0, in_dim, device=DEV), torch.zeros(0, 3, device=DEV))
     assert r0.shape == (0, 3) and d0.shape == (0, 1)
 
 
