@@ -189,11 +189,15 @@ int wisp_codebook_trilinear_bwd(const float* coords, const void* pidx, int pidx_
  * mask into the packed outputs at offsets[r].  jitter: f32 [R,N] in [0,1) or NULL, in which case a
  * counter-based generator keyed by (seed, ray, step) is used (the reference uses torch.rand, unseeded).
  * occ_bits: bitfield of `level` (wisp_spc_build_bitfield) - or NULL to walk octree/exsum.
+ * coarse_bits: optional bitfield of a coarser level of the SAME octree (coarse_level <= 5, <= level), or NULL.
+ * It only prunes work - 64-candidate chunks whose segment meets no occupied coarse cell are not evaluated -
+ * and never changes an output; pick the level whose cell size is about one chunk (64 * range / num_samples).
  */
 int wisp_raymarch_ray_count(const uint32_t* occ_bits, const uint8_t* octree, const int32_t* exsum,
                             const float* origins, const float* dirs, int64_t num_rays,
                             float near, float range /* fl32(dist_max - dist_min) */, int num_samples, int level,
                             const float* jitter, uint64_t seed,
+                            const uint32_t* coarse_bits, int coarse_level,
                             uint32_t* hitmask, int32_t* counts, wisp_stream_t stream);
 int wisp_raymarch_ray_emit(const float* origins, const float* dirs, int64_t num_rays,
                            float near, float range, int num_samples,

@@ -63,17 +63,53 @@ static __device__ __forceinline__ bool occupied(const uint32_t* __restrict__ occ
     return true;
 }
 
+// Coarse pre-test of one 64-candidate chunk: can the ray segment [ta, tb] touch an occupied cell of the coarse level?
+// The segment's axis-aligned box (inflated by 1e-4, far above the 1e-6 rounding of o + d*t) is mapped to coarse cells with
+// the SAME float expression the exact test uses one octree level per factor of two finer (floor(2^L * fl(0.5 x + 0.5)):
+// scaling by a power of two is exact, so coarse index == fine index >> (L - Lc)) - every cell a candidate of the chunk can
+// fall into is visited, hence skipping is conservative and the kernel's outputs do not change.
+static __device__ __forceinline__ bool coarse_segment_occupied(const uint32_t* s_coarse, int lc, const float (&o)[3],
+                                                               const float (&d)[3], float ta, float tb) {
+    const float resc = (float)(1 << lc);
+    const int top = (1 << lc) - 1;
+    int i0[3], i1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float pa = o[a] + d[a] * ta, pb = o[a] + d[a] * tb;
+        const float mn = fminf(pa, pb) - 1e-4f, mx = fmaxf(pa, pb) + 1e-4f;
+        i0[a] = min(max((int)floorf(resc * (0.5f * mn + 0.5f)), 0), top);
+        i1[a] = min(max((int)floorf(resc * (0.5f * mx + 0.5f)), 0), top);
+        if (i1[a] - i0[a] > 2) return true;               // chunk much longer than a coarse cell: no pre-test
+    }
+    for (int z = i0[2]; z <= i1[2]; ++z)
+        for (int y = i0[1]; y <= i1[1]; ++y)
+            for (int x = i0[0]; x <= i1[0]; ++x) {
+                const uint32_t m = wisp_cell_bit((uint32_t)x, (uint32_t)y, (uint32_t)z, lc);
+                if ((s_coarse[m >> 5] >> (m & 31u)) & 1u) return true;
+            }
+    return false;
+}
+
+#define RM_COARSE_MAX_LEVEL 5          // 32^3 bits = 4 KiB of LDS
+
 __global__ void __launch_bounds__(256)
 raymarch_ray_count_kernel(const uint32_t* __restrict__ occ_bits, const uint8_t* __restrict__ octree,
                           const int32_t* __restrict__ exsum, const float* __restrict__ origins,
                           const float* __restrict__ dirs, int64_t num_rays, float near, float range, int n, int level,
-                          const float* __restrict__ jitter, uint64_t seed, uint32_t* __restrict__ hitmask,
-                          int32_t* __restrict__ counts) {
+                          const float* __restrict__ jitter, uint64_t seed, const uint32_t* __restrict__ coarse_bits,
+                          int coarse_level, uint32_t* __restrict__ hitmask, int32_t* __restrict__ counts) {
+    __shared__ uint32_t s_coarse[(1 << (3 * RM_COARSE_MAX_LEVEL)) / 32];
+    if (coarse_bits) {
+        const int cw = max(1, (1 << (3 * coarse_level)) >> 5);
+        for (int e = threadIdx.x; e < cw; e += blockDim.x) s_coarse[e] = coarse_bits[e];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= num_rays) return;
-    const float ox = origins[r * 3], oy = origins[r * 3 + 1], oz = origins[r * 3 + 2];
-    const float dx = dirs[r * 3], dy = dirs[r * 3 + 1], dz = dirs[r * 3 + 2];
+    const float o3[3] = {origins[r * 3], origins[r * 3 + 1], origins[r * 3 + 2]};
+    const float d3[3] = {dirs[r * 3], dirs[r * 3 + 1], dirs[r * 3 + 2]};
+    const float ox = o3[0], oy = o3[1], oz = o3[2], dx = d3[0], dy = d3[1], dz = d3[2];
     const float step = n > 1 ? __fdiv_rn(1.0f, (float)(n - 1)) : 0.0f;
     const float fn = (float)n;
     const int words = (n + 31) >> 5;
@@ -83,47 +119,58 @@ raymarch_ray_count_kernel(const uint32_t* __restrict__ occ_bits, const uint8_t* 
     // inflation (1e-4 in space) is far above the rounding of o + d*t (|x| < 8 -> 1e-6), so no candidate the exact test
     // would accept is ever skipped; the per-candidate test itself is unchanged.
     float t_in = -INFINITY, t_out = INFINITY;
-    {
-        const float o3[3] = {ox, oy, oz}, d3[3] = {dx, dy, dz};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (fabsf(d3[a]) > 1e-12f) {
-                const float ta = (-1.0001f - o3[a]) / d3[a], tb = (1.0001f - o3[a]) / d3[a];
-                t_in = fmaxf(t_in, fminf(ta, tb));
-                t_out = fminf(t_out, fmaxf(ta, tb));
-            } else if (fabsf(o3[a]) > 1.0001f) {
-                t_out = -INFINITY;                       // parallel to the slab and outside it: never inside
-            }
+    for (int a = 0; a < 3; ++a) {
+        if (fabsf(d3[a]) > 1e-12f) {
+            const float ta = (-1.0001f - o3[a]) / d3[a], tb = (1.0001f - o3[a]) / d3[a];
+            t_in = fmaxf(t_in, fminf(ta, tb));
+            t_out = fminf(t_out, fmaxf(ta, tb));
+        } else if (fabsf(o3[a]) > 1.0001f) {
+            t_out = -INFINITY;                       // parallel to the slab and outside it: never inside
         }
     }
     const float pad = 1e-3f * fabsf(range) + 1e-6f;
+    const int nchunks = (n + 63) >> 6;
     int cnt = 0;
-    for (int base = 0; base < n; base += 64) {
-        // depths of candidates base .. base+63 lie in [near + range*base/n, near + range*((base+64)/(n-1) + 1/n)] (range >= 0)
-        const float c_lo = near + range * ((float)base / fn) - pad;
-        const float c_hi = near + range * ((float)(base + 64) / (float)(n > 1 ? n - 1 : 1) + 1.0f / fn) + pad;
-        if (range >= 0.0f && (c_hi < t_in || c_lo > t_out)) {
+    // Chunks are classified 64 at a time, one per lane: outside the cube interval -> skipped; inside, but the coarse
+    // occupancy level (LDS) shows nothing along the segment -> skipped; the survivors are evaluated by the whole wave.
+    for (int cg = 0; cg < nchunks; cg += 64) {
+        const int ci = cg + lane;
+        bool act = ci < nchunks;
+        if (act && range >= 0.0f) {
+            // depths of candidates base .. base+63 lie in [near + range*base/n, near + range*((base+64)/(n-1) + 1/n)]
+            const int base = ci << 6;
+            const float c_lo = near + range * ((float)base / fn) - pad;
+            const float c_hi = near + range * ((float)(base + 64) / (float)(n > 1 ? n - 1 : 1) + 1.0f / fn) + pad;
+            act = !(c_hi < t_in || c_lo > t_out);
+            if (act && coarse_bits)
+                act = coarse_segment_occupied(s_coarse, coarse_level, o3, d3, fmaxf(c_lo, t_in), fminf(c_hi, t_out));
+        }
+        if (ci < nchunks && !act) {
+            const int w = ci << 1;
+            hitmask[r * words + w] = 0u;
+            if (w + 1 < words) hitmask[r * words + w + 1] = 0u;
+        }
+        unsigned long long todo = __ballot(act);
+        while (todo) {
+            const int c = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int base = (cg + c) << 6;
+            const int s = base + lane;
+            bool hit = false;
+            if (s < n) {
+                const float u = jitter ? jitter[r * n + s] : wisp_uniform01_keyed(key, (uint32_t)s);
+                const float t = ray_depth(s, n, step, u, fn, range, near);
+                hit = occupied(occ_bits, octree, exsum, axpy_unfused(ox, dx, t), axpy_unfused(oy, dy, t),
+                               axpy_unfused(oz, dz, t), level);
+            }
+            const unsigned long long m = __ballot(hit);
+            cnt += __popcll(m);
             if (lane == 0) {
                 const int w = base >> 5;
-                hitmask[r * words + w] = 0u;
-                if (w + 1 < words) hitmask[r * words + w + 1] = 0u;
+                hitmask[r * words + w] = (uint32_t)m;
+                if (w + 1 < words) hitmask[r * words + w + 1] = (uint32_t)(m >> 32);
             }
-            continue;
-        }
-        const int s = base + lane;
-        bool hit = false;
-        if (s < n) {
-            const float u = jitter ? jitter[r * n + s] : wisp_uniform01_keyed(key, (uint32_t)s);
-            const float t = ray_depth(s, n, step, u, fn, range, near);
-            hit = occupied(occ_bits, octree, exsum, axpy_unfused(ox, dx, t), axpy_unfused(oy, dy, t),
-                           axpy_unfused(oz, dz, t), level);
-        }
-        const unsigned long long m = __ballot(hit);
-        cnt += __popcll(m);
-        if (lane == 0) {
-            const int w = base >> 5;
-            hitmask[r * words + w] = (uint32_t)m;
-            if (w + 1 < words) hitmask[r * words + w + 1] = (uint32_t)(m >> 32);
         }
     }
     if (lane == 0) counts[r] = cnt;
@@ -177,15 +224,18 @@ raymarch_ray_emit_kernel(const float* __restrict__ origins, const float* __restr
 extern "C" int wisp_raymarch_ray_count(const uint32_t* occ_bits, const uint8_t* octree, const int32_t* exsum,
                                        const float* origins, const float* dirs, int64_t num_rays, float near,
                                        float range, int num_samples, int level, const float* jitter, uint64_t seed,
-                                       uint32_t* hitmask, int32_t* counts, wisp_stream_t stream) {
+                                       const uint32_t* coarse_bits, int coarse_level, uint32_t* hitmask, int32_t* counts,
+                                       wisp_stream_t stream) {
     WISP_REQUIRE(num_rays >= 0 && num_samples >= 1 && level >= 0 && level <= 15, "bad sizes");
     if (num_rays == 0) return WISP_OK;
     WISP_REQUIRE(origins && dirs && hitmask && counts, "null pointer");
     WISP_REQUIRE(occ_bits || (exsum && (octree || level == 0)), "need occ_bits or octree+exsum");
     WISP_REQUIRE(!occ_bits || level <= 10, "bitfield path supports level <= 10");
+    WISP_REQUIRE(!coarse_bits || (coarse_level >= 0 && coarse_level <= RM_COARSE_MAX_LEVEL && coarse_level <= level),
+                 "coarse_level out of range");
     hipLaunchKernelGGL(raymarch_ray_count_kernel, dim3((unsigned)ceil_div64(num_rays, 4)), dim3(256), 0,
                        (hipStream_t)stream, occ_bits, octree, exsum, origins, dirs, num_rays, near, range, num_samples,
-                       level, jitter, seed, hitmask, counts);
+                       level, jitter, seed, coarse_bits, coarse_level, hitmask, counts);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }

@@ -316,32 +316,46 @@ extern "C" int64_t wisp_scan_workspace_bytes(int64_t n) {
     return (nt + 8) * 8;
 }
 
-// Up to 64 K values (the per-ray sample counts of one training batch): ONE workgroup, one launch - every thread sums a
-// contiguous run, the 1024 run totals are scanned with wave shuffles + 16 LDS cells, then the runs are re-walked.  The
-// three-kernel tile scan below takes over for longer inputs; a launch costs ~5 us of timeline here, the scan itself ~2.
+// Up to 64 K values (the per-ray sample counts of one training batch): ONE launch, every workgroup independent.
+// Workgroup b owns values [1024 b, 1024 b + 1024) and simply re-sums everything in front of them (coalesced 16-byte loads of
+// at most 256 KiB that sit in L2) instead of waiting for anybody: no spine kernel, no look-back flags, and the longest
+// workgroup reads what ONE workgroup of a serial scan would have read anyway.  (History: a one-workgroup version took 89 us
+// for 50 K values with strided per-thread runs and still 37 us with coalesced tiles - one CU cannot move the data faster;
+// a launch costs ~5 us of timeline on this stack, so the three-kernel tile scan below is kept for long inputs only.)
+#define SC1_TILE (SC_THREADS * 4)
 #define SC1_MAX (64 * 1024)
-__global__ void __launch_bounds__(1024)
-scan_single_block_kernel(const int32_t* __restrict__ in, int n, int64_t* __restrict__ out) {
-    __shared__ int64_t wave_tot[16];
-    const int per = (n + 1023) / 1024;
-    const int lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
-    int64_t run = 0;
-    for (int i = lo; i < hi; ++i) run += in[i];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int64_t inc = run;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int64_t t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
+__global__ void __launch_bounds__(SC_THREADS)
+scan_small_kernel(const int32_t* __restrict__ in, int n, int64_t* __restrict__ out) {
+    const int tile0 = blockIdx.x * SC1_TILE;
+    int64_t part = 0;
+    for (int i = 4 * (int)threadIdx.x; i < tile0; i += SC1_TILE) {        // tile0 is a multiple of the stride: no tail
+        const int4 q = *reinterpret_cast<const int4*>(in + i);
+        part += (int64_t)q.x + q.y + q.z + q.w;
     }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    int64_t base = 0, total = 0;
+    int64_t base;
+    block_excl_scan(part, &base);                                         // base = sum of everything before this tile
+    const int i = tile0 + 4 * (int)threadIdx.x;
+    int32_t v[4] = {0, 0, 0, 0};
+    if (i + 3 < n) {
+        const int4 q = *reinterpret_cast<const int4*>(in + i);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
 #pragma unroll
-    for (int w = 0; w < 16; ++w) { const int64_t t = wave_tot[w]; if (w < wave) base += t; total += t; }
-    int64_t acc = base + inc - run;                      // exclusive prefix of this thread's run
-    for (int i = lo; i < hi; ++i) { out[i] = acc; acc += in[i]; }
-    if (threadIdx.x == 0) out[n] = total;
+        for (int e = 0; e < 4; ++e) if (i + e < n) v[e] = in[i + e];
+    }
+    int64_t tot;
+    const int64_t e0 = base + block_excl_scan((int64_t)v[0] + v[1] + v[2] + v[3], &tot);
+    const int64_t e1 = e0 + v[0], e2 = e1 + v[1], e3 = e2 + v[2];
+    if (i + 3 < n) {
+        longlong2* dst = reinterpret_cast<longlong2*>(out + i);
+        dst[0] = make_longlong2(e0, e1);
+        dst[1] = make_longlong2(e2, e3);
+    } else {
+        const int64_t ex[4] = {e0, e1, e2, e3};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (i + e < n) out[i + e] = ex[e];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = base + tot;
 }
 
 extern "C" int wisp_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* offsets, void* workspace,
@@ -354,7 +368,7 @@ extern "C" int wisp_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t
     }
     WISP_REQUIRE(counts && workspace, "null pointer");
     if (n <= SC1_MAX) {
-        hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(1024), 0, s, counts, (int)n, offsets);
+        hipLaunchKernelGGL(scan_small_kernel, dim3((unsigned)ceil_div64(n, SC1_TILE)), dim3(SC_THREADS), 0, s, counts, (int)n, offsets);
         WISP_CHECK_LAUNCH();
         return WISP_OK;
     }

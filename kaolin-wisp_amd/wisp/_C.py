@@ -54,7 +54,7 @@ SIGNATURES = {
     "wisp_inclusive_scan_i32": [c_vp, c_i64, c_vp, c_vp, c_vp],
     "wisp_boundary_tile_counts": [c_vp, c_i64, c_vp, c_vp],
     "wisp_boundary_pack_starts": [c_vp, c_i64, c_vp, c_vp, c_vp],
-    "wisp_raymarch_ray_count": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_i32, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp],
+    "wisp_raymarch_ray_count": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_i32, c_i32, c_vp, c_u64, c_vp, c_i32, c_vp, c_vp, c_vp],
     "wisp_raymarch_ray_emit": [c_vp, c_vp, c_i64, c_f32, c_f32, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_voxel_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_uniform_count": [c_vp, c_i64, c_f32, c_vp, c_vp],
@@ -454,10 +454,25 @@ def _alloc_samples(S, dev):
             torch.empty(S, dtype=torch.bool, device=dev))
 
 
-def raymarch_ray_count(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level, jitter=None, seed=0):
+RAYMARCH_COARSE_MAX_LEVEL = 5
+
+
+def raymarch_coarse_level(near, far, num_samples, level):
+    """Occupancy level whose cell is about as long as one 64-candidate chunk of a ray (what the count kernel's LDS pre-test
+    wants), or None when no coarser level than `level` qualifies."""
+    chunk = 64.0 * abs(float(far) - float(near)) / max(int(num_samples), 1)
+    if not (chunk > 0.0):
+        return None
+    lc = min(int(np.floor(np.log2(2.0 / chunk))), RAYMARCH_COARSE_MAX_LEVEL, level - 1)
+    return lc if lc >= 1 else None
+
+
+def raymarch_ray_count(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level, jitter=None, seed=0,
+                       coarse_bits=None, coarse_level=0):
     """First half of OctreeAS._raymarch_ray (octree_as.py:247-309): occupancy test of every candidate + per-ray offsets.
     Needs no field parameters and no host read-back, so a trainer can issue it for the NEXT batch early.  Returns the state
-    raymarch_ray_finish() expands into packed samples."""
+    raymarch_ray_finish() expands into packed samples.  coarse_bits / coarse_level: optional bitfield of a coarser level
+    of the same octree (see raymarch_coarse_level); it prunes work, never results."""
     origins = _need(origins, torch.float32, "origins").reshape(-1, 3)
     dirs = _need(dirs, torch.float32, "dirs").reshape(-1, 3)
     R, dev = origins.shape[0], origins.device
@@ -470,11 +485,49 @@ def raymarch_ray_count(occ_bits, octree, exsum, origins, dirs, near, far, num_sa
     hitmask = torch.empty(R, words, dtype=torch.int32, device=dev)
     counts = torch.empty(R, dtype=torch.int32, device=dev)
     _check(lib.wisp_raymarch_ray_count(_p(occ_bits), _p(octree), _p(exsum), _p(origins), _p(dirs), R, near32, range32,
-                                       num_samples, level, _p(jitter), seed, _p(hitmask), _p(counts), _stream()),
+                                       num_samples, level, _p(jitter), seed, _p(coarse_bits), int(coarse_level), _p(hitmask),
+                                       _p(counts), _stream()),
            "raymarch_ray_count")
     offsets = exclusive_scan(counts)
-    return dict(origins=origins, dirs=dirs, near32=near32, range32=range32, num_samples=num_samples, jitter=jitter, seed=seed,
-                hitmask=hitmask, offsets=offsets)
+    st = dict(origins=origins, dirs=dirs, near32=near32, range32=range32, num_samples=num_samples, jitter=jitter, seed=seed,
+              hitmask=hitmask, offsets=offsets)
+    _read_total_async(st)
+    return st
+
+
+# The sample count has to reach the host before the packed outputs can be allocated.  offsets[-1].item() on the compute
+# stream would drain EVERYTHING queued there (with the trainer's one-batch look-ahead: the whole previous step) and leave
+# the GPU idle while the host wakes up and launches again (measured: 43 us per step).  Instead the total is copied to
+# pinned memory on a side stream that only waits for the scan; raymarch_ray_finish() waits for that copy alone.
+_copy_streams, _pinned_pool = {}, []
+
+
+def _read_total_async(st):
+    offsets = st["offsets"]
+    dev = offsets.device
+    side = _copy_streams.get(dev)
+    if side is None:
+        side = _copy_streams[dev] = torch.cuda.Stream(dev)
+    host = _pinned_pool.pop() if _pinned_pool else torch.empty(1, dtype=torch.int64, pin_memory=True)
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        host.copy_(offsets[-1:], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(side)
+    st["total_host"], st["total_done"] = host, done
+
+
+def _total(st):
+    done = st.pop("total_done", None)
+    if done is None:
+        return int(st["offsets"][-1].item())
+    done.synchronize()
+    host = st.pop("total_host")
+    total = int(host[0])
+    _pinned_pool.append(host)
+    return total
 
 
 def raymarch_ray_finish(st):
@@ -482,7 +535,7 @@ def raymarch_ray_finish(st):
     emit.  Returns (ridx, samples, depth, deltas, boundary, ray_offsets)."""
     origins, offsets = st["origins"], st["offsets"]
     R, dev = origins.shape[0], origins.device
-    S = int(offsets[-1].item())
+    S = _total(st)
     ridx, samples, depth, deltas, boundary = _alloc_samples(S, dev)
     if S:
         _check(lib.wisp_raymarch_ray_emit(_p(origins), _p(st["dirs"]), R, st["near32"], st["range32"], st["num_samples"],
@@ -491,10 +544,11 @@ def raymarch_ray_finish(st):
     return ridx, samples, depth, deltas, boundary, offsets
 
 
-def raymarch_ray(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level, jitter=None, seed=0):
+def raymarch_ray(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level, jitter=None, seed=0,
+                 coarse_bits=None, coarse_level=0):
     """OctreeAS._raymarch_ray (octree_as.py:247-309).  Returns (ridx, samples, depth, deltas, boundary, ray_offsets)."""
     return raymarch_ray_finish(raymarch_ray_count(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level,
-                                                  jitter, seed))
+                                                  jitter, seed, coarse_bits, coarse_level))
 
 
 def raymarch_voxel(origins, dirs, nug_ridx, nug_depth, num_samples, jitter=None, seed=0):

@@ -122,9 +122,10 @@ class _DirectHashNeRFStep:
             raise TypeError("'ray' raymarch needs scalar Rays.dist_min / dist_max (as the reference, octree_as.py:276-277)")
         blas._to_device(rays.origins.device)
         level = blas.max_level
+        coarse, lc = blas._coarse_bitfield(rays, pipe.tracer.num_steps, level)
         st = C.raymarch_ray_count(blas._bitfield(level), blas.octree, blas.prefix, rays.origins, rays.dirs, rays.dist_min,
                                   rays.dist_max, pipe.tracer.num_steps, level, jitter,
-                                  blas._draw_seed() if seed is None else seed)
+                                  blas._draw_seed() if seed is None else seed, coarse, lc)
         st["rays"], st["blas"] = rays, blas
         return st
 

@@ -1,0 +1,36 @@
+"""Idle time between kernels of the steady-state training step, from a rocprofv3 --kernel-trace CSV.
+usage: python scripts/trace_gaps.py <dir with *_kernel_trace.csv> [marker kernel substring = hashgrid_fwd]
+Steps are delimited by the marker kernel; the last 5 complete steps are summarised: busy time, idle time and the idle
+time attributed to the kernel that FOLLOWS each gap (the launch that arrived late)."""
+import csv, glob, os, sys, collections
+
+root = sys.argv[1]
+marker = sys.argv[2] if len(sys.argv) > 2 else "hashgrid_fwd"
+files = glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)
+rows = []
+for f in files:
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+marks = [i for i, r in enumerate(rows) if marker in r[2]]
+if len(marks) < 7:
+    sys.exit(f"only {len(marks)} marker kernels found")
+steps = [(marks[i], marks[i + 1]) for i in range(len(marks) - 6, len(marks) - 1)]
+busy = idle = 0
+gap_by = collections.Counter(); time_by = collections.Counter(); n_by = collections.Counter()
+for a, b in steps:
+    for i in range(a, b):
+        s, e, name = rows[i]
+        short = name.split("(")[0].split("<")[0].replace("void ", "").replace("(anonymous namespace)::", "")[-60:]
+        busy += e - s; time_by[short] += e - s; n_by[short] += 1
+        nxt = rows[i + 1]
+        g = max(0, nxt[0] - e)
+        idle += g
+        nshort = nxt[2].split("(")[0].split("<")[0].replace("void ", "").replace("(anonymous namespace)::", "")[-60:]
+        gap_by[nshort] += g
+n = len(steps)
+print(f"steps {n}: wall {(busy + idle) / n / 1e3:.1f} us  busy {busy / n / 1e3:.1f} us  idle {idle / n / 1e3:.1f} us  launches/step {sum(n_by.values()) / n:.1f}")
+print("kernel".ljust(62), "calls/step   us/step   idle-before us/step")
+for k, t in time_by.most_common():
+    print(k.ljust(62), f"{n_by[k] / n:9.1f} {t / n / 1e3:9.1f} {gap_by[k] / n / 1e3:12.1f}")

@@ -206,7 +206,7 @@ def test_raytrace_bit_exact_sparse_and_dense():
 
 def test_scans_boundaries_and_pack_starts():
     g = torch.Generator().manual_seed(5)
-    for n in (1, 63, 2048, 2049, 65536, 65537, 300001):      # single-workgroup scan up to 64 K, tile scan above
+    for n in (1, 63, 1023, 1024, 1025, 2048, 2049, 49623, 65536, 65537, 300001):   # one-launch scan up to 64 K, tile scan above
         c = torch.randint(0, 9, (n,), generator=g, dtype=torch.int32)
         off = _C().exclusive_scan(c.to(DEV)).cpu()
         assert torch.equal(off[1:], torch.cumsum(c.long(), 0)) and int(off[0]) == 0
@@ -221,9 +221,14 @@ def test_scans_boundaries_and_pack_starts():
 
 
 # ------------------------------------------------------------------------------------------------ raymarch
-@pytest.mark.parametrize("tree,level", [("sparse", 6), ("dense", 4), ("blob", 11)])
+@pytest.mark.parametrize("tree,level", [("sparse", 6), ("dense", 4), ("blob", 11), ("clusters", 6)])
 def test_raymarch_ray_bit_exact(tree, level):
-    if tree == "dense":
+    if tree == "clusters":         # a few blobs, most coarse cells empty: the case the coarse pre-test prunes
+        rng = np.random.default_rng(47)
+        centres = rng.uniform(12, 52, size=(5, 1, 3))
+        cells = np.clip(centres + rng.normal(0, 2.5, size=(5, 3000, 3)), 0, 63).reshape(-1, 3).astype(np.int64)
+        oc = ospc.points_to_octree(cells, level); pts, pyr, ex = ospc.octree_to_spc(oc)
+    elif tree == "dense":
         oc = ospc.create_dense_octree(level); pts, pyr, ex = ospc.octree_to_spc(oc)
     elif tree == "blob":           # level 11 (> 10: no bitfield, octree-walk path): a dense blob near the origin
         rng = np.random.default_rng(41)
@@ -245,6 +250,13 @@ def test_raymarch_ray_bit_exact(tree, level):
         assert np.array_equal(samples.cpu().numpy(), want["samples"])
         assert np.array_equal(depth.cpu().numpy(), want["depth_samples"])
         assert np.array_equal(deltas.cpu().numpy(), want["deltas"])
+    # the LDS pre-test against a coarser occupancy level only prunes work: every coarse level, same bits as the oracle
+    for lc in range(1, min(level - 1, 5) + 1):
+        cpts = pts[pyr[1, lc]:pyr[1, lc] + pyr[0, lc]]
+        got = _C().raymarch_ray(bits, cuda(oc), cuda(ex), cuda(o), cuda(d), 1.0, 5.0, N, level, cuda(jit),
+                                coarse_bits=_C().spc_bitfield(cuda(cpts), lc), coarse_level=lc)
+        assert np.array_equal(got[0].cpu().numpy(), want["ridx"]) and np.array_equal(got[1].cpu().numpy(), want["samples"])
+        assert np.array_equal(got[4].cpu().numpy(), want["boundary"]) and np.array_equal(got[3].cpu().numpy(), want["deltas"])
     # in-kernel jitter: same structure invariants, reproducible for a fixed seed, different across seeds
     a = _C().raymarch_ray(bits, cuda(oc), cuda(ex), cuda(o), cuda(d), 1.0, 5.0, N, level, None, seed=7)
     b = _C().raymarch_ray(bits, cuda(oc), cuda(ex), cuda(o), cuda(d), 1.0, 5.0, N, level, None, seed=7)
@@ -252,6 +264,28 @@ def test_raymarch_ray_bit_exact(tree, level):
     assert a[1].shape[0] > 0 and want["ridx"].shape[0] > 0
     assert torch.equal(a[1], b[1]) and (a[1].shape != c[1].shape or not torch.equal(a[1], c[1]))
     assert bool((ospc.query(oc, ex, a[1].cpu().numpy(), level) >= 0).all())
+
+
+def test_raymarch_ray_coarse_pretest_changes_nothing_at_flagship_shape():
+    """nerf_hash.yaml shape (level 7, 2048 candidates, near/far 1/5, in-kernel jitter): with and without the coarse level."""
+    from wisp.accelstructs import OctreeAS
+    from wisp.core import Rays
+    rng = np.random.default_rng(45)
+    centres = rng.uniform(20, 108, size=(12, 1, 3))
+    cells = np.clip(centres + rng.normal(0, 5.0, size=(12, 8000, 3)), 0, 127).reshape(-1, 3).astype(np.int64)
+    oc = ospc.points_to_octree(cells, 7)
+    blas = OctreeAS(cuda(oc))
+    assert blas.pyramid[0, 4] < 0.5 * 4096          # most level-4 cells are empty: the pre-test has something to skip
+    o, d = make_rays(3000, 46)
+    rays = Rays(cuda(o), cuda(d), dist_min=1.0, dist_max=5.0)
+    coarse, lc = blas._coarse_bitfield(rays, 2048, 7)
+    assert lc == 4 and coarse is not None
+    args = (blas._bitfield(7), blas.octree, blas.prefix, rays.origins, rays.dirs, 1.0, 5.0, 2048, 7, None, 123)
+    a = _C().raymarch_ray(*args)
+    b = _C().raymarch_ray(*args, coarse_bits=coarse, coarse_level=lc)
+    assert a[0].shape[0] > 10000
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
 
 
 def test_raymarch_voxel_and_uniform_bit_exact():
