@@ -204,7 +204,10 @@ int wisp_raymarch_ray_emit(const float* origins, const float* dirs, int64_t num_
                            const float* jitter, uint64_t seed,
                            const uint32_t* hitmask, const int64_t* offsets,
                            int64_t* ridx, float* samples, float* depth_samples, float* deltas,
-                           uint8_t* boundary, wisp_stream_t stream);
+                           uint8_t* boundary,
+                           float* sample_dirs /* f32 [S,3] = dirs[ridx] (rays.dirs.index_select(0, ridx),
+                                                 packed_rf_tracer.py:120), or NULL */,
+                           wisp_stream_t stream);
 
 /* 'voxel' mode: num_samples jittered samples inside every nugget; S = M*num_samples.
  * nug_ridx i32 [M], nug_depth f32 [M,2]; jitter f32 [M,N] or NULL (+seed). */

@@ -181,7 +181,7 @@ raymarch_ray_emit_kernel(const float* __restrict__ origins, const float* __restr
                          float near, float range, int n, const float* __restrict__ jitter, uint64_t seed,
                          const uint32_t* __restrict__ hitmask, const int64_t* __restrict__ offsets,
                          int64_t* __restrict__ ridx, float* __restrict__ samples, float* __restrict__ depth_samples,
-                         float* __restrict__ deltas, uint8_t* __restrict__ boundary) {
+                         float* __restrict__ deltas, uint8_t* __restrict__ boundary, float* __restrict__ sample_dirs) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= num_rays) return;
@@ -194,30 +194,39 @@ raymarch_ray_emit_kernel(const float* __restrict__ origins, const float* __restr
     const int words = (n + 31) >> 5;
     const uint32_t key = wisp_stream_key(seed, (uint64_t)r);            // wave-uniform, same stream as the count kernel
     int64_t wr = begin;
-    for (int base = 0; base < n; base += 64) {
-        const int w = base >> 5;
-        unsigned long long m = hitmask[r * words + w];
-        if (w + 1 < words) m |= (unsigned long long)hitmask[r * words + w + 1] << 32;
-        if (m == 0ull) continue;
-        if ((m >> lane) & 1ull) {
-            const int s = base + lane;
-            const int64_t o = wr + __popcll(m & ((1ull << lane) - 1ull));
-            const float u = jitter ? jitter[r * n + s] : wisp_uniform01_keyed(key, (uint32_t)s);
-            const float t = ray_depth(s, n, step, u, fn, range, near);
-            float prev = near;                                   // depth.diff(prepend=near), octree_as.py:290-291
-            if (s > 0) {
-                const float up = jitter ? jitter[r * n + s - 1] : wisp_uniform01_keyed(key, (uint32_t)(s - 1));
-                prev = ray_depth(s - 1, n, step, up, fn, range, near);
+    // The ray's mask words are fetched 64 at a time with ONE coalesced load (lane = word) and only the 64-candidate chunks
+    // that hold a hit are visited; walking the words one by one put a dependent load in front of every (mostly empty) chunk.
+    for (int wg = 0; wg < words; wg += 64) {
+        const uint32_t mine = (wg + lane < words) ? hitmask[r * words + wg + lane] : 0u;
+        const unsigned long long nz = __ballot(mine != 0u);
+        unsigned long long pairs = (nz | (nz >> 1)) & 0x5555555555555555ull;     // bit 2c: chunk c of this group has a hit
+        while (pairs) {
+            const int b = __builtin_ctzll(pairs);                                // even word index, wave-uniform
+            pairs &= pairs - 1ull;
+            const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine, b) |
+                                         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine, b + 1) << 32);
+            const int base = (wg + b) << 5;
+            if ((m >> lane) & 1ull) {
+                const int s = base + lane;
+                const int64_t o = wr + __popcll(m & ((1ull << lane) - 1ull));
+                const float u = jitter ? jitter[r * n + s] : wisp_uniform01_keyed(key, (uint32_t)s);
+                const float t = ray_depth(s, n, step, u, fn, range, near);
+                float prev = near;                                   // depth.diff(prepend=near), octree_as.py:290-291
+                if (s > 0) {
+                    const float up = jitter ? jitter[r * n + s - 1] : wisp_uniform01_keyed(key, (uint32_t)(s - 1));
+                    prev = ray_depth(s - 1, n, step, up, fn, range, near);
+                }
+                ridx[o] = r;
+                samples[o * 3 + 0] = axpy_unfused(ox, dx, t);
+                samples[o * 3 + 1] = axpy_unfused(oy, dy, t);
+                samples[o * 3 + 2] = axpy_unfused(oz, dz, t);
+                depth_samples[o] = t;
+                deltas[o] = t - prev;
+                boundary[o] = (o == begin) ? 1 : 0;
+                if (sample_dirs) { sample_dirs[o * 3 + 0] = dx; sample_dirs[o * 3 + 1] = dy; sample_dirs[o * 3 + 2] = dz; }
             }
-            ridx[o] = r;
-            samples[o * 3 + 0] = axpy_unfused(ox, dx, t);
-            samples[o * 3 + 1] = axpy_unfused(oy, dy, t);
-            samples[o * 3 + 2] = axpy_unfused(oz, dz, t);
-            depth_samples[o] = t;
-            deltas[o] = t - prev;
-            boundary[o] = (o == begin) ? 1 : 0;
+            wr += __popcll(m);
         }
-        wr += __popcll(m);
     }
 }
 
@@ -243,13 +252,13 @@ extern "C" int wisp_raymarch_ray_count(const uint32_t* occ_bits, const uint8_t* 
 extern "C" int wisp_raymarch_ray_emit(const float* origins, const float* dirs, int64_t num_rays, float near, float range,
                                       int num_samples, const float* jitter, uint64_t seed, const uint32_t* hitmask,
                                       const int64_t* offsets, int64_t* ridx, float* samples, float* depth_samples,
-                                      float* deltas, uint8_t* boundary, wisp_stream_t stream) {
+                                      float* deltas, uint8_t* boundary, float* sample_dirs, wisp_stream_t stream) {
     WISP_REQUIRE(num_rays >= 0 && num_samples >= 1, "bad sizes");
     if (num_rays == 0) return WISP_OK;
     WISP_REQUIRE(origins && dirs && hitmask && offsets, "null pointer");
     hipLaunchKernelGGL(raymarch_ray_emit_kernel, dim3((unsigned)ceil_div64(num_rays, 4)), dim3(256), 0,
                        (hipStream_t)stream, origins, dirs, num_rays, near, range, num_samples, jitter, seed, hitmask,
-                       offsets, ridx, samples, depth_samples, deltas, boundary);
+                       offsets, ridx, samples, depth_samples, deltas, boundary, sample_dirs);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }

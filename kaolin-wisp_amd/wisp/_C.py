@@ -55,7 +55,7 @@ SIGNATURES = {
     "wisp_boundary_tile_counts": [c_vp, c_i64, c_vp, c_vp],
     "wisp_boundary_pack_starts": [c_vp, c_i64, c_vp, c_vp, c_vp],
     "wisp_raymarch_ray_count": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_i32, c_i32, c_vp, c_u64, c_vp, c_i32, c_vp, c_vp, c_vp],
-    "wisp_raymarch_ray_emit": [c_vp, c_vp, c_i64, c_f32, c_f32, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_raymarch_ray_emit": [c_vp, c_vp, c_i64, c_f32, c_f32, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_voxel_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_uniform_count": [c_vp, c_i64, c_f32, c_vp, c_vp],
     "wisp_raymarch_uniform_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
@@ -530,17 +530,21 @@ def _total(st):
     return total
 
 
-def raymarch_ray_finish(st):
+def raymarch_ray_finish(st, with_dirs=False):
     """Second half: read the sample count back (the reference syncs here too: nonzero, octree_as.py:288), allocate and
-    emit.  Returns (ridx, samples, depth, deltas, boundary, ray_offsets)."""
+    emit.  Returns (ridx, samples, depth, deltas, boundary, ray_offsets) - plus the per-sample view directions
+    dirs[ridx] ([S,3], what packed_rf_tracer.py:120 gathers) when with_dirs is set."""
     origins, offsets = st["origins"], st["offsets"]
     R, dev = origins.shape[0], origins.device
     S = _total(st)
     ridx, samples, depth, deltas, boundary = _alloc_samples(S, dev)
+    sample_dirs = torch.empty(S, 3, dtype=torch.float32, device=dev) if with_dirs else None
     if S:
         _check(lib.wisp_raymarch_ray_emit(_p(origins), _p(st["dirs"]), R, st["near32"], st["range32"], st["num_samples"],
                                           _p(st["jitter"]), st["seed"], _p(st["hitmask"]), _p(offsets), _p(ridx), _p(samples),
-                                          _p(depth), _p(deltas), _p(boundary), _stream()), "raymarch_ray_emit")
+                                          _p(depth), _p(deltas), _p(boundary), _p(sample_dirs), _stream()), "raymarch_ray_emit")
+    if with_dirs:
+        return ridx, samples, depth, deltas, boundary, offsets, sample_dirs
     return ridx, samples, depth, deltas, boundary, offsets
 
 

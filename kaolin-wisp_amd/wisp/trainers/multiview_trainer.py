@@ -146,12 +146,11 @@ class _DirectHashNeRFStep:
             st = self._count(rays, jitter)                # nothing was prefetched for this batch
         elif st["blas"] is not blas:
             st = self._count(rays, None, seed=st["seed"])  # the octree was pruned since: redo it (same jitter stream)
-        ridx, samples, depths, deltas, boundary, offsets = C.raymarch_ray_finish(st)
+        ridx, samples, depths, deltas, boundary, offsets, dirs = C.raymarch_ray_finish(st, with_dirs=True)
         if prefetch is not None:
             self._pending = self._count(prefetch, None)
         S = samples.shape[0]
         tracer.prev_num_samples = S
-        dirs = rays.dirs.index_select(0, ridx)
         t.wait_for_parameters()                 # everything above overlapped the previous step's all-reduce + update
         table = self.table
         if t.enable_amp:

@@ -257,6 +257,10 @@ def test_raymarch_ray_bit_exact(tree, level):
                                 coarse_bits=_C().spc_bitfield(cuda(cpts), lc), coarse_level=lc)
         assert np.array_equal(got[0].cpu().numpy(), want["ridx"]) and np.array_equal(got[1].cpu().numpy(), want["samples"])
         assert np.array_equal(got[4].cpu().numpy(), want["boundary"]) and np.array_equal(got[3].cpu().numpy(), want["deltas"])
+    # optional per-sample view directions = dirs[ridx] (the gather of packed_rf_tracer.py:120 folded into the emit kernel)
+    st = _C().raymarch_ray_count(bits, cuda(oc), cuda(ex), cuda(o), cuda(d), 1.0, 5.0, N, level, cuda(jit))
+    out = _C().raymarch_ray_finish(st, with_dirs=True)
+    assert np.array_equal(out[0].cpu().numpy(), want["ridx"]) and torch.equal(out[6], cuda(d).index_select(0, out[0]))
     # in-kernel jitter: same structure invariants, reproducible for a fixed seed, different across seeds
     a = _C().raymarch_ray(bits, cuda(oc), cuda(ex), cuda(o), cuda(d), 1.0, 5.0, N, level, None, seed=7)
     b = _C().raymarch_ray(bits, cuda(oc), cuda(ex), cuda(o), cuda(d), 1.0, 5.0, N, level, None, seed=7)
