@@ -9,20 +9,28 @@
 // fused into the same kernel.
 #include "wisp_common.h"
 
-static __device__ __forceinline__ float wave_incl_scan_f(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+// Wave-wide inclusive scan / sum on the VALU (DPP), no LDS traffic: Hillis-Steele inside each 16-lane row (row_shr 1, 2, 4, 8),
+// then the row totals travel with row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3).  Lanes without a
+// source add 0.  These kernels run one wave per ray and are bound by the LATENCY of their dependent chain - with
+// ds_bpermute shuffles (~100+ cycles each, 30-50 per ray) that chain was most of the kernel.
+#define WISP_DPP_ADD(V, CTRL, RMASK)                                                                                  \
+    V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, RMASK, 0xf, false))
+static __device__ __forceinline__ float wave_incl_scan_f(float v, int /*lane*/) {
+    WISP_DPP_ADD(v, 0x111, 0xf);      // row_shr:1
+    WISP_DPP_ADD(v, 0x112, 0xf);      // row_shr:2
+    WISP_DPP_ADD(v, 0x114, 0xf);      // row_shr:4
+    WISP_DPP_ADD(v, 0x118, 0xf);      // row_shr:8
+    WISP_DPP_ADD(v, 0x142, 0xa);      // row_bcast:15 -> rows 1, 3
+    WISP_DPP_ADD(v, 0x143, 0xc);      // row_bcast:31 -> rows 2, 3
     return v;
+}
+#undef WISP_DPP_ADD
+
+static __device__ __forceinline__ float wave_last_f(float v) {      // value of lane 63, wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-static __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
+static __device__ __forceinline__ float wave_sum_f(float v) { return wave_last_f(wave_incl_scan_f(v, 0)); }
 
 // ---------------------------------------------------------------------------------------------- generic pack ops
 __global__ void __launch_bounds__(256)
@@ -57,7 +65,7 @@ packed_cumsum_kernel(const float* __restrict__ feats, int64_t s_total, int chann
             const float v = (k < len) ? feats[i * channels + c] : 0.0f;
             const float inc = wave_incl_scan_f(v, lane);
             if (k < len) out[i * channels + c] = carry + (exclusive ? inc - v : inc);
-            carry += __shfl(inc, 63, 64);
+            carry += wave_last_f(inc);
         }
     }
 }
@@ -128,7 +136,7 @@ composite_fwd_kernel(const float* __restrict__ color, const float* __restrict__ 
         const float tau = live ? density[i] * deltas[i] : 0.0f;           // :152
         const float inc = wave_incl_scan_f(tau, lane);
         const float excl = carry + (inc - tau);
-        carry += __shfl(inc, 63, 64);
+        carry += wave_last_f(inc);
         if (live) {
             const float T = expf(-excl);                                  // exponential_integration, exclusive=True
             const float w = T * (1.0f - expf(-tau));
@@ -177,7 +185,7 @@ composite_bwd_kernel(const float* __restrict__ grad_rgb, const float* __restrict
         const float tau = live ? density[i] * deltas[i] : 0.0f;
         const float inc = wave_incl_scan_f(tau, lane);
         const float excl = carry + (inc - tau);
-        carry += __shfl(inc, 63, 64);
+        carry += wave_last_f(inc);
         if (live) {
             const float w = expf(-excl) * (1.0f - expf(-tau));
             float G = gr * (color[i * 3] - bg.r) + gg * (color[i * 3 + 1] - bg.g) + gb * (color[i * 3 + 2] - bg.b) + ga;
@@ -196,7 +204,7 @@ composite_bwd_kernel(const float* __restrict__ grad_rgb, const float* __restrict
         const float tau = live ? density[i] * dl : 0.0f;
         const float inc = wave_incl_scan_f(tau, lane);
         const float excl = carry + (inc - tau);
-        carry += __shfl(inc, 63, 64);
+        carry += wave_last_f(inc);
         float T = 0.0f, et = 0.0f, w = 0.0f, G = 0.0f;
         if (live) {
             T = expf(-excl); et = expf(-tau); w = T * (1.0f - et);
@@ -206,7 +214,7 @@ composite_bwd_kernel(const float* __restrict__ grad_rgb, const float* __restrict
         const float gw = G * w;
         const float ginc = wave_incl_scan_f(gw, lane);
         const float suffix = tot - (gcarry + ginc);
-        gcarry += __shfl(ginc, 63, 64);
+        gcarry += wave_last_f(ginc);
         if (live) {
             grad_color[i * 3] = w * gr; grad_color[i * 3 + 1] = w * gg; grad_color[i * 3 + 2] = w * gb;
             grad_density[i] = (G * T * et - suffix) * dl;
@@ -501,3 +509,4 @@ extern "C" int wisp_rgb_loss(const float* rgb, const float* gt, int64_t num_elem
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
