@@ -331,6 +331,14 @@ int wisp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                     float grad_scale, int zero_grad /* also zero grad[] */, void* bf16_shadow,
                     wisp_stream_t stream);
+/* The same update for up to 4 parameter groups of ONE flat buffer in one launch - the optimizer's param groups
+ * ('decoder' / 'grid' / rest with their own learning rates, base_trainer.py:216-235).  group_begin / group_len (elements,
+ * begin a multiple of 4), group_lr, group_weight_decay, group_bf16_shadow (device pointers, bf16 [len], or NULL entries /
+ * a NULL array) are HOST arrays of num_groups entries. */
+int wisp_adamw_step_groups(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int num_groups,
+                           const int64_t* group_begin, const int64_t* group_len, const float* group_lr,
+                           const float* group_weight_decay, void* const* group_bf16_shadow, float beta1, float beta2,
+                           float eps, int64_t step, float grad_scale, int zero_grad, wisp_stream_t stream);
 
 #ifdef __cplusplus
 }

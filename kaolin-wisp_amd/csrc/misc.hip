@@ -72,3 +72,92 @@ extern "C" int wisp_adamw_step(float* param, const float* grad, float* exp_avg, 
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---- several parameter groups of ONE flat buffer in one launch (decoder | grid | rest, each with its own learning rate:
+// base_trainer.py:216-235).  The decoder group is ~10 K parameters: as a launch of its own it costs more timeline than
+// arithmetic.  Work is indexed by 4-float chunks across the groups; the arithmetic is adamw_kernel's.
+#define ADAMW_MAX_GROUPS 4
+struct AdamGroups {
+    int n;
+    int64_t begin[ADAMW_MAX_GROUPS], len[ADAMW_MAX_GROUPS], chunk0[ADAMW_MAX_GROUPS + 1];
+    float lr[ADAMW_MAX_GROUPS], wd[ADAMW_MAX_GROUPS];
+    __hip_bfloat16* shadow[ADAMW_MAX_GROUPS];
+};
+
+__global__ void __launch_bounds__(256)
+adamw_groups_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                    AdamGroups gr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale, int zero_grad) {
+    const int64_t total = gr.chunk0[gr.n];
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < ADAMW_MAX_GROUPS; ++q) k += (q < gr.n && c >= gr.chunk0[q]) ? 1 : 0;
+        const int64_t off = (c - gr.chunk0[k]) * 4;                 // inside the group
+        const int64_t i = gr.begin[k] + off;
+        const int cnt = (int)(gr.len[k] - off < 4 ? gr.len[k] - off : 4);
+        const float lr = gr.lr[k], wd = gr.wd[k];
+        __hip_bfloat16* shadow = gr.shadow[k];
+        float pv[4], gv[4], mv[4], vv[4];
+        if (cnt == 4) {
+            *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + i);
+            *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + i);
+            *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m + i);
+            *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v + i);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pv[e] = e < cnt ? p[i + e] : 0.f; gv[e] = e < cnt ? g[i + e] : 0.f; mv[e] = e < cnt ? m[i + e] : 0.f; vv[e] = e < cnt ? v[i + e] : 0.f; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = gv[e] * gscale;
+            pv[e] *= (1.0f - lr * wd);
+            mv[e] = b1 * mv[e] + (1.0f - b1) * x;
+            vv[e] = b2 * vv[e] + (1.0f - b2) * x * x;
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            pv[e] -= (lr / bc1) * (mv[e] / denom);
+        }
+        if (cnt == 4) {
+            *reinterpret_cast<float4*>(p + i) = *reinterpret_cast<float4*>(pv);
+            *reinterpret_cast<float4*>(m + i) = *reinterpret_cast<float4*>(mv);
+            *reinterpret_cast<float4*>(v + i) = *reinterpret_cast<float4*>(vv);
+            if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < cnt) { p[i + e] = pv[e]; m[i + e] = mv[e]; v[i + e] = vv[e]; if (zero_grad) g[i + e] = 0.0f; }
+        }
+        if (shadow) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < cnt) shadow[off + e] = __float2bfloat16(pv[e]);
+        }
+    }
+}
+
+extern "C" int wisp_adamw_step_groups(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int num_groups,
+                                      const int64_t* group_begin, const int64_t* group_len, const float* group_lr,
+                                      const float* group_weight_decay, void* const* group_bf16_shadow, float beta1,
+                                      float beta2, float eps, int64_t step, float grad_scale, int zero_grad,
+                                      wisp_stream_t stream) {
+    WISP_REQUIRE(num_groups >= 1 && num_groups <= ADAMW_MAX_GROUPS && step >= 1, "bad group count / step");
+    WISP_REQUIRE(param && grad && exp_avg && exp_avg_sq && group_begin && group_len && group_lr && group_weight_decay, "null pointer");
+    WISP_REQUIRE(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)exp_avg % 16 == 0) &&
+                 ((uintptr_t)exp_avg_sq % 16 == 0), "buffers must be 16-byte aligned");
+    AdamGroups gr{};
+    gr.n = num_groups;
+    gr.chunk0[0] = 0;
+    for (int k = 0; k < num_groups; ++k) {
+        WISP_REQUIRE(group_begin[k] >= 0 && group_len[k] >= 0 && group_begin[k] % 4 == 0, "group ranges must start on a 16-byte boundary");
+        gr.begin[k] = group_begin[k]; gr.len[k] = group_len[k];
+        gr.lr[k] = group_lr[k]; gr.wd[k] = group_weight_decay[k];
+        gr.shadow[k] = group_bf16_shadow ? (__hip_bfloat16*)group_bf16_shadow[k] : nullptr;
+        gr.chunk0[k + 1] = gr.chunk0[k] + ceil_div64(group_len[k], 4);
+    }
+    if (gr.chunk0[num_groups] == 0) return WISP_OK;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    const int grid = (int)min64(ceil_div64(gr.chunk0[num_groups], 256), 4096);
+    hipLaunchKernelGGL(adamw_groups_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, const_cast<float*>(grad),
+                       exp_avg, exp_avg_sq, gr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, zero_grad);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

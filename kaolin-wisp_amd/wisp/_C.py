@@ -63,6 +63,7 @@ SIGNATURES = {
     "wisp_packed_cumsum": [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "wisp_find_depth_bound": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp],
     "wisp_sphere_trace_step": [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_adamw_step_groups": [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp],
     "wisp_rgb_loss": [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
     "wisp_generate_rays": [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_composite_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
@@ -717,6 +718,25 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_d
         assert bf16_shadow.dtype == torch.bfloat16 and bf16_shadow.numel() == param.numel() and bf16_shadow.is_contiguous()
     _check(lib.wisp_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2, eps,
                                weight_decay, step, grad_scale, int(zero_grad), _p(bf16_shadow), _stream()), "adamw_step")
+
+
+def adamw_step_groups(param, grad, exp_avg, exp_avg_sq, groups, beta1, beta2, eps, step, grad_scale=1.0, zero_grad=False):
+    """One launch for several parameter groups of a flat buffer.  groups: list of (begin, length, lr, weight_decay,
+    bf16_shadow or None) with `begin` a multiple of 4 elements."""
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    n = len(groups)
+    begin = (ctypes.c_int64 * n)(*[int(g[0]) for g in groups])
+    length = (ctypes.c_int64 * n)(*[int(g[1]) for g in groups])
+    lr = (ctypes.c_float * n)(*[float(g[2]) for g in groups])
+    wd = (ctypes.c_float * n)(*[float(g[3]) for g in groups])
+    for g in groups:
+        assert g[0] + g[1] <= param.numel()
+        if g[4] is not None:
+            assert g[4].dtype == torch.bfloat16 and g[4].numel() == g[1] and g[4].is_contiguous()
+    shadow = (ctypes.c_void_p * n)(*[(g[4].data_ptr() if g[4] is not None else None) for g in groups])
+    _check(lib.wisp_adamw_step_groups(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, begin, length, lr, wd, shadow,
+                                      beta1, beta2, eps, step, grad_scale, int(zero_grad), _stream()), "adamw_step_groups")
 
 
 # ------------------------------------------------------------------------------------------------ fused NeRF decoder

@@ -226,12 +226,14 @@ class MultiviewTrainStep:
         s = self._lr_scale()
         f = self.flat
         gs = 1.0 / self.world
+        groups = []
         for g, lr in (("decoder", self.lr), ("grid", self.lr * self.grid_lr_weight), ("rest", self.lr)):
             a, b = f.ranges[g]
             if b > a:
-                C.adamw_step(f.data[a:b], f.grad[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], lr * s, self.betas[0],
-                             self.betas[1], self.eps, self.weight_decay, self.opt_steps, grad_scale=gs, zero_grad=True,
-                             bf16_shadow=f.shadow if g == "grid" else None)
+                groups.append((a, b - a, lr * s, self.weight_decay, f.shadow if g == "grid" else None))
+        # all parameter groups in ONE launch (the decoder group alone is ~10 K parameters)
+        C.adamw_step_groups(f.data, f.grad, f.exp_avg, f.exp_avg_sq, groups, self.betas[0], self.betas[1], self.eps,
+                            self.opt_steps, grad_scale=gs, zero_grad=True)
 
     def allreduce_grads(self):
         if self.world > 1 or self.force_allreduce:

@@ -395,6 +395,38 @@ def test_adamw_matches_torch():
     np.testing.assert_allclose(p.cpu().numpy(), ref.detach().cpu().numpy(), atol=2e-6)
 
 
+def test_adamw_groups_equal_one_launch_per_group():
+    """wisp_adamw_step_groups (all optimizer param groups of the flat buffer in one launch) against wisp_adamw_step run once
+    per group: bit-identical parameters, moments, zeroed gradients and bf16 shadow; group lengths not multiples of 4."""
+    torch.manual_seed(4)
+    lens = [10259, 70001, 6]                      # decoder-like, grid-like, a tiny 'rest'
+    begins, off = [], 0
+    for k in lens:
+        begins.append(off); off += (k + 3) // 4 * 4
+    n = off
+    base = [torch.randn(n, device=DEV) for _ in range(2)]
+    lrs, wds = [1e-2, 5.0, 3e-3], [1e-3, 0.0, 1e-2]
+    def fresh():
+        return base[0].clone(), base[1].clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pa, ga, ma, va = fresh()
+    pb, gb, mb, vb = fresh()
+    sh_a = torch.zeros(lens[1], dtype=torch.bfloat16, device=DEV); sh_b = torch.zeros_like(sh_a)
+    for step in (1, 2):
+        ga.copy_(base[1] * step); gb.copy_(base[1] * step)
+        for k in range(3):
+            a, b = begins[k], begins[k] + lens[k]
+            _C().adamw_step(pa[a:b], ga[a:b], ma[a:b], va[a:b], lrs[k], 0.9, 0.99, 1e-15, wds[k], step, grad_scale=0.25,
+                            zero_grad=True, bf16_shadow=sh_a if k == 1 else None)
+        _C().adamw_step_groups(pb, gb, mb, vb, [(begins[k], lens[k], lrs[k], wds[k], sh_b if k == 1 else None) for k in range(3)],
+                               0.9, 0.99, 1e-15, step, grad_scale=0.25, zero_grad=True)
+        for x, y in ((pa, pb), (ma, mb), (va, vb), (sh_a, sh_b)):
+            assert torch.equal(x, y)
+        for k in range(3):
+            assert float(gb[begins[k]:begins[k] + lens[k]].abs().max()) == 0.0
+        pad = begins[1] - lens[0]                                   # padding between groups is never touched
+        assert pad > 0 and torch.equal(pb[lens[0]:begins[1]], base[0][lens[0]:begins[1]])
+
+
 # ------------------------------------------------------------------------------------------------ end to end
 def _build_pair(level=4, bitwidth=12, lods=16, hidden=64):
     from wisp.accelstructs import OctreeAS
