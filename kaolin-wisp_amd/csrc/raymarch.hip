@@ -91,6 +91,8 @@ static __device__ __forceinline__ bool coarse_segment_occupied(const uint32_t* s
 }
 
 #define RM_COARSE_MAX_LEVEL 5          // 32^3 bits = 4 KiB of LDS
+#define RAY_WAVES 1                    // rays (waves) per workgroup of the count / emit kernels: rays differ a lot in work, and a
+                                       // workgroup keeps its slots until its slowest ray is done (4 -> 1: -3 us on count, -1.5 on emit)
 
 __global__ void __launch_bounds__(256)
 raymarch_ray_count_kernel(const uint32_t* __restrict__ occ_bits, const uint8_t* __restrict__ octree,
@@ -242,7 +244,7 @@ extern "C" int wisp_raymarch_ray_count(const uint32_t* occ_bits, const uint8_t* 
     WISP_REQUIRE(!occ_bits || level <= 10, "bitfield path supports level <= 10");
     WISP_REQUIRE(!coarse_bits || (coarse_level >= 0 && coarse_level <= RM_COARSE_MAX_LEVEL && coarse_level <= level),
                  "coarse_level out of range");
-    hipLaunchKernelGGL(raymarch_ray_count_kernel, dim3((unsigned)ceil_div64(num_rays, 4)), dim3(256), 0,
+    hipLaunchKernelGGL(raymarch_ray_count_kernel, dim3((unsigned)ceil_div64(num_rays, RAY_WAVES)), dim3(64 * RAY_WAVES), 0,
                        (hipStream_t)stream, occ_bits, octree, exsum, origins, dirs, num_rays, near, range, num_samples,
                        level, jitter, seed, coarse_bits, coarse_level, hitmask, counts);
     WISP_CHECK_LAUNCH();
@@ -256,7 +258,7 @@ extern "C" int wisp_raymarch_ray_emit(const float* origins, const float* dirs, i
     WISP_REQUIRE(num_rays >= 0 && num_samples >= 1, "bad sizes");
     if (num_rays == 0) return WISP_OK;
     WISP_REQUIRE(origins && dirs && hitmask && offsets, "null pointer");
-    hipLaunchKernelGGL(raymarch_ray_emit_kernel, dim3((unsigned)ceil_div64(num_rays, 4)), dim3(256), 0,
+    hipLaunchKernelGGL(raymarch_ray_emit_kernel, dim3((unsigned)ceil_div64(num_rays, RAY_WAVES)), dim3(64 * RAY_WAVES), 0,
                        (hipStream_t)stream, origins, dirs, num_rays, near, range, num_samples, jitter, seed, hitmask,
                        offsets, ridx, samples, depth_samples, deltas, boundary, sample_dirs);
     WISP_CHECK_LAUNCH();

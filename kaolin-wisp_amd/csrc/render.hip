@@ -95,6 +95,10 @@ extern "C" int wisp_packed_cumsum(const float* feats, int64_t num_samples, int c
 // ---------------------------------------------------------------------------------------------- fused compositing
 struct Bg { float r, g, b; };
 
+// One wave per ray, ONE wave per workgroup: these kernels are bound by the latency of a ray's dependent chain, and a
+// workgroup of several rays holds its slots until its longest ray is done (4 -> 1 waves per workgroup: -2 us per kernel).
+#define PACK_WAVES 1
+
 __global__ void __launch_bounds__(256)
 composite_init_kernel(int64_t num_rays, Bg bg, float* __restrict__ rgb, float* __restrict__ alpha,
                       float* __restrict__ depth, uint8_t* __restrict__ hit) {
@@ -237,7 +241,7 @@ extern "C" int wisp_composite_fwd(const float* color, const float* density, cons
     if (ridx == nullptr) {      // per-ray offsets mode: pack_starts = ray_offsets [num_rays + 1], num_packs must equal num_rays
         WISP_REQUIRE(pack_starts && num_packs == num_rays, "ray-offset mode needs offsets[R+1] and num_packs == num_rays");
         WISP_REQUIRE(num_samples == 0 || (color && density && deltas && weights), "null pointer");
-        hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3((unsigned)ceil_div64(num_rays, 4)), dim3(256), 0, s, color,
+        hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3((unsigned)ceil_div64(num_rays, PACK_WAVES)), dim3(64 * PACK_WAVES), 0, s, color,
                            density, deltas, out_depth ? depths : nullptr, ridx, pack_starts, num_rays, num_samples, b,
                            out_rgb, out_alpha, out_depth, out_hit, weights);
         WISP_CHECK_LAUNCH();
@@ -265,7 +269,7 @@ extern "C" int wisp_composite_bwd(const float* grad_rgb, const float* grad_alpha
     WISP_REQUIRE(grad_rgb && color && density && deltas && pack_starts && grad_color && grad_density, "null pointer");
     const Bg b{bg[0], bg[1], bg[2]};
     if (ridx == nullptr)        // per-ray offsets mode (see wisp_composite_fwd): num_packs = number of rays
-        hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3((unsigned)ceil_div64(num_packs, 4)), dim3(256), 0,
+        hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3((unsigned)ceil_div64(num_packs, PACK_WAVES)), dim3(64 * PACK_WAVES), 0,
                            (hipStream_t)stream, grad_rgb, grad_alpha, grad_depth, color, density, deltas, depths, ridx,
                            pack_starts, num_packs, num_samples, b, grad_color, grad_density);
     else
