@@ -123,8 +123,8 @@ def main():
 
     def batch(n):
         idx = torch.randint(0, bank_o.shape[0], (n,), device=dev, generator=gen)
-        return Rays(bank_o.index_select(0, idx), bank_d.index_select(0, idx), dist_min=synlego.NEAR, dist_max=synlego.FAR), \
-            bank_rgb.index_select(0, idx)
+        o, d, rgb = C.gather_rows(idx, [bank_o, bank_d, bank_rgb])       # SampleRays: one launch for the three gathers
+        return Rays(o, d, dist_min=synlego.NEAR, dist_max=synlego.FAR), rgb
 
     # warm-up raymarch sizes the batch like MultiviewTrainer.step's first call (multiview_trainer.py:119-122)
     rays, _ = batch(4096)

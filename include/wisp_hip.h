@@ -340,6 +340,14 @@ int wisp_adamw_step_groups(float* param, const float* grad, float* exp_avg, floa
                            const float* group_weight_decay, void* const* group_bf16_shadow, float beta1, float beta2,
                            float eps, int64_t step, float grad_scale, int zero_grad, wisp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Ray-batch sampling (replaces the per-tensor index_select of SampleRays,
+ * wisp/datasets/transforms/ray_sampler.py:25-35): dst[k][i, :] = src[k][index[i], :] for up to 4 row-major f32 tensors
+ * of num_src_rows rows sharing one index vector (i64 [num], negative entries count from the end).  src / width / dst are
+ * HOST arrays of num_tensors device pointers / row widths. */
+int wisp_gather_rows(const int64_t* index, int64_t num, int64_t num_src_rows, int num_tensors, const float* const* src,
+                     const int* width, float* const* dst, wisp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

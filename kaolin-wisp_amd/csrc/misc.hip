@@ -161,3 +161,39 @@ extern "C" int wisp_adamw_step_groups(float* param, const float* grad, float* ex
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---- ray-batch sampling: out_k[i, :] = src_k[index[i], :] for up to 4 row-major fp32 tensors that share ONE index vector
+// (SampleRays, wisp/datasets/transforms/ray_sampler.py:25-35, picks the same random rays out of origins / dirs / rgb /
+// further per-ray channels: one index_select launch each in the reference).  One launch, one pass over the index.
+#define GATHER_MAX_SRCS 4
+struct GatherSrcs { int n; const float* src[GATHER_MAX_SRCS]; float* dst[GATHER_MAX_SRCS]; int width[GATHER_MAX_SRCS]; };
+
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const int64_t* __restrict__ index, int64_t num, int64_t num_src_rows, GatherSrcs g) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num) return;
+    int64_t r = index[i];
+    if (r < 0) r += num_src_rows;                                   // torch indexing semantics
+    for (int k = 0; k < g.n; ++k) {
+        const float* __restrict__ s = g.src[k] + r * g.width[k];
+        float* __restrict__ d = g.dst[k] + i * g.width[k];
+        for (int c = 0; c < g.width[k]; ++c) d[c] = s[c];
+    }
+}
+
+extern "C" int wisp_gather_rows(const int64_t* index, int64_t num, int64_t num_src_rows, int num_tensors,
+                                const float* const* src, const int* width, float* const* dst, wisp_stream_t stream) {
+    WISP_REQUIRE(num >= 0 && num_src_rows >= 0 && num_tensors >= 1 && num_tensors <= GATHER_MAX_SRCS, "bad sizes");
+    if (num == 0) return WISP_OK;
+    WISP_REQUIRE(index && src && width && dst && num_src_rows > 0, "null pointer");
+    GatherSrcs g{};
+    g.n = num_tensors;
+    for (int k = 0; k < num_tensors; ++k) {
+        WISP_REQUIRE(src[k] && dst[k] && width[k] >= 1, "null tensor / bad width");
+        g.src[k] = src[k]; g.dst[k] = dst[k]; g.width[k] = width[k];
+    }
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div64(num, 256)), dim3(256), 0, (hipStream_t)stream, index, num,
+                       num_src_rows, g);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

@@ -64,6 +64,7 @@ SIGNATURES = {
     "wisp_find_depth_bound": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp],
     "wisp_sphere_trace_step": [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_adamw_step_groups": [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp],
+    "wisp_gather_rows": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
     "wisp_rgb_loss": [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
     "wisp_generate_rays": [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_composite_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
@@ -718,6 +719,27 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_d
         assert bf16_shadow.dtype == torch.bfloat16 and bf16_shadow.numel() == param.numel() and bf16_shadow.is_contiguous()
     _check(lib.wisp_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2, eps,
                                weight_decay, step, grad_scale, int(zero_grad), _p(bf16_shadow), _stream()), "adamw_step")
+
+
+def gather_rows(index, tensors):
+    """[t[index] for t in tensors] for up to 4 fp32 tensors with the same number of rows - one launch, one read of `index`
+    (the ray-batch sampling of SampleRays, ray_sampler.py:25-35)."""
+    index = _need(index, torch.int64, "index").reshape(-1)
+    assert 1 <= len(tensors) <= 4
+    rows = tensors[0].shape[0]
+    srcs, outs = [], []
+    for t in tensors:
+        t = _need(t, torch.float32, "tensor")
+        assert t.shape[0] == rows and t.is_contiguous()
+        srcs.append(t)
+        outs.append(torch.empty((index.shape[0],) + tuple(t.shape[1:]), dtype=torch.float32, device=t.device))
+    n = len(srcs)
+    widths = [int(t.numel() // max(rows, 1)) for t in srcs]
+    src_p = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    dst_p = (ctypes.c_void_p * n)(*[t.data_ptr() for t in outs])
+    w_p = (ctypes.c_int * n)(*widths)
+    _check(lib.wisp_gather_rows(_p(index), index.shape[0], rows, n, src_p, w_p, dst_p, _stream()), "gather_rows")
+    return outs
 
 
 def adamw_step_groups(param, grad, exp_avg, exp_avg_sq, groups, beta1, beta2, eps, step, grad_scale=1.0, zero_grad=False):

@@ -942,6 +942,27 @@ def test_ray_generation_matches_oracle():
     np.testing.assert_allclose(r.origins[0].cpu().numpy(), np.array(cam0.eye), atol=2e-6)
 
 
+def test_sample_rays_one_launch_gather_equals_indexing():
+    """SampleRays on GPU tensors gathers origins / dirs / rgb with ONE wisp_gather_rows launch: same rays as tensor indexing
+    with the same random indices (ray_sampler.py:25-35), negative indices included at the C-ABI level."""
+    from wisp.core import Rays
+    from wisp.datasets import MultiviewBatch, SampleRays
+    g = torch.Generator(device=DEV).manual_seed(9)
+    n = 70001
+    o = torch.randn(n, 3, device=DEV, generator=g); d = torch.randn(n, 3, device=DEV, generator=g)
+    rgb = torch.rand(n, 3, device=DEV, generator=g); wide = torch.rand(n, 5, device=DEV, generator=g)
+    idx = torch.randint(-n, n, (4099,), device=DEV, generator=g)
+    got = _C().gather_rows(idx, [o, d, rgb, wide])
+    for t, q in zip((o, d, rgb, wide), got):
+        assert torch.equal(q, t[idx])
+    batch = MultiviewBatch(rays=Rays(o, d, dist_min=1.0, dist_max=5.0), rgb=rgb)
+    g1 = torch.Generator(device=DEV).manual_seed(3); g2 = torch.Generator(device=DEV).manual_seed(3)
+    out = SampleRays(777)(batch, generator=g1)
+    ridx = torch.randint(0, n, [777], device=DEV, generator=g2)
+    assert torch.equal(out['rays'].origins, o[ridx]) and torch.equal(out['rays'].dirs, d[ridx]) and torch.equal(out['rgb'], rgb[ridx])
+    assert out['rays'].dist_min == 1.0 and out['rays'].dist_max == 5.0
+
+
 @pytest.mark.parametrize("kind", ["huber", "l2", "l1"])
 def test_rgb_loss_matches_torch_autograd(kind):
     """wisp_rgb_loss (loss + gradient in one launch) against torch's loss functions and their autograd backward,
