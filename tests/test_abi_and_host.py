@@ -38,6 +38,19 @@ def test_hot_path_refuses_cpu_tensors():
         blas.query(torch.zeros(4, 3))
 
 
+def test_raymarch_coarse_level_choice():
+    """Host-side choice of the occupancy level the 'ray' count kernel stages in LDS: the level whose cell is about one
+    64-candidate chunk long, never finer than level 5 (LDS budget) nor than marching level - 1."""
+    import wisp._C as C
+    assert C.raymarch_coarse_level(1.0, 5.0, 2048, 7) == 4          # nerf_hash.yaml: chunk 0.125 = a level-4 cell
+    assert C.raymarch_coarse_level(1.0, 5.0, 512, 7) == 2           # chunk 0.5
+    assert C.raymarch_coarse_level(1.0, 5.0, 65536, 9) == 5         # capped by the LDS budget
+    assert C.raymarch_coarse_level(1.0, 5.0, 2048, 3) == 2          # capped by the marching level
+    assert C.raymarch_coarse_level(1.0, 5.0, 64, 7) is None         # one chunk spans the whole scene
+    assert C.raymarch_coarse_level(2.0, 2.0, 128, 7) is None        # empty depth range
+    assert C.raymarch_coarse_level(0.0, 6.0, 1024, 1) is None       # nothing coarser than level 1 is worth a test
+
+
 def test_no_product_code_imports_the_oracle():
     pkg = os.path.join(ROOT, "kaolin-wisp_amd")
     for dirpath, _, files in os.walk(pkg):
