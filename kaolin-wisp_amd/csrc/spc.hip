@@ -317,34 +317,68 @@ extern "C" int64_t wisp_scan_workspace_bytes(int64_t n) {
 }
 
 // Up to 64 K values (the per-ray sample counts of one training batch): ONE launch, every workgroup independent.
-// Workgroup b owns values [1024 b, 1024 b + 1024) and simply re-sums everything in front of them (coalesced 16-byte loads of
-// at most 256 KiB that sit in L2) instead of waiting for anybody: no spine kernel, no look-back flags, and the longest
+// Workgroup b owns values [4096 b, 4096 b + 4096) and simply re-sums everything in front of them (coalesced 16-byte loads of
+// at most 240 KiB that sit in L2) instead of waiting for anybody: no spine kernel, no look-back flags, and the longest
 // workgroup reads what ONE workgroup of a serial scan would have read anyway.  (History: a one-workgroup version took 89 us
 // for 50 K values with strided per-thread runs and still 37 us with coalesced tiles - one CU cannot move the data faster;
 // a launch costs ~5 us of timeline on this stack, so the three-kernel tile scan below is kept for long inputs only.)
-#define SC1_TILE (SC_THREADS * 4)
-#define SC1_MAX (64 * 1024)
-__global__ void __launch_bounds__(SC_THREADS)
-scan_small_kernel(const int32_t* __restrict__ in, int n, int64_t* __restrict__ out) {
-    const int tile0 = blockIdx.x * SC1_TILE;
-    int64_t part = 0;
-    for (int i = 4 * (int)threadIdx.x; i < tile0; i += SC1_TILE) {        // tile0 is a multiple of the stride: no tail
-        const int4 q = *reinterpret_cast<const int4*>(in + i);
-        part += (int64_t)q.x + q.y + q.z + q.w;
+#define SC1_THREADS 1024
+#define SC1_TILE (SC1_THREADS * 4)
+#define SC1_MAX_TILES 16
+#define SC1_MAX (SC1_TILE * SC1_MAX_TILES)
+
+// block-wide exclusive scan of one int64 per thread (SC1_THREADS threads); *total = sum over the workgroup
+static __device__ __forceinline__ int64_t sc1_block_excl_scan(int64_t v, int64_t* total) {
+    __shared__ int64_t s_w[SC1_THREADS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int64_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SC1_THREADS / 64; ++k) {
+        const int64_t x = s_w[k];
+        if (k < w) base += x;
+        tot += x;
     }
-    int64_t base;
-    block_excl_scan(part, &base);                                         // base = sum of everything before this tile
-    const int i = tile0 + 4 * (int)threadIdx.x;
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ void __launch_bounds__(SC1_THREADS)
+scan_small_kernel(const int32_t* __restrict__ in, int n, int64_t* __restrict__ out) {
+    // everything in front of this tile: at most SC1_MAX_TILES - 1 tiles, one 16-byte load per thread and tile, issued
+    // eight at a time before any is consumed (a rolled loop waits for every load in turn)
+    const int4* __restrict__ in4 = reinterpret_cast<const int4*>(in);
+    int64_t part = 0;
+    if (blockIdx.x > 0) {                        // (tile 0 is complete then: it is the safe address for masked-off loads)
+#pragma unroll
+        for (int k0 = 0; k0 < SC1_MAX_TILES; k0 += 8) {                      // eight loads in flight, then eight more
+            int4 q[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                                    // no branch per load: a branch ends the
+                const unsigned tile = (k0 + k < (int)blockIdx.x) ? (unsigned)(k0 + k) : 0u;   // basic block and its wait
+                q[k] = in4[tile * SC1_THREADS + threadIdx.x];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k0 + k < (int)blockIdx.x) part += ((int64_t)q[k].x + q[k].y) + ((int64_t)q[k].z + q[k].w);
+        }
+    }
+    const int i = blockIdx.x * SC1_TILE + 4 * (int)threadIdx.x;
     int32_t v[4] = {0, 0, 0, 0};
     if (i + 3 < n) {
-        const int4 q = *reinterpret_cast<const int4*>(in + i);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        const int4 t = *reinterpret_cast<const int4*>(in + i);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (i + e < n) v[e] = in[i + e];
     }
+    int64_t base;
+    sc1_block_excl_scan(part, &base);                                     // base = sum of everything before this tile
     int64_t tot;
-    const int64_t e0 = base + block_excl_scan((int64_t)v[0] + v[1] + v[2] + v[3], &tot);
+    const int64_t e0 = base + sc1_block_excl_scan((int64_t)v[0] + v[1] + v[2] + v[3], &tot);
     const int64_t e1 = e0 + v[0], e2 = e1 + v[1], e3 = e2 + v[2];
     if (i + 3 < n) {
         longlong2* dst = reinterpret_cast<longlong2*>(out + i);
@@ -368,7 +402,7 @@ extern "C" int wisp_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t
     }
     WISP_REQUIRE(counts && workspace, "null pointer");
     if (n <= SC1_MAX) {
-        hipLaunchKernelGGL(scan_small_kernel, dim3((unsigned)ceil_div64(n, SC1_TILE)), dim3(SC_THREADS), 0, s, counts, (int)n, offsets);
+        hipLaunchKernelGGL(scan_small_kernel, dim3((unsigned)ceil_div64(n, SC1_TILE)), dim3(SC1_THREADS), 0, s, counts, (int)n, offsets);
         WISP_CHECK_LAUNCH();
         return WISP_OK;
     }
