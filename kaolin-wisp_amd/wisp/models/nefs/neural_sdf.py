@@ -3,8 +3,6 @@ Mirrors the surface of wisp/models/nefs/neural_sdf.py:20-175 (constructor schema
 construction itself lives in _grid_mlp.py."""
 from typing import Any, Dict
 
-import torch
-
 from wisp.models.grids import BLASGrid
 from wisp.models.nefs import _grid_mlp
 from wisp.models.nefs.base_nef import BaseNeuralField

@@ -7,7 +7,6 @@ semantics of wisp/trainers/multiview_trainer.py:111-180 / wisp/trainers/base_tra
 Parameter names equal the reference's state-dict names so weights can be copied between this oracle and
 the HIP-backed classes with load_state_dict.
 """
-import math
 import numpy as np
 import torch
 import torch.nn as nn

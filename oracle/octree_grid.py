@@ -6,7 +6,6 @@ Restates kaolin.ops.spc.unbatched_interpolate_trilinear / coords_to_trilinear_co
 Kaolin is not available (parity unpinned for this leaf); the half-precision call `feats.half() ... .float()` of
 octree_grid.py:147-149 is modelled as: features rounded to fp16, fp32 accumulation, result rounded to fp16.
 """
-import numpy as np
 import torch
 import torch.nn.functional as F
 

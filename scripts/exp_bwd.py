@@ -1,6 +1,6 @@
 """Experiment harness: time the hash-grid backward alone on realistic samples (SynLego raymarch) with HIP events,
 for the env configuration it is started under.  Prints one line."""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "kaolin-wisp_amd")]
 import torch, numpy as np

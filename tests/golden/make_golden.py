@@ -15,11 +15,10 @@ import os
 import sys
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle import hashgrid, raymarch, ref_lib, spc  # noqa: E402
+from oracle import hashgrid, ref_lib, spc  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 

@@ -5,7 +5,6 @@ loss); what is under test is everything that differs between N=1 and N>1."""
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
