@@ -792,6 +792,57 @@ def test_codebook_grid_matches_oracle(training, fused):
             np.testing.assert_allclose(grid.dictionary[i].grad.cpu().numpy(), dict_cpu[i].grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("kind", ["octree", "codebook"])
+def test_octree_radiance_fields_fused_decoder_equals_module_decoder(kind):
+    """nerf_octree.yaml / nerf_codebook.yaml shapes (5 'sum' grid features, hidden 64, 'voxel' march, white background):
+    the pipeline with the fused HIP decoder (narrow-input path) against the same pipeline evaluating the decoder's torch
+    modules - rendered colours and every parameter gradient (grid features, dictionaries, decoder weights)."""
+    import copy
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.models.grids import CodebookOctreeGrid, OctreeGrid
+    from wisp.models.nefs import NeuralRadianceField
+    from wisp.tracers import PackedRFTracer
+    blas, _ = _sparse_blas(5, 3000, 131)
+    torch.manual_seed(3)
+    if kind == "octree":
+        grid = OctreeGrid(blas, feature_dim=5, num_lods=4, multiscale_type='sum', feature_std=0.5)
+    else:
+        grid = CodebookOctreeGrid(blas, feature_dim=5, num_lods=4, multiscale_type='sum', feature_std=0.7, codebook_bitwidth=4)
+    nef = NeuralRadianceField(grid, view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1,
+                              bias=(kind == "octree")).to(DEV)
+    nef.decoder_compute = 'fp32'
+    with torch.no_grad():
+        for n, p in nef.named_parameters():
+            if 'decoder' in n:
+                p.mul_(2.0)
+    ref = copy.deepcopy(nef)
+    ref.fused_decoder = False
+    probe = torch.zeros(4, 5, device=DEV)
+    assert nef._can_fuse(probe) and not ref._can_fuse(probe)
+    o, d = make_rays(400, 132)
+    rays = Rays(cuda(o), cuda(d), dist_min=1.0, dist_max=5.0)
+    gts = cuda(np.random.default_rng(133).uniform(size=(400, 3)).astype(np.float32))
+    rgbs = []
+    for m in (nef, ref):
+        torch.manual_seed(7)                               # same in-kernel jitter seed for both pipelines
+        pipe = Pipeline(m, PackedRFTracer(raymarch_type='voxel', num_steps=4, bg_color=(1.0, 1.0, 1.0)))
+        rb = pipe(rays=rays, channels=["rgb"])
+        torch.nn.functional.smooth_l1_loss(rb.rgb, gts).backward()
+        rgbs.append(rb.rgb.detach())
+        assert pipe.tracer.get_prev_num_samples() > 1000
+    np.testing.assert_allclose(rgbs[0].cpu().numpy(), rgbs[1].cpu().numpy(), atol=1e-4)
+    checked = 0
+    for (n1, p1), (n2, p2) in zip(sorted(nef.named_parameters()), sorted(ref.named_parameters())):
+        assert n1 == n2 and (p1.grad is None) == (p2.grad is None)
+        if p1.grad is None:
+            continue
+        scale = max(float(p2.grad.abs().max()), 1e-6)
+        assert float((p1.grad - p2.grad).abs().max()) <= 3e-4 * scale + 1e-7, n1
+        checked += 1
+    assert checked >= 6
+
+
 # ------------------------------------------------------------------------------------------------ SDF path (NGLOD)
 def test_find_depth_bound_bit_exact():
     from oracle import sdf as osdf
