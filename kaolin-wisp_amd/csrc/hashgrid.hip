@@ -144,6 +144,15 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
                 const T* __restrict__ table = codebook + first_idx[l] * F;
                 CornerSetup<DIM> cs;
                 corner_setup<DIM>(c, res, dense, tsize, tsize_pow2 != 0, cs);
+                if (dense && res >= 258) {
+                    // the fp32 clamp bound rounds up to res - 1 here, so a corner can be `res` and its index
+                    // can leave the level: the reference then reads the next level's rows - and past the allocation on the
+                    // last level, which is the one case refused here (the read is pinned to the table's last row)
+                    const int64_t last = first_idx[num_lods] - 1 - first_idx[l];
+#pragma unroll
+                    for (int j = 0; j < (1 << DIM); ++j)
+                        if ((int64_t)(uint32_t)cs.idx[j] > last) cs.idx[j] = (int32_t)last;
+                }
                 T v[1 << DIM][F];
 #pragma unroll
                 for (int j = 0; j < (1 << DIM); ++j) {
@@ -301,10 +310,12 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
             const bool issue = tail_compute<T, F, DIM, MERGE>(c, live, l, res, dense, tsize, tsize_pow2 != 0, zero_from_col,
                                                               grad_feats + (i * num_lods + l) * F, lane, cs, v);
             if (issue) {
-                float* __restrict__ gt = grad_codebook + first_idx[l] * F;
+                const int64_t base = first_idx[l], total_rows = first_idx[num_lods];
 #pragma unroll
                 for (int j = 0; j < (1 << DIM); ++j) {
-                    float* p = gt + (int64_t)cs.idx[j] * F;
+                    const int64_t row = base + (int64_t)(uint32_t)cs.idx[j];
+                    if (row >= total_rows) continue;          // spill index past the whole table (reference: out of bounds)
+                    float* p = grad_codebook + row * F;
 #pragma unroll
                     for (int k = 0; k < F; ++k) atomicAdd(p + k, v[j][k]);   // global_atomic_add_f32
                 }
@@ -390,6 +401,7 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
     const int wave = threadIdx.x >> 6;
     const uint32_t ntiles = gridDim.x;
     const int64_t tile0 = (int64_t)blockIdx.x * EM_TILE;
+    const int64_t total_rows = first_idx[num_lods];     // rows of the whole table
     for (int b = threadIdx.x; b < total_ranks; b += EM_THREADS) s_rank[b] = 0;
     {
         const int64_t rows = (n - tile0) < (int64_t)EM_TILE ? (n - tile0) : (int64_t)EM_TILE;
@@ -421,6 +433,9 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
         // (the compiler otherwise re-associates it into (b * ntiles + blockIdx) * cap: two quarter-rate multiplies)
         const uint32_t bucket_stride = __builtin_amdgcn_readfirstlane(ntiles * cap);
         const uint32_t slot0 = __builtin_amdgcn_readfirstlane(blockIdx.x * cap);
+        // rows this level owns (bounded by the plan's figure AND by the table the caller really passed)
+        const int64_t rows_l = first_idx[l + 1] - first_idx[l];
+        const uint32_t owned = (uint32_t)(rows_l < (int64_t)bins.entries[li] ? (rows_l < 0 ? 0 : rows_l) : (int64_t)bins.entries[li]);
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             const int sl = (wave * GROUPS + g) * 64 + lane;
@@ -433,7 +448,11 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
             // writing corner by corner put a full LDS round trip in front of every record.
             uint32_t pos[NC];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) pos[j] = atomicAdd(&rank_l[(uint32_t)cs.idx[j] >> chunk_shift], 1u);
+            for (int j = 0; j < NC; ++j) {
+                const uint32_t idx = (uint32_t)cs.idx[j];
+                // an index past the rows the level owns has no bucket (and no rank counter): straight to the atomic
+                pos[j] = idx < owned ? atomicAdd(&rank_l[idx >> chunk_shift], 1u) : 0xffffffffu;
+            }
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const uint32_t idx = (uint32_t)cs.idx[j];
@@ -441,10 +460,15 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
                 if (pos[j] < cap) {
                     uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos[j]) * RW);   // < 2^32 dwords (bin_plan)
                     Codec::store(dst, idx, (1u << chunk_shift) - 1u, v[j]);
-                } else {                                  // slot full: fall back to the memory-side atomic
-                    float* p = grad_codebook + (first_idx[l] + (int64_t)idx) * F;
+                } else {
+                    // slot full, or a spill index: the memory-side atomic.  A spill lands where the reference's pointer
+                    // arithmetic puts it (rows of the next level, .cu:124-161) unless that is past the whole table.
+                    const int64_t row = first_idx[l] + (int64_t)idx;
+                    if (row < total_rows) {
+                        float* p = grad_codebook + row * F;
 #pragma unroll
-                    for (int k = 0; k < F; ++k) atomicAdd(p + k, v[j][k]);
+                        for (int k = 0; k < F; ++k) atomicAdd(p + k, v[j][k]);
+                    }
                 }
             }
         }
@@ -497,7 +521,10 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
     const uint32_t csize = 1u << chunk_shift;
     const uint32_t cap = bins.cap[li];
     const uint32_t first = (uint32_t)b << chunk_shift;
-    const uint32_t entries = bins.entries[li];
+    // the slice [first, first + lim / F) lies inside the rows level l owns: a bucket is flushed with plain read-modify-writes,
+    // which is only race free while no other workgroup (of this or the next level) touches those addresses
+    const int64_t rows_l = first_idx[l + 1] - first_idx[l];
+    const uint32_t entries = (uint32_t)(rows_l < (int64_t)bins.entries[li] ? (rows_l < 0 ? 0 : rows_l) : (int64_t)bins.entries[li]);
     const uint32_t lim = (entries > first ? min(entries - first, csize) : 0u) * F;
     for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) rd_acc[e] = (acc_t)0;
     __syncthreads();
@@ -655,9 +682,13 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
     p.ok = true;
     for (int li = 0; li < levels.n; ++li) {
         const int l = levels.lv[li];
+        // Rows the level OWNS in the table: res^dim on a dense level (MultiTable: min(T, res^dim), models/grids/utils.py:48-54),
+        // T on a hashed one.  A dense corner index can exceed that only when the fp32 clamp bound rounds up to res - 1
+        // (res >= 258): such contributions never enter a bucket (emit sends them to the guarded atomic), so
+        // no bucket ever covers rows of the next level.  The kernels clamp once more against first_idx[l + 1] - first_idx[l].
         int64_t entries = tsize;
-        if (lv.dense[l]) { entries = 1; for (int a = 0; a < dim; ++a) entries *= (int64_t)(lv.res[l] + 1); }   // corner index < (res+1)^dim
-        if (entries > tsize && !lv.dense[l]) entries = tsize;
+        if (lv.dense[l]) { entries = 1; for (int a = 0; a < dim; ++a) entries *= (int64_t)lv.res[l]; }
+        if (entries > tsize) entries = tsize;
         const int64_t chunks = (entries + ((int64_t)1 << p.chunk_shift) - 1) >> p.chunk_shift;
         // slot = the records one emitting tile sends to one bucket: no-merge expectation under a uniform spread x 1.5,
         // at least 128 (overflow falls back to atomics, so the bound only has to be a good guess)

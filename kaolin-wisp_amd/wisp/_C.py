@@ -156,6 +156,24 @@ def _host_f32(values):
 
 
 # ------------------------------------------------------------------------------------------------ hash grid
+_first_idx_ok = {}
+
+
+def _check_first_idx(first_idx, num_lods, rows):
+    """codebook_first_idx is [L+1] (hashgrid_interpolate.h:18-23): the kernels read entry L as the end of the table, so a
+    short or inconsistent vector would let them write past it.  Checked once per (tensor, version): one D2H read."""
+    if first_idx.numel() < num_lods + 1:
+        raise RuntimeError(f"codebook_first_idx must hold num_lods + 1 = {num_lods + 1} offsets, got {first_idx.numel()}")
+    key = (first_idx.data_ptr(), first_idx._version, num_lods, rows)
+    if key not in _first_idx_ok:
+        if len(_first_idx_ok) > 64:
+            _first_idx_ok.clear()
+        end = int(first_idx[num_lods].item())
+        if end > rows:
+            raise RuntimeError(f"codebook_first_idx[{num_lods}] = {end} exceeds the {rows} rows of the table")
+        _first_idx_ok[key] = True
+
+
 def hashgrid_interpolate(coords, codebook, first_idx, resolutions, codebook_bitwidth, zero_from_col=None):
     """feats[N, L*F] - the reference's wisp._C.ops.hashgrid_interpolate_cuda (hashgrid_interpolate.cpp:46-69)."""
     coords = _need(coords, torch.float32, "coords")
@@ -163,6 +181,7 @@ def hashgrid_interpolate(coords, codebook, first_idx, resolutions, codebook_bitw
     first_idx = _need(first_idx, torch.int64, "codebook_first_idx")
     n, dim = coords.shape
     L, F = len(resolutions), codebook.shape[1]
+    _check_first_idx(first_idx, L, codebook.shape[0])
     if zero_from_col is None:
         zero_from_col = L * F
     res_arr, res_ptr = _host_i32(resolutions)
@@ -183,6 +202,7 @@ def hashgrid_interpolate_backward(coords, grad_feats, codebook_shape, first_idx,
     first_idx = _need(first_idx, torch.int64, "codebook_first_idx")
     n, dim = coords.shape
     L, F = len(resolutions), codebook_shape[1]
+    _check_first_idx(first_idx, L, codebook_shape[0])
     if zero_from_col is None:
         zero_from_col = L * F
     res_arr, res_ptr = _host_i32(resolutions)
@@ -204,19 +224,27 @@ _bwd_ws = {}
 
 
 def _bwd_workspace(device, nbytes):
-    buf = _bwd_ws.get(device)
+    """Scratch of the binned backward, cached per (device, stream): two backward calls on different streams (the trainer's
+    side stream next to a second model) must not share records."""
+    key = (device, _stream().value)
+    buf = _bwd_ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None
-        _bwd_ws[device] = None
+        _bwd_ws[key] = None
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        _bwd_ws[device] = buf
+        _bwd_ws[key] = buf
     return buf
 
 
 # ------------------------------------------------------------------------------------------------ scans / packs
+def _aligned16(t):
+    """the scan kernels read their input with 16-byte loads: a slice that starts mid-allocation is copied."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def exclusive_scan(counts):
     """int32 counts [n] -> int64 offsets [n+1] (offsets[n] = total)."""
-    counts = _need(counts, torch.int32, "counts")
+    counts = _aligned16(_need(counts, torch.int32, "counts"))
     n = counts.shape[0]
     offsets = torch.empty(n + 1, dtype=torch.int64, device=counts.device)
     ws = torch.empty(int(lib.wisp_scan_workspace_bytes(n)), dtype=torch.uint8, device=counts.device)
@@ -226,7 +254,7 @@ def exclusive_scan(counts):
 
 def inclusive_scan(values):
     """kaolin._C.render.spc.inclusive_sum_cuda (octree_as.py:351): int32 -> int32 inclusive prefix sum."""
-    values = _need(values, torch.int32, "values")
+    values = _aligned16(_need(values, torch.int32, "values"))
     n = values.shape[0]
     out = torch.empty_like(values)
     ws = torch.empty(int(lib.wisp_scan_workspace_bytes(n)), dtype=torch.uint8, device=values.device)

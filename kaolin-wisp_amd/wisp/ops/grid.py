@@ -5,6 +5,8 @@ forward and backward are single launches over all levels (csrc/hashgrid.hip).  D
 is accumulated in fp32 (the reference adds __half2 atomics in the table dtype), bf16 tables are accepted, and
 the 'cat' zeroing of HashGrid.interpolate can be fused through `zero_from_col`.
 """
+import weakref
+
 import torch
 
 PRIMES = [1, 2654435761, 805459861]
@@ -21,6 +23,75 @@ def _as_int_list(resolutions):
     return [int(r) for r in resolutions]
 
 
+# Trainer-side helpers of a table Parameter, kept OUT of Parameter.__dict__ (which torch.save(pipeline) would pickle: the
+# flat gradient / shadow storages would travel with the checkpoint and come back dangling).  Weak keys: an entry dies
+# with its Parameter.
+class _ById:
+    """id-keyed weak registry (a WeakKeyDictionary would compare keys with Tensor.__eq__, which is elementwise)."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, obj):
+        ent = self._d.get(id(obj))
+        return ent[1] if ent is not None and ent[0]() is obj else None
+
+    def __setitem__(self, obj, value):
+        key = id(obj)
+        self._d[key] = (weakref.ref(obj, lambda _r, k=key, d=self._d: d.pop(k, None)), value)
+
+
+_TABLE_AUX = _ById()
+
+
+class _TableAux:
+    __slots__ = ("shadow", "shadow_version", "grad_buffer")
+
+    def __init__(self):
+        self.shadow, self.shadow_version, self.grad_buffer = None, -1, None
+
+
+def register_table_aux(codebook, shadow=None, grad_buffer=None):
+    """A trainer announces (a) a low-precision copy of `codebook` that its fused optimizer keeps current and/or (b) the
+    pre-allocated fp32 gradient buffer the backward may scatter into.  Both are validated at every use."""
+    aux = _TABLE_AUX.get(codebook)
+    if aux is None:
+        aux = _TABLE_AUX[codebook] = _TableAux()
+    if shadow is not None:
+        aux.shadow, aux.shadow_version = shadow, codebook._version
+    if grad_buffer is not None:
+        aux.grad_buffer = grad_buffer
+    return aux
+
+
+def mark_shadow_current(codebook):
+    """Called by the trainer right after its fused optimizer rewrote table AND shadow (the raw-pointer kernels do not bump
+    the autograd version counter; any torch-side in-place write - load_state_dict, .copy_, an external optimizer - does,
+    which is what invalidates the shadow until the next fused step)."""
+    aux = _TABLE_AUX.get(codebook)
+    if aux is not None and aux.shadow is not None:
+        aux.shadow_version = codebook._version
+
+
+def current_shadow(codebook, dtype):
+    """The registered copy of `codebook` in `dtype` if it is known to mirror the master weights, else None."""
+    aux = _TABLE_AUX.get(codebook)
+    if aux is None or aux.shadow is None or aux.shadow.dtype != dtype or aux.shadow_version != codebook._version:
+        return None
+    return aux.shadow
+
+
+def current_grad_buffer(codebook):
+    """The registered gradient buffer iff it IS codebook.grad (same storage) - otherwise autograd gets a normal gradient."""
+    aux = _TABLE_AUX.get(codebook)
+    if aux is None or aux.grad_buffer is None or codebook.grad is None:
+        return None
+    buf = aux.grad_buffer
+    if codebook.grad.data_ptr() != buf.data_ptr() or buf.dtype != torch.float32 or tuple(buf.shape) != tuple(codebook.shape):
+        return None
+    return buf
+
+
 class HashGridInterpolate(torch.autograd.Function):
     """feats[N, L*F] = multi-resolution (dense or hashed) trilinear / bilinear lookup of `codebook`."""
 
@@ -34,15 +105,15 @@ class HashGridInterpolate(torch.autograd.Function):
             # the reference casts to fp16 under autocast (grid.py:88-89); follow the active autocast dtype (bf16 on MI355X).
             # A trainer may keep an up-to-date low-precision copy next to the master weights (refreshed by the fused AdamW).
             dt = torch.get_autocast_dtype('cuda')
-            shadow = getattr(codebook, '_wisp_shadow', None)
-            table = shadow if (shadow is not None and shadow.dtype == dt) else codebook.to(dt)
+            shadow = current_shadow(codebook, dt)
+            table = shadow if shadow is not None else codebook.to(dt)
         res = _as_int_list(resolutions)
         feats = _hip().hashgrid_interpolate(coords.detach(), table.detach(), codebook_first_idx, res, codebook_bitwidth,
                                             zero_from_col)
         ctx.save_for_backward(coords, codebook_first_idx)
         ctx.meta = (res, codebook_bitwidth, tuple(codebook.shape), codebook.dtype, zero_from_col)
         # a trainer may pre-allocate the fp32 gradient buffer of the table (flat-parameter layout): scatter into it
-        ctx.grad_buffer = getattr(codebook, '_wisp_grad_buffer', None)
+        ctx.grad_buffer = current_grad_buffer(codebook)
         return feats
 
     @staticmethod

@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from wisp.core import Rays
+from wisp.ops.grid import current_shadow, mark_shadow_current, register_table_aux
 
 
 def _hip():
@@ -46,7 +47,7 @@ class FlatParams:
                 p.data = self.data[off:off + k].view(p.shape)
                 p.grad = self.grad[off:off + k].view(p.shape)
                 if "grid" in n:
-                    p._wisp_grad_buffer = p.grad        # hash-grid backward scatters straight into the flat buffer
+                    register_table_aux(p, grad_buffer=p.grad)   # hash-grid backward scatters straight into the flat buffer
                 off += ((k + 3) // 4) * 4
             self.ranges[g] = (start, off)
         self.exp_avg = torch.zeros_like(self.data)
@@ -56,13 +57,27 @@ class FlatParams:
 
     def enable_bf16_shadow(self):
         """Keep a bf16 copy of the grid parameters, refreshed by the fused AdamW kernel, and hand it to the hash-grid op
-        (attribute `_wisp_shadow`), so that the bf16 forward needs no cast pass over the 41.7 MB table."""
+        (`wisp.ops.grid.register_table_aux`), so that the bf16 forward needs no cast pass over the 41.7 MB table."""
         a, b = self.ranges["grid"]
         if b <= a:
             return
         self.shadow = self.data[a:b].to(torch.bfloat16)
         for p, off in self._grid_params:
-            p._wisp_shadow = self.shadow[off - a:off - a + p.numel()].view(p.shape)
+            register_table_aux(p, shadow=self.shadow[off - a:off - a + p.numel()].view(p.shape))
+
+    def refresh_shadow(self):
+        """Re-derive the shadow from the master weights where a torch-side write (load_state_dict, ...) outdated it."""
+        if self.shadow is None:
+            return
+        a, _ = self.ranges["grid"]
+        for p, off in self._grid_params:
+            if current_shadow(p, self.shadow.dtype) is None:
+                self.shadow[off - a:off - a + p.numel()].copy_(p.detach().reshape(-1))
+                mark_shadow_current(p)
+
+    def mark_shadow_current(self):
+        for p, _ in self._grid_params:
+            mark_shadow_current(p)
 
 
 class _DirectHashNeRFStep:
@@ -154,7 +169,7 @@ class _DirectHashNeRFStep:
         t.wait_for_parameters()                 # everything above overlapped the previous step's all-reduce + update
         table = self.table
         if t.enable_amp:
-            shadow = getattr(table, '_wisp_shadow', None)
+            shadow = current_shadow(table, torch.bfloat16)
             table = shadow if shadow is not None else table.to(torch.bfloat16)
         feats = C.hashgrid_interpolate(samples, table.detach(), self.first_idx, self.res, self.bitwidth, self.zero_from_col)
         i, h, f = self.shape
@@ -234,6 +249,7 @@ class MultiviewTrainStep:
         # all parameter groups in ONE launch (the decoder group alone is ~10 K parameters)
         C.adamw_step_groups(f.data, f.grad, f.exp_avg, f.exp_avg_sq, groups, self.betas[0], self.betas[1], self.eps,
                             self.opt_steps, grad_scale=gs, zero_grad=True)
+        f.mark_shadow_current()                 # the kernel rewrote every shadow element from the new master weights
 
     def allreduce_grads(self):
         if self.world > 1 or self.force_allreduce:
@@ -271,8 +287,13 @@ class MultiviewTrainStep:
             self.prune()
 
     def prune(self):
+        """nef.prune() with rank-identical draws.  Like the reference (nerf.py:181-183: prune is a no-op unless the grid is
+        a HashGrid with both prune densities set), grids without an occupancy record are left alone."""
         self.wait_for_parameters()
         nef = self.pipeline.nef
+        if (getattr(nef, 'prune_density_decay', None) is None or getattr(nef, 'prune_min_density', None) is None
+                or getattr(nef.grid, 'dense_points', None) is None or not hasattr(nef, 'prune')):
+            return
         cells = nef.grid.dense_points.shape[0]
         unit = torch.rand(cells, 3, generator=self._prune_gen)
         views = torch.nn.functional.normalize(torch.randn(cells, 3, generator=self._prune_gen), dim=1)

@@ -40,30 +40,51 @@ def evaluate_psnr(pipeline, views, epoch=0, max_epochs=0, name=None, lod_idx=Non
     return mean, 'EPOCH {}/{} | {}: {:.2f}'.format(epoch, max_epochs, f"{name} psnr", mean)
 
 
+BLAS_SIDECAR_SUFFIX = ".blas"
+
+
 def save_pipeline(pipeline, path, model_format="full"):
+    """BaseTrainer.save_model (base_trainer.py:344-359): 'full' pickles the pipeline, anything else writes
+    `pipeline.state_dict()` - the bare OrderedDict, byte-compatible with the reference's loaders
+    (`pipeline.load_state_dict(torch.load(path))`).  The occupancy octree and the per-cell occupancy record, which the
+    reference's state_dict mode silently drops (OctreeAS tensors are plain attributes), go to the sidecar `path + '.blas'`."""
     if model_format == "full":
         torch.save(pipeline, path)
         return
-    state = {"state_dict": pipeline.state_dict()}
+    torch.save(pipeline.state_dict(), path)
     blas = getattr(getattr(pipeline.nef, "grid", None), "blas", None)
     if blas is not None:
-        state["blas_octree"] = blas.octree.detach().cpu()
         occ = getattr(pipeline.nef.grid, "occupancy", None)
-        state["grid_occupancy"] = None if occ is None else occ.detach().cpu()
-    torch.save(state, path)
+        torch.save({"blas_octree": blas.octree.detach().cpu(),
+                    "grid_occupancy": None if occ is None else occ.detach().cpu()}, path + BLAS_SIDECAR_SUFFIX)
+
+
+def _restore_blas(pipeline, extra):
+    if extra.get("blas_octree") is None:
+        return
+    grid = pipeline.nef.grid
+    dev = grid.blas.octree.device
+    grid.blas = grid.blas.__class__(extra["blas_octree"].to(dev))
+    if extra.get("grid_occupancy") is not None:
+        grid.occupancy = extra["grid_occupancy"]
 
 
 def load_pipeline(path, pipeline=None, map_location=None):
-    """'full' checkpoints return the pickled pipeline; 'state_dict' checkpoints are loaded into `pipeline`."""
+    """'full' checkpoints return the pickled pipeline.  A bare state_dict (what the reference and save_pipeline write) is
+    loaded into `pipeline`, plus the octree sidecar when one lies next to it; the wrapped {'state_dict': ...} files of
+    earlier versions of this package are still read."""
+    import os
+    from collections.abc import Mapping
     obj = torch.load(path, map_location=map_location, weights_only=False)
-    if not isinstance(obj, dict) or "state_dict" not in obj:
+    if not isinstance(obj, Mapping):
         return obj
     assert pipeline is not None, "a state_dict checkpoint needs the pipeline to load into"
-    pipeline.load_state_dict(obj["state_dict"])
-    if obj.get("blas_octree") is not None:
-        grid = pipeline.nef.grid
-        dev = grid.blas.octree.device
-        grid.blas = grid.blas.__class__(obj["blas_octree"].to(dev))
-        if obj.get("grid_occupancy") is not None:
-            grid.occupancy = obj["grid_occupancy"]
+    if "state_dict" in obj and isinstance(obj["state_dict"], Mapping):
+        pipeline.load_state_dict(obj["state_dict"])
+        _restore_blas(pipeline, obj)
+        return pipeline
+    pipeline.load_state_dict(obj)
+    side = path + BLAS_SIDECAR_SUFFIX
+    if os.path.exists(side):
+        _restore_blas(pipeline, torch.load(side, map_location=map_location, weights_only=False))
     return pipeline

@@ -246,3 +246,61 @@ def test_checkpoint_roundtrip_keeps_pruned_octree(tmp_path):
         p2 = load_pipeline(path, pipeline=make(torch.tensor([[1, 1, 1]], dtype=torch.int16)))
         assert torch.equal(p2.nef.grid.blas.octree.cpu(), p1.nef.grid.blas.octree.cpu())
         assert torch.equal(p2.nef.grid.codebook.feats.cpu(), p1.nef.grid.codebook.feats.cpu())
+    # 'state_dict' files are the bare OrderedDict the reference writes (base_trainer.py:357) and can load
+    import collections
+    raw = torch.load(str(tmp_path / "m_state_dict.pth"), weights_only=False)
+    assert isinstance(raw, collections.OrderedDict) and "nef.grid.codebook.feats" in raw and "state_dict" not in raw
+    p3 = make(torch.tensor([[1, 1, 1]], dtype=torch.int16))
+    p3.load_state_dict(raw)                                     # what reference code does with the file
+    # a reference-written file (no sidecar) loads too, and the wrapped files of earlier versions are still read
+    ref_path = str(tmp_path / "ref_style.pth")
+    torch.save(p1.state_dict(), ref_path)
+    p4 = load_pipeline(ref_path, pipeline=make(torch.tensor([[1, 1, 1]], dtype=torch.int16)))
+    assert torch.equal(p4.nef.grid.codebook.feats, p1.nef.grid.codebook.feats)
+    old_path = str(tmp_path / "old_style.pth")
+    torch.save({"state_dict": p1.state_dict(), "blas_octree": p1.nef.grid.blas.octree, "grid_occupancy": None}, old_path)
+    p5 = load_pipeline(old_path, pipeline=make(torch.tensor([[1, 1, 1]], dtype=torch.int16)))
+    assert torch.equal(p5.nef.grid.blas.octree.cpu(), p1.nef.grid.blas.octree.cpu())
+
+
+def test_table_aux_is_validated_and_never_pickled():
+    """the bf16 shadow / flat gradient buffer of a table Parameter must not be trusted blindly nor pickled."""
+    import pickle
+    from wisp.ops import grid as G
+    p = torch.nn.Parameter(torch.randn(64, 2))
+    p.grad = torch.zeros(64, 2)
+    shadow = p.detach().to(torch.bfloat16)
+    G.register_table_aux(p, shadow=shadow, grad_buffer=p.grad)
+    assert G.current_shadow(p, torch.bfloat16) is shadow and G.current_grad_buffer(p) is p.grad
+    assert G.current_shadow(p, torch.float16) is None
+    with torch.no_grad():
+        p.copy_(torch.randn(64, 2))                             # e.g. load_state_dict: bumps the version counter
+    assert G.current_shadow(p, torch.bfloat16) is None          # stale copy refused
+    G.mark_shadow_current(p)                                    # what the fused optimizer step announces
+    assert G.current_shadow(p, torch.bfloat16) is shadow
+    p.grad = torch.zeros(64, 2)                                 # a different storage: registered buffer no longer aliases .grad
+    assert G.current_grad_buffer(p) is None
+    assert "_wisp" not in repr(sorted(p.__dict__)) and b"_wisp" not in pickle.dumps(p)
+
+
+def test_trainer_prune_is_a_noop_without_an_occupancy_record():
+    """prune_every=100 with an Octree/Codebook/Triplanar grid must do nothing (reference: nerf.py:181-183)."""
+    from wisp.trainers.multiview_trainer import MultiviewTrainStep
+
+    class Grid:
+        pass
+
+    class Nef:
+        prune_density_decay, prune_min_density, grid = 0.95, 2.0, Grid()
+
+        def prune(self, **kw):
+            raise AssertionError("must not be reached")
+
+    class Pipe:
+        nef = Nef()
+    t = MultiviewTrainStep.__new__(MultiviewTrainStep)
+    t.pipeline, t._params_ready = Pipe(), None
+    t.prune()
+    Nef.prune_density_decay = None
+    Nef.grid.dense_points = torch.zeros(4, 3)
+    t.prune()

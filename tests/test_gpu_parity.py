@@ -143,6 +143,96 @@ def test_hashgrid_backward_other_shapes(dim, F, bitwidth, res, dtype):
     assert float((got.double().cpu() - want).abs().max()) <= (4e-6 if dtype == torch.float32 else 3e-5) * scale
 
 
+def _ray_like_coords(rng, n, dim=3, run=32):
+    start = rng.uniform(-1, 1, (n // run, 1, dim))
+    step = rng.normal(size=(n // run, 1, dim)) * 0.004
+    return np.clip(start + step * np.arange(run)[None, :, None], -1, 1).reshape(n, dim).astype(np.float32)
+
+
+@pytest.mark.parametrize("res,bitwidth", [([16, 64, 300, 1024, 2048, 8192], 19), (NGP_RES, 19)])
+@pytest.mark.parametrize("n", [4096, 8192, 65536])
+def test_hashgrid_backward_is_repeatable_and_race_free(res, bitwidth, n):
+    """Round-1 failure (GPUTEST_r01: error 1.7 on a gradient of scale 11.8): buckets of a dense level sized (res+1)^3 reached
+    into the next level's rows and its zero-adding flush raced with the owner of those rows.  50 repetitions of the same
+    backward must agree with the oracle every time; on hashed levels (one workgroup per bucket, 64-bit fixed-point sums)
+    they must be bitwise identical, on dense levels (partial sums of <= 64 workgroups added with float atomics) within
+    float add-order noise."""
+    rng = np.random.default_rng(5 + n)
+    _, begin = ohash.table_layout(res, 2 ** bitwidth)
+    shape = (int(begin[-1]), 2)
+    coords = _ray_like_coords(rng, n)
+    go = rng.normal(size=(n, len(res) * 2)).astype(np.float32)
+    want = ohash.hashgrid_backward(torch.from_numpy(coords), torch.from_numpy(go), shape, torch.from_numpy(begin), res, bitwidth,
+                                   torch.float64)
+    scale = float(want.abs().max())
+    dense = [ohash.level_is_dense(r, 2 ** bitwidth) for r in res]
+    first_hashed = int(begin[dense.index(False)])
+    c, g, b = cuda(coords), cuda(go), cuda(begin)
+    ref = None
+    for rep in range(50):
+        got = _C().hashgrid_interpolate_backward(c, g, shape, b, res, bitwidth)
+        if ref is None:
+            ref = got
+            assert float((got.double().cpu() - want).abs().max()) <= 4e-6 * scale
+        else:
+            assert torch.equal(got[first_hashed:], ref[first_hashed:]), f"repetition {rep}: hashed levels differ"
+            assert float((got[:first_hashed] - ref[:first_hashed]).abs().max()) <= 2e-6 * scale, f"repetition {rep}"
+    # the bf16 compact-record path, same property
+    gb = g.bfloat16()
+    want_b = ohash.hashgrid_backward(torch.from_numpy(coords), gb.float().cpu(), shape, torch.from_numpy(begin), res, bitwidth,
+                                     torch.float64)
+    ref = None
+    for rep in range(20):
+        got = _C().hashgrid_interpolate_backward(c, gb, shape, b, res, bitwidth)
+        if ref is None:
+            ref = got
+            assert float((got.double().cpu() - want_b).abs().max()) <= 3e-5 * scale
+        else:
+            assert torch.equal(got[first_hashed:], ref[first_hashed:]), f"bf16 repetition {rep}"
+            assert float((got[:first_hashed] - ref[:first_hashed]).abs().max()) <= 2e-6 * scale
+
+
+def test_hashgrid_dense_level_spill_follows_reference_pointer_arithmetic():
+    """A dense level with res >= 258 (needs T >= 2^25): the fp32 clamp bound res-1-1e-5 rounds to res-1, so a coordinate of
+    exactly +1 gives corner `res` and an index past the level's res^3 rows.  The reference's pointer arithmetic
+    (hashgrid_interpolate_cuda.cu:60-78,124-161) lands in the next level's rows; so must forward and backward here - and
+    the level's buckets must not cover those rows."""
+    res, bw = [300, 64], 25
+    assert ohash.level_is_dense(300, 2 ** bw) and float(np.float32(300 - 1 - 1e-5)) == 299.0
+    rng = np.random.default_rng(77)
+    _, begin = ohash.table_layout(res, 2 ** bw)
+    shape = (int(begin[-1]), 2)
+    n = 8192
+    coords = _ray_like_coords(rng, n)
+    coords[::7, 0] = 1.0                       # x corner = res: index spills by +1 row (stays in level for y, z < res)
+    coords[::11, 2] = 1.0                      # z corner = res: index = ... + 300 * 90000 -> first rows of level 64
+    coords[::13] = 1.0
+    table = (rng.uniform(-0.1, 0.1, shape)).astype(np.float32)
+    go = rng.normal(size=(n, 4)).astype(np.float32)
+    want_f = ohash.hashgrid_forward(torch.from_numpy(coords), torch.from_numpy(table), torch.from_numpy(begin), res, bw)
+    got_f = _C().hashgrid_interpolate(cuda(coords), cuda(table), cuda(begin), res, bw)
+    np.testing.assert_allclose(got_f.cpu().numpy(), want_f.numpy(), rtol=0, atol=2e-7)
+    want = ohash.hashgrid_backward(torch.from_numpy(coords), torch.from_numpy(go), shape, torch.from_numpy(begin), res, bw,
+                                   torch.float64)
+    spilled = want[int(begin[1]):int(begin[1]) + 90301].abs().sum()
+    assert float(spilled) > 0                  # the case really occurs in this input
+    for dt, tol in ((torch.float32, 4e-6), (torch.bfloat16, 3e-5)):
+        g = torch.from_numpy(go).to(dt)
+        w = want if dt == torch.float32 else ohash.hashgrid_backward(torch.from_numpy(coords), g.float(), shape,
+                                                                     torch.from_numpy(begin), res, bw, torch.float64)
+        got = _C().hashgrid_interpolate_backward(cuda(coords), g.to(DEV), shape, cuda(begin), res, bw)
+        assert float((got.double().cpu() - w).abs().max()) <= tol * float(w.abs().max()), dt
+    # last level dense and spilling: nothing may be written past the table (the reference would); in-range part unchanged
+    res1 = [300]
+    _, begin1 = ohash.table_layout(res1, 2 ** bw)
+    guard = torch.zeros(int(begin1[-1]) + 100000, 2, device=DEV)
+    tab = guard[:int(begin1[-1])]
+    _C().hashgrid_interpolate_backward(cuda(coords), cuda(go[:, :2].copy()), tuple(tab.shape), cuda(begin1), res1, bw, out=tab)
+    assert float(guard[int(begin1[-1]):].abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="num_lods \\+ 1"):
+        _C().hashgrid_interpolate(cuda(coords), cuda(table), cuda(begin[:2]), res, bw)
+
+
 def test_hashgrid_autograd_module_cat_and_sum():
     from wisp.accelstructs import OctreeAS
     from wisp.models.grids import HashGrid
