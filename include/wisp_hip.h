@@ -227,6 +227,12 @@ int wisp_raymarch_uniform_emit(const float* origins, const float* dirs,
                                int64_t* ridx, float* samples, float* depth_samples, uint8_t* boundary,
                                wisp_stream_t stream);
 
+/* wisp._C.ops.uniform_sample_cuda under its own signature (wisp/csrc/ops/uniform_sample.cpp:28-42; kernel
+ * uniform_sample_cuda.cu:18-59): ridx i32 [V], depth f32 [V,2], insum i32 [V] = inclusive sum of the per-nugget sample
+ * counts (all > 0) -> new_ridx i64 [S], depth_samples f32 [S], boundary u8 [S], S = insum[V-1] (read by the caller). */
+int wisp_uniform_sample(int scale, const int32_t* ridx, const float* depth, const int32_t* insum, int64_t num_nuggets,
+                        int64_t* new_ridx, float* depth_samples, uint8_t* boundary, wisp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Packed volume integration  (replace kaolin.render.spc.exponential_integration / sum_reduce / cumsum
  * and the scatter block of PackedRFTracer.trace, wisp/tracers/packed_rf_tracer.py:143-165)
@@ -338,6 +344,16 @@ int wisp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
 int wisp_adamw_step_groups(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int num_groups,
                            const int64_t* group_begin, const int64_t* group_len, const float* group_lr,
                            const float* group_weight_decay, void* const* group_bf16_shadow, float beta1, float beta2,
+                           float eps, int64_t step, float grad_scale, int zero_grad, wisp_stream_t stream);
+
+/* The other optimizers BaseTrainer.init_optimizer is configured with (wisp/config/presets/torch.py:45-68; RMSprop:
+ * app/nerf/configs/nerf_octree.yaml:85, nerf_codebook.yaml:86), same group / shadow / zeroing structure, arithmetic in
+ * torch.optim's order.  kind 0 = AdamW (state1 exp_avg, state2 exp_avg_sq, hyper0/1 = beta1/beta2), 1 = Adam (coupled
+ * weight decay), 2 = RMSprop (state2 square_avg, hyper0 = alpha, hyper1 = momentum, state1 = momentum buffer, may be NULL
+ * when momentum == 0; not centered). */
+int wisp_optim_step_groups(int kind, float* param, const float* grad, float* state1, float* state2, int num_groups,
+                           const int64_t* group_begin, const int64_t* group_len, const float* group_lr,
+                           const float* group_weight_decay, void* const* group_bf16_shadow, float hyper0, float hyper1,
                            float eps, int64_t step, float grad_scale, int zero_grad, wisp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -162,6 +162,116 @@ extern "C" int wisp_adamw_step_groups(float* param, const float* grad, float* ex
     return WISP_OK;
 }
 
+// ---- the other optimizers BaseTrainer.init_optimizer can be configured with (wisp/config/presets/torch.py:45-68): Adam with
+// coupled (L2) weight decay and RMSprop (nerf_octree.yaml:85, nerf_codebook.yaml:86 and the reference's best nerf_hash row,
+// docs/pages/app_nerf.md:185-192).  Same flat-buffer / group / shadow / fused-zeroing structure as adamw_groups_kernel;
+// arithmetic in torch.optim's order (torch/optim/adam.py _single_tensor_adam, rmsprop.py _single_tensor_rmsprop).
+//   kind 0 AdamW  (decoupled decay)      s1 = exp_avg, s2 = exp_avg_sq            h = {beta1, beta2, -}
+//   kind 1 Adam   (g += wd * p)          s1 = exp_avg, s2 = exp_avg_sq            h = {beta1, beta2, -}
+//   kind 2 RMSprop (g += wd * p)         s1 = momentum buffer (momentum > 0), s2 = square_avg   h = {alpha, momentum, -}
+template <int KIND>
+__global__ void __launch_bounds__(256)
+optim_groups_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1, float* __restrict__ s2,
+                    AdamGroups gr, float h0, float h1, float eps, float bc1, float bc2_sqrt, float gscale, int zero_grad) {
+    const int64_t total = gr.chunk0[gr.n];
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < ADAMW_MAX_GROUPS; ++q) k += (q < gr.n && c >= gr.chunk0[q]) ? 1 : 0;
+        const int64_t off = (c - gr.chunk0[k]) * 4;
+        const int64_t i = gr.begin[k] + off;
+        const int cnt = (int)(gr.len[k] - off < 4 ? gr.len[k] - off : 4);
+        const float lr = gr.lr[k], wd = gr.wd[k];
+        __hip_bfloat16* shadow = gr.shadow[k];
+        const bool use_s1 = (KIND != 2) || (h1 > 0.0f);
+        float pv[4], gv[4], av[4] = {0.f, 0.f, 0.f, 0.f}, bv[4];
+        if (cnt == 4) {                                            // groups start on 16-byte boundaries
+            *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + i);
+            *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + i);
+            *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(s2 + i);
+            if (use_s1) *reinterpret_cast<float4*>(av) = *reinterpret_cast<const float4*>(s1 + i);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool in = e < cnt;
+                pv[e] = in ? p[i + e] : 0.f; gv[e] = in ? g[i + e] : 0.f;
+                av[e] = (in && use_s1) ? s1[i + e] : 0.f; bv[e] = in ? s2[i + e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = gv[e] * gscale;
+            if (KIND == 0) pv[e] *= (1.0f - lr * wd); else x += wd * pv[e];
+            if (KIND == 2) {
+                bv[e] = h0 * bv[e] + (1.0f - h0) * x * x;                  // square_avg
+                const float avg = sqrtf(bv[e]) + eps;
+                if (h1 > 0.0f) { av[e] = h1 * av[e] + x / avg; pv[e] -= lr * av[e]; }
+                else pv[e] -= lr * (x / avg);
+            } else {
+                av[e] = h0 * av[e] + (1.0f - h0) * x;
+                bv[e] = h1 * bv[e] + (1.0f - h1) * x * x;
+                const float denom = sqrtf(bv[e]) / bc2_sqrt + eps;
+                pv[e] -= (lr / bc1) * (av[e] / denom);
+            }
+        }
+        if (cnt == 4) {
+            *reinterpret_cast<float4*>(p + i) = *reinterpret_cast<float4*>(pv);
+            *reinterpret_cast<float4*>(s2 + i) = *reinterpret_cast<float4*>(bv);
+            if (use_s1) *reinterpret_cast<float4*>(s1 + i) = *reinterpret_cast<float4*>(av);
+            if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < cnt) {
+                    p[i + e] = pv[e]; s2[i + e] = bv[e];
+                    if (use_s1) s1[i + e] = av[e];
+                    if (zero_grad) g[i + e] = 0.0f;
+                }
+        }
+        if (shadow) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < cnt) shadow[off + e] = __float2bfloat16(pv[e]);
+        }
+    }
+}
+
+extern "C" int wisp_optim_step_groups(int kind, float* param, const float* grad, float* state1, float* state2, int num_groups,
+                                      const int64_t* group_begin, const int64_t* group_len, const float* group_lr,
+                                      const float* group_weight_decay, void* const* group_bf16_shadow, float hyper0,
+                                      float hyper1, float eps, int64_t step, float grad_scale, int zero_grad,
+                                      wisp_stream_t stream) {
+    WISP_REQUIRE(kind >= 0 && kind <= 2, "kind must be 0 (AdamW), 1 (Adam) or 2 (RMSprop)");
+    WISP_REQUIRE(num_groups >= 1 && num_groups <= ADAMW_MAX_GROUPS && step >= 1, "bad group count / step");
+    WISP_REQUIRE(param && grad && state2 && group_begin && group_len && group_lr && group_weight_decay, "null pointer");
+    WISP_REQUIRE(state1 || (kind == 2 && hyper1 <= 0.0f), "state1 (exp_avg / momentum buffer) missing");
+    WISP_REQUIRE(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)state1 % 16 == 0) &&
+                 ((uintptr_t)state2 % 16 == 0), "buffers must be 16-byte aligned");
+    AdamGroups gr{};
+    gr.n = num_groups;
+    gr.chunk0[0] = 0;
+    for (int k = 0; k < num_groups; ++k) {
+        WISP_REQUIRE(group_begin[k] >= 0 && group_len[k] >= 0 && group_begin[k] % 4 == 0, "group ranges must start on a 16-byte boundary");
+        gr.begin[k] = group_begin[k]; gr.len[k] = group_len[k];
+        gr.lr[k] = group_lr[k]; gr.wd[k] = group_weight_decay[k];
+        gr.shadow[k] = group_bf16_shadow ? (__hip_bfloat16*)group_bf16_shadow[k] : nullptr;
+        gr.chunk0[k + 1] = gr.chunk0[k] + ceil_div64(group_len[k], 4);
+    }
+    if (gr.chunk0[num_groups] == 0) return WISP_OK;
+    const float bc1 = kind == 2 ? 1.0f : 1.0f - powf(hyper0, (float)step);
+    const float bc2_sqrt = kind == 2 ? 1.0f : sqrtf(1.0f - powf(hyper1, (float)step));
+    const int grid = (int)min64(ceil_div64(gr.chunk0[num_groups], 256), 4096);
+    float* gmut = const_cast<float*>(grad);
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == 0)
+        hipLaunchKernelGGL(optim_groups_kernel<0>, dim3(grid), dim3(256), 0, s, param, gmut, state1, state2, gr, hyper0, hyper1, eps, bc1, bc2_sqrt, grad_scale, zero_grad);
+    else if (kind == 1)
+        hipLaunchKernelGGL(optim_groups_kernel<1>, dim3(grid), dim3(256), 0, s, param, gmut, state1, state2, gr, hyper0, hyper1, eps, bc1, bc2_sqrt, grad_scale, zero_grad);
+    else
+        hipLaunchKernelGGL(optim_groups_kernel<2>, dim3(grid), dim3(256), 0, s, param, gmut, state1, state2, gr, hyper0, hyper1, eps, bc1, bc2_sqrt, grad_scale, zero_grad);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
 // ---- ray-batch sampling: out_k[i, :] = src_k[index[i], :] for up to 4 row-major fp32 tensors that share ONE index vector
 // (SampleRays, wisp/datasets/transforms/ray_sampler.py:25-35, picks the same random rays out of origins / dirs / rgb /
 // further per-ray channels: one index_select launch each in the reference).  One launch, one pass over the index.

@@ -399,3 +399,40 @@ extern "C" int wisp_raymarch_uniform_emit(const float* origins, const float* dir
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---- wisp._C.ops.uniform_sample_cuda under its own signature (wisp/csrc/ops/uniform_sample.cpp:28-42, kernel
+// uniform_sample_cuda.cu:18-59): nuggets already filtered to non-empty ones, `insum` = inclusive sum of their sample counts.
+// The marching path above (count + scan + emit with positions) does not go through this entry; it exists so that reference
+// code calling the op by name binds unchanged.
+__global__ void __launch_bounds__(256)
+uniform_sample_kernel(int64_t m, float scale, float inv_scale, const int32_t* __restrict__ ridx, const float* __restrict__ depth,
+                      const int32_t* __restrict__ insum, int64_t* __restrict__ new_ridx, float* __restrict__ depth_samples,
+                      uint8_t* __restrict__ boundary) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int base = i > 0 ? insum[i - 1] : 0;
+    const int n = insum[i] - base;
+    const int32_t r = ridx[i];
+    const float first = ceilf(scale * depth[i * 2]);
+    bool bval = i == 0 || ridx[i - 1] != r;
+    float f = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        depth_samples[base + k] = lattice_depth(inv_scale, first, f);
+        f += 1.0f;
+        new_ridx[base + k] = r;
+        boundary[base + k] = bval ? 1 : 0;
+        bval = false;
+    }
+}
+
+extern "C" int wisp_uniform_sample(int scale, const int32_t* ridx, const float* depth, const int32_t* insum,
+                                   int64_t num_nuggets, int64_t* new_ridx, float* depth_samples, uint8_t* boundary,
+                                   wisp_stream_t stream) {
+    WISP_REQUIRE(num_nuggets >= 0 && scale > 0, "bad sizes");
+    if (num_nuggets == 0) return WISP_OK;
+    WISP_REQUIRE(ridx && depth && insum && new_ridx && depth_samples && boundary, "null pointer");
+    hipLaunchKernelGGL(uniform_sample_kernel, dim3((unsigned)ceil_div64(num_nuggets, 256)), dim3(256), 0, (hipStream_t)stream,
+                       num_nuggets, (float)scale, 1.0f / (float)scale, ridx, depth, insum, new_ridx, depth_samples, boundary);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

@@ -58,11 +58,13 @@ SIGNATURES = {
     "wisp_raymarch_ray_emit": [c_vp, c_vp, c_i64, c_f32, c_f32, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_voxel_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_uniform_count": [c_vp, c_i64, c_f32, c_vp, c_vp],
+    "wisp_uniform_sample": [c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_uniform_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_packed_sum_reduce": [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
     "wisp_packed_cumsum": [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "wisp_find_depth_bound": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp],
     "wisp_sphere_trace_step": [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_optim_step_groups": [c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp],
     "wisp_adamw_step_groups": [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp],
     "wisp_gather_rows": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
     "wisp_rgb_loss": [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
@@ -789,6 +791,29 @@ def adamw_step_groups(param, grad, exp_avg, exp_avg_sq, groups, beta1, beta2, ep
                                       beta1, beta2, eps, step, grad_scale, int(zero_grad), _stream()), "adamw_step_groups")
 
 
+OPTIM_KINDS = {"adamw": 0, "adam": 1, "rmsprop": 2}
+
+
+def optim_step_groups(kind, param, grad, state1, state2, groups, hyper0, hyper1, eps, step, grad_scale=1.0, zero_grad=False):
+    """torch.optim.{AdamW, Adam, RMSprop} over several parameter groups of a flat buffer in one launch (see
+    wisp_optim_step_groups).  `groups` as in adamw_step_groups; state1 may be None for RMSprop without momentum."""
+    for t in (param, grad, state2) + ((state1,) if state1 is not None else ()):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    n = len(groups)
+    begin = (ctypes.c_int64 * n)(*[int(g[0]) for g in groups])
+    length = (ctypes.c_int64 * n)(*[int(g[1]) for g in groups])
+    lr = (ctypes.c_float * n)(*[float(g[2]) for g in groups])
+    wd = (ctypes.c_float * n)(*[float(g[3]) for g in groups])
+    for g in groups:
+        assert g[0] + g[1] <= param.numel()
+        if g[4] is not None:
+            assert g[4].dtype == torch.bfloat16 and g[4].numel() == g[1] and g[4].is_contiguous()
+    shadow = (ctypes.c_void_p * n)(*[(g[4].data_ptr() if g[4] is not None else None) for g in groups])
+    _check(lib.wisp_optim_step_groups(OPTIM_KINDS[kind], _p(param), _p(grad), _p(state1), _p(state2), n, begin, length, lr, wd,
+                                      shadow, hyper0, hyper1, eps, step, grad_scale, int(zero_grad), _stream()),
+           "optim_step_groups")
+
+
 # ------------------------------------------------------------------------------------------------ fused NeRF decoder
 def _check_decoder_shapes(feats, params, in_dim, hidden, view_freqs):
     if feats.dim() != 2 or feats.shape[1] != in_dim:
@@ -837,3 +862,68 @@ def nerf_mlp_backward(feats, dirs, params, grad_rgb, grad_density, in_dim, hidde
                                      BF16 if compute_bf16 else F32, _p(grad_rgb), _p(grad_density), _p(grad_feats),
                                      _p(grad_params), _p(ws), _stream()), "nerf_mlp_bwd")
     return grad_feats, grad_params
+
+
+# ------------------------------------------------------------------------------------------------ reference-named surface
+# The reference's pybind module is `wisp._C` with submodules `ops` / `render` (wisp/csrc/bindings.cpp:21-35); its Python
+# callers (wisp/ops/grid.py:92,117; wisp/accelstructs/octree_as.py:353; wisp/ops/geometric.py:22) use exactly the names and
+# positional signatures below, so reference code binds to this module unchanged.  Each function is a thin adapter onto
+# the C-ABI entry points above.
+class _Namespace:
+    def __init__(self, name, **fns):
+        self.__name__ = name
+        self.__dict__.update(fns)
+
+
+def _resolution_list(resolution):
+    # the reference passes a HOST int64 [L,1] tensor and reads it with .item<int>() (hashgrid_interpolate_cuda.cu:365)
+    if torch.is_tensor(resolution):
+        return [int(r) for r in resolution.reshape(-1).tolist()]
+    return [int(r) for r in resolution]
+
+
+def _ref_hashgrid_interpolate_cuda(coords, codebook, codebook_first_idx, resolution, codebook_bitwidth):
+    """hashgrid_interpolate.h:18-23 -> feats [N, L*F] in the dtype of `codebook`."""
+    coords = coords.reshape(-1, coords.shape[-1])
+    return hashgrid_interpolate(coords, codebook, codebook_first_idx, _resolution_list(resolution), int(codebook_bitwidth))
+
+
+def _ref_hashgrid_interpolate_backward_cuda(coords, grad_output, codebook, codebook_first_idx, resolution, codebook_bitwidth,
+                                            feature_dim, require_grad_coords):
+    """hashgrid_interpolate.h:25-33 -> [grad_coords (empty [0] unless requested), grad_codebook in codebook's dtype]."""
+    if require_grad_coords:
+        raise NotImplementedError("grad w.r.t. hash-grid coordinates: the reference's own kernel is known-broken "
+                                  "(hashgrid_interpolate_cuda.cu:165-166,193-194) and no in-scope caller requests it")
+    assert int(feature_dim) == codebook.shape[-1]
+    coords = coords.reshape(-1, coords.shape[-1])
+    grad = hashgrid_interpolate_backward(coords, grad_output.reshape(coords.shape[0], -1), tuple(codebook.shape),
+                                         codebook_first_idx, _resolution_list(resolution), int(codebook_bitwidth))
+    return [torch.empty(0, dtype=torch.float32, device=coords.device), grad.to(codebook.dtype)]
+
+
+def _ref_uniform_sample_cuda(scale, ridx, depth, insum):
+    """uniform_sample.cpp:28-42 -> [ridx i64 [S], depth_samples f32 [S,1], boundary bool [S]]."""
+    ridx = _need(ridx, torch.int32, "ridx")
+    depth = _need(depth, torch.float32, "depth")
+    insum = _need(insum, torch.int32, "insum")
+    V, dev = ridx.shape[0], ridx.device
+    S = int(insum[-1].item()) if V else 0                # the reference's blocking cudaMemcpy (uniform_sample_cuda.cu:76)
+    new_ridx = torch.empty(S, dtype=torch.int64, device=dev)
+    depth_samples = torch.empty(S, 1, dtype=torch.float32, device=dev)
+    boundary = torch.empty(S, dtype=torch.bool, device=dev)
+    if S:
+        _check(lib.wisp_uniform_sample(int(scale), _p(ridx), _p(depth), _p(insum), V, _p(new_ridx), _p(depth_samples),
+                                       _p(boundary), _stream()), "uniform_sample")
+    return [new_ridx, depth_samples, boundary]
+
+
+def _ref_find_depth_bound_cuda(query, curr_idxes, depth):
+    """find_depth_bound.cpp:23-36: query f32 [P,1], curr_idxes i32 [P], depth f32 [M,2] -> i32 [P]."""
+    return find_depth_bound(query.reshape(-1), curr_idxes, depth)
+
+
+ops = _Namespace("wisp._C.ops",
+                 hashgrid_interpolate_cuda=_ref_hashgrid_interpolate_cuda,
+                 hashgrid_interpolate_backward_cuda=_ref_hashgrid_interpolate_backward_cuda,
+                 uniform_sample_cuda=_ref_uniform_sample_cuda)
+render = _Namespace("wisp._C.render", find_depth_bound_cuda=_ref_find_depth_bound_cuda)

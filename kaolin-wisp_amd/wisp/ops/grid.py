@@ -23,6 +23,39 @@ def _as_int_list(resolutions):
     return [int(r) for r in resolutions]
 
 
+def hashgrid_naive(coords, resolutions, codebook_bitwidth, lod_idx, codebook, codebook_lod_sizes, codebook_lod_first_idx):
+    """Plain-PyTorch sketch of the hash-grid lookup, signature of wisp/ops/grid.py:16-76 (levels 0..lod_idx, [batch, (lod_idx+1)*F]).
+    Like the reference's, it is documentation, not the product path and not numerically 1:1 with the kernels (float32
+    scaling with torch.clip, `res**3 > T` as the hash test, int64 hashing: SURVEY 3.4-3); nothing in this package calls it.
+
+    Args:
+        coords (torch.FloatTensor): [batch, 3] in [-1, 1]
+        resolutions: per-level grid resolution, [num_lods]
+        codebook_bitwidth (int): hashed levels have 2^bitwidth rows
+        lod_idx (int): last level to evaluate
+        codebook (torch.Tensor): stacked per-level tables [sum rows, F]
+        codebook_lod_sizes / codebook_lod_first_idx: rows and first row of every level
+    """
+    size = 2 ** codebook_bitwidth
+    pts = coords.reshape(-1, 3)
+    offs = torch.tensor([[(j >> 2) & 1, (j >> 1) & 1, j & 1] for j in range(8)], device=pts.device)     # corner j = (dx, dy, dz)
+    out = []
+    for i, res in enumerate(_as_int_list(resolutions)[:lod_idx + 1]):
+        x = torch.clip((pts + 1.0) * 0.5 * res, 0, res - 1 - 1e-5)
+        base = torch.floor(x)
+        frac = x - base
+        corner = base.long()[:, None, :] + offs[None]                                  # [B, 8, 3]
+        if res ** 3 > size:
+            idx = ((corner[..., 0] * PRIMES[0]) ^ (corner[..., 1] * PRIMES[1]) ^ (corner[..., 2] * PRIMES[2])) % size
+        else:
+            idx = corner[..., 0] + corner[..., 1] * res + corner[..., 2] * res * res
+        first = int(codebook_lod_first_idx[i])
+        table = codebook[first:first + int(codebook_lod_sizes[i])]
+        w = torch.where(offs[None].bool(), frac[:, None, :], 1.0 - frac[:, None, :]).prod(-1)          # [B, 8]
+        out.append((table[idx] * w[..., None].to(table.dtype)).sum(1))
+    return torch.cat(out, -1)
+
+
 # Trainer-side helpers of a table Parameter, kept OUT of Parameter.__dict__ (which torch.save(pipeline) would pickle: the
 # flat gradient / shadow storages would travel with the checkpoint and come back dangling).  Weak keys: an entry dies
 # with its Parameter.

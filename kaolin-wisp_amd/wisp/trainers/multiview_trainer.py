@@ -199,8 +199,16 @@ def _decoder_tensors(nef):
 class MultiviewTrainStep:
     def __init__(self, pipeline, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, betas=(0.9, 0.999),
                  rgb_loss_type='huber', prune_every=100, target_sample_size=2 ** 18, max_rays=2 ** 18,
-                 enable_amp=False, scheduler_milestones=None, scheduler_gamma=0.333, process_group=None, seed=0):
+                 enable_amp=False, scheduler_milestones=None, scheduler_gamma=0.333, process_group=None, seed=0,
+                 optimizer='adamw', alpha=0.99, momentum=0.0):
+        """optimizer: 'adamw' | 'adam' | 'rmsprop' - the torch.optim classes the reference's configs select
+        (wisp/config/presets/torch.py:45-68; nerf_hash.yaml: AdamW, nerf_octree / nerf_codebook.yaml: RMSprop), each
+        one fused launch over the flat parameter buffer.  `betas` (Adam family) / `alpha`, `momentum` (RMSprop) as in torch."""
         self.pipeline = pipeline
+        self.optimizer = str(optimizer).lower()
+        if self.optimizer not in ('adamw', 'adam', 'rmsprop'):
+            raise ValueError(f"optimizer must be 'adamw', 'adam' or 'rmsprop', got {optimizer!r}")
+        self.alpha, self.momentum = alpha, momentum
         self.flat = FlatParams(pipeline.nef)
         self.lr, self.eps, self.weight_decay, self.grid_lr_weight, self.betas = lr, eps, weight_decay, grid_lr_weight, betas
         self.rgb_loss_type = rgb_loss_type
@@ -247,8 +255,15 @@ class MultiviewTrainStep:
             if b > a:
                 groups.append((a, b - a, lr * s, self.weight_decay, f.shadow if g == "grid" else None))
         # all parameter groups in ONE launch (the decoder group alone is ~10 K parameters)
-        C.adamw_step_groups(f.data, f.grad, f.exp_avg, f.exp_avg_sq, groups, self.betas[0], self.betas[1], self.eps,
-                            self.opt_steps, grad_scale=gs, zero_grad=True)
+        if self.optimizer == 'adamw':
+            C.adamw_step_groups(f.data, f.grad, f.exp_avg, f.exp_avg_sq, groups, self.betas[0], self.betas[1], self.eps,
+                                self.opt_steps, grad_scale=gs, zero_grad=True)
+        elif self.optimizer == 'adam':
+            C.optim_step_groups('adam', f.data, f.grad, f.exp_avg, f.exp_avg_sq, groups, self.betas[0], self.betas[1],
+                                self.eps, self.opt_steps, grad_scale=gs, zero_grad=True)
+        else:       # RMSprop: exp_avg_sq holds square_avg, exp_avg the momentum buffer
+            C.optim_step_groups('rmsprop', f.data, f.grad, f.exp_avg if self.momentum > 0 else None, f.exp_avg_sq, groups,
+                                self.alpha, self.momentum, self.eps, self.opt_steps, grad_scale=gs, zero_grad=True)
         f.mark_shadow_current()                 # the kernel rewrote every shadow element from the new master weights
 
     def allreduce_grads(self):

@@ -304,3 +304,59 @@ def test_trainer_prune_is_a_noop_without_an_occupancy_record():
     Nef.prune_density_decay = None
     Nef.grid.dense_points = torch.zeros(4, 3)
     t.prune()
+
+
+def test_hashgrid_naive_agrees_with_oracle_on_cpu():
+    from wisp.ops.grid import hashgrid_naive
+    from oracle import hashgrid as oh
+    res, bw = [4, 8, 16, 40], 10
+    sizes, begin = oh.table_layout(res, 2 ** bw)
+    torch.manual_seed(0)
+    table = torch.randn(int(begin[-1]), 2)
+    coords = torch.rand(500, 3) * 2 - 1
+    got = hashgrid_naive(coords, torch.tensor(res), bw, 3, table, sizes, begin[:-1])
+    want = oh.hashgrid_forward(coords, table, torch.from_numpy(begin), res, bw)
+    assert got.shape == (500, 8) and float((got - want).abs().max()) < 1e-5
+    assert hashgrid_naive(coords, res, bw, 1, table, sizes, begin[:-1]).shape == (500, 4)
+
+
+def test_reference_named_native_surface_exists():
+    """wisp._C.ops.* / wisp._C.render.* under the names and arities the reference binds (wisp/csrc/bindings.cpp:21-35)."""
+    import inspect
+    import wisp._C as C
+    want = {"ops": {"hashgrid_interpolate_cuda": 5, "hashgrid_interpolate_backward_cuda": 8, "uniform_sample_cuda": 4},
+            "render": {"find_depth_bound_cuda": 3}}
+    for ns, fns in want.items():
+        for name, arity in fns.items():
+            fn = getattr(getattr(C, ns), name)
+            assert len(inspect.signature(fn).parameters) == arity, name
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/wisp/ops/grid.py"), reason="reference tree not mounted (GPU box)")
+def test_reference_ops_grid_module_binds_to_this_C_unchanged():
+    """Execute the reference's OWN wisp/ops/grid.py source (read in place, never copied) with `wisp._C` = this package's
+    module and a stub for the absent kaolin import: every `wisp_C.<ns>.<fn>` it names must resolve here."""
+    import re
+    import sys
+    import types
+    import wisp._C as C
+    src = open("/root/reference/wisp/ops/grid.py").read()
+    used = set(re.findall(r"wisp_C\.(\w+)\.(\w+)", src))
+    assert ("ops", "hashgrid_interpolate_cuda") in used and ("ops", "hashgrid_interpolate_backward_cuda") in used
+    hot = {(ns, fn) for ns, fn in used if "hashgrid_interpolate" in fn}
+    for ns, fn in hot:
+        assert callable(getattr(getattr(C, ns), fn)), (ns, fn)
+    stub = types.ModuleType("kaolin"); stub.ops = types.ModuleType("kaolin.ops"); stub.ops.spc = types.ModuleType("kaolin.ops.spc")
+    stub._C = types.ModuleType("kaolin._C")
+    saved = {k: sys.modules.get(k) for k in ("kaolin", "kaolin.ops", "kaolin.ops.spc")}
+    sys.modules.update({"kaolin": stub, "kaolin.ops": stub.ops, "kaolin.ops.spc": stub.ops.spc})
+    try:
+        ns = {"__name__": "reference_ops_grid"}
+        exec(compile(src, "/root/reference/wisp/ops/grid.py", "exec"), ns)      # `import wisp._C as wisp_C` -> this package
+        assert ns["wisp_C"] is C and issubclass(ns["HashGridInterpolate"], torch.autograd.Function)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

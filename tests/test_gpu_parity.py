@@ -153,43 +153,29 @@ def _ray_like_coords(rng, n, dim=3, run=32):
 @pytest.mark.parametrize("n", [4096, 8192, 65536])
 def test_hashgrid_backward_is_repeatable_and_race_free(res, bitwidth, n):
     """Round-1 failure (GPUTEST_r01: error 1.7 on a gradient of scale 11.8): buckets of a dense level sized (res+1)^3 reached
-    into the next level's rows and its zero-adding flush raced with the owner of those rows.  50 repetitions of the same
-    backward must agree with the oracle every time; on hashed levels (one workgroup per bucket, 64-bit fixed-point sums)
-    they must be bitwise identical, on dense levels (partial sums of <= 64 workgroups added with float atomics) within
-    float add-order noise."""
+    into the next level's rows and its zero-adding flush raced with the owner of those rows - a LOST UPDATE, which showed up
+    only on some boxes.  50 repetitions of the same backward, each one compared with the float64 oracle at float
+    add-order tolerance (a lost update is five orders of magnitude above it).  Repetitions are not required to be bitwise
+    equal: a slot that overflows falls back to float atomics, whose order is free."""
     rng = np.random.default_rng(5 + n)
     _, begin = ohash.table_layout(res, 2 ** bitwidth)
     shape = (int(begin[-1]), 2)
     coords = _ray_like_coords(rng, n)
     go = rng.normal(size=(n, len(res) * 2)).astype(np.float32)
-    want = ohash.hashgrid_backward(torch.from_numpy(coords), torch.from_numpy(go), shape, torch.from_numpy(begin), res, bitwidth,
-                                   torch.float64)
-    scale = float(want.abs().max())
-    dense = [ohash.level_is_dense(r, 2 ** bitwidth) for r in res]
-    first_hashed = int(begin[dense.index(False)])
     c, g, b = cuda(coords), cuda(go), cuda(begin)
-    ref = None
-    for rep in range(50):
-        got = _C().hashgrid_interpolate_backward(c, g, shape, b, res, bitwidth)
-        if ref is None:
-            ref = got
-            assert float((got.double().cpu() - want).abs().max()) <= 4e-6 * scale
-        else:
-            assert torch.equal(got[first_hashed:], ref[first_hashed:]), f"repetition {rep}: hashed levels differ"
-            assert float((got[:first_hashed] - ref[:first_hashed]).abs().max()) <= 2e-6 * scale, f"repetition {rep}"
-    # the bf16 compact-record path, same property
-    gb = g.bfloat16()
-    want_b = ohash.hashgrid_backward(torch.from_numpy(coords), gb.float().cpu(), shape, torch.from_numpy(begin), res, bitwidth,
-                                     torch.float64)
-    ref = None
-    for rep in range(20):
-        got = _C().hashgrid_interpolate_backward(c, gb, shape, b, res, bitwidth)
-        if ref is None:
-            ref = got
-            assert float((got.double().cpu() - want_b).abs().max()) <= 3e-5 * scale
-        else:
-            assert torch.equal(got[first_hashed:], ref[first_hashed:]), f"bf16 repetition {rep}"
-            assert float((got[:first_hashed] - ref[:first_hashed]).abs().max()) <= 2e-6 * scale
+    for dt, tol, reps in ((torch.float32, 4e-6, 50), (torch.bfloat16, 3e-5, 25)):
+        gd = g.to(dt)
+        want = ohash.hashgrid_backward(torch.from_numpy(coords), gd.float().cpu(), shape, torch.from_numpy(begin), res, bitwidth,
+                                       torch.float64)
+        scale = float(want.abs().max())
+        want = want.to(DEV)
+        worst = 0.0
+        for rep in range(reps):
+            got = _C().hashgrid_interpolate_backward(c, gd, shape, b, res, bitwidth)
+            err = float((got.double() - want).abs().max())
+            worst = max(worst, err)
+            assert err <= tol * scale, f"{dt} repetition {rep}: |grad - oracle| = {err} on a gradient of scale {scale}"
+        print(f"n={n} {dt}: worst |grad - oracle| over {reps} repetitions = {worst:.3e} (scale {scale:.3f})")
 
 
 def test_hashgrid_dense_level_spill_follows_reference_pointer_arithmetic():
@@ -231,6 +217,49 @@ def test_hashgrid_dense_level_spill_follows_reference_pointer_arithmetic():
     assert float(guard[int(begin1[-1]):].abs().max()) == 0.0
     with pytest.raises(RuntimeError, match="num_lods \\+ 1"):
         _C().hashgrid_interpolate(cuda(coords), cuda(table), cuda(begin[:2]), res, bw)
+
+
+def test_reference_named_ops_follow_the_reference_call_pattern():
+    """The calls wisp/ops/grid.py:92-96,117-121 and wisp/accelstructs/octree_as.py:336-353 make into `wisp._C`, made with the
+    reference's own argument conventions (HOST int64 [L,1] resolutions, positional order) against this package's module."""
+    import wisp._C as wisp_C
+    rng = np.random.default_rng(31)
+    res = [16, 40, 101, 256]
+    bw = 14
+    _, begin = ohash.table_layout(res, 2 ** bw)
+    codebook = cuda(rng.uniform(-0.1, 0.1, (int(begin[-1]), 2)).astype(np.float32))
+    first_idx = cuda(begin)
+    resolutions = torch.tensor([[r] for r in res], dtype=torch.int64)              # models/grids/utils.py:44-46: stays on the host
+    coords = cuda(rng.uniform(-1, 1, (5000, 3)).astype(np.float32))
+    feats = wisp_C.ops.hashgrid_interpolate_cuda(coords.contiguous(), codebook, first_idx, resolutions, bw).contiguous()
+    want = ohash.hashgrid_forward(coords.cpu(), codebook.cpu(), torch.from_numpy(begin), res, bw)
+    np.testing.assert_allclose(feats.cpu().numpy(), want.numpy(), atol=2e-7)
+    go = cuda(rng.normal(size=(5000, 8)).astype(np.float32))
+    grad_coords, grad_codebook = wisp_C.ops.hashgrid_interpolate_backward_cuda(
+        coords.float().contiguous(), go.contiguous(), codebook, first_idx, resolutions, bw, 2, False)
+    wantg = ohash.hashgrid_backward(coords.cpu(), go.cpu(), tuple(codebook.shape), torch.from_numpy(begin), res, bw, torch.float64)
+    assert grad_coords.numel() == 0 and grad_codebook.dtype == codebook.dtype
+    assert float((grad_codebook.double().cpu() - wantg).abs().max()) <= 4e-6 * float(wantg.abs().max())
+    # half table -> half features and half gradient table, as AT_DISPATCH_FLOATING_TYPES_AND_HALF gives (.cu:358,413)
+    fh = wisp_C.ops.hashgrid_interpolate_cuda(coords, codebook.half(), first_idx, resolutions, bw)
+    assert fh.dtype == torch.float16
+    # uniform_sample_cuda after the reference's own filtering + inclusive sum (octree_as.py:336-353)
+    oc, pts, pyr, ex = sparse_tree(5, 400, 3)
+    o, d = make_rays(300, 8)
+    nr, npx, ndp = ospc.raytrace(oc, pts, pyr, ex, o, d, 5, with_exit=True)
+    scale, _ = omarch.uniform_scale(64)
+    depth = cuda(ndp.astype(np.float32))
+    ia = torch.ceil(scale * depth[..., 0]).int(); ib = torch.ceil(scale * depth[..., 1]).int()
+    cnt = ib - ia
+    nz = cnt != 0
+    insum = _C().inclusive_scan(cnt[nz].contiguous())
+    r2, dep2, b2 = wisp_C.ops.uniform_sample_cuda(scale, cuda(nr.astype(np.int32))[nz].contiguous(), depth[nz], insum)
+    want_u = omarch.raymarch_uniform(oc, pts, pyr, ex, o, d, 64, 5)
+    assert r2.dtype == torch.int64 and dep2.shape == (r2.shape[0], 1) and b2.dtype == torch.bool
+    assert np.array_equal(r2.cpu().numpy(), want_u["ridx"]) and np.array_equal(b2.cpu().numpy(), want_u["boundary"])
+    assert np.array_equal(dep2.cpu().numpy().reshape(-1), np.asarray(want_u["depth_samples"]).reshape(-1))
+    with pytest.raises(NotImplementedError):
+        wisp_C.ops.hashgrid_interpolate_backward_cuda(coords, go, codebook, first_idx, resolutions, bw, 2, True)
 
 
 def test_hashgrid_autograd_module_cat_and_sum():
@@ -483,6 +512,43 @@ def test_adamw_matches_torch():
         _C().adamw_step(p, gg, m, v, 1e-2, 0.9, 0.999, 1e-15, 1e-3, step, grad_scale=0.5, zero_grad=True, bf16_shadow=shadow)
         assert float(gg.abs().max()) == 0.0 and torch.equal(shadow, p.bfloat16())
     np.testing.assert_allclose(p.cpu().numpy(), ref.detach().cpu().numpy(), atol=2e-6)
+
+
+@pytest.mark.parametrize("kind,kw", [("rmsprop", dict(alpha=0.99, momentum=0.0)), ("rmsprop", dict(alpha=0.9, momentum=0.8)),
+                                     ("adam", dict(betas=(0.9, 0.999))), ("adamw", dict(betas=(0.85, 0.99)))])
+def test_fused_optimizers_match_torch_optim(kind, kw):
+    """wisp_optim_step_groups vs torch.optim.{RMSprop, Adam, AdamW} (the classes wisp/config/presets/torch.py:45-68 configure;
+    RMSprop: nerf_octree.yaml:85, nerf_codebook.yaml:86) over two parameter groups with different lr / weight decay."""
+    torch.manual_seed(4)
+    n0, n1 = 10259, 70001                         # decoder-sized group + a second one; neither a multiple of 4
+    pad0 = (n0 + 3) // 4 * 4
+    total = pad0 + (n1 + 3) // 4 * 4
+    flat = torch.randn(total, device=DEV)
+    grad = torch.zeros(total, device=DEV)
+    s1 = torch.zeros(total, device=DEV); s2 = torch.zeros(total, device=DEV)
+    r0 = flat[:n0].clone().requires_grad_(True); r1 = flat[pad0:pad0 + n1].clone().requires_grad_(True)
+    groups_t = [{"params": [r0], "lr": 1e-2, "weight_decay": 1e-3}, {"params": [r1], "lr": 5e-2, "weight_decay": 0.0}]
+    eps = 1e-8
+    if kind == "rmsprop":
+        opt = torch.optim.RMSprop(groups_t, eps=eps, **kw); h0, h1 = kw["alpha"], kw["momentum"]
+    elif kind == "adam":
+        opt = torch.optim.Adam(groups_t, eps=eps, **kw); h0, h1 = kw["betas"]
+    else:
+        opt = torch.optim.AdamW(groups_t, eps=eps, **kw); h0, h1 = kw["betas"]
+    shadow = torch.empty(n1, dtype=torch.bfloat16, device=DEV)
+    groups = [(0, n0, 1e-2, 1e-3, None), (pad0, n1, 5e-2, 0.0, shadow)]
+    untouched = flat[n0:pad0].clone()
+    for step in range(1, 6):
+        g = torch.randn(total, device=DEV) * (0.1 * step)
+        r0.grad = g[:n0].clone(); r1.grad = g[pad0:pad0 + n1].clone()
+        opt.step()
+        grad.copy_(g * 4.0)
+        _C().optim_step_groups(kind, flat, grad, s1 if (kind != "rmsprop" or h1 > 0) else None, s2, groups, h0, h1, eps, step,
+                               grad_scale=0.25, zero_grad=True)
+        assert float(grad[:n0].abs().max()) == 0.0 and float(grad[pad0:pad0 + n1].abs().max()) == 0.0
+    np.testing.assert_allclose(flat[:n0].cpu().numpy(), r0.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(flat[pad0:pad0 + n1].cpu().numpy(), r1.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+    assert torch.equal(shadow, flat[pad0:pad0 + n1].bfloat16()) and torch.equal(flat[n0:pad0], untouched)
 
 
 def test_adamw_groups_equal_one_launch_per_group():
