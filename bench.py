@@ -7,8 +7,14 @@
 
 One "step" = one pass of the hot path over one batch of rays: on-device ray sampling from the bank, raymarch
 ('ray', 2048 candidates per ray against the level-7 occupancy octree), hash-grid interpolation (L=16, F=2, T=2^19),
-density + colour MLPs, packed compositing, huber loss, backward, (RCCL all-reduce when N>1), fused AdamW.
+density + colour MLPs, packed compositing, huber loss, backward, (RCCL all-reduce when N>1), fused AdamW, and - every
+100th step, wherever that falls - the occupancy prune (nerf.py:175-212).
 Prints ONE JSON line (rank 0).  Inputs are synthetic (synlego.py) and resident in HBM before the timed region.
+
+Sequence: dense level-7 octree (nerf_hash.yaml:16-17) -> `--pretrain` untimed optimisation steps with the trainer's own
+adaptive ray count and pruning -> W warm-up + exactly K timed steps at `--target-samples` packed samples per step (the
+headline `value`) -> W + K steps at the reference trainer's 2^18 samples per step (`reference_regime`) -> one prune timed on
+its own (`prune`) -> PSNR on held-out rays -> live rocprofv3 --pmc passes for `roofline.traffic` -> CPU oracle baseline.
 """
 import argparse
 import json
@@ -34,16 +40,26 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pretrain", type=int, default=300,
+                    help="untimed optimisation steps from the DENSE level-7 octree before warm-up (prune every 100, adaptive "
+                         "ray count): the timed steps then run on an occupancy the model has learned, and the PSNR means something")
     ap.add_argument("--num-steps", type=int, default=2048, help="raymarch candidates per ray (nerf_hash.yaml:49)")
     ap.add_argument("--target-samples", type=int, default=2 ** 21,
-                    help="packed samples per step per GPU (reference trainer default is 2^18)")
+                    help="packed samples per step per GPU of the headline regime (reference trainer default: 2^18, reported "
+                         "next to it as reference_regime)")
+    ap.add_argument("--ref-target-samples", type=int, default=2 ** 18, help="multiview_trainer.py:58")
     ap.add_argument("--bank-rays", type=int, default=2 ** 21)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--occupancy", choices=["dense", "analytic"], default="dense",
+                    help="'dense' = nerf_hash.yaml:16-17 (make_dense level 7, pruned while training); 'analytic' = start from "
+                         "the scene's true occupied cells (kernel profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--eval-rays", type=int, default=2 ** 16)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -92,6 +108,69 @@ def cpu_baseline(blas_cells, hidden, num_steps, budget_s=20.0):
                        f"fp32, torch-CPU + numpy, {dt:.1f}s")
 
 
+# algorithmic work per packed sample (SURVEY.md 8d / DESIGN.md 4): bytes for the HBM-bound kernels, flops for the decoder
+def work_table(amp):
+    b = 2 if amp else 4
+    return {"hashgrid_fwd": ("hbm", 12 + 16 * 8 * 2 * b + 16 * 2 * b),        # coords + 128 gathered entries + 32 outputs
+            # SURVEY 8(d): 12 + L*F*b + 2*L*2^d*F*b_acc with b_acc = the table element size (1100 B for 16-bit tables).
+            # The kernels accumulate in fp32 / 64-bit fixed point and merge runs, so what they actually move is `traffic`.
+            "hashgrid_bwd": ("hbm", 12 + 16 * 2 * b + 2 * 16 * 8 * 2 * b),
+            "nerf_mlp_fwd": ("mfma", 20096), "nerf_mlp_bwd": ("mfma", 3 * 20096)}
+
+
+PMC_KERNELS = {"hashgrid_fwd": ["hashgrid_fwd_kernel"],
+               "hashgrid_bwd": ["hashgrid_bwd_emit_kernel", "hashgrid_bwd_reduce_kernel", "hashgrid_bwd_kernel"],
+               "nerf_mlp_fwd": ["mlp_fwd_kernel"], "nerf_mlp_bwd": ["mlp_bwd_kernel", "nerf_mlp_reduce_kernel"]}
+
+
+def live_pmc_traffic(args, kernel_names, timeout_s=240):
+    """HBM-side bytes per launch of `kernel_names`, measured NOW: this same script is re-run under rocprofv3 in its
+    --pmc-child mode (a few steps of the same step on the scene's analytic occupancy), one counter per pass as
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass; kernel-trace only, nothing else).
+    FETCH_SIZE is doubled (gfx950 tallies 128-B requests as 64 B); both counters are KiB.  Returns (bytes, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    rx = "|".join(kernel_names)
+    total, per = 0.0, {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        out = tempfile.mkdtemp(prefix="wisp_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--kernel-include-regex", rx, "--output-format", "csv", "-d", out,
+               "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--precision", args.precision,
+               "--hidden", str(args.hidden), "--num-steps", str(args.num_steps), "--target-samples", str(args.target_samples)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+        except (subprocess.TimeoutExpired, OSError) as e:
+            shutil.rmtree(out, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}"
+        vals = {}
+        for path in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    for kn in kernel_names:
+                        if kn in row.get("Kernel_Name", ""):
+                            vals.setdefault(kn, []).append(float(row["Counter_Value"]))
+        shutil.rmtree(out, ignore_errors=True)
+        if not vals:
+            return None, f"rocprofv3 --pmc {counter}: no rows (rc {r.returncode})"
+        for kn, v in vals.items():
+            # the child runs warm-up + timed steps; every dispatch of the kernel does the same work
+            per.setdefault(kn, {})[counter] = float(np.mean(v)) * 1024.0 * mult
+            total += float(np.mean(v)) * 1024.0 * mult
+    return total, {"source": "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (--pmc-child), FETCH_SIZE x2, "
+                             "bytes per launch", "per_kernel": per}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,10 +187,17 @@ def main():
 
     import synlego
     import wisp._C as C
+    from wisp.accelstructs import OctreeAS
     from wisp.core import Rays
     from wisp.trainers import MultiviewTrainStep
 
-    cells = synlego.occupied_cells(7, device=dev)
+    if args.pmc_child:                                     # profiling child: fixed occupancy, a handful of steps, no extras
+        args.occupancy, args.pretrain, args.warmup, args.steps = "analytic", 0, 2, 4
+    true_cells = synlego.occupied_cells(7, device=dev)
+    if args.occupancy == "dense":
+        cells = OctreeAS.make_dense(level=7).points[-(128 ** 3):].to(dev)     # nerf_hash.yaml:16-17
+    else:
+        cells = true_cells
     pipe = build_pipeline(dev, args.hidden, args.num_steps, cells)
     amp = args.precision == "bf16"
     trainer = MultiviewTrainStep(pipe, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, rgb_loss_type='huber',
@@ -126,63 +212,100 @@ def main():
         o, d, rgb = C.gather_rows(idx, [bank_o, bank_d, bank_rgb])       # SampleRays: one launch for the three gathers
         return Rays(o, d, dist_min=synlego.NEAR, dist_max=synlego.FAR), rgb
 
-    # warm-up raymarch sizes the batch like MultiviewTrainer.step's first call (multiview_trainer.py:119-122)
-    rays, _ = batch(4096)
-    rm = pipe.nef.grid.raymarch(rays, level=pipe.nef.grid.active_lods[-1], num_samples=args.num_steps, raymarch_type='ray')
-    pipe.tracer.prev_num_samples = rm.samples.shape[0]
-    R = trainer.calc_adaptive_rays(4096)
-    if world > 1:                                         # every rank uses the same ray count
-        t = torch.tensor([R], device=dev, dtype=torch.int64)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        R = int(t.item())
+    def common_rays(n):
+        """every rank uses the same ray count, so that the mean of the per-rank mean losses is the global mean"""
+        if world > 1:
+            t = torch.tensor([n], device=dev, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            n = int(t.item())
+        return max(int(n), 256)
 
-    # the loop hands the trainer the NEXT batch's rays as well (a one-batch look-ahead, like a prefetching data loader):
-    # their occupancy test is issued early and the next step does not stall on its sample-count read-back
-    rays, gts = batch(R)
-    for _ in range(args.warmup):
-        nrays, ngts = batch(R)
-        trainer.step(rays, gts, prefetch=nrays)
-        rays, gts = nrays, ngts
+    def size_batch(target):
+        """MultiviewTrainer.step's first call (multiview_trainer.py:119-122): a raymarch-only pass sizes the batch."""
+        trainer.target_sample_size = target
+        probe, _ = batch(4096)
+        rm = pipe.nef.grid.raymarch(probe, level=pipe.nef.grid.active_lods[-1], num_samples=args.num_steps, raymarch_type='ray')
+        pipe.tracer.prev_num_samples = rm.samples.shape[0]
+        return common_rays(trainer.calc_adaptive_rays(4096))
 
-    C.TIMING = {}                                         # HIP-event timing of the hash-grid kernels, live
-    if world > 1:
-        dist.barrier()
+    # ---- untimed pre-training from the dense octree: adaptive ray count every step (calc_adaptive_rays), prune every 100
+    R = size_batch(args.target_samples)
+    for _ in range(args.pretrain):
+        rays, gts = batch(R)
+        trainer.step(rays, gts)
+        R = common_rays(trainer.num_rays)
+    R = size_batch(args.target_samples)                    # fixed for the timed region: per-GPU work is constant ("weak")
+
+    def timed_steps(R, warmup, steps, timing_sink=None):
+        """`warmup` untimed + exactly `steps` timed steps with a one-batch look-ahead (like a prefetching data loader: the
+        next batch's occupancy test is issued early, so a step does not stall on its sample-count read-back).
+        -> (seconds [max over ranks], packed samples of this rank, prunes that fell into the timed steps)"""
+        rays, gts = batch(R)
+        for _ in range(warmup):
+            nrays, ngts = batch(R)
+            trainer.step(rays, gts, prefetch=nrays)
+            rays, gts = nrays, ngts
+        C.TIMING = timing_sink
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        it0 = trainer.total_iterations
+        t0 = time.perf_counter()
+        samples = 0
+        for _ in range(steps):
+            nrays, ngts = batch(R)
+            _, ns = trainer.step(rays, gts, prefetch=nrays)
+            samples += ns
+            rays, gts = nrays, ngts
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        C.TIMING = None
+        prunes = sum(1 for it in range(it0, it0 + steps) if it > 1 and it % trainer.prune_every == 0)
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, samples, prunes
+
+    def all_sum(v):
+        if world > 1:
+            t = torch.tensor([v], device=dev, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return int(t.item())
+        return v
+
+    timing = {}                                           # HIP-event timing of the hot kernels, live, on the launch stream
+    elapsed, total_samples, prunes_in = timed_steps(R, args.warmup, args.steps, timing)
+    total_samples_all = all_sum(total_samples)
+    blas_now = pipe.nef.grid.blas
+    cells_now = int(blas_now.pyramid[0, blas_now.max_level])          # leaf cells of the (pruned) octree
+    if args.pmc_child:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return None
+
+    # ---- the reference trainer's own regime: 2^18 samples per step (multiview_trainer.py:58), same model state
+    R_ref = size_batch(args.ref_target_samples)
+    ref_elapsed, ref_samples, ref_prunes = timed_steps(R_ref, min(args.warmup, 3), args.steps)
+    ref_samples_all = all_sum(ref_samples)
+    trainer.target_sample_size = args.target_samples
+
+    # ---- one prune, timed on its own (it falls into the timed steps only every 100th iteration)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    total_samples = 0
-    for _ in range(args.steps):
-        nrays, ngts = batch(R)
-        _, ns = trainer.step(rays, gts, prefetch=nrays)
-        total_samples += ns
-        rays, gts = nrays, ngts
+    tp = time.perf_counter()
+    trainer.prune()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    timing, C.TIMING = C.TIMING, None
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        t = torch.tensor([total_samples], device=dev, dtype=torch.int64)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        total_samples_all = int(t.item())
-    else:
-        total_samples_all = total_samples
+    prune_ms = 1e3 * (time.perf_counter() - tp)
 
     # ---- per-kernel roofline from the live HIP events (algorithmic bytes: SURVEY.md 8d / DESIGN.md)
     kern = {}
-    for name, evs in (timing or {}).items():
+    for name, evs in timing.items():
         ms = [a.elapsed_time(b) for a, b, _ in evs]
         units = [u for _, _, u in evs]
         kern[name] = dict(avg_ms=float(np.mean(ms)), launches=len(ms), avg_units=float(np.mean(units)), total_ms=float(np.sum(ms)))
-    b = 2 if amp else 4
-    # algorithmic work per packed sample (SURVEY.md 8d / DESIGN.md): bytes for the HBM-bound kernels, flops for the MLP
-    work = {"hashgrid_fwd": ("hbm", 12 + 16 * 8 * 2 * b + 16 * 2 * b),        # coords + 128 gathered entries + 32 outputs
-            # SURVEY 8(d): 12 + L*F*b + 2*L*2^d*F*b_acc with b_acc = the table element size (1100 B for 16-bit tables).
-            # The kernels accumulate in fp32 / 64-bit fixed point and merge runs, so what they actually move is `traffic`.
-            "hashgrid_bwd": ("hbm", 12 + 16 * 2 * b + 2 * 16 * 8 * 2 * b),
-            "nerf_mlp_fwd": ("mfma", 20096), "nerf_mlp_bwd": ("mfma", 3 * 20096)}
+    work = work_table(amp)
     peaks = {"hbm": (HBM_PEAK_GBS, "GB/s"), "mfma": (2500.0 if amp else 157.3, "TFLOP/s")}
 
     def rate(name, v):
@@ -190,24 +313,6 @@ def main():
         r = per * v["avg_units"] / (v["avg_ms"] * 1e-3)
         return bound, (r / 1e9 if bound == "hbm" else r / 1e12)
 
-    def pmc_traffic(kernel_prefixes):
-        """HBM-side bytes per launch from the committed rocprofv3 PMC summaries of this same command (profiles/r01_pmc_*):
-        FETCH_SIZE (KiB, doubled per MI355X_MICROARCH.md: it counts 128-B requests as 64 B) + WRITE_SIZE (KiB)."""
-        import csv
-        tot = 0.0
-        try:
-            for fname, mult in (("r01_pmc_FETCH_SIZE.csv", 2.0), ("r01_pmc_WRITE_SIZE.csv", 1.0)):
-                with open(os.path.join(ROOT, "profiles", fname)) as f:
-                    for row in csv.DictReader(f):
-                        if any(k in row["kernel"] for k in kernel_prefixes):
-                            tot += float(row["mean_per_dispatch"]) * 1024.0 * mult
-        except (OSError, KeyError, ValueError):
-            return None
-        return tot or None
-
-    pmc_names = {"hashgrid_fwd": ["hashgrid_fwd_kernel"], "hashgrid_bwd": ["hashgrid_bwd_emit_kernel", "hashgrid_bwd_reduce_kernel",
-                                                                           "hashgrid_bwd_kernel"],
-                 "nerf_mlp_fwd": ["mlp_fwd_kernel"], "nerf_mlp_bwd": ["mlp_bwd_kernel", "nerf_mlp_reduce_kernel"]}
     kern = {n: v for n, v in kern.items() if n in work}
     dominant = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
     roofline = None
@@ -216,17 +321,14 @@ def main():
         bound, achieved = rate(dominant, k)
         peak, unit = peaks[bound]
         roofline = dict(bound=bound, kernel=dominant, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
-                        traffic=pmc_traffic(pmc_names[dominant]) if (amp and world == 1) else None,
-                        traffic_note="bytes/launch from profiles/r01_pmc_{FETCH,WRITE}_SIZE.csv (rocprofv3 --pmc, same command, "
-                                     "FETCH_SIZE x2); hashgrid_bwd = emit + reduce kernels",
-                        avg_launch_ms=k["avg_ms"], units_per_launch=k["avg_units"],
-                        work_per_unit=work[dominant][1],
+                        traffic=None, traffic_note="not measured (--no-pmc, multi-GPU run or profiler unavailable); see profiles/",
+                        avg_launch_ms=k["avg_ms"], units_per_launch=k["avg_units"], work_per_unit=work[dominant][1],
                         all_kernels={n: dict(avg_ms=v["avg_ms"], bound=rate(n, v)[0], achieved=rate(n, v)[1],
                                              frac=rate(n, v)[1] / peaks[rate(n, v)[0]][0]) for n, v in kern.items()})
 
     out = None
     if rank == 0:
-        # quality probe: PSNR on held-out rays after the (short) run
+        # quality: PSNR on held-out rays after pretrain + warm-up + both timed loops (real optimisation steps all of them)
         with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
             eo, ed, ergb = synlego.ray_bank(args.eval_rays, seed=7, device=dev)
             chunks = []
@@ -236,6 +338,8 @@ def main():
             mse = float(((torch.cat(chunks) - ergb) ** 2).mean())
         psnr = 10 * math.log10(1.0 / max(mse, 1e-12))
         rays_total = R * args.steps * world
+        ref_rays_total = R_ref * args.steps * world
+        amort = elapsed + (args.steps / trainer.prune_every - prunes_in) * prune_ms * 1e-3   # exactly steps/100 prunes
         out = {
             "metric": "training rays/sec, HashGrid NeRF (nerf_hash.yaml), synthetic Lego 800x800",
             "value": rays_total / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -243,16 +347,29 @@ def main():
             "dtype": "bf16" if amp else "f32", "data": "synthetic",
             "config": {"workload": "app/nerf nerf_hash.yaml: OctreeAS level 7, HashGrid L=16 F=2 T=2^19 res 16..512 'cat', "
                                    f"NeRF hidden {args.hidden}, 'ray' raymarch {args.num_steps} candidates/ray, huber, AdamW; "
-                                   "SynLego 800x800 rays, analytic (post-prune) occupancy",
+                                   f"SynLego 800x800 rays; occupancy: {args.occupancy} level-7 start, pruned every 100 steps "
+                                   f"({args.pretrain} untimed pre-training steps before the timed ones)",
                        "rays_per_step_per_gpu": R, "target_samples_per_step": args.target_samples,
                        "samples_per_ray": total_samples_all / max(rays_total, 1), "parallelism": f"ray-sharded dp{world}",
-                       "occupied_cells": int(cells.shape[0])},
+                       "occupied_cells": cells_now, "true_occupied_cells": int(true_cells.shape[0]),
+                       "prunes_inside_timed_steps": prunes_in},
             "samples_per_sec": total_samples_all / elapsed,
-            "psnr_db_after_run": psnr,
+            "prune": {"ms": prune_ms, "every_steps": trainer.prune_every,
+                      "value_with_amortised_prune": rays_total / amort},
+            "reference_regime": {"target_samples_per_step": args.ref_target_samples, "rays_per_step_per_gpu": R_ref,
+                                 "value": ref_rays_total / ref_elapsed, "unit": "rays/s",
+                                 "ms_per_step": 1e3 * ref_elapsed / args.steps, "samples_per_sec": ref_samples_all / ref_elapsed,
+                                 "prunes_inside_timed_steps": ref_prunes,
+                                 "note": "multiview_trainer.py:58 default batch (2^18 packed samples per step), same run"},
+            "psnr_db": psnr, "optimisation_steps_before_psnr": trainer.total_iterations,
             "roofline": roofline,
         }
+        if world == 1 and roofline and not args.no_pmc:
+            traffic, note = live_pmc_traffic(args, PMC_KERNELS[roofline["kernel"]])
+            roofline["traffic"] = traffic
+            roofline["traffic_note"] = note
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cells, args.hidden, args.num_steps)
+            out["cpu_baseline"] = cpu_baseline(true_cells, args.hidden, args.num_steps)
         print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()

@@ -81,3 +81,100 @@ def test_ray_sharded_gradient_allreduce_gloo_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+# ---- the REAL MultiviewTrainStep.step() under world_size 2 -------------------------------------------------------------
+class _StubTracer:
+    def __init__(self):
+        self.prev_num_samples = 64
+
+    def get_prev_num_samples(self):
+        return self.prev_num_samples
+
+
+class _StubBuffer:
+    def __init__(self, rgb):
+        self.rgb = rgb
+
+
+class _StubPipeline(torch.nn.Module):
+    """Pipeline(nef, tracer) whose per-ray work is TinyField (independent rays, shared parameters) - the trainer only sees
+    `pipeline(rays=..., channels=['rgb']).rgb`, `pipeline.nef`, `pipeline.tracer`."""
+
+    def __init__(self):
+        super().__init__()
+        self.nef = TinyField()
+        self.nef.prune_density_decay, self.nef.prune_min_density = 0.95, 1.0
+        self.nef.grid.dense_points = torch.zeros(16, 3)
+        self.nef.prune_log = []
+        self.nef.prune = lambda unit_samples=None, view_dirs=None: self.nef.prune_log.append(
+            (unit_samples.clone(), view_dirs.clone()))
+        self.tracer = _StubTracer()
+
+    def forward(self, rays=None, lod_idx=None, channels=None):
+        return _StubBuffer(self.nef(rays.origins, rays.dirs))
+
+
+def _torch_adamw_groups(param, grad, exp_avg, exp_avg_sq, groups, beta1, beta2, eps, step, grad_scale=1.0, zero_grad=False):
+    """CPU stand-in for the HIP optimizer launch (test infrastructure): the arithmetic of csrc/misc.hip adamw_groups_kernel."""
+    bc1, bc2 = 1 - beta1 ** step, (1 - beta2 ** step) ** 0.5
+    for a, n, lr, wd, _shadow in groups:
+        p, g, m, v = param[a:a + n], grad[a:a + n] * grad_scale, exp_avg[a:a + n], exp_avg_sq[a:a + n]
+        p.mul_(1 - lr * wd)
+        m.mul_(beta1).add_(g, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        p.sub_((lr / bc1) * m / (v.sqrt() / bc2 + eps))
+    if zero_grad:
+        grad.zero_()
+
+
+def _step_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import wisp._C as C
+    from wisp.core import Rays
+    from wisp.trainers import MultiviewTrainStep, shard_rays
+    C.adamw_step_groups = _torch_adamw_groups
+    g = torch.Generator().manual_seed(3)
+    O, D, T = torch.rand(96, 3, generator=g) * 2 - 1, torch.randn(96, 3, generator=g), torch.rand(96, 3, generator=g)
+
+    def run(world_here, lo, hi, steps):
+        pipe = _StubPipeline()
+        tr = MultiviewTrainStep(pipe, lr=1e-2, grid_lr_weight=10.0, prune_every=2, seed=5)
+        tr.world = world_here                        # the single-process reference run uses the same trainer, world = 1
+        assert tr._direct is None                    # stub pipeline -> modular path: pipeline() + autograd + reduce_and_update()
+        for _ in range(steps):
+            loss, ns = tr.step(Rays(O[lo:hi], D[lo:hi]), T[lo:hi])
+        return pipe, tr
+
+    lo, hi = shard_rays(96, rank, world)
+    pipe, tr = run(world, lo, hi, 5)                 # prune_every=2: prunes fire before steps 3 and 5 (total_iterations 2, 4)
+    gathered = [torch.zeros_like(tr.flat.data) for _ in range(world)]
+    dist.all_gather(gathered, tr.flat.data)
+    identical = all(torch.equal(gathered[0], t) for t in gathered)             # replicas stay BIT-identical
+    draws = [torch.zeros(2, 16, 3) for _ in range(world)]
+    dist.all_gather(draws, torch.stack(pipe.nef.prune_log[-1]))
+    same_draws = len(pipe.nef.prune_log) == 2 and all(torch.equal(draws[0], t) for t in draws)
+    # against ONE process that sees all 96 rays: equal shards -> mean of shard means == global mean
+    dist.destroy_process_group()
+    C.adamw_step_groups = _torch_adamw_groups
+    ref_pipe, ref_tr = run(1, 0, 96, 5)
+    close = torch.allclose(tr.flat.data, ref_tr.flat.data, atol=2e-6)
+    moved = not torch.allclose(tr.flat.data, _StubPipeline_flat_init(), atol=1e-4)
+    out[rank] = bool(identical and same_draws and close and moved and tr.num_rays is not None)
+
+
+def _StubPipeline_flat_init():
+    from wisp.trainers import FlatParams
+    return FlatParams(_StubPipeline().nef).data
+
+
+def test_real_trainer_step_world2_gloo_replicas_identical_after_prune():
+    """MultiviewTrainStep.step() itself (pre_step/prune, pipeline forward, loss, backward, all-reduce of
+    the flat gradient, fused-optimizer arithmetic with 1/world folded in, adaptive ray count) under world_size 2."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_step_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}

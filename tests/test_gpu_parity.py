@@ -1259,3 +1259,90 @@ def test_triplanar_grid_matches_grid_sample(mtype):
     o, d = make_rays(16, 9)
     rm = grid.raymarch(Rays(cuda(o), cuda(d), 0.5, 6.0), 'voxel', 8)
     assert rm.samples.shape[1] == 3 and rm.samples.shape[0] % 8 == 0
+
+
+# ------------------------------------------------------------------------------------------------ flagship shape (nerf_hash.yaml)
+def test_flagship_shape_parity_nerf_hash_yaml():
+    """parity AT the bench shape, not at toy sizes - app/nerf/configs/nerf_hash.yaml: SynLego level-7
+    occupancy, HashGrid L=16 F=2 T=2^19 res 16..512 'cat', hidden-64 decoders, 'ray' march with 2048 candidates per ray,
+    near/far 1/5, 16 384 rays (33.5 M candidates) with injected jitter.
+      * raymarch: ridx / boundary / S / positions / depths / deltas BIT-EXACT against the oracle for every ray;
+      * fp32 tracer: rgb <= 1e-4, alpha <= 1e-4 against the oracle on a 2 048-ray subsample (north-star tolerance);
+      * bf16 step (compact 2-dword gradient records, bf16 shadow table): hash-grid gradient of the real bf16 upstream
+        gradient at ~0.68 M packed samples against the float64 oracle backward of the same upstream gradient."""
+    import synlego
+    from wisp.accelstructs import OctreeAS
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.models.grids import HashGrid
+    from wisp.models.nefs import NeuralRadianceField
+    from wisp.tracers import PackedRFTracer
+    level, N, R, sub = 7, 2048, 16384, 2048
+    cells = synlego.occupied_cells(level, device='cpu')
+    torch.manual_seed(0)
+    blas = OctreeAS.from_quantized_points(cells.to(DEV), level)
+    grid = HashGrid.from_geometric(blas, feature_dim=2, num_lods=16, multiscale_type='cat', feature_std=0.1,
+                                   codebook_bitwidth=19, min_grid_res=16, max_grid_res=512)
+    assert [int(r) for r in grid.resolutions] == NGP_RES and grid.codebook.feats.shape == (5217937, 2)
+    nef = NeuralRadianceField(grid, view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1, bias=True).to(DEV)
+    oc = ospc.points_to_octree(cells.numpy(), level)
+    pts, pyr, ex = ospc.octree_to_spc(oc)
+    assert np.array_equal(blas.octree.cpu().numpy(), oc)
+    o, d, _ = synlego.ray_bank(R, seed=21, device='cpu', with_gt=False)
+    o, d = o.numpy(), d.numpy()
+    jit = np.random.default_rng(22).uniform(size=(R, N)).astype(np.float32)
+    rays = Rays(cuda(o), cuda(d), dist_min=synlego.NEAR, dist_max=synlego.FAR)
+    rm = blas.raymarch(rays, 'ray', N, jitter=cuda(jit))
+    # ---- raymarch, every ray, in chunks of 2048 rays on the CPU side
+    got = {k: getattr(rm, k).cpu().numpy() for k in ("ridx", "samples", "depth_samples", "deltas", "boundary")}
+    pos = 0
+    for s in range(0, R, 2048):
+        want = omarch.raymarch_ray(oc, ex, o[s:s + 2048], d[s:s + 2048], synlego.NEAR, synlego.FAR, N, level, jit[s:s + 2048])
+        n = want["ridx"].shape[0]
+        assert np.array_equal(got["ridx"][pos:pos + n], want["ridx"] + s), f"ridx differs in rays {s}.."
+        for k in ("samples", "depth_samples", "deltas", "boundary"):
+            assert np.array_equal(got[k][pos:pos + n].reshape(want[k].shape), want[k]), (k, s)
+        pos += n
+    S = got["ridx"].shape[0]
+    assert pos == S and S > 500000, S
+    # ---- fp32 tracer against the oracle on a subsample of the rays
+    onef = onerf.OracleNeRF(grid.resolutions, 2, 19, 'cat', 0.1, 64, 1, True, 4)
+    onef.load_state_dict({k: v.detach().cpu() for k, v in nef.state_dict().items() if k in onef.state_dict()}, strict=False)
+    oblas = onerf.OracleBLAS(oc)
+    pipe = Pipeline(nef, PackedRFTracer(raymarch_type='ray', num_steps=N, bg_color=(0.0, 0.0, 0.0)))
+    pick = np.sort(np.random.default_rng(23).choice(R, sub, replace=False))
+    with torch.no_grad():
+        rb = pipe(rays=Rays(cuda(o[pick]), cuda(d[pick]), dist_min=synlego.NEAR, dist_max=synlego.FAR), channels=["rgb", "alpha"],
+                  jitter=cuda(jit[pick]))
+        want = onerf.trace(onef, oblas, torch.from_numpy(o[pick]), torch.from_numpy(d[pick]), synlego.NEAR, synlego.FAR, N,
+                           jit[pick], (0.0, 0.0, 0.0), 'ray', with_depth=False)
+    assert pipe.tracer.get_prev_num_samples() == want["raymarch"]["ridx"].shape[0]
+    e_rgb = float((rb.rgb.cpu() - want["rgb"]).abs().max())
+    e_a = float((rb.alpha.cpu().reshape(-1) - want["alpha"].reshape(-1)).abs().max())
+    assert e_rgb <= 1e-4 and e_a <= 1e-4, (e_rgb, e_a)
+    # ---- the bf16 training path at full batch: gradient records in their compact form, run merge over real ray order
+    from wisp.ops.nerf_mlp import fused_nerf_decoder
+    table16 = grid.codebook.feats.detach().to(torch.bfloat16)
+    zero_from = 15 * 2                                            # 'cat' at lod_idx 15 zeroes the finest level's columns
+    feats = _C().hashgrid_interpolate(rm.samples, table16, grid.codebook.begin_idxes, NGP_RES, 19, zero_from)
+    want_f = ohash.hashgrid_forward(torch.from_numpy(got["samples"][:200000]), table16.cpu(), grid.codebook.begin_idxes.cpu(), NGP_RES, 19)
+    want_f[:, zero_from:] = 0
+    assert float((feats[:200000].float().cpu() - want_f.float()).abs().max()) <= 1.5e-3       # one bf16 ulp of a 0.3-sized value
+    dirs = rays.dirs.index_select(0, rm.ridx)
+    f_in = feats.clone().requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        rgb, den = fused_nerf_decoder(nef, f_in, dirs)
+    w = torch.randn(S, 3, device=DEV)
+    ((rgb.float() * w).sum() + den.float().sum()).backward()
+    g16 = f_in.grad
+    assert g16.dtype == torch.bfloat16 and g16.shape == (S, 32)
+    shape = tuple(grid.codebook.feats.shape)
+    gt_hip = _C().hashgrid_interpolate_backward(rm.samples, g16, shape, grid.codebook.begin_idxes, NGP_RES, 19, zero_from)
+    gt_ref = ohash.hashgrid_backward(torch.from_numpy(got["samples"]), g16.float().cpu()[:, :zero_from].contiguous(), shape,
+                                     grid.codebook.begin_idxes.cpu(), NGP_RES[:15], 19, torch.float64)
+    scale = float(gt_ref.abs().max())
+    err = float((gt_hip.double().cpu() - gt_ref).abs().max())
+    rel = float((gt_hip.double().cpu() - gt_ref).norm() / gt_ref.norm())
+    # records carry 17 significant bits (2^-17 relative per contribution), sums of up to thousands of them per entry
+    assert err <= 1e-4 * scale and rel <= 2e-5, (err, scale, rel)
+    assert float(gt_hip[int(grid.codebook.begin_idxes[15]):].abs().max()) == 0.0
