@@ -40,9 +40,19 @@ class OctreeAS(BaseAS):
     @classmethod
     def from_mesh(cls, mesh_path: str, level: int, sample_tex: bool = False,
                   num_samples_on_mesh: int = 100000000) -> OctreeAS:
-        """Mesh ingestion (OBJ load + surface sampling) is dataset preparation, outside the hot path."""
-        raise NotImplementedError("OctreeAS.from_mesh: mesh ingestion is out of scope of this backend; "
-                                  "sample the surface offline and use OctreeAS.from_pointcloud.")
+        """Occupancy from samples over the faces of an OBJ mesh (octree_as.py:65-106): load, sphere-normalise, sample
+        `num_samples_on_mesh` surface points (+ a half-cell jittered copy), quantise to `level`.  Sampling-based, hence not
+        deterministic and not guaranteed hole-free - exactly the reference's caveat.  `sample_tex` (texture / material
+        loading, documented as unused) is not provided."""
+        from wisp.ops import mesh as mesh_ops
+        if sample_tex:
+            raise NotImplementedError("OctreeAS.from_mesh(sample_tex=True): textures / materials are not read by this backend")
+        vertices, faces = mesh_ops.load_obj(mesh_path)
+        vertices, faces = mesh_ops.normalize(vertices, faces, 'sphere')
+        accel_struct = cls(wisp_spc_ops.mesh_to_octree(vertices, faces, level, num_samples_on_mesh))
+        accel_struct.extent['vertices'] = vertices
+        accel_struct.extent['faces'] = faces
+        return accel_struct
 
     @classmethod
     def from_pointcloud(cls, pointcloud: torch.FloatTensor, level: int) -> OctreeAS:

@@ -360,3 +360,43 @@ def test_reference_ops_grid_module_binds_to_this_C_unchanged():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_octree_from_mesh_covers_the_surface(tmp_path):
+    """OctreeAS.from_mesh (octree_as.py:65-106) on a quad-faced cube OBJ: after sphere normalisation the cube has half-side
+    1/sqrt(3); every occupied level-4 cell must touch its surface, and every cell the six faces pass through must be occupied
+    (5e5 samples on 6 faces leave no holes at 16^3)."""
+    from wisp.accelstructs import OctreeAS
+    from wisp.ops import mesh as mesh_ops
+    obj = tmp_path / "cube.obj"
+    v = [(x, y, z) for x in (0, 2) for y in (0, 2) for z in (0, 2)]
+    quads = [(1, 2, 4, 3), (5, 7, 8, 6), (1, 5, 6, 2), (3, 4, 8, 7), (1, 3, 7, 5), (2, 6, 8, 4)]
+    obj.write_text("# cube\n" + "".join(f"v {a} {b} {c}\n" for a, b, c in v) + "".join("f " + " ".join(f"{i}/{i}" for i in q) + "\n" for q in quads))
+    V, F = mesh_ops.load_obj(str(obj))
+    assert V.shape == (8, 3) and F.shape == (12, 3)
+    Vn, _ = mesh_ops.normalize(V, F, 'sphere')
+    assert abs(float(Vn.norm(dim=1).max()) - 1.0) < 1e-6
+    pts, nrm = mesh_ops.sample_surface(Vn, F, 2000)
+    h = 1.0 / 3 ** 0.5
+    assert float((pts.abs().max(dim=1)[0] - h).abs().max()) < 1e-5 and nrm.shape == (2000, 3)
+    torch.manual_seed(0)
+    blas = OctreeAS.from_mesh(str(obj), level=4, num_samples_on_mesh=500000)
+    cells = blas.points[int(blas.pyramid[1, 4]):].float()                 # level-4 cell coordinates
+    lo, hi = cells / 16 * 2 - 1, (cells + 1) / 16 * 2 - 1
+    half = 1.0 / 32                                                      # jitter reach of the augmented samples
+    # distance of a cell (box) to the cube surface: the box must straddle |x|_inf = h within the jitter reach
+    far = torch.maximum(lo.abs(), hi.abs()).max(dim=1)[0]
+    near = torch.where((lo <= 0) & (hi >= 0), torch.zeros_like(lo), torch.minimum(lo.abs(), hi.abs())).max(dim=1)[0]
+    assert bool(((near <= h + half) & (far >= h - half)).all())
+    occ = torch.zeros(16, 16, 16, dtype=torch.bool)
+    occ[cells[:, 0].long(), cells[:, 1].long(), cells[:, 2].long()] = True
+    g = torch.linspace(-h, h, 97)
+    a, b = torch.meshgrid(g, g, indexing='ij')
+    for axis in range(3):
+        for s in (-h, h):
+            p = torch.stack([torch.full_like(a, s) if k == axis else (a if k == (axis + 1) % 3 else b) for k in range(3)], -1).reshape(-1, 3)
+            q = torch.clamp(torch.floor(16 * (0.5 * p + 0.5)), 0, 15).long()
+            assert bool(occ[q[:, 0], q[:, 1], q[:, 2]].all())
+    assert blas.extent['vertices'].shape == (8, 3) and blas.max_level == 4
+    with pytest.raises(NotImplementedError):
+        OctreeAS.from_mesh(str(obj), level=3, sample_tex=True)
