@@ -91,6 +91,17 @@ int wisp_spc_query(const uint8_t* octree, const int32_t* exsum, const float* coo
 int wisp_spc_build_bitfield(const int16_t* level_points, int64_t n_points, int level, uint32_t* bits,
                             wisp_stream_t stream);
 
+/* SPC build on the device (replaces Kaolin-Core unbatched_points_to_octree + scan_octrees + generate_points as called by
+ * wisp/ops/spc/conversions.py:29-40,72-88 and, once per prune, wisp/models/nefs/nerf.py:205-206).  The finest level is a
+ * dense mask in Morton order (code bit 3i = z, 3i+1 = y, 3i+2 = x); `dense` is u8 [(8^(level+1)-1)/7] = the levels
+ * 0..level concatenated.  mask_from_points marks cells (points i16 [n,3]; out-of-range points are ignored) in a zeroed
+ * leaf mask; dense_bytes fills the node bytes of levels level-1..0 in front of the leaf mask the caller put in the last
+ * 8^level entries; the non-zero entries of `dense`, in order, are the point hierarchy (compact them with
+ * wisp_boundary_tile_counts / wisp_boundary_pack_starts); points_from_index decodes those positions to coordinates. */
+int wisp_spc_mask_from_points(const int16_t* points, int64_t n, int level, uint8_t* leaf_mask, wisp_stream_t stream);
+int wisp_spc_dense_bytes(uint8_t* dense, int level, wisp_stream_t stream);
+int wisp_spc_points_from_index(const int64_t* index, int64_t n, int level, int16_t* points, wisp_stream_t stream);
+
 /* Two-phase ray / octree intersection.  count: nuggets per ray; emit: writes them at offsets[r]
  * (exclusive scan of counts), ordered by ray then front-to-back.  depth is [M,1] or [M,2]. */
 int wisp_spc_raytrace_count(const uint8_t* octree, const int16_t* points, const int32_t* exsum,

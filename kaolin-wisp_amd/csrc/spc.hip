@@ -483,3 +483,102 @@ extern "C" int wisp_boundary_pack_starts(const uint8_t* boundary, int64_t n, con
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- SPC build on the device
+// Replaces the Kaolin-Core build the reference runs at construction and inside every prune
+// (unbatched_points_to_octree + scan_octrees + generate_points: wisp/ops/spc/conversions.py:29-40,72-88,
+// wisp/models/nefs/nerf.py:205-206): sort + unique + level-by-level compaction there.  Here the cells of the finest level
+// are a DENSE mask in Morton order (1 byte per cell: 2 MiB at level 7, 16 MiB at level 8 - nothing on this GPU) and the
+// hierarchy falls out of it without any sort:
+//   * the byte of a level-l node IS eight consecutive entries of the level-(l+1) occupancy (child c = x<<2 | y<<1 | z are
+//     the low three Morton bits), so every level's node bytes come from the level below with one 8-byte load per node;
+//   * the concatenation [dense node bytes of levels 0..L-1 | leaf mask] in that order is the point hierarchy in BFS /
+//     Morton order with holes; ONE stream compaction of its non-zero entries (the boundary -> pack-starts kernels above)
+//     yields every point of every level in its final position;
+//   * a point's coordinates are the Morton decode of its dense index.
+static __device__ __forceinline__ uint32_t morton_spread3(uint32_t v) {       // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+static __device__ __forceinline__ uint32_t morton_compact3(uint32_t v) {      // inverse of morton_spread3
+    v &= 0x09249249u;
+    v = (v | (v >> 2)) & 0x030C30C3u;
+    v = (v | (v >> 4)) & 0x0300F00Fu;
+    v = (v | (v >> 8)) & 0x030000FFu;
+    v = (v | (v >> 16)) & 0x000003FFu;
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+spc_mask_from_points_kernel(const int16_t* __restrict__ points, int64_t n, int level, uint8_t* __restrict__ leaf_mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t res = 1u << level;
+    const uint32_t x = (uint32_t)points[i * 3], y = (uint32_t)points[i * 3 + 1], z = (uint32_t)points[i * 3 + 2];
+    if (x >= res || y >= res || z >= res) return;                              // also drops negative coordinates
+    leaf_mask[(morton_spread3(x) << 2) | (morton_spread3(y) << 1) | morton_spread3(z)] = 1;   // duplicates write the same value
+}
+
+// out[i] = sum_c (in[8 i + c] != 0) << c  : node bytes of one level from the occupancy (or node bytes) of the level below
+__global__ void __launch_bounds__(256)
+spc_parent_bytes_kernel(const uint8_t* __restrict__ in, int64_t n_parents, uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parents) return;
+    const uint64_t w = *reinterpret_cast<const uint64_t*>(in + i * 8);
+    uint32_t b = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) b |= (((w >> (8 * c)) & 0xffull) != 0 ? 1u : 0u) << c;
+    out[i] = (uint8_t)b;
+}
+
+__global__ void __launch_bounds__(256)
+spc_points_from_index_kernel(const int64_t* __restrict__ index, int64_t n, int level, int16_t* __restrict__ points) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t d = index[i];                                    // position in [level 0 | level 1 | ... | level L]
+    int l = 0;
+    while (l < level && d >= ((int64_t)1 << (3 * l))) { d -= (int64_t)1 << (3 * l); ++l; }
+    const uint32_t m = (uint32_t)d;                          // Morton code inside level l
+    points[i * 3 + 0] = (int16_t)morton_compact3(m >> 2);
+    points[i * 3 + 1] = (int16_t)morton_compact3(m >> 1);
+    points[i * 3 + 2] = (int16_t)morton_compact3(m);
+}
+
+extern "C" int wisp_spc_mask_from_points(const int16_t* points, int64_t n, int level, uint8_t* leaf_mask, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0 && level >= 1 && level <= 10, "bad sizes (level 1..10)");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(points && leaf_mask, "null pointer");
+    hipLaunchKernelGGL(spc_mask_from_points_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       points, n, level, leaf_mask);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_spc_dense_bytes(uint8_t* dense, int level, wisp_stream_t stream) {
+    // dense: u8 [(8^(level+1) - 1) / 7]: levels 0..level concatenated; the caller filled the last 8^level entries (leaf
+    // mask, Morton order); the node bytes of levels level-1 .. 0 are written in front of it.
+    WISP_REQUIRE(dense && level >= 1 && level <= 10, "bad arguments (level 1..10)");
+    int64_t off[12];
+    off[0] = 0;
+    for (int l = 0; l <= level; ++l) off[l + 1] = off[l] + ((int64_t)1 << (3 * l));
+    for (int l = level - 1; l >= 0; --l) {
+        const int64_t n = (int64_t)1 << (3 * l);
+        hipLaunchKernelGGL(spc_parent_bytes_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                           dense + off[l + 1], n, dense + off[l]);
+    }
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_spc_points_from_index(const int64_t* index, int64_t n, int level, int16_t* points, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0 && level >= 0 && level <= 10, "bad sizes");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(index && points, "null pointer");
+    hipLaunchKernelGGL(spc_points_from_index_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       index, n, level, points);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

@@ -58,6 +58,9 @@ SIGNATURES = {
     "wisp_raymarch_ray_emit": [c_vp, c_vp, c_i64, c_f32, c_f32, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_voxel_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_uniform_count": [c_vp, c_i64, c_f32, c_vp, c_vp],
+    "wisp_spc_mask_from_points": [c_vp, c_i64, c_i32, c_vp, c_vp],
+    "wisp_spc_dense_bytes": [c_vp, c_i32, c_vp],
+    "wisp_spc_points_from_index": [c_vp, c_i64, c_i32, c_vp, c_vp],
     "wisp_uniform_sample": [c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_uniform_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_packed_sum_reduce": [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
@@ -316,6 +319,61 @@ def spc_bitfield(level_points, level):
     _check(lib.wisp_spc_build_bitfield(_p(level_points), level_points.shape[0], level, _p(bits), _stream()),
            "spc_build_bitfield")
     return bits
+
+
+SPC_DEVICE_BUILD_MAX_LEVEL = 9          # leaf mask = 8^level bytes (128 MiB at level 9)
+
+
+def spc_build(level, points=None, leaf_mask=None):
+    """Point hierarchy of a level-`level` octree from quantised cells (i16 [n,3], any order, duplicates allowed) or from a
+    dense Morton-order occupancy of the finest level (u8 / bool [8^level]) -> (octree u8, points i16 [P,3], pyramid i32
+    [2, level+2] on the host, exsum i32 [len(octree)+1]) - what unbatched_points_to_octree + octree_to_spc return, built
+    without a sort (csrc/spc.hip: 'SPC build on the device').  Returns None when no cell is occupied."""
+    assert 1 <= level <= SPC_DEVICE_BUILD_MAX_LEVEL
+    n_leaf = 8 ** level
+    n_dense = (8 ** (level + 1) - 1) // 7
+    if leaf_mask is not None:
+        leaf_mask = _need(leaf_mask, None, "leaf_mask")
+        assert leaf_mask.numel() == n_leaf and leaf_mask.dtype in (torch.uint8, torch.bool)
+        dev = leaf_mask.device
+        dense = torch.empty(n_dense, dtype=torch.uint8, device=dev)
+        dense[n_dense - n_leaf:].copy_(leaf_mask.reshape(-1).view(torch.uint8))
+    else:
+        points = _need(points, torch.int16, "points")
+        dev = points.device
+        dense = torch.zeros(n_dense, dtype=torch.uint8, device=dev)
+        _check(lib.wisp_spc_mask_from_points(_p(points), points.shape[0], level, c_vp(dense.data_ptr() + n_dense - n_leaf),
+                                             _stream()), "spc_mask_from_points")
+    _check(lib.wisp_spc_dense_bytes(_p(dense), level, _stream()), "spc_dense_bytes")
+    starts = pack_starts(dense.view(torch.bool))         # dense position of every point, hierarchy order (one read-back)
+    P = starts.shape[0]
+    if P == 0:
+        return None
+    bounds = torch.tensor([(8 ** l - 1) // 7 for l in range(level + 2)], dtype=torch.int64, device=dev)
+    first = torch.searchsorted(starts, bounds).cpu()     # first point of every level (second read-back: the pyramid is host data)
+    pyramid = torch.zeros(2, level + 2, dtype=torch.int32)
+    pyramid[1, :level + 1] = first[:level + 1].int()
+    pyramid[1, level + 1] = P
+    pyramid[0, :level + 1] = (first[1:] - first[:-1]).int()
+    if int(pyramid[0, level]) == 0:
+        return None
+    num_nodes = int(first[level])
+    octree = dense[starts[:num_nodes]]
+    pts = torch.empty(P, 3, dtype=torch.int16, device=dev)
+    _check(lib.wisp_spc_points_from_index(_p(starts), P, level, _p(pts), _stream()), "spc_points_from_index")
+    exsum = torch.zeros(num_nodes + 1, dtype=torch.int32, device=dev)
+    exsum[1:] = torch.cumsum(_popc_table(dev)[octree.long()], 0)
+    return octree, pts, pyramid, exsum
+
+
+_POPC = {}
+
+
+def _popc_table(dev):
+    t = _POPC.get(dev)
+    if t is None:
+        t = _POPC[dev] = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int32, device=dev)
+    return t
 
 
 def spc_raytrace(octree, points, exsum, origins, dirs, level, with_exit=False):

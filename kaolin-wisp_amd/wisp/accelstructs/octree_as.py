@@ -31,7 +31,12 @@ class OctreeAS(BaseAS):
         """octree (torch.ByteTensor): one occupancy byte per non-leaf node, breadth first, Morton order."""
         super().__init__()
         self.octree = octree
-        self.points, self.pyramid, self.prefix = wisp_spc_ops.octree_to_spc(octree)
+        parts = getattr(octree, '_wisp_spc_parts', None)     # set by the device build: hierarchy already derived
+        if parts is not None:
+            del octree._wisp_spc_parts
+            self.points, self.pyramid, self.prefix = parts
+        else:
+            self.points, self.pyramid, self.prefix = wisp_spc_ops.octree_to_spc(octree)
         self.max_level = self.pyramid.shape[-1] - 2
         self.extent = dict()
         self._occ_bits = {}          # level -> occupancy bitfield (device tensor), built lazily
@@ -62,7 +67,23 @@ class OctreeAS(BaseAS):
     @classmethod
     def from_quantized_points(cls, quantized_points: torch.LongTensor, level: int) -> OctreeAS:
         """quantized_points: integer cell coordinates [N,3] in [0, 2**level)."""
+        built = wisp_spc_ops.build_spc(level, points=quantized_points)
+        if built is not None:
+            return cls._from_spc(*built)
         return cls(wisp_spc_ops.unbatched_points_to_octree(quantized_points, level, sorted=False))
+
+    @classmethod
+    def from_leaf_mask(cls, leaf_mask: torch.Tensor, level: int) -> OctreeAS:
+        """Octree whose level-`level` cells are the non-zero entries of `leaf_mask` (u8 / bool [8^level], MORTON order:
+        the order of the finest level of any point hierarchy).  The prune path: an occupancy test over the dense cells
+        turns into the new structure without a sort or a gather.  Returns None when the mask is empty."""
+        built = wisp_spc_ops.build_spc(level, leaf_mask=leaf_mask)
+        return None if built is None else cls._from_spc(*built)
+
+    @classmethod
+    def _from_spc(cls, octree, points, pyramid, prefix) -> OctreeAS:
+        octree._wisp_spc_parts = (points, pyramid, prefix)
+        return cls(octree)
 
     @classmethod
     def make_dense(cls, level: int) -> OctreeAS:

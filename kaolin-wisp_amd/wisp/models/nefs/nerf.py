@@ -107,7 +107,9 @@ class NeuralRadianceField(BaseNeuralField):
             raise NotImplementedError(f'Pruning not implemented for grid type {self.grid.__class__.__name__}')
         device = self.device
         self.grid.occupancy = self.grid.occupancy.to(device) * self.prune_density_decay
-        points = self.grid.dense_points.to(device)
+        if self.grid.dense_points.device != device:
+            self.grid.dense_points = self.grid.dense_points.to(device)       # once: 12 MB at level 7, not per prune
+        points = self.grid.dense_points
         res = 2.0 ** self.grid.blas.max_level
         if unit_samples is None:
             unit_samples = torch.rand(points.shape[0], 3, device=device)
@@ -116,15 +118,24 @@ class NeuralRadianceField(BaseNeuralField):
             view_dirs = torch.FloatTensor(sample_unif_sphere(samples.shape[0]))
         with torch.no_grad():
             density = self.forward(coords=samples, ray_d=view_dirs.to(device), channels="density")
-        self.grid.occupancy = torch.stack([density[:, 0].float(), self.grid.occupancy], -1).max(dim=-1)[0]
-        kept = points[self.grid.occupancy > self.prune_min_density]
-        if kept.shape[0] == 0:
-            return
+        self.grid.occupancy = torch.maximum(density[:, 0].float(), self.grid.occupancy)
+        keep = self.grid.occupancy > self.prune_min_density
         blas_cls = self.grid.blas.__class__
         if not hasattr(blas_cls, "from_quantized_points"):
             raise Exception(f"The BLAS {blas_cls.__name__} does not support initialization "
                             "from_quantized_points, which is required for pruning.")
-        self.grid.blas = blas_cls.from_quantized_points(kept, self.grid.blas.max_level)
+        level = self.grid.blas.max_level
+        if (hasattr(blas_cls, "from_leaf_mask") and keep.is_cuda and points.shape[0] == 8 ** level and level <= 9):
+            # dense_points are ALL cells of the level in hierarchy (= Morton) order, so `keep` already is the leaf mask of
+            # the new octree: no boolean gather, no sort, no size read-back before the build
+            new_blas = blas_cls.from_leaf_mask(keep, level)
+            if new_blas is not None:
+                self.grid.blas = new_blas
+            return
+        kept = points[keep]
+        if kept.shape[0] == 0:
+            return
+        self.grid.blas = blas_cls.from_quantized_points(kept, level)
 
     # ------------------------------------------------------------------ forward
     def register_forward_functions(self):

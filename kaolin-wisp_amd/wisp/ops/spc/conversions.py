@@ -49,6 +49,11 @@ def quantize_points(x, level):
 
 def unbatched_points_to_octree(points, level, sorted=False):
     """Quantised points [N,3] -> occupancy bytes of every non-leaf node, BFS / morton order."""
+    built = build_spc(level, points=points) if points.shape[0] else None
+    if built is not None:
+        octree = built[0]
+        octree._wisp_spc_parts = built[1:]          # OctreeAS(octree) picks the finished hierarchy up
+        return octree
     m = points_to_morton(points)
     m = torch.unique(m)                     # sorted + deduplicated
     per_level = []
@@ -62,6 +67,20 @@ def unbatched_points_to_octree(points, level, sorted=False):
     if not per_level:
         return torch.zeros(0, dtype=torch.uint8, device=points.device)
     return torch.cat(per_level[::-1])
+
+
+def build_spc(level, points=None, leaf_mask=None):
+    """(octree, points, pyramid, exsum) in one go on the GPU (csrc/spc.hip, no sort), or None when the inputs are not on a
+    GPU / the level is beyond the dense-mask build / nothing is occupied - callers then use the generic path below."""
+    src = points if points is not None else leaf_mask
+    if not (torch.is_tensor(src) and src.is_cuda):
+        return None
+    import wisp._C as _C
+    if level < 1 or level > _C.SPC_DEVICE_BUILD_MAX_LEVEL:
+        return None
+    if points is not None and points.dtype != torch.int16:
+        points = points.to(torch.int16)
+    return _C.spc_build(level, points=points, leaf_mask=leaf_mask)
 
 
 def scan_octrees(octree):

@@ -200,7 +200,7 @@ class MultiviewTrainStep:
     def __init__(self, pipeline, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, betas=(0.9, 0.999),
                  rgb_loss_type='huber', prune_every=100, target_sample_size=2 ** 18, max_rays=2 ** 18,
                  enable_amp=False, scheduler_milestones=None, scheduler_gamma=0.333, process_group=None, seed=0,
-                 optimizer='adamw', alpha=0.99, momentum=0.0):
+                 optimizer='adamw', alpha=0.99, momentum=0.0, prune_rng_device=None):
         """optimizer: 'adamw' | 'adam' | 'rmsprop' - the torch.optim classes the reference's configs select
         (wisp/config/presets/torch.py:45-68; nerf_hash.yaml: AdamW, nerf_octree / nerf_codebook.yaml: RMSprop), each
         one fused launch over the flat parameter buffer.  `betas` (Adam family) / `alpha`, `momentum` (RMSprop) as in torch."""
@@ -228,8 +228,12 @@ class MultiviewTrainStep:
         # WISP_FORCE_ALLREDUCE=1 runs the collective even with one rank (exercises the RCCL path on a single-GPU box)
         self.force_allreduce = (os.environ.get("WISP_FORCE_ALLREDUCE", "0") == "1" and dist.is_available()
                                 and dist.is_initialized())
-        # prune draws must be identical on every rank so the replicated octrees stay identical
-        self._prune_gen = torch.Generator().manual_seed(seed)
+        # prune draws must be identical on every rank so the replicated octrees stay identical: every rank seeds the same
+        # generator.  By default it lives on the parameters' device (the 2 x [cells, 3] draws of a level-7 prune take ~60 ms
+        # on the host plus 50 MB of H2D, against microseconds on the GPU); prune_rng_device='cpu' reproduces host draws
+        # (what the CPU oracle can replay: scripts/psnr_parity.py).
+        dev = self.flat.data.device if prune_rng_device is None else torch.device(prune_rng_device)
+        self._prune_gen = torch.Generator(device=dev).manual_seed(seed)
         self._side_stream = None
         self._params_ready = None
         # specialised issue order for the flagship pipeline shape (WISP_DIRECT_STEP=0 keeps the modular path)
@@ -310,8 +314,9 @@ class MultiviewTrainStep:
                 or getattr(nef.grid, 'dense_points', None) is None or not hasattr(nef, 'prune')):
             return
         cells = nef.grid.dense_points.shape[0]
-        unit = torch.rand(cells, 3, generator=self._prune_gen)
-        views = torch.nn.functional.normalize(torch.randn(cells, 3, generator=self._prune_gen), dim=1)
+        dev = self._prune_gen.device
+        unit = torch.rand(cells, 3, generator=self._prune_gen, device=dev)
+        views = torch.nn.functional.normalize(torch.randn(cells, 3, generator=self._prune_gen, device=dev), dim=1)
         nef.prune(unit_samples=unit, view_dirs=views)
 
     def calc_adaptive_rays(self, num_rays_in_batch):

@@ -93,7 +93,7 @@ def main():
         dev = torch.device("cuda", 0)
         nef = nef.to(dev)
         pipe = Pipeline(nef, PackedRFTracer(raymarch_type='ray', num_steps=args.num_steps, bg_color=(0.0, 0.0, 0.0)))
-        tr = MultiviewTrainStep(pipe, prune_every=100, lr=1e-3, grid_lr_weight=100.0, seed=0)
+        tr = MultiviewTrainStep(pipe, prune_every=100, lr=1e-3, grid_lr_weight=100.0, seed=0, prune_rng_device='cpu')
 
         def evaluate():
             with torch.no_grad():

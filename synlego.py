@@ -115,3 +115,93 @@ def occupied_cells(level, device='cpu', probes=3):
                 p = (cells.float() + torch.stack([ox, oy, oz])) / res * 2 - 1
                 occ |= density(p) > 0
     return cells[occ].short()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Stand-ins for the other BASELINE.json configs: none of their datasets exists on disk either.
+@torch.no_grad()
+def first_hit_depth(origins, dirs, steps=1024, chunk=1 << 15):
+    """depth [N] of the first quadrature node inside the SynLego density (inf for rays that miss) - the stand-in for the
+    RTMV depth maps that `OctreeAS.from_pointcloud` is fed from (wisp/datasets/formats/rtmv_dataset.py:517-570)."""
+    out = []
+    for s in range(0, origins.shape[0], chunk):
+        o, d = origins[s:s + chunk], dirs[s:s + chunk]
+        t = torch.linspace(NEAR, FAR, steps, device=o.device)
+        inside = density(o[:, None, :] + d[:, None, :] * t[None, :, None]) > 0
+        first = torch.where(inside.any(1), inside.float().argmax(1), torch.full((o.shape[0],), -1, device=o.device))
+        out.append(torch.where(first >= 0, t[first.clamp(min=0)], torch.full_like(t[first.clamp(min=0)], float('inf'))))
+    return torch.cat(out)
+
+
+def v8_pointcloud(num_rays=1 << 20, num_views=100, res=400, seed=0, device='cpu'):
+    """SynV8: surface point cloud of the scene from `num_views` mip-2-sized (400x400) depth maps -> [M,3] in [-1,1]."""
+    o, d, _ = ray_bank(num_rays, num_views=num_views, res=res, seed=seed, device=device, with_gt=False)
+    t = first_hit_depth(o, d)
+    keep = torch.isfinite(t)
+    return (o[keep] + d[keep] * t[keep, None]).contiguous()
+
+
+def render_gt_white(origins, dirs, steps=768):
+    """SynV8 / VQAD ground truth: the same field composited over a WHITE background (tests/apps/test_nerf.py:74-76)."""
+    out = []
+    for s in range(0, origins.shape[0], 1 << 16):
+        o, d = origins[s:s + (1 << 16)], dirs[s:s + (1 << 16)]
+        t = torch.linspace(NEAR, FAR, steps + 1, device=o.device)
+        tm = 0.5 * (t[1:] + t[:-1])
+        x = o[:, None, :] + d[:, None, :] * tm[None, :, None]
+        tau = density(x) * (t[1] - t[0])
+        T = torch.exp(-(torch.cumsum(tau, 1) - tau))
+        w = T * (1 - torch.exp(-tau))
+        out.append((w[..., None] * colour(x)).sum(1) + (1 - w.sum(1, keepdim=True)))
+    return torch.cat(out, 0)
+
+
+# SynArmadillo: an analytic signed-distance "creature" - smooth union of spheres and capsules inside the unit sphere.
+_SDF_SPHERES = [((0.0, 0.05, 0.0), 0.34), ((0.0, 0.50, 0.04), 0.20), ((0.10, 0.66, 0.10), 0.07), ((-0.10, 0.66, 0.10), 0.07)]
+_SDF_CAPSULES = [((0.22, 0.18, 0.0), (0.55, 0.30, 0.10), 0.08), ((-0.22, 0.18, 0.0), (-0.55, 0.30, 0.10), 0.08),
+                 ((0.14, -0.22, 0.0), (0.22, -0.70, 0.05), 0.10), ((-0.14, -0.22, 0.0), (-0.22, -0.70, 0.05), 0.10),
+                 ((0.0, -0.05, -0.25), (0.0, -0.35, -0.60), 0.06)]
+
+
+def armadillo_sdf(x, k=0.08):
+    """signed distance [..] (negative inside) of the SynArmadillo body; polynomial smooth minimum with radius k."""
+    def smin(a, b):
+        h = torch.clamp(0.5 + 0.5 * (b - a) / k, 0.0, 1.0)
+        return b + (a - b) * h - k * h * (1.0 - h)
+    dist = None
+    for c, r in _SDF_SPHERES:
+        s = (x - torch.tensor(c, device=x.device, dtype=x.dtype)).norm(dim=-1) - r
+        dist = s if dist is None else smin(dist, s)
+    for a, b, r in _SDF_CAPSULES:
+        a_t, b_t = torch.tensor(a, device=x.device, dtype=x.dtype), torch.tensor(b, device=x.device, dtype=x.dtype)
+        pa, ba = x - a_t, b_t - a_t
+        h = torch.clamp((pa * ba).sum(-1) / (ba * ba).sum(), 0.0, 1.0)
+        dist = smin(dist, (pa - ba * h[..., None]).norm(dim=-1) - r)
+    return dist
+
+
+def armadillo_surface_points(num=500000, seed=0, device='cpu', iters=12):
+    """points on the zero level set: uniform draws in the bounding box projected along the SDF gradient (finite
+    differences) - the stand-in for 'sample the mesh surface' (nglod_octree.yaml:54: 500 000 samples per epoch)."""
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(num, 3, generator=g) * 1.8 - 0.9).to(device)
+    eps = 1e-3
+    e = torch.eye(3, device=device) * eps
+    for _ in range(iters):
+        dist = armadillo_sdf(x)
+        grad = torch.stack([armadillo_sdf(x + e[i]) - armadillo_sdf(x - e[i]) for i in range(3)], -1) / (2 * eps)
+        x = x - dist[..., None] * torch.nn.functional.normalize(grad, dim=-1)
+    keep = armadillo_sdf(x).abs() < 2e-3
+    return x[keep].contiguous()
+
+
+def armadillo_training_samples(num, seed=0, device='cpu'):
+    """(coords [num,3], sdf [num,1]) in the mix of SDFDataset's sample modes (surface / near-surface / uniform thirds,
+    wisp/datasets/sdf_dataset.py 'sample_mode')."""
+    g = torch.Generator().manual_seed(seed + 17)
+    third = num // 3
+    surf = armadillo_surface_points(third * 2 + 1024, seed=seed, device=device)[:third * 2]
+    near = surf[third:] + torch.randn(surf[third:].shape, generator=g).to(device) * 0.01
+    uni = (torch.rand(num - 2 * third, 3, generator=g) * 2 - 1).to(device)
+    x = torch.cat([surf[:third], near, uni], 0)
+    return x.contiguous(), armadillo_sdf(x)[..., None].contiguous()

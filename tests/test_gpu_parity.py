@@ -323,6 +323,38 @@ def test_raytrace_bit_exact_sparse_and_dense():
     assert ridx.shape[0] == 0 and depth.shape == (0, 2)
 
 
+@pytest.mark.parametrize("level,n", [(1, 3), (3, 40), (5, 3000), (7, 60000), (8, 200000)])
+def test_device_spc_build_matches_oracle(level, n):
+    """csrc/spc.hip 'SPC build on the device' (dense Morton mask -> node bytes -> one stream compaction) against the oracle's
+    sort-based build: octree bytes, point hierarchy, pyramid and exsum must be identical - from unsorted points with
+    duplicates, from a leaf mask, and through the classes (OctreeAS.from_quantized_points / from_leaf_mask)."""
+    from wisp.accelstructs import OctreeAS
+    rng = np.random.default_rng(100 + level)
+    P = rng.integers(0, 2 ** level, size=(n, 3))
+    P = np.concatenate([P, P[: n // 3]])                           # duplicates, not sorted
+    oc = ospc.points_to_octree(P, level)
+    pts, pyr, ex = ospc.octree_to_spc(oc)
+    octree, points, pyramid, exsum = _C().spc_build(level, points=cuda(P.astype(np.int16)))
+    assert np.array_equal(octree.cpu().numpy(), oc) and np.array_equal(points.cpu().numpy(), pts)
+    assert np.array_equal(pyramid.numpy(), np.asarray(pyr)) and np.array_equal(exsum.cpu().numpy(), np.asarray(ex))
+    blas = OctreeAS.from_quantized_points(cuda(P.astype(np.int16)), level)
+    assert np.array_equal(blas.octree.cpu().numpy(), oc) and np.array_equal(blas.points.cpu().numpy(), pts)
+    assert blas.max_level == level and np.array_equal(blas.prefix.cpu().numpy(), np.asarray(ex))
+    # leaf mask in Morton order = the order of the dense hierarchy's finest level
+    dense = OctreeAS.make_dense(level)
+    leaves = dense.points[int(dense.pyramid[1, level]):].to(DEV)
+    occ = torch.zeros(2 ** level, 2 ** level, 2 ** level, dtype=torch.bool, device=DEV)
+    Pt = cuda(P)
+    occ[Pt[:, 0], Pt[:, 1], Pt[:, 2]] = True
+    mask = occ[leaves[:, 0].long(), leaves[:, 1].long(), leaves[:, 2].long()]
+    b2 = OctreeAS.from_leaf_mask(mask, level)
+    assert np.array_equal(b2.octree.cpu().numpy(), oc) and np.array_equal(b2.points.cpu().numpy(), pts)
+    assert OctreeAS.from_leaf_mask(torch.zeros_like(mask), level) is None
+    # queries against the rebuilt structure behave like the oracle's
+    q = rng.uniform(-1, 1, (2000, 3)).astype(np.float32)
+    assert np.array_equal(b2.query(cuda(q)).pidx.cpu().numpy(), ospc.query(oc, ex, q, level))
+
+
 def test_scans_boundaries_and_pack_starts():
     g = torch.Generator().manual_seed(5)
     for n in (1, 63, 1023, 1024, 1025, 2048, 2049, 49623, 65536, 65537, 300001):   # one-launch scan up to 64 K, tile scan above
