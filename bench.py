@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--eval-rays", type=int, default=2 ** 16)
+    ap.add_argument("--config", choices=["nerf_hash", "v8", "vqad", "nglod"], default="nerf_hash",
+                    help="nerf_hash = BASELINE.json's metric configuration (C2; the driver's line); v8 / vqad / nglod = the other "
+                         "configs on their synthetic stand-ins (bench_configs.py), one GPU, secondary lines")
+    ap.add_argument("--sdf-batch", type=int, default=512, help="nglod: coordinates per step (nglod_octree.yaml:78)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -191,6 +195,10 @@ def main():
     from wisp.core import Rays
     from wisp.trainers import MultiviewTrainStep
 
+    if args.config != "nerf_hash":
+        import bench_configs
+        assert world == 1, "the secondary configs are single-GPU lines"
+        return bench_configs.main(args, dev)
     if args.pmc_child:                                     # profiling child: fixed occupancy, a handful of steps, no extras
         args.occupancy, args.pretrain, args.warmup, args.steps = "analytic", 0, 2, 4
     true_cells = synlego.occupied_cells(7, device=dev)

@@ -1,0 +1,231 @@
+"""bench.py --config {v8, vqad, nglod}: the other BASELINE.json configurations on their synthetic stand-ins.
+
+  v8     C4, one GPU's share: HashGrid NeRF (nerf_hash.yaml model) over `OctreeAS.from_pointcloud(level 7)` of the SynV8 depth
+         point cloud, 'voxel' march with 16 samples per intersected cell, white background, mip-2 (400x400) rays
+         (tests/apps/test_nerf.py:65-87).
+  vqad   C5: CodebookOctreeGrid F=5, 4 LODs on a level-8 octree from the point cloud, 4-bit codebooks, decoders without bias,
+         'voxel' N=16, white background, RMSprop lr 1e-3, grid lr x100, L2 loss (app/nerf/configs/nerf_codebook.yaml).
+  nglod  C3: OctreeGrid F=16, 6 LODs on a level-7 octree from SynArmadillo surface samples, NeuralSDF 19 -> 128 -> 1,
+         Adam, 512 coordinates per step (app/nglod/configs/nglod_octree.yaml) + sphere-traced rendering (32 steps x 0.8).
+
+Each prints ONE JSON line in bench.py's format (value = whole-job throughput with inputs resident in HBM) plus `kernels`:
+every C-ABI launch of the timed steps, HIP-event timed on the launch stream, and a `roofline` object for the dominant one
+when its algorithmic bytes are defined below.  These are secondary lines (profiles/), not the driver's headline."""
+import json
+import math
+import time
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _kernel_table(sink):
+    out = {}
+    for name, evs in sink.items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out[name.replace("wisp_", "")] = dict(launches=len(ms), avg_ms=float(np.mean(ms)), total_ms=float(np.sum(ms)))
+    tot = sum(v["total_ms"] for v in out.values()) or 1.0
+    for v in out.values():
+        v["share"] = v["total_ms"] / tot
+    return dict(sorted(out.items(), key=lambda kv: -kv[1]["total_ms"]))
+
+
+def _roofline(kernels, bytes_per_launch, steps):
+    """dominant C-ABI entry point of the step vs the HBM roofline, when its algorithmic bytes are known."""
+    for name, v in kernels.items():
+        if name in bytes_per_launch:
+            achieved = bytes_per_launch[name] / (v["avg_ms"] * 1e-3) / 1e9
+            return dict(bound="hbm", kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                        traffic=None, avg_launch_ms=v["avg_ms"], algorithmic_bytes_per_launch=bytes_per_launch[name],
+                        share_of_kernel_time=v["share"])
+        if v["share"] > 0.05:
+            return dict(bound=None, kernel=name, note="dominant launch has no algorithmic-byte model here (torch GEMM or host-driven)",
+                        avg_launch_ms=v["avg_ms"], share_of_kernel_time=v["share"])
+    return None
+
+
+def _nerf_run(args, dev, pipe, trainer, bank, steps, warmup, label, metric, bytes_fn):
+    import wisp._C as C
+    from wisp.core import Rays
+    import synlego
+    bank_o, bank_d, bank_rgb = bank
+    gen = torch.Generator(device=dev).manual_seed(1234)
+
+    def batch(n):
+        idx = torch.randint(0, bank_o.shape[0], (n,), device=dev, generator=gen)
+        o, d, rgb = C.gather_rows(idx, [bank_o, bank_d, bank_rgb])
+        return Rays(o, d, dist_min=synlego.NEAR, dist_max=synlego.FAR), rgb
+
+    R = 4096
+    for _ in range(args.pretrain):
+        rays, gts = batch(R)
+        trainer.step(rays, gts)
+        R = max(256, trainer.num_rays)
+    for _ in range(warmup):
+        rays, gts = batch(R)
+        trainer.step(rays, gts)
+    C.TIMING_ALL = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    samples = 0
+    for _ in range(steps):
+        rays, gts = batch(R)
+        _, ns = trainer.step(rays, gts)
+        samples += ns
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sink, C.TIMING_ALL = C.TIMING_ALL, None
+    kernels = _kernel_table(sink)
+    S = samples / steps
+    with torch.no_grad():
+        eo, ed, ergb = bank_o[:16384], bank_d[:16384], bank_rgb[:16384]
+        rb = pipe(rays=Rays(eo, ed, dist_min=synlego.NEAR, dist_max=synlego.FAR), channels=["rgb"])
+        psnr = 10 * math.log10(1.0 / max(float(((rb.rgb.float() - ergb) ** 2).mean()), 1e-12))
+    return {"metric": metric, "value": R * steps / elapsed, "unit": "rays/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if trainer.enable_amp else "f32", "data": "synthetic",
+            "config": {"workload": label, "rays_per_step_per_gpu": R, "samples_per_ray": S / R, "samples_per_step": S,
+                       "pretrain_steps": args.pretrain},
+            "samples_per_sec": samples / elapsed, "psnr_db_train_rays": psnr,
+            "gpu_busy_fraction": sum(v["total_ms"] for v in kernels.values()) * 1e-3 / elapsed,
+            "roofline": _roofline(kernels, bytes_fn(S, R), steps), "kernels": kernels}
+
+
+def run_v8(args, dev):
+    import synlego
+    from wisp.accelstructs import OctreeAS
+    from wisp.models import Pipeline
+    from wisp.models.grids import HashGrid
+    from wisp.models.nefs import NeuralRadianceField
+    from wisp.tracers import PackedRFTracer
+    from wisp.trainers import MultiviewTrainStep
+    import bench
+    torch.manual_seed(0)
+    cloud = synlego.v8_pointcloud(1 << 20, res=400, device=dev)
+    blas = OctreeAS.from_pointcloud(cloud, 7)
+    grid = HashGrid.from_geometric(blas, **bench.NGP)
+    nef = NeuralRadianceField(grid, pos_embedder='none', view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1,
+                              bias=True, prune_density_decay=None, prune_min_density=None).to(dev)
+    pipe = Pipeline(nef, PackedRFTracer(raymarch_type='voxel', num_steps=16, bg_color=(1.0, 1.0, 1.0)))
+    tr = MultiviewTrainStep(pipe, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, rgb_loss_type='huber', prune_every=-1,
+                            target_sample_size=args.target_samples, enable_amp=args.precision == "bf16")
+    o, d, _ = synlego.ray_bank(1 << 20, res=400, seed=1000, device=dev, with_gt=False)
+    bank = (o, d, synlego.render_gt_white(o, d))
+    b = 2 if tr.enable_amp else 4
+    bytes_fn = lambda S, R: {"hashgrid_interpolate_bwd": (12 + 32 * b + 2 * 16 * 8 * 2 * b) * S,
+                             "hashgrid_interpolate_fwd": (12 + 16 * 8 * 2 * b + 32 * b) * S,
+                             "raymarch_voxel_emit": 37 * S, "composite_fwd": 25 * S, "composite_bwd": 41 * S}
+    return _nerf_run(args, dev, pipe, tr, bank, args.steps, args.warmup,
+                     f"C4 (one GPU): nerf_hash model over from_pointcloud(level 7) of SynV8 ({int(blas.pyramid[0, 7])} cells), "
+                     "'voxel' 16 samples per cell, white background, 400x400 rays, AdamW",
+                     "training rays/sec, HashGrid NeRF, synthetic V8 (voxel march)", bytes_fn)
+
+
+def run_vqad(args, dev):
+    import synlego
+    from wisp.accelstructs import OctreeAS
+    from wisp.models import Pipeline
+    from wisp.models.grids import CodebookOctreeGrid
+    from wisp.models.nefs import NeuralRadianceField
+    from wisp.tracers import PackedRFTracer
+    from wisp.trainers import MultiviewTrainStep
+    torch.manual_seed(0)
+    cloud = synlego.v8_pointcloud(1 << 21, res=400, device=dev)
+    blas = OctreeAS.from_pointcloud(cloud, 8)
+    grid = CodebookOctreeGrid(blas, feature_dim=5, num_lods=4, interpolation_type='linear', multiscale_type='sum', feature_std=0.01,
+                              feature_bias=0.0, codebook_bitwidth=4)
+    nef = NeuralRadianceField(grid, pos_embedder='none', view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1,
+                              bias=False, prune_density_decay=None, prune_min_density=None).to(dev)
+    pipe = Pipeline(nef, PackedRFTracer(raymarch_type='voxel', num_steps=16, bg_color=(1.0, 1.0, 1.0)))
+    tr = MultiviewTrainStep(pipe, lr=1e-3, eps=1e-8, weight_decay=0.0, grid_lr_weight=100.0, rgb_loss_type='l2', prune_every=-1,
+                            target_sample_size=args.target_samples, enable_amp=False, optimizer='rmsprop')
+    o, d, _ = synlego.ray_bank(1 << 20, res=400, seed=1000, device=dev, with_gt=False)
+    bank = (o, d, synlego.render_gt_white(o, d))
+    L = 4
+    # per sample and LOD: 8 corner logit rows of 16 fp32 (read; written again as gradients in the backward) + 8 trinket
+    # indices, + coordinates / voxel chain / one 5-wide output row
+    bytes_fn = lambda S, R: {"codebook_trilinear_fwd": (12 + 8 + 8 * 4 + 8 * 16 * 4 + 5 * 4) * S,
+                             "codebook_trilinear_bwd": (12 + 8 + 8 * 4 + 3 * 8 * 16 * 4 + 5 * 4) * S,
+                             "raymarch_voxel_emit": 37 * S, "composite_fwd": 25 * S, "composite_bwd": 41 * S}
+    return _nerf_run(args, dev, pipe, tr, bank, args.steps, args.warmup,
+                     f"C5: VQAD CodebookOctreeGrid F=5, {L} LODs (levels 5-8), 4-bit codebooks over from_pointcloud(level 8) "
+                     f"({int(blas.pyramid[0, 8])} cells), decoders hidden 64 without bias, 'voxel' 16, white background, RMSprop, L2",
+                     "training rays/sec, VQAD CodebookOctreeGrid radiance field (LOD 7 = finest of 4), synthetic V8", bytes_fn)
+
+
+def run_nglod(args, dev):
+    """C3: SDF regression steps (512 coordinates each) + sphere-traced rendering of the trained field."""
+    import synlego
+    import wisp._C as C
+    from wisp.accelstructs import OctreeAS
+    from wisp.core import Rays
+    from wisp.models.grids import OctreeGrid
+    from wisp.models.nefs import NeuralSDF
+    from wisp.tracers import PackedSDFTracer
+    from wisp.trainers import SDFTrainStep
+    torch.manual_seed(0)
+    surf = synlego.armadillo_surface_points(1 << 20, device=dev)
+    blas = OctreeAS.from_pointcloud(surf, 7)
+    grid = OctreeGrid(blas, feature_dim=16, num_lods=6, interpolation_type='linear', multiscale_type='sum', feature_std=0.01)
+    nef = NeuralSDF(grid, pos_embedder='none', position_input=True, hidden_dim=128, num_layers=1).to(dev)
+    tr = SDFTrainStep(nef, lr=1e-3, eps=1e-15, weight_decay=0.0, grid_lr_weight=1.0)
+    coords, gts = synlego.armadillo_training_samples(500000, device=dev)
+    # keep coordinates inside occupied cells (OctreeSampledSDFDataset samples the octree: every point has features)
+    inside = blas.query(coords, 7).pidx >= 0
+    coords, gts = coords[inside].contiguous(), gts[inside].contiguous()
+    B = args.sdf_batch
+    gen = torch.Generator(device=dev).manual_seed(7)
+
+    def batch():
+        idx = torch.randint(0, coords.shape[0], (B,), device=dev, generator=gen)
+        return C.gather_rows(idx, [coords, gts])
+
+    for _ in range(args.pretrain + args.warmup):
+        x, y = batch()
+        tr.step(x, y)
+    C.TIMING_ALL = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x, y = batch()
+        loss = tr.step(x, y)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sink, C.TIMING_ALL = C.TIMING_ALL, None
+    kernels = _kernel_table(sink)
+    # rendering: 800x800-style rays around the body, 32 marching steps x 0.8 (nglod_octree.yaml tracer)
+    o, d, _ = synlego.ray_bank(1 << 18, seed=5, device=dev, with_gt=False)
+    rays = Rays(o, d, dist_min=0.0, dist_max=6.0)
+    tracer = PackedSDFTracer(num_steps=32, step_size=0.8, min_dis=0.0003)
+    rb = tracer(nef, rays=rays, channels=["depth", "hit"], lod_idx=None)
+    C.TIMING_ALL = {}
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        rb = tracer(nef, rays=rays, channels=["depth", "hit"], lod_idx=None)
+    torch.cuda.synchronize()
+    render_s = (time.perf_counter() - t1) / reps
+    rsink, C.TIMING_ALL = C.TIMING_ALL, None
+    with torch.no_grad():
+        err = float((nef(coords=coords[:65536], channels="sdf") - gts[:65536]).abs().mean())
+    return {"metric": "SDF training coordinates/sec, NGLOD OctreeGrid (nglod_octree.yaml), synthetic Armadillo", "value": B * args.steps / elapsed,
+            "unit": "coords/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3: OctreeGrid F=16, 6 LODs (levels 2-7, 'sum') over from_pointcloud(level 7) of SynArmadillo "
+                                   f"({int(blas.pyramid[0, 7])} cells), NeuralSDF 19->128->1, Adam lr 1e-3, batch {B}",
+                       "batch": B, "pretrain_steps": args.pretrain},
+            "mean_abs_sdf_error": err, "final_loss": float(loss),
+            "render": {"rays": int(o.shape[0]), "ms": 1e3 * render_s, "rays_per_sec": o.shape[0] / render_s,
+                       "hit_fraction": float(rb.hit.float().mean()), "marching_steps": 32,
+                       "kernels": _kernel_table(rsink)},
+            "gpu_busy_fraction": sum(v["total_ms"] for v in kernels.values()) * 1e-3 / elapsed,
+            "roofline": _roofline(kernels, {}, args.steps), "kernels": kernels}
+
+
+def main(args, dev):
+    out = {"v8": run_v8, "vqad": run_vqad, "nglod": run_nglod}[args.config](args, dev)
+    print(json.dumps(out))
+    return out

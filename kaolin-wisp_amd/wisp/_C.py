@@ -94,6 +94,38 @@ for _name, _args in SIGNATURES.items():
 # Live HIP-event timing of selected kernels (bench.py sets TIMING = {} around its timed region).  Events are
 # recorded on the stream the kernel is launched on (torch's current stream).
 TIMING = None
+# TIMING_ALL = {} additionally brackets EVERY C-ABI entry point that launches work with events, keyed by symbol name
+# (the benches of the other configs use it to find the dominant kernel of a step).
+TIMING_ALL = None
+_cdll = lib
+
+
+class _LibProxy:
+    """`lib.<symbol>`: the ctypes function itself, or - for entry points that take a stream - a wrapper that records a pair
+    of events around the call while TIMING_ALL is set.  One dict lookup of overhead otherwise."""
+
+    def __getattr__(self, name):
+        fn = getattr(_cdll, name)
+        sig = SIGNATURES.get(name)
+        if not sig or sig[-1] is not c_vp or name.endswith("_bytes") or name.endswith("_count") and "raymarch" not in name and "raytrace" not in name:
+            setattr(self, name, fn)
+            return fn
+
+        def call(*args):
+            sink = TIMING_ALL
+            if sink is None:
+                return fn(*args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            sink.setdefault(name, []).append((e0, e1))
+            return rc
+        setattr(self, name, call)
+        return call
+
+
+lib = _LibProxy()
 
 
 class _timed:
@@ -293,6 +325,8 @@ def pack_starts(boundary):
     offsets = exclusive_scan(counts)
     num_packs = int(offsets[-1].item())
     starts = torch.empty(num_packs, dtype=torch.int64, device=boundary.device)
+    if num_packs == 0:
+        return starts
     _check(lib.wisp_boundary_pack_starts(_p(boundary), n, _p(offsets), _p(starts), _stream()), "boundary_pack_starts")
     return starts
 

@@ -1378,3 +1378,37 @@ def test_flagship_shape_parity_nerf_hash_yaml():
     # records carry 17 significant bits (2^-17 relative per contribution), sums of up to thousands of them per entry
     assert err <= 1e-4 * scale and rel <= 2e-5, (err, scale, rel)
     assert float(gt_hip[int(grid.codebook.begin_idxes[15]):].abs().max()) == 0.0
+
+
+def test_sdf_train_step_matches_torch_adam():
+    """SDFTrainStep (sdf_trainer.py:65-124 semantics: sum of squared errors / batch, Adam over the flat buffer in one fused
+    launch) against the same field stepped with torch.optim.Adam."""
+    import copy
+    from wisp.accelstructs import OctreeAS
+    from wisp.models.grids import OctreeGrid
+    from wisp.models.nefs import NeuralSDF
+    from wisp.trainers import SDFTrainStep
+    rng = np.random.default_rng(140)
+    P = rng.integers(0, 32, size=(4000, 3))
+    blas = OctreeAS.from_quantized_points(cuda(P.astype(np.int16)), 5)
+    torch.manual_seed(5)
+    grid = OctreeGrid(blas, feature_dim=16, num_lods=3, multiscale_type='sum', feature_std=0.05)
+    nef = NeuralSDF(grid, pos_embedder='none', position_input=True, hidden_dim=128, num_layers=1).to(DEV)
+    ref = copy.deepcopy(nef)
+    groups = [{"params": [p for n, p in ref.named_parameters() if 'decoder' in n], "lr": 1e-3},
+              {"params": [p for n, p in ref.named_parameters() if 'decoder' not in n and 'grid' in n], "lr": 2e-3},
+              {"params": [p for n, p in ref.named_parameters() if 'decoder' not in n and 'grid' not in n], "lr": 1e-3}]
+    opt = torch.optim.Adam([g for g in groups if g["params"]], eps=1e-15)
+    tr = SDFTrainStep(nef, lr=1e-3, eps=1e-15, grid_lr_weight=2.0)
+    cells = cuda(((P[rng.integers(0, P.shape[0], 512)] + rng.uniform(0.05, 0.95, (512, 3))) / 16 - 1).astype(np.float32))
+    gts = cuda(rng.normal(size=(512, 1)).astype(np.float32) * 0.1)
+    for _ in range(4):
+        l1 = tr.step(cells, gts)
+        opt.zero_grad()
+        pred = ref(coords=cells, lod_idx=2, channels="sdf")
+        l2 = ((pred - gts) ** 2).sum() / 512
+        l2.backward()
+        opt.step()
+        assert abs(float(l1) - float(l2)) <= 1e-5 * max(1.0, abs(float(l2)))
+    for (n1, p1), (n2, p2) in zip(sorted(nef.named_parameters()), sorted(ref.named_parameters())):
+        np.testing.assert_allclose(p1.detach().cpu().numpy(), p2.detach().cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg=n1)
