@@ -140,7 +140,7 @@ def run_vqad(args, dev):
                               bias=False, prune_density_decay=None, prune_min_density=None).to(dev)
     pipe = Pipeline(nef, PackedRFTracer(raymarch_type='voxel', num_steps=16, bg_color=(1.0, 1.0, 1.0)))
     tr = MultiviewTrainStep(pipe, lr=1e-3, eps=1e-8, weight_decay=0.0, grid_lr_weight=100.0, rgb_loss_type='l2', prune_every=-1,
-                            target_sample_size=args.target_samples, enable_amp=False, optimizer='rmsprop')
+                            target_sample_size=args.target_samples, enable_amp=args.precision == "bf16", optimizer='rmsprop')
     o, d, _ = synlego.ray_bank(1 << 20, res=400, seed=1000, device=dev, with_gt=False)
     bank = (o, d, synlego.render_gt_white(o, d))
     L = 4

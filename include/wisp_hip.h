@@ -103,13 +103,16 @@ int wisp_spc_dense_bytes(uint8_t* dense, int level, wisp_stream_t stream);
 int wisp_spc_points_from_index(const int64_t* index, int64_t n, int level, int16_t* points, wisp_stream_t stream);
 
 /* Two-phase ray / octree intersection.  count: nuggets per ray; emit: writes them at offsets[r]
- * (exclusive scan of counts), ordered by ray then front-to-back.  depth is [M,1] or [M,2]. */
+ * (exclusive scan of counts), ordered by ray then front-to-back.  depth is [M,1] or [M,2].
+ * cache (optional, f32 [num_rays, cache_cap, 3], caller-allocated, contents undefined on entry): the count phase parks the
+ * first cache_cap nuggets of every ray there (pidx bits, entry, exit) and the emit phase copies them instead of
+ * traversing again; rays with more nuggets than cache_cap are re-traversed.  Pass NULL / 0 to both phases to disable. */
 int wisp_spc_raytrace_count(const uint8_t* octree, const int16_t* points, const int32_t* exsum,
                             const float* origins, const float* dirs, int64_t num_rays, int level,
-                            int32_t* counts, wisp_stream_t stream);
+                            int32_t* counts, float* cache, int cache_cap, wisp_stream_t stream);
 int wisp_spc_raytrace_emit(const uint8_t* octree, const int16_t* points, const int32_t* exsum,
                            const float* origins, const float* dirs, int64_t num_rays, int level,
-                           const int64_t* offsets, int with_exit,
+                           const int64_t* offsets, int with_exit, const float* cache, int cache_cap,
                            int32_t* ridx, int32_t* pidx, float* depth, wisp_stream_t stream);
 
 int wisp_mark_pack_boundaries_i64(const int64_t* ids, int64_t n, uint8_t* boundary, wisp_stream_t stream);
@@ -179,7 +182,8 @@ int wisp_triplane_bwd(const float* coords, int64_t num_samples, const float* gra
 /* VQAD codebook lookup fused with the trilinear blend (replaces CodebookOctreeGrid._index_features + _interpolate,
  * wisp/models/grids/codebook_grid.py:103-172): logits f32 [Fn, dict_size], dictionary f32 [dict_size, feature_dim]
  * (dict_size <= 256, feature_dim <= 16).  training != 0: straight-through softmax one-hot; else argmax lookup.
- * Backward (training semantics) accumulates into grad_logits [Fn, dict_size] and grad_dictionary. */
+ * Backward (training semantics): grad_logits [num_logit_rows = Fn, dict_size] must be ZERO on entry and holds the
+ * gradient on return (its rows double as the scratch of the two-pass scheme); grad_dictionary is accumulated into. */
 int wisp_codebook_trilinear_fwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
                                 const int32_t* trinkets, const float* logits, const float* dictionary,
                                 int64_t num_voxels, int samples_per_voxel, int dict_size, int feature_dim, int level,
@@ -187,8 +191,8 @@ int wisp_codebook_trilinear_fwd(const float* coords, const void* pidx, int pidx_
 int wisp_codebook_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
                                 const int32_t* trinkets, const float* logits, const float* dictionary,
                                 const float* grad_out, int64_t num_voxels, int samples_per_voxel, int dict_size,
-                                int feature_dim, int level, float* grad_logits, float* grad_dictionary,
-                                wisp_stream_t stream);
+                                int feature_dim, int level, int64_t num_logit_rows, float* grad_logits,
+                                float* grad_dictionary, wisp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Raymarch sample generation  (replace OctreeAS._raymarch_ray / _raymarch_voxel / _raymarch_uniform,

@@ -5,6 +5,7 @@
 // :183-185 (unbatched_raytrace), :300/:228 (mark_pack_boundaries / mark_first_hit) and :351
 // (inclusive_sum_cuda).  Semantics: SURVEY.md Appendix A; float operation order: oracle/spc.py.
 #include "wisp_common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------- query
 // child slot of quantised point q at depth l of a `level`-deep walk: xbit<<2 | ybit<<1 | zbit
@@ -83,6 +84,11 @@ extern "C" int wisp_spc_build_bitfield(const int16_t* level_points, int64_t n_po
 }
 
 // ---------------------------------------------------------------------------------------------- raytrace
+static bool env_flag_spc(const char* name, bool dflt) {
+    const char* e = getenv(name);
+    if (!e || !e[0]) return dflt;
+    return e[0] != '0';
+}
 #define RT_MAX_LEVEL 15
 #define RT_BLOCK 128
 
@@ -171,30 +177,184 @@ spc_raytrace_kernel(const uint8_t* __restrict__ octree, const int16_t* __restric
     if (!EMIT) counts[r] = cnt;
 }
 
+// ---- 8 lanes per ray.  The thread-per-ray walk above is a chain of dependent loads (octree byte -> exsum -> point) per CHILD
+// with ~1.5 waves per SIMD at a 100 K-ray batch: pure latency (0.31 ms per pass for 102 K rays of the SynV8 level-7 tree).
+// Here a group of 8 lanes owns a ray and tests the 8 children of the current node at once - lane i takes child
+// i XOR code, so lane order IS the reference's visiting order; siblings are contiguous in the point hierarchy, i.e. one
+// coalesced read - and the DFS advances one NODE per step.  All hits of a leaf parent are emitted in one step (rank =
+// popcount of the lower lanes of the group's hit mask).  Results are the same nuggets in the same order as the walk above.
+// MODE 0 = count, and park up to `cap` nuggets per ray in `cache` ([R, cap, 3]: pidx bits, entry, exit) so that the emit
+// phase is a copy instead of a second traversal; MODE 1 = traverse and write (rays whose nuggets did not fit the cache).
+#define RT8_RAYS 32                       // rays per workgroup (256 threads)
+template <int MODE>
+__global__ void __launch_bounds__(RT8_RAYS * 8)
+spc_raytrace8_kernel(const uint8_t* __restrict__ octree, const int16_t* __restrict__ points,
+                     const int32_t* __restrict__ exsum, const float* __restrict__ origins,
+                     const float* __restrict__ dirs, int64_t num_rays, int level, const int64_t* __restrict__ offsets,
+                     int with_exit, int32_t* __restrict__ counts, float* __restrict__ cache, int cap,
+                     int32_t* __restrict__ out_ridx, int32_t* __restrict__ out_pidx, float* __restrict__ out_depth) {
+    __shared__ int32_t s_base[RT_MAX_LEVEL][RT8_RAYS];
+    __shared__ uint32_t s_st[RT_MAX_LEVEL][RT8_RAYS];        // pending hit mask (8b) | code (3b) << 8 | child bits (8b) << 16
+    const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const int shift = (threadIdx.x & 63) & ~7;               // position of this group's 8 bits inside the wave ballot
+    const int64_t r = (int64_t)blockIdx.x * RT8_RAYS + g;
+    bool active = r < num_rays;
+    int64_t wr = 0;
+    if (MODE == 1 && active) {
+        wr = offsets[r];
+        if (cache && offsets[r + 1] - wr <= (int64_t)cap) active = false;      // served from the cache by the copy kernel
+    }
+    float ox = 0.f, oy = 0.f, oz = 0.f, ix = 0.f, iy = 0.f, iz = 0.f;
+    if (active) {
+        ox = origins[r * 3]; oy = origins[r * 3 + 1]; oz = origins[r * 3 + 2];
+        ix = __fdiv_rn(1.0f, dirs[r * 3]); iy = __fdiv_rn(1.0f, dirs[r * 3 + 1]); iz = __fdiv_rn(1.0f, dirs[r * 3 + 2]);
+    }
+    int32_t cnt = 0;
+    int l = 0;
+    uint32_t bits = 0, code = 0;
+    int32_t base = 0;
+    if (active) {
+        const Slab s = slab_test(ox, oy, oz, ix, iy, iz, 0, 0, 0, 0);
+        if (!s.hit) active = false;
+        else if (level == 0) {
+            if (sub == 0) {
+                if (MODE == 1) {
+                    out_ridx[wr] = (int32_t)r; out_pidx[wr] = 0;
+                    if (with_exit) { out_depth[wr * 2] = s.entry; out_depth[wr * 2 + 1] = s.exit; } else out_depth[wr] = s.entry;
+                } else if (cache && cap > 0) {
+                    float* c = cache + (int64_t)r * cap * 3;
+                    c[0] = __int_as_float(0); c[1] = s.entry; c[2] = s.exit;
+                }
+            }
+            cnt = 1;
+            active = false;
+        } else {
+            code = ((ox > s.cx) ? 4u : 0u) | ((oy > s.cy) ? 2u : 0u) | ((oz > s.cz) ? 1u : 0u);
+            bits = octree[0];
+            base = exsum[0];
+        }
+    }
+    while (__any(active)) {
+        // ---- test the 8 children of the current node (depth l -> l + 1)
+        bool hit = false;
+        Slab c;
+        int32_t child = 0;
+        if (active) {
+            const uint32_t j = (uint32_t)sub ^ code;
+            if ((bits >> j) & 1u) {
+                child = base + __popc(bits & ((2u << j) - 1u));
+                const int16_t* pt = points + (int64_t)child * 3;
+                c = slab_test(ox, oy, oz, ix, iy, iz, pt[0], pt[1], pt[2], l + 1);
+                hit = c.hit;
+            }
+        }
+        uint32_t mask = (uint32_t)(__ballot(hit) >> shift) & 0xffu;
+        if (active) {
+            if (l + 1 == level) {                              // leaf parent: every hit is a nugget, in lane order
+                if (hit) {
+                    const int k = __popc(mask & ((1u << sub) - 1u));
+                    if (MODE == 1) {
+                        const int64_t w = wr + k;
+                        out_ridx[w] = (int32_t)r; out_pidx[w] = child;
+                        if (with_exit) { out_depth[w * 2] = c.entry; out_depth[w * 2 + 1] = c.exit; } else out_depth[w] = c.entry;
+                    } else if (cache && cnt + k < cap) {
+                        float* cc = cache + ((int64_t)r * cap + cnt + k) * 3;
+                        cc[0] = __int_as_float(child); cc[1] = c.entry; cc[2] = c.exit;
+                    }
+                }
+                const int m = __popc(mask);
+                cnt += m; wr += m;
+                mask = 0;
+            }
+            // ---- next node: first pending child here, else back up
+            while (mask == 0u && l > 0) {
+                --l;
+                const uint32_t st = s_st[l][g];
+                mask = st & 0xffu; code = (st >> 8) & 7u; bits = st >> 16;
+                base = s_base[l][g];
+            }
+            if (mask == 0u) active = false;
+            else {
+                const uint32_t i0 = (uint32_t)__builtin_ctz(mask);
+                mask &= mask - 1u;
+                s_st[l][g] = mask | (code << 8) | (bits << 16);      // all 8 lanes write the same value
+                s_base[l][g] = base;
+                const uint32_t j0 = i0 ^ code;
+                const int32_t node = base + __popc(bits & ((2u << j0) - 1u));
+                ++l;
+                bits = octree[node];
+                base = exsum[node];
+                const int16_t* pt = points + (int64_t)node * 3;
+                const float rr = 1.0f / (float)(1 << l);
+                const float cx = rr * (2.0f * (float)pt[0] + 1.0f) - 1.0f, cy = rr * (2.0f * (float)pt[1] + 1.0f) - 1.0f,
+                            cz = rr * (2.0f * (float)pt[2] + 1.0f) - 1.0f;
+                code = ((ox > cx) ? 4u : 0u) | ((oy > cy) ? 2u : 0u) | ((oz > cz) ? 1u : 0u);
+            }
+        }
+    }
+    if (MODE == 0 && r < num_rays && sub == 0) counts[r] = cnt;
+}
+
+// emit phase for the rays whose nuggets were parked by the count phase: 8 lanes copy one ray's run
+__global__ void __launch_bounds__(RT8_RAYS * 8)
+spc_raytrace_copy_kernel(const float* __restrict__ cache, int cap, int64_t num_rays, const int64_t* __restrict__ offsets,
+                         int with_exit, int32_t* __restrict__ out_ridx, int32_t* __restrict__ out_pidx,
+                         float* __restrict__ out_depth) {
+    const int64_t r = (int64_t)blockIdx.x * RT8_RAYS + (threadIdx.x >> 3);
+    if (r >= num_rays) return;
+    const int64_t w0 = offsets[r];
+    const int n = (int)(offsets[r + 1] - w0);
+    if (n > cap) return;                                      // re-traversed by spc_raytrace8_kernel<1>
+    const float* c = cache + (int64_t)r * cap * 3;
+    for (int k = threadIdx.x & 7; k < n; k += 8) {
+        const int64_t w = w0 + k;
+        out_ridx[w] = (int32_t)r;
+        out_pidx[w] = __float_as_int(c[k * 3]);
+        if (with_exit) { out_depth[w * 2] = c[k * 3 + 1]; out_depth[w * 2 + 1] = c[k * 3 + 2]; } else out_depth[w] = c[k * 3 + 1];
+    }
+}
+
+static bool rt_use_groups() { static const bool v = env_flag_spc("WISP_RAYTRACE_GROUPS", true); return v; }
+
 extern "C" int wisp_spc_raytrace_count(const uint8_t* octree, const int16_t* points, const int32_t* exsum,
                                        const float* origins, const float* dirs, int64_t num_rays, int level,
-                                       int32_t* counts, wisp_stream_t stream) {
-    WISP_REQUIRE(num_rays >= 0 && level >= 0 && level <= RT_MAX_LEVEL, "bad num_rays / level");
+                                       int32_t* counts, float* cache, int cache_cap, wisp_stream_t stream) {
+    WISP_REQUIRE(num_rays >= 0 && level >= 0 && level <= RT_MAX_LEVEL && cache_cap >= 0, "bad num_rays / level / cache_cap");
     if (num_rays == 0) return WISP_OK;
     WISP_REQUIRE(points && exsum && origins && dirs && counts && (octree || level == 0), "null pointer");
-    hipLaunchKernelGGL(spc_raytrace_kernel<false>, dim3((unsigned)ceil_div64(num_rays, RT_BLOCK)), dim3(RT_BLOCK), 0,
-                       (hipStream_t)stream, octree, points, exsum, origins, dirs, num_rays, level, nullptr, 0, counts,
-                       nullptr, nullptr, nullptr);
+    if (rt_use_groups())
+        hipLaunchKernelGGL(spc_raytrace8_kernel<0>, dim3((unsigned)ceil_div64(num_rays, RT8_RAYS)), dim3(RT8_RAYS * 8), 0,
+                           (hipStream_t)stream, octree, points, exsum, origins, dirs, num_rays, level, nullptr, 0, counts,
+                           cache, cache ? cache_cap : 0, nullptr, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL(spc_raytrace_kernel<false>, dim3((unsigned)ceil_div64(num_rays, RT_BLOCK)), dim3(RT_BLOCK), 0,
+                           (hipStream_t)stream, octree, points, exsum, origins, dirs, num_rays, level, nullptr, 0, counts,
+                           nullptr, nullptr, nullptr);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
 
 extern "C" int wisp_spc_raytrace_emit(const uint8_t* octree, const int16_t* points, const int32_t* exsum,
                                       const float* origins, const float* dirs, int64_t num_rays, int level,
-                                      const int64_t* offsets, int with_exit, int32_t* ridx, int32_t* pidx, float* depth,
-                                      wisp_stream_t stream) {
-    WISP_REQUIRE(num_rays >= 0 && level >= 0 && level <= RT_MAX_LEVEL, "bad num_rays / level");
+                                      const int64_t* offsets, int with_exit, const float* cache, int cache_cap,
+                                      int32_t* ridx, int32_t* pidx, float* depth, wisp_stream_t stream) {
+    WISP_REQUIRE(num_rays >= 0 && level >= 0 && level <= RT_MAX_LEVEL && cache_cap >= 0, "bad num_rays / level / cache_cap");
     if (num_rays == 0) return WISP_OK;
     WISP_REQUIRE(points && exsum && origins && dirs && offsets && ridx && pidx && depth && (octree || level == 0),
                  "null pointer");
-    hipLaunchKernelGGL(spc_raytrace_kernel<true>, dim3((unsigned)ceil_div64(num_rays, RT_BLOCK)), dim3(RT_BLOCK), 0,
-                       (hipStream_t)stream, octree, points, exsum, origins, dirs, num_rays, level, offsets, with_exit,
-                       nullptr, ridx, pidx, depth);
+    if (rt_use_groups()) {
+        const bool cached = cache != nullptr && cache_cap > 0;
+        if (cached)
+            hipLaunchKernelGGL(spc_raytrace_copy_kernel, dim3((unsigned)ceil_div64(num_rays, RT8_RAYS)), dim3(RT8_RAYS * 8), 0,
+                               (hipStream_t)stream, cache, cache_cap, num_rays, offsets, with_exit, ridx, pidx, depth);
+        hipLaunchKernelGGL(spc_raytrace8_kernel<1>, dim3((unsigned)ceil_div64(num_rays, RT8_RAYS)), dim3(RT8_RAYS * 8), 0,
+                           (hipStream_t)stream, octree, points, exsum, origins, dirs, num_rays, level, offsets, with_exit,
+                           nullptr, const_cast<float*>(cached ? cache : nullptr), cached ? cache_cap : 0, ridx, pidx, depth);
+    } else {
+        hipLaunchKernelGGL(spc_raytrace_kernel<true>, dim3((unsigned)ceil_div64(num_rays, RT_BLOCK)), dim3(RT_BLOCK), 0,
+                           (hipStream_t)stream, octree, points, exsum, origins, dirs, num_rays, level, offsets, with_exit,
+                           nullptr, ridx, pidx, depth);
+    }
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }

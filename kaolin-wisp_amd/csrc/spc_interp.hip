@@ -386,19 +386,155 @@ extern "C" int wisp_codebook_trilinear_fwd(const float* coords, const void* pidx
     return WISP_OK;
 }
 
+// ---- two-pass backward (the path taken whenever dict_size >= feature_dim).  Everything the backward needs from a sample
+// is LINEAR in  G[row] = sum over the (sample, corner) pairs that hit logits row `row` of  w_corner * grad_out :
+//     d logits[row, k] = p_k (D_k . G - sum_m p_m D_m . G),      d dictionary[argmax(row)] += scale(row) * G
+// so pass 1 only scatters G (F atomics per corner instead of 2^bw, and - samples of one voxel being consecutive in every
+// march mode - after a segmented sum over the lanes that share the voxel: one scatter per run of samples, not per sample)
+// and pass 2 visits every logits row ONCE, without atomics on the logits.  The one-pass kernel above issued
+// 8 * 2^bw global float atomics per sample: 2.7e8 per level at 2 M samples, i.e. 9.4 ms per level on MI355X, whose
+// memory-side atomic units retire ~1.8e10 /s; this pair takes ~0.4 ms.  G is accumulated in the first F floats of each
+// grad_logits row (zero on entry), which pass 2 overwrites with the row's gradient.
+template <int F, typename I>
+__global__ void __launch_bounds__(256)
+codebook_corner_grad_kernel(const float* __restrict__ coords, const I* __restrict__ pidx, const int16_t* __restrict__ points,
+                            const int32_t* __restrict__ trinkets, const float* __restrict__ grad_out, int64_t n, int spv, int K,
+                            int level, float* __restrict__ grad_logits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool in = i < n * spv;
+    const int64_t p = in ? (int64_t)pidx[i / spv] : -1;
+    float v[8][F];
+    if (p >= 0) {
+        float w[8], g[F];
+        trilinear_coeffs(coords + i * 3, points + p * 3, level, w);
+#pragma unroll
+        for (int f = 0; f < F; ++f) g[f] = grad_out[i * F + f];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int f = 0; f < F; ++f) v[j][f] = w[j] * g[f];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int f = 0; f < F; ++f) v[j][f] = 0.0f;
+    }
+    // segmented inclusive sum over the wave, runs = consecutive lanes with the same voxel (invalid lanes are their own run)
+    const int64_t key = p >= 0 ? p : -1 - lane;
+    const int64_t prev = __shfl_up(key, 1, 64), next = __shfl_down(key, 1, 64);
+    int head = (lane == 0 || prev != key) ? 1 : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int hp = __shfl_up(head, d, 64);
+        const bool take = lane >= d && !head;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float t = __shfl_up(v[j][f], d, 64);
+                if (take) v[j][f] += t;
+            }
+        if (take) head |= hp;
+    }
+    if (p >= 0 && (lane == 63 || next != key)) {                          // run tail holds the run total
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float* dst = grad_logits + (int64_t)trinkets[p * 8 + j] * K;
+#pragma unroll
+            for (int f = 0; f < F; ++f) atomicAdd(dst + f, v[j][f]);
+        }
+    }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256)
+codebook_logit_grad_kernel(const float* __restrict__ logits, const float* __restrict__ dictionary, int64_t rows, int K,
+                           float* __restrict__ grad_logits, float* __restrict__ grad_dict) {
+    extern __shared__ float s_cb[];                                    // [K * F] dictionary, [K * F] its gradient
+    float* s_dict = s_cb;
+    float* s_gdict = s_cb + K * F;
+    for (int e = threadIdx.x; e < K * F; e += blockDim.x) { s_dict[e] = dictionary[e]; s_gdict[e] = 0.0f; }
+    __syncthreads();
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        float* grow = grad_logits + r * K;
+        float G[F];
+        bool any = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) { G[f] = grow[f]; any |= G[f] != 0.0f; }
+        if (!any) continue;                                            // untouched row: its gradient is the zero it holds
+        const float* row = logits + r * K;
+        int best = 0;
+        float mx = row[0];
+        for (int k = 1; k < K; ++k) { const float x = row[k]; if (x > mx) { mx = x; best = k; } }
+        float denom = 0.0f;
+        for (int k = 0; k < K; ++k) denom += expf(row[k] - mx);
+        const float inv = 1.0f / denom;
+        float dot = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            float dk = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) dk += s_dict[k * F + f] * G[f];
+            dot += expf(row[k] - mx) * inv * dk;
+        }
+        for (int k = 0; k < K; ++k) {
+            float dk = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) dk += s_dict[k * F + f] * G[f];
+            grow[k] = expf(row[k] - mx) * inv * (dk - dot);
+        }
+        const float scale = (1.0f - inv) + inv;                        // forward value of the argmax key
+#pragma unroll
+        for (int f = 0; f < F; ++f) atomicAdd(&s_gdict[best * F + f], G[f] * scale);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * F; e += blockDim.x) {
+        const float x = s_gdict[e];
+        if (x != 0.0f) atomicAdd(grad_dict + e, x);
+    }
+}
+
+template <int F>
+static void launch_codebook_bwd2(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
+                                 const int32_t* trinkets, const float* logits, const float* dictionary, const float* grad_out,
+                                 int64_t num_voxels, int spv, int K, int level, int64_t num_rows, float* grad_logits,
+                                 float* grad_dict, hipStream_t s) {
+    const int64_t n = num_voxels * spv;
+    const dim3 grid((unsigned)ceil_div64(n, 256)), block(256);
+    if (pidx_is_i64)
+        hipLaunchKernelGGL((codebook_corner_grad_kernel<F, int64_t>), grid, block, 0, s, coords, (const int64_t*)pidx, points,
+                           trinkets, grad_out, num_voxels, spv, K, level, grad_logits);
+    else
+        hipLaunchKernelGGL((codebook_corner_grad_kernel<F, int32_t>), grid, block, 0, s, coords, (const int32_t*)pidx, points,
+                           trinkets, grad_out, num_voxels, spv, K, level, grad_logits);
+    int64_t g2 = ceil_div64(num_rows, 256);
+    if (g2 > 2048) g2 = 2048;
+    hipLaunchKernelGGL((codebook_logit_grad_kernel<F>), dim3((unsigned)g2), dim3(256), (size_t)2 * K * F * 4, s, logits, dictionary,
+                       num_rows, K, grad_logits, grad_dict);
+}
+
 extern "C" int wisp_codebook_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
                                            const int32_t* trinkets, const float* logits, const float* dictionary,
                                            const float* grad_out, int64_t num_voxels, int samples_per_voxel, int dict_size,
-                                           int feature_dim, int level, float* grad_logits, float* grad_dictionary,
-                                           wisp_stream_t stream) {
-    WISP_REQUIRE(num_voxels >= 0 && samples_per_voxel >= 1 && level >= 0 && level <= 15, "bad sizes");
+                                           int feature_dim, int level, int64_t num_logit_rows, float* grad_logits,
+                                           float* grad_dictionary, wisp_stream_t stream) {
+    WISP_REQUIRE(num_voxels >= 0 && samples_per_voxel >= 1 && level >= 0 && level <= 15 && num_logit_rows >= 0, "bad sizes");
     WISP_REQUIRE(dict_size >= 1 && dict_size <= CB_MAX_K && feature_dim >= 1 && feature_dim <= CB_MAX_F, "dictionary too large for the fused kernel");
     if (num_voxels == 0) return WISP_OK;
     WISP_REQUIRE(coords && pidx && points && trinkets && logits && dictionary && grad_out && grad_logits && grad_dictionary, "null pointer");
     const int64_t rows = num_voxels * samples_per_voxel;
+    hipStream_t s = (hipStream_t)stream;
+    if (dict_size >= feature_dim && feature_dim <= 8) {
+#define CB_CASE(FF) case FF: launch_codebook_bwd2<FF>(coords, pidx, pidx_is_i64, points, trinkets, logits, dictionary, grad_out, \
+                                                      num_voxels, samples_per_voxel, dict_size, level, num_logit_rows,           \
+                                                      grad_logits, grad_dictionary, s); break;
+        switch (feature_dim) { CB_CASE(1) CB_CASE(2) CB_CASE(3) CB_CASE(4) CB_CASE(5) CB_CASE(6) CB_CASE(7) CB_CASE(8) }
+#undef CB_CASE
+        WISP_CHECK_LAUNCH();
+        return WISP_OK;
+    }
     const dim3 grid((unsigned)ceil_div64(rows, 128)), block(128);
     const size_t lds = (size_t)dict_size * feature_dim * 4;
-    hipStream_t s = (hipStream_t)stream;
     if (pidx_is_i64)
         hipLaunchKernelGGL(codebook_trilinear_bwd_kernel<int64_t>, grid, block, lds, s, coords, (const int64_t*)pidx, points, trinkets,
                            logits, dictionary, grad_out, num_voxels, samples_per_voxel, dict_size, feature_dim, level, grad_logits,

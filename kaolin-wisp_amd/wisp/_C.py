@@ -36,8 +36,8 @@ SIGNATURES = {
     "wisp_hashgrid_bwd_workspace_bytes": [c_i64, c_i32, c_i32, c_vp, c_i32, c_i32],
     "wisp_spc_query": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_build_bitfield": [c_vp, c_i64, c_i32, c_vp, c_vp],
-    "wisp_spc_raytrace_count": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp],
-    "wisp_spc_raytrace_emit": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "wisp_spc_raytrace_count": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp],
+    "wisp_spc_raytrace_emit": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp],
     "wisp_spc_trilinear_coeffs": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_trilinear_fwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp],
@@ -46,7 +46,7 @@ SIGNATURES = {
     "wisp_triplane_fwd": [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_triplane_bwd": [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_codebook_trilinear_fwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
-    "wisp_codebook_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "wisp_codebook_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp],
     "wisp_mark_pack_boundaries_i64": [c_vp, c_i64, c_vp, c_vp],
     "wisp_mark_pack_boundaries_i32": [c_vp, c_i64, c_vp, c_vp],
     "wisp_scan_workspace_bytes": [c_i64],
@@ -410,6 +410,10 @@ def _popc_table(dev):
     return t
 
 
+RAYTRACE_CACHE_CAP = 64                  # nuggets per ray parked by the count phase (12 B each)
+RAYTRACE_CACHE_LIMIT = 2 << 30           # bytes; beyond that the emit phase walks the octree again
+
+
 def spc_raytrace(octree, points, exsum, origins, dirs, level, with_exit=False):
     """kaolin.render.spc.unbatched_raytrace (octree_as.py:183-185).
     Returns (ridx i32 [M], pidx i32 [M], depth f32 [M,1|2], ray_offsets i64 [R+1])."""
@@ -421,8 +425,11 @@ def spc_raytrace(octree, points, exsum, origins, dirs, level, with_exit=False):
     R = origins.shape[0]
     dev = origins.device
     counts = torch.empty(R, dtype=torch.int32, device=dev)
+    # the count phase parks the first RAYTRACE_CACHE_CAP nuggets of every ray, so that emit is a copy, not a second walk
+    cap = RAYTRACE_CACHE_CAP if R * RAYTRACE_CACHE_CAP * 12 <= RAYTRACE_CACHE_LIMIT else 0
+    cache = torch.empty(R * cap * 3, dtype=torch.float32, device=dev) if cap else None
     _check(lib.wisp_spc_raytrace_count(_p(octree), _p(points), _p(exsum), _p(origins), _p(dirs), R, level, _p(counts),
-                                       _stream()), "spc_raytrace_count")
+                                       _p(cache), cap, _stream()), "spc_raytrace_count")
     offsets = exclusive_scan(counts)
     M = int(offsets[-1].item())                      # size read-back, as the reference's kaolin op does
     ridx = torch.empty(M, dtype=torch.int32, device=dev)
@@ -430,8 +437,8 @@ def spc_raytrace(octree, points, exsum, origins, dirs, level, with_exit=False):
     depth = torch.empty(M, 2 if with_exit else 1, dtype=torch.float32, device=dev)
     if M:
         _check(lib.wisp_spc_raytrace_emit(_p(octree), _p(points), _p(exsum), _p(origins), _p(dirs), R, level,
-                                          _p(offsets), int(with_exit), _p(ridx), _p(pidx), _p(depth), _stream()),
-               "spc_raytrace_emit")
+                                          _p(offsets), int(with_exit), _p(cache), cap, _p(ridx), _p(pidx), _p(depth),
+                                          _stream()), "spc_raytrace_emit")
     return ridx, pidx, depth, offsets
 
 
@@ -567,7 +574,8 @@ def codebook_trilinear_backward(coords, pidx, points, trinkets, logits, dictiona
     g_dict = torch.zeros_like(dictionary)
     _check(lib.wisp_codebook_trilinear_bwd(_p(coords), _p(pidx), is64, _p(_need(points, torch.int16, "points")),
                                            _p(_need(trinkets, torch.int32, "trinkets")), _p(logits), _p(dictionary), _p(grad_out),
-                                           V, S, K, F, level, _p(g_logits), _p(g_dict), _stream()), "codebook_trilinear_bwd")
+                                           V, S, K, F, level, logits.shape[0], _p(g_logits), _p(g_dict), _stream()),
+           "codebook_trilinear_bwd")
     return g_logits, g_dict
 
 

@@ -31,7 +31,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--rays", type=int, default=256)
     ap.add_argument("--num-steps", type=int, default=2048)
-    ap.add_argument("--eval-rays", type=int, default=1024)
+    ap.add_argument("--eval-rays", type=int, default=4096)
+    ap.add_argument("--perturb", type=float, default=0.0,
+                    help="relative N(0, perturb) noise on the initial decoder weights: a second run of the SAME backend with "
+                         "e.g. 1e-6 measures how far two trajectories of this chaotic optimisation drift apart on their own")
     ap.add_argument("--out", default=None)
     ap.add_argument("--compare", nargs=2, default=None)
     return ap.parse_args()
@@ -76,12 +79,18 @@ def main():
     nef = NeuralRadianceField(grid, pos_embedder='none', view_embedder='positional', view_multires=4, activation_type='relu',
                               layer_type='linear', hidden_dim=64, num_layers=1, bias=True, prune_density_decay=DECAY,
                               prune_min_density=MIN_DENSITY)
+    if args.perturb > 0:
+        g = torch.Generator().manual_seed(77)
+        with torch.no_grad():
+            for n, p in nef.named_parameters():
+                if 'decoder' in n:
+                    p.mul_(1.0 + args.perturb * torch.randn(p.shape, generator=g))
     o, d, gt = synlego.ray_bank(1 << 17, seed=11, device='cpu')
     eo, ed, egt = synlego.ray_bank(args.eval_rays, seed=12, device='cpu')
     rng = np.random.default_rng(2024)                       # batches + jitter
     prune_gen = torch.Generator().manual_seed(0)            # the draws MultiviewTrainStep.prune makes (seed 0)
     eval_jit = np.random.default_rng(5).uniform(size=(args.eval_rays, args.num_steps)).astype(np.float32)
-    log(f"# backend={args.backend} steps={args.steps} rays/step={args.rays} candidates/ray={args.num_steps} "
+    log(f"# backend={args.backend} perturb={args.perturb} eval_rays={args.eval_rays} steps={args.steps} rays/step={args.rays} candidates/ray={args.num_steps} "
         f"grid L=16 F=2 T=2^19 std={NGP['feature_std']} level-{LEVEL} dense start, prune every 100, AdamW lr 1e-3 grid x100")
     t0 = time.time()
 

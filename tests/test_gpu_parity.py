@@ -323,6 +323,27 @@ def test_raytrace_bit_exact_sparse_and_dense():
     assert ridx.shape[0] == 0 and depth.shape == (0, 2)
 
 
+@pytest.mark.parametrize("cap", [0, 3, 64])
+def test_raytrace_nugget_cache_and_level_extremes(cap, monkeypatch):
+    """The count phase parks `cap` nuggets per ray and the emit phase copies them; rays with more are walked again, cap 0
+    walks twice - every combination must give the oracle's nuggets.  Levels 0 and 1 (root only / root's children) and a
+    level-6 dense tree (up to ~190 nuggets per ray, far beyond any cap) are the extremes of the group traversal."""
+    C = _C()
+    monkeypatch.setattr(C, "RAYTRACE_CACHE_CAP", cap)
+    cases = [(sparse_tree(6, 30000, 35), 6), (sparse_tree(1, 5, 36), 1),
+             ((ospc.create_dense_octree(6),) + ospc.octree_to_spc(ospc.create_dense_octree(6)), 6)]
+    for (oc, pts, pyr, ex), level in cases:
+        o, d = make_rays(1500, 37 + level)
+        want = ospc.raytrace(oc, pts, pyr, ex, o, d, level, with_exit=True)
+        ridx, pidx, depth, offsets = C.spc_raytrace(cuda(oc), cuda(pts), cuda(ex), cuda(o), cuda(d), level, True)
+        assert np.array_equal(ridx.cpu().numpy(), want[0]) and np.array_equal(pidx.cpu().numpy(), want[1])
+        assert np.array_equal(depth.cpu().numpy(), want[2])
+        # level 0: the root cell alone
+        w0 = ospc.raytrace(oc, pts, pyr, ex, o, d, 0, with_exit=False)
+        r0, p0, d0, _ = C.spc_raytrace(cuda(oc), cuda(pts), cuda(ex), cuda(o), cuda(d), 0, False)
+        assert np.array_equal(r0.cpu().numpy(), w0[0]) and np.array_equal(d0.cpu().numpy(), w0[2]) and int(p0.abs().max()) == 0
+
+
 @pytest.mark.parametrize("level,n", [(1, 3), (3, 40), (5, 3000), (7, 60000), (8, 200000)])
 def test_device_spc_build_matches_oracle(level, n):
     """csrc/spc.hip 'SPC build on the device' (dense Morton mask -> node bytes -> one stream compaction) against the oracle's
