@@ -690,13 +690,17 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         if (lv.dense[l]) { entries = 1; for (int a = 0; a < dim; ++a) entries *= (int64_t)lv.res[l]; }
         if (entries > tsize) entries = tsize;
         const int64_t chunks = (entries + ((int64_t)1 << p.chunk_shift) - 1) >> p.chunk_shift;
-        // slot = the records one emitting tile sends to one bucket: no-merge expectation under a uniform spread x 1.5,
-        // at least 128 (overflow falls back to atomics, so the bound only has to be a good guess)
+        // slot = the records one emitting tile sends to one bucket.  Starting point: the NO-merge expectation under a uniform
+        // spread (the run merge removes half of the records on the finest levels and ~95 % on the coarsest, so that
+        // expectation already is 2-20 x what arrives).  A hash spreads a tile's records evenly over the buckets (x 1.25 for the
+        // tail); on a dense level a bucket is a slab of space and a tile's rays may favour some slabs (x 2), but no tile of
+        // 1024 ray-ordered samples has ever been seen to send more than ~800 merged records to one dense level, hence the
+        // 2048 ceiling.  Overflow falls back to atomics, so the bound only has to be a good guess: 2.5 GB of scratch for
+        // 2 M samples at the nerf_hash shape instead of the 4.5 GB the no-merge worst case asked for.
         int64_t cap = ((int64_t)EM_TILE * corners + chunks - 1) / chunks;
-        // a hash spreads a tile's records evenly over the buckets (x 1.5 covers the Poisson tail); on a dense level a
-        // bucket is a slab of space and a tile's rays may favour some slabs (x 4)
-        cap = lv.dense[l] ? cap * 4 : cap + cap / 2;
+        cap = lv.dense[l] ? cap * 2 : cap + cap / 4;
         if (cap < 128) cap = 128;
+        if (lv.dense[l] && cap > 2048) cap = 2048;
         if (cap > (int64_t)EM_TILE * corners) cap = (int64_t)EM_TILE * corners;
         if (chunks > BIN_MAX_CHUNKS || entries > 0xffffffffLL || chunks * p.ntiles * cap * rec_dwords > 0xffffffffLL) p.ok = false;
         p.bins.chunks[li] = (int32_t)chunks;

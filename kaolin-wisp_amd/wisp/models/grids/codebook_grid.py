@@ -66,8 +66,10 @@ class CodebookOctreeGrid(OctreeGrid):
                 raise NotImplementedError
             raise Exception(f"Interpolation mode {self.interpolation_type} is not supported.")
         dictionary = self.dictionary[lod_idx]
+        # (under autocast too: the fused op computes in fp32 whatever the ambient autocast dtype - the softmax the
+        # reference runs here is an fp32-autocast op as well, codebook_grid.py:117-125)
         if (self.fused and coords.is_cuda and feats.dtype == torch.float32 and feats.ndim == 2
-                and dictionary.shape[0] <= 256 and dictionary.shape[1] <= 16 and not torch.is_autocast_enabled()):
+                and dictionary.shape[0] <= 256 and dictionary.shape[1] <= 16):
             return grid_ops.codebook_interpolate_trilinear(coords, pidx, self.blas.points, self.trinkets.int(), feats,
                                                            dictionary, self.active_lods[lod_idx], self.training)
         fs = torch.zeros(batch, num_samples, self.feature_dim, device=coords.device)
