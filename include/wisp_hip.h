@@ -297,6 +297,21 @@ int wisp_sphere_trace_step(int64_t num_packs, const float* nug_o, const float* n
                            const float* dist, float* dist_prev, uint8_t* mask, uint8_t* hit, const int32_t* curr_in,
                            int32_t* curr_out, int64_t* curr_pidx, float* x, wisp_stream_t stream);
 
+/* One marching iteration INCLUDING the field query of a NeuralSDF over an OctreeGrid ('sum' of the active levels, 16
+ * feature channels) with a one-hidden-layer relu decoder on [position, features] (wisp/models/nefs/neural_sdf.py:120-155,
+ * nglod_octree.yaml): everything wisp_sphere_trace_step does, then dist[p] = scale * decoder(x[p]) for the packs still
+ * marching - one launch per iteration, no host decision in between (first != 0: only the query, for the start positions).
+ * feats / levels: HOST arrays of num_lods device pointers / octree levels (ascending); w1 f32 [hidden, 3 + channels] in
+ * nn.Linear layout, b1 [hidden], w2 [hidden] (the output layer's row), b2 [1].  any_active (optional device counter) is
+ * incremented once per pack that is still marching after the step. */
+int wisp_sdf_trace_step_fused(int64_t num_packs, int first, const float* nug_o, const float* nug_d, const float* nug_depth,
+                              const int32_t* nug_pidx, float dist_max, float thr_close, float thr_avg, float* t, float* dist,
+                              float* dist_prev, uint8_t* mask, uint8_t* hit, const int32_t* curr_in, int32_t* curr_out,
+                              int64_t* curr_pidx, float* x, const uint8_t* octree, const int32_t* exsum, const int16_t* points,
+                              const int32_t* trinkets, const void* const* feats, int feats_dtype, const int32_t* levels,
+                              int num_lods, int channels, int half_round, const float* w1, const float* b1, const float* w2,
+                              const float* b2, int hidden, float scale, int32_t* any_active, wisp_stream_t stream);
+
 /* Photometric loss of MultiviewTrainer.step (wisp/trainers/multiview_trainer.py:140-154) and its gradient in one launch:
  * loss[0] = mean over the num_elements entries of huber(beta = 1) (kind 0) / squared (1) / absolute (2) error of rgb
  * against gt; grad[i] = d loss / d rgb[i].  rgb, gt, grad: f32 [num_elements]; loss: f32 [1];

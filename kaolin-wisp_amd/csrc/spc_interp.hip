@@ -651,3 +651,194 @@ extern "C" int wisp_triplane_bwd(const float* coords, int64_t num_samples, const
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- fused sphere-tracing iteration
+// One marching iteration of PackedSDFTracer.trace (wisp/tracers/packed_sdf_tracer.py:118-146) INCLUDING the field query
+// nef(coords=x, channels="sdf") of a NeuralSDF over an OctreeGrid (wisp/models/nefs/neural_sdf.py:120-155:
+// OctreeGrid.interpolate 'sum' over the active LODs -> [position, features] -> Linear -> relu -> Linear), in one launch and
+// without a host decision in between: the reference iterates ~25 masked tensor ops + a query + an MLP + `mask.any()`
+// read-back per step.  16 lanes own one pack (= one ray that hit the octree):
+//   * all 16 run the (pack-uniform) bookkeeping of sphere_trace_step_kernel (csrc/render.hip, same statements, same
+//     order: advance, convergence tests, far plane, find_depth_bound incl. its neighbour-bound quirk, jump, new position);
+//   * they walk the octree once for the new position (the voxel on every active level);
+//   * lane c gathers feature channel c of the 8 corners per level: one contiguous 64-byte row per corner and group;
+//   * the hidden layer is split over the lanes (hidden / 16 neurons each, weights in LDS), the output dot product is
+//     reduced over the group with four DPP-class shuffles.
+// Arithmetic of query and interpolation is that of spc_query_kernel / spc_trilinear_multi_fwd_kernel (so positions, cells and
+// features are bit-identical to the modular path); the decoder is an fp32 fma chain in input order, which differs from
+// the library GEMM of the modular path by summation order only.
+#define SDF_GROUP 16
+#define SDF_MAX_HIDDEN 256
+struct SdfField {
+    const void* feats[SPC_MAX_LODS];
+    int32_t level[SPC_MAX_LODS];
+    int num_lods, channels, half_round, hidden, max_level;
+    const float *w1, *b1, *w2, *b2;       // [hidden, 3 + channels], [hidden], [hidden], [1]
+    float scale;
+};
+
+static __device__ __forceinline__ int sdf_child_slot(int qx, int qy, int qz, int sh) {
+    return (((qx >> sh) & 1) << 2) | (((qy >> sh) & 1) << 1) | ((qz >> sh) & 1);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+sdf_trace_fused_kernel(int64_t num_packs, int first, const float* __restrict__ nug_o, const float* __restrict__ nug_d,
+                       const float* __restrict__ nug_depth, const int32_t* __restrict__ nug_pidx, float dist_max, float thr_close,
+                       float thr_avg, float* __restrict__ t, float* __restrict__ dist, float* __restrict__ dist_prev,
+                       uint8_t* __restrict__ mask, uint8_t* __restrict__ hit, const int32_t* __restrict__ curr_in,
+                       int32_t* __restrict__ curr_out, int64_t* __restrict__ curr_pidx, float* __restrict__ x,
+                       const uint8_t* __restrict__ octree, const int32_t* __restrict__ exsum, const int16_t* __restrict__ points,
+                       const int32_t* __restrict__ trinkets, SdfField fld, int32_t* __restrict__ any_active) {
+    extern __shared__ float s_sdf[];                    // W1 [hidden][in_pad], b1, w2 | per group: 3 + channels inputs
+    const int in_dim = 3 + fld.channels;
+    const int in_pad = in_dim | 1;                      // odd row stride: the lanes of a group read different rows
+    float* s_w1 = s_sdf;
+    float* s_b1 = s_w1 + fld.hidden * in_pad;
+    float* s_w2 = s_b1 + fld.hidden;
+    float* s_in = s_w2 + fld.hidden;                    // [groups per block][in_dim]
+    for (int e = threadIdx.x; e < fld.hidden * in_dim; e += blockDim.x) s_w1[(e / in_dim) * in_pad + e % in_dim] = fld.w1[e];
+    for (int e = threadIdx.x; e < fld.hidden; e += blockDim.x) { s_b1[e] = fld.b1[e]; s_w2[e] = fld.w2[e]; }
+    __syncthreads();
+    const int c = threadIdx.x & (SDF_GROUP - 1);
+    const int grp = threadIdx.x / SDF_GROUP;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x / SDF_GROUP) + grp;
+    if (p >= num_packs) return;
+    float px, py, pz;
+    bool m;
+    if (first) {
+        m = mask[p] != 0;
+        px = x[p * 3]; py = x[p * 3 + 1]; pz = x[p * 3 + 2];
+    } else {
+#pragma clang fp contract(off)
+        const int32_t cur = curr_in[p];
+        m = mask[p] != 0;
+        const bool was = m;
+        bool h = hit[p] != 0;
+        const float dd = dist[p];
+        float tt = t[p] + dd;                                                        // t += dist          (:120)
+        if (m) {
+            h = fabsf(dd) < thr_close;                                               // :122
+            h = h || (fabsf(dd + dist_prev[p]) * 0.5f < thr_avg);                    // :123-124
+            m = tt < dist_max;                                                       // :125
+        }
+        m = m && !h;                                                                 // :126
+        const float dprev = dd;
+        int32_t nxt = -1;
+        if (cur > -1) {                                                              // find_depth_bound (:131)
+            uint32_t i = (uint32_t)cur;
+            const uint32_t stop = (p == num_packs - 1) ? (uint32_t)num_packs : (uint32_t)curr_in[p + 1];
+            while (i < stop) {
+                const float entry = nug_depth[2 * (int64_t)i], exit_ = nug_depth[2 * (int64_t)i + 1];
+                if ((tt >= entry && tt <= exit_) || tt < entry) { nxt = (int32_t)i; break; }
+                ++i;
+            }
+        }
+        const bool keep_prev = m;                                                    // :129 runs before :132
+        m = m && (nxt != -1);                                                        // :132
+        const bool jumped = nxt != cur;                                              // :133
+        const int32_t now = m ? nxt : cur;                                           // :134
+        if (m && jumped) tt = nug_depth[2 * (int64_t)now];                           // :136
+        px = nug_o[p * 3 + 0] + nug_d[p * 3 + 0] * tt;                               // :137-139 / :121
+        py = nug_o[p * 3 + 1] + nug_d[p * 3 + 1] * tt;
+        pz = nug_o[p * 3 + 2] + nug_d[p * 3 + 2] * tt;
+        if (c == 0) {
+            if (keep_prev) dist_prev[p] = dprev;
+            if (m || was) { x[p * 3 + 0] = px; x[p * 3 + 1] = py; x[p * 3 + 2] = pz; }
+            if (m) curr_pidx[p] = (int64_t)nug_pidx[now];
+            t[p] = tt;
+            mask[p] = m ? 1 : 0;
+            hit[p] = h ? 1 : 0;
+            curr_out[p] = now;
+        }
+    }
+    if (!m) return;                                      // the whole group leaves together: nothing below is wave-wide
+    if (c == 0 && any_active) atomicAdd(any_active, 1);
+    // ---- field query at (px, py, pz): voxel on every active level (spc_query_kernel's walk)
+    const int L = fld.max_level;
+    const bool inside = (fabsf(px) <= 1.0f) && (fabsf(py) <= 1.0f) && (fabsf(pz) <= 1.0f);
+    const float res = (float)(1 << L);
+    const int top = (1 << L) - 1;
+    const int qx = min((int)floorf(res * (0.5f * px + 0.5f)), top);
+    const int qy = min((int)floorf(res * (0.5f * py + 0.5f)), top);
+    const int qz = min((int)floorf(res * (0.5f * pz + 0.5f)), top);
+    const float pos[3] = {px, py, pz};
+    float feat = 0.0f;                                   // channel c, summed over the levels
+    int64_t node = inside ? 0 : -1;
+    int li = 0;
+    for (int l = 0; l <= L && li < fld.num_lods; ++l) {
+        if (l == fld.level[li]) {
+            float acc = 0.0f;
+            if (node >= 0) {
+                float w[8];
+                trilinear_coeffs(pos, points + node * 3, l, w);
+                const int32_t* tr = trinkets + node * 8;
+                const T* f = reinterpret_cast<const T*>(fld.feats[li]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float fv = Cvt<T>::to_f(f[(int64_t)tr[j] * fld.channels + c]);
+                    if (fld.half_round) fv = __half2float(__float2half_rn(fv));
+                    acc += fv * w[j];
+                }
+                if (fld.half_round) acc = __half2float(__float2half_rn(acc));
+            }
+            feat += acc;
+            ++li;
+        }
+        if (l < L && node >= 0) {
+            const int cs = sdf_child_slot(qx, qy, qz, L - 1 - l);
+            const uint32_t bits = octree[node];
+            node = ((bits >> cs) & 1u) ? (int64_t)exsum[node] + __popc(bits & ((2u << cs) - 1u)) : -1;
+        }
+    }
+    // ---- decoder: in = [position, features] (neural_sdf.py: embedded position first)
+    float* gin = s_in + grp * in_dim;
+    if (c < 3) gin[c] = pos[c];
+    gin[3 + c] = feat;
+    __builtin_amdgcn_wave_barrier();                     // the group's lanes are in one wave: LDS order suffices
+    float out = 0.0f;
+    for (int hh = c; hh < fld.hidden; hh += SDF_GROUP) {
+        const float* wr = s_w1 + hh * in_pad;
+        float a = s_b1[hh];
+        for (int i = 0; i < in_dim; ++i) a = __builtin_fmaf(wr[i], gin[i], a);
+        out = __builtin_fmaf(s_w2[hh], fmaxf(a, 0.0f), out);
+    }
+#pragma unroll
+    for (int d = SDF_GROUP / 2; d >= 1; d >>= 1) out += __shfl_xor(out, d, SDF_GROUP);
+    if (c == 0) dist[p] = (out + fld.b2[0]) * fld.scale;
+}
+
+extern "C" int wisp_sdf_trace_step_fused(int64_t num_packs, int first, const float* nug_o, const float* nug_d, const float* nug_depth,
+                                         const int32_t* nug_pidx, float dist_max, float thr_close, float thr_avg, float* t,
+                                         float* dist, float* dist_prev, uint8_t* mask, uint8_t* hit, const int32_t* curr_in,
+                                         int32_t* curr_out, int64_t* curr_pidx, float* x, const uint8_t* octree,
+                                         const int32_t* exsum, const int16_t* points, const int32_t* trinkets,
+                                         const void* const* feats, int feats_dtype, const int32_t* levels, int num_lods,
+                                         int channels, int half_round, const float* w1, const float* b1, const float* w2,
+                                         const float* b2, int hidden, float scale, int32_t* any_active, wisp_stream_t stream) {
+    WISP_REQUIRE(num_packs >= 0 && num_lods >= 1 && num_lods <= SPC_MAX_LODS, "bad sizes");
+    WISP_REQUIRE(channels == SDF_GROUP, "the fused tracer step is built for 16 feature channels (nglod_octree.yaml)");
+    WISP_REQUIRE(hidden >= 1 && hidden <= SDF_MAX_HIDDEN, "hidden width out of range");
+    if (num_packs == 0) return WISP_OK;
+    WISP_REQUIRE(nug_o && nug_d && nug_depth && nug_pidx && t && dist && dist_prev && mask && hit && curr_in && curr_out &&
+                 curr_pidx && x && octree && exsum && points && trinkets && feats && levels && w1 && b1 && w2 && b2, "null pointer");
+    SdfField fld;
+    for (int l = 0; l < num_lods; ++l) {
+        WISP_REQUIRE(feats[l] && levels[l] >= 0 && levels[l] <= 15 && (l == 0 || levels[l] > levels[l - 1]), "bad level list");
+        fld.feats[l] = feats[l]; fld.level[l] = levels[l];
+    }
+    fld.num_lods = num_lods; fld.channels = channels; fld.half_round = half_round; fld.hidden = hidden;
+    fld.max_level = levels[num_lods - 1];
+    fld.w1 = w1; fld.b1 = b1; fld.w2 = w2; fld.b2 = b2; fld.scale = scale;
+    const int groups = 256 / SDF_GROUP;
+    const size_t lds = ((size_t)hidden * ((3 + channels) | 1) + 2 * hidden + (size_t)groups * (3 + channels)) * 4;
+    const dim3 grid((unsigned)ceil_div64(num_packs, groups)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define SDF_LAUNCH(T) hipLaunchKernelGGL((sdf_trace_fused_kernel<T>), grid, block, lds, s, num_packs, first, nug_o, nug_d, nug_depth,   \
+                                         nug_pidx, dist_max, thr_close, thr_avg, t, dist, dist_prev, mask, hit, curr_in, curr_out,     \
+                                         curr_pidx, x, octree, exsum, points, trinkets, fld, any_active)
+    if (feats_dtype == WISP_F32) SDF_LAUNCH(float); else if (feats_dtype == WISP_F16) SDF_LAUNCH(__half); else SDF_LAUNCH(__hip_bfloat16);
+#undef SDF_LAUNCH
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

@@ -61,6 +61,9 @@ SIGNATURES = {
     "wisp_spc_mask_from_points": [c_vp, c_i64, c_i32, c_vp, c_vp],
     "wisp_spc_dense_bytes": [c_vp, c_i32, c_vp],
     "wisp_spc_points_from_index": [c_vp, c_i64, c_i32, c_vp, c_vp],
+    "wisp_sdf_trace_step_fused": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                  c_vp, c_i32, c_f32, c_vp, c_vp],
     "wisp_uniform_sample": [c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_uniform_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_packed_sum_reduce": [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
@@ -801,6 +804,26 @@ def sphere_trace_step(nug_o, nug_d, nug_depth, nug_pidx, dist_max, thr_close, th
                                       float(np.float32(thr_close)), float(np.float32(thr_avg)), _p(t), _p(dist), _p(dist_prev),
                                       _p(mask), _p(hit), _p(curr_in), _p(curr_out), _p(curr_pidx), _p(x), _stream()),
            "sphere_trace_step")
+
+
+def sdf_trace_step_fused(first, nug_o, nug_d, nug_depth, nug_pidx, dist_max, thr_close, thr_avg, t, dist, dist_prev, mask, hit,
+                         curr_in, curr_out, curr_pidx, x, octree, exsum, points, trinkets, feats, levels, half_round, w1, b1, w2, b2,
+                         scale, any_active=None):
+    """sphere_trace_step + the NeuralSDF / OctreeGrid field query at the new positions, one launch (csrc/spc_interp.hip)."""
+    P = nug_o.shape[0]
+    n = len(feats)
+    for f in feats:
+        assert f.is_cuda and f.is_contiguous() and f.dtype == feats[0].dtype and f.shape[1] == feats[0].shape[1]
+    fp = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
+    lv = (ctypes.c_int32 * n)(*[int(l) for l in levels])
+    for a in (w1, b1, w2, b2):
+        assert a.is_cuda and a.dtype == torch.float32 and a.is_contiguous()
+    _check(lib.wisp_sdf_trace_step_fused(P, int(first), _p(nug_o), _p(nug_d), _p(nug_depth), _p(nug_pidx), float(np.float32(dist_max)),
+                                         float(np.float32(thr_close)), float(np.float32(thr_avg)), _p(t), _p(dist), _p(dist_prev),
+                                         _p(mask), _p(hit), _p(curr_in), _p(curr_out), _p(curr_pidx), _p(x), _p(octree), _p(exsum),
+                                         _p(points), _p(trinkets), fp, _DTYPE_CODE[feats[0].dtype], lv, n, feats[0].shape[1],
+                                         int(half_round), _p(w1), _p(b1), _p(w2), _p(b2), w1.shape[0], float(np.float32(scale)),
+                                         _p(any_active), _stream()), "sdf_trace_step_fused")
 
 
 _LOSS_KIND = {"huber": 0, "l2": 1, "l1": 2}

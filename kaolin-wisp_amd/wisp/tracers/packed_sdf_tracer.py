@@ -72,6 +72,57 @@ class PackedSDFTracer(BaseTracer):
             st.dist[sel] = sdf.reshape(-1).to(st.dist.dtype)
         return sel
 
+    # ------------------------------------------------------------------ fused iteration (field query inside the launch)
+    @staticmethod
+    def _fused_field(nef, lod_idx):
+        """The tensors wisp_sdf_trace_step_fused needs, or None when the field is not the shape it is built for: a plain
+        NeuralSDF (nglod_octree.yaml) - OctreeGrid with 16 'sum'-med feature channels, linear interpolation, raw position
+        input without embedding, one hidden relu layer with bias.  Anything else marches through `nef(...)` per iteration."""
+        from wisp.models.grids.octree_grid import OctreeGrid
+        from wisp.models.nefs.neural_sdf import NeuralSDF
+        import os
+        if os.environ.get("WISP_SDF_FUSED", "1") == "0" or type(nef) is not NeuralSDF or type(nef.grid) is not OctreeGrid:
+            return None
+        g, dec = nef.grid, nef.decoder
+        if (g.multiscale_type != 'sum' or g.interpolation_type != 'linear' or g.feature_dim != 16 or lod_idx < 1
+                or not nef.position_input or not isinstance(nef.pos_embedder, torch.nn.Identity)
+                or nef.activation_type != 'relu' or nef.num_layers != 1 or len(dec.layers) != 1 or dec.skip
+                or type(dec.layers[0]) is not torch.nn.Linear or type(dec.lout) is not torch.nn.Linear
+                or dec.layers[0].bias is None or dec.lout.bias is None or dec.lout.out_features != 1
+                or dec.layers[0].out_features > 256 or not g.features[0].is_cuda):
+            return None
+        n = lod_idx + 1
+        feats = [g.features[i].detach().contiguous() for i in range(n)]
+        if any(f.dtype != feats[0].dtype or f.shape[1] != 16 for f in feats):
+            return None
+        g._sync_device(feats[0].device)
+        return dict(feats=feats, levels=[int(l) for l in g.active_lods[:n]], half_round=bool(g.half_features),
+                    w1=dec.layers[0].weight.detach().float().contiguous(), b1=dec.layers[0].bias.detach().float().contiguous(),
+                    w2=dec.lout.weight.detach().float().reshape(-1).contiguous(), b2=dec.lout.bias.detach().float().contiguous(),
+                    octree=g.blas.octree, exsum=g.blas.prefix, points=g.blas.points, trinkets=g.trinkets.int().contiguous())
+
+    def _march_fused(self, fld, rays, rt_pidx, depth, st, num_steps, step_size, min_dis):
+        """All marching iterations as one launch each, no host decision per iteration: the loop only peeks at a device
+        counter of still-marching packs every 8 iterations (the reference reads `mask.any()` twice per iteration)."""
+        import wisp._C as _C
+        counter = torch.zeros(1, dtype=torch.int32, device=st.t.device)
+
+        def launch(first, cnt):
+            _C.sdf_trace_step_fused(first, st.o, st.d, depth, rt_pidx, rays.dist_max, min_dis, min_dis * 5, st.t, st.dist,
+                                    st.dist_prev, st.active, st.hit, st.nug, st.nug_next, st.cell, st.x, fld["octree"],
+                                    fld["exsum"], fld["points"], fld["trinkets"], fld["feats"], fld["levels"], fld["half_round"],
+                                    fld["w1"], fld["b1"], fld["w2"], fld["b2"], step_size, cnt)
+        launch(True, None)
+        st.dist_prev.copy_(st.dist)
+        for it in range(num_steps):
+            peek = (it % 8) == 7
+            if peek:
+                counter.zero_()
+            launch(False, counter if peek else None)
+            st.nug, st.nug_next = st.nug_next, st.nug
+            if peek and int(counter.item()) == 0:
+                break
+
     def trace(self, nef, rays, channels, extra_channels, lod_idx=None, num_steps=64, step_size=1.0, min_dis=1e-4):
         """Sphere-trace `rays`; returns RenderBuffer(xyz, depth, hit, normal, rgb (= normal colours), alpha)."""
         import wisp._C as _C
@@ -83,6 +134,11 @@ class PackedSDFTracer(BaseTracer):
         depth = rt.depth
         depth[..., 0:1] += 1e-5                               # start just inside the first cell
         st = self._start(rays, rt.ridx, rt.pidx, depth)
+        fld = self._fused_field(nef, lod_idx) if st.t.shape[0] else None
+        if fld is not None:
+            with torch.no_grad():
+                self._march_fused(fld, rays, rt.pidx, depth, st, num_steps, invres * step_size, min_dis * invres)
+            return self._gather(nef, rays, st, channels, extra_channels, lod_idx)
         with torch.no_grad():
             self._query(nef, st, lod_idx, invres * step_size)
             st.dist_prev.copy_(st.dist)

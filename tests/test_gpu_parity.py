@@ -1433,3 +1433,49 @@ def test_sdf_train_step_matches_torch_adam():
         assert abs(float(l1) - float(l2)) <= 1e-5 * max(1.0, abs(float(l2)))
     for (n1, p1), (n2, p2) in zip(sorted(nef.named_parameters()), sorted(ref.named_parameters())):
         np.testing.assert_allclose(p1.detach().cpu().numpy(), p2.detach().cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg=n1)
+
+
+def test_sdf_tracer_fused_iteration_equals_modular_marching(monkeypatch):
+    """wisp_sdf_trace_step_fused (step + octree walk + multi-level trilinear + decoder in one launch per iteration) against
+    the modular loop (sphere_trace_step kernel, then nef(...) through spc_query / trilinear / torch Linear modules) on a
+    NeuralSDF that was actually fitted to a sphere: same packs hit, same depths and positions up to the summation order of
+    the decoder's dot products (rays whose decision sits on the convergence threshold are compared by count)."""
+    from wisp.accelstructs import OctreeAS
+    from wisp.core import Rays
+    from wisp.models.grids import OctreeGrid
+    from wisp.models.nefs import NeuralSDF
+    from wisp.tracers import PackedSDFTracer
+    from wisp.trainers import SDFTrainStep
+    level = 5
+    idx = np.stack(np.meshgrid(*[np.arange(32)] * 3, indexing='ij'), -1).reshape(-1, 3)
+    ctr = (idx + 0.5) / 16 - 1
+    P = idx[np.abs(np.linalg.norm(ctr, axis=1) - 0.55) < 0.15]
+    blas = OctreeAS.from_quantized_points(torch.from_numpy(P).short().to(DEV), level)
+    torch.manual_seed(11)
+    grid = OctreeGrid(blas, feature_dim=16, num_lods=3, multiscale_type='sum', feature_std=0.01)
+    nef = NeuralSDF(grid, pos_embedder='none', position_input=True, hidden_dim=128, num_layers=1).to(DEV)
+    tr = SDFTrainStep(nef, lr=3e-3, grid_lr_weight=10.0)
+    g = torch.Generator(device=DEV).manual_seed(12)
+    cells = cuda(P.astype(np.float32))
+    for _ in range(300):
+        pick = torch.randint(0, cells.shape[0], (2048,), device=DEV, generator=g)
+        xs = (cells[pick] + torch.rand(2048, 3, device=DEV, generator=g)) / 16 - 1
+        tr.step(xs, xs.norm(dim=-1, keepdim=True) - 0.55)
+    o, d = make_rays(3000, 151, radius=2.5, spread=0.7)
+    rays = Rays(cuda(o), cuda(d), dist_min=0.0, dist_max=6.0)
+    tracer = PackedSDFTracer(num_steps=40, step_size=0.8, min_dis=0.0003)
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("WISP_SDF_FUSED", fused)
+        assert (PackedSDFTracer._fused_field(nef, 2) is not None) == (fused == "1")
+        outs.append(tracer(nef, rays=rays, channels=["depth", "hit"], lod_idx=2))
+    a, b = outs
+    hits_a, hits_b = a.hit.reshape(-1), b.hit.reshape(-1)
+    assert int(hits_b.sum()) > 500                                   # the fitted field is a surface the rays find
+    differ = int((hits_a != hits_b).sum())
+    assert differ <= max(2, int(0.002 * hits_b.numel())), differ
+    both = hits_a & hits_b
+    assert float((a.depth.reshape(-1)[both] - b.depth.reshape(-1)[both]).abs().max()) <= 2e-4
+    assert float((a.xyz[both] - b.xyz[both]).abs().max()) <= 2e-4
+    # and the surface found is the sphere the field was fitted to
+    assert float((b.xyz[both].norm(dim=-1) - 0.55).abs().mean()) < 0.02
