@@ -337,14 +337,16 @@ def main():
     out = None
     if rank == 0:
         # quality: PSNR on held-out rays after pretrain + warm-up + both timed loops (real optimisation steps all of them)
-        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
-            eo, ed, ergb = synlego.ray_bank(args.eval_rays, seed=7, device=dev)
-            chunks = []
-            for s in range(0, eo.shape[0], 8192):
-                rb = pipe(rays=Rays(eo[s:s + 8192], ed[s:s + 8192], dist_min=synlego.NEAR, dist_max=synlego.FAR), channels=["rgb"])
-                chunks.append(rb.rgb.float())
-            mse = float(((torch.cat(chunks) - ergb) ** 2).mean())
-        psnr = 10 * math.log10(1.0 / max(mse, 1e-12))
+        psnr = None
+        if args.eval_rays > 0:
+            with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+                eo, ed, ergb = synlego.ray_bank(args.eval_rays, seed=7, device=dev)
+                chunks = []
+                for s in range(0, eo.shape[0], 8192):
+                    rb = pipe(rays=Rays(eo[s:s + 8192], ed[s:s + 8192], dist_min=synlego.NEAR, dist_max=synlego.FAR), channels=["rgb"])
+                    chunks.append(rb.rgb.float())
+                mse = float(((torch.cat(chunks) - ergb) ** 2).mean())
+            psnr = 10 * math.log10(1.0 / max(mse, 1e-12))
         rays_total = R * args.steps * world
         ref_rays_total = R_ref * args.steps * world
         amort = elapsed + (args.steps / trainer.prune_every - prunes_in) * prune_ms * 1e-3   # exactly steps/100 prunes

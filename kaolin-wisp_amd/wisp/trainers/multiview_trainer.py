@@ -236,9 +236,8 @@ class MultiviewTrainStep:
         self._prune_gen = torch.Generator(device=dev).manual_seed(seed)
         self._side_stream = None
         self._params_ready = None
-        # single GPU: run the (HBM-streaming) optimizer launch on the side stream as well, under the next step's (VALU / L2
-        # bound) raymarch.  Opt-in: code that reads parameters right after step() must then call wait_for_parameters().
-        self.overlap_optimizer = os.environ.get("WISP_OVERLAP_OPTIMIZER", "0") == "1"
+        # (single GPU: putting the optimizer launch on the side stream too, under the next step's raymarch, was measured
+        # neutral - 1.270 vs 1.284 ms/step - so one rank keeps everything on one stream)
         # specialised issue order for the flagship pipeline shape (WISP_DIRECT_STEP=0 keeps the modular path)
         self._direct = None
         if os.environ.get("WISP_DIRECT_STEP", "1") != "0" and _DirectHashNeRFStep.supports(pipeline):
@@ -281,7 +280,7 @@ class MultiviewTrainStep:
         """Gradient all-reduce + optimizer.  With more than one rank both run on a side stream, so that the part of the
         NEXT step that does not read parameters (ray gathering, raymarch against the occupancy structure, its size
         read-back) overlaps the collective; whoever reads parameters next calls wait_for_parameters() first."""
-        if not (self.world > 1 or self.force_allreduce or self.overlap_optimizer) or not self.flat.data.is_cuda:
+        if not (self.world > 1 or self.force_allreduce) or not self.flat.data.is_cuda:
             self.allreduce_grads()
             self.optimizer_step()
             return

@@ -1475,7 +1475,10 @@ def test_sdf_tracer_fused_iteration_equals_modular_marching(monkeypatch):
     differ = int((hits_a != hits_b).sum())
     assert differ <= max(2, int(0.002 * hits_b.numel())), differ
     both = hits_a & hits_b
-    assert float((a.depth.reshape(-1)[both] - b.depth.reshape(-1)[both]).abs().max()) <= 2e-4
-    assert float((a.xyz[both] - b.xyz[both]).abs().max()) <= 2e-4
+    # a ray may converge one iteration earlier on one side when its distance sits at the threshold: both stop within
+    # min_dis of the surface, so depths agree to ~2 min_dis; the bulk is identical to rounding
+    dd = (a.depth.reshape(-1)[both] - b.depth.reshape(-1)[both]).abs()
+    assert float(dd.max()) <= 6e-4 and float(dd.median()) <= 1e-6
+    assert float((a.xyz[both] - b.xyz[both]).abs().max()) <= 6e-4
     # and the surface found is the sphere the field was fitted to
     assert float((b.xyz[both].norm(dim=-1) - 0.55).abs().mean()) < 0.02
