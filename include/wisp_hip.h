@@ -179,6 +179,14 @@ int wisp_triplane_fwd(const float* coords, int64_t num_samples, const float* con
 int wisp_triplane_bwd(const float* coords, int64_t num_samples, const float* grad_out, const int32_t* sizes, int num_lods,
                       int feature_dim, int sum, float* const* grad_planes, wisp_stream_t stream);
 
+/* wisp._C.ops.grid_interpolate_cuda / grid_interpolate_backward_cuda (wisp/csrc/ops/grid_interpolate.h; kernels
+ * grid_interpolate_cuda.cu:17-129): blend of eight gathered corner rows.  coords f32 [N,3] LOCAL coordinates in [0,1],
+ * feats / grad_feats [N, 8, feature_dim] and out / grad_out [N, feature_dim] in `dtype`; corner k = dx<<2 | dy<<1 | dz. */
+int wisp_grid_interpolate_fwd(const float* coords, const void* feats, int dtype, int64_t num_coords, int feature_dim,
+                              void* out, wisp_stream_t stream);
+int wisp_grid_interpolate_bwd(const float* coords, const void* grad_out, int dtype, int64_t num_coords, int feature_dim,
+                              void* grad_feats, wisp_stream_t stream);
+
 /* VQAD codebook lookup fused with the trilinear blend (replaces CodebookOctreeGrid._index_features + _interpolate,
  * wisp/models/grids/codebook_grid.py:103-172): logits f32 [Fn, dict_size], dictionary f32 [dict_size, feature_dim]
  * (dict_size <= 256, feature_dim <= 16).  training != 0: straight-through softmax one-hot; else argmax lookup.

@@ -842,3 +842,71 @@ extern "C" int wisp_sdf_trace_step_fused(int64_t num_packs, int first, const flo
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- blend of gathered corners
+// wisp._C.ops.grid_interpolate_cuda / _backward_cuda (wisp/csrc/ops/grid_interpolate_cuda.cu:17-129): trilinear blend of
+// eight already-gathered corner rows, feats [N, 8, F] with LOCAL coordinates [N, 3] in [0, 1]; corner k = dx<<2 | dy<<1 | dz.
+// Peripheral in the reference (only tests/core/test_grid_interpolation.py calls it); kept so that the whole `ops` surface
+// binds.  One thread per (sample, feature): consecutive lanes read consecutive features of a corner row.  The backward
+// writes every (sample, corner, feature) exactly once, so it stores instead of the reference's atomicAdd.
+template <typename T>
+__global__ void __launch_bounds__(256)
+grid_interpolate_kernel(const float* __restrict__ coords, const T* __restrict__ feats, int64_t n, int F, T* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * F) return;
+    const int64_t i = e / F;
+    const int j = (int)(e - i * F);
+    const float x = coords[i * 3], y = coords[i * 3 + 1], z = coords[i * 3 + 2];
+    const float gx = 1.0f - x, gy = 1.0f - y, gz = 1.0f - z;
+    const float c[8] = {gx * gy * gz, gx * gy * z, gx * y * gz, gx * y * z, x * gy * gz, x * gy * z, x * y * gz, x * y * z};
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += Cvt<T>::to_f(feats[(i * 8 + k) * F + j]) * c[k];
+    out[e] = Cvt<T>::from_f(acc);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+grid_interpolate_bwd_kernel(const float* __restrict__ coords, const T* __restrict__ grad_out, int64_t n, int F,
+                            T* __restrict__ grad_feats) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * F) return;
+    const int64_t i = e / F;
+    const int j = (int)(e - i * F);
+    const float x = coords[i * 3], y = coords[i * 3 + 1], z = coords[i * 3 + 2];
+    const float gx = 1.0f - x, gy = 1.0f - y, gz = 1.0f - z;
+    const float c[8] = {gx * gy * gz, gx * gy * z, gx * y * gz, gx * y * z, x * gy * gz, x * gy * z, x * y * gz, x * y * z};
+    const float g = Cvt<T>::to_f(grad_out[e]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) grad_feats[(i * 8 + k) * F + j] = Cvt<T>::from_f(g * c[k]);
+}
+
+extern "C" int wisp_grid_interpolate_fwd(const float* coords, const void* feats, int dtype, int64_t num_coords, int feature_dim,
+                                         void* out, wisp_stream_t stream) {
+    WISP_REQUIRE(num_coords >= 0 && feature_dim >= 1, "bad sizes");
+    WISP_REQUIRE(dtype == WISP_F32 || dtype == WISP_F16 || dtype == WISP_BF16, "bad dtype");
+    if (num_coords == 0) return WISP_OK;
+    WISP_REQUIRE(coords && feats && out, "null pointer");
+    const dim3 grid((unsigned)ceil_div64(num_coords * feature_dim, 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == WISP_F32) hipLaunchKernelGGL(grid_interpolate_kernel<float>, grid, block, 0, s, coords, (const float*)feats, num_coords, feature_dim, (float*)out);
+    else if (dtype == WISP_F16) hipLaunchKernelGGL(grid_interpolate_kernel<__half>, grid, block, 0, s, coords, (const __half*)feats, num_coords, feature_dim, (__half*)out);
+    else hipLaunchKernelGGL(grid_interpolate_kernel<__hip_bfloat16>, grid, block, 0, s, coords, (const __hip_bfloat16*)feats, num_coords, feature_dim, (__hip_bfloat16*)out);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_grid_interpolate_bwd(const float* coords, const void* grad_out, int dtype, int64_t num_coords, int feature_dim,
+                                         void* grad_feats, wisp_stream_t stream) {
+    WISP_REQUIRE(num_coords >= 0 && feature_dim >= 1, "bad sizes");
+    WISP_REQUIRE(dtype == WISP_F32 || dtype == WISP_F16 || dtype == WISP_BF16, "bad dtype");
+    if (num_coords == 0) return WISP_OK;
+    WISP_REQUIRE(coords && grad_out && grad_feats, "null pointer");
+    const dim3 grid((unsigned)ceil_div64(num_coords * feature_dim, 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == WISP_F32) hipLaunchKernelGGL(grid_interpolate_bwd_kernel<float>, grid, block, 0, s, coords, (const float*)grad_out, num_coords, feature_dim, (float*)grad_feats);
+    else if (dtype == WISP_F16) hipLaunchKernelGGL(grid_interpolate_bwd_kernel<__half>, grid, block, 0, s, coords, (const __half*)grad_out, num_coords, feature_dim, (__half*)grad_feats);
+    else hipLaunchKernelGGL(grid_interpolate_bwd_kernel<__hip_bfloat16>, grid, block, 0, s, coords, (const __hip_bfloat16*)grad_out, num_coords, feature_dim, (__hip_bfloat16*)grad_feats);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

@@ -64,6 +64,8 @@ SIGNATURES = {
     "wisp_sdf_trace_step_fused": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                   c_vp, c_i32, c_f32, c_vp, c_vp],
+    "wisp_grid_interpolate_fwd": [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp],
+    "wisp_grid_interpolate_bwd": [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp],
     "wisp_uniform_sample": [c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_uniform_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_packed_sum_reduce": [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
@@ -1045,7 +1047,31 @@ def _ref_find_depth_bound_cuda(query, curr_idxes, depth):
     return find_depth_bound(query.reshape(-1), curr_idxes, depth)
 
 
+def _ref_grid_interpolate_cuda(coords, feats_in):
+    """grid_interpolate.h: coords f32 [N,3] local in [0,1], feats [N,8,F] -> [N,F] in feats' dtype."""
+    coords = _need(coords, torch.float32, "coords")
+    feats_in = _need(feats_in, None, "feats_in")
+    N, F = coords.shape[0], feats_in.shape[-1]
+    out = torch.empty(N, F, dtype=feats_in.dtype, device=coords.device)
+    _check(lib.wisp_grid_interpolate_fwd(_p(coords), _p(feats_in), _DTYPE_CODE[feats_in.dtype], N, F, _p(out), _stream()),
+           "grid_interpolate_fwd")
+    return out
+
+
+def _ref_grid_interpolate_backward_cuda(coords, grad_output, feature_dim):
+    """-> grad_feats [N,8,F] in grad_output's dtype."""
+    coords = _need(coords, torch.float32, "coords")
+    grad_output = _need(grad_output, None, "grad_output")
+    N = coords.shape[0]
+    grad = torch.empty(N, 8, int(feature_dim), dtype=grad_output.dtype, device=coords.device)
+    _check(lib.wisp_grid_interpolate_bwd(_p(coords), _p(grad_output), _DTYPE_CODE[grad_output.dtype], N, int(feature_dim),
+                                         _p(grad), _stream()), "grid_interpolate_bwd")
+    return grad
+
+
 ops = _Namespace("wisp._C.ops",
+                 grid_interpolate_cuda=_ref_grid_interpolate_cuda,
+                 grid_interpolate_backward_cuda=_ref_grid_interpolate_backward_cuda,
                  hashgrid_interpolate_cuda=_ref_hashgrid_interpolate_cuda,
                  hashgrid_interpolate_backward_cuda=_ref_hashgrid_interpolate_backward_cuda,
                  uniform_sample_cuda=_ref_uniform_sample_cuda)

@@ -182,6 +182,30 @@ def hashgrid(coords, codebook_bitwidth, lod_idx, codebook, zero_from_col=None):
     return feats.reshape(batch, feature_dim)
 
 
+class GridInterpolate(torch.autograd.Function):
+    """Trilinear blend of eight gathered corner rows (wisp/ops/grid.py:146-168): feats [N,8,F], local coords [N,3] in [0,1]."""
+
+    @staticmethod
+    def forward(ctx, coords, feats):
+        if torch.is_autocast_enabled():
+            feats = feats.float()                                  # custom_fwd(cast_inputs=torch.float) in the reference
+        out = _hip().ops.grid_interpolate_cuda(coords.float().contiguous(), feats.contiguous())
+        ctx.save_for_backward(coords)
+        ctx.feature_dim = feats.shape[-1]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        coords = ctx.saved_tensors[0]
+        return None, _hip().ops.grid_interpolate_backward_cuda(coords.float().contiguous(), grad_output.contiguous(),
+                                                               ctx.feature_dim)
+
+
+def grid_interpolate(coords, feats):
+    """feats [N,8,F] blended with the trilinear weights of the local coordinates [N,3] -> [N,F]."""
+    return GridInterpolate.apply(coords.contiguous(), feats.contiguous())
+
+
 class SPCTrilinear(torch.autograd.Function):
     """Differentiable (w.r.t. the features) dual-octree trilinear interpolation - the Kaolin-Core leaf
     unbatched_interpolate_trilinear that OctreeGrid._interpolate calls (wisp/models/grids/octree_grid.py:147-149)."""

@@ -324,7 +324,8 @@ def test_reference_named_native_surface_exists():
     """wisp._C.ops.* / wisp._C.render.* under the names and arities the reference binds (wisp/csrc/bindings.cpp:21-35)."""
     import inspect
     import wisp._C as C
-    want = {"ops": {"hashgrid_interpolate_cuda": 5, "hashgrid_interpolate_backward_cuda": 8, "uniform_sample_cuda": 4},
+    want = {"ops": {"hashgrid_interpolate_cuda": 5, "hashgrid_interpolate_backward_cuda": 8, "uniform_sample_cuda": 4,
+                    "grid_interpolate_cuda": 2, "grid_interpolate_backward_cuda": 3},
             "render": {"find_depth_bound_cuda": 3}}
     for ns, fns in want.items():
         for name, arity in fns.items():

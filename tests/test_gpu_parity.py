@@ -1482,3 +1482,31 @@ def test_sdf_tracer_fused_iteration_equals_modular_marching(monkeypatch):
     assert float((a.xyz[both] - b.xyz[both]).abs().max()) <= 6e-4
     # and the surface found is the sphere the field was fitted to
     assert float((b.xyz[both].norm(dim=-1) - 0.55).abs().mean()) < 0.02
+
+
+@pytest.mark.parametrize("dtype", [torch.float, torch.half])
+def test_grid_interpolate_follows_the_references_own_unit_test(dtype):
+    """The check of the reference's tests/core/test_grid_interpolation.py:16-59 (its one valid kernel unit test), restated:
+    wisp.ops.grid.grid_interpolate against the analytic trilinear blend in torch - loss, features and gradient."""
+    from wisp.ops.grid import grid_interpolate
+    torch.manual_seed(0)
+    N = 100000
+    x_ = torch.rand([N, 3], device=DEV, dtype=torch.float)
+    _x = 1.0 - x_
+    fs = (10 * torch.rand([N, 8, 2], device=DEV, dtype=dtype)).requires_grad_(True)
+    coeffs = torch.cat([_x[..., 0:1] * _x[..., 1:2] * _x[..., 2:3], _x[..., 0:1] * _x[..., 1:2] * x_[..., 2:3],
+                        _x[..., 0:1] * x_[..., 1:2] * _x[..., 2:3], _x[..., 0:1] * x_[..., 1:2] * x_[..., 2:3],
+                        x_[..., 0:1] * _x[..., 1:2] * _x[..., 2:3], x_[..., 0:1] * _x[..., 1:2] * x_[..., 2:3],
+                        x_[..., 0:1] * x_[..., 1:2] * _x[..., 2:3], x_[..., 0:1] * x_[..., 1:2] * x_[..., 2:3]], dim=-1)[..., None].detach()
+    feat0 = (coeffs * fs.float()).sum(-2).to(dtype)
+    loss0 = feat0.sum()
+    loss0.backward()
+    grad0 = fs.grad.clone()
+    fs.grad.zero_()
+    feat1 = grid_interpolate(x_, fs)
+    loss1 = feat1.sum()
+    loss1.backward()
+    grad1 = fs.grad.clone()
+    atol, rtol = (1e-2, 1e-2) if dtype == torch.half else (1e-6, 1e-4)
+    assert feat1.dtype == dtype and torch.allclose(loss0, loss1, atol=atol, rtol=rtol)
+    assert torch.allclose(feat0, feat1, atol=atol, rtol=rtol) and torch.allclose(grad0, grad1, atol=atol, rtol=rtol)
