@@ -343,9 +343,10 @@ int wisp_generate_rays(const float* pixel_x, const float* pixel_y, int64_t num_p
  * features -> cat positional-encoded view dir (wisp/models/embedders/positional_embedder.py:51-66)
  * -> decoder_color (Linear-ReLU x2, Linear) -> sigmoid)
  *
- *  feats   dtype_io [S, in_dim], rows packed (stride in_dim).  This build: 1 <= in_dim <= 32, hidden = 64,
- *          view_freqs = 4 - the decoders of every app/nerf config (in_dim 32 nerf_hash, 5 nerf_octree /
- *          nerf_codebook, 12 nerf_triplanar); other shapes return WISP_ERR_UNSUPPORTED
+ *  feats   dtype_io [S, in_dim], rows packed (stride in_dim).  This build: 1 <= in_dim <= 32, view_freqs = 4 and
+ *          hidden = 64 (the YAML decoders of every app/nerf config: in_dim 32 nerf_hash, 5 nerf_octree / nerf_codebook,
+ *          12 nerf_triplanar; fp32 or bf16 compute) or hidden = 128 (the reference's best nerf_hash row and the documented
+ *          VQAD command line, docs/pages/app_nerf.md:175-192; bf16 compute only); other shapes return WISP_ERR_UNSUPPORTED
  *  dirs    f32 [S,3]
  *  params  f32 packed, layout given by wisp_nerf_mlp_param_count(): W1[hid,in], b1[hid], W2[16,hid],
  *          b2[16], W3[hid, 15+pe], b3[hid], W4[hid,hid], b4[hid], W5[3,hid], b5[3]   (row-major
@@ -353,8 +354,11 @@ int wisp_generate_rays(const float* pixel_x, const float* pixel_y, int64_t num_p
  *  compute_dtype: WISP_F32 (exact fp32 MFMA) or WISP_BF16 (bf16 MFMA, fp32 accumulate)
  */
 int64_t wisp_nerf_mlp_param_count(int in_dim, int hidden, int view_freqs);
-/* floats of device scratch wisp_nerf_mlp_bwd needs (per-wave partial weight gradients). */
+/* floats of device scratch the hidden-64 backward needs (per-wave partial weight gradients). */
 int64_t wisp_nerf_mlp_workspace_floats(void);
+/* bytes of device scratch wisp_nerf_mlp_bwd needs for `num_samples` samples: the above for hidden 64; for hidden 128 the
+ * partial gradient rows plus the (dY, X) operand dump of one chunk of <= 2^20 samples (1.76 KB per sample). */
+int64_t wisp_nerf_mlp_bwd_workspace_bytes(int64_t num_samples, int hidden);
 int wisp_nerf_mlp_fwd(const void* feats, int dtype_io, const float* dirs, int64_t num_samples,
                       int in_dim, int hidden, int view_freqs, const float* params, int compute_dtype,
                       float* rgb /* [S,3] */, float* density /* [S] */, wisp_stream_t stream);
@@ -362,7 +366,8 @@ int wisp_nerf_mlp_bwd(const void* feats, int dtype_io, const float* dirs, int64_
                       int in_dim, int hidden, int view_freqs, const float* params, int compute_dtype,
                       const float* grad_rgb /* [S,3] */, const float* grad_density /* [S] */,
                       void* grad_feats /* dtype_io [S,in_dim] */, float* grad_params /* accumulated */,
-                      float* workspace /* wisp_nerf_mlp_workspace_floats() floats */, wisp_stream_t stream);
+                      float* workspace, int64_t workspace_bytes /* >= wisp_nerf_mlp_bwd_workspace_bytes() */,
+                      wisp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer  (replaces torch.optim.AdamW / apex FusedAdam over the flat parameter buffer,

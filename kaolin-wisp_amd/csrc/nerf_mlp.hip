@@ -478,9 +478,17 @@ extern "C" int64_t wisp_nerf_mlp_param_count(int in_dim, int hidden, int view_fr
 
 extern "C" int64_t wisp_nerf_mlp_workspace_floats(void) { return (int64_t)cu_count() * 4 * NPARAM_PAD; }
 
+extern "C" int64_t wisp_nerf_mlp_bwd_workspace_bytes(int64_t num_samples, int hidden) {
+    if (hidden == H) return wisp_nerf_mlp_workspace_floats() * 4;
+    if (wisp_mlp::wide_supported(hidden) && num_samples >= 0) return wisp_mlp::wide_workspace_bytes(num_samples, hidden);
+    return 0;
+}
+
 static int check_shape(int in_dim, int hidden, int view_freqs, int dtype_io, int compute) {
-    if (in_dim < 1 || in_dim > IN || hidden != H || view_freqs != NF)
-        return wisp_fail(WISP_ERR_UNSUPPORTED, "nerf_mlp", "this build supports 1 <= in_dim <= 32, hidden=64, view_freqs=4");
+    if (in_dim < 1 || in_dim > IN || view_freqs != NF || !(hidden == H || wisp_mlp::wide_supported(hidden)))
+        return wisp_fail(WISP_ERR_UNSUPPORTED, "nerf_mlp", "this build supports 1 <= in_dim <= 32, hidden 64 or 128, view_freqs=4");
+    if (hidden != H && compute != WISP_BF16)
+        return wisp_fail(WISP_ERR_UNSUPPORTED, "nerf_mlp", "hidden 128 is built for bf16 compute only (the exact fp32 path is hidden 64)");
     if (dtype_io != WISP_F32 && dtype_io != WISP_F16 && dtype_io != WISP_BF16) return wisp_fail(WISP_ERR_INVALID, "nerf_mlp", "bad dtype_io");
     if (compute != WISP_F32 && compute != WISP_BF16) return wisp_fail(WISP_ERR_INVALID, "nerf_mlp", "compute must be f32 or bf16");
     return 0;
@@ -493,6 +501,13 @@ extern "C" int wisp_nerf_mlp_fwd(const void* feats, int dtype_io, const float* d
     if (int rc = check_shape(in_dim, hidden, view_freqs, dtype_io, compute_dtype)) return rc;
     if (num_samples == 0) return WISP_OK;
     WISP_REQUIRE(feats && dirs && params && rgb && density, "null pointer");
+    if (hidden != H) {
+        if (int rc = wisp_mlp::wide_forward_dispatch(feats, dtype_io, dirs, num_samples, in_dim, hidden, params, rgb, density,
+                                                     (hipStream_t)stream))
+            return rc;
+        WISP_CHECK_LAUNCH();
+        return WISP_OK;
+    }
     if (int rc = dispatch<false>(feats, dtype_io, dirs, num_samples, in_dim, params, compute_dtype, rgb, density, nullptr, nullptr,
                                  nullptr, nullptr, nullptr, (hipStream_t)stream))
         return rc;
@@ -503,11 +518,19 @@ extern "C" int wisp_nerf_mlp_fwd(const void* feats, int dtype_io, const float* d
 extern "C" int wisp_nerf_mlp_bwd(const void* feats, int dtype_io, const float* dirs, int64_t num_samples, int in_dim,
                                  int hidden, int view_freqs, const float* params, int compute_dtype, const float* grad_rgb,
                                  const float* grad_density, void* grad_feats, float* grad_params, float* workspace,
-                                 wisp_stream_t stream) {
+                                 int64_t workspace_bytes, wisp_stream_t stream) {
     WISP_REQUIRE(num_samples >= 0, "negative count");
     if (int rc = check_shape(in_dim, hidden, view_freqs, dtype_io, compute_dtype)) return rc;
     if (num_samples == 0) return WISP_OK;
     WISP_REQUIRE(feats && dirs && params && grad_rgb && grad_density && grad_feats && grad_params && workspace, "null pointer");
+    WISP_REQUIRE(workspace_bytes >= wisp_nerf_mlp_bwd_workspace_bytes(num_samples, hidden), "workspace too small (wisp_nerf_mlp_bwd_workspace_bytes)");
+    if (hidden != H) {
+        if (int rc = wisp_mlp::wide_backward_dispatch(feats, dtype_io, dirs, num_samples, in_dim, hidden, params, grad_rgb, grad_density,
+                                                      grad_feats, grad_params, workspace, (hipStream_t)stream))
+            return rc;
+        WISP_CHECK_LAUNCH();
+        return WISP_OK;
+    }
     if (int rc = dispatch<true>(feats, dtype_io, dirs, num_samples, in_dim, params, compute_dtype, nullptr, nullptr, grad_rgb,
                                 grad_density, grad_feats, grad_params, workspace, (hipStream_t)stream))
         return rc;

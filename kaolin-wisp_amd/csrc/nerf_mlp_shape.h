@@ -41,4 +41,13 @@ int bf16_backward(const void* feats, int dtype_io, const float* dirs, int64_t nu
                   const float* grad_rgb, const float* grad_density, void* grad_feats, float* partials, int* partial_rows,
                   hipStream_t st);
 
+// wide decoders (hidden 128; nerf_mlp_wide.hip): bf16 compute only.  `workspace` = wide_workspace_bytes(num_samples, hidden).
+bool wide_supported(int hidden);
+int64_t wide_workspace_bytes(int64_t num_samples, int hidden);
+int wide_forward_dispatch(const void* feats, int dtype_io, const float* dirs, int64_t num_samples, int in_dim, int hidden,
+                          const float* params, float* rgb, float* density, hipStream_t st);
+int wide_backward_dispatch(const void* feats, int dtype_io, const float* dirs, int64_t num_samples, int in_dim, int hidden,
+                           const float* params, const float* grad_rgb, const float* grad_density, void* grad_feats,
+                           float* grad_params, void* workspace, hipStream_t st);
+
 }  // namespace wisp_mlp

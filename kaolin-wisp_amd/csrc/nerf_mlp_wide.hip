@@ -1,0 +1,619 @@
+// Fused radiance-field decoder for WIDE hidden layers (hidden = 128; written for any multiple of 64 whose weight images
+// fit LDS) on the matrix cores.
+//
+// The reference's best configuration, the documented VQAD command line and NeuralSDF all use hidden_dim = 128
+// (docs/pages/app_nerf.md:185-192, wisp/models/nefs/nerf.py:151-173); nerf_mlp_bf16.hip is hand-scheduled for 64.  This
+// file keeps that kernel's central idea - activations stay in registers between layers: sample n = lane & 31 sits on the
+// N side of v_mfma_f32_32x32x16_bf16, the accumulator registers of a 32-row block ARE two K blocks of the next layer after
+// one v_cvt_pk_bf16_f32 per pair, the weight columns in LDS are stored pre-permuted to match - written as loops over
+// NB = hidden / 32 row blocks and NK = hidden / 16 K blocks.  What does NOT carry over is the weight-gradient scheme: at
+// hidden 128 the dW blocks (120 of 16x16) no longer fit the registers of one accumulator wave next to 125 KB of weight
+// images, so the backward is split in two kernels:
+//   * chain kernel: forward recompute, back-propagation through the transposed (also permuted) weights, grad_feats; every
+//     (dY, X) operand pair of the five weight gradients is dumped to a scratch buffer exactly as it sits in the registers
+//     (one coalesced 1 KB store per K block and wave);
+//   * dW kernel: four waves load four tiles' operands back, write them into LDS transposition images
+//     (ds_read_b64_tr_b16 turns "lane = sample" into "K = sample"), and accumulate dW += dY^T X with
+//     v_mfma_f32_16x16x32_bf16 - each wave owns a quarter of the 16x16 blocks for the whole launch (120 VGPRs) and adds
+//     them to the workgroup's partial row at the end; a small kernel sums the rows.
+// The scratch costs 2 x 1.7 KB of traffic per sample (it is the price of not re-deriving the operands); at 2 M samples
+// that is the larger part of the backward's time, see DESIGN.md.
+#include "nerf_mlp_bf16_dev.h"
+#include <cstdlib>
+
+namespace {
+using namespace wisp_mlp_dev;
+
+template <int HH> struct Wide {
+    static_assert(HH % 64 == 0 && HH >= 64, "hidden width: a multiple of 64");
+    static constexpr int NB = HH / 32, NK = HH / 16;
+    // canonical parameter order  W1[H,IN] b1[H] W2[16,H] b2[16] W3[H,X2] b3[H] W4[H,H] b4[H] W5[3,H] b5[3]
+    static constexpr int OW1 = 0, OB1 = OW1 + HH * IN, OW2 = OB1 + HH, OB2 = OW2 + 16 * HH, OW3 = OB2 + 16, OB3 = OW3 + HH * X2,
+                         OW4 = OB3 + HH, OB4 = OW4 + HH * HH, OW5 = OB4 + HH, OB5 = OW5 + 3 * HH, NPARAM = OB5 + 3;
+    static constexpr int NPARAM_PAD = (NPARAM + 63) / 64 * 64;
+    // forward operand images [out row][K slots], row stride = K + 8 elements (conflict-free ds_read_b128)
+    static constexpr int LD1 = IN + 8, LD2 = HH + 8, LD3 = 48 + 8, LD4 = HH + 8, LD5 = HH + 8;
+    static constexpr int L_W1 = 0, L_W2 = L_W1 + HH * LD1, L_W3 = L_W2 + 16 * LD2, L_W4 = L_W3 + HH * LD3, L_W5 = L_W4 + HH * LD4,
+                         L_FWD_END = L_W5 + 4 * LD5;
+    // backward operand images [in row][out-neuron slots]
+    static constexpr int LT5 = 24, LT4 = HH + 8, LT3 = HH + 8, LT2 = 24, LT1 = HH + 8;
+    static constexpr int L_W5T = L_FWD_END, L_W4T = L_W5T + HH * LT5, L_W3T = L_W4T + HH * LT4, L_W2T = L_W3T + 16 * LT3,
+                         L_W1T = L_W2T + HH * LT2, L_BWD_END = L_W1T + IN * LT1;
+    static constexpr int BIASV_FLOATS = 2 * NB * 2 * 16;          // [layer 1 | layer 4][t][g][16] in accumulator layout
+    // scratch slots of one tile (1 KB each: 64 lanes x 16 B), in the order the dW kernel consumes them
+    static constexpr int S5Y = 0, S5X = S5Y + 1, S4Y = S5X + NK, S4X = S4Y + NK, S3Y = S4X + NK, S3X = S3Y + NK, S2Y = S3X + 3,
+                         S2X = S2Y + 1, S1Y = S2X + NK, S1X = S1Y + NK, NSLOT = S1X + 2;
+    static constexpr int IMG_BYTES = (HH / 8) * TILE_REGION;      // transposition image of HH features x 32 samples
+    // forward + transposed weight images must fit the 160 KB of LDS next to the bias vectors: true for 64 and 128
+    static_assert((L_BWD_END * 2 + BIASV_FLOATS * 4) <= 160 * 1024, "weight images exceed the LDS of one CU");
+};
+
+__host__ __device__ inline int wide_packed_index(int canonical, int in_dim, int hh) {
+    if (canonical < hh * IN) {
+        const int r = canonical / IN, c = canonical % IN;
+        return c < in_dim ? r * in_dim + c : -1;
+    }
+    return canonical - hh * (IN - in_dim);
+}
+DEV float wide_param(const float* __restrict__ P, int canonical, int in_dim, int hh) {
+    const int i = wide_packed_index(canonical, in_dim, hh);
+    return i < 0 ? 0.0f : P[i];
+}
+
+// weights straight from global memory into the permuted bf16 operand images (once per workgroup; the parameter vector is
+// L2 resident).  P is the caller's packed buffer (W1 rows in_dim wide).
+template <int HH, bool BWD>
+DEV void stage_weights_wide(__bf16* sw, float* biasv, const float* __restrict__ P, int in_dim, int tid, int nthreads) {
+    typedef Wide<HH> W;
+#define PV(idx) wide_param(P, (idx), in_dim, HH)
+    for (int e = tid; e < HH * IN; e += nthreads) { const int r = e / IN, c = e % IN; sw[W::L_W1 + r * W::LD1 + c] = (__bf16)PV(W::OW1 + r * IN + c); }
+    for (int e = tid; e < 16 * HH; e += nthreads) { const int r = e / HH, s = e % HH; sw[W::L_W2 + r * W::LD2 + s] = (__bf16)PV(W::OW2 + r * HH + phi(s)); }
+    for (int e = tid; e < HH * 48; e += nthreads) {
+        const int r = e / 48, s = e % 48;
+        float v = 0.0f;
+        if (s < 16) { const int m = phi16(s); if (m) v = PV(W::OW3 + r * X2 + m - 1); }
+        else if (s < ONES_SLOT) v = PV(W::OW3 + r * X2 + s - 1);
+        else if (s == ONES_SLOT) v = PV(W::OB3 + r);
+        sw[W::L_W3 + r * W::LD3 + s] = (__bf16)v;
+    }
+    for (int e = tid; e < HH * HH; e += nthreads) { const int r = e / HH, s = e % HH; sw[W::L_W4 + r * W::LD4 + s] = (__bf16)PV(W::OW4 + r * HH + phi(s)); }
+    for (int e = tid; e < 4 * HH; e += nthreads) { const int r = e / HH, s = e % HH; sw[W::L_W5 + r * W::LD5 + s] = (__bf16)(r < 3 ? PV(W::OW5 + r * HH + phi(s)) : 0.0f); }
+    for (int e = tid; e < W::BIASV_FLOATS; e += nthreads) {
+        const int r = e & 15, g = (e >> 4) & 1, t = (e >> 5) % W::NB, layer = e / (32 * W::NB);
+        biasv[e] = PV((layer ? W::OB4 : W::OB1) + 32 * t + acc_row(r, g));
+    }
+    if (BWD) {
+        for (int e = tid; e < HH * 16; e += nthreads) { const int k = e >> 4, p = e & 15; sw[W::L_W5T + k * W::LT5 + p] = (__bf16)(p < 3 ? PV(W::OW5 + p * HH + k) : 0.0f); }
+        for (int e = tid; e < HH * HH; e += nthreads) { const int k = e / HH, s = e % HH; sw[W::L_W4T + k * W::LT4 + s] = (__bf16)PV(W::OW4 + phi(s) * HH + k); }
+        for (int e = tid; e < 16 * HH; e += nthreads) { const int m = e / HH, s = e % HH; sw[W::L_W3T + m * W::LT3 + s] = (__bf16)(m ? PV(W::OW3 + phi(s) * X2 + m - 1) : 0.0f); }
+        for (int e = tid; e < HH * 16; e += nthreads) { const int k = e >> 4, p = e & 15; sw[W::L_W2T + k * W::LT2 + p] = (__bf16)PV(W::OW2 + phi16(p) * HH + k); }
+        for (int e = tid; e < IN * HH; e += nthreads) { const int k = e / HH, s = e % HH; sw[W::L_W1T + k * W::LT1 + s] = (__bf16)PV(W::OW1 + phi(s) * IN + k); }
+    }
+#undef PV
+}
+
+// The weight images never change after staging, so the optimiser would hoist every ds_read of an A operand out of the tile
+// loop and try to keep 125 KB of weights in registers (measured: 496-512 VGPRs and spills).  A compiler-level memory
+// barrier per layer keeps the reads where they are used.
+DEV void keep_lds_reads_here() { asm volatile("" ::: "memory"); }
+
+template <int HH> struct ActsW {
+    bf16x8 x0[2], h1[Wide<HH>::NK], x2[3], h2[Wide<HH>::NK], h3[Wide<HH>::NK];
+    float y0, sg[3];
+};
+
+template <int HH> struct LaneW {
+    int n, g;
+    const __bf16 *w1, *w2, *w3, *w4, *w5;
+    const float* bias_lds;           // + 16 g
+    float b2[8], b5[3];
+};
+
+template <int HH>
+DEV void lane_const_wide(LaneW<HH>& L, const __bf16* sw, const float* biasv, const float* __restrict__ P, int in_dim, int lane) {
+    typedef Wide<HH> W;
+    L.n = lane & 31; L.g = lane >> 5;
+    L.w1 = sw + W::L_W1 + L.n * W::LD1 + 8 * L.g;
+    L.w2 = sw + W::L_W2 + (L.n & 15) * W::LD2 + 8 * L.g;
+    L.w3 = sw + W::L_W3 + L.n * W::LD3 + 8 * L.g;
+    L.w4 = sw + W::L_W4 + L.n * W::LD4 + 8 * L.g;
+    L.w5 = sw + W::L_W5 + (L.n < 3 ? L.n : 3) * W::LD5 + 8 * L.g;
+    L.bias_lds = biasv + 16 * L.g;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) L.b2[r] = wide_param(P, W::OB2 + acc_row(r, L.g), in_dim, HH);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) L.b5[c] = wide_param(P, W::OB5 + c, in_dim, HH);
+}
+
+template <int HH>
+DEV void forward_tile_wide(const LaneW<HH>& L, const float d[3], ActsW<HH>& A) {
+    typedef Wide<HH> W;
+    // L1: h1 = relu(W1 x0 + b1)
+    keep_lds_reads_here();
+#pragma unroll
+    for (int t = 0; t < W::NB; ++t) {
+        floatx16 acc = *reinterpret_cast<const floatx16*>(L.bias_lds + t * 32);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) acc = mma32(lds_a(L.w1, t * 32 * W::LD1 + 16 * kb), A.x0[kb], acc);
+        A.h1[2 * t] = pack8<0, true>(acc);
+        A.h1[2 * t + 1] = pack8<8, true>(acc);
+    }
+    // L2: y = W2 h1 + b2 (16 rows = accumulator registers 0..7); density = relu(y0)
+    keep_lds_reads_here();
+    {
+        floatx16 acc = zero16();
+#pragma unroll
+        for (int kb = 0; kb < W::NK; ++kb) acc = mma32(lds_a(L.w2, 16 * kb), A.h1[kb], acc);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] += L.b2[r];
+        A.y0 = acc[0];
+        if (L.g == 0) acc[0] = 0.0f;
+        A.x2[0] = pack8<0, false>(acc);
+    }
+    encode_dir(d, L.g, A.x2[1], A.x2[2]);
+    // L3: h2 = relu(W3 x2 + b3)   (b3 rides on the ones slot)
+    keep_lds_reads_here();
+#pragma unroll
+    for (int t = 0; t < W::NB; ++t) {
+        floatx16 acc = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) acc = mma32(lds_a(L.w3, t * 32 * W::LD3 + 16 * kb), A.x2[kb], acc);
+        A.h2[2 * t] = pack8<0, true>(acc);
+        A.h2[2 * t + 1] = pack8<8, true>(acc);
+    }
+    // L4: h3 = relu(W4 h2 + b4)
+#pragma unroll
+    for (int t = 0; t < W::NB; ++t) {
+        keep_lds_reads_here();
+        floatx16 acc = *reinterpret_cast<const floatx16*>(L.bias_lds + 32 * W::NB + t * 32);
+#pragma unroll
+        for (int kb = 0; kb < W::NK; ++kb) acc = mma32(lds_a(L.w4, t * 32 * W::LD4 + 16 * kb), A.h2[kb], acc);
+        A.h3[2 * t] = pack8<0, true>(acc);
+        A.h3[2 * t + 1] = pack8<8, true>(acc);
+    }
+    keep_lds_reads_here();
+    // L5: rgb = sigmoid(W5 h3 + b5)
+    {
+        floatx16 acc = zero16();
+#pragma unroll
+        for (int kb = 0; kb < W::NK; ++kb) acc = mma32(lds_a(L.w5, 16 * kb), A.h3[kb], acc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) A.sg[c] = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[c] + L.b5[c])));
+    }
+}
+
+template <typename TIO>
+DEV void fetch_inputs_wide(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t s, bool live, int g, int in_dim,
+                           bf16x8 x0[2], float d[3]) {
+    if (in_dim != IN) {
+        x0[0] = load_feats8_narrow<TIO>(feats + s * in_dim, 8 * g, in_dim, live);
+        x0[1] = load_feats8_narrow<TIO>(feats + s * in_dim, 16 + 8 * g, in_dim, live);
+    } else {
+        x0[0] = load_feats8<TIO>(feats + s * IN + 8 * g, live);
+        x0[1] = load_feats8<TIO>(feats + s * IN + 16 + 8 * g, live);
+    }
+    d[0] = live ? dirs[s * 3] : 0.0f; d[1] = live ? dirs[s * 3 + 1] : 0.0f; d[2] = live ? dirs[s * 3 + 2] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------- forward kernel
+constexpr int WF_WAVES = 8;
+
+template <int HH, typename TIO>
+__global__ void __launch_bounds__(WF_WAVES * 64)
+wide_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples, int in_dim,
+                const float* __restrict__ params, float* __restrict__ out_rgb, float* __restrict__ out_density) {
+    typedef Wide<HH> W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* sw = reinterpret_cast<__bf16*>(smem);
+    float* biasv = reinterpret_cast<float*>(smem + (size_t)W::L_FWD_END * 2);
+    stage_weights_wide<HH, false>(sw, biasv, params, in_dim, threadIdx.x, WF_WAVES * 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LaneW<HH> L;
+    lane_const_wide<HH>(L, sw, biasv, params, in_dim, lane);
+    __syncthreads();
+    const int64_t ntiles = (num_samples + TS - 1) / TS;
+    const int64_t stride = (int64_t)gridDim.x * WF_WAVES;
+    ActsW<HH> A;
+    float d[3];
+    for (int64_t tile = (int64_t)blockIdx.x * WF_WAVES + wave; tile < ntiles; tile += stride) {
+        const int64_t s = tile * TS + L.n;
+        const bool live = s < num_samples;
+        fetch_inputs_wide<TIO>(feats, dirs, s, live, L.g, in_dim, A.x0, d);
+        forward_tile_wide<HH>(L, d, A);
+        if (L.g == 0 && live) {
+            out_density[s] = fmaxf(A.y0, 0.0f);
+            out_rgb[s * 3] = A.sg[0]; out_rgb[s * 3 + 1] = A.sg[1]; out_rgb[s * 3 + 2] = A.sg[2];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward: chain kernel
+constexpr int WC_WAVES = 4;
+
+template <int NKB> DEV floatx16 back_block_w(const __bf16* wt_lane_row, const bf16x8* dy) {
+    keep_lds_reads_here();
+    floatx16 acc = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) acc = mma32(lds_a(wt_lane_row, 16 * kb), dy[kb], acc);
+    return acc;
+}
+
+template <int HH, typename TIO>
+__global__ void __launch_bounds__(WC_WAVES * 64)
+wide_chain_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples, int in_dim,
+                  const float* __restrict__ params, const float* __restrict__ grad_rgb, const float* __restrict__ grad_density,
+                  TIO* __restrict__ grad_feats, bf16x8* __restrict__ scratch) {
+    typedef Wide<HH> W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* sw = reinterpret_cast<__bf16*>(smem);
+    float* biasv = reinterpret_cast<float*>(smem + (size_t)W::L_BWD_END * 2);
+    stage_weights_wide<HH, true>(sw, biasv, params, in_dim, threadIdx.x, WC_WAVES * 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LaneW<HH> L;
+    lane_const_wide<HH>(L, sw, biasv, params, in_dim, lane);
+    __syncthreads();
+    const int n = L.n, g = L.g;
+    const __bf16* w5t = sw + W::L_W5T + n * W::LT5 + 8 * g;
+    const __bf16* w4t = sw + W::L_W4T + n * W::LT4 + 8 * g;
+    const __bf16* w3t = sw + W::L_W3T + (n & 15) * W::LT3 + 8 * g;
+    const __bf16* w2t = sw + W::L_W2T + n * W::LT2 + 8 * g;
+    const __bf16* w1t = sw + W::L_W1T + n * W::LT1 + 8 * g;
+    const int64_t ntiles = (num_samples + TS - 1) / TS;
+    const int64_t stride = (int64_t)gridDim.x * WC_WAVES;
+    ActsW<HH> A;
+    float d[3];
+    for (int64_t tile = (int64_t)blockIdx.x * WC_WAVES + wave; tile < ntiles; tile += stride) {
+        const int64_t s = tile * TS + n;
+        const bool live = s < num_samples;
+        float gr[3] = {0.f, 0.f, 0.f}, gd = 0.0f;
+        if (live && g == 0) { gr[0] = grad_rgb[s * 3]; gr[1] = grad_rgb[s * 3 + 1]; gr[2] = grad_rgb[s * 3 + 2]; gd = grad_density[s]; }
+        fetch_inputs_wide<TIO>(feats, dirs, s, live, g, in_dim, A.x0, d);
+        forward_tile_wide<HH>(L, d, A);
+        bf16x8* out = scratch + tile * (int64_t)(W::NSLOT * 64) + lane;        // slot k of this tile: out[k * 64]
+        // ---- stage 5: dY5 = g_rgb * s (1 - s)  (natural slots 0..2 of the g = 0 lanes) ; X = h3
+        float g5[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g5[c] = g == 0 ? gr[c] * A.sg[c] * (1.0f - A.sg[c]) : 0.0f;
+        const bf16x8 dy5 = pack8f(g5);
+        out[W::S5Y * 64] = dy5;
+#pragma unroll
+        for (int kb = 0; kb < W::NK; ++kb) out[(W::S5X + kb) * 64] = A.h3[kb];
+        bf16x8 dh3[W::NK];
+#pragma unroll
+        for (int t = 0; t < W::NB; ++t) {                       // dH3 = (W5^T dY5) * (h3 > 0)
+            const floatx16 acc = back_block_w<1>(w5t + t * 32 * W::LT5, &dy5);
+            dh3[2 * t] = pack8_masked<0>(acc, A.h3[2 * t]);
+            dh3[2 * t + 1] = pack8_masked<8>(acc, A.h3[2 * t + 1]);
+        }
+        // ---- stage 4: dY = dH3, X = h2
+#pragma unroll
+        for (int kb = 0; kb < W::NK; ++kb) { out[(W::S4Y + kb) * 64] = dh3[kb]; out[(W::S4X + kb) * 64] = A.h2[kb]; }
+        bf16x8 dh2[W::NK];
+#pragma unroll
+        for (int t = 0; t < W::NB; ++t) {                       // dH2 = (W4^T dH3) * (h2 > 0)
+            const floatx16 acc = back_block_w<W::NK>(w4t + t * 32 * W::LT4, dh3);
+            dh2[2 * t] = pack8_masked<0>(acc, A.h2[2 * t]);
+            dh2[2 * t + 1] = pack8_masked<8>(acc, A.h2[2 * t + 1]);
+        }
+        // ---- stage 3: dY = dH2, X = x2 (chained density-feature block + two natural view-encoding blocks)
+#pragma unroll
+        for (int kb = 0; kb < W::NK; ++kb) out[(W::S3Y + kb) * 64] = dh2[kb];
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) out[(W::S3X + kb) * 64] = A.x2[kb];
+        bf16x8 dy2;
+        {                                                       // dY2[m] = W3^T dH2 (m = 1..15), dY2[0] = g_density * (y0 > 0)
+            floatx16 acc = back_block_w<W::NK>(w3t, dh2);
+            if (g == 0) acc[0] = A.y0 > 0.0f ? gd : 0.0f;
+            dy2 = pack8<0, false>(acc);
+        }
+        // ---- stage 2: dY = dY2, X = h1
+        out[W::S2Y * 64] = dy2;
+#pragma unroll
+        for (int kb = 0; kb < W::NK; ++kb) out[(W::S2X + kb) * 64] = A.h1[kb];
+        bf16x8 dh1[W::NK];
+#pragma unroll
+        for (int t = 0; t < W::NB; ++t) {                       // dH1 = (W2^T dY2) * (h1 > 0)
+            const floatx16 acc = back_block_w<1>(w2t + t * 32 * W::LT2, &dy2);
+            dh1[2 * t] = pack8_masked<0>(acc, A.h1[2 * t]);
+            dh1[2 * t + 1] = pack8_masked<8>(acc, A.h1[2 * t + 1]);
+        }
+        // ---- stage 1: dY = dH1, X = x0
+#pragma unroll
+        for (int kb = 0; kb < W::NK; ++kb) out[(W::S1Y + kb) * 64] = dh1[kb];
+        out[(W::S1X + 0) * 64] = A.x0[0];
+        out[(W::S1X + 1) * 64] = A.x0[1];
+        {                                                       // dX0 = W1^T dH1 -> grad_feats
+            const floatx16 acc = back_block_w<W::NK>(w1t, dh1);
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (in_dim != IN)
+                        store_grad4_narrow<TIO>(grad_feats + s * in_dim, 8 * q + 4 * g, in_dim, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                    else
+                        store_grad4<TIO>(grad_feats + s * IN + 8 * q + 4 * g, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward: dW kernel
+// Workgroup = 4 waves = 4 tiles per round.  Per stage: every wave brings ITS tile's operands from the scratch into the
+// stage's LDS images (the layouts store_chained / store_natural / load_transposed define), barrier, then every wave adds the
+// products of ITS dW blocks for all four tiles, barrier.  Ownership: for stages whose dY is HH wide wave w owns the dY
+// blocks it = w, w + 4, ... (and their bias sums); for the two 16-wide dY's (dY5, dY2) it owns the X blocks kt = w, w + 4, ...
+// (their bias sums go to wave 0).
+constexpr int WD_WAVES = 4;
+
+template <int HH> struct GradW {
+    static constexpr int NK = Wide<HH>::NK, Q = NK / 4;     // blocks of an HH-wide operand owned by one wave
+    floatx4 dW5[Q], dW4[Q * NK], dW3[Q * 3], dW2[Q], dW1[Q * 2];
+    floatx4 db;          // rows: 0..Q-1 layer-4 blocks, Q..2Q-1 layer-1 blocks, 2Q layer 2, 2Q+1 layer 5 (wave 0 only)
+};
+
+template <int HH>
+__global__ void __launch_bounds__(WD_WAVES * 64)
+wide_dw_kernel(const bf16x8* __restrict__ scratch, int64_t num_tiles, int in_dim, int accumulate, float* __restrict__ partials) {
+    typedef Wide<HH> W;
+    typedef GradW<HH> G_t;
+    constexpr int NK = W::NK, Q = G_t::Q;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [4 tiles][Y image | X image]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, g = lane >> 5;
+    const int wc_off = (2 * n + g) * 8, wn_off = g * TILE_REGION + n * 16;
+    const int tr_off = ((lane >> 1) & 1) * TILE_REGION + (8 * (lane >> 4) + 2 * ((lane >> 2) & 3) + (lane & 1)) * 8;
+    unsigned char* my_img = smem + (size_t)wave * 2 * W::IMG_BYTES;
+    G_t G;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) { G.dW5[i] = zero4(); G.dW2[i] = zero4(); }
+#pragma unroll
+    for (int i = 0; i < Q * NK; ++i) G.dW4[i] = zero4();
+#pragma unroll
+    for (int i = 0; i < Q * 3; ++i) G.dW3[i] = zero4();
+#pragma unroll
+    for (int i = 0; i < Q * 2; ++i) G.dW1[i] = zero4();
+    G.db = zero4();
+    const int64_t rounds = (num_tiles + WD_WAVES - 1) / WD_WAVES;
+    for (int64_t rd = blockIdx.x; rd < rounds; rd += gridDim.x) {
+        const int64_t tile = rd * WD_WAVES + wave;
+        const bool have = tile < num_tiles;
+        const bf16x8* in = scratch + tile * (int64_t)(W::NSLOT * 64) + lane;
+        const bf16x8 zero8 = __builtin_bit_cast(bf16x8, (u32x4)(0u));
+#define LOADK(slot) (have ? in[(slot) * 64] : zero8)
+        // bias sum of the dY block held in operand `a` into row `row` of the shared block
+#define BIAS_ROW(a, row) { const unsigned one2 = (lane & 15) == (row) ? 0x3f803f80u : 0u; const u32x4 ones = {one2, one2, one2, one2}; \
+                           G.db = mma16(__builtin_bit_cast(bf16x8, ones), (a), G.db); }
+        // ---------------- stage 5: dY5 natural [1 kb] x h3 chained [NK kb] -> dW5 (this wave: X blocks kt = wave + 4 q)
+        store_natural(my_img + wn_off, 0, LOADK(W::S5Y));
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + W::IMG_BYTES + wc_off, kb, LOADK(W::S5X + kb));
+        __syncthreads();
+#pragma unroll
+        for (int tl = 0; tl < WD_WAVES; ++tl) {
+            const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
+            const bf16x8 a = load_transposed(img, 0);
+            if (wave == 0) BIAS_ROW(a, 2 * Q + 1)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) G.dW5[q] = mma16(a, load_transposed(img + W::IMG_BYTES, wave + 4 * q), G.dW5[q]);
+        }
+        __syncthreads();
+        // ---------------- stage 4: dH3 [NK] x h2 [NK] -> dW4 (this wave: dY blocks it = wave + 4 q), b4
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) { store_chained(my_img + wc_off, kb, LOADK(W::S4Y + kb)); store_chained(my_img + W::IMG_BYTES + wc_off, kb, LOADK(W::S4X + kb)); }
+        __syncthreads();
+#pragma unroll
+        for (int tl = 0; tl < WD_WAVES; ++tl) {
+            const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
+            bf16x8 xb[NK];
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) xb[kt] = load_transposed(img + W::IMG_BYTES, kt);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const bf16x8 a = load_transposed(img, wave + 4 * q);
+                BIAS_ROW(a, q)
+#pragma unroll
+                for (int kt = 0; kt < NK; ++kt) G.dW4[q * NK + kt] = mma16(a, xb[kt], G.dW4[q * NK + kt]);
+            }
+        }
+        __syncthreads();
+        // ---------------- stage 3: dH2 [NK] x x2 [chained block 0, natural blocks 1, 2] -> dW3 (+ b3 on the ones slot)
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + wc_off, kb, LOADK(W::S3Y + kb));
+        store_chained(my_img + W::IMG_BYTES + wc_off, 0, LOADK(W::S3X + 0));
+        store_natural(my_img + W::IMG_BYTES + wn_off, 1, LOADK(W::S3X + 1));
+        store_natural(my_img + W::IMG_BYTES + wn_off, 2, LOADK(W::S3X + 2));
+        __syncthreads();
+#pragma unroll
+        for (int tl = 0; tl < WD_WAVES; ++tl) {
+            const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
+            bf16x8 xb[3];
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) xb[kt] = load_transposed(img + W::IMG_BYTES, kt);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const bf16x8 a = load_transposed(img, wave + 4 * q);
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) G.dW3[q * 3 + kt] = mma16(a, xb[kt], G.dW3[q * 3 + kt]);
+            }
+        }
+        __syncthreads();
+        // ---------------- stage 2: dY2 chained [1] x h1 [NK] -> dW2 (X blocks kt = wave + 4 q), b2 (wave 0)
+        store_chained(my_img + wc_off, 0, LOADK(W::S2Y));
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + W::IMG_BYTES + wc_off, kb, LOADK(W::S2X + kb));
+        __syncthreads();
+#pragma unroll
+        for (int tl = 0; tl < WD_WAVES; ++tl) {
+            const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
+            const bf16x8 a = load_transposed(img, 0);
+            if (wave == 0) BIAS_ROW(a, 2 * Q)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) G.dW2[q] = mma16(a, load_transposed(img + W::IMG_BYTES, wave + 4 * q), G.dW2[q]);
+        }
+        __syncthreads();
+        // ---------------- stage 1: dH1 [NK] x x0 natural [2] -> dW1, b1
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + wc_off, kb, LOADK(W::S1Y + kb));
+        store_natural(my_img + W::IMG_BYTES + wn_off, 0, LOADK(W::S1X + 0));
+        store_natural(my_img + W::IMG_BYTES + wn_off, 1, LOADK(W::S1X + 1));
+        __syncthreads();
+#pragma unroll
+        for (int tl = 0; tl < WD_WAVES; ++tl) {
+            const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
+            const bf16x8 x0a = load_transposed(img + W::IMG_BYTES, 0), x0b = load_transposed(img + W::IMG_BYTES, 1);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const bf16x8 a = load_transposed(img, wave + 4 * q);
+                BIAS_ROW(a, Q + q)
+                G.dW1[q * 2] = mma16(a, x0a, G.dW1[q * 2]);
+                G.dW1[q * 2 + 1] = mma16(a, x0b, G.dW1[q * 2 + 1]);
+            }
+        }
+        __syncthreads();
+#undef LOADK
+#undef BIAS_ROW
+    }
+    // ---- the workgroup's partial row (canonical parameter order): every element has exactly one owner
+    float* out = partials + (int64_t)blockIdx.x * W::NPARAM_PAD;
+    const int col = lane & 15, rg = lane >> 4;
+    auto put = [&](int idx, float v) { if (accumulate) out[idx] += v; else out[idx] = v; };
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = 4 * rg + rr;                                     // row inside a 16-row block
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int kt = wave + 4 * q;                                 // stages 5 / 2: owned X block
+            if (row < 3) put(W::OW5 + row * HH + 16 * kt + col, G.dW5[q][rr]);
+            put(W::OW2 + row * HH + 16 * kt + col, G.dW2[q][rr]);
+            const int R = 16 * (wave + 4 * q) + row;                     // stages 4 / 3 / 1: owned dY block -> output neuron R
+#pragma unroll
+            for (int k2 = 0; k2 < NK; ++k2) put(W::OW4 + R * HH + 16 * k2 + col, G.dW4[q * NK + k2][rr]);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) put(W::OW1 + R * IN + 16 * k2 + col, G.dW1[q * 2 + k2][rr]);
+#pragma unroll
+            for (int k2 = 0; k2 < 3; ++k2) {
+                const int u = 16 * k2 + col;                             // feature inside the 48-wide colour input
+                if (k2 == 0) { if (u >= 1) put(W::OW3 + R * X2 + u - 1, G.dW3[q * 3 + k2][rr]); }
+                else if (u < ONES_SLOT) put(W::OW3 + R * X2 + u - 1, G.dW3[q * 3 + k2][rr]);
+                else if (u == ONES_SLOT) put(W::OB3 + R, G.dW3[q * 3 + k2][rr]);
+            }
+        }
+        // shared bias block: row = combo, column = neuron inside its 16-block
+        if (row < Q) put(W::OB4 + 16 * (wave + 4 * row) + col, G.db[rr]);
+        else if (row < 2 * Q) put(W::OB1 + 16 * (wave + 4 * (row - Q)) + col, G.db[rr]);
+        else if (wave == 0 && row == 2 * Q) put(W::OB2 + col, G.db[rr]);
+        else if (wave == 0 && row == 2 * Q + 1 && col < 3) put(W::OB5 + col, G.db[rr]);
+    }
+}
+
+// grad_params[packed(j)] += sum over the workgroups' partial rows
+template <int HH>
+__global__ void __launch_bounds__(1024)
+wide_reduce_kernel(const float* __restrict__ partials, int rows, int in_dim, float* __restrict__ grad_params) {
+    typedef Wide<HH> W;
+    __shared__ float s[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tx;
+    float a = 0.0f;
+    if (j < W::NPARAM)
+        for (int r = ty; r < rows; r += 16) a += partials[(int64_t)r * W::NPARAM_PAD + j];
+    s[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && j < W::NPARAM) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s[k][tx];
+        const int dst = wide_packed_index(j, in_dim, HH);
+        if (dst >= 0) grad_params[dst] += t;
+    }
+}
+
+int cu_count_w() {
+    static int n = [] { int d = 0, c = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d); return c > 0 ? c : 256; }();
+    return n;
+}
+
+constexpr int64_t WIDE_CHUNK_SAMPLES = (int64_t)1 << 20;      // samples per chain + dW launch pair (scratch = 1.8 GB at hidden 128)
+
+template <int HH, typename TIO>
+int wide_forward(const void* feats, const float* dirs, int64_t S, int in_dim, const float* params, float* rgb, float* density,
+                 hipStream_t st) {
+    typedef Wide<HH> W;
+    const size_t lds = (size_t)W::L_FWD_END * 2 + (size_t)W::BIASV_FLOATS * 4;
+    auto kern = wide_fwd_kernel<HH, TIO>;
+    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_wide", hipGetErrorString(e));
+    const int64_t ntiles = (S + TS - 1) / TS;
+    const int grid = (int)min64(ceil_div64(ntiles, WF_WAVES), cu_count_w());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WF_WAVES * 64), lds, st, (const TIO*)feats, dirs, S, in_dim, params, rgb, density);
+    return 0;
+}
+
+template <int HH, typename TIO>
+int wide_backward(const void* feats, const float* dirs, int64_t S, int in_dim, const float* params, const float* grad_rgb,
+                  const float* grad_density, void* grad_feats, float* grad_params, void* workspace, hipStream_t st) {
+    typedef Wide<HH> W;
+    const size_t lds_c = (size_t)W::L_BWD_END * 2 + (size_t)W::BIASV_FLOATS * 4;
+    const size_t lds_d = (size_t)WD_WAVES * 2 * W::IMG_BYTES;
+    auto kc = wide_chain_kernel<HH, TIO>;
+    auto kd = wide_dw_kernel<HH>;
+    static const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+    static const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
+    if (e1 != hipSuccess || e2 != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_wide", "hipFuncSetAttribute");
+    const int cus = cu_count_w();
+    float* partials = (float*)workspace;                                             // [cus][NPARAM_PAD]
+    bf16x8* scratch = (bf16x8*)((char*)workspace + (size_t)cus * W::NPARAM_PAD * 4);
+    const size_t io = sizeof(TIO);
+    int first = 1;
+    for (int64_t s0 = 0; s0 < S; s0 += WIDE_CHUNK_SAMPLES) {
+        const int64_t n = S - s0 < WIDE_CHUNK_SAMPLES ? S - s0 : WIDE_CHUNK_SAMPLES;
+        const int64_t ntiles = (n + TS - 1) / TS;
+        const int grid_c = (int)min64(ceil_div64(ntiles, WC_WAVES), cus);
+        hipLaunchKernelGGL(kc, dim3(grid_c), dim3(WC_WAVES * 64), lds_c, st, (const TIO*)((const char*)feats + (size_t)s0 * in_dim * io),
+                           dirs + s0 * 3, n, in_dim, params, grad_rgb + s0 * 3, grad_density + s0,
+                           (TIO*)((char*)grad_feats + (size_t)s0 * in_dim * io), scratch);
+        // always `cus` workgroups: the partial rows of ALL of them are summed, and a row must have been written once
+        hipLaunchKernelGGL(kd, dim3(cus), dim3(WD_WAVES * 64), lds_d, st, scratch, ntiles, in_dim, first ? 0 : 1, partials);
+        first = 0;
+    }
+    hipLaunchKernelGGL(wide_reduce_kernel<HH>, dim3((W::NPARAM + 63) / 64), dim3(1024), 0, st, partials, cus, in_dim, grad_params);
+    return 0;
+}
+
+}  // namespace
+
+namespace wisp_mlp {
+
+bool wide_supported(int hidden) { return hidden == 128; }
+
+int64_t wide_workspace_bytes(int64_t num_samples, int hidden) {
+    const int64_t chunk = num_samples < WIDE_CHUNK_SAMPLES ? num_samples : WIDE_CHUNK_SAMPLES;
+    const int64_t tiles = (chunk + TS - 1) / TS;
+    const int nk = hidden / 16;
+    const int64_t nslot = 7 + 6 * (int64_t)nk;
+    const int64_t nparam = (int64_t)hidden * IN + hidden + 16 * hidden + 16 + (int64_t)hidden * X2 + hidden + (int64_t)hidden * hidden + hidden + 3 * hidden + 3;
+    const int64_t npad = (nparam + 63) / 64 * 64;
+    return (int64_t)cu_count_w() * npad * 4 + tiles * nslot * 1024 + 1024;
+}
+
+#define WIDE_DISPATCH(FN, ...)                                                                        \
+    if (hidden != 128) return wisp_fail(WISP_ERR_UNSUPPORTED, "nerf_mlp_wide", "hidden must be 128");   \
+    switch (dtype_io) {                                                                               \
+        case WISP_F32: return FN<128, float>(__VA_ARGS__);                                            \
+        case WISP_F16: return FN<128, __half>(__VA_ARGS__);                                           \
+        default: return FN<128, __hip_bfloat16>(__VA_ARGS__);                                         \
+    }
+
+int wide_forward_dispatch(const void* feats, int dtype_io, const float* dirs, int64_t S, int in_dim, int hidden, const float* params,
+                          float* rgb, float* density, hipStream_t st) {
+    WIDE_DISPATCH(wide_forward, feats, dirs, S, in_dim, params, rgb, density, st)
+}
+
+int wide_backward_dispatch(const void* feats, int dtype_io, const float* dirs, int64_t S, int in_dim, int hidden, const float* params,
+                           const float* grad_rgb, const float* grad_density, void* grad_feats, float* grad_params, void* workspace,
+                           hipStream_t st) {
+    WIDE_DISPATCH(wide_backward, feats, dirs, S, in_dim, params, grad_rgb, grad_density, grad_feats, grad_params, workspace, st)
+}
+#undef WIDE_DISPATCH
+
+}  // namespace wisp_mlp

@@ -81,13 +81,14 @@ SIGNATURES = {
     "wisp_composite_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_nerf_mlp_param_count": [c_i32, c_i32, c_i32],
     "wisp_nerf_mlp_fwd": [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp],
-    "wisp_nerf_mlp_bwd": [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_nerf_mlp_bwd": [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "wisp_nerf_mlp_bwd_workspace_bytes": [c_i64, c_i32],
     "wisp_nerf_mlp_workspace_floats": [],
     "wisp_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp, c_vp],
     "wisp_last_error": [],
     "wisp_abi_version": [],
 }
-_RESTYPES = {"wisp_hashgrid_bwd_workspace_bytes": c_i64, "wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_nerf_mlp_workspace_floats": c_i64,
+_RESTYPES = {"wisp_nerf_mlp_bwd_workspace_bytes": c_i64, "wisp_hashgrid_bwd_workspace_bytes": c_i64, "wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_nerf_mlp_workspace_floats": c_i64,
              "wisp_last_error": ctypes.c_char_p}
 
 for _name, _args in SIGNATURES.items():
@@ -978,14 +979,16 @@ def nerf_mlp_backward(feats, dirs, params, grad_rgb, grad_density, in_dim, hidde
     grad_feats = torch.empty_like(feats)
     if grad_params is None:
         grad_params = torch.zeros_like(params)
-    ws = _mlp_workspace.get(dev)
-    if ws is None:
-        ws = torch.empty(int(lib.wisp_nerf_mlp_workspace_floats()), dtype=torch.float32, device=dev)
-        _mlp_workspace[dev] = ws
+    need = int(lib.wisp_nerf_mlp_bwd_workspace_bytes(S, hidden))
+    key = (dev, hidden)
+    ws = _mlp_workspace.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        _mlp_workspace[key] = None
+        ws = _mlp_workspace[key] = torch.empty((need + 3) // 4 + 64, dtype=torch.float32, device=dev)
     with _timed("nerf_mlp_bwd", S):
         _check(lib.wisp_nerf_mlp_bwd(_p(feats), _DTYPE_CODE[feats.dtype], _p(dirs), S, in_dim, hidden, view_freqs, _p(params),
                                      BF16 if compute_bf16 else F32, _p(grad_rgb), _p(grad_density), _p(grad_feats),
-                                     _p(grad_params), _p(ws), _stream()), "nerf_mlp_bwd")
+                                     _p(grad_params), _p(ws), ws.numel() * 4, _stream()), "nerf_mlp_bwd")
     return grad_feats, grad_params
 
 

@@ -10,6 +10,15 @@ import torch
 # decoder shapes the kernels are built for: every app/nerf config of the reference (grid feature width 32 for nerf_hash,
 # 5 for nerf_octree / nerf_codebook, 12 for nerf_triplanar; hidden 64, one hidden layer, 4 view octaves)
 SUPPORTED = dict(max_in_dim=32, hidden=64, view_freqs=4)
+# hidden widths with a fused kernel: 64 (register-chained forward AND weight gradients, fp32 or bf16 compute) and 128 (the
+# reference's best nerf_hash row / the documented VQAD command line: csrc/nerf_mlp_wide.hip, bf16 compute only)
+FUSED_HIDDEN = (64, 128)
+BF16_ONLY_HIDDEN = (128,)
+
+
+def _compute_bf16(nef):
+    mode = getattr(nef, 'decoder_compute', 'auto')
+    return (mode == 'bf16') or (mode == 'auto' and torch.is_autocast_enabled())
 
 
 def _hip():
@@ -55,8 +64,9 @@ class _FusedDecoder(torch.autograd.Function):
         C = _hip()
         flat = _flat_view([p.detach() if p is not None else None for p in params])
         packed = flat if flat is not None else _pack(params, shapes)
-        rgb, density = C.nerf_mlp_forward(feats.detach(), dirs, packed, feats.shape[-1], SUPPORTED["hidden"],
-                                          SUPPORTED["view_freqs"], compute_bf16)
+        hidden = shapes[0][0]
+        rgb, density = C.nerf_mlp_forward(feats.detach(), dirs, packed, feats.shape[-1], hidden, SUPPORTED["view_freqs"],
+                                          compute_bf16)
         ctx.save_for_backward(feats.detach(), dirs, packed)
         ctx.compute_bf16, ctx.shapes = compute_bf16, shapes
         # in-place gradient accumulation when the parameters' .grad tensors are views of one flat buffer
@@ -74,7 +84,7 @@ class _FusedDecoder(torch.autograd.Function):
         if g_density is None:
             g_density = torch.zeros(feats.shape[0], 1, device=feats.device)
         g_feats, g_params = C.nerf_mlp_backward(feats, dirs, packed, g_rgb.contiguous().float(), g_density.contiguous().float(),
-                                                feats.shape[-1], SUPPORTED["hidden"], SUPPORTED["view_freqs"],
+                                                feats.shape[-1], ctx.shapes[0][0], SUPPORTED["view_freqs"],
                                                 ctx.compute_bf16, grad_params=ctx.grad_flat)
         if ctx.grad_flat is not None:
             return (g_feats, None, None, None) + tuple(None for _ in ctx.present)
@@ -89,7 +99,9 @@ class _FusedDecoder(torch.autograd.Function):
 
 
 def supports(nef, feats):
-    return (feats.is_cuda and 1 <= feats.shape[-1] <= SUPPORTED["max_in_dim"] and nef.hidden_dim == SUPPORTED["hidden"]
+    if nef.hidden_dim not in FUSED_HIDDEN or (nef.hidden_dim in BF16_ONLY_HIDDEN and not _compute_bf16(nef)):
+        return False
+    return (feats.is_cuda and 1 <= feats.shape[-1] <= SUPPORTED["max_in_dim"]
             and nef.view_multires == SUPPORTED["view_freqs"] and nef.num_layers == 1 and nef.pos_embedder is None
             and nef.view_embedder_type == 'positional' and nef.activation_type == 'relu'
             and nef.layer_type in ('linear', 'none') and feats.dtype in (torch.float32, torch.float16, torch.bfloat16))
@@ -97,9 +109,8 @@ def supports(nef, feats):
 
 def fused_nerf_decoder(nef, feats, ray_d):
     """(rgb [S,3] fp32, density [S,1] fp32) for the decoder shapes of the reference's app/nerf configs (see SUPPORTED)."""
-    mode = getattr(nef, 'decoder_compute', 'auto')
-    compute_bf16 = (mode == 'bf16') or (mode == 'auto' and torch.is_autocast_enabled())
+    compute_bf16 = _compute_bf16(nef)
     params = _decoder_tensors(nef)
-    H, I = SUPPORTED["hidden"], feats.shape[-1]
+    H, I = nef.hidden_dim, feats.shape[-1]
     shapes = ((H, I), (H,), (16, H), (16,), (H, 42), (H,), (H, H), (H,), (3, H), (3,))
     return _FusedDecoder.apply(feats.contiguous(), ray_d.contiguous().float(), compute_bf16, shapes, *params)

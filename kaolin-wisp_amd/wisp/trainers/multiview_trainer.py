@@ -102,7 +102,7 @@ class _DirectHashNeRFStep:
             return False
         if getattr(tracer, 'raymarch_type', None) != 'ray' or grid.blas.max_level > 10:
             return False
-        return (nef.fused_decoder and nef.hidden_dim == SUPPORTED["hidden"] and nef.num_layers == 1
+        return (nef.fused_decoder and nef.hidden_dim == SUPPORTED["hidden"] and nef.num_layers == 1      # (hidden 128: modular path)
                 and nef.view_multires == SUPPORTED["view_freqs"] and nef.pos_embedder is None
                 and nef.view_embedder_type == 'positional' and nef.activation_type == 'relu'
                 and nef.layer_type in ('linear', 'none') and 1 <= nef.effective_feature_dim() <= SUPPORTED["max_in_dim"]

@@ -33,7 +33,7 @@ ws = torch.empty(int(C.lib.wisp_nerf_mlp_workspace_floats()), device=dev)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 mlp_f = lambda: C.lib.wisp_nerf_mlp_fwd(P(g), 2, P(dirs), S, 32, 64, 4, P(params), 2, P(rgb), P(den), st)
-mlp_b = lambda: C.lib.wisp_nerf_mlp_bwd(P(g), 2, P(dirs), S, 32, 64, 4, P(params), 2, P(gr), P(gd), P(gf), P(gp), P(ws), st)
+mlp_b = lambda: C.lib.wisp_nerf_mlp_bwd(P(g), 2, P(dirs), S, 32, 64, 4, P(params), 2, P(gr), P(gd), P(gf), P(gp), P(ws), ws.numel() * 4, st)
 
 
 def timeit(fn, reps=20):
