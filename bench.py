@@ -113,13 +113,14 @@ def cpu_baseline(blas_cells, hidden, num_steps, budget_s=20.0):
 
 
 # algorithmic work per packed sample (SURVEY.md 8d / DESIGN.md 4): bytes for the HBM-bound kernels, flops for the decoder
-def work_table(amp):
+def work_table(amp, hidden=64):
     b = 2 if amp else 4
+    mlp_flop = 2 * (32 * hidden + 16 * hidden + 42 * hidden + hidden * hidden + 3 * hidden)     # 20 096 at hidden 64
     return {"hashgrid_fwd": ("hbm", 12 + 16 * 8 * 2 * b + 16 * 2 * b),        # coords + 128 gathered entries + 32 outputs
             # 12 + L*F*b + 2*L*2^d*F*b_acc with b_acc = the table element size (1100 B for 16-bit tables).
             # The kernels accumulate in fp32 / 64-bit fixed point and merge runs, so what they actually move is `traffic`.
             "hashgrid_bwd": ("hbm", 12 + 16 * 2 * b + 2 * 16 * 8 * 2 * b),
-            "nerf_mlp_fwd": ("mfma", 20096), "nerf_mlp_bwd": ("mfma", 3 * 20096)}
+            "nerf_mlp_fwd": ("mfma", mlp_flop), "nerf_mlp_bwd": ("mfma", 3 * mlp_flop)}
 
 
 PMC_KERNELS = {"hashgrid_fwd": ["hashgrid_fwd_kernel"],
@@ -313,7 +314,7 @@ def main():
         ms = [a.elapsed_time(b) for a, b, _ in evs]
         units = [u for _, _, u in evs]
         kern[name] = dict(avg_ms=float(np.mean(ms)), launches=len(ms), avg_units=float(np.mean(units)), total_ms=float(np.sum(ms)))
-    work = work_table(amp)
+    work = work_table(amp, args.hidden)
     peaks = {"hbm": (HBM_PEAK_GBS, "GB/s"), "mfma": (2500.0 if amp else 157.3, "TFLOP/s")}
 
     def rate(name, v):

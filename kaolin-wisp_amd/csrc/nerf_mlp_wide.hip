@@ -12,12 +12,13 @@
 //   * chain kernel: forward recompute, back-propagation through the transposed (also permuted) weights, grad_feats; every
 //     (dY, X) operand pair of the five weight gradients is dumped to a scratch buffer exactly as it sits in the registers
 //     (one coalesced 1 KB store per K block and wave);
-//   * dW kernel: four waves load four tiles' operands back, write them into LDS transposition images
+//   * dW kernel: four waves load four tiles' dY operands back, recompute the activations, write both into LDS transposition images
 //     (ds_read_b64_tr_b16 turns "lane = sample" into "K = sample"), and accumulate dW += dY^T X with
 //     v_mfma_f32_16x16x32_bf16 - each wave owns a quarter of the 16x16 blocks for the whole launch (120 VGPRs) and adds
 //     them to the workgroup's partial row at the end; a small kernel sums the rows.
-// The scratch costs 2 x 1.7 KB of traffic per sample (it is the price of not re-deriving the operands); at 2 M samples
-// that is the larger part of the backward's time, see DESIGN.md.
+// Only the dY operands go through the scratch (26 KB per 32-sample tile = 0.83 KB per sample, written once and read once);
+// the X operands - the activations - are re-derived in the dW kernel by running the tile through the forward pass again
+// (68 MFMAs), which is cheaper than another 0.9 KB per sample of traffic.
 #include "nerf_mlp_bf16_dev.h"
 #include <cstdlib>
 
@@ -40,9 +41,9 @@ template <int HH> struct Wide {
     static constexpr int L_W5T = L_FWD_END, L_W4T = L_W5T + HH * LT5, L_W3T = L_W4T + HH * LT4, L_W2T = L_W3T + 16 * LT3,
                          L_W1T = L_W2T + HH * LT2, L_BWD_END = L_W1T + IN * LT1;
     static constexpr int BIASV_FLOATS = 2 * NB * 2 * 16;          // [layer 1 | layer 4][t][g][16] in accumulator layout
-    // scratch slots of one tile (1 KB each: 64 lanes x 16 B), in the order the dW kernel consumes them
-    static constexpr int S5Y = 0, S5X = S5Y + 1, S4Y = S5X + NK, S4X = S4Y + NK, S3Y = S4X + NK, S3X = S3Y + NK, S2Y = S3X + 3,
-                         S2X = S2Y + 1, S1Y = S2X + NK, S1X = S1Y + NK, NSLOT = S1X + 2;
+    // scratch slots of one tile (1 KB each: 64 lanes x 16 B): the dY operand of every weight gradient, in the order the dW
+    // kernel consumes them (the X operands are re-derived there by a forward pass: cheaper than 0.9 KB / sample of traffic)
+    static constexpr int S5Y = 0, S4Y = S5Y + 1, S3Y = S4Y + NK, S2Y = S3Y + NK, S1Y = S2Y + 1, NSLOT = S1Y + NK;
     static constexpr int IMG_BYTES = (HH / 8) * TILE_REGION;      // transposition image of HH features x 32 samples
     // forward + transposed weight images must fit the 160 KB of LDS next to the bias vectors: true for 64 and 128
     static_assert((L_BWD_END * 2 + BIASV_FLOATS * 4) <= 160 * 1024, "weight images exceed the LDS of one CU");
@@ -228,7 +229,7 @@ wide_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, i
 }
 
 // ---------------------------------------------------------------------------------------------- backward: chain kernel
-constexpr int WC_WAVES = 4;
+constexpr int WC_WAVES = 8;
 
 template <int NKB> DEV floatx16 back_block_w(const __bf16* wt_lane_row, const bf16x8* dy) {
     keep_lds_reads_here();
@@ -276,8 +277,6 @@ wide_chain_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs,
         for (int c = 0; c < 3; ++c) g5[c] = g == 0 ? gr[c] * A.sg[c] * (1.0f - A.sg[c]) : 0.0f;
         const bf16x8 dy5 = pack8f(g5);
         out[W::S5Y * 64] = dy5;
-#pragma unroll
-        for (int kb = 0; kb < W::NK; ++kb) out[(W::S5X + kb) * 64] = A.h3[kb];
         bf16x8 dh3[W::NK];
 #pragma unroll
         for (int t = 0; t < W::NB; ++t) {                       // dH3 = (W5^T dY5) * (h3 > 0)
@@ -287,7 +286,7 @@ wide_chain_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs,
         }
         // ---- stage 4: dY = dH3, X = h2
 #pragma unroll
-        for (int kb = 0; kb < W::NK; ++kb) { out[(W::S4Y + kb) * 64] = dh3[kb]; out[(W::S4X + kb) * 64] = A.h2[kb]; }
+        for (int kb = 0; kb < W::NK; ++kb) out[(W::S4Y + kb) * 64] = dh3[kb];
         bf16x8 dh2[W::NK];
 #pragma unroll
         for (int t = 0; t < W::NB; ++t) {                       // dH2 = (W4^T dH3) * (h2 > 0)
@@ -298,8 +297,6 @@ wide_chain_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs,
         // ---- stage 3: dY = dH2, X = x2 (chained density-feature block + two natural view-encoding blocks)
 #pragma unroll
         for (int kb = 0; kb < W::NK; ++kb) out[(W::S3Y + kb) * 64] = dh2[kb];
-#pragma unroll
-        for (int kb = 0; kb < 3; ++kb) out[(W::S3X + kb) * 64] = A.x2[kb];
         bf16x8 dy2;
         {                                                       // dY2[m] = W3^T dH2 (m = 1..15), dY2[0] = g_density * (y0 > 0)
             floatx16 acc = back_block_w<W::NK>(w3t, dh2);
@@ -308,8 +305,6 @@ wide_chain_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs,
         }
         // ---- stage 2: dY = dY2, X = h1
         out[W::S2Y * 64] = dy2;
-#pragma unroll
-        for (int kb = 0; kb < W::NK; ++kb) out[(W::S2X + kb) * 64] = A.h1[kb];
         bf16x8 dh1[W::NK];
 #pragma unroll
         for (int t = 0; t < W::NB; ++t) {                       // dH1 = (W2^T dY2) * (h1 > 0)
@@ -320,8 +315,6 @@ wide_chain_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs,
         // ---- stage 1: dY = dH1, X = x0
 #pragma unroll
         for (int kb = 0; kb < W::NK; ++kb) out[(W::S1Y + kb) * 64] = dh1[kb];
-        out[(W::S1X + 0) * 64] = A.x0[0];
-        out[(W::S1X + 1) * 64] = A.x0[1];
         {                                                       // dX0 = W1^T dH1 -> grad_feats
             const floatx16 acc = back_block_w<W::NK>(w1t, dh1);
             if (live) {
@@ -351,14 +344,24 @@ template <int HH> struct GradW {
     floatx4 db;          // rows: 0..Q-1 layer-4 blocks, Q..2Q-1 layer-1 blocks, 2Q layer 2, 2Q+1 layer 5 (wave 0 only)
 };
 
-template <int HH>
+template <int HH, typename TIO>
 __global__ void __launch_bounds__(WD_WAVES * 64)
-wide_dw_kernel(const bf16x8* __restrict__ scratch, int64_t num_tiles, int in_dim, int accumulate, float* __restrict__ partials) {
+wide_dw_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples, int in_dim,
+               const float* __restrict__ params, const bf16x8* __restrict__ scratch, int accumulate, float* __restrict__ partials) {
     typedef Wide<HH> W;
     typedef GradW<HH> G_t;
     constexpr int NK = W::NK, Q = G_t::Q;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [4 tiles][Y image | X image]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    // forward weight images + bias vectors (for the X operands), then [4 tiles][Y image | X image]
+    __bf16* sw = reinterpret_cast<__bf16*>(smem_all);
+    float* biasv = reinterpret_cast<float*>(smem_all + (size_t)W::L_FWD_END * 2);
+    unsigned char* smem = smem_all + (size_t)W::L_FWD_END * 2 + (size_t)W::BIASV_FLOATS * 4;
+    stage_weights_wide<HH, false>(sw, biasv, params, in_dim, threadIdx.x, WD_WAVES * 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LaneW<HH> L;
+    lane_const_wide<HH>(L, sw, biasv, params, in_dim, lane);
+    __syncthreads();
+    const int64_t num_tiles = (num_samples + TS - 1) / TS;
     const int n = lane & 31, g = lane >> 5;
     const int wc_off = (2 * n + g) * 8, wn_off = g * TILE_REGION + n * 16;
     const int tr_off = ((lane >> 1) & 1) * TILE_REGION + (8 * (lane >> 4) + 2 * ((lane >> 2) & 3) + (lane & 1)) * 8;
@@ -380,13 +383,29 @@ wide_dw_kernel(const bf16x8* __restrict__ scratch, int64_t num_tiles, int in_dim
         const bf16x8* in = scratch + tile * (int64_t)(W::NSLOT * 64) + lane;
         const bf16x8 zero8 = __builtin_bit_cast(bf16x8, (u32x4)(0u));
 #define LOADK(slot) (have ? in[(slot) * 64] : zero8)
+        // dY operands are fetched one stage ahead of their use (behind the forward pass / the previous stage's MFMAs): issued
+        // right before the stage that consumes them, every one of the five stages exposed a full HBM round trip per round
+        const bf16x8 r5 = LOADK(W::S5Y);
+        bf16x8 r4[NK], r3[NK], r1[NK];
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) r4[kb] = LOADK(W::S4Y + kb);
+        // X operands: this wave's tile through the forward pass again (68 MFMAs; the chain kernel does not dump them)
+        ActsW<HH> A;
+        {
+            float d[3];
+            const int64_t sidx = tile * TS + n;
+            fetch_inputs_wide<TIO>(feats, dirs, sidx, have && sidx < num_samples, g, in_dim, A.x0, d);
+            forward_tile_wide<HH>(L, d, A);
+        }
         // bias sum of the dY block held in operand `a` into row `row` of the shared block
 #define BIAS_ROW(a, row) { const unsigned one2 = (lane & 15) == (row) ? 0x3f803f80u : 0u; const u32x4 ones = {one2, one2, one2, one2}; \
                            G.db = mma16(__builtin_bit_cast(bf16x8, ones), (a), G.db); }
         // ---------------- stage 5: dY5 natural [1 kb] x h3 chained [NK kb] -> dW5 (this wave: X blocks kt = wave + 4 q)
-        store_natural(my_img + wn_off, 0, LOADK(W::S5Y));
+        store_natural(my_img + wn_off, 0, r5);
 #pragma unroll
-        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + W::IMG_BYTES + wc_off, kb, LOADK(W::S5X + kb));
+        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + W::IMG_BYTES + wc_off, kb, A.h3[kb]);
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) r3[kb] = LOADK(W::S3Y + kb);
         __syncthreads();
 #pragma unroll
         for (int tl = 0; tl < WD_WAVES; ++tl) {
@@ -399,7 +418,10 @@ wide_dw_kernel(const bf16x8* __restrict__ scratch, int64_t num_tiles, int in_dim
         __syncthreads();
         // ---------------- stage 4: dH3 [NK] x h2 [NK] -> dW4 (this wave: dY blocks it = wave + 4 q), b4
 #pragma unroll
-        for (int kb = 0; kb < NK; ++kb) { store_chained(my_img + wc_off, kb, LOADK(W::S4Y + kb)); store_chained(my_img + W::IMG_BYTES + wc_off, kb, LOADK(W::S4X + kb)); }
+        for (int kb = 0; kb < NK; ++kb) { store_chained(my_img + wc_off, kb, r4[kb]); store_chained(my_img + W::IMG_BYTES + wc_off, kb, A.h2[kb]); }
+        const bf16x8 r2 = LOADK(W::S2Y);
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) r1[kb] = LOADK(W::S1Y + kb);
         __syncthreads();
 #pragma unroll
         for (int tl = 0; tl < WD_WAVES; ++tl) {
@@ -418,10 +440,10 @@ wide_dw_kernel(const bf16x8* __restrict__ scratch, int64_t num_tiles, int in_dim
         __syncthreads();
         // ---------------- stage 3: dH2 [NK] x x2 [chained block 0, natural blocks 1, 2] -> dW3 (+ b3 on the ones slot)
 #pragma unroll
-        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + wc_off, kb, LOADK(W::S3Y + kb));
-        store_chained(my_img + W::IMG_BYTES + wc_off, 0, LOADK(W::S3X + 0));
-        store_natural(my_img + W::IMG_BYTES + wn_off, 1, LOADK(W::S3X + 1));
-        store_natural(my_img + W::IMG_BYTES + wn_off, 2, LOADK(W::S3X + 2));
+        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + wc_off, kb, r3[kb]);
+        store_chained(my_img + W::IMG_BYTES + wc_off, 0, A.x2[0]);
+        store_natural(my_img + W::IMG_BYTES + wn_off, 1, A.x2[1]);
+        store_natural(my_img + W::IMG_BYTES + wn_off, 2, A.x2[2]);
         __syncthreads();
 #pragma unroll
         for (int tl = 0; tl < WD_WAVES; ++tl) {
@@ -438,9 +460,9 @@ wide_dw_kernel(const bf16x8* __restrict__ scratch, int64_t num_tiles, int in_dim
         }
         __syncthreads();
         // ---------------- stage 2: dY2 chained [1] x h1 [NK] -> dW2 (X blocks kt = wave + 4 q), b2 (wave 0)
-        store_chained(my_img + wc_off, 0, LOADK(W::S2Y));
+        store_chained(my_img + wc_off, 0, r2);
 #pragma unroll
-        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + W::IMG_BYTES + wc_off, kb, LOADK(W::S2X + kb));
+        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + W::IMG_BYTES + wc_off, kb, A.h1[kb]);
         __syncthreads();
 #pragma unroll
         for (int tl = 0; tl < WD_WAVES; ++tl) {
@@ -453,9 +475,9 @@ wide_dw_kernel(const bf16x8* __restrict__ scratch, int64_t num_tiles, int in_dim
         __syncthreads();
         // ---------------- stage 1: dH1 [NK] x x0 natural [2] -> dW1, b1
 #pragma unroll
-        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + wc_off, kb, LOADK(W::S1Y + kb));
-        store_natural(my_img + W::IMG_BYTES + wn_off, 0, LOADK(W::S1X + 0));
-        store_natural(my_img + W::IMG_BYTES + wn_off, 1, LOADK(W::S1X + 1));
+        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + wc_off, kb, r1[kb]);
+        store_natural(my_img + W::IMG_BYTES + wn_off, 0, A.x0[0]);
+        store_natural(my_img + W::IMG_BYTES + wn_off, 1, A.x0[1]);
         __syncthreads();
 #pragma unroll
         for (int tl = 0; tl < WD_WAVES; ++tl) {
@@ -554,9 +576,9 @@ int wide_backward(const void* feats, const float* dirs, int64_t S, int in_dim, c
                   const float* grad_density, void* grad_feats, float* grad_params, void* workspace, hipStream_t st) {
     typedef Wide<HH> W;
     const size_t lds_c = (size_t)W::L_BWD_END * 2 + (size_t)W::BIASV_FLOATS * 4;
-    const size_t lds_d = (size_t)WD_WAVES * 2 * W::IMG_BYTES;
+    const size_t lds_d = (size_t)W::L_FWD_END * 2 + (size_t)W::BIASV_FLOATS * 4 + (size_t)WD_WAVES * 2 * W::IMG_BYTES;
     auto kc = wide_chain_kernel<HH, TIO>;
-    auto kd = wide_dw_kernel<HH>;
+    auto kd = wide_dw_kernel<HH, TIO>;
     static const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
     static const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
     if (e1 != hipSuccess || e2 != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_wide", "hipFuncSetAttribute");
@@ -573,7 +595,8 @@ int wide_backward(const void* feats, const float* dirs, int64_t S, int in_dim, c
                            dirs + s0 * 3, n, in_dim, params, grad_rgb + s0 * 3, grad_density + s0,
                            (TIO*)((char*)grad_feats + (size_t)s0 * in_dim * io), scratch);
         // always `cus` workgroups: the partial rows of ALL of them are summed, and a row must have been written once
-        hipLaunchKernelGGL(kd, dim3(cus), dim3(WD_WAVES * 64), lds_d, st, scratch, ntiles, in_dim, first ? 0 : 1, partials);
+        hipLaunchKernelGGL(kd, dim3(cus), dim3(WD_WAVES * 64), lds_d, st, (const TIO*)((const char*)feats + (size_t)s0 * in_dim * io),
+                           dirs + s0 * 3, n, in_dim, params, scratch, first ? 0 : 1, partials);
         first = 0;
     }
     hipLaunchKernelGGL(wide_reduce_kernel<HH>, dim3((W::NPARAM + 63) / 64), dim3(1024), 0, st, partials, cus, in_dim, grad_params);
@@ -590,7 +613,7 @@ int64_t wide_workspace_bytes(int64_t num_samples, int hidden) {
     const int64_t chunk = num_samples < WIDE_CHUNK_SAMPLES ? num_samples : WIDE_CHUNK_SAMPLES;
     const int64_t tiles = (chunk + TS - 1) / TS;
     const int nk = hidden / 16;
-    const int64_t nslot = 7 + 6 * (int64_t)nk;
+    const int64_t nslot = 2 + 3 * (int64_t)nk;
     const int64_t nparam = (int64_t)hidden * IN + hidden + 16 * hidden + 16 + (int64_t)hidden * X2 + hidden + (int64_t)hidden * hidden + hidden + 3 * hidden + 3;
     const int64_t npad = (nparam + 63) / 64 * 64;
     return (int64_t)cu_count_w() * npad * 4 + tiles * nslot * 1024 + 1024;
