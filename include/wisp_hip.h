@@ -369,6 +369,17 @@ int wisp_nerf_mlp_bwd(const void* feats, int dtype_io, const float* dirs, int64_
                       float* workspace, int64_t workspace_bytes /* >= wisp_nerf_mlp_bwd_workspace_bytes() */,
                       wisp_stream_t stream);
 
+/* One-hidden-layer relu decoder with a single output, out = W2 relu(W1 x + b1) + b2 - the NeuralSDF decoder
+ * (wisp/models/nefs/neural_sdf.py:102-118; nglod_octree.yaml: 19 -> 128 -> 1; BasicDecoder.forward,
+ * wisp/models/decoders/basic_decoders.py:73-101).  x f32 [n, in_dim] (in_dim <= 32), w1 [hidden, in_dim], b1 [hidden],
+ * w2 [hidden], b2 [1] (nn.Linear layouts), hidden <= 256.  bwd: grad_out f32 [n]; grad_x is written, the parameter
+ * gradients are accumulated into. */
+int wisp_small_decoder_fwd(const float* x, int64_t n, int in_dim, int hidden, const float* w1, const float* b1,
+                           const float* w2, const float* b2, float* out /* [n] */, wisp_stream_t stream);
+int wisp_small_decoder_bwd(const float* x, int64_t n, int in_dim, int hidden, const float* w1, const float* b1,
+                           const float* w2, const float* b2, const float* grad_out, float* grad_x, float* grad_w1,
+                           float* grad_b1, float* grad_w2, float* grad_b2, wisp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimizer  (replaces torch.optim.AdamW / apex FusedAdam over the flat parameter buffer,
  * wisp/trainers/base_trainer.py:205-235, wisp/config/presets/torch.py:22-58)

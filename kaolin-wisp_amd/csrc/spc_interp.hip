@@ -910,3 +910,131 @@ extern "C" int wisp_grid_interpolate_bwd(const float* coords, const void* grad_o
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- small one-hidden-layer decoder
+// out = W2 relu(W1 x + b1) + b2 with one output - the NeuralSDF decoder (wisp/models/nefs/neural_sdf.py:102-118,
+// nglod_octree.yaml: 19 -> 128 -> 1), forward and backward, for the training / query path (the sphere tracer has the same
+// arithmetic inlined in its fused step).  16 lanes own a sample; lane c computes hidden units c, c + 16, ... from the
+// weights in LDS.  Backward: g_h = dout w2_h [a_h > 0] per owned unit; d x = sum_h g_h W1[h][:] is summed per lane over
+// its units and then over the group with shuffles; dW1 / db1 / dw2 / db2 accumulate in an LDS copy per workgroup (LDS
+// float atomics are slow, but the whole problem is a few thousand samples per step) that is added to the global
+// gradients once at the end.  fp32 throughout, fma chains in input order.
+#define DEC_MAX_IN 32
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+small_decoder_kernel(const float* __restrict__ x, int64_t n, int in_dim, int hidden, const float* __restrict__ w1,
+                     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                     float* __restrict__ out, const float* __restrict__ grad_out, float* __restrict__ grad_x,
+                     float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2) {
+    extern __shared__ float s_dec[];
+    const int in_pad = in_dim | 1;
+    const int groups = blockDim.x / SDF_GROUP;
+    float* s_w1 = s_dec;                                 // [hidden][in_pad]
+    float* s_b1 = s_w1 + hidden * in_pad;
+    float* s_w2 = s_b1 + hidden;
+    float* s_in = s_w2 + hidden;                         // [groups][in_dim]
+    float* s_g1 = s_in + groups * in_dim;                // backward only: dW1 [hidden][in_pad], db1 [hidden], dw2 [hidden], db2 [1]
+    float* s_gb1 = s_g1 + hidden * in_pad;
+    float* s_gw2 = s_gb1 + hidden;
+    float* s_gb2 = s_gw2 + hidden;
+    for (int e = threadIdx.x; e < hidden * in_dim; e += blockDim.x) s_w1[(e / in_dim) * in_pad + e % in_dim] = w1[e];
+    for (int e = threadIdx.x; e < hidden; e += blockDim.x) { s_b1[e] = b1[e]; s_w2[e] = w2[e]; }
+    if (BWD)
+        for (int e = threadIdx.x; e < hidden * in_pad + 2 * hidden + 1; e += blockDim.x) s_g1[e] = 0.0f;
+    __syncthreads();
+    const int c = threadIdx.x & (SDF_GROUP - 1), grp = threadIdx.x / SDF_GROUP;
+    float* gin = s_in + grp * in_dim;
+    const int64_t rounds = (n + groups - 1) / groups;
+    for (int64_t rd = blockIdx.x; rd < rounds; rd += gridDim.x) {
+        const int64_t i = rd * groups + grp;
+        const bool live = i < n;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = c; k < in_dim; k += SDF_GROUP) gin[k] = live ? x[i * in_dim + k] : 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        const float go = (BWD && live) ? grad_out[i] : 0.0f;
+        float o = 0.0f;
+        float dx[DEC_MAX_IN];
+#pragma unroll
+        for (int k = 0; k < DEC_MAX_IN; ++k) dx[k] = 0.0f;
+        for (int hh = c; hh < hidden; hh += SDF_GROUP) {
+            const float* wr = s_w1 + hh * in_pad;
+            float a = s_b1[hh];
+            for (int k = 0; k < in_dim; ++k) a = __builtin_fmaf(wr[k], gin[k], a);
+            const float r = fmaxf(a, 0.0f);
+            o = __builtin_fmaf(s_w2[hh], r, o);
+            if (BWD) {
+                if (go != 0.0f && r > 0.0f) {
+                    const float g = go * s_w2[hh];
+                    atomicAdd(&s_gw2[hh], go * r);
+                    atomicAdd(&s_gb1[hh], g);
+#pragma unroll
+                    for (int k = 0; k < DEC_MAX_IN; ++k)
+                        if (k < in_dim) { atomicAdd(&s_g1[hh * in_pad + k], g * gin[k]); dx[k] = __builtin_fmaf(g, wr[k], dx[k]); }
+                }
+            }
+        }
+        if (!BWD) {
+#pragma unroll
+            for (int d = SDF_GROUP / 2; d >= 1; d >>= 1) o += __shfl_xor(o, d, SDF_GROUP);
+            if (live && c == 0) out[i] = o + b2[0];
+        } else {
+#pragma unroll
+            for (int k = 0; k < DEC_MAX_IN; ++k) {
+                if (k < in_dim) {                            // in_dim is uniform: no divergence around the shuffles
+                    float v = dx[k];
+#pragma unroll
+                    for (int d = SDF_GROUP / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, SDF_GROUP);
+                    if (live && c == (k & (SDF_GROUP - 1))) grad_x[i * in_dim + k] = v;
+                }
+            }
+            if (live && c == 0 && go != 0.0f) atomicAdd(s_gb2, go);
+        }
+    }
+    if (BWD) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < hidden * in_dim; e += blockDim.x) {
+            const float v = s_g1[(e / in_dim) * in_pad + e % in_dim];
+            if (v != 0.0f) atomicAdd(gw1 + e, v);
+        }
+        for (int e = threadIdx.x; e < hidden; e += blockDim.x) {
+            if (s_gb1[e] != 0.0f) atomicAdd(gb1 + e, s_gb1[e]);
+            if (s_gw2[e] != 0.0f) atomicAdd(gw2 + e, s_gw2[e]);
+        }
+        if (threadIdx.x == 0 && s_gb2[0] != 0.0f) atomicAdd(gb2, s_gb2[0]);
+    }
+}
+
+static size_t small_decoder_lds(int in_dim, int hidden, bool bwd) {
+    const size_t in_pad = in_dim | 1, groups = 256 / SDF_GROUP;
+    size_t f = (size_t)hidden * in_pad + 2 * hidden + groups * in_dim;
+    if (bwd) f += (size_t)hidden * in_pad + 2 * hidden + 1;
+    return f * 4;
+}
+
+extern "C" int wisp_small_decoder_fwd(const float* x, int64_t n, int in_dim, int hidden, const float* w1, const float* b1,
+                                      const float* w2, const float* b2, float* out, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0 && in_dim >= 1 && in_dim <= DEC_MAX_IN && hidden >= 1 && hidden <= SDF_MAX_HIDDEN, "bad sizes (in_dim <= 32, hidden <= 256)");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(x && w1 && b1 && w2 && b2 && out, "null pointer");
+    const int64_t rounds = ceil_div64(n, 256 / SDF_GROUP);
+    hipLaunchKernelGGL(small_decoder_kernel<false>, dim3((unsigned)min64(rounds, 4096)), dim3(256), small_decoder_lds(in_dim, hidden, false),
+                       (hipStream_t)stream, x, n, in_dim, hidden, w1, b1, w2, b2, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_small_decoder_bwd(const float* x, int64_t n, int in_dim, int hidden, const float* w1, const float* b1,
+                                      const float* w2, const float* b2, const float* grad_out, float* grad_x, float* grad_w1,
+                                      float* grad_b1, float* grad_w2, float* grad_b2, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0 && in_dim >= 1 && in_dim <= DEC_MAX_IN && hidden >= 1 && hidden <= SDF_MAX_HIDDEN, "bad sizes (in_dim <= 32, hidden <= 256)");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(x && w1 && b1 && w2 && b2 && grad_out && grad_x && grad_w1 && grad_b1 && grad_w2 && grad_b2, "null pointer");
+    const size_t lds = small_decoder_lds(in_dim, hidden, true);
+    WISP_REQUIRE(lds <= 64 * 1024, "decoder too large for the LDS gradient copy");
+    const int64_t rounds = ceil_div64(n, 256 / SDF_GROUP);
+    // few, long-running workgroups: every one ends with hidden x in_dim global atomics
+    hipLaunchKernelGGL(small_decoder_kernel<true>, dim3((unsigned)min64(rounds, 512)), dim3(256), lds, (hipStream_t)stream, x, n,
+                       in_dim, hidden, w1, b1, w2, b2, nullptr, grad_out, grad_x, grad_w1, grad_b1, grad_w2, grad_b2);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

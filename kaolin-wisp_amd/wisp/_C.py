@@ -66,6 +66,8 @@ SIGNATURES = {
                                   c_vp, c_i32, c_f32, c_vp, c_vp],
     "wisp_grid_interpolate_fwd": [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp],
     "wisp_grid_interpolate_bwd": [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp],
+    "wisp_small_decoder_fwd": [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wisp_small_decoder_bwd": [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_uniform_sample": [c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_raymarch_uniform_emit": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_packed_sum_reduce": [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
@@ -827,6 +829,28 @@ def sdf_trace_step_fused(first, nug_o, nug_d, nug_depth, nug_pidx, dist_max, thr
                                          _p(points), _p(trinkets), fp, _DTYPE_CODE[feats[0].dtype], lv, n, feats[0].shape[1],
                                          int(half_round), _p(w1), _p(b1), _p(w2), _p(b2), w1.shape[0], float(np.float32(scale)),
                                          _p(any_active), _stream()), "sdf_trace_step_fused")
+
+
+def small_decoder_forward(x, w1, b1, w2, b2):
+    """[n, in] -> [n, 1]: W2 relu(W1 x + b1) + b2 in one launch (csrc/spc_interp.hip)."""
+    x = _need(x, torch.float32, "x")
+    n, in_dim = x.shape
+    out = torch.empty(n, 1, dtype=torch.float32, device=x.device)
+    _check(lib.wisp_small_decoder_fwd(_p(x), n, in_dim, w1.shape[0], _p(w1), _p(b1), _p(w2), _p(b2), _p(out), _stream()),
+           "small_decoder_fwd")
+    return out
+
+
+def small_decoder_backward(x, w1, b1, w2, b2, grad_out):
+    """-> (grad_x [n, in], grad_w1, grad_b1, grad_w2 [hidden], grad_b2 [1])."""
+    x = _need(x, torch.float32, "x")
+    grad_out = _need(grad_out, torch.float32, "grad_out").reshape(-1)
+    n, in_dim = x.shape
+    gx = torch.empty_like(x)
+    gw1, gb1, gw2, gb2 = torch.zeros_like(w1), torch.zeros_like(b1), torch.zeros_like(w2), torch.zeros_like(b2)
+    _check(lib.wisp_small_decoder_bwd(_p(x), n, in_dim, w1.shape[0], _p(w1), _p(b1), _p(w2), _p(b2), _p(grad_out), _p(gx),
+                                      _p(gw1), _p(gb1), _p(gw2), _p(gb2), _stream()), "small_decoder_bwd")
+    return gx, gw1, gb1, gw2, gb2
 
 
 _LOSS_KIND = {"huber": 0, "l2": 1, "l1": 2}

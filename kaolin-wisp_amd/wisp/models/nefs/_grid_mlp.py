@@ -36,6 +36,38 @@ def make_decoder(in_width, out_width, activation_type, layer_type, num_layers, h
                         skip=[])
 
 
+class _SmallDecoder(torch.autograd.Function):
+    """BasicDecoder with one hidden relu layer, biases and a single output as one HIP launch per direction
+    (wisp_small_decoder_fwd / _bwd); what NeuralSDF's decoder is in every shipped NGLOD config."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        import wisp._C as C
+        x, w1, b1, w2, b2 = (t.detach().float().contiguous() for t in (x, w1, b1, w2, b2))
+        w2 = w2.reshape(-1)
+        ctx.save_for_backward(x, w1, b1, w2, b2)
+        return C.small_decoder_forward(x, w1, b1, w2, b2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        import wisp._C as C
+        x, w1, b1, w2, b2 = ctx.saved_tensors
+        gx, gw1, gb1, gw2, gb2 = C.small_decoder_backward(x, w1, b1, w2, b2, grad_out.contiguous().float())
+        return gx, gw1, gb1, gw2.reshape(1, -1), gb2
+
+
+def _fusable_small_decoder(decoder, feats):
+    import os
+    if os.environ.get("WISP_SMALL_DECODER_FUSED", "1") == "0" or not feats.is_cuda or feats.shape[-1] > 32:
+        return False
+    layers = getattr(decoder, 'layers', None)
+    lout = getattr(decoder, 'lout', None)
+    return (type(decoder) is BasicDecoder and layers is not None and len(layers) == 1 and not decoder.skip
+            and type(layers[0]) is torch.nn.Linear and type(lout) is torch.nn.Linear and layers[0].bias is not None
+            and lout.bias is not None and lout.out_features == 1 and layers[0].out_features <= 256
+            and decoder.activation in (torch.relu, torch.nn.functional.relu) and layers[0].weight.dtype == torch.float32)
+
+
 def decode(grid, decoder, embedder, coords, lod_idx, embed_first):
     """coords [N, D] -> decoder output [N, out].  Features and embedding are concatenated in the order the checkpoint
     layout of the corresponding reference field expects (embedding first for the SDF, features first for images)."""
@@ -44,4 +76,6 @@ def decode(grid, decoder, embedder, coords, lod_idx, embed_first):
     if embedder is not None:
         emb = embedder(coords).reshape(n, -1)
         feats = torch.cat([emb, feats] if embed_first else [feats, emb], dim=-1)
+    if _fusable_small_decoder(decoder, feats):
+        return _SmallDecoder.apply(feats, decoder.layers[0].weight, decoder.layers[0].bias, decoder.lout.weight, decoder.lout.bias)
     return decoder(feats)
