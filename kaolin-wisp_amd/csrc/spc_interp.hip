@@ -1017,6 +1017,9 @@ extern "C" int wisp_small_decoder_fwd(const float* x, int64_t n, int in_dim, int
     if (n == 0) return WISP_OK;
     WISP_REQUIRE(x && w1 && b1 && w2 && b2 && out, "null pointer");
     const int64_t rounds = ceil_div64(n, 256 / SDF_GROUP);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(small_decoder_kernel<false>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (attr != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(attr));
     hipLaunchKernelGGL(small_decoder_kernel<false>, dim3((unsigned)min64(rounds, 4096)), dim3(256), small_decoder_lds(in_dim, hidden, false),
                        (hipStream_t)stream, x, n, in_dim, hidden, w1, b1, w2, b2, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     WISP_CHECK_LAUNCH();
@@ -1030,7 +1033,10 @@ extern "C" int wisp_small_decoder_bwd(const float* x, int64_t n, int in_dim, int
     if (n == 0) return WISP_OK;
     WISP_REQUIRE(x && w1 && b1 && w2 && b2 && grad_out && grad_x && grad_w1 && grad_b1 && grad_w2 && grad_b2, "null pointer");
     const size_t lds = small_decoder_lds(in_dim, hidden, true);
-    WISP_REQUIRE(lds <= 64 * 1024, "decoder too large for the LDS gradient copy");
+    WISP_REQUIRE(lds <= 150 * 1024, "decoder too large for the LDS gradient copy");
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(small_decoder_kernel<true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (attr != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(attr));
     const int64_t rounds = ceil_div64(n, 256 / SDF_GROUP);
     // few, long-running workgroups: every one ends with hidden x in_dim global atomics
     hipLaunchKernelGGL(small_decoder_kernel<true>, dim3((unsigned)min64(rounds, 512)), dim3(256), lds, (hipStream_t)stream, x, n,
