@@ -61,36 +61,67 @@ DEV float wide_param(const float* __restrict__ P, int canonical, int in_dim, int
     return i < 0 ? 0.0f : P[i];
 }
 
-// weights straight from global memory into the permuted bf16 operand images (once per workgroup; the parameter vector is
-// L2 resident).  P is the caller's packed buffer (W1 rows in_dim wide).
+// Weights from the caller's packed buffer (W1 rows in_dim wide) into the permuted bf16 operand images, once per workgroup.
+// The parameter vector is read in ITS order - consecutive threads, consecutive floats, several loads in flight - and every
+// value is scattered to its slot(s): phi16 is an involution, so "slot of column c" is phi(c) just like "column of slot s".
+// (Walking the images and gathering the parameters instead cost a scattered global load plus two integer divisions per
+// element: ~0.1 ms per workgroup and launch, more than the forward pass itself.)
 template <int HH, bool BWD>
 DEV void stage_weights_wide(__bf16* sw, float* biasv, const float* __restrict__ P, int in_dim, int tid, int nthreads) {
     typedef Wide<HH> W;
-#define PV(idx) wide_param(P, (idx), in_dim, HH)
-    for (int e = tid; e < HH * IN; e += nthreads) { const int r = e / IN, c = e % IN; sw[W::L_W1 + r * W::LD1 + c] = (__bf16)PV(W::OW1 + r * IN + c); }
-    for (int e = tid; e < 16 * HH; e += nthreads) { const int r = e / HH, s = e % HH; sw[W::L_W2 + r * W::LD2 + s] = (__bf16)PV(W::OW2 + r * HH + phi(s)); }
-    for (int e = tid; e < HH * 48; e += nthreads) {
-        const int r = e / 48, s = e % 48;
-        float v = 0.0f;
-        if (s < 16) { const int m = phi16(s); if (m) v = PV(W::OW3 + r * X2 + m - 1); }
-        else if (s < ONES_SLOT) v = PV(W::OW3 + r * X2 + s - 1);
-        else if (s == ONES_SLOT) v = PV(W::OB3 + r);
-        sw[W::L_W3 + r * W::LD3 + s] = (__bf16)v;
+    {   // zero everything first: padding columns (in_dim < 32, the y0 slot, slots 44-47, row 3 of W5, unused W3T / W5T slots)
+        uint4* z = reinterpret_cast<uint4*>(sw);
+        const int n16 = ((BWD ? W::L_BWD_END : W::L_FWD_END) * 2) / 16;
+        for (int e = tid; e < n16; e += nthreads) z[e] = make_uint4(0u, 0u, 0u, 0u);
     }
-    for (int e = tid; e < HH * HH; e += nthreads) { const int r = e / HH, s = e % HH; sw[W::L_W4 + r * W::LD4 + s] = (__bf16)PV(W::OW4 + r * HH + phi(s)); }
-    for (int e = tid; e < 4 * HH; e += nthreads) { const int r = e / HH, s = e % HH; sw[W::L_W5 + r * W::LD5 + s] = (__bf16)(r < 3 ? PV(W::OW5 + r * HH + phi(s)) : 0.0f); }
-    for (int e = tid; e < W::BIASV_FLOATS; e += nthreads) {
-        const int r = e & 15, g = (e >> 4) & 1, t = (e >> 5) % W::NB, layer = e / (32 * W::NB);
-        biasv[e] = PV((layer ? W::OB4 : W::OB1) + 32 * t + acc_row(r, g));
+    __syncthreads();
+    // accumulator-layout position of neuron h inside a bias vector: block t = h / 32, row rho = h % 32 = acc_row(r, g)
+    auto bias_pos = [](int h) { const int t = h >> 5, rho = h & 31; return ((rho & 3) + 4 * (rho >> 3)) + 16 * ((rho >> 2) & 1) + 32 * t; };
+    const float* p = P;
+#pragma unroll 4
+    for (int e = tid; e < HH * in_dim; e += nthreads) {                        // W1 [HH, in_dim]
+        const int r = e / in_dim, c = e - r * in_dim;
+        const __bf16 v = (__bf16)p[e];
+        sw[W::L_W1 + r * W::LD1 + c] = v;
+        if (BWD) sw[W::L_W1T + c * W::LT1 + phi(r)] = v;
     }
-    if (BWD) {
-        for (int e = tid; e < HH * 16; e += nthreads) { const int k = e >> 4, p = e & 15; sw[W::L_W5T + k * W::LT5 + p] = (__bf16)(p < 3 ? PV(W::OW5 + p * HH + k) : 0.0f); }
-        for (int e = tid; e < HH * HH; e += nthreads) { const int k = e / HH, s = e % HH; sw[W::L_W4T + k * W::LT4 + s] = (__bf16)PV(W::OW4 + phi(s) * HH + k); }
-        for (int e = tid; e < 16 * HH; e += nthreads) { const int m = e / HH, s = e % HH; sw[W::L_W3T + m * W::LT3 + s] = (__bf16)(m ? PV(W::OW3 + phi(s) * X2 + m - 1) : 0.0f); }
-        for (int e = tid; e < HH * 16; e += nthreads) { const int k = e >> 4, p = e & 15; sw[W::L_W2T + k * W::LT2 + p] = (__bf16)PV(W::OW2 + phi16(p) * HH + k); }
-        for (int e = tid; e < IN * HH; e += nthreads) { const int k = e / HH, s = e % HH; sw[W::L_W1T + k * W::LT1 + s] = (__bf16)PV(W::OW1 + phi(s) * IN + k); }
+    p += HH * in_dim;
+    for (int e = tid; e < HH; e += nthreads) biasv[bias_pos(e)] = p[e];        // b1
+    p += HH;
+#pragma unroll 4
+    for (int e = tid; e < 16 * HH; e += nthreads) {                            // W2 [16, HH]
+        const int r = e / HH, c = e - r * HH;
+        const __bf16 v = (__bf16)p[e];
+        sw[W::L_W2 + r * W::LD2 + phi(c)] = v;
+        if (BWD) sw[W::L_W2T + c * W::LT2 + phi16(r)] = v;
     }
-#undef PV
+    p += 16 * HH + 16;                                                         // (b2 is read by lane_const_wide)
+#pragma unroll 4
+    for (int e = tid; e < HH * X2; e += nthreads) {                            // W3 [HH, 42]: column c <-> colour input u = c + 1
+        const int r = e / X2, c = e - r * X2, u = c + 1;
+        const __bf16 v = (__bf16)p[e];
+        sw[W::L_W3 + r * W::LD3 + (u < 16 ? phi16(u) : u)] = v;
+        if (BWD && u < 16) sw[W::L_W3T + u * W::LT3 + phi(r)] = v;
+    }
+    p += HH * X2;
+    for (int e = tid; e < HH; e += nthreads) sw[W::L_W3 + e * W::LD3 + ONES_SLOT] = (__bf16)p[e];     // b3 rides on the ones slot
+    p += HH;
+#pragma unroll 4
+    for (int e = tid; e < HH * HH; e += nthreads) {                            // W4 [HH, HH]
+        const int r = e / HH, c = e - r * HH;
+        const __bf16 v = (__bf16)p[e];
+        sw[W::L_W4 + r * W::LD4 + phi(c)] = v;
+        if (BWD) sw[W::L_W4T + c * W::LT4 + phi(r)] = v;
+    }
+    p += HH * HH;
+    for (int e = tid; e < HH; e += nthreads) biasv[32 * W::NB + bias_pos(e)] = p[e];      // b4
+    p += HH;
+    for (int e = tid; e < 3 * HH; e += nthreads) {                             // W5 [3, HH]
+        const int r = e / HH, c = e - r * HH;
+        const __bf16 v = (__bf16)p[e];
+        sw[W::L_W5 + r * W::LD5 + phi(c)] = v;
+        if (BWD) sw[W::L_W5T + c * W::LT5 + r] = v;
+    }
 }
 
 // The weight images never change after staging, so the optimiser would hoist every ds_read of an A operand out of the tile
@@ -120,10 +151,12 @@ DEV void lane_const_wide(LaneW<HH>& L, const __bf16* sw, const float* biasv, con
     L.w4 = sw + W::L_W4 + L.n * W::LD4 + 8 * L.g;
     L.w5 = sw + W::L_W5 + (L.n < 3 ? L.n : 3) * W::LD5 + 8 * L.g;
     L.bias_lds = biasv + 16 * L.g;
+    const float* pb2 = P + HH * in_dim + HH + 16 * HH;                        // packed offsets (W1 rows in_dim wide)
+    const float* pb5 = pb2 + 16 + HH * X2 + HH + HH * HH + HH + 3 * HH;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) L.b2[r] = wide_param(P, W::OB2 + acc_row(r, L.g), in_dim, HH);
+    for (int r = 0; r < 8; ++r) L.b2[r] = pb2[acc_row(r, L.g)];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) L.b5[c] = wide_param(P, W::OB5 + c, in_dim, HH);
+    for (int c = 0; c < 3; ++c) L.b5[c] = pb5[c];
 }
 
 template <int HH>
@@ -331,17 +364,20 @@ wide_chain_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs,
 }
 
 // ---------------------------------------------------------------------------------------------- backward: dW kernel
-// Workgroup = 4 waves = 4 tiles per round.  Per stage: every wave brings ITS tile's operands from the scratch into the
-// stage's LDS images (the layouts store_chained / store_natural / load_transposed define), barrier, then every wave adds the
-// products of ITS dW blocks for all four tiles, barrier.  Ownership: for stages whose dY is HH wide wave w owns the dY
-// blocks it = w, w + 4, ... (and their bias sums); for the two 16-wide dY's (dY5, dY2) it owns the X blocks kt = w, w + 4, ...
-// (their bias sums go to wave 0).
-constexpr int WD_WAVES = 4;
+// Workgroup = 8 waves, 4 tiles per round.  Waves 0..3 re-derive the X operands of "their" tile (forward pass, 68 MFMAs) and
+// write the X images; waves 4..7 fetch the dY operands of the same four tiles from the scratch (all 26 KB of a tile in flight
+// at once) and write the dY images (the layouts store_chained / store_natural / load_transposed define).  After a barrier ALL
+// eight waves add the products of THEIR dW blocks for the four tiles: wave w owns dY block it = w of every HH-wide dY (and
+// its bias sums), and X block kt = w of the two 16-wide dY's (dY5, dY2; their bias sums go to wave 0) - 15 blocks of 16x16
+// (60 VGPRs) per wave, two waves per SIMD.
+constexpr int WD_TILES = 4;
+constexpr int WD_WAVES = 2 * WD_TILES;
 
 template <int HH> struct GradW {
-    static constexpr int NK = Wide<HH>::NK, Q = NK / 4;     // blocks of an HH-wide operand owned by one wave
-    floatx4 dW5[Q], dW4[Q * NK], dW3[Q * 3], dW2[Q], dW1[Q * 2];
-    floatx4 db;          // rows: 0..Q-1 layer-4 blocks, Q..2Q-1 layer-1 blocks, 2Q layer 2, 2Q+1 layer 5 (wave 0 only)
+    static constexpr int NK = Wide<HH>::NK;
+    static_assert(NK == WD_WAVES, "block ownership below is written for hidden = 16 x (number of waves) = 128");
+    floatx4 dW5, dW4[NK], dW3[3], dW2, dW1[2];
+    floatx4 db;          // rows: 0 layer-4 block `wave`, 1 layer-1 block `wave`, 2 layer 2 (wave 0), 3 layer 5 (wave 0)
 };
 
 template <int HH, typename TIO>
@@ -349,8 +385,7 @@ __global__ void __launch_bounds__(WD_WAVES * 64)
 wide_dw_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples, int in_dim,
                const float* __restrict__ params, const bf16x8* __restrict__ scratch, int accumulate, float* __restrict__ partials) {
     typedef Wide<HH> W;
-    typedef GradW<HH> G_t;
-    constexpr int NK = W::NK, Q = G_t::Q;
+    constexpr int NK = W::NK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     // forward weight images + bias vectors (for the X operands), then [4 tiles][Y image | X image]
     __bf16* sw = reinterpret_cast<__bf16*>(smem_all);
@@ -365,131 +400,133 @@ wide_dw_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
     const int n = lane & 31, g = lane >> 5;
     const int wc_off = (2 * n + g) * 8, wn_off = g * TILE_REGION + n * 16;
     const int tr_off = ((lane >> 1) & 1) * TILE_REGION + (8 * (lane >> 4) + 2 * ((lane >> 2) & 3) + (lane & 1)) * 8;
-    unsigned char* my_img = smem + (size_t)wave * 2 * W::IMG_BYTES;
-    G_t G;
+    const bool x_role = wave < WD_TILES;                       // waves 0..3: X operands; waves 4..7: dY operands
+    const int my_tile = wave & (WD_TILES - 1);
+    unsigned char* imgY = smem + (size_t)my_tile * 2 * W::IMG_BYTES;
+    unsigned char* imgX = imgY + W::IMG_BYTES;
+    GradW<HH> G;
+    G.dW5 = zero4(); G.dW2 = zero4(); G.db = zero4();
 #pragma unroll
-    for (int i = 0; i < Q; ++i) { G.dW5[i] = zero4(); G.dW2[i] = zero4(); }
+    for (int i = 0; i < NK; ++i) G.dW4[i] = zero4();
 #pragma unroll
-    for (int i = 0; i < Q * NK; ++i) G.dW4[i] = zero4();
-#pragma unroll
-    for (int i = 0; i < Q * 3; ++i) G.dW3[i] = zero4();
-#pragma unroll
-    for (int i = 0; i < Q * 2; ++i) G.dW1[i] = zero4();
-    G.db = zero4();
-    const int64_t rounds = (num_tiles + WD_WAVES - 1) / WD_WAVES;
+    for (int i = 0; i < 3; ++i) G.dW3[i] = zero4();
+    G.dW1[0] = zero4(); G.dW1[1] = zero4();
+    const int64_t rounds = (num_tiles + WD_TILES - 1) / WD_TILES;
+    const bf16x8 zero8 = __builtin_bit_cast(bf16x8, (u32x4)(0u));
     for (int64_t rd = blockIdx.x; rd < rounds; rd += gridDim.x) {
-        const int64_t tile = rd * WD_WAVES + wave;
+        const int64_t tile = rd * WD_TILES + my_tile;
         const bool have = tile < num_tiles;
         const bf16x8* in = scratch + tile * (int64_t)(W::NSLOT * 64) + lane;
-        const bf16x8 zero8 = __builtin_bit_cast(bf16x8, (u32x4)(0u));
-#define LOADK(slot) (have ? in[(slot) * 64] : zero8)
-        // dY operands are fetched one stage ahead of their use (behind the forward pass / the previous stage's MFMAs): issued
-        // right before the stage that consumes them, every one of the five stages exposed a full HBM round trip per round
-        const bf16x8 r5 = LOADK(W::S5Y);
-        bf16x8 r4[NK], r3[NK], r1[NK];
-#pragma unroll
-        for (int kb = 0; kb < NK; ++kb) r4[kb] = LOADK(W::S4Y + kb);
-        // X operands: this wave's tile through the forward pass again (68 MFMAs; the chain kernel does not dump them)
+#define LOADK(slot) ((have && !x_role) ? in[(slot) * 64] : zero8)
+        // bias sum of the dY block held in operand `a` into row `row` of the shared block
+#define BIAS_ROW(a, row) { const unsigned one2 = (lane & 15) == (row) ? 0x3f803f80u : 0u; const u32x4 ones = {one2, one2, one2, one2}; \
+                           G.db = mma16(__builtin_bit_cast(bf16x8, ones), (a), G.db); }
+        // one register set for both roles (a wave has one role): in the dY role the fetched operands live in the fields of A
         ActsW<HH> A;
-        {
+        bf16x8& r5 = A.x0[0];
+        bf16x8& r2 = A.x0[1];
+        bf16x8 (&r4)[NK] = A.h2;
+        bf16x8 (&r3)[NK] = A.h3;
+        bf16x8 (&r1)[NK] = A.h1;
+        if (x_role) {                                          // wave-uniform branch
             float d[3];
             const int64_t sidx = tile * TS + n;
             fetch_inputs_wide<TIO>(feats, dirs, sidx, have && sidx < num_samples, g, in_dim, A.x0, d);
             forward_tile_wide<HH>(L, d, A);
+        } else {                                               // all 26 operand blocks of the tile in flight at once
+            r5 = LOADK(W::S5Y);
+            r2 = LOADK(W::S2Y);
+#pragma unroll
+            for (int kb = 0; kb < NK; ++kb) r4[kb] = LOADK(W::S4Y + kb);
+#pragma unroll
+            for (int kb = 0; kb < NK; ++kb) r3[kb] = LOADK(W::S3Y + kb);
+#pragma unroll
+            for (int kb = 0; kb < NK; ++kb) r1[kb] = LOADK(W::S1Y + kb);
         }
-        // bias sum of the dY block held in operand `a` into row `row` of the shared block
-#define BIAS_ROW(a, row) { const unsigned one2 = (lane & 15) == (row) ? 0x3f803f80u : 0u; const u32x4 ones = {one2, one2, one2, one2}; \
-                           G.db = mma16(__builtin_bit_cast(bf16x8, ones), (a), G.db); }
-        // ---------------- stage 5: dY5 natural [1 kb] x h3 chained [NK kb] -> dW5 (this wave: X blocks kt = wave + 4 q)
-        store_natural(my_img + wn_off, 0, r5);
+        // ---------------- stage 5: dY5 natural [1 kb] x h3 chained [NK kb] -> dW5 (this wave: X block kt = wave)
+        if (x_role) {
 #pragma unroll
-        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + W::IMG_BYTES + wc_off, kb, A.h3[kb]);
-#pragma unroll
-        for (int kb = 0; kb < NK; ++kb) r3[kb] = LOADK(W::S3Y + kb);
+            for (int kb = 0; kb < NK; ++kb) store_chained(imgX + wc_off, kb, A.h3[kb]);
+        } else {
+            store_natural(imgY + wn_off, 0, r5);
+        }
         __syncthreads();
 #pragma unroll
-        for (int tl = 0; tl < WD_WAVES; ++tl) {
+        for (int tl = 0; tl < WD_TILES; ++tl) {
             const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
             const bf16x8 a = load_transposed(img, 0);
-            if (wave == 0) BIAS_ROW(a, 2 * Q + 1)
-#pragma unroll
-            for (int q = 0; q < Q; ++q) G.dW5[q] = mma16(a, load_transposed(img + W::IMG_BYTES, wave + 4 * q), G.dW5[q]);
+            if (wave == 0) BIAS_ROW(a, 3)
+            G.dW5 = mma16(a, load_transposed(img + W::IMG_BYTES, wave), G.dW5);
         }
         __syncthreads();
-        // ---------------- stage 4: dH3 [NK] x h2 [NK] -> dW4 (this wave: dY blocks it = wave + 4 q), b4
+        // ---------------- stage 4: dH3 [NK] x h2 [NK] -> dW4 (this wave: dY block it = wave), b4
+        if (x_role) {
 #pragma unroll
-        for (int kb = 0; kb < NK; ++kb) { store_chained(my_img + wc_off, kb, r4[kb]); store_chained(my_img + W::IMG_BYTES + wc_off, kb, A.h2[kb]); }
-        const bf16x8 r2 = LOADK(W::S2Y);
+            for (int kb = 0; kb < NK; ++kb) store_chained(imgX + wc_off, kb, A.h2[kb]);
+        } else {
 #pragma unroll
-        for (int kb = 0; kb < NK; ++kb) r1[kb] = LOADK(W::S1Y + kb);
+            for (int kb = 0; kb < NK; ++kb) store_chained(imgY + wc_off, kb, r4[kb]);
+        }
         __syncthreads();
 #pragma unroll
-        for (int tl = 0; tl < WD_WAVES; ++tl) {
+        for (int tl = 0; tl < WD_TILES; ++tl) {
             const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
-            bf16x8 xb[NK];
+            const bf16x8 a = load_transposed(img, wave);
+            BIAS_ROW(a, 0)
 #pragma unroll
-            for (int kt = 0; kt < NK; ++kt) xb[kt] = load_transposed(img + W::IMG_BYTES, kt);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const bf16x8 a = load_transposed(img, wave + 4 * q);
-                BIAS_ROW(a, q)
-#pragma unroll
-                for (int kt = 0; kt < NK; ++kt) G.dW4[q * NK + kt] = mma16(a, xb[kt], G.dW4[q * NK + kt]);
-            }
+            for (int kt = 0; kt < NK; ++kt) G.dW4[kt] = mma16(a, load_transposed(img + W::IMG_BYTES, kt), G.dW4[kt]);
         }
         __syncthreads();
         // ---------------- stage 3: dH2 [NK] x x2 [chained block 0, natural blocks 1, 2] -> dW3 (+ b3 on the ones slot)
+        if (x_role) {
+            store_chained(imgX + wc_off, 0, A.x2[0]);
+            store_natural(imgX + wn_off, 1, A.x2[1]);
+            store_natural(imgX + wn_off, 2, A.x2[2]);
+        } else {
 #pragma unroll
-        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + wc_off, kb, r3[kb]);
-        store_chained(my_img + W::IMG_BYTES + wc_off, 0, A.x2[0]);
-        store_natural(my_img + W::IMG_BYTES + wn_off, 1, A.x2[1]);
-        store_natural(my_img + W::IMG_BYTES + wn_off, 2, A.x2[2]);
-        __syncthreads();
-#pragma unroll
-        for (int tl = 0; tl < WD_WAVES; ++tl) {
-            const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
-            bf16x8 xb[3];
-#pragma unroll
-            for (int kt = 0; kt < 3; ++kt) xb[kt] = load_transposed(img + W::IMG_BYTES, kt);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const bf16x8 a = load_transposed(img, wave + 4 * q);
-#pragma unroll
-                for (int kt = 0; kt < 3; ++kt) G.dW3[q * 3 + kt] = mma16(a, xb[kt], G.dW3[q * 3 + kt]);
-            }
+            for (int kb = 0; kb < NK; ++kb) store_chained(imgY + wc_off, kb, r3[kb]);
         }
         __syncthreads();
-        // ---------------- stage 2: dY2 chained [1] x h1 [NK] -> dW2 (X blocks kt = wave + 4 q), b2 (wave 0)
-        store_chained(my_img + wc_off, 0, r2);
 #pragma unroll
-        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + W::IMG_BYTES + wc_off, kb, A.h1[kb]);
+        for (int tl = 0; tl < WD_TILES; ++tl) {
+            const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
+            const bf16x8 a = load_transposed(img, wave);
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) G.dW3[kt] = mma16(a, load_transposed(img + W::IMG_BYTES, kt), G.dW3[kt]);
+        }
+        __syncthreads();
+        // ---------------- stage 2: dY2 chained [1] x h1 [NK] -> dW2 (X block kt = wave), b2 (wave 0)
+        if (x_role) {
+#pragma unroll
+            for (int kb = 0; kb < NK; ++kb) store_chained(imgX + wc_off, kb, A.h1[kb]);
+        } else {
+            store_chained(imgY + wc_off, 0, r2);
+        }
         __syncthreads();
 #pragma unroll
-        for (int tl = 0; tl < WD_WAVES; ++tl) {
+        for (int tl = 0; tl < WD_TILES; ++tl) {
             const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
             const bf16x8 a = load_transposed(img, 0);
-            if (wave == 0) BIAS_ROW(a, 2 * Q)
-#pragma unroll
-            for (int q = 0; q < Q; ++q) G.dW2[q] = mma16(a, load_transposed(img + W::IMG_BYTES, wave + 4 * q), G.dW2[q]);
+            if (wave == 0) BIAS_ROW(a, 2)
+            G.dW2 = mma16(a, load_transposed(img + W::IMG_BYTES, wave), G.dW2);
         }
         __syncthreads();
         // ---------------- stage 1: dH1 [NK] x x0 natural [2] -> dW1, b1
+        if (x_role) {
+            store_natural(imgX + wn_off, 0, A.x0[0]);
+            store_natural(imgX + wn_off, 1, A.x0[1]);
+        } else {
 #pragma unroll
-        for (int kb = 0; kb < NK; ++kb) store_chained(my_img + wc_off, kb, r1[kb]);
-        store_natural(my_img + W::IMG_BYTES + wn_off, 0, A.x0[0]);
-        store_natural(my_img + W::IMG_BYTES + wn_off, 1, A.x0[1]);
+            for (int kb = 0; kb < NK; ++kb) store_chained(imgY + wc_off, kb, r1[kb]);
+        }
         __syncthreads();
 #pragma unroll
-        for (int tl = 0; tl < WD_WAVES; ++tl) {
+        for (int tl = 0; tl < WD_TILES; ++tl) {
             const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
-            const bf16x8 x0a = load_transposed(img + W::IMG_BYTES, 0), x0b = load_transposed(img + W::IMG_BYTES, 1);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const bf16x8 a = load_transposed(img, wave + 4 * q);
-                BIAS_ROW(a, Q + q)
-                G.dW1[q * 2] = mma16(a, x0a, G.dW1[q * 2]);
-                G.dW1[q * 2 + 1] = mma16(a, x0b, G.dW1[q * 2 + 1]);
-            }
+            const bf16x8 a = load_transposed(img, wave);
+            BIAS_ROW(a, 1)
+            G.dW1[0] = mma16(a, load_transposed(img + W::IMG_BYTES, 0), G.dW1[0]);
+            G.dW1[1] = mma16(a, load_transposed(img + W::IMG_BYTES, 1), G.dW1[1]);
         }
         __syncthreads();
 #undef LOADK
@@ -502,29 +539,25 @@ wide_dw_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int row = 4 * rg + rr;                                     // row inside a 16-row block
+        if (row < 3) put(W::OW5 + row * HH + 16 * wave + col, G.dW5[rr]);       // stages 5 / 2: owned X block kt = wave
+        put(W::OW2 + row * HH + 16 * wave + col, G.dW2[rr]);
+        const int R = 16 * wave + row;                                   // stages 4 / 3 / 1: owned dY block -> output neuron R
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int kt = wave + 4 * q;                                 // stages 5 / 2: owned X block
-            if (row < 3) put(W::OW5 + row * HH + 16 * kt + col, G.dW5[q][rr]);
-            put(W::OW2 + row * HH + 16 * kt + col, G.dW2[q][rr]);
-            const int R = 16 * (wave + 4 * q) + row;                     // stages 4 / 3 / 1: owned dY block -> output neuron R
+        for (int k2 = 0; k2 < NK; ++k2) put(W::OW4 + R * HH + 16 * k2 + col, G.dW4[k2][rr]);
 #pragma unroll
-            for (int k2 = 0; k2 < NK; ++k2) put(W::OW4 + R * HH + 16 * k2 + col, G.dW4[q * NK + k2][rr]);
+        for (int k2 = 0; k2 < 2; ++k2) put(W::OW1 + R * IN + 16 * k2 + col, G.dW1[k2][rr]);
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) put(W::OW1 + R * IN + 16 * k2 + col, G.dW1[q * 2 + k2][rr]);
-#pragma unroll
-            for (int k2 = 0; k2 < 3; ++k2) {
-                const int u = 16 * k2 + col;                             // feature inside the 48-wide colour input
-                if (k2 == 0) { if (u >= 1) put(W::OW3 + R * X2 + u - 1, G.dW3[q * 3 + k2][rr]); }
-                else if (u < ONES_SLOT) put(W::OW3 + R * X2 + u - 1, G.dW3[q * 3 + k2][rr]);
-                else if (u == ONES_SLOT) put(W::OB3 + R, G.dW3[q * 3 + k2][rr]);
-            }
+        for (int k2 = 0; k2 < 3; ++k2) {
+            const int u = 16 * k2 + col;                                 // feature inside the 48-wide colour input
+            if (k2 == 0) { if (u >= 1) put(W::OW3 + R * X2 + u - 1, G.dW3[k2][rr]); }
+            else if (u < ONES_SLOT) put(W::OW3 + R * X2 + u - 1, G.dW3[k2][rr]);
+            else if (u == ONES_SLOT) put(W::OB3 + R, G.dW3[k2][rr]);
         }
         // shared bias block: row = combo, column = neuron inside its 16-block
-        if (row < Q) put(W::OB4 + 16 * (wave + 4 * row) + col, G.db[rr]);
-        else if (row < 2 * Q) put(W::OB1 + 16 * (wave + 4 * (row - Q)) + col, G.db[rr]);
-        else if (wave == 0 && row == 2 * Q) put(W::OB2 + col, G.db[rr]);
-        else if (wave == 0 && row == 2 * Q + 1 && col < 3) put(W::OB5 + col, G.db[rr]);
+        if (row == 0) put(W::OB4 + 16 * wave + col, G.db[rr]);
+        else if (row == 1) put(W::OB1 + 16 * wave + col, G.db[rr]);
+        else if (wave == 0 && row == 2) put(W::OB2 + col, G.db[rr]);
+        else if (wave == 0 && row == 3 && col < 3) put(W::OB5 + col, G.db[rr]);
     }
 }
 
@@ -566,7 +599,7 @@ int wide_forward(const void* feats, const float* dirs, int64_t S, int in_dim, co
     static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_wide", hipGetErrorString(e));
     const int64_t ntiles = (S + TS - 1) / TS;
-    const int grid = (int)min64(ceil_div64(ntiles, WF_WAVES), cu_count_w());
+    const int grid = (int)min64(ceil_div64(ntiles, WF_WAVES), 2 * cu_count_w());      // 66 KB of LDS: two workgroups per CU
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WF_WAVES * 64), lds, st, (const TIO*)feats, dirs, S, in_dim, params, rgb, density);
     return 0;
 }
@@ -576,7 +609,7 @@ int wide_backward(const void* feats, const float* dirs, int64_t S, int in_dim, c
                   const float* grad_density, void* grad_feats, float* grad_params, void* workspace, hipStream_t st) {
     typedef Wide<HH> W;
     const size_t lds_c = (size_t)W::L_BWD_END * 2 + (size_t)W::BIASV_FLOATS * 4;
-    const size_t lds_d = (size_t)W::L_FWD_END * 2 + (size_t)W::BIASV_FLOATS * 4 + (size_t)WD_WAVES * 2 * W::IMG_BYTES;
+    const size_t lds_d = (size_t)W::L_FWD_END * 2 + (size_t)W::BIASV_FLOATS * 4 + (size_t)WD_TILES * 2 * W::IMG_BYTES;
     auto kc = wide_chain_kernel<HH, TIO>;
     auto kd = wide_dw_kernel<HH, TIO>;
     static const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
