@@ -263,17 +263,21 @@ static __device__ __forceinline__ bool tail_compute(const float* c, bool live, i
     // v_fmac_f32 with the DPP shift on its first source per value (lanes whose source is outside the row / row mask keep v).
     // Written as inline asm because the compiler otherwise splits it into v_mov_dpp + packed fma + register shuffles; the
     // leading s_nop covers the VALU-write -> DPP-read hazard the assembler does not see.  (A non-finite gradient would
-    // leak into neighbouring runs through 0 * inf - gradients that far gone are lost anyway.)
+    // leak into neighbouring runs through 0 * inf - gradients that far gone are lost anyway.)  A step in which NO lane of
+    // the wave takes anything (no run longer than the step's distance: the usual case on the fine levels, where a cell
+    // holds two or three consecutive samples) is skipped with one scalar branch.
 #define HG_SEG_STEP(CTRL, RMASK, DPPSTR, VALID)                                                            \
     {                                                                                                      \
-        const int fp = __builtin_amdgcn_update_dpp(1, f, CTRL, RMASK, 0xf, false);                         \
         const bool take = (VALID) && !f;                                                                   \
-        const float tk = take ? 1.0f : 0.0f;                                                               \
-        asm volatile("s_nop 1");                                                                           \
-        _Pragma("unroll") for (int j = 0; j < (1 << DIM); ++j)                                             \
-            _Pragma("unroll") for (int k = 0; k < F; ++k)                                                  \
-                asm volatile("v_fmac_f32_dpp %0, %0, %1 " DPPSTR : "+v"(v[j][k]) : "v"(tk));                 \
-        if (take) f |= fp;                                                                                 \
+        if (__builtin_amdgcn_ballot_w64(take) != 0) {      /* wave-uniform: no run reaches back this far -> skip */ \
+            const int fp = __builtin_amdgcn_update_dpp(1, f, CTRL, RMASK, 0xf, false);                     \
+            const float tk = take ? 1.0f : 0.0f;                                                           \
+            asm volatile("s_nop 1");                                                                       \
+            _Pragma("unroll") for (int j = 0; j < (1 << DIM); ++j)                                         \
+                _Pragma("unroll") for (int k = 0; k < F; ++k)                                              \
+                    asm volatile("v_fmac_f32_dpp %0, %0, %1 " DPPSTR : "+v"(v[j][k]) : "v"(tk));             \
+            if (take) f |= fp;                                                                             \
+        }                                                                                                  \
     }
     HG_SEG_STEP(0x111, 0xf, "row_shr:1 row_mask:0xf bank_mask:0xf", (lane & 15) >= 1)
     HG_SEG_STEP(0x112, 0xf, "row_shr:2 row_mask:0xf bank_mask:0xf", (lane & 15) >= 2)
@@ -471,6 +475,142 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
                     }
                 }
             }
+        }
+    }
+    __syncthreads();
+    for (int li = 0; li < levels.n; ++li) {
+        const int chunks = bins.chunks[li];
+        const uint32_t cap = bins.cap[li];
+        const uint32_t* rank_l = s_rank + bins.rank_base[li];
+        uint32_t* __restrict__ cnt_l = counts + bins.cnt_base[li];
+        for (int b = threadIdx.x; b < chunks; b += EM_THREADS) {
+            const uint32_t cn = rank_l[b];
+            cnt_l[(size_t)b * ntiles + blockIdx.x] = cn < cap ? cn : cap;
+        }
+    }
+}
+
+// Emit kernel for the training shape: two features in a 16-bit gradient tensor (compact 2-dword records), at most 16 levels.
+// Same slots / counts / records as the generic kernel above, two differences:
+//   * a lane keeps the whole gradient row of its sample (num_lods dwords, 64 contiguous bytes) in REGISTERS - four
+//     coalesced 16-byte loads per sample, no LDS staging pass, no staging barrier;
+//   * record emission is split from the scan.  Only the run tails have something to emit - 2 lanes of 64 on the coarsest
+//     levels, about half of them on the finest - and ranking + addressing + packing + storing cost ~19 vector
+//     instructions per corner whatever the number of live lanes: 150 of the ~400 instructions of a (64 samples, level)
+//     pass.  Here the tails park (index, v0, v1) of their corners in the wave's LDS queue ([tail][corner], row stride
+//     3 * corners + 1 dwords: conflict free both ways) and the wave then walks the queue with ALL lanes busy, lane = one
+//     (tail, corner) entry: ceil(tails / 8) passes instead of 8.  LDS instructions of one wave execute in order, so the
+//     hand-over needs no barrier.
+#define EQ_MAX_ROW 16
+template <typename T, int DIM>
+__global__ void __launch_bounds__(EM_THREADS, EM_MIN_WAVES)
+hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ grad_feats,
+                           const int64_t* __restrict__ first_idx, HashLevels lv, LevelList levels, int num_lods,
+                           uint32_t tsize, int tsize_pow2, int zero_from_col, int chunk_shift, BinLevels bins,
+                           uint32_t* __restrict__ counts, uint32_t* __restrict__ records, float* __restrict__ grad_codebook) {
+    constexpr int F = 2;
+    constexpr int NC = 1 << DIM;
+    typedef RecordCodec<T, F> Codec;
+    static_assert(Codec::COMPACT, "two 16-bit features per level");
+    constexpr int RW = Codec::RW;
+    constexpr int GROUPS = EM_TILE / EM_THREADS;
+    constexpr int QROW = 3 * NC + 1;                     // dwords per parked tail
+    extern __shared__ __attribute__((aligned(16))) uint32_t em_smem[];
+    const int total_ranks = bins.rank_base[levels.n];
+    uint32_t* s_rank = em_smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint32_t* s_queue = em_smem + ((total_ranks + 3) & ~3) + wave * (64 * QROW);
+    const uint32_t ntiles = gridDim.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * EM_TILE;
+    const int64_t total_rows = first_idx[num_lods];
+    for (int b = threadIdx.x; b < total_ranks; b += EM_THREADS) s_rank[b] = 0;
+    float c[GROUPS][DIM];
+    bool live[GROUPS];
+    typedef uint32_t row_t __attribute__((ext_vector_type(EQ_MAX_ROW)));     // indexed by the (wave-uniform) level: v_movrels
+    row_t grow[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+        const int64_t i = tile0 + (int64_t)(wave * GROUPS + g) * 64 + lane;
+        live[g] = i < n;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) c[g][a] = live[g] ? coords[i * DIM + a] : 0.0f;
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(grad_feats) + (live[g] ? i : 0) * num_lods;
+        if (num_lods == EQ_MAX_ROW) {
+#pragma unroll
+            for (int q = 0; q < EQ_MAX_ROW / 4; ++q) {
+                const uint4 t = reinterpret_cast<const uint4*>(src)[q];
+                grow[g][4 * q] = t.x; grow[g][4 * q + 1] = t.y; grow[g][4 * q + 2] = t.z; grow[g][4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < EQ_MAX_ROW; ++q) grow[g][q] = q < num_lods ? src[q] : 0u;
+        }
+    }
+    __syncthreads();
+    // lane -> (tail, corner) of a queue pass
+    const uint32_t q_lane = (uint32_t)((lane / NC) * QROW + (lane % NC) * 3);
+    for (int li = 0; li < levels.n; ++li) {
+        const int l = levels.lv[li];
+        const int32_t res = lv.res[l];
+        const bool dense = lv.dense[l] != 0;
+        const uint32_t cap = bins.cap[li];
+        uint32_t* rank_l = s_rank + bins.rank_base[li];
+        uint32_t* __restrict__ rec_l = records + (size_t)bins.rec_base[li] * RW;
+        const uint32_t bucket_stride = __builtin_amdgcn_readfirstlane(ntiles * cap);
+        const uint32_t slot0 = __builtin_amdgcn_readfirstlane(blockIdx.x * cap);
+        const int64_t base_l = first_idx[l];
+        const int64_t rows_l = first_idx[l + 1] - base_l;
+        const uint32_t owned = (uint32_t)(rows_l < (int64_t)bins.entries[li] ? (rows_l < 0 ? 0 : rows_l) : (int64_t)bins.entries[li]);
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            CornerSetup<DIM> cs;
+            float v[NC][F];
+            uint32_t gw = grow[g][l & (EQ_MAX_ROW - 1)];
+            const bool issue = tail_compute<T, F, DIM, true>(c[g], live[g], l, res, dense, tsize, tsize_pow2 != 0, zero_from_col,
+                                                             reinterpret_cast<const T*>(&gw), lane, cs, v);
+            const uint64_t tails = __builtin_amdgcn_ballot_w64(issue);
+            if (tails == 0) continue;
+            if (issue) {
+                const uint32_t t = __builtin_amdgcn_mbcnt_hi((uint32_t)(tails >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tails, 0u));
+                uint32_t* q = s_queue + t * QROW;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    q[3 * j] = (uint32_t)cs.idx[j];
+                    q[3 * j + 1] = __float_as_uint(v[j][0]);
+                    q[3 * j + 2] = __float_as_uint(v[j][1]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t total = (uint32_t)__popcll(tails) * NC;
+            for (uint32_t p = 0; p < total; p += 64) {
+                if (p + lane < total) {
+                    const uint32_t* q = s_queue + (p / NC) * QROW + q_lane;
+                    const uint32_t idx = q[0];
+                    float val[F];
+                    val[0] = __uint_as_float(q[1]);
+                    val[1] = __uint_as_float(q[2]);
+                    const uint32_t b = idx >> chunk_shift;
+                    // an index past the rows the level owns has no bucket (and no rank counter): straight to the atomic
+                    const uint32_t pos = idx < owned ? atomicAdd(&rank_l[b], 1u) : 0xffffffffu;
+                    if (pos < cap) {
+                        uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos) * RW);   // < 2^32 dwords (bin_plan)
+                        Codec::store(dst, idx, (1u << chunk_shift) - 1u, val);
+                    } else {
+                        // slot full, or a spill index (lands where the reference's pointer arithmetic puts it, .cu:124-161,
+                        // unless that is past the whole table)
+                        const int64_t row = base_l + (int64_t)idx;
+                        if (row < total_rows) {
+                            float* pg = grad_codebook + row * F;
+                            atomicAdd(pg, val[0]);
+                            atomicAdd(pg + 1, val[1]);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
@@ -757,11 +897,26 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     }
     uint32_t* counts = (uint32_t*)workspace;              // every count cell is written by the emit kernel: no memset
     uint32_t* records = (uint32_t*)((char*)workspace + plan.count_bytes);
-    auto em = hashgrid_bwd_emit_kernel<T, F, DIM>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)em_lds);
-    hipLaunchKernelGGL(em, dim3((unsigned)plan.ntiles), dim3(EM_THREADS), em_lds, s,
-                       coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
-                       plan.chunk_shift, plan.bins, counts, records, grad_codebook);
+    bool launched = false;
+    if constexpr (RecordCodec<T, F>::COMPACT) {
+        static const bool use_queue = env_flag("WISP_HG_BWD_QUEUE", true);
+        if (use_queue && num_lods <= EQ_MAX_ROW) {
+            const size_t q_lds = ((size_t)((plan.total_ranks + 3) & ~3) + (size_t)(EM_THREADS / 64) * 64 * (3 * (1 << DIM) + 1)) * 4;
+            auto eq = hashgrid_bwd_emit_q_kernel<T, DIM>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds);
+            hipLaunchKernelGGL(eq, dim3((unsigned)plan.ntiles), dim3(EM_THREADS), q_lds, s,
+                               coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
+                               plan.chunk_shift, plan.bins, counts, records, grad_codebook);
+            launched = true;
+        }
+    }
+    if (!launched) {
+        auto em = hashgrid_bwd_emit_kernel<T, F, DIM>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)em_lds);
+        hipLaunchKernelGGL(em, dim3((unsigned)plan.ntiles), dim3(EM_THREADS), em_lds, s,
+                           coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
+                           plan.chunk_shift, plan.bins, counts, records, grad_codebook);
+    }
     const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 8;
     auto rd = hashgrid_bwd_reduce_kernel<T, F, AccFix64>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
