@@ -247,15 +247,14 @@ static __device__ __forceinline__ bool tail_compute(const float* c, bool live, i
     if (DIM > 1) key_xy |= cs.cell[1] << 16;
     if (DIM > 2) key_z = cs.cell[2];
     if (!live) key_z = -1 - lane;                          // never equal to a neighbour
-    // wave_shr:1 / wave_shl:1 DPP moves (lane 0 / lane 63 keep their own value; both are forced below).  All four are
-    // evaluated unconditionally: a cross-lane read under a short-circuited '&&' would run with a partial exec mask.
+    // wave_shr:1 DPP move (lane 0 keeps its own value and is forced to be a head below)
     const int32_t prev_xy = __builtin_amdgcn_update_dpp(key_xy, key_xy, 0x138, 0xf, 0xf, false);
     const int32_t prev_z = __builtin_amdgcn_update_dpp(key_z, key_z, 0x138, 0xf, 0xf, false);
-    const int32_t next_xy = __builtin_amdgcn_update_dpp(key_xy, key_xy, 0x130, 0xf, 0xf, false);
-    const int32_t next_z = __builtin_amdgcn_update_dpp(key_z, key_z, 0x130, 0xf, 0xf, false);
-    const bool same_as_prev = (key_xy == prev_xy) & (key_z == prev_z);
-    const bool same_as_next = (key_xy == next_xy) & (key_z == next_z);
-    int f = (lane == 0 || !same_as_prev) ? 1 : 0;          // run-head flag
+    // Run-head flags of the whole wave as ONE 64-bit scalar: everything the scan needs to know about the flags (who takes
+    // its predecessor's partial sum in a step, how the flags combine, which lanes are run tails) is bit arithmetic on the
+    // scalar unit; the vector unit only does the value updates.
+    uint64_t heads = __builtin_amdgcn_ballot_w64((key_xy != prev_xy) | (key_z != prev_z)) | 1ull;
+    const uint64_t tails = (heads >> 1) | 0x8000000000000000ull;      // lane i ends a run iff lane i + 1 starts one
     // Segmented inclusive scan on the VALU (DPP), no LDS traffic: four row_shr steps inside each 16-lane row, then the
     // row totals are carried across rows with row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3).  (v, f) pairs
     // combine as (v1,f1)+(v2,f2) = (f2 ? v2 : v1+v2, f1|f2), which is associative, so the row carries compose.
@@ -266,27 +265,32 @@ static __device__ __forceinline__ bool tail_compute(const float* c, bool live, i
     // leak into neighbouring runs through 0 * inf - gradients that far gone are lost anyway.)  A step in which NO lane of
     // the wave takes anything (no run longer than the step's distance: the usual case on the fine levels, where a cell
     // holds two or three consecutive samples) is skipped with one scalar branch.
-#define HG_SEG_STEP(CTRL, RMASK, DPPSTR, VALID)                                                            \
+#define HG_SEG_STEP(DPPSTR, VALID, SRC_FLAGS)                                                              \
     {                                                                                                      \
-        const bool take = (VALID) && !f;                                                                   \
-        if (__builtin_amdgcn_ballot_w64(take) != 0) {      /* wave-uniform: no run reaches back this far -> skip */ \
-            const int fp = __builtin_amdgcn_update_dpp(1, f, CTRL, RMASK, 0xf, false);                     \
-            const float tk = take ? 1.0f : 0.0f;                                                           \
-            asm volatile("s_nop 1");                                                                       \
+        const uint64_t take = (VALID) & ~heads;                                                            \
+        if (take != 0) {                                                                                   \
+            float tk;                                                                                      \
+            asm volatile("v_cndmask_b32_e64 %0, 0, 1.0, %1\n\ts_nop 1" : "=v"(tk) : "s"(take));            \
             _Pragma("unroll") for (int j = 0; j < (1 << DIM); ++j)                                         \
                 _Pragma("unroll") for (int k = 0; k < F; ++k)                                              \
                     asm volatile("v_fmac_f32_dpp %0, %0, %1 " DPPSTR : "+v"(v[j][k]) : "v"(tk));             \
-            if (take) f |= fp;                                                                             \
+            heads |= take & (SRC_FLAGS);                                                                   \
         }                                                                                                  \
     }
-    HG_SEG_STEP(0x111, 0xf, "row_shr:1 row_mask:0xf bank_mask:0xf", (lane & 15) >= 1)
-    HG_SEG_STEP(0x112, 0xf, "row_shr:2 row_mask:0xf bank_mask:0xf", (lane & 15) >= 2)
-    HG_SEG_STEP(0x114, 0xf, "row_shr:4 row_mask:0xf bank_mask:0xf", (lane & 15) >= 4)
-    HG_SEG_STEP(0x118, 0xf, "row_shr:8 row_mask:0xf bank_mask:0xf", (lane & 15) >= 8)
-    HG_SEG_STEP(0x142, 0xa, "row_bcast:15 row_mask:0xa bank_mask:0xf", (lane >> 4) & 1)      // rows 1 and 3
-    HG_SEG_STEP(0x143, 0xc, "row_bcast:31 row_mask:0xc bank_mask:0xf", lane >= 32)           // rows 2 and 3
+    HG_SEG_STEP("row_shr:1 row_mask:0xf bank_mask:0xf", 0xfffefffefffefffeull, heads << 1)
+    HG_SEG_STEP("row_shr:2 row_mask:0xf bank_mask:0xf", 0xfffcfffcfffcfffcull, heads << 2)
+    HG_SEG_STEP("row_shr:4 row_mask:0xf bank_mask:0xf", 0xfff0fff0fff0fff0ull, heads << 4)
+    HG_SEG_STEP("row_shr:8 row_mask:0xf bank_mask:0xf", 0xff00ff00ff00ff00ull, heads << 8)
+    HG_SEG_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf", 0xffff0000ffff0000ull,                      // rows 1 and 3
+                (((heads >> 15) & 1ull) ? 0x00000000ffff0000ull : 0ull) | (((heads >> 47) & 1ull) ? 0xffff000000000000ull : 0ull))
+    HG_SEG_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf", 0xffffffff00000000ull,                      // rows 2 and 3
+                ((heads >> 31) & 1ull) ? 0xffffffff00000000ull : 0ull)
 #undef HG_SEG_STEP
-    return live && (lane == 63 || !same_as_next);         // run tail holds the run total
+    // run tail holds the run total
+    const uint64_t emitters = tails & __builtin_amdgcn_ballot_w64(live);
+    uint32_t is_tail;
+    asm volatile("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(is_tail) : "s"(emitters));
+    return is_tail != 0;
 }
 
 // direct-atomic path: wave w of a workgroup handles level levels.lv[w] for a tile of 64 samples
@@ -633,8 +637,14 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
 struct AccFix64 {
     typedef unsigned long long type;
     static __device__ __forceinline__ void add(type* acc, uint32_t i, float v) {
-        const long long q = (long long)((double)v * 17592186044416.0);                                      // 2^44
-        atomicAdd(acc + i, (unsigned long long)q);                                                           // ds_add_u64
+        // trunc(v * 2^44) without fp64: |v| * 2^12 is exact, so are its floor (the high word) and the remainder in [0, 1)
+        // (the low word); the sign is applied to the 64-bit magnitude
+        const float a = fabsf(v) * 4096.0f;
+        const float h = floorf(a);
+        const unsigned long long mag = ((unsigned long long)(uint32_t)h << 32) | (uint32_t)((a - h) * 4294967296.0f);
+        const unsigned long long sgn = (unsigned long long)(long long)((int32_t)__float_as_uint(v) >> 31);   // 0 or ~0
+        const unsigned long long q = (mag ^ sgn) - sgn;
+        atomicAdd(acc + i, q);                                                                               // ds_add_u64
     }
     static __device__ __forceinline__ float get(const type* acc, uint32_t i) {
         return (float)((double)(long long)acc[i] * (1.0 / 17592186044416.0));
@@ -652,10 +662,12 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
     extern __shared__ __attribute__((aligned(16))) unsigned char rd_smem[];
     acc_t* rd_acc = reinterpret_cast<acc_t*>(rd_smem);                  // [chunk entries * F]
     // flattened (level, bucket, split) grid
+    // heaviest first: the fine (hashed) levels carry most of the records, the cheap coarse buckets fill the tail of the grid
+    const int bid = (int)(gridDim.x - 1u - blockIdx.x);
     int li = 0;
-    while (li + 1 < levels.n && (int)blockIdx.x >= bins.blk_base[li + 1]) ++li;
+    while (li + 1 < levels.n && bid >= bins.blk_base[li + 1]) ++li;
     const int splits = bins.splits[li];
-    const int local = (int)blockIdx.x - bins.blk_base[li];
+    const int local = bid - bins.blk_base[li];
     const int b = local / splits, z = local - b * splits;
     const int l = levels.lv[li];
     const uint32_t csize = 1u << chunk_shift;

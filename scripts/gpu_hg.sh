@@ -7,4 +7,10 @@ echo "pytest exit: $?" >> gpurun_out/pytest_hg.log
 tail -5 gpurun_out/pytest_hg.log
 for q in 0 1 0 1; do WISP_HG_BWD_QUEUE=$q timeout 300 python scripts/ab_kernels.py 2>&1 | grep -v amdgpu.ids | tail -1 | sed "s/^/queue=$q /"; done | tee gpurun_out/ab_hg.log
 (cd /tmp && rm -rf /tmp/prof_hg && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_hg -o hg -- python "$GRAFT_REPO_ROOT/scripts/ab_kernels.py" > /dev/null 2>&1)
-find /tmp/prof_hg -name "*kernel_stats.csv" -exec cat {} \; | grep -i "hashgrid" | cut -d, -f1-4 | sed 's/(.*)//' | cut -c1-160 | tee gpurun_out/hg_stats.txt
+python - <<'PY' | tee gpurun_out/hg_stats.txt
+import csv, glob
+for f in glob.glob('/tmp/prof_hg/**/*kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'hashgrid' in r['Name'] or 'mlp' in r['Name']:
+            print(r['Name'].split('(')[0][-60:], r['Calls'], r['AverageNs'])
+PY

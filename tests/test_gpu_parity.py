@@ -110,7 +110,9 @@ def test_hashgrid_backward_slot_overflow_falls_back_to_atomics():
     go = rng.normal(size=(n, 32)).astype(np.float32)
     want = ohash.hashgrid_backward(torch.from_numpy(coords), torch.from_numpy(go), shape, torch.from_numpy(begin), NGP_RES, 19,
                                    torch.float64)
-    for dt, tol in ((torch.float32, 3e-6), (torch.bfloat16, 1e-4)):
+    # fp32: the overflow path sums ~12 K fp32 atomics per entry in an order that changes from run to run (random-walk rounding
+    # error ~ sqrt(N) * 2^-24 of the running sum: a few 1e-6 of the result's scale)
+    for dt, tol in ((torch.float32, 1.5e-5), (torch.bfloat16, 1e-4)):
         g = torch.from_numpy(go).to(dt)
         want_d = want if dt == torch.float32 else ohash.hashgrid_backward(
             torch.from_numpy(coords), g.float(), shape, torch.from_numpy(begin), NGP_RES, 19, torch.float64)
