@@ -244,8 +244,8 @@ static __device__ __forceinline__ bool tail_compute(const float* c, bool live, i
     // Two samples belong to one run iff they sit in the same cell.  Only NEIGHBOURING lanes are ever compared, so the cell
     // is carried as (x | y << 16, z) - exact for res <= 65536 (checked on the host), no integer multiplies.
     int32_t key_xy = cs.cell[0], key_z = 0;
-    if (DIM > 1) key_xy |= cs.cell[1] << 16;
-    if (DIM > 2) key_z = cs.cell[2];
+    if constexpr (DIM > 1) key_xy |= cs.cell[1] << 16;
+    if constexpr (DIM > 2) key_z = cs.cell[2];
     if (!live) key_z = -1 - lane;                          // never equal to a neighbour
     // wave_shr:1 DPP move (lane 0 keeps its own value and is forced to be a head below)
     const int32_t prev_xy = __builtin_amdgcn_update_dpp(key_xy, key_xy, 0x138, 0xf, 0xf, false);
@@ -526,9 +526,16 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
     const int wave = threadIdx.x >> 6;
     uint32_t* s_queue = em_smem + ((total_ranks + 3) & ~3) + wave * (64 * QROW);
     const uint32_t ntiles = gridDim.x;
-    const int64_t tile0 = (int64_t)blockIdx.x * EM_TILE;
     const int64_t total_rows = first_idx[num_lods];
     for (int b = threadIdx.x; b < total_ranks; b += EM_THREADS) s_rank[b] = 0;
+    __syncthreads();
+    // lane -> (tail, corner) of a queue pass
+    const uint32_t q_lane = (uint32_t)((lane / NC) * QROW + (lane % NC) * 3);
+    // The grid is capped at what the chip holds at once; a workgroup takes the EM_TILE pieces blockIdx, blockIdx + grid, ...
+    // and all of them feed the same slots (the rank counters live on).  No barrier inside: the waves drift freely.
+    const int64_t pieces = (n + EM_TILE - 1) / EM_TILE;
+    for (int64_t piece = blockIdx.x; piece < pieces; piece += gridDim.x) {
+    const int64_t tile0 = piece * EM_TILE;
     float c[GROUPS][DIM];
     bool live[GROUPS];
     typedef uint32_t row_t __attribute__((ext_vector_type(EQ_MAX_ROW)));     // indexed by the (wave-uniform) level: v_movrels
@@ -551,9 +558,6 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
             for (int q = 0; q < EQ_MAX_ROW; ++q) grow[g][q] = q < num_lods ? src[q] : 0u;
         }
     }
-    __syncthreads();
-    // lane -> (tail, corner) of a queue pass
-    const uint32_t q_lane = (uint32_t)((lane / NC) * QROW + (lane % NC) * 3);
     for (int li = 0; li < levels.n; ++li) {
         const int l = levels.lv[li];
         const int32_t res = lv.res[l];
@@ -617,6 +621,7 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
             __builtin_amdgcn_wave_barrier();
         }
     }
+    }   // pieces
     __syncthreads();
     for (int li = 0; li < levels.n; ++li) {
         const int chunks = bins.chunks[li];
@@ -628,6 +633,25 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
             cnt_l[(size_t)b * ntiles + blockIdx.x] = cn < cap ? cn : cap;
         }
     }
+}
+
+// queue + rank counters
+static inline size_t queue_emitter_lds(int total_ranks, int dim) {
+    return ((size_t)((total_ranks + 3) & ~3) + (size_t)(EM_THREADS / 64) * 64 * (3 * (1 << dim) + 1)) * 4;
+}
+// Workgroups of the queue emitter one CU holds at once (registers + LDS; asked from the runtime, once per instance; the
+// half and bf16 instances are the same code).  The rank counters vary a little with the level layout: 1024 is a safe figure.
+template <typename T, int DIM>
+static int queue_emitter_residency() {
+    static const int v = [] {
+        int nb = 0;
+        auto eq = hashgrid_bwd_emit_q_kernel<T, DIM>;
+        const size_t lds = queue_emitter_lds(1024, DIM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eq, EM_THREADS, lds) != hipSuccess || nb <= 0) nb = 2;
+        return nb;
+    }();
+    return v;
 }
 
 // LDS accumulator of the reduce kernel.  LDS *float* atomics (ds_add_f32) turned out to retire roughly one lane per
@@ -821,15 +845,38 @@ static bool env_flag(const char* name, bool dflt) {
 static bool bwd_merge_enabled() { static const bool v = env_flag("WISP_HG_BWD_MERGE", true); return v; }
 static bool bwd_bin_enabled() { static const bool v = env_flag("WISP_HG_BWD_BIN", true); return v; }
 
+static bool queue_emitter_enabled() { static const bool v = env_flag("WISP_HG_BWD_QUEUE", true); return v; }
+// workgroups of the queue emitter the chip holds at once; 0 = no cap
+static int64_t queue_emitter_grid_cap(int resident_per_cu) {
+    static const int forced = [] { const char* e = getenv("WISP_HG_EMIT_WGS_PER_CU"); return e && e[0] ? atoi(e) : -1; }();
+    const int per_cu = forced >= 0 ? forced : resident_per_cu;
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return per_cu > 0 ? (int64_t)per_cu * cus : 0;
+}
+
 // bin geometry shared by the workspace query and the launcher
 struct BinPlan { int chunk_shift, max_chunks, max_splits, total_blocks, total_ranks; int64_t ntiles; BinLevels bins; int64_t count_bytes, record_bytes; bool ok; };
 static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels, int feature_dim, int64_t tsize, int dim,
-                        int rec_dwords) {
+                        int rec_dwords, int64_t max_emitters = 0) {
     BinPlan p{};
     const int corners = 1 << dim;
     int64_t centries = 16384 / feature_dim;               // chunk entries: 64 KiB as fp32, 128 KiB as 64-bit fixed point
     while (((int64_t)1 << (p.chunk_shift + 1)) <= centries) ++p.chunk_shift;
+    // "tile" = what ONE emitting workgroup sends: EM_TILE samples, or (queue emitter) several EM_TILE pieces when the grid is
+    // capped at the number of workgroups the chip holds at once - fewer, fuller slots for the reduce kernel to walk
+    // (its loads then run with all 64 lanes busy: 200 -> 160 us at 2 M samples)
     p.ntiles = ceil_div64(n, EM_TILE);
+    int64_t tile_samples = EM_TILE;
+    if (max_emitters > 0 && p.ntiles > max_emitters) {
+        const int64_t pieces_per_wg = ceil_div64(p.ntiles, max_emitters);
+        tile_samples = pieces_per_wg * EM_TILE;
+        p.ntiles = ceil_div64(p.ntiles, pieces_per_wg);       // same makespan as max_emitters workgroups, no idle slots
+    }
     int64_t cnt = 0, rec = 0;
     p.ok = true;
     for (int li = 0; li < levels.n; ++li) {
@@ -849,11 +896,18 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         // 1024 ray-ordered samples has ever been seen to send more than ~800 merged records to one dense level, hence the
         // 2048 ceiling.  Overflow falls back to atomics, so the bound only has to be a good guess: 2.5 GB of scratch for
         // 2 M samples at the nerf_hash shape instead of the 4.5 GB the no-merge worst case asked for.
-        int64_t cap = ((int64_t)EM_TILE * corners + chunks - 1) / chunks;
+        int64_t cap = (tile_samples * corners + chunks - 1) / chunks;
         cap = lv.dense[l] ? cap * 2 : cap + cap / 4;
         if (cap < 128) cap = 128;
-        if (lv.dense[l] && cap > 2048) cap = 2048;
-        if (cap > (int64_t)EM_TILE * corners) cap = (int64_t)EM_TILE * corners;
+        if (lv.dense[l] && cap > 2048 * (tile_samples / EM_TILE)) cap = 2048 * (tile_samples / EM_TILE);
+        if (cap > tile_samples * corners) cap = tile_samples * corners;
+        if (max_emitters > 0) {
+            // slot stride = an ODD multiple of 32 records (256 B in the compact form): the workgroups of a capped grid run
+            // roughly in step and write slot b at b * stride + (a common offset) - an even multiple would put them on a
+            // fraction of the memory channels
+            cap = (cap + 31) / 32;
+            cap = (cap | 1) * 32;
+        }
         if (chunks > BIN_MAX_CHUNKS || entries > 0xffffffffLL || chunks * p.ntiles * cap * rec_dwords > 0xffffffffLL) p.ok = false;
         p.bins.chunks[li] = (int32_t)chunks;
         p.bins.cap[li] = (uint32_t)cap;
@@ -892,7 +946,13 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     for (int l = 0; l < num_lods; ++l)
         if (l * F < zero_from_col) active.lv[active.n++] = l;
     if (active.n == 0) return 0;
-    const BinPlan plan = bin_plan(n, lv, active, F, (int64_t)tsize, DIM, RecordCodec<T, F>::RW);
+    bool queue_emitter = false;
+    int64_t max_emitters = 0;
+    if constexpr (RecordCodec<T, F>::COMPACT) {
+        queue_emitter = queue_emitter_enabled() && num_lods <= EQ_MAX_ROW;
+        if (queue_emitter) max_emitters = queue_emitter_grid_cap(queue_emitter_residency<__hip_bfloat16, DIM>());   // (as the workspace query)
+    }
+    const BinPlan plan = bin_plan(n, lv, active, F, (int64_t)tsize, DIM, RecordCodec<T, F>::RW, max_emitters);
     // emit kernel LDS: rank counters of every (level, bucket) + the tile's gradient rows
     const size_t em_lds = ((size_t)plan.total_ranks + (size_t)EM_TILE * ((num_lods * ((F * (int)sizeof(T)) / 4)) | 1)) * 4;
     const bool can_bin = merge && bwd_bin_enabled() && workspace && plan.ok && em_lds <= 150 * 1024 &&
@@ -911,9 +971,8 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     uint32_t* records = (uint32_t*)((char*)workspace + plan.count_bytes);
     bool launched = false;
     if constexpr (RecordCodec<T, F>::COMPACT) {
-        static const bool use_queue = env_flag("WISP_HG_BWD_QUEUE", true);
-        if (use_queue && num_lods <= EQ_MAX_ROW) {
-            const size_t q_lds = ((size_t)((plan.total_ranks + 3) & ~3) + (size_t)(EM_THREADS / 64) * 64 * (3 * (1 << DIM) + 1)) * 4;
+        if (queue_emitter) {
+            const size_t q_lds = queue_emitter_lds(plan.total_ranks, DIM);
             auto eq = hashgrid_bwd_emit_q_kernel<T, DIM>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds);
             hipLaunchKernelGGL(eq, dim3((unsigned)plan.ntiles), dim3(EM_THREADS), q_lds, s,
@@ -1009,5 +1068,11 @@ extern "C" int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, i
     LevelList all{0, {0}};
     for (int l = 0; l < num_lods; ++l) all.lv[all.n++] = l;
     const BinPlan p = bin_plan(n, lv, all, feature_dim, tsize, coord_dim, 1 + feature_dim);   // widest record form
-    return p.ok ? p.count_bytes + p.record_bytes : 0;
+    int64_t bytes = p.ok ? p.count_bytes + p.record_bytes : 0;
+    if (feature_dim == 2 && num_lods <= EQ_MAX_ROW && queue_emitter_enabled()) {             // the queue emitter's capped grid
+        const int resident = coord_dim == 3 ? queue_emitter_residency<__hip_bfloat16, 3>() : queue_emitter_residency<__hip_bfloat16, 2>();
+        const BinPlan q = bin_plan(n, lv, all, feature_dim, tsize, coord_dim, 2, queue_emitter_grid_cap(resident));
+        if (q.ok && q.count_bytes + q.record_bytes > bytes) bytes = q.count_bytes + q.record_bytes;
+    }
+    return bytes;
 }
