@@ -124,7 +124,7 @@ def work_table(amp, hidden=64):
 
 
 PMC_KERNELS = {"hashgrid_fwd": ["hashgrid_fwd_kernel"],
-               "hashgrid_bwd": ["hashgrid_bwd_emit_kernel", "hashgrid_bwd_reduce_kernel", "hashgrid_bwd_kernel"],
+               "hashgrid_bwd": ["hashgrid_bwd_emit_kernel", "hashgrid_bwd_emit_q_kernel", "hashgrid_bwd_reduce_kernel", "hashgrid_bwd_kernel"],
                "nerf_mlp_fwd": ["mlp_fwd_kernel"], "nerf_mlp_bwd": ["mlp_bwd_kernel", "nerf_mlp_reduce_kernel"]}
 
 
