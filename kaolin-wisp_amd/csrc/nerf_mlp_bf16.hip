@@ -133,9 +133,14 @@ DEV void lane_const(LaneConst& L, const __bf16* sw, const float* P, int lane, co
 }
 
 // forward of one tile; x0 and the view direction are already in registers
-template <bool BIAS_LDS>
+// PIN: a compiler-level memory barrier in front of every layer.  The operand images never change after staging, so without
+// it the optimiser hoists all 26 operand reads (and the bias vectors) out of the tile loop: 256 registers, two waves per SIMD.
+// That is what the backward's chain waves want (they share the SIMD with a 180-register accumulator wave anyway); the forward
+// kernel is bound by the latency of its input loads and wants waves instead: ~110 registers, four per SIMD.
+template <bool BIAS_LDS, bool PIN = false>
 DEV void forward_tile(const LaneConst& L, const float d[3], Acts& A) {
     // L1: h1 = relu(W1 x0 + b1)
+    if (PIN) asm volatile("" ::: "memory");
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         floatx16 acc = BIAS_LDS ? *reinterpret_cast<const floatx16*>(L.bias_lds + t * 32) : L.b1[t];
@@ -145,6 +150,7 @@ DEV void forward_tile(const LaneConst& L, const float d[3], Acts& A) {
         A.h1[2 * t + 1] = pack8<8, true>(acc);
     }
     // L2: y = W2 h1 + b2 (16 rows = accumulator registers 0..7); density = relu(y0); y[1..15] feed the colour MLP
+    if (PIN) asm volatile("" ::: "memory");
     {
         floatx16 acc = zero16();
 #pragma unroll
@@ -157,6 +163,7 @@ DEV void forward_tile(const LaneConst& L, const float d[3], Acts& A) {
     }
     encode_dir(d, L.g, A.x2[1], A.x2[2]);
     // L3: h2 = relu(W3 x2 + b3)   (b3 rides on the ones slot)
+    if (PIN) asm volatile("" ::: "memory");
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         floatx16 acc = zero16();
@@ -166,6 +173,7 @@ DEV void forward_tile(const LaneConst& L, const float d[3], Acts& A) {
         A.h2[2 * t + 1] = pack8<8, true>(acc);
     }
     // L4: h3 = relu(W4 h2 + b4)
+    if (PIN) asm volatile("" ::: "memory");
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         floatx16 acc = BIAS_LDS ? *reinterpret_cast<const floatx16*>(L.bias_lds + 64 + t * 32) : L.b4[t];
@@ -175,6 +183,7 @@ DEV void forward_tile(const LaneConst& L, const float d[3], Acts& A) {
         A.h3[2 * t + 1] = pack8<8, true>(acc);
     }
     // L5: rgb = sigmoid(W5 h3 + b5)  (rows 0..2 = registers 0..2 of the g = 0 lanes)
+    if (PIN) asm volatile("" ::: "memory");
     {
         floatx16 acc = zero16();
 #pragma unroll
@@ -200,19 +209,24 @@ DEV void fetch_inputs(const TIO* __restrict__ feats, const float* __restrict__ d
 // ---------------------------------------------------------------------------------------------- forward kernel
 constexpr int FWD_WAVES = 8;
 
-template <typename TIO, bool NARROW>
+constexpr int FWD_OFF_BIASV = L_FWD_END * 2;
+constexpr int FWD_OFF_STG = FWD_OFF_BIASV + BIASV_FLOATS * 4;
+constexpr int FWD_LDS = FWD_OFF_STG + NPARAM_PAD * 4;
+template <typename TIO, bool NARROW, bool PIN>
 __global__ void __launch_bounds__(FWD_WAVES * 64)
 mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples, int in_dim,
                const float* __restrict__ params, float* __restrict__ out_rgb, float* __restrict__ out_density) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16* sw = reinterpret_cast<__bf16*>(smem);
-    float* stg = reinterpret_cast<float*>(smem + (size_t)L_FWD_END * 2);
+    float* biasv = reinterpret_cast<float*>(smem + FWD_OFF_BIASV);
+    float* stg = reinterpret_cast<float*>(smem + FWD_OFF_STG);
     stage_params<FWD_WAVES * 64>(stg, params, threadIdx.x, NARROW ? in_dim : IN);
     __syncthreads();
     stage_weights<false>(sw, stg, threadIdx.x, FWD_WAVES * 64);
+    if (PIN) stage_bias_vectors(biasv, stg, threadIdx.x, FWD_WAVES * 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LaneConst L;
-    lane_const<false>(L, sw, stg, lane);
+    lane_const<PIN>(L, sw, stg, lane, biasv);
     __syncthreads();
 
     const int64_t ntiles = (num_samples + TS - 1) / TS;
@@ -230,7 +244,7 @@ mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
         const int64_t ns = (tile + stride) * TS + L.n;
         const bool more = tile + stride < ntiles;
         if (more) fetch_inputs<TIO, NARROW>(feats, dirs, ns, ns < num_samples, L.g, in_dim, nx0, nd);
-        forward_tile<false>(L, d, A);
+        forward_tile<PIN, PIN>(L, d, A);
         if (L.g == 0 && live) {
             out_density[s] = fmaxf(A.y0, 0.0f);
             out_rgb[s * 3] = A.sg[0]; out_rgb[s * 3 + 1] = A.sg[1]; out_rgb[s * 3 + 2] = A.sg[2];
@@ -541,13 +555,22 @@ int cu_count() {
 template <typename TIO, bool NARROW>
 int launch_fwd(const void* feats, const float* dirs, int64_t S, int in_dim, const float* params, float* rgb, float* density,
                hipStream_t st) {
-    const size_t lds = (size_t)L_FWD_END * 2 + (size_t)NPARAM_PAD * 4;
-    auto kern = mlp_fwd_kernel<TIO, NARROW>;
-    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
+    const size_t lds = FWD_LDS;
     const int64_t ntiles = (S + TS - 1) / TS;
-    const int grid = (int)min64(ceil_div64(ntiles, FWD_WAVES), cu_count());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, S, in_dim, params, rgb, density);
+    static const int pin = [] { const char* v = getenv("WISP_MLP_FWD_PIN"); return v && v[0] ? atoi(v) : 2; }();   // workgroups per CU; 0 = register-resident weights
+    if (pin > 0) {
+        auto kern = mlp_fwd_kernel<TIO, NARROW, true>;
+        static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
+        const int grid = (int)min64(ceil_div64(ntiles, FWD_WAVES), (int64_t)pin * cu_count());
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, S, in_dim, params, rgb, density);
+    } else {
+        auto kern = mlp_fwd_kernel<TIO, NARROW, false>;
+        static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
+        const int grid = (int)min64(ceil_div64(ntiles, FWD_WAVES), cu_count());
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, S, in_dim, params, rgb, density);
+    }
     return 0;
 }
 
