@@ -16,4 +16,5 @@ timeout 600 python bench.py --hidden 128 --no-cpu-baseline --no-pmc --steps 60 2
 (cd /tmp && rm -rf /tmp/prof && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python "$REPO/bench.py" --steps 60 --pretrain 300 --eval-rays 0 --no-cpu-baseline --no-pmc > "$REPO/gpurun_out/prof.log" 2>&1)
 find /tmp/prof -name "*kernel_stats.csv" -exec cp {} gpurun_out/prof/r02_bench_default_kernel_stats.csv \;
 python scripts/trace_gaps.py /tmp/prof > gpurun_out/prof/r02_step_timeline.txt 2>&1; cat gpurun_out/prof/r02_step_timeline.txt | head -24
+python scripts/trace_gaps.py /tmp/prof hashgrid_fwd 100 > gpurun_out/prof/r02_step_timeline_2p21.txt 2>&1; cat gpurun_out/prof/r02_step_timeline_2p21.txt | head -30
 head -16 gpurun_out/prof/r02_bench_default_kernel_stats.csv | cut -c1-200

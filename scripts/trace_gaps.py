@@ -1,7 +1,9 @@
 """Idle time between kernels of the steady-state training step, from a rocprofv3 --kernel-trace CSV.
-usage: python scripts/trace_gaps.py <dir with *_kernel_trace.csv> [marker kernel substring = hashgrid_fwd]
+usage: python scripts/trace_gaps.py <dir with *_kernel_trace.csv> [marker kernel substring = hashgrid_fwd] [min marker us]
 Steps are delimited by the marker kernel; the last 5 complete steps are summarised: busy time, idle time and the idle
-time attributed to the kernel that FOLLOWS each gap (the launch that arrived late)."""
+time attributed to the kernel that FOLLOWS each gap (the launch that arrived late).  With a minimum marker duration only
+steps whose marker kernel ran at least that long count (bench.py times the 2^21 regime first and the 2^18 regime last:
+`hashgrid_fwd 100` selects the former)."""
 import csv, glob, os, sys, collections
 
 root = sys.argv[1]
@@ -13,10 +15,16 @@ for f in files:
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
+min_ns = float(sys.argv[3]) * 1e3 if len(sys.argv) > 3 else 0.0
 marks = [i for i, r in enumerate(rows) if marker in r[2]]
 if len(marks) < 7:
     sys.exit(f"only {len(marks)} marker kernels found")
-steps = [(marks[i], marks[i + 1]) for i in range(len(marks) - 6, len(marks) - 1)]
+pairs = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1)
+         if rows[marks[i]][1] - rows[marks[i]][0] >= min_ns and rows[marks[i + 1]][1] - rows[marks[i + 1]][0] >= min_ns
+         and marks[i + 1] - marks[i] < 64]
+if len(pairs) < 6:
+    sys.exit(f"only {len(pairs)} qualifying steps found")
+steps = pairs[-6:-1]
 busy = idle = 0
 gap_by = collections.Counter(); time_by = collections.Counter(); n_by = collections.Counter()
 for a, b in steps:
@@ -34,3 +42,11 @@ print(f"steps {n}: wall {(busy + idle) / n / 1e3:.1f} us  busy {busy / n / 1e3:.
 print("kernel".ljust(62), "calls/step   us/step   idle-before us/step")
 for k, t in time_by.most_common():
     print(k.ljust(62), f"{n_by[k] / n:9.1f} {t / n / 1e3:9.1f} {gap_by[k] / n / 1e3:12.1f}")
+# the last summarised step in launch order
+a, b = steps[-1]
+t0 = rows[a][0]
+print("\nlast step in order:  start us   dur us   gap-before us")
+for i in range(a, b):
+    s0, e0, name = rows[i]
+    short = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[-70:]
+    print(f"  {short.ljust(70)} {(s0 - t0) / 1e3:9.1f} {(e0 - s0) / 1e3:8.1f} {max(0, s0 - rows[i - 1][1]) / 1e3:8.1f}")
