@@ -369,6 +369,22 @@ int wisp_nerf_mlp_bwd(const void* feats, int dtype_io, const float* dirs, int64_
                       float* workspace, int64_t workspace_bytes /* >= wisp_nerf_mlp_bwd_workspace_bytes() */,
                       wisp_stream_t stream);
 
+/* The same decoder with the view direction given per RAY.  The reference gathers a direction per sample
+ * (wisp/tracers/packed_rf_tracer.py:70-76 `rays.dirs.index_select(0, ridx)`) and positional_embedder.py:61-65 encodes each
+ * sample; the encoding depends on the ray only, so wisp_nerf_mlp_dir_code encodes every ray once
+ * (code: bf16 [num_rays, 32], opaque layout) and the *_rays kernels gather the code by `ridx` (int64 [S], the ray of every
+ * sample as the raymarch returns it).  Same arithmetic, bit-identical outputs to wisp_nerf_mlp_fwd / _bwd on gathered
+ * directions.  Built for the training shape only: in_dim 32, hidden 64, view_freqs 4, f16 / bf16 features, bf16 compute;
+ * anything else returns WISP_ERR_UNSUPPORTED (use the per-sample entry points). */
+int wisp_nerf_mlp_dir_code(const float* ray_dirs /* [R,3] */, int64_t num_rays, int view_freqs, void* code, wisp_stream_t stream);
+int wisp_nerf_mlp_fwd_rays(const void* feats, int dtype_io, const void* dir_code, const int64_t* ridx, int64_t num_samples,
+                           int in_dim, int hidden, int view_freqs, const float* params, float* rgb, float* density,
+                           wisp_stream_t stream);
+int wisp_nerf_mlp_bwd_rays(const void* feats, int dtype_io, const void* dir_code, const int64_t* ridx, int64_t num_samples,
+                           int in_dim, int hidden, int view_freqs, const float* params, const float* grad_rgb,
+                           const float* grad_density, void* grad_feats, float* grad_params, float* workspace,
+                           int64_t workspace_bytes, wisp_stream_t stream);
+
 /* One-hidden-layer relu decoder with a single output, out = W2 relu(W1 x + b1) + b2 - the NeuralSDF decoder
  * (wisp/models/nefs/neural_sdf.py:102-118; nglod_octree.yaml: 19 -> 128 -> 1; BasicDecoder.forward,
  * wisp/models/decoders/basic_decoders.py:73-101).  x f32 [n, in_dim] (in_dim <= 32), w1 [hidden, in_dim], b1 [hidden],

@@ -537,3 +537,53 @@ extern "C" int wisp_nerf_mlp_bwd(const void* feats, int dtype_io, const float* d
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---- view direction per RAY (hidden 64, bf16 compute, 32-wide 16-bit feature rows: the training shape) ----------------
+// The reference gathers ray directions per sample (packed_rf_tracer.py: rays.dirs.index_select(0, ridx)) and encodes every
+// sample; here the encoding is done once per ray and the decoder kernels gather the 64-byte code by ray index.
+extern "C" int wisp_nerf_mlp_dir_code(const float* ray_dirs, int64_t num_rays, int view_freqs, void* code, wisp_stream_t stream) {
+    WISP_REQUIRE(num_rays >= 0, "negative count");
+    WISP_REQUIRE(view_freqs == NF, "this build supports view_freqs=4");
+    if (num_rays == 0) return WISP_OK;
+    WISP_REQUIRE(ray_dirs && code, "null pointer");
+    wisp_mlp::bf16_dir_code(ray_dirs, num_rays, code, (hipStream_t)stream);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+static int check_rays_shape(int in_dim, int hidden, int view_freqs, int dtype_io) {
+    if (hidden != H || view_freqs != NF || !wisp_mlp::bf16_rays_supported(dtype_io, in_dim))
+        return wisp_fail(WISP_ERR_UNSUPPORTED, "nerf_mlp_rays", "per-ray view codes: in_dim 32, hidden 64, view_freqs 4, f16 / bf16 features");
+    return 0;
+}
+
+extern "C" int wisp_nerf_mlp_fwd_rays(const void* feats, int dtype_io, const void* dir_code, const int64_t* ridx,
+                                      int64_t num_samples, int in_dim, int hidden, int view_freqs, const float* params,
+                                      float* rgb, float* density, wisp_stream_t stream) {
+    WISP_REQUIRE(num_samples >= 0, "negative count");
+    if (int rc = check_rays_shape(in_dim, hidden, view_freqs, dtype_io)) return rc;
+    if (num_samples == 0) return WISP_OK;
+    WISP_REQUIRE(feats && dir_code && ridx && params && rgb && density, "null pointer");
+    if (int rc = wisp_mlp::bf16_forward_rays(feats, dtype_io, dir_code, ridx, num_samples, params, rgb, density, (hipStream_t)stream))
+        return rc;
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_nerf_mlp_bwd_rays(const void* feats, int dtype_io, const void* dir_code, const int64_t* ridx,
+                                      int64_t num_samples, int in_dim, int hidden, int view_freqs, const float* params,
+                                      const float* grad_rgb, const float* grad_density, void* grad_feats, float* grad_params,
+                                      float* workspace, int64_t workspace_bytes, wisp_stream_t stream) {
+    WISP_REQUIRE(num_samples >= 0, "negative count");
+    if (int rc = check_rays_shape(in_dim, hidden, view_freqs, dtype_io)) return rc;
+    if (num_samples == 0) return WISP_OK;
+    WISP_REQUIRE(feats && dir_code && ridx && params && grad_rgb && grad_density && grad_feats && grad_params && workspace, "null pointer");
+    WISP_REQUIRE(workspace_bytes >= wisp_nerf_mlp_bwd_workspace_bytes(num_samples, hidden), "workspace too small (wisp_nerf_mlp_bwd_workspace_bytes)");
+    int rows = 0;
+    if (int rc = wisp_mlp::bf16_backward_rays(feats, dtype_io, dir_code, ridx, num_samples, params, grad_rgb, grad_density, grad_feats,
+                                              workspace, &rows, (hipStream_t)stream))
+        return rc;
+    hipLaunchKernelGGL(nerf_mlp_reduce_kernel, dim3((NPARAM + 63) / 64), dim3(1024), 0, (hipStream_t)stream, workspace, rows, in_dim, grad_params);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

@@ -137,7 +137,8 @@ DEV void lane_const(LaneConst& L, const __bf16* sw, const float* P, int lane, co
 // it the optimiser hoists all 26 operand reads (and the bias vectors) out of the tile loop: 256 registers, two waves per SIMD.
 // That is what the backward's chain waves want (they share the SIMD with a 180-register accumulator wave anyway); the forward
 // kernel is bound by the latency of its input loads and wants waves instead: ~110 registers, four per SIMD.
-template <bool BIAS_LDS, bool PIN = false>
+// CODED: the caller has put the view-direction blocks into A.x2[1..2] already (per-RAY code table, see dir_code_kernel).
+template <bool BIAS_LDS, bool PIN = false, bool CODED = false>
 DEV void forward_tile(const LaneConst& L, const float d[3], Acts& A) {
     // L1: h1 = relu(W1 x0 + b1)
     if (PIN) asm volatile("" ::: "memory");
@@ -161,7 +162,7 @@ DEV void forward_tile(const LaneConst& L, const float d[3], Acts& A) {
         if (L.g == 0) acc[0] = 0.0f;                     // slot of y0 in the colour input (its weight column is zero)
         A.x2[0] = pack8<0, false>(acc);
     }
-    encode_dir(d, L.g, A.x2[1], A.x2[2]);
+    if (!CODED) encode_dir(d, L.g, A.x2[1], A.x2[2]);
     // L3: h2 = relu(W3 x2 + b3)   (b3 rides on the ones slot)
     if (PIN) asm volatile("" ::: "memory");
 #pragma unroll
@@ -206,16 +207,45 @@ DEV void fetch_inputs(const TIO* __restrict__ feats, const float* __restrict__ d
     d[0] = live ? dirs[s * 3] : 0.0f; d[1] = live ? dirs[s * 3 + 1] : 0.0f; d[2] = live ? dirs[s * 3 + 2] : 0.0f;
 }
 
+// Per-RAY view code.  The view direction of a sample is the direction of its ray, and its encoding (3 sincos + 9 angle
+// doublings + 16 selects + 8 packs: ~80 of the ~250 vector instructions of a forward tile) does not depend on the sample:
+// dir_code_kernel encodes every ray once ([ray][g][16] bf16 = the two K blocks of both lane halves, 64 B) and the
+// decoder kernels gather 32 bytes per lane by ray index.  Same arithmetic, same values.
+__global__ void __launch_bounds__(256)
+dir_code_kernel(const float* __restrict__ dirs, int64_t num_rays, bf16x8* __restrict__ code) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= num_rays * 2) return;
+    const int64_t r = e >> 1;
+    const int g = (int)(e & 1);
+    const float d[3] = {dirs[r * 3], dirs[r * 3 + 1], dirs[r * 3 + 2]};
+    bf16x8 k1, k2;
+    encode_dir(d, g, k1, k2);
+    code[e * 2] = k1;
+    code[e * 2 + 1] = k2;
+}
+template <typename TIO>
+DEV void fetch_inputs_coded(const TIO* __restrict__ feats, const bf16x8* __restrict__ code, const int64_t* __restrict__ ridx,
+                            int64_t s, bool live, int g, bf16x8 x0[2], bf16x8 k[2]) {
+    x0[0] = load_feats8<TIO>(feats + s * IN + 8 * g, live);
+    x0[1] = load_feats8<TIO>(feats + s * IN + 16 + 8 * g, live);
+    const int64_t r = live ? ridx[s] : 0;
+    const bf16x8* cp = code + (r * 2 + g) * 2;
+    k[0] = cp[0]; k[1] = cp[1];
+}
+
 // ---------------------------------------------------------------------------------------------- forward kernel
 constexpr int FWD_WAVES = 8;
 
 constexpr int FWD_OFF_BIASV = L_FWD_END * 2;
 constexpr int FWD_OFF_STG = FWD_OFF_BIASV + BIASV_FLOATS * 4;
 constexpr int FWD_LDS = FWD_OFF_STG + NPARAM_PAD * 4;
-template <typename TIO, bool NARROW, bool PIN>
+template <typename TIO, bool NARROW, bool PIN, bool CODED = false>
 __global__ void __launch_bounds__(FWD_WAVES * 64)
-mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples, int in_dim,
+mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, const int64_t* __restrict__ ridx,
+               int64_t num_samples, int in_dim,
                const float* __restrict__ params, float* __restrict__ out_rgb, float* __restrict__ out_density) {
+    static_assert(!CODED || !NARROW, "the per-ray view code is built for 32-wide feature rows");
+    const bf16x8* code = reinterpret_cast<const bf16x8*>(dirs);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16* sw = reinterpret_cast<__bf16*>(smem);
     float* biasv = reinterpret_cast<float*>(smem + FWD_OFF_BIASV);
@@ -233,23 +263,33 @@ mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
     const int64_t stride = (int64_t)gridDim.x * FWD_WAVES;
     int64_t tile = (int64_t)blockIdx.x * FWD_WAVES + wave;
     Acts A;
-    float d[3];
-    if (tile < ntiles) fetch_inputs<TIO, NARROW>(feats, dirs, tile * TS + L.n, tile * TS + L.n < num_samples, L.g, in_dim, A.x0, d);
+    float d[3] = {0.f, 0.f, 0.f};
+    if (tile < ntiles) {
+        if constexpr (CODED) fetch_inputs_coded<TIO>(feats, code, ridx, tile * TS + L.n, tile * TS + L.n < num_samples, L.g, A.x0, &A.x2[1]);
+        else fetch_inputs<TIO, NARROW>(feats, dirs, tile * TS + L.n, tile * TS + L.n < num_samples, L.g, in_dim, A.x0, d);
+    }
     for (; tile < ntiles; tile += stride) {
         const int64_t s = tile * TS + L.n;
         const bool live = s < num_samples;
         // prefetch the next tile's inputs behind this tile's arithmetic
-        bf16x8 nx0[2];
+        bf16x8 nx0[2], nk[2];
         float nd[3];
         const int64_t ns = (tile + stride) * TS + L.n;
         const bool more = tile + stride < ntiles;
-        if (more) fetch_inputs<TIO, NARROW>(feats, dirs, ns, ns < num_samples, L.g, in_dim, nx0, nd);
-        forward_tile<PIN, PIN>(L, d, A);
+        if (more) {
+            if constexpr (CODED) fetch_inputs_coded<TIO>(feats, code, ridx, ns, ns < num_samples, L.g, nx0, nk);
+            else fetch_inputs<TIO, NARROW>(feats, dirs, ns, ns < num_samples, L.g, in_dim, nx0, nd);
+        }
+        forward_tile<PIN, PIN, CODED>(L, d, A);
         if (L.g == 0 && live) {
             out_density[s] = fmaxf(A.y0, 0.0f);
             out_rgb[s * 3] = A.sg[0]; out_rgb[s * 3 + 1] = A.sg[1]; out_rgb[s * 3 + 2] = A.sg[2];
         }
-        if (more) { A.x0[0] = nx0[0]; A.x0[1] = nx0[1]; d[0] = nd[0]; d[1] = nd[1]; d[2] = nd[2]; }
+        if (more) {
+            A.x0[0] = nx0[0]; A.x0[1] = nx0[1];
+            if constexpr (CODED) { A.x2[1] = nk[0]; A.x2[2] = nk[1]; }
+            else { d[0] = nd[0]; d[1] = nd[1]; d[2] = nd[2]; }
+        }
     }
 }
 
@@ -366,9 +406,10 @@ DEV void accumulate_stage(const unsigned char* imgY, const unsigned char* imgX, 
     }
 }
 
-template <typename TIO, bool NARROW>
+template <typename TIO, bool NARROW, bool CODED = false>
 __global__ void __launch_bounds__(BWD_THREADS)
-mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples, int in_dim,
+mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, const int64_t* __restrict__ ridx,
+               int64_t num_samples, int in_dim,
                const float* __restrict__ params, const float* __restrict__ grad_rgb, const float* __restrict__ grad_density,
                TIO* __restrict__ grad_feats, float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -406,20 +447,27 @@ mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
         const __bf16* w1t = sw + L_W1T + n * LT1 + 8 * g;
         const int wc_off = (2 * n + g) * 8, wn_off = g * TILE_REGION + n * 16;
         Acts A;
-        float d[3];
-        if (tile < ntiles) fetch_inputs<TIO, NARROW>(feats, dirs, tile * TS + n, tile * TS + n < num_samples, g, in_dim, A.x0, d);
+        float d[3] = {0.f, 0.f, 0.f};
+        const bf16x8* code = reinterpret_cast<const bf16x8*>(dirs);
+        if (tile < ntiles) {
+            if constexpr (CODED) fetch_inputs_coded<TIO>(feats, code, ridx, tile * TS + n, tile * TS + n < num_samples, g, A.x0, &A.x2[1]);
+            else fetch_inputs<TIO, NARROW>(feats, dirs, tile * TS + n, tile * TS + n < num_samples, g, in_dim, A.x0, d);
+        }
         for (; tile < ntiles; tile += stride) {
             const int64_t s = tile * TS + n;
             const bool live = s < num_samples;
             float gr[3] = {0.f, 0.f, 0.f}, gd = 0.0f;
             if (live && g == 0) { gr[0] = grad_rgb[s * 3]; gr[1] = grad_rgb[s * 3 + 1]; gr[2] = grad_rgb[s * 3 + 2]; gd = grad_density[s]; }
-            bf16x8 nx0[2];
+            bf16x8 nx0[2], nk[2];
             float nd[3];
             const int64_t ns = (tile + stride) * TS + n;
             const bool more = tile + stride < ntiles;
-            if (more) fetch_inputs<TIO, NARROW>(feats, dirs, ns, ns < num_samples, g, in_dim, nx0, nd);
+            if (more) {
+                if constexpr (CODED) fetch_inputs_coded<TIO>(feats, code, ridx, ns, ns < num_samples, g, nx0, nk);
+                else fetch_inputs<TIO, NARROW>(feats, dirs, ns, ns < num_samples, g, in_dim, nx0, nd);
+            }
 
-            forward_tile<true>(L, d, A);
+            forward_tile<true, false, CODED>(L, d, A);
 
             // ---- stage 5: dY5 = g_rgb * s (1 - s) (3 channels, natural slots 0..2 of the g = 0 lanes)
             float g5[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // the g = 1 lanes hold other rows in sg: keep them 0
@@ -511,7 +559,11 @@ mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
                     }
                 }
             }
-            if (more) { A.x0[0] = nx0[0]; A.x0[1] = nx0[1]; d[0] = nd[0]; d[1] = nd[1]; d[2] = nd[2]; }
+            if (more) {
+                A.x0[0] = nx0[0]; A.x0[1] = nx0[1];
+                if constexpr (CODED) { A.x2[1] = nk[0]; A.x2[2] = nk[1]; }
+                else { d[0] = nd[0]; d[1] = nd[1]; d[2] = nd[2]; }
+            }
         }
     } else {
         grad_zero(G);
@@ -552,38 +604,38 @@ int cu_count() {
     return n;
 }
 
-template <typename TIO, bool NARROW>
-int launch_fwd(const void* feats, const float* dirs, int64_t S, int in_dim, const float* params, float* rgb, float* density,
-               hipStream_t st) {
+template <typename TIO, bool NARROW, bool CODED>
+int launch_fwd(const void* feats, const float* dirs, const int64_t* ridx, int64_t S, int in_dim, const float* params, float* rgb,
+               float* density, hipStream_t st) {
     const size_t lds = FWD_LDS;
     const int64_t ntiles = (S + TS - 1) / TS;
     static const int pin = [] { const char* v = getenv("WISP_MLP_FWD_PIN"); return v && v[0] ? atoi(v) : 2; }();   // workgroups per CU; 0 = register-resident weights
-    if (pin > 0) {
-        auto kern = mlp_fwd_kernel<TIO, NARROW, true>;
+    if (pin > 0 || CODED) {
+        auto kern = mlp_fwd_kernel<TIO, NARROW, true, CODED>;
         static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
-        const int grid = (int)min64(ceil_div64(ntiles, FWD_WAVES), (int64_t)pin * cu_count());
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, S, in_dim, params, rgb, density);
-    } else {
-        auto kern = mlp_fwd_kernel<TIO, NARROW, false>;
+        const int grid = (int)min64(ceil_div64(ntiles, FWD_WAVES), (int64_t)(pin > 0 ? pin : 2) * cu_count());
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, ridx, S, in_dim, params, rgb, density);
+    } else if constexpr (!CODED) {
+        auto kern = mlp_fwd_kernel<TIO, NARROW, false, false>;
         static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
         const int grid = (int)min64(ceil_div64(ntiles, FWD_WAVES), cu_count());
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, S, in_dim, params, rgb, density);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, ridx, S, in_dim, params, rgb, density);
     }
     return 0;
 }
 
-template <typename TIO, bool NARROW>
-int launch_bwd(const void* feats, const float* dirs, int64_t S, int in_dim, const float* params, const float* grad_rgb,
-               const float* grad_density, void* grad_feats, float* partials, int* partial_rows, hipStream_t st) {
+template <typename TIO, bool NARROW, bool CODED>
+int launch_bwd(const void* feats, const float* dirs, const int64_t* ridx, int64_t S, int in_dim, const float* params,
+               const float* grad_rgb, const float* grad_density, void* grad_feats, float* partials, int* partial_rows, hipStream_t st) {
     const size_t lds = BWD_LDS;
-    auto kern = mlp_bwd_kernel<TIO, NARROW>;
+    auto kern = mlp_bwd_kernel<TIO, NARROW, CODED>;
     static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
     const int64_t ntiles = (S + TS - 1) / TS;
     const int grid = (int)min64(ceil_div64(ntiles, BWD_PAIRS), cu_count());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), lds, st, (const TIO*)feats, dirs, S, in_dim, params, grad_rgb,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), lds, st, (const TIO*)feats, dirs, ridx, S, in_dim, params, grad_rgb,
                        grad_density, (TIO*)grad_feats, partials);
     *partial_rows = grid;
     return 0;
@@ -595,26 +647,51 @@ namespace wisp_mlp {
 
 #define WISP_MLP_IO(FN, ...)                                                                        \
     if (in_dim == IN) switch (dtype_io) {                                                           \
-        case WISP_F32: return FN<float, false>(__VA_ARGS__);                                        \
-        case WISP_F16: return FN<__half, false>(__VA_ARGS__);                                       \
-        default: return FN<__hip_bfloat16, false>(__VA_ARGS__);                                     \
+        case WISP_F32: return FN<float, false, false>(__VA_ARGS__);                                 \
+        case WISP_F16: return FN<__half, false, false>(__VA_ARGS__);                                \
+        default: return FN<__hip_bfloat16, false, false>(__VA_ARGS__);                              \
     }                                                                                               \
     switch (dtype_io) {                                                                             \
-        case WISP_F32: return FN<float, true>(__VA_ARGS__);                                         \
-        case WISP_F16: return FN<__half, true>(__VA_ARGS__);                                        \
-        default: return FN<__hip_bfloat16, true>(__VA_ARGS__);                                      \
+        case WISP_F32: return FN<float, true, false>(__VA_ARGS__);                                  \
+        case WISP_F16: return FN<__half, true, false>(__VA_ARGS__);                                 \
+        default: return FN<__hip_bfloat16, true, false>(__VA_ARGS__);                               \
     }
 
 int bf16_forward(const void* feats, int dtype_io, const float* dirs, int64_t S, int in_dim, const float* params, float* rgb,
                  float* density, hipStream_t st) {
-    WISP_MLP_IO(launch_fwd, feats, dirs, S, in_dim, params, rgb, density, st)
+    WISP_MLP_IO(launch_fwd, feats, dirs, nullptr, S, in_dim, params, rgb, density, st)
 }
 
 int bf16_backward(const void* feats, int dtype_io, const float* dirs, int64_t S, int in_dim, const float* params,
                   const float* grad_rgb, const float* grad_density, void* grad_feats, float* partials, int* partial_rows,
                   hipStream_t st) {
-    WISP_MLP_IO(launch_bwd, feats, dirs, S, in_dim, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st)
+    WISP_MLP_IO(launch_bwd, feats, dirs, nullptr, S, in_dim, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st)
 }
 #undef WISP_MLP_IO
+
+// per-ray view code variants: 32-wide 16-bit feature rows only (the training shape)
+bool bf16_rays_supported(int dtype_io, int in_dim) { return in_dim == IN && (dtype_io == WISP_F16 || dtype_io == WISP_BF16); }
+
+void bf16_dir_code(const float* dirs, int64_t num_rays, void* code, hipStream_t st) {
+    if (num_rays <= 0) return;
+    hipLaunchKernelGGL(dir_code_kernel, dim3((unsigned)ceil_div64(num_rays * 2, 256)), dim3(256), 0, st, dirs, num_rays,
+                       reinterpret_cast<bf16x8*>(code));
+}
+
+int bf16_forward_rays(const void* feats, int dtype_io, const void* code, const int64_t* ridx, int64_t S, const float* params,
+                      float* rgb, float* density, hipStream_t st) {
+    const float* c = reinterpret_cast<const float*>(code);
+    if (dtype_io == WISP_F16) return launch_fwd<__half, false, true>(feats, c, ridx, S, IN, params, rgb, density, st);
+    return launch_fwd<__hip_bfloat16, false, true>(feats, c, ridx, S, IN, params, rgb, density, st);
+}
+
+int bf16_backward_rays(const void* feats, int dtype_io, const void* code, const int64_t* ridx, int64_t S, const float* params,
+                       const float* grad_rgb, const float* grad_density, void* grad_feats, float* partials, int* partial_rows,
+                       hipStream_t st) {
+    const float* c = reinterpret_cast<const float*>(code);
+    if (dtype_io == WISP_F16)
+        return launch_bwd<__half, false, true>(feats, c, ridx, S, IN, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st);
+    return launch_bwd<__hip_bfloat16, false, true>(feats, c, ridx, S, IN, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st);
+}
 
 }  // namespace wisp_mlp

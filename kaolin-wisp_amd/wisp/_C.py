@@ -84,6 +84,9 @@ SIGNATURES = {
     "wisp_nerf_mlp_param_count": [c_i32, c_i32, c_i32],
     "wisp_nerf_mlp_fwd": [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp],
     "wisp_nerf_mlp_bwd": [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "wisp_nerf_mlp_dir_code": [c_vp, c_i64, c_i32, c_vp, c_vp],
+    "wisp_nerf_mlp_fwd_rays": [c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "wisp_nerf_mlp_bwd_rays": [c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "wisp_nerf_mlp_bwd_workspace_bytes": [c_i64, c_i32],
     "wisp_nerf_mlp_workspace_floats": [],
     "wisp_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp, c_vp],
@@ -973,28 +976,53 @@ def _check_decoder_shapes(feats, params, in_dim, hidden, view_freqs):
         raise ValueError(f"packed decoder parameters: expected {want} floats for in_dim={in_dim}, got {params.numel()}")
 
 
-def nerf_mlp_forward(feats, dirs, params, in_dim, hidden, view_freqs, compute_bf16):
-    """(rgb [S,3], density [S,1]) = fused density + colour decoders (nerf.py:245-264)."""
+def nerf_mlp_forward(feats, dirs, params, in_dim, hidden, view_freqs, compute_bf16, ray_code=None):
+    """(rgb [S,3], density [S,1]) = fused density + colour decoders (nerf.py:245-264).
+    ray_code = (ridx int64 [S], code from nerf_mlp_dir_code) replaces the per-sample `dirs` (then None)."""
     feats = _need(feats, None, "feats")
-    dirs = _need(dirs, torch.float32, "dirs")
     params = _need(params, torch.float32, "params")
     _check_decoder_shapes(feats, params, in_dim, hidden, view_freqs)
     S = feats.shape[0]
     rgb = torch.empty(S, 3, dtype=torch.float32, device=feats.device)
     density = torch.empty(S, 1, dtype=torch.float32, device=feats.device)
+    if ray_code is not None:
+        ridx, code = _need(ray_code[0], torch.int64, "ridx"), _need(ray_code[1], torch.bfloat16, "dir_code")
+        if ridx.shape[0] != S:
+            raise ValueError("ridx must have one entry per sample")
+        with _timed("nerf_mlp_fwd", S):
+            _check(lib.wisp_nerf_mlp_fwd_rays(_p(feats), _DTYPE_CODE[feats.dtype], _p(code), _p(ridx), S, in_dim, hidden, view_freqs,
+                                              _p(params), _p(rgb), _p(density), _stream()), "nerf_mlp_fwd_rays")
+        return rgb, density
+    dirs = _need(dirs, torch.float32, "dirs")
     with _timed("nerf_mlp_fwd", S):
         _check(lib.wisp_nerf_mlp_fwd(_p(feats), _DTYPE_CODE[feats.dtype], _p(dirs), S, in_dim, hidden, view_freqs, _p(params),
                                      BF16 if compute_bf16 else F32, _p(rgb), _p(density), _stream()), "nerf_mlp_fwd")
     return rgb, density
 
 
+def nerf_mlp_dir_code(ray_dirs, view_freqs=4):
+    """bf16 [R, 32] view code of every ray for nerf_mlp_forward / nerf_mlp_backward(..., ray_code=(ridx, code))."""
+    ray_dirs = _need(ray_dirs, torch.float32, "ray_dirs")
+    R = ray_dirs.shape[0]
+    code = torch.empty(R, 32, dtype=torch.bfloat16, device=ray_dirs.device)
+    _check(lib.wisp_nerf_mlp_dir_code(_p(ray_dirs), R, view_freqs, _p(code), _stream()), "nerf_mlp_dir_code")
+    return code
+
+
+def nerf_mlp_rays_supported(feats_dtype, in_dim, hidden, view_freqs, compute_bf16):
+    """the per-ray view code path exists for the training shape only"""
+    return bool(compute_bf16) and in_dim == 32 and hidden == 64 and view_freqs == 4 and feats_dtype in (torch.float16, torch.bfloat16)
+
+
 _mlp_workspace = {}
 
 
-def nerf_mlp_backward(feats, dirs, params, grad_rgb, grad_density, in_dim, hidden, view_freqs, compute_bf16, grad_params=None):
+def nerf_mlp_backward(feats, dirs, params, grad_rgb, grad_density, in_dim, hidden, view_freqs, compute_bf16, grad_params=None,
+                      ray_code=None):
     """(grad_feats [S,in_dim] in feats.dtype, grad_params fp32 - accumulated into `grad_params` when given)."""
     feats = _need(feats, None, "feats")
-    dirs = _need(dirs, torch.float32, "dirs")
+    if ray_code is None:
+        dirs = _need(dirs, torch.float32, "dirs")
     params = _need(params, torch.float32, "params")
     grad_rgb = _need(grad_rgb, torch.float32, "grad_rgb")
     grad_density = _need(grad_density, torch.float32, "grad_density")
@@ -1009,6 +1037,15 @@ def nerf_mlp_backward(feats, dirs, params, grad_rgb, grad_density, in_dim, hidde
     if ws is None or ws.numel() * 4 < need:
         _mlp_workspace[key] = None
         ws = _mlp_workspace[key] = torch.empty((need + 3) // 4 + 64, dtype=torch.float32, device=dev)
+    if ray_code is not None:
+        ridx, code = _need(ray_code[0], torch.int64, "ridx"), _need(ray_code[1], torch.bfloat16, "dir_code")
+        if ridx.shape[0] != S:
+            raise ValueError("ridx must have one entry per sample")
+        with _timed("nerf_mlp_bwd", S):
+            _check(lib.wisp_nerf_mlp_bwd_rays(_p(feats), _DTYPE_CODE[feats.dtype], _p(code), _p(ridx), S, in_dim, hidden, view_freqs,
+                                              _p(params), _p(grad_rgb), _p(grad_density), _p(grad_feats), _p(grad_params), _p(ws),
+                                              ws.numel() * 4, _stream()), "nerf_mlp_bwd_rays")
+        return grad_feats, grad_params
     with _timed("nerf_mlp_bwd", S):
         _check(lib.wisp_nerf_mlp_bwd(_p(feats), _DTYPE_CODE[feats.dtype], _p(dirs), S, in_dim, hidden, view_freqs, _p(params),
                                      BF16 if compute_bf16 else F32, _p(grad_rgb), _p(grad_density), _p(grad_feats),

@@ -161,7 +161,16 @@ class _DirectHashNeRFStep:
             st = self._count(rays, jitter)                # nothing was prefetched for this batch
         elif st["blas"] is not blas:
             st = self._count(rays, None, seed=st["seed"])  # the octree was pruned since: redo it (same jitter stream)
-        ridx, samples, depths, deltas, boundary, offsets, dirs = C.raymarch_ray_finish(st, with_dirs=True)
+        # view directions: encoded once per ray and gathered by ray index inside the decoder kernels where that variant exists
+        # (the training shape), else gathered per sample by the raymarch
+        i, h, f = self.shape
+        coded = C.nerf_mlp_rays_supported(torch.bfloat16 if t.enable_amp else torch.float32, i, h, f, t.enable_amp)
+        if coded:
+            ridx, samples, depths, deltas, boundary, offsets = C.raymarch_ray_finish(st)
+            dirs, ray_code = None, None
+        else:
+            ridx, samples, depths, deltas, boundary, offsets, dirs = C.raymarch_ray_finish(st, with_dirs=True)
+            ray_code = None
         if prefetch is not None:
             self._pending = self._count(prefetch, None)
         S = samples.shape[0]
@@ -172,8 +181,9 @@ class _DirectHashNeRFStep:
             shadow = current_shadow(table, torch.bfloat16)
             table = shadow if shadow is not None else table.to(torch.bfloat16)
         feats = C.hashgrid_interpolate(samples, table.detach(), self.first_idx, self.res, self.bitwidth, self.zero_from_col)
-        i, h, f = self.shape
-        color, density = C.nerf_mlp_forward(feats, dirs, self.packed, i, h, f, t.enable_amp)
+        if coded:
+            ray_code = (ridx, C.nerf_mlp_dir_code(rays.dirs, f))
+        color, density = C.nerf_mlp_forward(feats, dirs, self.packed, i, h, f, t.enable_amp, ray_code=ray_code)
         if tracer.bg_color.device != dev:
             tracer.bg_color = tracer.bg_color.to(dev)
         bg = tracer._bg_host()
@@ -185,7 +195,7 @@ class _DirectHashNeRFStep:
         loss = loss[0]
         g_color, g_density = C.composite_bwd(g_rgb, None, None, color, density, deltas, None, None, offsets, bg)
         g_feats, _ = C.nerf_mlp_backward(feats, dirs, self.packed, g_color, g_density, i, h, f, t.enable_amp,
-                                         grad_params=self.packed_grad)
+                                         grad_params=self.packed_grad, ray_code=ray_code)
         C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res, self.bitwidth,
                                         self.zero_from_col, out=self.table.grad)
         return loss, S

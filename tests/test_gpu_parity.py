@@ -754,6 +754,38 @@ def test_fused_wide_decoder_hidden_128(io_dtype, bias, in_dim, S):
     _check_fused_decoder("bf16", io_dtype, 4e-2, bias, in_dim, 128, S)
 
 
+@pytest.mark.parametrize("io_dtype", [torch.bfloat16, torch.float16])
+def test_decoder_with_per_ray_view_code_equals_per_sample_directions(io_dtype):
+    """wisp_nerf_mlp_{fwd,bwd}_rays: the view direction encoded once per ray (wisp_nerf_mlp_dir_code) and gathered by ray index
+    inside the kernels must give exactly what the per-sample entry points give on directions gathered like
+    packed_rf_tracer.py:70-76 does - same arithmetic, so bit-identical outputs and gradients."""
+    C = _C()
+    rng = np.random.default_rng(91)
+    R, S = 4097, 200003
+    d = rng.normal(size=(R, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ray_dirs = cuda(d)
+    ridx = torch.from_numpy(np.sort(rng.integers(0, R, S))).to(DEV)
+    feats = torch.from_numpy(rng.normal(size=(S, 32)).astype(np.float32) * 0.5).to(DEV).to(io_dtype)
+    n = int(C.lib.wisp_nerf_mlp_param_count(32, 64, 4))
+    params = torch.from_numpy(rng.normal(size=n).astype(np.float32) * 0.2).to(DEV)
+    g_rgb = torch.from_numpy(rng.normal(size=(S, 3)).astype(np.float32)).to(DEV)
+    g_den = torch.from_numpy(rng.normal(size=(S, 1)).astype(np.float32)).to(DEV)
+    assert C.nerf_mlp_rays_supported(io_dtype, 32, 64, 4, True)
+    assert not C.nerf_mlp_rays_supported(torch.float32, 32, 64, 4, True)
+    code = C.nerf_mlp_dir_code(ray_dirs)
+    sample_dirs = ray_dirs.index_select(0, ridx)
+    rgb_a, den_a = C.nerf_mlp_forward(feats, sample_dirs, params, 32, 64, 4, True)
+    rgb_b, den_b = C.nerf_mlp_forward(feats, None, params, 32, 64, 4, True, ray_code=(ridx, code))
+    assert torch.equal(rgb_a, rgb_b) and torch.equal(den_a, den_b)
+    gf_a, gp_a = C.nerf_mlp_backward(feats, sample_dirs, params, g_rgb, g_den, 32, 64, 4, True)
+    gf_b, gp_b = C.nerf_mlp_backward(feats, None, params, g_rgb, g_den, 32, 64, 4, True, ray_code=(ridx, code))
+    assert torch.equal(gf_a, gf_b)
+    assert torch.equal(gp_a, gp_b)
+    with pytest.raises(RuntimeError):                      # fp32 rows: no per-ray variant, the library says so
+        C.nerf_mlp_forward(feats.float(), None, params, 32, 64, 4, True, ray_code=(ridx, code))
+
+
 def _check_fused_decoder(mode, io_dtype, tol, bias, in_dim, hidden, S):
     from wisp.ops.nerf_mlp import fused_nerf_decoder, supports
     nef = _decoder_pair(bias, in_dim, hidden)
