@@ -23,6 +23,10 @@
 struct HashLevels {
     int32_t res[HG_MAX_LODS];
     int32_t dense[HG_MAX_LODS];
+    // per level, computed once on the host (the same IEEE operations the kernels used to repeat per wave and level, three of
+    // them in fp64): the float32 clamp bound of hashgrid_interpolate_cuda.cu:40 and res / 2
+    float hi[HG_MAX_LODS];
+    float hr[HG_MAX_LODS];
 };
 
 template <int DIM>
@@ -34,12 +38,11 @@ struct CornerSetup {
 
 // Position / coefficient / index computation shared by forward and backward.
 template <int DIM>
-static __device__ __forceinline__ void corner_setup(const float* __restrict__ c, int32_t res, bool dense,
+static __device__ __forceinline__ void corner_setup(const float* __restrict__ c, int32_t res, float hi, float hr, bool dense,
                                                     uint32_t tsize, bool tsize_pow2, CornerSetup<DIM>& cs) {
-    const float hi = (float)((double)(res - 1) - 1e-5);          // hashgrid_interpolate_cuda.cu:40, clamp bound
+    // hi = (float)((double)(res - 1) - 1e-5): hashgrid_interpolate_cuda.cu:40, clamp bound;  hr = 0.5f * res (exact: res < 2^24)
     int32_t pos[DIM];
     float f[DIM], g[DIM];
-    const float hr = 0.5f * (float)res;                           // exact: res < 2^24
 #pragma unroll
     for (int a = 0; a < DIM; ++a) {
         // reference (hash_utils.cuh:108-112): float x = res * (c * 0.5 + 0.5) evaluated in double, rounded once to float.
@@ -73,15 +76,26 @@ static __device__ __forceinline__ void corner_setup(const float* __restrict__ c,
             term[a][1] = term[a][0] + primes[a];
         }
     }
+    if constexpr (DIM == 3) {
+        // left-to-right products (.cu:49-56) two at a time: v_pk_mul_f32 does the (x y) pairs and then (xy z0, xy z1) =
+        // coefficients j, j + 1 - six packed multiplies instead of twelve scalar ones, same roundings
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 X = {g[0], f[0]}, Z = {g[2], f[2]};
+        const f32x2 xy0 = X * g[1], xy1 = X * f[1];              // (bx, by = 0), (bx, by = 1)
+        const f32x2 c00 = Z * xy0[0], c01 = Z * xy1[0], c10 = Z * xy0[1], c11 = Z * xy1[1];
+        cs.coef[0] = c00[0]; cs.coef[1] = c00[1]; cs.coef[2] = c01[0]; cs.coef[3] = c01[1];
+        cs.coef[4] = c10[0]; cs.coef[5] = c10[1]; cs.coef[6] = c11[0]; cs.coef[7] = c11[1];
+    } else {
 #pragma unroll
-    for (int j = 0; j < (1 << DIM); ++j) {
-        float w = 1.0f;
+        for (int j = 0; j < (1 << DIM); ++j) {
+            float w = 1.0f;
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) {
-            const float t = ((j >> (DIM - 1 - a)) & 1) ? f[a] : g[a];
-            w = (a == 0) ? t : w * t;                             // left-to-right product, .cu:49-56
+            for (int a = 0; a < DIM; ++a) {
+                const float t = ((j >> (DIM - 1 - a)) & 1) ? f[a] : g[a];
+                w = (a == 0) ? t : w * t;                         // left-to-right product, .cu:49-56
+            }
+            cs.coef[j] = w;
         }
-        cs.coef[j] = w;
     }
     // the index flavour is uniform for the whole wave: branch once, not per corner
 #define HG_CORNER_TERMS(OP)                                                                               \
@@ -117,7 +131,7 @@ template <typename T, int F, int DIM>
 __global__ void __launch_bounds__(FW_WAVES * 64)
 hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ codebook,
                     const int64_t* __restrict__ first_idx, HashLevels lv, int num_lods, uint32_t tsize,
-                    int tsize_pow2, int zero_from_col, int row_shift, T* __restrict__ feats) {
+                    int tsize_pow2, int zero_from_col, int row_shift, int off32, T* __restrict__ feats) {
     extern __shared__ __attribute__((aligned(16))) uint32_t stage_all[];   // per wave: [num_lods][65][W] dwords
     constexpr int W = (F * (int)sizeof(T)) / 4;                            // payload dwords per (sample, level)
     const int lane = threadIdx.x & 63;
@@ -143,7 +157,7 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
             if (live && l * F < zero_from_col) {
                 const T* __restrict__ table = codebook + first_idx[l] * F;
                 CornerSetup<DIM> cs;
-                corner_setup<DIM>(c, res, dense, tsize, tsize_pow2 != 0, cs);
+                corner_setup<DIM>(c, res, lv.hi[l], lv.hr[l], dense, tsize, tsize_pow2 != 0, cs);
                 if (dense && res >= 258) {
                     // the fp32 clamp bound rounds up to res - 1 here, so a corner can be `res` and its index
                     // can leave the level: the reference then reads the next level's rows - and past the allocation on the
@@ -154,9 +168,7 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
                         if ((int64_t)(uint32_t)cs.idx[j] > last) cs.idx[j] = (int32_t)last;
                 }
                 T v[1 << DIM][F];
-#pragma unroll
-                for (int j = 0; j < (1 << DIM); ++j) {
-                    const T* p = table + (int64_t)cs.idx[j] * F;
+                auto fetch = [&](int j, const T* p) {
                     if constexpr (W == 1) {
                         *reinterpret_cast<uint32_t*>(&v[j][0]) = *reinterpret_cast<const uint32_t*>(p);
                     } else if constexpr (W == 2) {
@@ -167,6 +179,29 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #pragma unroll
                         for (int k = 0; k < F; ++k) v[j][k] = p[k];
                     }
+                };
+                if (off32 && (W == 1 || W == 2 || W == 4)) {
+                    // byte offsets inside the level fit 32 bits whenever the whole table is < 4 GB (checked on the host):
+                    // buffer loads - scalar descriptor of the level + 32-bit vector offset, one multiply / shift per corner
+                    // instead of a sign extension and a 64-bit add
+                    const __amdgpu_buffer_rsrc_t rsrc =
+                        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(table), (short)0, (int)0x7fffffff, 0x00020000);
+#pragma unroll
+                    for (int j = 0; j < (1 << DIM); ++j) {
+                        const int voff = (int)((uint32_t)cs.idx[j] * (uint32_t)(F * sizeof(T)));
+                        if constexpr (W == 1) {
+                            *reinterpret_cast<uint32_t*>(&v[j][0]) = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0);
+                        } else if constexpr (W == 2) {
+                            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+                            *reinterpret_cast<u32x2_t*>(&v[j][0]) = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0);
+                        } else if constexpr (W == 4) {
+                            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                            *reinterpret_cast<u32x4_t*>(&v[j][0]) = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < (1 << DIM); ++j) fetch(j, table + (int64_t)cs.idx[j] * F);
                 }
 #pragma unroll
                 for (int j = 0; j < (1 << DIM); ++j)
@@ -224,7 +259,7 @@ struct BinLevels {
 };
 
 template <typename T, int F, int DIM, bool MERGE>
-static __device__ __forceinline__ bool tail_compute(const float* c, bool live, int l, int32_t res, bool dense, uint32_t tsize,
+static __device__ __forceinline__ bool tail_compute(const float* c, bool live, int l, int32_t res, float hi, float hr, bool dense, uint32_t tsize,
                                                     bool pow2, int zero_from_col, const T* gp, int lane,
                                                     CornerSetup<DIM>& cs, float (&v)[1 << DIM][F]) {
     // gp -> the F gradient values of this (sample, level) (global memory or an LDS copy); read only for live samples
@@ -235,11 +270,19 @@ static __device__ __forceinline__ bool tail_compute(const float* c, bool live, i
 #pragma unroll
         for (int k = 0; k < F; ++k) g[k] = (l * F + k < zero_from_col) ? Cvt<T>::to_f(gp[k]) : 0.0f;
     }
-    corner_setup<DIM>(c, res, dense, tsize, pow2, cs);
+    corner_setup<DIM>(c, res, hi, hr, dense, tsize, pow2, cs);
+    {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));     // two features per v_pk_mul_f32
+        static_assert(F % 2 == 0, "feature_dim is even");
 #pragma unroll
-    for (int j = 0; j < (1 << DIM); ++j)
+        for (int j = 0; j < (1 << DIM); ++j)
 #pragma unroll
-        for (int k = 0; k < F; ++k) v[j][k] = g[k] * cs.coef[j];
+            for (int k = 0; k < F; k += 2) {
+                const f32x2 gg = {g[k], g[k + 1]};
+                const f32x2 r = gg * cs.coef[j];
+                v[j][k] = r[0]; v[j][k + 1] = r[1];
+            }
+    }
     if (!MERGE) return live;
     // Two samples belong to one run iff they sit in the same cell.  Only NEIGHBOURING lanes are ever compared, so the cell
     // is carried as (x | y << 16, z) - exact for res <= 65536 (checked on the host), no integer multiplies.
@@ -315,7 +358,7 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
             const bool dense = __builtin_amdgcn_readfirstlane(lv.dense[l]) != 0;
             CornerSetup<DIM> cs;
             float v[1 << DIM][F];
-            const bool issue = tail_compute<T, F, DIM, MERGE>(c, live, l, res, dense, tsize, tsize_pow2 != 0, zero_from_col,
+            const bool issue = tail_compute<T, F, DIM, MERGE>(c, live, l, res, lv.hi[l], lv.hr[l], dense, tsize, tsize_pow2 != 0, zero_from_col,
                                                               grad_feats + (i * num_lods + l) * F, lane, cs, v);
             if (issue) {
                 const int64_t base = first_idx[l], total_rows = first_idx[num_lods];
@@ -449,7 +492,7 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
             const int sl = (wave * GROUPS + g) * 64 + lane;
             CornerSetup<DIM> cs;
             float v[NC][F];
-            const bool issue = tail_compute<T, F, DIM, true>(c[g], live[g], l, res, dense, tsize, tsize_pow2 != 0, zero_from_col,
+            const bool issue = tail_compute<T, F, DIM, true>(c[g], live[g], l, res, lv.hi[l], lv.hr[l], dense, tsize, tsize_pow2 != 0, zero_from_col,
                                                              reinterpret_cast<const T*>(s_grad + sl * rowp + l * W), lane, cs, v);
             if (!issue) continue;
             // Rank all corners first - eight independent LDS atomics in flight - and only then write: ranking and
@@ -575,7 +618,7 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
             CornerSetup<DIM> cs;
             float v[NC][F];
             uint32_t gw = grow[g][l & (EQ_MAX_ROW - 1)];
-            const bool issue = tail_compute<T, F, DIM, true>(c[g], live[g], l, res, dense, tsize, tsize_pow2 != 0, zero_from_col,
+            const bool issue = tail_compute<T, F, DIM, true>(c[g], live[g], l, res, lv.hi[l], lv.hr[l], dense, tsize, tsize_pow2 != 0, zero_from_col,
                                                              reinterpret_cast<const T*>(&gw), lane, cs, v);
             const uint64_t tails = __builtin_amdgcn_ballot_w64(issue);
             if (tails == 0) continue;
@@ -796,6 +839,8 @@ static int fill_levels(const int32_t* resolutions, int num_lods, int coord_dim, 
         const int32_t r = resolutions[l];
         if (r < 1) return -1;
         lv.res[l] = r;
+        lv.hi[l] = (float)((double)(r - 1) - 1e-5);
+        lv.hr[l] = 0.5f * (float)r;
         // hash_utils.cuh:27-29 / :75-76 -- strict '<' on int32 products (wrap-around preserved)
         const int32_t ts = (int32_t)tsize;
         const int32_t r2 = (int32_t)((uint32_t)r * (uint32_t)r);
@@ -804,7 +849,7 @@ static int fill_levels(const int32_t* resolutions, int num_lods, int coord_dim, 
         if (coord_dim == 3) dense = dense && (r3 < ts);
         lv.dense[l] = dense ? 1 : 0;
     }
-    for (int l = num_lods; l < HG_MAX_LODS; ++l) { lv.res[l] = 1; lv.dense[l] = 1; }
+    for (int l = num_lods; l < HG_MAX_LODS; ++l) { lv.res[l] = 1; lv.dense[l] = 1; lv.hi[l] = 0.0f; lv.hr[l] = 0.5f; }
     return 0;
 }
 
@@ -832,8 +877,11 @@ static int launch_fwd(const float* coords, int64_t n, const void* codebook, cons
     const int64_t tiles = ceil_div64(n, HG_TILE);
     int64_t g = ceil_div64(tiles, waves);
     if (g > 8192) g = 8192;                               // 256 CUs x 32; grid-stride beyond that
+    // every level has at most tsize rows: the whole table is below 2 GB <=> 31-bit byte offsets inside a level are safe
+    // (the buffer descriptor covers 2^31 - 1 bytes from the level's first row)
+    const int off32 = (uint64_t)num_lods * tsize * F * sizeof(T) < 0x7fffffffull ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)(g < 1 ? 1 : g)), dim3(waves * 64), lds, s, coords, n, (const T*)codebook,
-                       first_idx, lv, num_lods, tsize, pow2, zero_from_col, row_shift, (T*)feats);
+                       first_idx, lv, num_lods, tsize, pow2, zero_from_col, row_shift, off32, (T*)feats);
     return 0;
 }
 
