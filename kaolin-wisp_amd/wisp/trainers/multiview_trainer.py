@@ -250,6 +250,7 @@ class MultiviewTrainStep:
         # neutral - 1.270 vs 1.284 ms/step - so one rank keeps everything on one stream)
         # specialised issue order for the flagship pipeline shape (WISP_DIRECT_STEP=0 keeps the modular path)
         self._direct = None
+        self._last_step_modular = True
         if os.environ.get("WISP_DIRECT_STEP", "1") != "0" and _DirectHashNeRFStep.supports(pipeline):
             d = _DirectHashNeRFStep(self)
             self._direct = d if d.ok else None
@@ -282,9 +283,31 @@ class MultiviewTrainStep:
                                 self.alpha, self.momentum, self.eps, self.opt_steps, grad_scale=gs, zero_grad=True)
         f.mark_shadow_current()                 # the kernel rewrote every shadow element from the new master weights
 
+    def _live_grad_numel(self):
+        """How much of the flat gradient buffer can be non-zero after a step of the direct-issue path: the tracer queries
+        lod_idx = num_lods - 1 and 'cat' zeroes the columns of the FINEST level (reference hash_grid.py:226-229), so that level's
+        rows - the tail of the buffer when the table is its last tensor - never receive a gradient and need not travel:
+        4 MB of the 41.8 MB of nerf_hash.yaml.  (Their weight decay is the same arithmetic on every rank.)"""
+        f, d = self.flat, getattr(self, "_direct", None)
+        if d is None or getattr(self, "_last_step_modular", True):
+            return f.grad.numel()
+        a, b = f.ranges["grid"]
+        ra, rb = f.ranges["rest"]
+        if rb > ra or len(f._grid_params) != 1 or f._grid_params[0][0] is not d.table:
+            return f.grad.numel()
+        F = d.table.shape[1]
+        live_levels = min((d.zero_from_col + F - 1) // F, len(d.res))
+        if live_levels >= len(d.res):
+            return f.grad.numel()
+        first = getattr(d, "_first_idx_host", None)
+        if first is None:
+            first = d._first_idx_host = [int(v) for v in d.first_idx.detach().cpu().reshape(-1).tolist()]
+        return f._grid_params[0][1] + first[live_levels] * F
+
     def allreduce_grads(self):
         if self.world > 1 or self.force_allreduce:
-            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)     # RCCL over xGMI
+            n = self._live_grad_numel()
+            dist.all_reduce(self.flat.grad[:n], op=dist.ReduceOp.SUM, group=self.group)     # RCCL over xGMI
 
     def reduce_and_update(self):
         """Gradient all-reduce + optimizer.  With more than one rank both run on a side stream, so that the part of the
@@ -353,7 +376,8 @@ class MultiviewTrainStep:
         occupancy test early (a data-loader style look-ahead; results are the same with or without it)."""
         self.pre_step()
         self.total_iterations += 1
-        if self._direct is not None and self.pipeline.nef.training:
+        self._last_step_modular = not (self._direct is not None and self.pipeline.nef.training)
+        if not self._last_step_modular:
             with torch.no_grad():
                 loss, _ = self._direct.run(rays, img_gts, jitter, prefetch)
         else:

@@ -62,7 +62,11 @@ def main():
         same_tree = all(torch.equal(trees[0], t) for t in trees)
     pruned = int(pipe.nef.grid.blas.pyramid[0, level]) < 8 ** level
     res = dict(world=world, identical=bool(identical), same_tree=bool(same_tree), pruned=bool(pruned), direct=bool(used_direct),
-               finite=bool(torch.isfinite(flat).all()))
+               finite=bool(torch.isfinite(flat).all()),
+               # the all-reduce leaves out the finest level's rows (never a gradient under 'cat' with lod_idx = num_lods - 1):
+               # the skipped tail of the gradient buffer must indeed be all zero
+               allreduce_numel=int(tr._live_grad_numel()), grad_numel=int(tr.flat.grad.numel()),
+               skipped_tail_zero=bool((tr.flat.grad[tr._live_grad_numel():] == 0).all()))
     # single-rank reference of the SAME global batch, on rank 0 only, without any collective: the data-parallel result must
     # agree with it up to the summation order of the gradient
     dist.barrier()

@@ -35,6 +35,7 @@ def test_forced_allreduce_side_stream_on_one_gpu(amp):
     read before their update lands) shows up as a difference of the size of a whole optimizer step."""
     res = _launch(1, {"WISP_FORCE_ALLREDUCE": "1", "DP_AMP": amp})
     assert res["direct"] and res["pruned"] and res["finite"] and res["identical"] and res["same_tree"], res
+    assert res["allreduce_numel"] < res["grad_numel"] and res["skipped_tail_zero"], res
     # not bitwise: overflowing gradient slots and the coarse levels' split flush add with float atomics (free order)
     print(res)
     assert res["rel_l2_vs_single"] < 2e-3, res
