@@ -48,13 +48,50 @@ class SDFTrainStep:
             C.optim_step_groups(self.optimizer, f.data, f.grad, f.exp_avg, f.exp_avg_sq, groups, self.betas[0], self.betas[1],
                                 self.eps, self.opt_steps, zero_grad=True)
 
-    def step(self, coords, gts):
-        """coords [B,3], gts [B,1] on the GPU -> loss tensor (already divided by the batch size, like the reference)."""
+    def _forward_backward(self, coords, gts):
         loss = 0.0
         for lod_idx in self.loss_lods():
             pred = self.nef(coords=coords, lod_idx=lod_idx, channels="sdf")
             loss = loss + ((pred - gts) ** 2).sum()
         loss = loss / coords.shape[0]
         loss.backward()
-        self.optimizer_step()
         return loss.detach()
+
+    def capture(self, batch_size):
+        """Capture forward + loss + backward for a FIXED batch size as one HIP graph (torch.cuda.CUDAGraph on ROCm).
+        The step of nglod_octree.yaml is 512 coordinates: a dozen small launches whose GPU time (~50 us) is a fraction of
+        what Python + autograd need to issue them (~0.8 ms).  Every shape in it is static - query, trilinear blend and
+        decoder see [batch_size, ...] tensors, nothing depends on data - so the launches are recorded once and replayed;
+        the fused optimizer stays outside (its bias correction changes every step and it is one launch anyway).
+        step() uses the graph whenever it is handed a batch of the captured size; results equal the eager step's."""
+        dev = self.flat.data.device
+        if dev.type != 'cuda':
+            raise RuntimeError("SDFTrainStep.capture needs the model on the GPU")
+        self._g_coords = torch.zeros(batch_size, 3, dtype=torch.float32, device=dev)
+        self._g_gts = torch.zeros(batch_size, 1, dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                          # warm-up off the default stream (allocator, lazy set-up)
+            for _ in range(3):
+                self._forward_backward(self._g_coords, self._g_gts)
+        torch.cuda.current_stream().wait_stream(side)
+        self.flat.grad.zero_()                                 # the warm-up passes accumulated gradients; parameters untouched
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._g_loss = self._forward_backward(self._g_coords, self._g_gts)
+        self.flat.grad.zero_()
+        self._graph = graph
+        return self
+
+    def step(self, coords, gts):
+        """coords [B,3], gts [B,1] on the GPU -> loss tensor (already divided by the batch size, like the reference)."""
+        graph = getattr(self, "_graph", None)
+        if graph is not None and tuple(coords.shape) == tuple(self._g_coords.shape) and tuple(gts.shape) == tuple(self._g_gts.shape):
+            self._g_coords.copy_(coords)
+            self._g_gts.copy_(gts)
+            graph.replay()
+            self.optimizer_step()
+            return self._g_loss.clone()
+        loss = self._forward_backward(coords, gts)
+        self.optimizer_step()
+        return loss
