@@ -73,6 +73,21 @@ int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, int feature_
                                           const int32_t* resolutions /* host */, int num_lods,
                                           int codebook_bitwidth);
 
+/* Corner query without the blend: wisp._C.ops.hashgrid_query_cuda / hashgrid_query_backward_cuda
+ * (wisp/csrc/ops/hashgrid_query_cuda.cu:19-186, hashgrid_query.cpp:41-97, bound in bindings.cpp:31-32; Python callers
+ * wisp/ops/grid.py:169-245 - nothing else in the reference uses them).  One codebook [2^codebook_bitwidth, feature_dim] per
+ * level (device pointers in a HOST array), 3-D coordinates; feats / grad_feats = [N, 8, num_lods, P, feature_dim] with
+ * P = 2^probe_bitwidth in the tables' dtype: corner k = dx<<2 | dy<<1 | dz, index = hash_index_3d(corner, res, 2^bw - P), the
+ * row repeated for every probe slot (as the reference's forward does).  Backward adds grad_feats into the gradient tables
+ * (caller zeroes them): fp32 puts probe p into row idx + p, the 16-bit dtypes all probes into row idx with packed atomics -
+ * the two behaviours of the reference's kernel. */
+int wisp_hashgrid_query_fwd(const float* coords, int64_t n, const void* const* codebooks, int dtype, int feature_dim,
+                            const int32_t* resolutions, int num_lods, int codebook_bitwidth, int probe_bitwidth,
+                            void* feats, wisp_stream_t stream);
+int wisp_hashgrid_query_bwd(const float* coords, int64_t n, const void* grad_feats, int dtype, int feature_dim,
+                            const int32_t* resolutions, int num_lods, int codebook_bitwidth, int probe_bitwidth,
+                            void* const* grad_codebooks, wisp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * SPC octree queries  (replace kaolin.ops.spc.unbatched_query at wisp/accelstructs/octree_as.py:162,
  * kaolin.render.spc.unbatched_raytrace at :183-185, mark_pack_boundaries at :300 and

@@ -1106,6 +1106,127 @@ extern "C" int wisp_hashgrid_interpolate_bwd(const float* coords, int64_t n, int
     return WISP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- corner query (no blend)
+// wisp._C.ops.hashgrid_query_cuda / hashgrid_query_backward_cuda (wisp/csrc/ops/hashgrid_query_cuda.cu:19-186, bound in
+// bindings.cpp:31-32; Python side wisp/ops/grid.py:169-245).  Peripheral in the reference (nothing in wisp/ calls it), kept so
+// that the whole `ops` surface binds.  Per level its OWN codebook tensor [2^bitwidth, F]; output [N, 8, num_lods, P, F] with
+// P = 2^probe_bitwidth: the eight corner rows of every level, un-blended, each repeated for every probe slot - the reference's
+// forward reads row idx for every p (its TODO), the index is taken modulo (2^bitwidth - P), corner k = dx<<2 | dy<<1 | dz
+// (NOT the interpolation kernel's order - it is the same order: bit 2 = x).  Backward = scatter-add of the incoming
+// gradient into those rows; the reference's fp32 path adds probe p into row idx + p, its half path into row idx (both
+// reproduced; bf16 follows the half path), with packed 16-bit atomics for 16-bit tables like the reference's __half2 adds.
+// One thread per (sample, level): consecutive threads are the levels of one sample, so for a fixed corner they write one
+// contiguous run of num_lods * P * F elements.
+struct QueryLevels {
+    int32_t res[HG_MAX_LODS]; int32_t dense[HG_MAX_LODS]; float hi[HG_MAX_LODS]; float hr[HG_MAX_LODS];
+    void* table[HG_MAX_LODS];
+};
+
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256)
+hashgrid_query_kernel(const float* __restrict__ coords, int64_t n, QueryLevels lv, int num_lods, uint32_t mod, int pow2,
+                      int probe, int F, T* __restrict__ io) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * num_lods) return;
+    const int64_t i = e / num_lods;
+    const int l = (int)(e - i * num_lods);
+    const float c[3] = {coords[i * 3], coords[i * 3 + 1], coords[i * 3 + 2]};
+    CornerSetup<3> cs;
+    corner_setup<3>(c, lv.res[l], lv.hi[l], lv.hr[l], lv.dense[l] != 0, mod, pow2 != 0, cs);
+    T* __restrict__ table = reinterpret_cast<T*>(lv.table[l]);
+    const int64_t corner_stride = (int64_t)num_lods * probe * F;
+    T* __restrict__ base = io + i * 8 * corner_stride + (int64_t)l * probe * F;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t row = (int64_t)(uint32_t)cs.idx[k];
+        for (int p = 0; p < probe; ++p) {
+            T* __restrict__ cell = base + k * corner_stride + (int64_t)p * F;
+            if (!BWD) {
+                const T* __restrict__ src = table + row * F;
+                for (int j = 0; j < F; ++j) cell[j] = src[j];
+            } else if constexpr (sizeof(T) == 4) {
+                float* dst = reinterpret_cast<float*>(table) + (row + p) * F;           // .cu:163 adds probe p into row idx + p
+                for (int j = 0; j < F; ++j) atomicAdd(dst + j, (float)cell[j]);
+            } else {
+                T* dst = table + row * F;                                                // .cu:150-151: the half path does not
+                for (int j = 0; j < F; j += 2) {
+                    if constexpr (__is_same(T, __half)) {
+                        unsafeAtomicAdd(reinterpret_cast<__half2*>(dst + j), *reinterpret_cast<const __half2*>(cell + j));
+                    } else {
+                        typedef short s16x2 __attribute__((ext_vector_type(2)));
+                        __builtin_amdgcn_global_atomic_fadd_v2bf16(reinterpret_cast<s16x2*>(dst + j), *reinterpret_cast<const s16x2*>(cell + j));
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int query_levels(const int32_t* resolutions, int num_lods, int64_t mod, void* const* tables, QueryLevels& q) {
+    HashLevels lv;
+    if (fill_levels(resolutions, num_lods, 3, mod, lv) != 0) return -1;
+    for (int l = 0; l < HG_MAX_LODS; ++l) {
+        q.res[l] = lv.res[l]; q.dense[l] = lv.dense[l]; q.hi[l] = lv.hi[l]; q.hr[l] = lv.hr[l];
+        q.table[l] = l < num_lods ? tables[l] : nullptr;
+    }
+    return 0;
+}
+
+template <bool BWD>
+static int launch_query(const float* coords, int64_t n, void* const* tables, int dtype, int feature_dim, const int32_t* resolutions,
+                        int num_lods, int codebook_bitwidth, int probe_bitwidth, void* io, hipStream_t s) {
+    const int64_t probe = (int64_t)1 << probe_bitwidth;
+    const int64_t mod = ((int64_t)1 << codebook_bitwidth) - probe;                     // .cu:34 / :113 codebook_mod
+    QueryLevels q;
+    if (mod < 1 || query_levels(resolutions, num_lods, mod, tables, q) != 0) return -1;
+    const int pow2 = (mod & (mod - 1)) == 0;
+    const dim3 grid((unsigned)ceil_div64(n * num_lods, 256)), block(256);
+    if (dtype == WISP_F32)
+        hipLaunchKernelGGL((hashgrid_query_kernel<float, BWD>), grid, block, 0, s, coords, n, q, num_lods, (uint32_t)mod, pow2, (int)probe, feature_dim, (float*)io);
+    else if (dtype == WISP_F16)
+        hipLaunchKernelGGL((hashgrid_query_kernel<__half, BWD>), grid, block, 0, s, coords, n, q, num_lods, (uint32_t)mod, pow2, (int)probe, feature_dim, (__half*)io);
+    else
+        hipLaunchKernelGGL((hashgrid_query_kernel<__hip_bfloat16, BWD>), grid, block, 0, s, coords, n, q, num_lods, (uint32_t)mod, pow2, (int)probe, feature_dim, (__hip_bfloat16*)io);
+    return 0;
+}
+
+static int query_check(const float* coords, int64_t n, const void* tables, int dtype, int feature_dim, const int32_t* resolutions,
+                       int num_lods, int codebook_bitwidth, int probe_bitwidth, const void* io) {
+    WISP_REQUIRE(n >= 0, "negative n");
+    WISP_REQUIRE(num_lods >= 1 && num_lods <= HG_MAX_LODS, "num_lods out of range");
+    WISP_REQUIRE(codebook_bitwidth >= 1 && codebook_bitwidth <= 30 && probe_bitwidth >= 0 && probe_bitwidth < codebook_bitwidth, "bad bitwidths");
+    WISP_REQUIRE(dtype == WISP_F32 || dtype == WISP_F16 || dtype == WISP_BF16, "bad dtype");
+    WISP_REQUIRE(feature_dim >= 2 && feature_dim % 2 == 0, "feature_dim must be a multiple of 2 (grid.py:174)");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(coords && tables && resolutions && io, "null pointer");
+    WISP_REQUIRE(n * num_lods < ((int64_t)1 << 40), "too many (sample, level) pairs");
+    return WISP_OK;
+}
+
+extern "C" int wisp_hashgrid_query_fwd(const float* coords, int64_t n, const void* const* codebooks, int dtype, int feature_dim,
+                                       const int32_t* resolutions, int num_lods, int codebook_bitwidth, int probe_bitwidth,
+                                       void* feats, wisp_stream_t stream) {
+    if (int rc = query_check(coords, n, codebooks, dtype, feature_dim, resolutions, num_lods, codebook_bitwidth, probe_bitwidth, feats)) return rc;
+    if (n == 0) return WISP_OK;
+    for (int l = 0; l < num_lods; ++l) WISP_REQUIRE(codebooks[l], "null codebook");
+    WISP_REQUIRE(launch_query<false>(coords, n, const_cast<void* const*>(codebooks), dtype, feature_dim, resolutions, num_lods,
+                                     codebook_bitwidth, probe_bitwidth, feats, (hipStream_t)stream) == 0, "bad resolution");
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+extern "C" int wisp_hashgrid_query_bwd(const float* coords, int64_t n, const void* grad_feats, int dtype, int feature_dim,
+                                       const int32_t* resolutions, int num_lods, int codebook_bitwidth, int probe_bitwidth,
+                                       void* const* grad_codebooks, wisp_stream_t stream) {
+    if (int rc = query_check(coords, n, grad_codebooks, dtype, feature_dim, resolutions, num_lods, codebook_bitwidth, probe_bitwidth, grad_feats)) return rc;
+    if (n == 0) return WISP_OK;
+    for (int l = 0; l < num_lods; ++l) WISP_REQUIRE(grad_codebooks[l], "null gradient table");
+    WISP_REQUIRE(launch_query<true>(coords, n, grad_codebooks, dtype, feature_dim, resolutions, num_lods, codebook_bitwidth,
+                                    probe_bitwidth, const_cast<void*>(grad_feats), (hipStream_t)stream) == 0, "bad resolution");
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
 extern "C" int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, int feature_dim,
                                                      const int32_t* resolutions, int num_lods, int codebook_bitwidth) {
     if (n <= 0 || num_lods <= 0 || num_lods > HG_MAX_LODS || feature_dim <= 0 || !resolutions) return 0;

@@ -34,6 +34,8 @@ SIGNATURES = {
     "wisp_hashgrid_interpolate_fwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_hashgrid_interpolate_bwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp],
     "wisp_hashgrid_bwd_workspace_bytes": [c_i64, c_i32, c_i32, c_vp, c_i32, c_i32],
+    "wisp_hashgrid_query_fwd": [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
+    "wisp_hashgrid_query_bwd": [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_query": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_build_bitfield": [c_vp, c_i64, c_i32, c_vp, c_vp],
     "wisp_spc_raytrace_count": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp],
@@ -1133,7 +1135,62 @@ def _ref_grid_interpolate_backward_cuda(coords, grad_output, feature_dim):
     return grad
 
 
+def _table_pointers(tables):
+    return (ctypes.c_void_p * len(tables))(*[t.data_ptr() for t in tables])
+
+
+def hashgrid_query(coords, codebooks, resolutions, codebook_bitwidth, probe_bitwidth=0):
+    """Eight un-blended corner rows per level (hashgrid_query_cuda.cu:19-66): coords f32 [N,3], one [2^bw, F] table per level
+    -> [N, 8, L * P * F] in the tables' dtype, P = 2^probe_bitwidth."""
+    coords = _need(coords, torch.float32, "coords")
+    tables = [_need(t, codebooks[0].dtype, "codebook") for t in codebooks]
+    res = [int(r) for r in resolutions]
+    if coords.shape[-1] != 3 or len(tables) != len(res):
+        raise ValueError("hashgrid_query: 3-D coordinates and one codebook per resolution")
+    N, L, F, P = coords.shape[0], len(res), tables[0].shape[1], 1 << int(probe_bitwidth)
+    if any(tuple(t.shape) != (1 << int(codebook_bitwidth), F) for t in tables):
+        raise ValueError("hashgrid_query: every codebook is [2^codebook_bitwidth, feature_dim]")
+    feats = torch.empty(N, 8, L * P * F, dtype=tables[0].dtype, device=coords.device)
+    rarr = (ctypes.c_int32 * L)(*res)
+    _check(lib.wisp_hashgrid_query_fwd(_p(coords), N, _table_pointers(tables), _DTYPE_CODE[tables[0].dtype], F, rarr, L,
+                                       int(codebook_bitwidth), int(probe_bitwidth), _p(feats), _stream()), "hashgrid_query_fwd")
+    return feats
+
+
+def hashgrid_query_backward(coords, grad_output, resolutions, codebook_rows, codebook_bitwidth, feature_dim, probe_bitwidth=0):
+    """-> list of gradient tables [rows_l, feature_dim] in grad_output's dtype (hashgrid_query.cpp:69-97)."""
+    coords = _need(coords, torch.float32, "coords")
+    grad_output = _need(grad_output, None, "grad_output")
+    res = [int(r) for r in resolutions]
+    N, L, F = coords.shape[0], len(res), int(feature_dim)
+    rows = [int(r) for r in codebook_rows]
+    if any(r < (1 << int(codebook_bitwidth)) for r in rows):
+        raise ValueError("hashgrid_query_backward: gradient tables need 2^codebook_bitwidth rows")
+    if grad_output.numel() != N * 8 * L * (1 << int(probe_bitwidth)) * F:
+        raise ValueError("hashgrid_query_backward: grad_output is [N, 8, L * P * F]")
+    grads = [torch.zeros(r, F, dtype=grad_output.dtype, device=coords.device) for r in rows]
+    rarr = (ctypes.c_int32 * L)(*res)
+    _check(lib.wisp_hashgrid_query_bwd(_p(coords), N, _p(grad_output), _DTYPE_CODE[grad_output.dtype], F, rarr, L,
+                                       int(codebook_bitwidth), int(probe_bitwidth), _table_pointers(grads), _stream()),
+           "hashgrid_query_bwd")
+    return grads
+
+
+def _ref_hashgrid_query_cuda(coords, codebook, resolution, codebook_bitwidth, probe_bitwidth):
+    """hashgrid_query.cpp:41-67: std::vector<Tensor> codebook, std::vector<int32_t> resolution -> [N, 8, L * P * F]."""
+    return hashgrid_query(coords, list(codebook), _resolution_list(resolution), int(codebook_bitwidth), int(probe_bitwidth))
+
+
+def _ref_hashgrid_query_backward_cuda(coords, grad_output, resolution, codebook_shapes, codebook_bitwidth, feature_dim,
+                                      probe_bitwidth):
+    """hashgrid_query.cpp:69-97 -> std::vector<Tensor> of gradient tables."""
+    return hashgrid_query_backward(coords, grad_output, _resolution_list(resolution), list(codebook_shapes),
+                                   int(codebook_bitwidth), int(feature_dim), int(probe_bitwidth))
+
+
 ops = _Namespace("wisp._C.ops",
+                 hashgrid_query_cuda=_ref_hashgrid_query_cuda,
+                 hashgrid_query_backward_cuda=_ref_hashgrid_query_backward_cuda,
                  grid_interpolate_cuda=_ref_grid_interpolate_cuda,
                  grid_interpolate_backward_cuda=_ref_grid_interpolate_backward_cuda,
                  hashgrid_interpolate_cuda=_ref_hashgrid_interpolate_cuda,

@@ -206,6 +206,56 @@ def grid_interpolate(coords, feats):
     return GridInterpolate.apply(coords.contiguous(), feats.contiguous())
 
 
+class HashGridQuery(torch.autograd.Function):
+    """The eight un-blended corner rows of every level (wisp/ops/grid.py:169-209): differentiable w.r.t. the per-level
+    codebooks.  Under autocast the reference casts its inputs to half (custom_fwd(cast_inputs=torch.half))."""
+
+    @staticmethod
+    def forward(ctx, coords, resolutions, codebook_bitwidth, probe_bitwidth, lod_idx, *codebook):
+        if codebook[0].shape[-1] % 2 == 1:
+            raise Exception("The codebook feature dimension needs to be a multiple of 2.")
+        if torch.is_autocast_enabled():
+            codebook = tuple(c.half() for c in codebook)
+        feats = _hip().ops.hashgrid_query_cuda(coords.float().contiguous(), [c.contiguous() for c in codebook],
+                                               resolutions, codebook_bitwidth, probe_bitwidth).contiguous()
+        ctx.save_for_backward(coords)
+        ctx.resolutions = resolutions
+        ctx.codebook_rows = [c.shape[0] for c in codebook]
+        ctx.codebook_dtypes = [c.dtype for c in codebook]
+        ctx.codebook_bitwidth = codebook_bitwidth
+        ctx.feature_dim = codebook[0].shape[-1]
+        ctx.probe_bitwidth = probe_bitwidth
+        return feats
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        coords = ctx.saved_tensors[0]
+        grads = _hip().ops.hashgrid_query_backward_cuda(coords.float().contiguous(), grad_output.contiguous(), ctx.resolutions,
+                                                        ctx.codebook_rows, ctx.codebook_bitwidth, ctx.feature_dim,
+                                                        ctx.probe_bitwidth)
+        return (None, None, None, None, None, *grads)
+
+
+def hashgrid_query_fwd(coords, resolutions, codebook_bitwidth, lod_idx, codebook, probe_bitwidth=0):
+    """Non-differentiable corner query (wisp/ops/grid.py:211-224) -> [batch, 8, feature_dim * num_lods * 2^probe_bitwidth]."""
+    batch, dim = coords.shape
+    assert coords.shape[-1] in [2, 3]
+    feats = _hip().ops.hashgrid_query_cuda(coords.float().contiguous(), [c.contiguous() for c in codebook], resolutions,
+                                           codebook_bitwidth, probe_bitwidth).contiguous()
+    feature_dim = codebook[0].shape[1] * len(resolutions)
+    return feats.reshape(batch, 8, feature_dim * (2 ** probe_bitwidth))
+
+
+def hashgrid_query(coords, resolutions, codebook_bitwidth, lod_idx, codebook, probe_bitwidth=0):
+    """Differentiable corner query (wisp/ops/grid.py:226-245): coords [batch, 3], codebook = one [2^bw, feature_dim] tensor per
+    level -> [batch, 8, feature_dim * num_lods * 2^probe_bitwidth].  (`lod_idx` is accepted and ignored, as in the reference.)"""
+    batch, dim = coords.shape
+    assert coords.shape[-1] in [2, 3]
+    feats = HashGridQuery.apply(coords.contiguous(), resolutions, codebook_bitwidth, probe_bitwidth, lod_idx, *[c for c in codebook])
+    feature_dim = codebook[0].shape[1] * len(resolutions)
+    return feats.reshape(batch, 8, feature_dim * (2 ** probe_bitwidth))
+
+
 class SPCTrilinear(torch.autograd.Function):
     """Differentiable (w.r.t. the features) dual-octree trilinear interpolation - the Kaolin-Core leaf
     unbatched_interpolate_trilinear that OctreeGrid._interpolate calls (wisp/models/grids/octree_grid.py:147-149)."""

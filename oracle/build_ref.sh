@@ -14,5 +14,10 @@ awk '/^void hashgrid_interpolate_cuda_impl\(/{exit} {print}' "$SRC/hashgrid_inte
 awk '/^std::vector<at::Tensor> uniform_sample_cuda_impl\(/{exit} {print}' "$SRC/uniform_sample_cuda.cu" \
   | sed -e 's/^uniform_sample_cuda_kernel(/uniform_sample_cuda_kernel_at(uint tidx_in,/' \
         -e 's/uint tidx = blockDim.x \* blockIdx.x + threadIdx.x;/uint tidx = tidx_in;/' > "$HERE/_ref/uniform_kernels.inc"
+# corner query (no blend): forward kernel = everything before its ATen launcher; backward kernel = the template between the two launchers
+awk '/^void hashgrid_query_cuda_impl\(/{exit} {print}' "$SRC/hashgrid_query_cuda.cu" \
+  | sed -e 's/^#include "hash_utils.cuh"//' > "$HERE/_ref/query_fwd_kernel.inc"
+awk '/^hashgrid_query_backward_cuda_kernel\(/{f=1; print "template<typename scalar_t>\n__global__ void"} f&&/^void hashgrid_query_backward_cuda_impl\(/{exit} f{print}' \
+  "$SRC/hashgrid_query_cuda.cu" > "$HERE/_ref/query_bwd_kernel.inc"
 g++ -O2 -std=c++17 -shared -fPIC -ffp-contract=off -I "$HERE/ref_shim" -I "$SRC" "$HERE/ref_wrap.cpp" -o "$HERE/_ref/libwisp_ref.so"
 echo "built $HERE/_ref/libwisp_ref.so"

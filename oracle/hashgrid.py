@@ -156,3 +156,39 @@ def grid_interpolate(coords, lod_idx, multiscale_type, feature_dim, resolutions,
         L = len(resolutions)
         return feats.reshape(*out_shape, L, feats.shape[-1] // L).sum(-2)
     raise NotImplementedError
+
+
+def hashgrid_query(coords, tables, resolutions, codebook_bitwidth, probe_bitwidth=0):
+    """wisp._C.ops.hashgrid_query_cuda (wisp/csrc/ops/hashgrid_query_cuda.cu:19-66, hashgrid_query.cpp:41-67): the eight corner
+    rows of every level, un-blended.  One table [2^bw, F] per level; corner k = dx<<2 | dy<<1 | dz; index = hash_index_3d(corner,
+    res, 2^bw - P) with P = 2^probe_bitwidth; the row is written to ALL P probe slots (the kernel reads row idx for every p).
+    -> [N, 8, L, P, F] in the tables' dtype.  3-D coordinates only (the kernel reads coords[i*3 ..])."""
+    N = coords.shape[0]
+    L, F, P = len(resolutions), tables[0].shape[1], 2 ** probe_bitwidth
+    mod = 2 ** codebook_bitwidth - P
+    out = torch.zeros(N, 8, L, P, F, dtype=tables[0].dtype)
+    for l, r in enumerate(resolutions):
+        _, idx = corner_setup(coords, int(r), mod)
+        rows = tables[l][idx.reshape(-1)].reshape(N, 8, 1, F)
+        out[:, :, l] = rows.expand(N, 8, P, F)
+    return out
+
+
+def hashgrid_query_backward(coords, grad_out, resolutions, codebook_bitwidth, feature_dim, probe_bitwidth=0, half_path=False,
+                            acc_dtype=torch.float64):
+    """hashgrid_query_backward_cuda (hashgrid_query_cuda.cu:100-171): scatter-add of grad_out [N, 8, L, P, F] into one table
+    [2^bw, F] per level.  fp32 path (:157-166): probe p goes to row idx + p; half path (:141-155): every probe to row idx."""
+    N = coords.shape[0]
+    L, P = len(resolutions), 2 ** probe_bitwidth
+    mod = 2 ** codebook_bitwidth - P
+    g = grad_out.reshape(N, 8, L, P, feature_dim).to(acc_dtype)
+    out = []
+    for l, r in enumerate(resolutions):
+        _, idx = corner_setup(coords, int(r), mod)
+        t = torch.zeros(2 ** codebook_bitwidth, feature_dim, dtype=acc_dtype)
+        for p in range(P):
+            rows = (idx if half_path else idx + p).reshape(-1)
+            t.index_add_(0, rows, g[:, :, l, p].reshape(-1, feature_dim))
+        out.append(t)
+    return out
+

@@ -73,6 +73,36 @@ def hashgrid_backward(coords, grad_out, table, begin_idxes, resolutions, codeboo
     return grad
 
 
+def hashgrid_query(coords, tables, resolutions, codebook_bitwidth, probe_bitwidth=0):
+    """hashgrid_query_cuda (hashgrid_query.cpp:41-67) with the reference kernel, float32 tables (one per level):
+    -> [N, 8, L, P, F]."""
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    n, L, F, P = coords.shape[0], len(resolutions), tables[0].shape[1], 2 ** probe_bitwidth
+    feats = np.zeros((n, 8, L, P, F), dtype=np.float32)
+    for l, r in enumerate(resolutions):
+        t = np.ascontiguousarray(tables[l], dtype=np.float32)
+        lib().ref_hashgrid_query_level(ctypes.c_int64(n), ctypes.c_int32(2 ** codebook_bitwidth), ctypes.c_int32(P),
+                                       ctypes.c_int64(F), ctypes.c_int32(int(r)), ctypes.c_int32(l), ctypes.c_int32(L),
+                                       _p(coords), _p(t), _p(feats))
+    return feats
+
+
+def hashgrid_query_backward(coords, grad_out, resolutions, codebook_bitwidth, feature_dim, probe_bitwidth=0):
+    """hashgrid_query_backward_cuda (hashgrid_query.cpp:69-97), float32 (the path that adds probe p into row idx + p),
+    sequential adds: -> list of [2^bw, F] tables."""
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    grad_out = np.ascontiguousarray(grad_out, dtype=np.float32)
+    n, L, P = coords.shape[0], len(resolutions), 2 ** probe_bitwidth
+    out = []
+    for l, r in enumerate(resolutions):
+        g = np.zeros((2 ** codebook_bitwidth, feature_dim), dtype=np.float32)
+        lib().ref_hashgrid_query_bwd_level(ctypes.c_int64(n), ctypes.c_int32(2 ** codebook_bitwidth), ctypes.c_int32(P),
+                                           ctypes.c_int64(feature_dim), ctypes.c_int32(int(r)), ctypes.c_int32(l),
+                                           ctypes.c_int32(L), _p(coords), _p(grad_out), _p(g))
+        out.append(g)
+    return out
+
+
 def uniform_sample(scale, ridx, depth, insum):
     ridx = np.ascontiguousarray(ridx, dtype=np.int32)
     depth = np.ascontiguousarray(depth, dtype=np.float32)

@@ -8,6 +8,9 @@
 }   // closes `namespace wisp` left open by the extracted fragment
 #include "_ref/uniform_kernels.inc"
 }   // closes `namespace wisp`
+#include "_ref/query_fwd_kernel.inc"
+#include "_ref/query_bwd_kernel.inc"
+}   // closes `namespace wisp` (opened by the forward fragment)
 
 extern "C" {
 
@@ -42,6 +45,19 @@ void ref_hashgrid_bwd_level(int64_t n, int32_t codebook_size, int64_t feature_di
         wisp::hashgrid_interpolate_2d_backward_cuda_kernel<float>(n, codebook_size, feature_dim, resolution, lod_idx,
                                                                   num_lods, false, coords, codebook, first_idx,
                                                                   grad_output, grad_codebook, nullptr);
+}
+
+// hashgrid_query_cuda_kernel / _backward_ (hashgrid_query_cuda.cu:19-66, :100-171), one level, float tables
+void ref_hashgrid_query_level(int64_t n, int32_t codebook_size, int32_t probe_size, int64_t feature_dim, int32_t resolution,
+                              int32_t lod_idx, int32_t num_lods, const float* coords, const float* codebook, float* feats) {
+    wisp::hashgrid_query_cuda_kernel<float>(n, codebook_size, probe_size, feature_dim, resolution, lod_idx, num_lods, coords,
+                                            codebook, feats);
+}
+void ref_hashgrid_query_bwd_level(int64_t n, int32_t codebook_size, int32_t probe_size, int64_t feature_dim, int32_t resolution,
+                                  int32_t lod_idx, int32_t num_lods, const float* coords, const float* grad_output,
+                                  float* grad_codebook) {
+    wisp::hashgrid_query_backward_cuda_kernel<float>(n, codebook_size, probe_size, feature_dim, resolution, lod_idx, num_lods,
+                                                     coords, grad_output, grad_codebook);
 }
 
 // uniform_sample_cuda_kernel (uniform_sample_cuda.cu:18-59) over all nuggets

@@ -7,6 +7,7 @@ by oracle/build_ref.sh):
 Outputs (small, committed):
   hashgrid_ref.npz   - inputs + outputs of the reference hashgrid forward/backward kernels (3-D and 2-D, float32),
                        hash-index known answers, the clamp bound probes of SURVEY.md Appendix B
+  hashgrid_query_ref.npz - inputs + outputs of the reference hashgrid_query forward/backward kernels (probe_bitwidth 0 and 1)
   uniform_ref.npz    - inputs + outputs of the reference uniform_sample kernel
   spc_kats.npz       - hand-checkable SPC cases (dense level-2 tree, 3-point sparse tree, query / raytrace answers)
                        produced by oracle/spc.py and verified inside this script against brute force in float64
@@ -58,6 +59,25 @@ def hashgrid_vectors():
     probe = np.array([ref_lib.clamp(1e9, 0, r - 1 - 1e-5) for r in probe_res], dtype=np.float32)
     out.update(kat_in=kat_in, kat_out=kat_out, kat2_in=kat2_in, kat2_out=kat2_out, probe_res=probe_res, probe=probe)
     np.savez_compressed(os.path.join(OUT, "hashgrid_ref.npz"), **out)
+
+
+def query_vectors():
+    """hashgrid_query_ref.npz: the reference's corner-query kernels (hashgrid_query_cuda.cu) on two dense + three hashed levels,
+    without and with probe slots."""
+    assert ref_lib.available(), "run oracle/build_ref.sh first"
+    rng = np.random.default_rng(4321)
+    res, bw, F = [4, 7, 12, 20, 33], 10, 2
+    coords = rng.uniform(-1, 1, (200, 3)).astype(np.float32)
+    coords[:4] = [[1, 1, 1], [-1, -1, -1], [0, 0, 0], [1.5, -2.0, 0.3]]
+    tables = [rng.uniform(-0.5, 0.5, (2 ** bw, F)).astype(np.float32) for _ in res]
+    out = dict(res=np.array(res), bw=bw, coords=coords, tables=np.stack(tables))
+    for pb in (0, 1):
+        P = 2 ** pb
+        grad = rng.normal(size=(200, 8, len(res), P, F)).astype(np.float32)
+        out[f"feats_p{pb}"] = ref_lib.hashgrid_query(coords, tables, res, bw, pb)
+        out[f"grad_p{pb}"] = grad
+        out[f"gtables_p{pb}"] = np.stack(ref_lib.hashgrid_query_backward(coords, grad, res, bw, F, pb))
+    np.savez_compressed(os.path.join(OUT, "hashgrid_query_ref.npz"), **out)
 
 
 def uniform_vectors():
@@ -116,6 +136,7 @@ def spc_vectors():
 
 if __name__ == "__main__":
     hashgrid_vectors()
+    query_vectors()
     uniform_vectors()
     spc_vectors()
     print("golden vectors written to", OUT)

@@ -97,6 +97,61 @@ def test_hashgrid_backward_nerf_hash_shape_and_adjoint():
         assert abs(float(lhs - rhs)) <= 1e-5 * abs(float(lhs)) + 1e-3 * (S / (1 << 20))
 
 
+@pytest.mark.parametrize("pb", [0, 1])
+def test_hashgrid_query_golden_reference_vectors(golden_dir, pb):
+    """wisp._C.ops.hashgrid_query_cuda / _backward_cuda against vectors produced by the reference's own kernels
+    (hashgrid_query_cuda.cu compiled for the host, tests/golden/make_golden.py): the forward is a gather - bit-exact; the
+    fp32 backward adds the same values in another order."""
+    q = np.load(os.path.join(golden_dir, "hashgrid_query_ref.npz"))
+    res, bw = [int(r) for r in q["res"]], int(q["bw"])
+    coords = cuda(q["coords"])
+    tables = [cuda(t) for t in q["tables"]]
+    ops = _C().ops
+    feats = ops.hashgrid_query_cuda(coords, tables, res, bw, pb)
+    L, P, F = len(res), 2 ** pb, 2
+    assert feats.shape == (200, 8, L * P * F)
+    assert np.array_equal(feats.cpu().numpy().reshape(200, 8, L, P, F), q[f"feats_p{pb}"])
+    grads = ops.hashgrid_query_backward_cuda(coords, cuda(q[f"grad_p{pb}"]).reshape(200, 8, -1), res, [2 ** bw] * L, bw, F, pb)
+    np.testing.assert_allclose(np.stack([g.cpu().numpy() for g in grads]), q[f"gtables_p{pb}"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_hashgrid_query_op_matches_oracle(dtype):
+    """wisp.ops.grid.hashgrid_query (HashGridQuery autograd function) at nerf_hash-like sizes, against oracle.hashgrid: the
+    forward is a gather (bit-exact in every dtype); the backward of the 16-bit dtypes adds all probes into row idx with packed
+    atomics that round every partial sum (the reference's __half2 atomicAdd, hashgrid_query_cuda.cu:141-155), the fp32 one
+    puts probe p into row idx + p."""
+    from wisp.ops.grid import hashgrid_query, hashgrid_query_fwd
+    rng = np.random.default_rng(31)
+    res, bw, pb, F, N = [16, 40, 101, 256, 512], 12, 1, 4, 3000
+    P, L = 2 ** pb, len(res)
+    coords = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
+    tables_cpu = [torch.from_numpy(rng.uniform(-0.5, 0.5, (2 ** bw, F)).astype(np.float32)).to(dtype) for _ in res]
+    tables = [t.to(DEV).requires_grad_(True) for t in tables_cpu]
+    out = hashgrid_query(cuda(coords), res, bw, None, tables, probe_bitwidth=pb)
+    want = ohash.hashgrid_query(torch.from_numpy(coords), tables_cpu, res, bw, pb)
+    assert out.shape == (N, 8, L * P * F) and out.dtype == dtype
+    assert torch.equal(out.detach().cpu().reshape(N, 8, L, P, F), want)
+    assert torch.equal(hashgrid_query_fwd(cuda(coords), res, bw, None, [t.detach() for t in tables], probe_bitwidth=pb), out.detach())
+    go = torch.from_numpy(rng.normal(size=(N, 8, L * P * F)).astype(np.float32)).to(dtype)
+    out.backward(go.to(DEV))
+    want_g = ohash.hashgrid_query_backward(torch.from_numpy(coords), go.float().reshape(N, 8, L, P, F), res, bw, F, pb,
+                                           half_path=dtype != torch.float32)
+    for l in range(L):
+        got = tables[l].grad.double().cpu()
+        scale = float(want_g[l].abs().max())
+        if dtype == torch.float32:
+            assert float((got - want_g[l]).abs().max()) <= 2e-6 * scale + 1e-6, l
+        else:
+            # every atomic rounds the running sum to the 16-bit type: error ~ (adds per entry) x half an ulp of the sum
+            eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+            adds = max(1.0, N * 8 * P / min(2 ** bw, res[l] ** 3))
+            assert float((got - want_g[l]).abs().max()) <= (2.0 + adds) * eps * scale, (l, dtype)
+            assert float((got - want_g[l]).abs().median()) <= 2 * eps * scale, (l, dtype)
+    with pytest.raises(Exception):
+        hashgrid_query(cuda(coords), res, bw, None, [torch.zeros(2 ** bw, 3, device=DEV) for _ in res])
+
+
 def test_hashgrid_backward_slot_overflow_falls_back_to_atomics():
     """Adversarial batch for the binned backward: consecutive samples jump between 97 points of one small region, so there
     are no runs to merge and every tile sends its 8192 records per level to one or two buckets - far beyond the slot

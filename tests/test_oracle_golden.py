@@ -56,6 +56,19 @@ def test_hashgrid_backward_matches_reference_kernels(hg, dim):
     np.testing.assert_allclose(g, hg["gtable" + s], rtol=0, atol=2e-5)   # reference adds sequentially in fp32
 
 
+@pytest.mark.parametrize("pb", [0, 1])
+def test_hashgrid_query_matches_reference_kernels(golden_dir, pb):
+    """oracle.hashgrid.hashgrid_query / _backward against the reference's own corner-query kernels (hashgrid_query_cuda.cu)."""
+    q = np.load(os.path.join(golden_dir, "hashgrid_query_ref.npz"))
+    res, bw = [int(r) for r in q["res"]], int(q["bw"])
+    coords = torch.from_numpy(q["coords"])
+    tables = [torch.from_numpy(t) for t in q["tables"]]
+    out = hashgrid.hashgrid_query(coords, tables, res, bw, pb).numpy()
+    assert np.array_equal(out, q[f"feats_p{pb}"])                     # a gather: bit-exact
+    g = hashgrid.hashgrid_query_backward(coords, torch.from_numpy(q[f"grad_p{pb}"]), res, bw, 2, pb)
+    np.testing.assert_allclose(np.stack([t.numpy() for t in g]), q[f"gtables_p{pb}"], rtol=0, atol=2e-5)   # sequential fp32 adds
+
+
 def test_uniform_sampler_matches_reference_kernel(golden_dir):
     u = np.load(os.path.join(golden_dir, "uniform_ref.npz"))
     got = raymarch.uniform_sample(int(u["scale"]), u["ridx"], u["depth"], u["insum"])
