@@ -1034,8 +1034,8 @@ def nerf_mlp_backward(feats, dirs, params, grad_rgb, grad_density, in_dim, hidde
     if grad_params is None:
         grad_params = torch.zeros_like(params)
     need = int(lib.wisp_nerf_mlp_bwd_workspace_bytes(S, hidden))
-    key = (dev, hidden)
-    ws = _mlp_workspace.get(key)
+    key = (dev, hidden, _stream().value)          # per stream, like the hash-grid scratch: two backward calls on different streams
+    ws = _mlp_workspace.get(key)                  # must not share partial gradient rows
     if ws is None or ws.numel() * 4 < need:
         _mlp_workspace[key] = None
         ws = _mlp_workspace[key] = torch.empty((need + 3) // 4 + 64, dtype=torch.float32, device=dev)
