@@ -928,7 +928,8 @@ def test_trainer_flat_params_step_matches_unfused_torch_path():
         # noise (the scatter adds with atomics in free order on both sides) can step the other way.  A handful of such
         # entries (seen: 4 of 78 442) is the optimizer's sensitivity, not a kernel difference; everything else must agree.
         diff = (p1.detach() - p2.detach()).abs()
-        assert float((diff > 3e-4).float().mean()) <= 5e-4 and float(diff.median()) <= 1e-6, n1
+        allowed = max(5e-4, 3.0 / diff.numel())             # at least three entries of a small tensor
+        assert float((diff > 3e-4).float().mean()) <= allowed and float(diff.median()) <= 1e-6, n1
 
 
 @pytest.mark.parametrize("amp", [False, True])
