@@ -211,6 +211,11 @@ int wisp_codebook_trilinear_fwd(const float* coords, const void* pidx, int pidx_
                                 const int32_t* trinkets, const float* logits, const float* dictionary,
                                 int64_t num_voxels, int samples_per_voxel, int dict_size, int feature_dim, int level,
                                 int training, float* out /* [V,S,feature_dim] */, wisp_stream_t stream);
+/* decoded[row] = dictionary[argmax(logits[row])] * straight-through scale (training) - the per-corner feature the VQAD grid
+ * blends (wisp/models/grids/codebook_grid.py:103-127 `_index_features`), f32 [num_rows, feature_dim]; wisp_spc_trilinear_fwd
+ * over it equals wisp_codebook_trilinear_fwd bit for bit at a fraction of the work. */
+int wisp_codebook_decode_rows(const float* logits, const float* dictionary, int64_t num_rows, int dict_size, int feature_dim,
+                              int training, float* decoded, wisp_stream_t stream);
 int wisp_codebook_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
                                 const int32_t* trinkets, const float* logits, const float* dictionary,
                                 const float* grad_out, int64_t num_voxels, int samples_per_voxel, int dict_size,

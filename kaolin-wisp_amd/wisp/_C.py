@@ -48,6 +48,7 @@ SIGNATURES = {
     "wisp_triplane_fwd": [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_triplane_bwd": [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_codebook_trilinear_fwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
+    "wisp_codebook_decode_rows": [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_codebook_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp],
     "wisp_mark_pack_boundaries_i64": [c_vp, c_i64, c_vp, c_vp],
     "wisp_mark_pack_boundaries_i32": [c_vp, c_i64, c_vp, c_vp],
@@ -560,6 +561,9 @@ def triplane_backward(coords, grad_out, plane_shapes, sum_lods):
     return grads
 
 
+CODEBOOK_DECODE_ROWS = os.environ.get("WISP_CODEBOOK_DECODE_ROWS", "1") != "0"
+
+
 def codebook_trilinear_forward(coords, pidx, points, trinkets, logits, dictionary, level, training):
     """Fused VQAD lookup + trilinear blend: coords [V,S,3] -> f32 [V,S,F]."""
     coords = _need(coords, torch.float32, "coords")
@@ -568,6 +572,12 @@ def codebook_trilinear_forward(coords, pidx, points, trinkets, logits, dictionar
     dictionary = _need(dictionary, torch.float32, "dictionary")
     V, S = coords.shape[0], coords.shape[1]
     K, F = dictionary.shape
+    if CODEBOOK_DECODE_ROWS and V * S >= 4 * logits.shape[0]:
+        # decode every logits row once, then the plain trilinear blend (bit-identical; see wisp_codebook_decode_rows)
+        decoded = torch.empty(logits.shape[0], F, dtype=torch.float32, device=coords.device)
+        _check(lib.wisp_codebook_decode_rows(_p(logits), _p(dictionary), logits.shape[0], K, F, int(training), _p(decoded),
+                                             _stream()), "codebook_decode_rows")
+        return spc_trilinear_forward(coords, pidx, points, trinkets, decoded, level)
     out = torch.empty(V, S, F, dtype=torch.float32, device=coords.device)
     _check(lib.wisp_codebook_trilinear_fwd(_p(coords), _p(pidx), is64, _p(_need(points, torch.int16, "points")),
                                            _p(_need(trinkets, torch.int32, "trinkets")), _p(logits), _p(dictionary), V, S, K, F,
