@@ -325,7 +325,8 @@ def test_reference_named_native_surface_exists():
     import inspect
     import wisp._C as C
     want = {"ops": {"hashgrid_interpolate_cuda": 5, "hashgrid_interpolate_backward_cuda": 8, "uniform_sample_cuda": 4,
-                    "grid_interpolate_cuda": 2, "grid_interpolate_backward_cuda": 3},
+                    "grid_interpolate_cuda": 2, "grid_interpolate_backward_cuda": 3,
+                    "hashgrid_query_cuda": 5, "hashgrid_query_backward_cuda": 7},
             "render": {"find_depth_bound_cuda": 3}}
     for ns, fns in want.items():
         for name, arity in fns.items():
@@ -344,9 +345,9 @@ def test_reference_ops_grid_module_binds_to_this_C_unchanged():
     src = open("/root/reference/wisp/ops/grid.py").read()
     used = set(re.findall(r"wisp_C\.(\w+)\.(\w+)", src))
     assert ("ops", "hashgrid_interpolate_cuda") in used and ("ops", "hashgrid_interpolate_backward_cuda") in used
-    hot = {(ns, fn) for ns, fn in used if "hashgrid_interpolate" in fn}
-    for ns, fn in hot:
+    for ns, fn in used:                                   # every native function the reference's grid.py names
         assert callable(getattr(getattr(C, ns), fn)), (ns, fn)
+    assert {fn for _, fn in used} >= {"hashgrid_query_cuda", "hashgrid_query_backward_cuda", "grid_interpolate_cuda"}
     stub = types.ModuleType("kaolin"); stub.ops = types.ModuleType("kaolin.ops"); stub.ops.spc = types.ModuleType("kaolin.ops.spc")
     stub._C = types.ModuleType("kaolin._C")
     saved = {k: sys.modules.get(k) for k in ("kaolin", "kaolin.ops", "kaolin.ops.spc")}
@@ -361,6 +362,20 @@ def test_reference_ops_grid_module_binds_to_this_C_unchanged():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_hashgrid_backward_workspace_query_is_sane_without_a_gpu():
+    """wisp_hashgrid_bwd_workspace_bytes is pure host arithmetic (slot plan of the binned backward, incl. the capped grid of
+    the queue emitter): callable without a device, monotone in the sample count, and a few GB at the nerf_hash shape."""
+    import ctypes
+    import wisp._C as C
+    res = [16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406, 512]
+    arr = (ctypes.c_int32 * len(res))(*res)
+    sizes = [int(C.lib.wisp_hashgrid_bwd_workspace_bytes(n, 3, 2, arr, len(res), 19)) for n in (4096, 1 << 16, 1 << 18, 1 << 21)]
+    assert all(b > 0 for b in sizes) and sizes == sorted(sizes)
+    assert (1 << 30) < sizes[-1] < (6 << 30)
+    assert int(C.lib.wisp_hashgrid_bwd_workspace_bytes(0, 3, 2, arr, len(res), 19)) == 0
+    assert int(C.lib.wisp_hashgrid_bwd_workspace_bytes(1 << 18, 4, 2, arr, len(res), 19)) == 0       # bad coord_dim
 
 
 def test_octree_from_mesh_covers_the_surface(tmp_path):
