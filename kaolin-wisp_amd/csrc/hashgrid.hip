@@ -578,93 +578,93 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
     // and all of them feed the same slots (the rank counters live on).  No barrier inside: the waves drift freely.
     const int64_t pieces = (n + EM_TILE - 1) / EM_TILE;
     for (int64_t piece = blockIdx.x; piece < pieces; piece += gridDim.x) {
-    const int64_t tile0 = piece * EM_TILE;
-    float c[GROUPS][DIM];
-    bool live[GROUPS];
-    typedef uint32_t row_t __attribute__((ext_vector_type(EQ_MAX_ROW)));     // indexed by the (wave-uniform) level: v_movrels
-    row_t grow[GROUPS];
-#pragma unroll
-    for (int g = 0; g < GROUPS; ++g) {
-        const int64_t i = tile0 + (int64_t)(wave * GROUPS + g) * 64 + lane;
-        live[g] = i < n;
-#pragma unroll
-        for (int a = 0; a < DIM; ++a) c[g][a] = live[g] ? coords[i * DIM + a] : 0.0f;
-        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(grad_feats) + (live[g] ? i : 0) * num_lods;
-        if (num_lods == EQ_MAX_ROW) {
-#pragma unroll
-            for (int q = 0; q < EQ_MAX_ROW / 4; ++q) {
-                const uint4 t = reinterpret_cast<const uint4*>(src)[q];
-                grow[g][4 * q] = t.x; grow[g][4 * q + 1] = t.y; grow[g][4 * q + 2] = t.z; grow[g][4 * q + 3] = t.w;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < EQ_MAX_ROW; ++q) grow[g][q] = q < num_lods ? src[q] : 0u;
-        }
-    }
-    for (int li = 0; li < levels.n; ++li) {
-        const int l = levels.lv[li];
-        const int32_t res = lv.res[l];
-        const bool dense = lv.dense[l] != 0;
-        const uint32_t cap = bins.cap[li];
-        uint32_t* rank_l = s_rank + bins.rank_base[li];
-        uint32_t* __restrict__ rec_l = records + (size_t)bins.rec_base[li] * RW;
-        const uint32_t bucket_stride = __builtin_amdgcn_readfirstlane(ntiles * cap);
-        const uint32_t slot0 = __builtin_amdgcn_readfirstlane(blockIdx.x * cap);
-        const int64_t base_l = first_idx[l];
-        const int64_t rows_l = first_idx[l + 1] - base_l;
-        const uint32_t owned = (uint32_t)(rows_l < (int64_t)bins.entries[li] ? (rows_l < 0 ? 0 : rows_l) : (int64_t)bins.entries[li]);
+        const int64_t tile0 = piece * EM_TILE;
+        float c[GROUPS][DIM];
+        bool live[GROUPS];
+        typedef uint32_t row_t __attribute__((ext_vector_type(EQ_MAX_ROW)));     // indexed by the (wave-uniform) level: v_movrels
+        row_t grow[GROUPS];
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
-            CornerSetup<DIM> cs;
-            float v[NC][F];
-            uint32_t gw = grow[g][l & (EQ_MAX_ROW - 1)];
-            const bool issue = tail_compute<T, F, DIM, true>(c[g], live[g], l, res, lv.hi[l], lv.hr[l], dense, tsize, tsize_pow2 != 0, zero_from_col,
-                                                             reinterpret_cast<const T*>(&gw), lane, cs, v);
-            const uint64_t tails = __builtin_amdgcn_ballot_w64(issue);
-            if (tails == 0) continue;
-            if (issue) {
-                const uint32_t t = __builtin_amdgcn_mbcnt_hi((uint32_t)(tails >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tails, 0u));
-                uint32_t* q = s_queue + t * QROW;
+            const int64_t i = tile0 + (int64_t)(wave * GROUPS + g) * 64 + lane;
+            live[g] = i < n;
 #pragma unroll
-                for (int j = 0; j < NC; ++j) {
-                    q[3 * j] = (uint32_t)cs.idx[j];
-                    q[3 * j + 1] = __float_as_uint(v[j][0]);
-                    q[3 * j + 2] = __float_as_uint(v[j][1]);
+            for (int a = 0; a < DIM; ++a) c[g][a] = live[g] ? coords[i * DIM + a] : 0.0f;
+            const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(grad_feats) + (live[g] ? i : 0) * num_lods;
+            if (num_lods == EQ_MAX_ROW) {
+#pragma unroll
+                for (int q = 0; q < EQ_MAX_ROW / 4; ++q) {
+                    const uint4 t = reinterpret_cast<const uint4*>(src)[q];
+                    grow[g][4 * q] = t.x; grow[g][4 * q + 1] = t.y; grow[g][4 * q + 2] = t.z; grow[g][4 * q + 3] = t.w;
                 }
+            } else {
+#pragma unroll
+                for (int q = 0; q < EQ_MAX_ROW; ++q) grow[g][q] = q < num_lods ? src[q] : 0u;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t total = (uint32_t)__popcll(tails) * NC;
-            for (uint32_t p = 0; p < total; p += 64) {
-                if (p + lane < total) {
-                    const uint32_t* q = s_queue + (p / NC) * QROW + q_lane;
-                    const uint32_t idx = q[0];
-                    float val[F];
-                    val[0] = __uint_as_float(q[1]);
-                    val[1] = __uint_as_float(q[2]);
-                    const uint32_t b = idx >> chunk_shift;
-                    // an index past the rows the level owns has no bucket (and no rank counter): straight to the atomic
-                    const uint32_t pos = idx < owned ? atomicAdd(&rank_l[b], 1u) : 0xffffffffu;
-                    if (pos < cap) {
-                        uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos) * RW);   // < 2^32 dwords (bin_plan)
-                        Codec::store(dst, idx, (1u << chunk_shift) - 1u, val);
-                    } else {
-                        // slot full, or a spill index (lands where the reference's pointer arithmetic puts it, .cu:124-161,
-                        // unless that is past the whole table)
-                        const int64_t row = base_l + (int64_t)idx;
-                        if (row < total_rows) {
-                            float* pg = grad_codebook + row * F;
-                            atomicAdd(pg, val[0]);
-                            atomicAdd(pg + 1, val[1]);
+        }
+        for (int li = 0; li < levels.n; ++li) {
+            const int l = levels.lv[li];
+            const int32_t res = lv.res[l];
+            const bool dense = lv.dense[l] != 0;
+            const uint32_t cap = bins.cap[li];
+            uint32_t* rank_l = s_rank + bins.rank_base[li];
+            uint32_t* __restrict__ rec_l = records + (size_t)bins.rec_base[li] * RW;
+            const uint32_t bucket_stride = __builtin_amdgcn_readfirstlane(ntiles * cap);
+            const uint32_t slot0 = __builtin_amdgcn_readfirstlane(blockIdx.x * cap);
+            const int64_t base_l = first_idx[l];
+            const int64_t rows_l = first_idx[l + 1] - base_l;
+            const uint32_t owned = (uint32_t)(rows_l < (int64_t)bins.entries[li] ? (rows_l < 0 ? 0 : rows_l) : (int64_t)bins.entries[li]);
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) {
+                CornerSetup<DIM> cs;
+                float v[NC][F];
+                uint32_t gw = grow[g][l & (EQ_MAX_ROW - 1)];
+                const bool issue = tail_compute<T, F, DIM, true>(c[g], live[g], l, res, lv.hi[l], lv.hr[l], dense, tsize, tsize_pow2 != 0, zero_from_col,
+                                                                 reinterpret_cast<const T*>(&gw), lane, cs, v);
+                const uint64_t tails = __builtin_amdgcn_ballot_w64(issue);
+                if (tails == 0) continue;
+                if (issue) {
+                    const uint32_t t = __builtin_amdgcn_mbcnt_hi((uint32_t)(tails >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tails, 0u));
+                    uint32_t* q = s_queue + t * QROW;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) {
+                        q[3 * j] = (uint32_t)cs.idx[j];
+                        q[3 * j + 1] = __float_as_uint(v[j][0]);
+                        q[3 * j + 2] = __float_as_uint(v[j][1]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t total = (uint32_t)__popcll(tails) * NC;
+                for (uint32_t p = 0; p < total; p += 64) {
+                    if (p + lane < total) {
+                        const uint32_t* q = s_queue + (p / NC) * QROW + q_lane;
+                        const uint32_t idx = q[0];
+                        float val[F];
+                        val[0] = __uint_as_float(q[1]);
+                        val[1] = __uint_as_float(q[2]);
+                        const uint32_t b = idx >> chunk_shift;
+                        // an index past the rows the level owns has no bucket (and no rank counter): straight to the atomic
+                        const uint32_t pos = idx < owned ? atomicAdd(&rank_l[b], 1u) : 0xffffffffu;
+                        if (pos < cap) {
+                            uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos) * RW);   // < 2^32 dwords (bin_plan)
+                            Codec::store(dst, idx, (1u << chunk_shift) - 1u, val);
+                        } else {
+                            // slot full, or a spill index (lands where the reference's pointer arithmetic puts it, .cu:124-161,
+                            // unless that is past the whole table)
+                            const int64_t row = base_l + (int64_t)idx;
+                            if (row < total_rows) {
+                                float* pg = grad_codebook + row * F;
+                                atomicAdd(pg, val[0]);
+                                atomicAdd(pg + 1, val[1]);
+                            }
                         }
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
     }
-    }   // pieces
     __syncthreads();
     for (int li = 0; li < levels.n; ++li) {
         const int chunks = bins.chunks[li];
