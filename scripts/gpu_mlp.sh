@@ -5,5 +5,5 @@ timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -p no
 echo "pytest exit: $?" >> gpurun_out/pytest_mlp.log
 tail -15 gpurun_out/pytest_mlp.log | cut -c1-300
 for rep in 1 2; do
-for q in 2 3; do WISP_MLP_BWD_WAVES=$q timeout 300 python scripts/ab_kernels.py 2>&1 | grep -v amdgpu.ids | tail -1 | sed "s/^/bwd_waves=$q /"; done
+for q in 0 2; do WISP_MLP_FWD_PIN=$q timeout 300 python scripts/ab_kernels.py 2>&1 | grep -v amdgpu.ids | tail -1 | sed "s/^/fwd_pin=$q /"; done
 done | tee gpurun_out/ab_mlp.log
