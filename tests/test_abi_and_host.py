@@ -364,6 +364,43 @@ def test_reference_ops_grid_module_binds_to_this_C_unchanged():
                 sys.modules[k] = v
 
 
+def test_allreduce_range_leaves_out_only_a_gradient_free_tail():
+    """MultiviewTrainStep._live_grad_numel (host logic): under 'cat' with lod_idx = num_lods - 1 the finest level's rows get no
+    gradient; they are skipped by the all-reduce only when they really are the tail of the flat buffer (one table, last
+    tensor, nothing after it) and the step went through the direct path."""
+    import types
+    from wisp.trainers import FlatParams, MultiviewTrainStep
+
+    class Field(torch.nn.Module):
+        def __init__(self, with_rest):
+            super().__init__()
+            self.decoder = torch.nn.Linear(4, 3)
+            self.grid_table = torch.nn.Parameter(torch.zeros(10 + 20 + 30, 2))          # three levels: 10, 20, 30 rows
+            if with_rest:
+                self.extra = torch.nn.Parameter(torch.zeros(5))
+
+    def trainer(with_rest):
+        m = Field(with_rest)
+        t = MultiviewTrainStep.__new__(MultiviewTrainStep)
+        t.flat = FlatParams(m)
+        t._direct = types.SimpleNamespace(table=m.grid_table, zero_from_col=2 * 2, res=[4, 8, 16],
+                                          first_idx=torch.tensor([0, 10, 30, 60]))
+        t._last_step_modular = False
+        return t, m
+
+    t, m = trainer(False)
+    table_off = (m.grid_table.data_ptr() - t.flat.data.data_ptr()) // 4
+    assert t._live_grad_numel() == table_off + 30 * 2                                   # levels 0 and 1 travel, level 2 does not
+    assert t._live_grad_numel() < t.flat.grad.numel()
+    t._direct.zero_from_col = 3 * 2                                                     # every level has a gradient
+    assert t._live_grad_numel() == t.flat.grad.numel()
+    t._direct.zero_from_col = 2 * 2
+    t._last_step_modular = True                                                         # autograd path: no assumption
+    assert t._live_grad_numel() == t.flat.grad.numel()
+    t2, _ = trainer(True)                                                               # a tensor after the table
+    assert t2._live_grad_numel() == t2.flat.grad.numel()
+
+
 def test_hashgrid_backward_workspace_query_is_sane_without_a_gpu():
     """wisp_hashgrid_bwd_workspace_bytes is pure host arithmetic (slot plan of the binned backward, incl. the capped grid of
     the queue emitter): callable without a device, monotone in the sample count, and a few GB at the nerf_hash shape."""
