@@ -1125,7 +1125,7 @@ struct QueryLevels {
 template <typename T, bool BWD>
 __global__ void __launch_bounds__(256)
 hashgrid_query_kernel(const float* __restrict__ coords, int64_t n, QueryLevels lv, int num_lods, uint32_t mod, int pow2,
-                      int probe, int F, T* __restrict__ io) {
+                      int probe, int F, int64_t table_rows, T* __restrict__ io) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * num_lods) return;
     const int64_t i = e / num_lods;
@@ -1139,11 +1139,17 @@ hashgrid_query_kernel(const float* __restrict__ coords, int64_t n, QueryLevels l
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int64_t row = (int64_t)(uint32_t)cs.idx[k];
+        // A dense level whose res^3 sits just below the modulus can produce a corner index past the table when the fp32
+        // clamp bound rounds up to res - 1 (res >= 258); the reference reads / writes out of bounds there.
+        // Such a corner reads as zero and receives no gradient here.
+        const bool inside = row + (BWD && sizeof(T) == 4 ? probe - 1 : 0) < table_rows;
         for (int p = 0; p < probe; ++p) {
             T* __restrict__ cell = base + k * corner_stride + (int64_t)p * F;
             if (!BWD) {
                 const T* __restrict__ src = table + row * F;
-                for (int j = 0; j < F; ++j) cell[j] = src[j];
+                for (int j = 0; j < F; ++j) cell[j] = inside ? src[j] : Cvt<T>::from_f(0.0f);
+            } else if (!inside) {
+                continue;
             } else if constexpr (sizeof(T) == 4) {
                 float* dst = reinterpret_cast<float*>(table) + (row + p) * F;           // .cu:163 adds probe p into row idx + p
                 for (int j = 0; j < F; ++j) atomicAdd(dst + j, (float)cell[j]);
@@ -1182,11 +1188,11 @@ static int launch_query(const float* coords, int64_t n, void* const* tables, int
     const int pow2 = (mod & (mod - 1)) == 0;
     const dim3 grid((unsigned)ceil_div64(n * num_lods, 256)), block(256);
     if (dtype == WISP_F32)
-        hipLaunchKernelGGL((hashgrid_query_kernel<float, BWD>), grid, block, 0, s, coords, n, q, num_lods, (uint32_t)mod, pow2, (int)probe, feature_dim, (float*)io);
+        hipLaunchKernelGGL((hashgrid_query_kernel<float, BWD>), grid, block, 0, s, coords, n, q, num_lods, (uint32_t)mod, pow2, (int)probe, feature_dim, (int64_t)1 << codebook_bitwidth, (float*)io);
     else if (dtype == WISP_F16)
-        hipLaunchKernelGGL((hashgrid_query_kernel<__half, BWD>), grid, block, 0, s, coords, n, q, num_lods, (uint32_t)mod, pow2, (int)probe, feature_dim, (__half*)io);
+        hipLaunchKernelGGL((hashgrid_query_kernel<__half, BWD>), grid, block, 0, s, coords, n, q, num_lods, (uint32_t)mod, pow2, (int)probe, feature_dim, (int64_t)1 << codebook_bitwidth, (__half*)io);
     else
-        hipLaunchKernelGGL((hashgrid_query_kernel<__hip_bfloat16, BWD>), grid, block, 0, s, coords, n, q, num_lods, (uint32_t)mod, pow2, (int)probe, feature_dim, (__hip_bfloat16*)io);
+        hipLaunchKernelGGL((hashgrid_query_kernel<__hip_bfloat16, BWD>), grid, block, 0, s, coords, n, q, num_lods, (uint32_t)mod, pow2, (int)probe, feature_dim, (int64_t)1 << codebook_bitwidth, (__hip_bfloat16*)io);
     return 0;
 }
 
