@@ -31,7 +31,8 @@ enum {
 };
 
 const char* wisp_last_error(void);
-/* ABI version of this library; bumped whenever a signature changes. */
+/* ABI version of this library; bumped whenever a signature changes (1 = round 1; 2 = round 2: scratch arguments of the backward
+ * passes, raytrace nugget cache, optimizer kinds, per-ray view codes, corner query, decoded codebook rows). */
 int wisp_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------

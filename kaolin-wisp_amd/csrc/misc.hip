@@ -9,7 +9,7 @@
 thread_local char g_wisp_err[512] = "";
 
 extern "C" const char* wisp_last_error(void) { return g_wisp_err; }
-extern "C" int wisp_abi_version(void) { return 1; }
+extern "C" int wisp_abi_version(void) { return 2; }   // 2: round-2 surface (workspace arguments, raytrace cache, *_rays, query, decode_rows, optimizer kinds)
 
 __global__ void __launch_bounds__(256)
 adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
