@@ -17,15 +17,7 @@ from wisp.models.embedders import get_positional_embedder
 from wisp.models.grids import BLASGrid, HashGrid
 from wisp.models.layers import get_layer_class
 from wisp.models.nefs.base_nef import BaseNeuralField
-
-
-def sample_unif_sphere(n):
-    """n points uniformly on the unit sphere (wisp/ops/geometric.py:44)."""
-    u = np.random.rand(2, n)
-    z = 1 - 2 * u[0, :]
-    r = np.sqrt(1. - z * z)
-    phi = 2 * np.pi * u[1, :]
-    return np.array([r * np.cos(phi), r * np.sin(phi), z]).transpose()
+from wisp.ops.geometric import sample_unif_sphere
 
 
 class NeuralRadianceField(BaseNeuralField):

@@ -158,3 +158,163 @@ def test_spc_sampling_helpers_equal_the_reference_functions():
     assert torch.equal(got, want)                                                        # same draws, same arithmetic
     flags = torch.from_numpy(rng.integers(0, 2, 50).astype(bool))
     assert torch.equal(mine.expand_pack_boundary(flags, 16), ref["expand_pack_boundary"](flags, 16))
+
+
+def _kaolin_stub():
+    """the one Kaolin leaf HashGrid.__init__ calls: unbatched_get_level_points = the slice of the point hierarchy of a level
+    (pyramid row 0 = counts, row 1 = offsets; kaolin/ops/spc/spc.py)"""
+    k = types.ModuleType("kaolin"); k.ops = types.ModuleType("kaolin.ops"); k.ops.spc = types.ModuleType("kaolin.ops.spc")
+    k.ops.spc.unbatched_get_level_points = lambda points, pyramid, level: points[int(pyramid[1, level]):int(pyramid[1, level]) + int(pyramid[0, level])]
+    return {"kaolin": k, "kaolin.ops": k.ops, "kaolin.ops.spc": k.ops.spc}
+
+
+def test_hash_grid_constructors_equal_the_reference_class():
+    """The reference's OWN HashGrid class (models/grids/hash_grid.py:28-200), executed in place over this package's BLAS,
+    BLASGrid base and ops - and over the reference's own MultiTable - against wisp.models.grids.HashGrid: same level
+    resolutions from from_geometric / from_octree, same bookkeeping attributes, same state dict, same dense cell list."""
+    from wisp.accelstructs import OctreeAS
+    from wisp.models.grids import HashGrid as Mine
+    import wisp.models.grids.utils as my_utils
+    ref_utils = _exec_reference("models/grids/utils.py")
+    stubs = _kaolin_stub()
+    saved = {k: sys.modules.get(k) for k in stubs}
+    saved_table = my_utils.MultiTable
+    sys.modules.update(stubs)
+    my_utils.MultiTable = ref_utils["MultiTable"]              # `from wisp.models.grids.utils import MultiTable` inside the reference file
+    try:
+        Ref = _exec_reference("models/grids/hash_grid.py")["HashGrid"]
+    finally:
+        my_utils.MultiTable = saved_table
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    blas = OctreeAS.make_dense(3)
+    cases = [("from_geometric", dict(feature_dim=2, num_lods=16, multiscale_type='cat', feature_std=0.01, codebook_bitwidth=19,
+                                     min_grid_res=16, max_grid_res=512)),
+             ("from_geometric", dict(feature_dim=4, num_lods=5, multiscale_type='sum', feature_std=0.1, codebook_bitwidth=12,
+                                     min_grid_res=8, max_grid_res=300)),
+             ("from_octree", dict(feature_dim=2, base_lod=3, num_lods=4, multiscale_type='cat', feature_std=0.01, codebook_bitwidth=14))]
+    for ctor, kw in cases:
+        torch.manual_seed(0)
+        r = getattr(Ref, ctor)(blas, **kw)
+        torch.manual_seed(0)
+        m = getattr(Mine, ctor)(blas, **kw)
+        assert [int(x) for x in r.resolutions] == [int(x) for x in m.resolutions], ctor
+        for attr in ("num_lods", "max_lod", "active_lods", "codebook_size", "codebook_bitwidth", "feature_dim", "multiscale_type",
+                     "coord_dim", "num_cells"):
+            assert getattr(r, attr) == getattr(m, attr), (ctor, attr)
+        assert torch.equal(r.dense_points.long(), m.dense_points.long()) and r.occupancy.shape == m.occupancy.shape
+        rs, ms = r.state_dict(), m.state_dict()
+        assert list(rs) == list(ms), (list(rs), list(ms))
+        for k in rs:
+            assert rs[k].shape == ms[k].shape and rs[k].dtype == ms[k].dtype, k
+        assert torch.equal(rs["codebook.feats"], ms["codebook.feats"])                   # same initial draw
+        assert r.blas is m.blas is blas
+
+
+def test_accelstruct_result_dataclasses_equal_the_reference_definitions():
+    """AS*Results (accelstructs/base_as.py): field names, order and defaults are the contract between BLAS and tracers."""
+    import dataclasses
+    import wisp.accelstructs as mine
+    ref = _exec_reference("accelstructs/base_as.py")
+    for name in ("ASQueryResults", "ASRaytraceResults", "ASRaymarchResults"):
+        rf, mf = dataclasses.fields(ref[name]), dataclasses.fields(getattr(mine, name))
+        assert [f.name for f in rf] == [f.name for f in mf], name
+        for a, b in zip(rf, mf):
+            assert (a.default is dataclasses.MISSING) == (b.default is dataclasses.MISSING), (name, a.name)
+            if a.default is not dataclasses.MISSING:
+                assert a.default == b.default, (name, a.name)
+    for meth in ("query", "raytrace", "raymarch", "occupancy", "capacity_at", "name"):
+        if hasattr(ref["BaseAS"], meth):
+            assert hasattr(mine.BaseAS, meth), meth
+
+
+def test_sphere_samplers_equal_the_reference_functions():
+    """wisp/ops/geometric.py:25-62 - the prune's view directions come from sample_unif_sphere (numpy's global generator)."""
+    import wisp.ops.geometric as mine
+    ref = _exec_reference("ops/geometric.py")             # its `import wisp._C` is this package's module
+    np.random.seed(4)
+    want = ref["sample_unif_sphere"](1000)
+    np.random.seed(4)
+    got = mine.sample_unif_sphere(1000)
+    assert np.array_equal(got, want) and got.shape == (1000, 3)
+    assert np.array_equal(mine.sample_fib_sphere(777), ref["sample_fib_sphere"](777))
+
+
+def test_radiance_field_construction_equals_the_reference_class():
+    """The reference's OWN NeuralRadianceField (models/nefs/nerf.py:30-217), executed in place over this package's grids,
+    decoders, embedders and base class, next to wisp.models.nefs.NeuralRadianceField built with the same arguments: same
+    decoders (names, order, shapes, initial values incl. the density bias of nerf.py:162-163), same registered channels,
+    same feature / embedding widths - for the nerf_hash.yaml arguments and a positional-position, bias-free variant."""
+    from wisp.accelstructs import OctreeAS
+    from wisp.models.grids import HashGrid
+    from wisp.models.nefs import NeuralRadianceField as Mine
+    Ref = _exec_reference("models/nefs/nerf.py")["NeuralRadianceField"]
+    blas = OctreeAS.make_dense(3)
+    for kw in (dict(pos_embedder='none', view_embedder='positional', view_multires=4, activation_type='relu', layer_type='linear',
+                    hidden_dim=64, num_layers=1, bias=True, prune_density_decay=0.95, prune_min_density=2.956),
+               dict(pos_embedder='positional', pos_multires=6, view_embedder='positional', view_multires=2, activation_type='relu',
+                    layer_type='linear', hidden_dim=128, num_layers=2, bias=False)):
+        torch.manual_seed(1)
+        grid_r = HashGrid.from_geometric(blas, feature_dim=2, num_lods=16, multiscale_type='cat', feature_std=0.01,
+                                         codebook_bitwidth=12, min_grid_res=16, max_grid_res=512)
+        r = Ref(grid_r, **kw)
+        torch.manual_seed(1)
+        grid_m = HashGrid.from_geometric(blas, feature_dim=2, num_lods=16, multiscale_type='cat', feature_std=0.01,
+                                         codebook_bitwidth=12, min_grid_res=16, max_grid_res=512)
+        m = Mine(grid_m, **kw)
+        rs, ms = r.state_dict(), m.state_dict()
+        assert list(rs) == list(ms)
+        for k in rs:
+            assert torch.equal(rs[k], ms[k]), k                                          # same construction order => same draws
+        assert r.effective_feature_dim() == m.effective_feature_dim()
+        assert r.view_embed_dim == m.view_embed_dim and r.pos_embed_dim == m.pos_embed_dim
+        assert r.get_supported_channels() == m.get_supported_channels() == {"rgb", "density"}
+        for attr in ("prune_density_decay", "prune_min_density", "hidden_dim", "num_layers", "bias", "position_input"):
+            if hasattr(r, attr):
+                assert getattr(r, attr) == getattr(m, attr), attr
+
+
+def test_base_tracer_argument_plumbing_equals_the_reference_class():
+    """BaseTracer.forward (tracers/base_tracer.py:99-162): channel negotiation and how trace()'s optional arguments are filled
+    from keyword arguments or from same-named attributes - the reference's class and this package's, subclassed identically."""
+    from wisp.tracers import BaseTracer as Mine
+    Ref = _exec_reference("tracers/base_tracer.py")["BaseTracer"]
+
+    def make(base):
+        class T(base):
+            def __init__(self):
+                super().__init__(bg_color=(0.1, 0.2, 0.3))
+                self.num_steps, self.raymarch_type, self.step_size = 96, 'voxel', None
+
+            def get_supported_channels(self):
+                return {"rgb", "depth"}
+
+            def get_required_nef_channels(self):
+                return {"rgb", "density"}
+
+            def trace(self, nef, rays, channels, extra_channels, lod_idx=None, raymarch_type='ray', num_steps=64, step_size=1.0, bg_color=None):
+                return dict(channels=channels, extra=extra_channels, lod_idx=lod_idx, raymarch_type=raymarch_type,
+                            num_steps=num_steps, step_size=step_size, bg_color=bg_color)
+        return T()
+
+    class Nef:
+        def __init__(self, chans):
+            self.chans = chans
+
+        def get_supported_channels(self):
+            return set(self.chans)
+
+    r, m = make(Ref), make(Mine)
+    nef = Nef({"rgb", "density", "normal"})
+    for kw in (dict(), dict(channels="rgb"), dict(channels=["rgb", "normal"]), dict(channels={"depth"}, num_steps=7, lod_idx=2),
+               dict(channels=None, raymarch_type='uniform', step_size=0.5)):
+        assert r(nef, "rays", **kw) == m(nef, "rays", **kw), kw
+    for bad_nef, kw in ((Nef({"rgb"}), dict()), (nef, dict(channels=["rgb", "semantics"]))):
+        with pytest.raises(Exception) as e1:
+            r(bad_nef, "rays", **kw)
+        with pytest.raises(Exception) as e2:
+            m(bad_nef, "rays", **kw)
+        assert type(e1.value) is type(e2.value)
