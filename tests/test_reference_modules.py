@@ -398,3 +398,141 @@ def test_neural_sdf_and_pipeline_construction_equal_the_reference_classes():
     pr, pm = RefPipe(m, Tracer()), MinePipe(m, Tracer())
     assert pr(rays="R", channels=["sdf"])[2] == pm(rays="R", channels=["sdf"])[2]
     assert [n for n, _ in pr.named_children()] == [n for n, _ in pm.named_children()]
+
+
+def _reference_method(rel, cls_name, meth_name, glb):
+    """compile ONE method of a reference class from the file where it lies (the module itself imports the whole application)"""
+    import ast
+    path = os.path.join(REF, rel)
+    tree = ast.parse(open(path).read(), path)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls_name)
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == meth_name)
+    fn.decorator_list = []                                    # profiler ranges (@torch.cuda.nvtx.range): not part of the semantics
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = dict(glb)
+    exec(compile(mod, path, "exec"), ns)
+    return ns[meth_name]
+
+
+def test_optimizer_parameter_groups_equal_the_reference_init_optimizer():
+    """BaseTrainer.init_optimizer (trainers/base_trainer.py:205-236), the method itself compiled from the reference file and
+    run on a stand-in trainer: which parameter lands in which group with which learning rate / weight decay - against the
+    flat-buffer groups MultiviewTrainStep hands its fused optimizer."""
+    from wisp.accelstructs import OctreeAS
+    from wisp.models.grids import HashGrid
+    from wisp.models.nefs import NeuralRadianceField
+    from wisp.trainers import FlatParams
+    init_optimizer = _reference_method("trainers/base_trainer.py", "BaseTrainer", "init_optimizer",
+                                       dict(torch=torch, instantiate=lambda cfg, params: torch.optim.AdamW(
+                                           params, lr=cfg.lr, eps=cfg.eps, weight_decay=cfg.weight_decay, betas=cfg.betas)))
+    torch.manual_seed(0)
+    grid = HashGrid.from_geometric(OctreeAS.make_dense(3), feature_dim=2, num_lods=8, multiscale_type='cat', feature_std=0.01,
+                                   codebook_bitwidth=10, min_grid_res=8, max_grid_res=64)
+    nef = NeuralRadianceField(grid, view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1, bias=True)
+    cfg = types.SimpleNamespace(optimizer=types.SimpleNamespace(lr=1e-3, eps=1e-16, weight_decay=1e-6, betas=(0.9, 0.999)),
+                                grid_lr_weight=100.0, max_epochs=10, scheduler=False, scheduler_milestones=[0.5], scheduler_gamma=0.333)
+    me = types.SimpleNamespace(pipeline=types.SimpleNamespace(nef=nef), cfg=cfg, train_dataset=list(range(7)))
+    init_optimizer(me)
+    groups = me.optimizer.param_groups
+    assert len(groups) == 3
+    by_ptr = {}
+    for g in groups:
+        for p in g["params"]:
+            by_ptr[p.data_ptr()] = (g["lr"], g["weight_decay"], g["eps"])
+    # this package: one flat buffer, ranges per group; MultiviewTrainStep.optimizer_step gives range g (lr_g, weight_decay, eps)
+    names = {p.data_ptr(): n for n, p in nef.named_parameters()}
+    want = {n: by_ptr[ptr] for ptr, n in names.items()}
+    flat = FlatParams(nef)
+    lr_of = {"decoder": cfg.optimizer.lr, "grid": cfg.optimizer.lr * cfg.grid_lr_weight, "rest": cfg.optimizer.lr}
+    base = flat.data.data_ptr()
+    seen = 0
+    for n, p in nef.named_parameters():
+        if not p.requires_grad:                            # the embedder's frozen `bands`: in the reference's 'rest' group, never stepped
+            assert want[n][0] == cfg.optimizer.lr
+            continue
+        off = (p.data_ptr() - base) // 4
+        grp = next(g for g, (a, b) in flat.ranges.items() if a <= off < b)
+        assert (lr_of[grp], cfg.optimizer.weight_decay, cfg.optimizer.eps) == want[n], (n, grp)
+        seen += 1
+    assert seen == sum(1 for _, p in nef.named_parameters() if p.requires_grad) >= 9
+    assert abs(want["grid.codebook.feats"][0] - 0.1) < 1e-12
+
+
+class _TorchWithoutNvtx:
+    """`torch` for reference method bodies on a CPU box: everything forwarded, torch.cuda.nvtx.range a no-op context"""
+    def __init__(self):
+        import contextlib
+        self.cuda = types.SimpleNamespace(nvtx=types.SimpleNamespace(range=lambda *_a, **_k: contextlib.nullcontext()),
+                                          amp=torch.cuda.amp)
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+
+@pytest.mark.parametrize("loss_type", ["huber", "l2", "l1"])
+def test_training_step_semantics_equal_the_reference_methods(loss_type):
+    """MultiviewTrainer.pre_step / step / calc_adaptive_rays (trainers/multiview_trainer.py:86-180): the three method bodies
+    compiled from the reference file and driven for six iterations (prune_every = 2: two prunes) over a CPU stand-in
+    pipeline with torch.optim.AdamW - next to MultiviewTrainStep.step over an identical pipeline (its fused optimizer replaced
+    by the CPU restatement of the kernel arithmetic).  Same prune timing, same loss, same parameters afterwards, same adaptive
+    ray count."""
+    import math
+    import random
+    import test_distributed_gloo as stub
+    import wisp._C as C
+    from wisp.core import Rays
+    from wisp.datasets.transforms import SampleRays
+    from wisp.trainers import MultiviewTrainStep
+    glb = dict(torch=_TorchWithoutNvtx(), math=math, random=random, SampleRays=SampleRays)
+    ref_pre = _reference_method("trainers/multiview_trainer.py", "MultiviewTrainer", "pre_step", glb)
+    ref_step = _reference_method("trainers/multiview_trainer.py", "MultiviewTrainer", "step", glb)
+    ref_rays = _reference_method("trainers/multiview_trainer.py", "MultiviewTrainer", "calc_adaptive_rays", glb)
+    g = torch.Generator().manual_seed(3)
+    O, D, T = torch.rand(96, 3, generator=g) * 2 - 1, torch.randn(96, 3, generator=g), torch.rand(96, 3, generator=g)
+    lr, wd, eps, glw = 1e-2, 1e-6, 1e-16, 10.0
+
+    # ---- the reference's methods on a stand-in trainer object
+    pipe_r = stub._StubPipeline()
+    pipe_r.tracer.raymarch_type, pipe_r.tracer.num_steps = 'ray', 64
+    prunes_r = []
+    pipe_r.nef.prune = lambda: prunes_r.append(me.total_iterations)
+    named = dict(pipe_r.nef.named_parameters())
+    groups = [{"params": [p for n, p in named.items() if 'decoder' in n], "lr": lr},
+              {"params": [p for n, p in named.items() if 'decoder' not in n and 'grid' in n], "lr": lr * glw},
+              {"params": [p for n, p in named.items() if 'decoder' not in n and 'grid' not in n], "lr": lr}]
+    metrics = types.SimpleNamespace(total_loss=0.0, rgb_loss=0.0, num_samples=0)
+    me = types.SimpleNamespace(
+        pipeline=pipe_r, device='cpu', total_iterations=0, optimizer=torch.optim.AdamW(groups, lr=lr, eps=eps, weight_decay=wd),
+        cfg=types.SimpleNamespace(prune_every=2, random_lod=False, rgb_loss_type=loss_type, rgb_loss_denom='rays', opacity_loss=0.0,
+                                  enable_amp=False, scheduler=False, target_sample_size=2 ** 12),
+        tracker=types.SimpleNamespace(metrics=metrics), train_dataset=types.SimpleNamespace(transform=SampleRays(96)))
+    me.calc_adaptive_rays = lambda rays, warmup=False: ref_rays(me, rays, warmup)
+
+    class _Base:                                              # super().pre_step() of BaseTrainer: nothing this path reads
+        def pre_step(self):
+            pass
+    glb["super"] = lambda: _Base()
+    ref_pre = _reference_method("trainers/multiview_trainer.py", "MultiviewTrainer", "pre_step", glb)
+    ref_losses = []
+    for it in range(6):
+        ref_pre(me)
+        before = metrics.rgb_loss
+        ref_step(me, {"rays": Rays(O, D)[None] if False else Rays(O[None], D[None]), "rgb": T[None]})
+        ref_losses.append(metrics.rgb_loss - before)
+        me.total_iterations += 1                              # BaseTrainer.iterate: post_step bookkeeping
+
+    # ---- this package's step
+    C.adamw_step_groups = stub._torch_adamw_groups
+    pipe_m = stub._StubPipeline()
+    tr = MultiviewTrainStep(pipe_m, lr=lr, eps=eps, weight_decay=wd, grid_lr_weight=glw, rgb_loss_type=loss_type, prune_every=2,
+                            target_sample_size=2 ** 12, seed=5)
+    my_losses = []
+    for it in range(6):
+        loss, _ = tr.step(Rays(O, D), T)
+        my_losses.append(float(loss))
+    assert prunes_r == [2, 4] and len(pipe_m.nef.prune_log) == 2                          # prune before iterations 2 and 4 on both sides
+    np.testing.assert_allclose(my_losses, ref_losses, rtol=2e-6, atol=1e-8)
+    for (n1, p1), (n2, p2) in zip(pipe_r.nef.named_parameters(), pipe_m.nef.named_parameters()):
+        assert n1 == n2
+        np.testing.assert_allclose(p2.detach().numpy(), p1.detach().numpy(), rtol=1e-5, atol=2e-7, err_msg=n1)
+    assert tr.num_rays == me.train_dataset.transform.num_samples                          # same adaptive ray count
