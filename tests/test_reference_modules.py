@@ -536,3 +536,66 @@ def test_training_step_semantics_equal_the_reference_methods(loss_type):
         assert n1 == n2
         np.testing.assert_allclose(p2.detach().numpy(), p1.detach().numpy(), rtol=1e-5, atol=2e-7, err_msg=n1)
     assert tr.num_rays == me.train_dataset.transform.num_samples                          # same adaptive ray count
+
+
+def _torch_optim_groups(kind, param, grad, s1, s2, groups, h0, h1, eps, step, grad_scale=1.0, zero_grad=False):
+    """CPU stand-in for the fused optimizer launch (test infrastructure): csrc/misc.hip optim_groups_kernel, kind 'adam'."""
+    assert kind == 'adam'
+    bc1, bc2 = 1 - h0 ** step, (1 - h1 ** step) ** 0.5
+    for a, n, lr, wd, _shadow in groups:
+        p, g, m, v = param[a:a + n], grad[a:a + n] * grad_scale, s1[a:a + n], s2[a:a + n]
+        g = g + wd * p
+        m.mul_(h0).add_(g, alpha=1 - h0)
+        v.mul_(h1).addcmul_(g, g, value=1 - h1)
+        p.sub_((lr / bc1) * m / (v.sqrt() / bc2 + eps))
+    if zero_grad:
+        grad.zero_()
+
+
+def test_sdf_training_step_semantics_equal_the_reference_method():
+    """SDFTrainer.step (trainers/sdf_trainer.py:65-124), the method body compiled from the reference file, over a CPU
+    stand-in field with torch.optim.Adam - next to SDFTrainStep.step (fused optimizer replaced by its CPU restatement):
+    loss = sum over the loss LODs of the squared error, divided by the batch size; same parameters after five steps."""
+    import wisp._C as C
+    from wisp.trainers import SDFTrainStep
+    ref_step = _reference_method("trainers/sdf_trainer.py", "SDFTrainer", "step", dict(torch=_TorchWithoutNvtx()))
+
+    class Field(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(8)
+            self.grid = torch.nn.Module()
+            self.grid.num_lods = 3
+            self.grid.feats = torch.nn.Parameter(torch.randn(3, 32, 4) * 0.1)            # 'grid' in the name -> grid group
+            self.decoder = torch.nn.Linear(4 + 3, 1)
+
+        def forward(self, coords=None, lod_idx=None, channels=None):
+            cell = ((coords[:, 0] * 0.5 + 0.5) * 31).long().clamp(0, 31)
+            f = self.grid.feats[: lod_idx + 1, cell].sum(0)
+            out = self.decoder(torch.cat([f, coords], -1))
+            return [out] if isinstance(channels, (list, tuple)) else out
+
+    g = torch.Generator().manual_seed(2)
+    X, Y = torch.rand(5, 64, 3, generator=g) * 2 - 1, torch.randn(5, 64, 1, generator=g) * 0.1
+    for only_last in (True, False):
+        fr, fm = Field(), Field()
+        lods = [2] if only_last else [0, 1, 2]
+        named = dict(fr.named_parameters())
+        opt = torch.optim.Adam([{"params": [p for n, p in named.items() if 'decoder' in n], "lr": 1e-3},
+                                {"params": [p for n, p in named.items() if 'decoder' not in n], "lr": 2e-3}], eps=1e-15)
+        metrics = types.SimpleNamespace(total_loss=0.0, l2_loss=0.0, rgb_loss=0.0, num_samples=0)
+        me = types.SimpleNamespace(pipeline=types.SimpleNamespace(nef=fr, zero_grad=fr.zero_grad), device='cpu', loss_lods=lods,
+                                   train_dataset=types.SimpleNamespace(), tracker=types.SimpleNamespace(metrics=metrics), optimizer=opt)
+        saved = getattr(C, "optim_step_groups")
+        C.optim_step_groups = _torch_optim_groups
+        try:
+            tr = SDFTrainStep(fm, lr=1e-3, eps=1e-15, grid_lr_weight=2.0, optimizer='adam', only_last=only_last)
+            for x, y in zip(X, Y):
+                before = metrics.total_loss
+                ref_step(me, {"coords": x, "sdf": y})
+                loss = tr.step(x, y)
+                assert abs(float(loss) * x.shape[0] - (metrics.total_loss - before)) <= 2e-5 * max(1.0, metrics.total_loss - before)
+        finally:
+            C.optim_step_groups = saved
+        for (n1, p1), (n2, p2) in zip(fr.named_parameters(), fm.named_parameters()):
+            np.testing.assert_allclose(p2.detach().numpy(), p1.detach().numpy(), rtol=1e-5, atol=2e-7, err_msg=n1)
