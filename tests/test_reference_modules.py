@@ -599,3 +599,63 @@ def test_sdf_training_step_semantics_equal_the_reference_method():
             C.optim_step_groups = saved
         for (n1, p1), (n2, p2) in zip(fr.named_parameters(), fm.named_parameters()):
             np.testing.assert_allclose(p2.detach().numpy(), p1.detach().numpy(), rtol=1e-5, atol=2e-7, err_msg=n1)
+
+
+@pytest.mark.parametrize("mode,steps", [("ray", 96), ("voxel", 6)])
+def test_oracle_tracer_equals_the_reference_trace_body(mode, steps):
+    """PackedRFTracer.trace (tracers/packed_rf_tracer.py:84-181), the method body compiled from the reference file, driven with
+    the oracle's raymarch as `nef.grid.raymarch`, the oracle's radiance field as `nef(...)` and the oracle's restatement of the
+    two Kaolin compositing leaves as `spc_render` - against oracle.nerf.trace, the tracer every GPU end-to-end test is compared
+    with: the way the pieces are put together (optical thickness, exclusive transmittance, depth / alpha / hit / background
+    scatter) is the reference's own code, bit for bit."""
+    from oracle import nerf as onerf, raymarch as oray, render as orender
+    from wisp.core import Rays, RenderBuffer
+    spc_render = types.SimpleNamespace(exponential_integration=orender.exponential_integration, sum_reduce=orender.sum_reduce)
+    trace = _reference_method("tracers/packed_rf_tracer.py", "PackedRFTracer", "trace",
+                              dict(torch=_TorchWithoutNvtx(), spc_render=spc_render, RenderBuffer=RenderBuffer))
+    rng = np.random.default_rng(60)
+    blas = onerf.OracleBLAS.from_quantized_points(rng.integers(0, 16, size=(500, 3)), 4)
+    res = [8, 16, 32, 64]
+    torch.manual_seed(4)
+    onef = onerf.OracleNeRF(res, 2, 10, 'cat', 0.3, 64, 1, True, 4)
+    o = rng.normal(size=(120, 3)).astype(np.float32)
+    o = 3.0 * o / np.linalg.norm(o, axis=1, keepdims=True)
+    d = (-o + rng.normal(size=o.shape).astype(np.float32) * 0.4)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    O, D = torch.from_numpy(o), torch.from_numpy(d)
+    if mode == "ray":
+        jit = rng.uniform(size=(120, steps)).astype(np.float32)
+    else:
+        from oracle import spc as ospc
+        nn = ospc.raytrace(blas.octree, blas.points, blas.pyramid, blas.exsum, o, d, blas.max_level, True)[0].shape[0]
+        jit = rng.uniform(size=(nn, steps)).astype(np.float32)
+    bg = (0.2, 0.5, 0.7)
+    with torch.no_grad():
+        want = onerf.trace(onef, blas, O, D, 1.0, 5.0, steps, jit, bg, mode, with_depth=True)
+
+    class Grid:
+        num_lods, active_lods = len(res), [blas.max_level] * len(res)
+
+        @staticmethod
+        def raymarch(rays, level, num_samples, raymarch_type):
+            rm = want["raymarch"]                             # the oracle's samples for exactly these rays
+            assert raymarch_type == mode and num_samples == steps
+            return types.SimpleNamespace(ridx=torch.from_numpy(rm["ridx"]), samples=torch.from_numpy(rm["samples"]),
+                                         deltas=torch.from_numpy(rm["deltas"]), depth_samples=torch.from_numpy(rm["depth_samples"]),
+                                         boundary=torch.from_numpy(rm["boundary"]), pack_info=None)
+
+    class Nef:
+        grid = Grid()
+
+        def __call__(self, coords=None, ray_d=None, lod_idx=None, channels=None):
+            out = onef.rgba(coords, ray_d, lod_idx)
+            return [out[c] for c in channels] if isinstance(channels, (list, tuple)) else out[channels]
+
+    me = types.SimpleNamespace(bg_color=torch.tensor(bg), prev_num_samples=None)
+    with torch.no_grad():
+        rb = trace(me, Nef(), Rays(O, D, dist_min=1.0, dist_max=5.0), {"rgb", "depth", "alpha", "hit"}, set(), lod_idx=None,
+                   raymarch_type=mode, num_steps=steps, bg_color=bg)
+    assert me.prev_num_samples == want["raymarch"]["ridx"].shape[0] > 500
+    assert torch.equal(rb.rgb, want["rgb"]) and torch.equal(rb.alpha, want["alpha"])
+    assert torch.equal(rb.depth, want["depth"]) and torch.equal(rb.hit, want["hit"])
+    assert int(rb.hit.sum()) > 20
