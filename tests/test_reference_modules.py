@@ -659,3 +659,94 @@ def test_oracle_tracer_equals_the_reference_trace_body(mode, steps):
     assert torch.equal(rb.rgb, want["rgb"]) and torch.equal(rb.alpha, want["alpha"])
     assert torch.equal(rb.depth, want["depth"]) and torch.equal(rb.hit, want["hit"])
     assert int(rb.hit.sum()) > 20
+
+
+def _reference_function(rel, fn_name, glb):
+    """compile ONE module-level function of a reference file (decorators dropped)"""
+    import ast
+    path = os.path.join(REF, rel)
+    tree = ast.parse(open(path).read(), path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == fn_name)
+    fn.decorator_list = []
+    ns = dict(glb)
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    return ns[fn_name]
+
+
+class _TorchWithDraws(_TorchWithoutNvtx):
+    """... and torch.rand / torch.rand_like hand out prepared jitter instead of fresh draws"""
+    def __init__(self, draws):
+        super().__init__()
+        self._draws = draws
+
+    def rand(self, *shape, **kw):
+        assert tuple(shape) == tuple(self._draws.shape), (shape, self._draws.shape)
+        return self._draws.clone()
+
+    def rand_like(self, t, **kw):
+        assert tuple(t.shape) == tuple(self._draws.shape), (t.shape, self._draws.shape)
+        return self._draws.clone()
+
+
+@pytest.mark.parametrize("mode,steps", [("ray", 128), ("voxel", 5), ("uniform", 48)])
+def test_oracle_raymarch_equals_the_reference_method_bodies(mode, steps):
+    """OctreeAS._raymarch_ray / _raymarch_voxel / _raymarch_uniform (accelstructs/octree_as.py:188-374) and the helper
+    fast_filter_method, compiled from the reference file and run with the oracle's restatements of the Kaolin leaves
+    (query, raytrace, pack boundaries, inclusive sum) and of the uniform-sample kernel (itself pinned to the reference's CUDA
+    body, test_oracle_golden) plugged in, and the random draws injected - against oracle.raymarch.*, what the HIP raymarch
+    kernels are compared with bit for bit: ray indices, sample positions, depths, deltas and pack boundaries."""
+    from typing import Tuple
+    from oracle import nerf as onerf, raymarch as oray, spc as ospc
+    from wisp.accelstructs import ASRaymarchResults
+    from wisp.core import Rays
+    rng = np.random.default_rng(70)
+    blas = onerf.OracleBLAS.from_quantized_points(rng.integers(0, 32, size=(1500, 3)), 5)
+    o = rng.normal(size=(150, 3)).astype(np.float32)
+    o = 3.0 * o / np.linalg.norm(o, axis=1, keepdims=True)
+    d = (-o + rng.normal(size=o.shape).astype(np.float32) * 0.5)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = Rays(torch.from_numpy(o), torch.from_numpy(d), dist_min=1.0, dist_max=5.0)
+    level = blas.max_level
+    nug = ospc.raytrace(blas.octree, blas.points, blas.pyramid, blas.exsum, o, d, level, True)
+    if mode == "ray":
+        jit = rng.uniform(size=(150, steps)).astype(np.float32)
+        want = oray.raymarch_ray(blas.octree, blas.exsum, o, d, 1.0, 5.0, steps, level, jit)
+    elif mode == "voxel":
+        jit = rng.uniform(size=(nug[0].shape[0], steps)).astype(np.float32)
+        want = oray.raymarch_voxel(blas.octree, blas.points, blas.pyramid, blas.exsum, o, d, steps, level, jit)
+    else:
+        jit = np.zeros((1, 1), np.float32)
+        want = oray.raymarch_uniform(blas.octree, blas.points, blas.pyramid, blas.exsum, o, d, steps, level)
+    tproxy = _TorchWithDraws(torch.from_numpy(jit))
+    sampling = _exec_reference("ops/spc/sampling.py")
+    sampling["torch"] = tproxy                                   # its rand_like -> the injected jitter
+    wisp_spc_ops = types.SimpleNamespace(sample_from_depth_intervals=sampling["sample_from_depth_intervals"],
+                                         expand_pack_boundary=sampling["expand_pack_boundary"])
+    first_hit = lambda ridx: torch.from_numpy(ospc.mark_pack_boundaries(ridx.numpy()))
+    spc_render = types.SimpleNamespace(mark_pack_boundaries=first_hit, mark_first_hit=first_hit)
+    kaolin_C = types.SimpleNamespace(render=types.SimpleNamespace(spc=types.SimpleNamespace(
+        inclusive_sum_cuda=lambda x: torch.from_numpy(ospc.inclusive_sum(x.numpy())))))
+
+    def uniform_sample_cuda(scale, ridx, depth, insum):
+        out = oray.uniform_sample(scale, ridx.numpy(), depth.numpy(), insum.numpy())
+        return [torch.from_numpy(out["ridx"]), torch.from_numpy(out["depth_samples"]), torch.from_numpy(out["boundary"])]
+    wisp_C = types.SimpleNamespace(ops=types.SimpleNamespace(uniform_sample_cuda=uniform_sample_cuda))
+    glb = dict(torch=tproxy, np=np, Tuple=Tuple, ASRaymarchResults=ASRaymarchResults, wisp_spc_ops=wisp_spc_ops,
+               spc_render=spc_render, _C=kaolin_C, wisp_C=wisp_C)
+    glb["fast_filter_method"] = _reference_function("accelstructs/octree_as.py", "fast_filter_method", glb)
+    method = _reference_method("accelstructs/octree_as.py", "OctreeAS", "_raymarch_" + mode, glb)
+    me = types.SimpleNamespace(
+        max_level=level,
+        query=lambda coords, level=None, with_parents=False: types.SimpleNamespace(
+            pidx=torch.from_numpy(ospc.query(blas.octree, blas.exsum, coords.numpy(), level))),
+        raytrace=lambda rays, level=None, with_exit=False: types.SimpleNamespace(
+            ridx=torch.from_numpy(nug[0]).int(), pidx=torch.from_numpy(nug[1]).int(), depth=torch.from_numpy(nug[2])))
+    res = method(me, rays, steps, level)
+    assert res.ridx.shape[0] == want["ridx"].shape[0] > 150
+    assert np.array_equal(res.ridx.numpy(), want["ridx"])                               # the same samples survive, in the same order
+    assert np.array_equal(res.boundary.numpy().astype(bool), want["boundary"])
+    # values: the oracle restates the arithmetic as the GPU evaluates it (product of addcmul rounded before the add, DESIGN 7);
+    # torch's CPU kernels fuse / order a few of these operations differently - a last-bit matter
+    np.testing.assert_allclose(res.depth_samples.numpy(), want["depth_samples"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(res.deltas.numpy(), want["deltas"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(res.samples.numpy(), want["samples"], rtol=0, atol=1e-6)
