@@ -750,3 +750,49 @@ def test_oracle_raymarch_equals_the_reference_method_bodies(mode, steps):
     np.testing.assert_allclose(res.depth_samples.numpy(), want["depth_samples"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(res.deltas.numpy(), want["deltas"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(res.samples.numpy(), want["samples"], rtol=0, atol=1e-6)
+
+
+def test_oracle_prune_equals_the_reference_method_body(monkeypatch):
+    """NeuralRadianceField.prune (models/nefs/nerf.py:175-212), the method body compiled from the reference file with the
+    random draws injected and the oracle's field / octree builder plugged in - against oracle.nerf.prune: decayed occupancy,
+    density query at the jittered cell positions, running maximum, threshold, rebuilt octree."""
+    from oracle import nerf as onerf
+    rng = np.random.default_rng(80)
+    blas = onerf.OracleBLAS.make_dense(4)
+    dense = blas.level_points().copy()
+    cells = dense.shape[0]
+    torch.manual_seed(6)
+    onef = onerf.OracleNeRF([8, 16, 32, 64], 2, 10, 'cat', 0.5, 64, 1, True, 4)
+    unit = torch.from_numpy(rng.uniform(size=(cells, 3)).astype(np.float32))
+    views = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(cells, 3)).astype(np.float32)), dim=1)
+    occ0 = torch.from_numpy(rng.uniform(0, 2, cells).astype(np.float32))
+    with torch.no_grad():
+        dens = onef.rgba((((torch.from_numpy(dense.astype(np.float32)) + unit) / 16) * 2 - 1), views)["density"][:, 0]
+    thr = float(torch.maximum(dens, occ0 * 0.95).median())                          # keeps about half of the cells
+    want_blas, want_occ = onerf.prune(onef, blas, occ0.clone(), dense, 0.95, thr, unit, views)
+
+    class Grid:
+        pass
+
+    class Blas:
+        max_level = blas.max_level
+        rebuilt = None
+
+        @classmethod
+        def from_quantized_points(cls, pts, level):
+            b = cls()
+            b.oracle = onerf.OracleBLAS.from_quantized_points(pts.numpy(), level)
+            return b
+    grid = Grid()
+    grid.occupancy, grid.dense_points, grid.blas = occ0.clone(), torch.from_numpy(dense.astype(np.int16)), Blas()
+    me = types.SimpleNamespace(prune_density_decay=0.95, prune_min_density=thr, grid=grid,
+                               forward=lambda coords=None, ray_d=None, channels=None: onef.rgba(coords, ray_d)[channels])
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)            # `.cuda()` calls of the body on a CPU box
+    body = _reference_method("models/nefs/nerf.py", "NeuralRadianceField", "prune",
+                             dict(torch=_TorchWithDraws(unit), HashGrid=Grid, TriplanarGrid=Grid,
+                                  sample_unif_sphere=lambda n: views.numpy()))
+    body(me)
+    assert torch.equal(grid.occupancy, want_occ)
+    assert want_blas is not None and np.array_equal(grid.blas.oracle.octree, want_blas.octree)
+    kept = int(grid.blas.oracle.pyramid[0, blas.max_level])
+    assert 0.3 * cells < kept < 0.7 * cells
