@@ -165,7 +165,8 @@ def _kaolin_stub():
     (pyramid row 0 = counts, row 1 = offsets; kaolin/ops/spc/spc.py)"""
     k = types.ModuleType("kaolin"); k.ops = types.ModuleType("kaolin.ops"); k.ops.spc = types.ModuleType("kaolin.ops.spc")
     k.ops.spc.unbatched_get_level_points = lambda points, pyramid, level: points[int(pyramid[1, level]):int(pyramid[1, level]) + int(pyramid[0, level])]
-    return {"kaolin": k, "kaolin.ops": k.ops, "kaolin.ops.spc": k.ops.spc}
+    k._C = types.ModuleType("kaolin._C")                      # `from kaolin import _C` (wisp/ops/grid.py:10): imported, unused here
+    return {"kaolin": k, "kaolin.ops": k.ops, "kaolin.ops.spc": k.ops.spc, "kaolin._C": k._C}
 
 
 def test_hash_grid_constructors_equal_the_reference_class():
@@ -796,3 +797,66 @@ def test_oracle_prune_equals_the_reference_method_body(monkeypatch):
     assert want_blas is not None and np.array_equal(grid.blas.oracle.octree, want_blas.octree)
     kept = int(grid.blas.oracle.pyramid[0, blas.max_level])
     assert 0.3 * cells < kept < 0.7 * cells
+
+
+@pytest.mark.parametrize("multiscale", ["cat", "sum"])
+def test_oracle_hash_grid_equals_the_whole_reference_stack_on_the_host(multiscale):
+    """The reference's complete hash-grid path on the CPU: `HashGrid.interpolate` (models/grids/hash_grid.py:205-233, body
+    compiled from the file) -> `wisp/ops/grid.py` (hashgrid + the HashGridInterpolate autograd function, executed in place) ->
+    `wisp._C.ops.hashgrid_interpolate_cuda / _backward_cuda` = the reference's own kernel bodies compiled for the host
+    (oracle/_ref, oracle/build_ref.sh) - against oracle.hashgrid.grid_interpolate, forward (bit-exact, every lod_idx, [B,3]
+    and [B,S,3] inputs) and the gradient w.r.t. the table."""
+    from oracle import hashgrid as ohash, ref_lib
+    if not ref_lib.available():
+        pytest.skip("oracle/_ref not built")
+    from wisp.models.grids.utils import MultiTable
+
+    def fwd(coords, codebook, first_idx, resolution, bitwidth):
+        res = [int(r) for r in resolution.reshape(-1).tolist()]
+        return torch.from_numpy(ref_lib.hashgrid_forward(coords.numpy(), codebook.detach().numpy(), first_idx.numpy(), res, int(bitwidth)))
+
+    def bwd(coords, grad_output, codebook, first_idx, resolution, bitwidth, feature_dim, require_grad_coords):
+        res = [int(r) for r in resolution.reshape(-1).tolist()]
+        g = ref_lib.hashgrid_backward(coords.numpy(), grad_output.numpy(), codebook.detach().numpy(), first_idx.numpy(), res, int(bitwidth))
+        return [torch.empty(0), torch.from_numpy(g)]
+    native = types.ModuleType("wisp._C")
+    native.ops = types.SimpleNamespace(hashgrid_interpolate_cuda=fwd, hashgrid_interpolate_backward_cuda=bwd)
+    import wisp
+    stubs = dict(_kaolin_stub())
+    stubs["wisp._C"] = native
+    saved = {k: sys.modules.get(k) for k in stubs}
+    saved_attr = getattr(wisp, "_C", None)
+    sys.modules.update(stubs)
+    wisp._C = native
+    try:
+        grid_ops = _exec_reference("ops/grid.py")                 # `import wisp._C as wisp_C` -> the host build of the reference kernels
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        if saved_attr is not None:
+            wisp._C = saved_attr
+    interpolate = _reference_method("models/grids/hash_grid.py", "HashGrid", "interpolate",
+                                    dict(torch=torch, grid_ops=types.SimpleNamespace(hashgrid=grid_ops["hashgrid"])))
+    res, bw, F = [4, 6, 8, 10, 13, 16, 23, 32], 10, 2
+    torch.manual_seed(7)
+    table = MultiTable(res, 3, F, 0.3, 2 ** bw)
+    me = types.SimpleNamespace(codebook=table, codebook_bitwidth=bw, multiscale_type=multiscale, feature_dim=F, resolutions=res)
+    rng = np.random.default_rng(90)
+    flat = torch.from_numpy(rng.uniform(-1, 1, (120, 3)).astype(np.float32))
+    for coords in (flat, flat.reshape(30, 4, 3)):
+        for lod_idx in (0, 3, len(res) - 1):
+            got = interpolate(me, coords, lod_idx)
+            want = ohash.grid_interpolate(coords, lod_idx, multiscale, F, res, bw, table.feats.detach(), table.begin_idxes)
+            assert got.shape == want.shape and torch.equal(got.detach(), want), (tuple(coords.shape), lod_idx)
+    # backward through the reference's autograd function and kernels vs the oracle's
+    go = torch.from_numpy(rng.normal(size=(120, F * len(res) if multiscale == "cat" else F)).astype(np.float32))
+    table.feats.grad = None
+    interpolate(me, flat, len(res) - 1).backward(go)
+    ref_grad = table.feats.grad.clone()
+    t2 = table.feats.detach().clone().requires_grad_(True)
+    ohash.grid_interpolate(flat, len(res) - 1, multiscale, F, res, bw, t2, table.begin_idxes).backward(go)
+    np.testing.assert_allclose(t2.grad.numpy(), ref_grad.numpy(), rtol=0, atol=2e-5)      # the reference adds sequentially in fp32
+    assert float(ref_grad.abs().max()) > 0.1
