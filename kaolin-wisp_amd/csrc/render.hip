@@ -285,6 +285,8 @@ extern "C" int wisp_composite_bwd(const float* grad_rgb, const float* grad_alpha
 // index to the first nugget whose [entry, exit] contains, or lies beyond, the query depth; -1 when there is none.
 // Bug-compatible with the reference on purpose: the search of pack i is bounded by the CURRENT index of pack i+1
 // (not that pack's first nugget), and the last pack is bounded by num_packs rather than num_nugs (.cu:29).
+// One deliberate difference: a finished neighbour (-1) makes that bound 0xFFFFFFFF and the reference then reads past the end
+// of `depth` when the query lies beyond every remaining nugget (undefined there); here the scan also stops at num_nugs -> -1.
 __global__ void __launch_bounds__(256)
 find_depth_bound_kernel(int64_t num_packs, int64_t num_nugs, const float* __restrict__ query,
                         const int32_t* __restrict__ curr_in, int32_t* __restrict__ curr_out,
@@ -295,7 +297,8 @@ find_depth_bound_kernel(int64_t num_packs, int64_t num_nugs, const float* __rest
     const int32_t start = curr_in[t];
     if (start > -1) {
         uint32_t i = (uint32_t)start;
-        const uint32_t stop = (t == num_packs - 1) ? (uint32_t)num_packs : (uint32_t)curr_in[t + 1];
+        uint32_t stop = (t == num_packs - 1) ? (uint32_t)num_packs : (uint32_t)curr_in[t + 1];
+        if ((int64_t)stop > num_nugs) stop = (uint32_t)num_nugs;
         const float q = query[t];
         while (i < stop) {
             const float entry = depth[2 * (int64_t)i], exit_ = depth[2 * (int64_t)i + 1];

@@ -19,5 +19,9 @@ awk '/^void hashgrid_query_cuda_impl\(/{exit} {print}' "$SRC/hashgrid_query_cuda
   | sed -e 's/^#include "hash_utils.cuh"//' > "$HERE/_ref/query_fwd_kernel.inc"
 awk '/^hashgrid_query_backward_cuda_kernel\(/{f=1; print "template<typename scalar_t>\n__global__ void"} f&&/^void hashgrid_query_backward_cuda_impl\(/{exit} f{print}' \
   "$SRC/hashgrid_query_cuda.cu" > "$HERE/_ref/query_bwd_kernel.inc"
+# depth-bound search of the SDF tracer: kernel only, explicit thread index (no grid-stride loop in the kernel)
+awk '/^void find_depth_bound_cuda_impl\(/{exit} {print}' "$REF/wisp/csrc/render/find_depth_bound_cuda.cu" \
+  | sed -e 's/^find_depth_bound_cuda_kernel(/find_depth_bound_cuda_kernel_at(uint tidx_in,/' \
+        -e 's/uint tidx = blockDim.x \* blockIdx.x + threadIdx.x;/uint tidx = tidx_in;/' > "$HERE/_ref/depth_bound_kernel.inc"
 g++ -O2 -std=c++17 -shared -fPIC -ffp-contract=off -I "$HERE/ref_shim" -I "$SRC" "$HERE/ref_wrap.cpp" -o "$HERE/_ref/libwisp_ref.so"
 echo "built $HERE/_ref/libwisp_ref.so"

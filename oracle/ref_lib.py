@@ -103,6 +103,17 @@ def hashgrid_query_backward(coords, grad_out, resolutions, codebook_bitwidth, fe
     return out
 
 
+def find_depth_bound(query, curr_idxes, depth):
+    """find_depth_bound_cuda (render/find_depth_bound.cpp:23-36 + the kernel): query f32 [P], curr_idxes i32 [P], depth f32 [M,2]
+    -> i32 [P] (-1 where nothing is found)."""
+    q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+    cur = np.ascontiguousarray(curr_idxes, dtype=np.int32)
+    dep = np.ascontiguousarray(depth, dtype=np.float32)
+    out = np.empty(q.shape[0], dtype=np.int32)
+    lib().ref_find_depth_bound(ctypes.c_int64(q.shape[0]), ctypes.c_int64(dep.shape[0]), _p(q), _p(cur), _p(out), _p(dep))
+    return out
+
+
 def uniform_sample(scale, ridx, depth, insum):
     ridx = np.ascontiguousarray(ridx, dtype=np.int32)
     depth = np.ascontiguousarray(depth, dtype=np.float32)

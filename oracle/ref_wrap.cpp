@@ -8,6 +8,8 @@
 }   // closes `namespace wisp` left open by the extracted fragment
 #include "_ref/uniform_kernels.inc"
 }   // closes `namespace wisp`
+#include "_ref/depth_bound_kernel.inc"
+}   // closes `namespace wisp`
 #include "_ref/query_fwd_kernel.inc"
 #include "_ref/query_bwd_kernel.inc"
 }   // closes `namespace wisp` (opened by the forward fragment)
@@ -58,6 +60,16 @@ void ref_hashgrid_query_bwd_level(int64_t n, int32_t codebook_size, int32_t prob
                                   float* grad_codebook) {
     wisp::hashgrid_query_backward_cuda_kernel<float>(n, codebook_size, probe_size, feature_dim, resolution, lod_idx, num_lods,
                                                      coords, grad_output, grad_codebook);
+}
+
+// find_depth_bound_cuda_kernel (render/find_depth_bound_cuda.cu:16-45), one "thread" per pack; curr_idxes_out starts as -1
+// like the ATen wrapper's at::zeros_like(...) - 1 (find_depth_bound.cpp:23-36)
+void ref_find_depth_bound(int64_t num_packs, int64_t num_nugs, const float* query, const int* curr_in, int* curr_out,
+                          const float* depth) {
+    for (int64_t t = 0; t < num_packs; ++t) curr_out[t] = -1;
+    for (int64_t t = 0; t < num_packs; ++t)
+        wisp::find_depth_bound_cuda_kernel_at((wisp::uint)t, num_packs, num_nugs, query, curr_in, curr_out,
+                                              reinterpret_cast<const float2*>(depth));
 }
 
 // uniform_sample_cuda_kernel (uniform_sample_cuda.cu:18-59) over all nuggets

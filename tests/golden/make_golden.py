@@ -9,6 +9,7 @@ Outputs (small, committed):
                        hash-index known answers, the clamp bound probes of SURVEY.md Appendix B
   hashgrid_query_ref.npz - inputs + outputs of the reference hashgrid_query forward/backward kernels (probe_bitwidth 0 and 1)
   uniform_ref.npz    - inputs + outputs of the reference uniform_sample kernel
+  depth_bound_ref_{a,b}.npz - inputs + outputs of the reference find_depth_bound kernel (SDF tracer)
   spc_kats.npz       - hand-checkable SPC cases (dense level-2 tree, 3-point sparse tree, query / raytrace answers)
                        produced by oracle/spc.py and verified inside this script against brute force in float64
 """
@@ -97,6 +98,43 @@ def uniform_vectors():
                         insum=insum, out_ridx=got["ridx"], out_depth=got["depth_samples"], out_boundary=got["boundary"])
 
 
+def depth_bound_vectors():
+    """depth_bound_ref.npz: the SDF tracer's depth-bound search (render/find_depth_bound_cuda.cu) on ragged packs: queries
+    inside an interval, in the gap before one, past the pack's last exit (the search then runs into the NEXT pack - the
+    kernel bounds it by the neighbour's start index only), finished packs (-1), a pack whose right neighbour is finished
+    (bound 0xFFFFFFFF; queries kept inside so the reference body terminates), and the last pack (bounded by num_packs)."""
+    rng = np.random.default_rng(11)
+    for name, P in (("a", 48), ("b", 7)):
+        counts = rng.integers(1, 6, P)
+        start = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int32)
+        M = int(counts.sum())
+        depth = np.empty((M, 2), np.float32)
+        for p in range(P):
+            e = np.sort(rng.uniform(0.2, 3.0, 2 * counts[p]).astype(np.float32))
+            depth[start[p]:start[p] + counts[p], 0] = e[0::2]
+            depth[start[p]:start[p] + counts[p], 1] = e[1::2]
+        cur = start.copy()
+        dead = rng.random(P) < 0.2
+        dead[0] = False
+        cur[dead] = -1
+        kind = rng.integers(0, 4, P)
+        q = np.empty(P, np.float32)
+        for p in range(P):
+            lo, hi = start[p], start[p] + counts[p]
+            k = rng.integers(lo, hi)
+            right_dead = p + 1 < P and cur[p + 1] < 0
+            if kind[p] == 0 or right_dead:
+                q[p] = np.float32(0.5) * (depth[k, 0] + depth[k, 1])          # inside interval k
+            elif kind[p] == 1:
+                q[p] = depth[k, 0] - np.float32(1e-3)                         # just before interval k
+            elif kind[p] == 2:
+                q[p] = depth[hi - 1, 1] + np.float32(10.0)                    # past every exit: nothing up to the neighbour
+            else:
+                q[p] = depth[k, 1]                                            # exactly on an exit (<= is inclusive)
+        out = ref_lib.find_depth_bound(q, cur, depth)
+        np.savez_compressed(os.path.join(OUT, "depth_bound_ref_%s.npz" % name), query=q, curr=cur, depth=depth, out=out)
+
+
 def spc_vectors():
     out = {}
     # sparse 3-point tree at level 2: points (0,0,0), (3,3,3), (2,1,0)
@@ -138,5 +176,6 @@ if __name__ == "__main__":
     hashgrid_vectors()
     query_vectors()
     uniform_vectors()
+    depth_bound_vectors()
     spc_vectors()
     print("golden vectors written to", OUT)

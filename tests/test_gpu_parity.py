@@ -1181,6 +1181,27 @@ def test_find_depth_bound_bit_exact():
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_find_depth_bound_golden_reference_vectors(golden_dir, name):
+    """the reference kernel's own outputs (host build of render/find_depth_bound_cuda.cu, tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(golden_dir, "depth_bound_ref_%s.npz" % name))
+    got = _C().find_depth_bound(cuda(g["query"]), cuda(g["curr"]), cuda(g["depth"]))
+    assert np.array_equal(got.cpu().numpy(), g["out"])
+
+
+def test_find_depth_bound_stops_at_the_last_nugget():
+    """A finished right neighbour (-1) makes the reference's bound 0xFFFFFFFF and its scan leaves `depth` when the query is
+    past every remaining nugget (undefined there).  The HIP kernel stops at num_nugs and reports -1."""
+    depth = np.array([[0.1, 0.2], [0.3, 0.4], [0.5, 0.6], [0.7, 0.8]], np.float32)
+    cur = np.array([0, -1, 3], np.int32)
+    q = np.array([5.0, 0.0, 0.75], np.float32)
+    got = _C().find_depth_bound(cuda(q), cuda(cur), cuda(depth)).cpu().numpy()
+    assert got.tolist() == [-1, -1, -1]            # pack 2 is the last pack: bound num_packs = 3 <= its index
+    q[0] = 0.65                                    # the scan runs on into the following packs' nuggets, as in the reference
+    got = _C().find_depth_bound(cuda(q), cuda(cur), cuda(depth)).cpu().numpy()
+    assert got.tolist() == [3, -1, -1]
+
+
 def test_neural_sdf_and_sdf_tracer_match_oracle():
     from oracle import octree_grid as og, sdf as osdf
     from wisp.core import Rays

@@ -77,6 +77,19 @@ def test_uniform_sampler_matches_reference_kernel(golden_dir):
     assert np.array_equal(got["boundary"], u["out_boundary"])
 
 
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_depth_bound_search_matches_reference_kernel(golden_dir, name):
+    """oracle.sdf.find_depth_bound against the reference kernel body (render/find_depth_bound_cuda.cu:16-45, host build):
+    inside / before / past-the-pack queries, finished packs, a finished right neighbour, and the last pack, whose bound is
+    num_packs (so it finds nothing once its index is >= num_packs)."""
+    from oracle import sdf
+    g = np.load(os.path.join(golden_dir, "depth_bound_ref_%s.npz" % name))
+    assert np.array_equal(sdf.find_depth_bound(g["query"], g["curr"], g["depth"]), g["out"])
+    assert (g["out"] < 0).any() and (g["out"] >= 0).any() and (g["curr"] < 0).any()
+    if name == "a":                                   # the last-pack quirk is exercised: valid start index, nothing found
+        assert g["curr"][-1] >= len(g["curr"]) and g["out"][-1] == -1
+
+
 @pytest.mark.skipif(not ref_lib.available(), reason="oracle/_ref not built (needs /root/reference)")
 def test_oracle_vs_live_reference_kernels_nerf_hash_shape():
     """nerf_hash.yaml shape (L=16, T=2^19, res 16..512) on fresh random inputs, forward bit-exact."""

@@ -860,3 +860,73 @@ def test_oracle_hash_grid_equals_the_whole_reference_stack_on_the_host(multiscal
     ohash.grid_interpolate(flat, len(res) - 1, multiscale, F, res, bw, t2, table.begin_idxes).backward(go)
     np.testing.assert_allclose(t2.grad.numpy(), ref_grad.numpy(), rtol=0, atol=2e-5)      # the reference adds sequentially in fp32
     assert float(ref_grad.abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("num_steps,step_size,min_dis", [(48, 0.8, 3e-4), (6, 1.0, 1e-4)])
+def test_oracle_sphere_tracer_equals_the_reference_trace_body(num_steps, step_size, min_dis):
+    """PackedSDFTracer.trace (tracers/packed_sdf_tracer.py:57-174): the method body compiled from the reference file, with the
+    reference's own find_depth_bound wrapper (ops/geometric.py:15-22) over its kernel body built for the host and its own
+    finitediff_gradient (ops/differential/gradients.py:29-45) - driven with the oracle's octree raytrace and an analytic distance
+    function - against oracle.sdf.sphere_trace, the tracer the GPU SDF tests are compared with.  Marching order, both convergence
+    tests, the far plane, the nugget jump and the output scatter are the reference's code; every buffer must be identical."""
+    import torch.nn.functional as F
+    from oracle import nerf as onerf, sdf as osdf, spc as ospc, ref_lib
+    from wisp.core import Rays, RenderBuffer
+
+    def sdf_fn(x):
+        return (x.norm(dim=-1, keepdim=True) - 0.55) + 0.02 * torch.sin(9.0 * x[..., 0:1]) * torch.cos(7.0 * x[..., 1:2])
+
+    level = 5
+    g = (np.stack(np.meshgrid(*[np.arange(32)] * 3, indexing="ij"), -1).reshape(-1, 3) + 0.5) / 16.0 - 1.0
+    shell = np.abs(np.linalg.norm(g, axis=1) - 0.55) < 0.09
+    blas = onerf.OracleBLAS.from_quantized_points(((g[shell] + 1.0) * 16.0).astype(np.int64), level)
+    rng = np.random.default_rng(77)
+    o = rng.normal(size=(160, 3)).astype(np.float32)
+    o = (2.5 * o / np.linalg.norm(o, axis=1, keepdims=True)).astype(np.float32)
+    d = -o + rng.normal(size=o.shape).astype(np.float32) * 0.55          # some rays graze or miss the shell
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    O, D = torch.from_numpy(o), torch.from_numpy(d)
+    dist_max = 6.0
+    want = osdf.sphere_trace(sdf_fn, blas, O, D, dist_max, level, num_steps, step_size, min_dis)
+
+    kernel = ref_lib.find_depth_bound if ref_lib.available() else osdf.find_depth_bound       # the latter is golden-pinned
+    c_ext = types.SimpleNamespace(render=types.SimpleNamespace(find_depth_bound_cuda=lambda q, cur, dep: torch.from_numpy(
+        kernel(q.numpy(), cur.numpy(), dep.numpy()))))
+    find_depth_bound = _reference_function("ops/geometric.py", "find_depth_bound", dict(torch=torch, _C=c_ext))
+    finitediff = _reference_function("ops/differential/gradients.py", "finitediff_gradient", dict(torch=torch))
+    spc_render = types.SimpleNamespace(mark_pack_boundaries=lambda r: torch.from_numpy(ospc.mark_pack_boundaries(r.numpy())))
+    trace = _reference_method("tracers/packed_sdf_tracer.py", "PackedSDFTracer", "trace",
+                              dict(torch=_TorchWithoutNvtx(), F=F, spc_render=spc_render, RenderBuffer=RenderBuffer,
+                                   find_depth_bound=find_depth_bound, finitediff_gradient=finitediff))
+    seen = {}
+
+    class Grid:
+        num_lods, active_lods = 1, [level]
+
+        @staticmethod
+        def raytrace(rays, lvl, with_exit=False):
+            assert lvl == level and with_exit
+            ridx, pidx, depth = ospc.raytrace(blas.octree, blas.points, blas.pyramid, blas.exsum, rays.origins.numpy(),
+                                              rays.dirs.numpy(), lvl, with_exit=True)
+            seen["nuggets"] = ridx.shape[0]
+            return types.SimpleNamespace(ridx=torch.from_numpy(ridx), pidx=torch.from_numpy(pidx), depth=torch.from_numpy(depth.copy()))
+
+    class Nef:
+        grid = Grid()
+
+        def __call__(self, coords=None, lod_idx=None, pidx=None, channels=None):
+            assert channels == "sdf" and lod_idx == 0 and pidx.shape[0] == coords.shape[0]
+            return sdf_fn(coords)
+
+        @staticmethod
+        def get_forward_function(channel):
+            assert channel == "sdf"
+            return sdf_fn
+
+    rb = trace(types.SimpleNamespace(), Nef(), Rays(O, D, dist_min=0.0, dist_max=dist_max), {"rgb", "normal", "depth", "hit"}, set(),
+               lod_idx=None, num_steps=num_steps, step_size=step_size, min_dis=min_dis)
+    assert seen["nuggets"] > 1000
+    for name in ("xyz", "depth", "hit", "normal", "rgb", "alpha"):
+        assert torch.equal(getattr(rb, name), want[name]), name
+    hits = int(rb.hit.sum())
+    assert (20 < hits < 160) if num_steps == 48 else hits < 100           # the short run stops with rays still marching
