@@ -210,7 +210,7 @@ class MultiviewTrainStep:
     def __init__(self, pipeline, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, betas=(0.9, 0.999),
                  rgb_loss_type='huber', prune_every=100, target_sample_size=2 ** 18, max_rays=2 ** 18,
                  enable_amp=False, scheduler_milestones=None, scheduler_gamma=0.333, process_group=None, seed=0,
-                 optimizer='adamw', alpha=0.99, momentum=0.0, prune_rng_device=None):
+                 optimizer='adamw', alpha=0.99, momentum=0.0, prune_rng_device=None, sharded_optimizer=None):
         """optimizer: 'adamw' | 'adam' | 'rmsprop' - the torch.optim classes the reference's configs select
         (wisp/config/presets/torch.py:45-68; nerf_hash.yaml: AdamW, nerf_octree / nerf_codebook.yaml: RMSprop), each
         one fused launch over the flat parameter buffer.  `betas` (Adam family) / `alpha`, `momentum` (RMSprop) as in torch."""
@@ -246,6 +246,15 @@ class MultiviewTrainStep:
         self._prune_gen = torch.Generator(device=dev).manual_seed(seed)
         self._side_stream = None
         self._params_ready = None
+        # WISP_SHARDED_OPTIM=1 (or sharded_optimizer=True): reduce-scatter + optimizer on this rank's slice of the grid + all-gather
+        # instead of all-reduce + replicated optimizer (see _sharded_reduce_and_update).  Off by default: the all-reduce path is the
+        # one that has run on hardware with more than one rank.
+        want = sharded_optimizer if sharded_optimizer is not None else os.environ.get("WISP_SHARDED_OPTIM", "0") == "1"
+        self.sharded_optimizer = bool(want and dist.is_available() and dist.is_initialized())
+        self.rank = dist.get_rank(process_group) if self.sharded_optimizer else 0
+        self._master_stale = False
+        self._stage = {}
+        self._plan = None
         # (single GPU: putting the optimizer launch on the side stream too, under the next step's raymarch, was measured
         # neutral - 1.270 vs 1.284 ms/step - so one rank keeps everything on one stream)
         # specialised issue order for the flagship pipeline shape (WISP_DIRECT_STEP=0 keeps the modular path)
@@ -260,7 +269,9 @@ class MultiviewTrainStep:
         k = sum(1 for m in self.milestones if self.opt_steps >= m)       # MultiStepLR
         return self.gamma ** k
 
-    def optimizer_step(self):
+    def optimizer_step(self, grid_ranges=None):
+        """grid_ranges: None -> the whole grid group; else a list of [lo, hi) element ranges of the flat buffer inside the grid
+        group (the sharded path: this rank's slice, plus the rows no gradient can reach)."""
         C = _hip()
         self.opt_steps += 1
         s = self._lr_scale()
@@ -269,8 +280,14 @@ class MultiviewTrainStep:
         groups = []
         for g, lr in (("decoder", self.lr), ("grid", self.lr * self.grid_lr_weight), ("rest", self.lr)):
             a, b = f.ranges[g]
-            if b > a:
-                groups.append((a, b - a, lr * s, self.weight_decay, f.shadow if g == "grid" else None))
+            if b <= a:
+                continue
+            if g != "grid" or grid_ranges is None:
+                groups.append((a, b - a, lr * s, self.weight_decay, f.shadow[:b - a] if (g == "grid" and f.shadow is not None) else None))
+                continue
+            for lo, hi in grid_ranges:
+                if hi > lo:
+                    groups.append((lo, hi - lo, lr * s, self.weight_decay, None if f.shadow is None else f.shadow[lo - a:hi - a]))
         # all parameter groups in ONE launch (the decoder group alone is ~10 K parameters)
         if self.optimizer == 'adamw':
             C.adamw_step_groups(f.data, f.grad, f.exp_avg, f.exp_avg_sq, groups, self.betas[0], self.betas[1], self.eps,
@@ -314,18 +331,113 @@ class MultiviewTrainStep:
         NEXT step that does not read parameters (ray gathering, raymarch against the occupancy structure, its size
         read-back) overlaps the collective; whoever reads parameters next calls wait_for_parameters() first."""
         if not (self.world > 1 or self.force_allreduce) or not self.flat.data.is_cuda:
-            self.allreduce_grads()
-            self.optimizer_step()
+            self._reduce_and_update_here()
             return
         main = torch.cuda.current_stream()
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream()
         self._side_stream.wait_stream(main)
         with torch.cuda.stream(self._side_stream):
-            self.allreduce_grads()
-            self.optimizer_step()
+            self._reduce_and_update_here()
             self._params_ready = torch.cuda.Event()
             self._params_ready.record()
+
+    def _reduce_and_update_here(self):
+        plan = self._shard_plan() if (self.world > 1 or self.force_allreduce) else None
+        if plan is None:
+            self.allreduce_grads()
+            self.optimizer_step()
+        else:
+            self._sharded_reduce_and_update(plan)
+
+    # -------------------------------------------------------------------------------------------- sharded optimizer (opt-in)
+    def _shard_plan(self):
+        """How the grid group is cut over the ranks, or None when this step goes through the all-reduce.
+        Only the elements a gradient can reach ([ga, ga + live), see _live_grad_numel) are cut, into `world` slices of `c`
+        elements (c a multiple of 4 = the optimizer kernel's alignment).  direct: the padded window [ga, ga + world*c) lies inside
+        the grid group, so the collectives run on views of the flat buffers; otherwise (the pad would run into the next group:
+        small or oddly sized tables) they go through zero-padded staging buffers."""
+        if not self.sharded_optimizer:
+            return None
+        f = self.flat
+        ga, gb = f.ranges["grid"]
+        live_end = min(self._live_grad_numel(), gb)
+        if self._plan is not None:
+            # The cut is fixed by the first sharded step: the optimizer state of a slice lives on its owner only, and the rows
+            # behind the window are updated by every rank on the assumption that no gradient reaches them.
+            if self._plan and live_end > min(self._plan["ga"] + self._plan["npad"], gb):
+                raise RuntimeError("sharded optimizer: this step's gradient reaches table rows outside the partition fixed at the "
+                                   "first step (the step path changed mid-run); use the all-reduce path (WISP_SHARDED_OPTIM=0)")
+            return self._plan or None
+        live = live_end - ga
+        if live < 4 * self.world:
+            self._plan = False                            # table too small to cut: all-reduce for the whole run
+            return None
+        c = ((live + 4 * self.world - 1) // (4 * self.world)) * 4
+        npad = c * self.world
+        lo = ga + self.rank * c
+        self._plan = dict(ga=ga, gb=gb, c=c, npad=npad, direct=ga + npad <= gb, lo=min(lo, gb), hi=min(lo + c, gb))
+        return self._plan
+
+    def _staging(self, name, numel, dtype):
+        t = self._stage.get(name)
+        if t is None or t.numel() != numel or t.dtype != dtype:
+            t = self._stage[name] = torch.zeros(numel, dtype=dtype, device=self.flat.data.device)
+        return t
+
+    def _gather_grid(self, full, plan, tag):
+        """all-gather of every rank's slice of `full` (the grid group's master weights or their bf16 shadow, [gb - ga] elements).
+        The send buffer is always a copy, never a view of the receive buffer."""
+        ga, gb, c, npad, lo, hi = (plan[k] for k in ("ga", "gb", "c", "npad", "lo", "hi"))
+        own = self._staging("own_" + tag, c, full.dtype)
+        own[:hi - lo].copy_(full[lo - ga:hi - ga])
+        out = full[:npad] if plan["direct"] else self._staging("all_" + tag, npad, full.dtype)
+        dist.all_gather_into_tensor(out, own, group=self.group)
+        if not plan["direct"]:
+            full[:gb - ga].copy_(out[:gb - ga])
+
+    def _sharded_reduce_and_update(self, plan):
+        """Reduce-scatter + optimizer on this rank's slice + all-gather, for the grid group only; the decoder
+        (and any other small group) keeps its all-reduce and replicated update.  Against all-reduce + replicated optimizer:
+        the optimizer touches 1/world of the table, and with the bf16 shadow the wire carries 4 + 2 bytes per element
+        instead of 4 + 4 (only the shadow travels back; the fp32 master of the other ranks' slices goes STALE until
+        sync_master(), which prune() calls - everything else on the training path reads the shadow).  Without a shadow the
+        fp32 master is gathered every step and never stale.  Optimizer state (exp_avg, exp_avg_sq) exists only for the own slice.
+        The sums are the same numbers in the same order as the all-reduce's for 2 ranks; for more, RCCL's ring order applies
+        to both."""
+        f = self.flat
+        ga, gb, c, npad, lo, hi = (plan[k] for k in ("ga", "gb", "c", "npad", "lo", "hi"))
+        for a, b in (f.ranges["decoder"], f.ranges["rest"]):
+            if b > a:
+                dist.all_reduce(f.grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
+        if plan["direct"]:
+            send = f.grad[ga:ga + npad]
+        else:
+            send = self._staging("rs_in", npad, torch.float32)
+            send[:gb - ga].copy_(f.grad[ga:gb])
+        mine = self._staging("rs_out", c, torch.float32)
+        dist.reduce_scatter_tensor(mine, send, op=dist.ReduceOp.SUM, group=self.group)
+        f.grad[ga:min(ga + npad, gb)].zero_()             # the other ranks' slices of this rank's gradient are spent
+        f.grad[lo:hi].copy_(mine[:hi - lo])
+        self.optimizer_step(grid_ranges=[(lo, hi), (min(ga + npad, gb), gb)])
+        if f.shadow is not None:
+            self._gather_grid(f.shadow, plan, "bf16")
+            self._master_stale = self.world > 1
+        else:
+            self._gather_grid(f.data[ga:gb], plan, "fp32")
+
+    def sync_master(self):
+        """Collective (every rank): bring the fp32 master weights of the other ranks' slices up to date after sharded steps
+        that only exchanged the bf16 shadow.  Needed before anything reads the table in fp32: prune() (does it itself),
+        checkpoints, fp32 evaluation."""
+        if not self._master_stale:
+            return
+        self.wait_for_parameters()
+        plan = self._plan
+        f = self.flat
+        self._gather_grid(f.data[plan["ga"]:plan["gb"]], plan, "fp32")
+        f.mark_shadow_current()          # the shadow already holds bf16(master) everywhere; the in-place copy bumped versions
+        self._master_stale = False
 
     def wait_for_parameters(self):
         """Order the current stream after the last reduce_and_update()."""
@@ -348,6 +460,7 @@ class MultiviewTrainStep:
         if (getattr(nef, 'prune_density_decay', None) is None or getattr(nef, 'prune_min_density', None) is None
                 or getattr(nef.grid, 'dense_points', None) is None or not hasattr(nef, 'prune')):
             return
+        self.sync_master()                      # the density query below runs in fp32 on the master weights
         cells = nef.grid.dense_points.shape[0]
         dev = self._prune_gen.device
         unit = torch.rand(cells, 3, generator=self._prune_gen, device=dev)

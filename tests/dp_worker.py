@@ -47,6 +47,9 @@ def main():
     for _ in range(steps):
         tr.step(Rays(o[lo:hi], d[lo:hi], dist_min=1.0, dist_max=5.0), gt[lo:hi], jitter=jit[lo:hi])
     tr.wait_for_parameters()
+    sharded = bool(tr._plan)
+    stale_before_sync = bool(tr._master_stale)
+    tr.sync_master()                          # no-op on the all-reduce path; collective on the sharded one (bf16 shadow travelled)
     torch.cuda.synchronize()
     flat = tr.flat.data
     gathered = [torch.empty_like(flat) for _ in range(world)]
@@ -66,12 +69,26 @@ def main():
                # the all-reduce leaves out the finest level's rows (never a gradient under 'cat' with lod_idx = num_lods - 1):
                # the skipped tail of the gradient buffer must indeed be all zero
                allreduce_numel=int(tr._live_grad_numel()), grad_numel=int(tr.flat.grad.numel()),
-               skipped_tail_zero=bool((tr.flat.grad[tr._live_grad_numel():] == 0).all()))
+               skipped_tail_zero=bool((tr.flat.grad[tr._live_grad_numel():] == 0).all()),
+               sharded=sharded, stale_before_sync=stale_before_sync, grads_consumed=bool((tr.flat.grad == 0).all()))
+    if sharded:
+        ga, gb = tr.flat.ranges["grid"]
+        plan = tr._plan
+        res.update(plan_direct=bool(plan["direct"]), slice_elems=int(plan["c"]), window=int(plan["npad"]), grid_elems=int(gb - ga))
+        if tr.flat.shadow is not None:        # every slice's shadow, and the tail every rank updates itself, mirror the master
+            res["shadow_is_bf16_of_master"] = bool(torch.equal(tr.flat.shadow, tr.flat.data[ga:gb].to(torch.bfloat16)))
+        own = torch.zeros(tr.flat.data.numel(), dtype=torch.bool, device=dev)
+        own[plan["lo"]:plan["hi"]] = True
+        window = torch.zeros_like(own)
+        window[ga:min(ga + plan["npad"], gb)] = True
+        off = tr.flat.exp_avg_sq[window & ~own]
+        res["state_only_on_owner"] = bool(off.numel() == 0 or float(off.abs().max()) == 0.0)
     # single-rank reference of the SAME global batch, on rank 0 only, without any collective: the data-parallel result must
     # agree with it up to the summation order of the gradient
     dist.barrier()
     if rank == 0:
         os.environ["WISP_FORCE_ALLREDUCE"] = "0"
+        os.environ["WISP_SHARDED_OPTIM"] = "0"
         pipe1, tr1 = build()
         tr1.world, tr1.force_allreduce = 1, False
         for _ in range(steps):

@@ -41,6 +41,34 @@ def test_forced_allreduce_side_stream_on_one_gpu(amp):
     assert res["rel_l2_vs_single"] < 2e-3, res
 
 
+@pytest.mark.parametrize("amp", ["1", "0"])
+def test_forced_sharded_optimizer_on_one_gpu(amp):
+    """WISP_SHARDED_OPTIM=1 with one forced rank: RCCL reduce-scatter and all-gather (bf16 shadow with amp, fp32 master
+    without), the HIP optimizer launched on a slice of the grid group plus the rows no gradient reaches, the staging copies and
+    the side stream all run.  With one rank the slice is the whole window, so the result must equal the plain run like the
+    forced all-reduce does; the shadow must be bf16(master) over the whole table afterwards."""
+    res = _launch(1, {"WISP_FORCE_ALLREDUCE": "1", "WISP_SHARDED_OPTIM": "1", "DP_AMP": amp})
+    print(res)
+    assert res["sharded"] and res["plan_direct"] and res["window"] < res["grid_elems"], res      # finest level = untouched tail
+    assert res["direct"] and res["pruned"] and res["finite"] and res["identical"] and res["same_tree"], res
+    assert res["grads_consumed"] and res["state_only_on_owner"] and not res["stale_before_sync"], res
+    if amp == "1":
+        assert res["shadow_is_bf16_of_master"], res
+    assert res["rel_l2_vs_single"] < 2e-3, res
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (gpurun boxes have one)")
+def test_two_gpu_sharded_optimizer_stays_in_lockstep():
+    """Two ranks, WISP_SHARDED_OPTIM=1: each rank updates half of the live table rows; after sync_master() the replicas hold
+    bit-identical master weights and octrees (the prunes inside the run read synced weights), the shadow mirrors the master,
+    optimizer state exists only on the owner, and the result agrees with a single-GPU run like the all-reduce path does."""
+    res = _launch(2, {"WISP_SHARDED_OPTIM": "1", "DP_AMP": "1"})
+    assert res["world"] == 2 and res["sharded"] and res["stale_before_sync"], res
+    assert res["direct"] and res["pruned"] and res["finite"] and res["identical"] and res["same_tree"], res
+    assert res["grads_consumed"] and res["state_only_on_owner"] and res["shadow_is_bf16_of_master"], res
+    assert res["rel_l2_vs_single"] < 2e-2, res
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (gpurun boxes have one)")
 def test_two_gpu_ray_sharded_training_stays_in_lockstep():
     """Two ranks over RCCL/xGMI: disjoint ray shards, one all-reduce of the flat gradient per step, identical prune draws -
