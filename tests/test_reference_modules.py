@@ -930,3 +930,119 @@ def test_oracle_sphere_tracer_equals_the_reference_trace_body(num_steps, step_si
         assert torch.equal(getattr(rb, name), want[name]), name
     hits = int(rb.hit.sum())
     assert (20 < hits < 160) if num_steps == 48 else hits < 100           # the short run stops with rays still marching
+
+
+def _octree_grid_scene(num_lods=3, base_lod=2, feature_dim=4, codes=None, seed=8):
+    """a sparse level-(base_lod + num_lods - 1) tree with its dual corners, one feature (or logits) table per active level"""
+    from oracle import nerf as onerf, spc as ospc
+    rng = np.random.default_rng(seed)
+    top = base_lod + num_lods - 1
+    blas = onerf.OracleBLAS.from_quantized_points(rng.integers(0, 2 ** top, size=(90, 3)), top)
+    pd, pyd = ospc.make_dual(blas.points, blas.pyramid)
+    trinkets, _ = ospc.make_trinkets(blas.points, blas.pyramid, pd, pyd)
+    active = list(range(base_lod, top + 1))
+    torch.manual_seed(seed)
+    width = feature_dim if codes is None else codes
+    feats = [torch.randn(int(pyd[0, l]) + 1, width, requires_grad=True) for l in active]
+    x = rng.uniform(-1.05, 1.05, (300, 3)).astype(np.float32)                  # a few land outside the cube -> pidx -1
+    return blas, torch.from_numpy(np.asarray(trinkets)), active, feats, torch.from_numpy(x)
+
+
+def _reference_octree_grid(blas, trinkets, active, feats, base_lod, multiscale, feature_dim, glb, cls_file=None, extra=None):
+    """`self` for the compiled reference methods: the attributes OctreeGrid.interpolate / _interpolate read, the oracle's octree
+    query behind `blas.query`, and the Kaolin leaves restated by the oracle as `spc_ops`."""
+    import functools
+    from oracle import octree_grid as og, spc as ospc
+
+    class Blas:
+        points = torch.from_numpy(np.asarray(blas.points))
+        pyramid = torch.from_numpy(np.asarray(blas.pyramid))
+
+        @staticmethod
+        def query(coords, level=None, with_parents=False):
+            return types.SimpleNamespace(pidx=torch.from_numpy(ospc.query(blas.octree, blas.exsum, coords.detach().numpy(), level,
+                                                                          with_parents=with_parents)))
+
+    spc_ops = types.SimpleNamespace(
+        unbatched_interpolate_trilinear=lambda c, pidx, pts, tr, f, lod: og.interpolate_trilinear(c, pidx.long(), pts, tr, f.float(), lod,
+                                                                                                   half_round=True),
+        coords_to_trilinear_coeffs=lambda c, pts, lod: og.trilinear_coeffs(c, pts.long(), lod))
+    glb = dict(glb, torch=torch, spc_ops=spc_ops)
+    me = types.SimpleNamespace(blas=Blas, trinkets=trinkets, active_lods=active, base_lod=base_lod, features=feats,
+                               interpolation_type='linear', multiscale_type=multiscale, feature_dim=feature_dim, training=True,
+                               **(extra or {}))
+    interp_cls = ("models/grids/octree_grid.py", "OctreeGrid") if cls_file is None else cls_file
+    me._interpolate = functools.partial(_reference_method(*interp_cls, "_interpolate", glb), me)
+    if cls_file is not None:
+        me._index_features = functools.partial(_reference_method(*cls_file, "_index_features", glb), me)
+    me.interpolate = functools.partial(_reference_method("models/grids/octree_grid.py", "OctreeGrid", "interpolate", glb), me)
+    return me
+
+
+@pytest.mark.parametrize("multiscale", ["cat", "sum"])
+def test_oracle_octree_grid_equals_the_reference_interpolate_bodies(multiscale):
+    """OctreeGrid.interpolate + _interpolate (models/grids/octree_grid.py:130-219) compiled from the reference file over the oracle's
+    octree query and its restatement of kaolin's unbatched_interpolate_trilinear - against oracle.octree_grid.octree_grid_interpolate,
+    what the HIP octree-grid kernels are compared with: which pidx column feeds which level (`pidx[..., base_lod:]`, `_interpolate(...,
+    i)` -> active_lods[i]), the lod_idx == 0 shortcut, 'cat' / 'sum', output shapes, cells outside the tree, gradients per table."""
+    from oracle import octree_grid as og
+    base_lod, F = 2, 4
+    blas, trinkets, active, feats, x = _octree_grid_scene(3, base_lod, F)
+    me = _reference_octree_grid(blas, trinkets, active, feats, base_lod, multiscale, F, {})
+    for lod_idx in (0, 1, 2):
+        for coords in (x, x.reshape(60, 5, 3)):
+            if lod_idx == 0 and coords.ndim == 3:
+                continue              # the reference reuses sample 0's cell for the whole row there (base-level samples share a cell)
+            for f in feats:
+                f.grad = None
+            got = me.interpolate(coords, lod_idx)
+            got.square().sum().backward()
+            g_ref = [None if f.grad is None else f.grad.clone() for f in feats]
+            for f in feats:
+                f.grad = None
+            want = og.octree_grid_interpolate(blas, trinkets, feats, coords, lod_idx, base_lod, active, multiscale, F, half_round=True)
+            want.square().sum().backward()
+            width = F if (multiscale == 'sum' or lod_idx == 0) else F * (lod_idx + 1)
+            assert got.shape == (*coords.shape[:-1], width)
+            assert torch.equal(got.reshape(-1, width), want), (lod_idx, coords.shape)
+            assert int((got.reshape(-1, width).abs().sum(-1) == 0).sum()) >= 5                # the samples outside the cube
+            for i, f in enumerate(feats):
+                assert (f.grad is None) == (g_ref[i] is None) == (i > lod_idx)
+                if f.grad is not None:
+                    assert torch.equal(f.grad, g_ref[i]) and float(f.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("multiscale", ["cat", "sum"])
+def test_oracle_codebook_grid_equals_the_reference_interpolate_bodies(multiscale, training):
+    """CodebookOctreeGrid._index_features + _interpolate (models/grids/codebook_grid.py:103-172) under the inherited
+    OctreeGrid.interpolate, all compiled from the reference files - against oracle.octree_grid.codebook_grid_interpolate: straight-through
+    softmax keys while training / argmax rows in eval, invalid cells, level selection, 'cat' / 'sum', gradients into logits and
+    dictionaries."""
+    import torch.nn.functional as F_
+    from oracle import octree_grid as og
+    base_lod, F, K = 2, 4, 16
+    blas, trinkets, active, logits, x = _octree_grid_scene(3, base_lod, F, codes=K)
+    torch.manual_seed(21)
+    dictionary = [torch.randn(K, F, requires_grad=True) for _ in active]
+    me = _reference_octree_grid(blas, trinkets, active, logits, base_lod, multiscale, F, dict(F=F_),
+                                cls_file=("models/grids/codebook_grid.py", "CodebookOctreeGrid"), extra=dict(dictionary=dictionary))
+    me.training = training
+    for lod_idx in (0, 2):
+        leaves = logits + dictionary
+        for t in leaves:
+            t.grad = None
+        got = me.interpolate(x, lod_idx)
+        got.square().sum().backward()
+        g_ref = [None if t.grad is None else t.grad.clone() for t in leaves]
+        for t in leaves:
+            t.grad = None
+        want = og.codebook_grid_interpolate(blas, trinkets, logits, dictionary, x, lod_idx, active, multiscale, F, training)
+        want.square().sum().backward()
+        assert got.shape == want.shape and torch.allclose(got, want, atol=1e-6, rtol=0), float((got - want).abs().max())
+        assert int((got.abs().sum(-1) == 0).sum()) >= 5
+        for t, g in zip(leaves, g_ref):
+            assert (t.grad is None) == (g is None)
+            if g is not None:
+                assert torch.allclose(t.grad, g, atol=1e-5, rtol=1e-5)
+        assert dictionary[0].grad is not None and (logits[0].grad is not None) == training   # eval: argmax rows, no logits gradient
