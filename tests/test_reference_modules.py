@@ -1046,3 +1046,75 @@ def test_oracle_codebook_grid_equals_the_reference_interpolate_bodies(multiscale
             if g is not None:
                 assert torch.allclose(t.grad, g, atol=1e-5, rtol=1e-5)
         assert dictionary[0].grad is not None and (logits[0].grad is not None) == training   # eval: argmax rows, no logits gradient
+
+
+@pytest.mark.parametrize("position_input", [True, False])
+def test_oracle_sdf_field_composition_equals_the_reference_sdf_body(position_input):
+    """NeuralSDF.sdf (models/nefs/neural_sdf.py:120-155) compiled from the reference file, with its own init_embedder choice
+    (Identity for 'none' + position_input, :89-100), over the oracle's octree-grid lookup and decoder - against the composition the
+    GPU SDF tests use as the oracle field, decoder(cat([position, features])): concatenation order, [B,3] and [B,S,3] shapes, the
+    default lod_idx, the empty batch."""
+    from oracle import nerf as onerf, octree_grid as og
+    base_lod, F = 2, 4
+    blas, trinkets, active, feats, x = _octree_grid_scene(3, base_lod, F)
+    torch.manual_seed(31)
+    embed_dim = 3 if position_input else 0
+    dec = onerf.OracleDecoder(F + embed_dim, 1, 32, 1, True)
+
+    def lookup(coords, lod_idx):
+        out = og.octree_grid_interpolate(blas, trinkets, feats, coords, lod_idx, base_lod, active, 'sum', F, half_round=True)
+        return out.reshape(*coords.shape[:-1], F)
+
+    init_embedder = _reference_method("models/nefs/neural_sdf.py", "NeuralSDF", "init_embedder", dict(torch=torch))
+    embedder, dim = init_embedder(None, 'none', None, position_input)
+    assert dim == embed_dim and (embedder is None) == (not position_input)
+    me = types.SimpleNamespace(grid=types.SimpleNamespace(num_lods=3, interpolate=lookup), pos_embedder=embedder, pos_embed_dim=dim,
+                               decoder=dec)
+    sdf = _reference_method("models/nefs/neural_sdf.py", "NeuralSDF", "sdf", dict(torch=torch))
+    for coords, lod_idx in ((x, 1), (x, None), (x.reshape(60, 5, 3), 2)):
+        got = sdf(me, coords, lod_idx)["sdf"]
+        f = lookup(coords, 2 if lod_idx is None else lod_idx)
+        want = dec(torch.cat([coords, f], -1) if position_input else f)
+        assert got.shape == (*coords.shape[:-1], 1) and torch.equal(got, want)
+    assert float(got.detach().abs().max()) > 0
+    empty = sdf(me, torch.zeros(0, 3), None)["sdf"]
+    assert empty.shape == (0, 1)
+
+
+@pytest.mark.parametrize("lod_idx", [None, 9])
+def test_oracle_radiance_field_equals_the_reference_rgba_body(lod_idx):
+    """NeuralRadianceField.rgba (models/nefs/nerf.py:219-264), the method body compiled from the reference file, with the reference's
+    own PositionalEmbedder as view embedder and the oracle's hash-grid lookup as `grid.interpolate` - against OracleNeRF.rgba, the field
+    every GPU NeRF test is compared with: default lod_idx, the [batch, effective_feature_dim] reshape, density features -> view embedding
+    concatenation, colour decoded from fdir[..., 1:], relu density."""
+    from oracle import hashgrid as ohash, nerf as onerf
+    emb_cls = _exec_reference("models/embedders/positional_embedder.py")["PositionalEmbedder"]
+    res = [16, 32, 64, 128, 256, 300, 350, 400, 420, 440, 460, 470, 480, 490, 500, 512]
+    torch.manual_seed(12)
+    onef = onerf.OracleNeRF(res, 2, 10, 'cat', 0.1, 64, 1, True, 4)
+    emb = emb_cls(4, 3, log_sampling=True, include_input=True, input_dim=3)
+    assert emb.out_dim == onef.view_embed_dim
+    seen = []
+
+    class Grid:
+        active_lods, multiscale_type, feature_dim, num_lods = list(range(len(res))), 'cat', 2, len(res)
+
+        @staticmethod
+        def interpolate(coords, lod):
+            seen.append(lod)
+            return ohash.grid_interpolate(coords, lod, 'cat', 2, res, 10, onef.grid.codebook.feats, onef.begin_idxes)
+
+    me = types.SimpleNamespace(grid=Grid, pos_embedder=None, view_embedder=emb, view_embedder_type='positional',
+                               view_embed_dim=emb.out_dim, decoder_density=onef.decoder_density, decoder_color=onef.decoder_color)
+    me.effective_feature_dim = lambda: _reference_method("models/nefs/nerf.py", "NeuralRadianceField", "effective_feature_dim", {})(me)
+    rgba = _reference_method("models/nefs/nerf.py", "NeuralRadianceField", "rgba", dict(torch=torch))
+    rng = np.random.default_rng(13)
+    coords = torch.from_numpy(rng.uniform(-1, 1, (300, 3)).astype(np.float32))
+    dirs = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(300, 3)).astype(np.float32)), dim=1)
+    with torch.no_grad():
+        got = rgba(me, coords, dirs, lod_idx)
+        want = onef.rgba(coords, dirs, lod_idx)
+    assert seen == [len(res) - 1 if lod_idx is None else lod_idx]
+    assert got["rgb"].shape == (300, 3) and got["density"].shape == (300, 1)
+    assert torch.equal(got["rgb"], want["rgb"]) and torch.equal(got["density"], want["density"])
+    assert float(got["density"].max()) > 0 and float(got["rgb"].std()) > 0
