@@ -1118,3 +1118,49 @@ def test_oracle_radiance_field_equals_the_reference_rgba_body(lod_idx):
     assert got["rgb"].shape == (300, 3) and got["density"].shape == (300, 1)
     assert torch.equal(got["rgb"], want["rgb"]) and torch.equal(got["density"], want["density"])
     assert float(got["density"].max()) > 0 and float(got["rgb"].std()) > 0
+
+
+@pytest.mark.parametrize("ortho", [False, True])
+def test_oracle_ray_generation_equals_the_reference_function_bodies(ortho):
+    """generate_default_grid / generate_centered_pixel_coords / _to_ndc_coords / generate_pinhole_rays / generate_ortho_rays
+    (ops/raygen/raygen.py:16-119) compiled from the reference file and run on an adapter around this package's LookAtCamera (kaolin's
+    Camera surface: width, height, x0, y0, tan_half_fov(CameraFOV), fov_distance, extrinsics.inv_transform_rays - the last restated as
+    R^T (x - t), Kaolin's leaf) - against oracle.raygen, what the wisp_generate_rays kernel is compared with on the GPU: pixel centres,
+    principal-point signs (x - x0, y + y0), NDC scaling, the flipped y axis, -z viewing direction, ortho plane scaling, normalisation."""
+    from oracle import raygen as oray
+    from wisp.core import Rays
+    from wisp.ops.raygen import LookAtCamera
+    W, H = 40, 24
+    cam = LookAtCamera(eye=(1.5, 0.8, 2.5), at=(0.1, -0.2, 0.0), up=(0, 1, 0), fov=0.6911112, width=W, height=H, near=0.5, far=7.0,
+                       x0=1.75, y0=-0.6, fov_distance=1.3)
+    m = cam.view_matrix()[0]
+    R, t = m[:3, :3], m[:3, 3]
+    fov_axis = types.SimpleNamespace(HORIZONTAL='horizontal', VERTICAL='vertical')
+
+    class Extrinsics:
+        @staticmethod
+        def inv_transform_rays(orig, dirs):
+            return ((orig - t) @ R)[None], (dirs @ R)[None]                  # rows: R^T (x - t), R^T d
+
+    kcam = types.SimpleNamespace(device=torch.device('cpu'), dtype=torch.float32, width=W, height=H, x0=cam.x0, y0=cam.y0,
+                                 near=cam.near, far=cam.far, fov_distance=cam.fov_distance, extrinsics=Extrinsics,
+                                 tan_half_fov=lambda axis: cam.tan_half_fov(axis))
+    glb = dict(torch=torch, Rays=Rays, CameraFOV=fov_axis, Camera=object)
+    glb["generate_default_grid"] = _reference_function("ops/raygen/raygen.py", "generate_default_grid", glb)
+    glb["_to_ndc_coords"] = _reference_function("ops/raygen/raygen.py", "_to_ndc_coords", glb)
+    grid = _reference_function("ops/raygen/raygen.py", "generate_centered_pixel_coords", glb)
+    gen = _reference_function("ops/raygen/raygen.py", "generate_ortho_rays" if ortho else "generate_pinhole_rays", glb)
+    for res in ((None, None), (20, 12)):                                      # native grid, and a coarser one scaled to the image
+        py, px = grid(W, H, *res) if res[0] else grid(W, H, W, H)
+        opy, opx = oray.centered_pixel_coords(W, H, *res)
+        assert np.array_equal(py.numpy(), opy) and np.array_equal(px.numpy(), opx)
+        rays = gen(kcam, (py, px))
+        if ortho:
+            sx, sy, x0, y0 = np.float32(cam.fov_distance) * np.float32(W / H), cam.fov_distance, 0.0, 0.0
+        else:
+            sx, sy, x0, y0 = cam.tan_half_fov('horizontal'), cam.tan_half_fov('vertical'), cam.x0, cam.y0
+        o, d = oray.generate_rays(opx, opy, ortho, x0, y0, W, H, sx, sy, R.numpy(), t.numpy())
+        assert rays.origins.shape == (py.numel(), 3) and (rays.dist_min, rays.dist_max) == (0.5, 7.0)
+        np.testing.assert_allclose(rays.origins.numpy(), o, atol=2e-6, rtol=0)
+        np.testing.assert_allclose(rays.dirs.numpy(), d, atol=2e-6, rtol=0)
+    assert float(np.abs(d - d[0]).max()) == 0.0 if ortho else float(np.abs(d - d[0]).max()) > 0.1
