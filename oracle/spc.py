@@ -119,9 +119,38 @@ def create_dense_octree(level):
     return np.full(n, 255, dtype=np.uint8)
 
 
-def pointcloud_to_octree(pointcloud, level):
-    """wisp pointcloud_to_octree(dilate=0) (conversions.py:15-48)."""
-    return points_to_octree(quantize_points(pointcloud, level), level)
+# processing.py:26-41, duplicates removed: everything in {-1,0,1}^3 except the centre and the three two-negative edges
+DILATE_OFFSETS = tuple(o for o in ((x, y, z) for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1))
+                       if o not in ((0, 0, 0), (-1, -1, 0), (-1, 0, -1), (0, -1, -1)))
+
+
+def dilate_points(points, level):
+    """wisp dilate_points (ops/spc/processing.py:13-47): the offsets the reference's list spells out - 6 faces, 8 corners and 9 of the
+    12 edges: it has no -x-y, -x-z, -y-z term (`+y-x` etc. cover the mixed signs, nothing covers two negatives) and no `points` term
+    either, so a cell grows into 23 neighbours without itself - clipped to the grid, unique, morton order."""
+    p = np.asarray(points).astype(np.int64)
+    offs = np.array([o for o in DILATE_OFFSETS], dtype=np.int64)
+    grown = np.clip((p[None, :, :] + offs[:, None, :]).reshape(-1, 3), 0, 2 ** level - 1)
+    return morton_to_points(np.unique(points_to_morton(grown)))
+
+
+def pointcloud_to_octree(pointcloud, level, attributes=None, dilate=0):
+    """wisp pointcloud_to_octree (conversions.py:15-48): quantise, dilate `dilate` times, unique, morton sort, octree; with
+    `attributes` [N, F] also the per-cell mean (float32 sum in input order / count) in morton order.  (The reference allocates the
+    accumulator as zeros_like(unique): it only runs for F == 3; the restatement takes any F.)"""
+    points = quantize_points(pointcloud, level)
+    for _ in range(dilate):
+        points = dilate_points(points, level)
+    codes = points_to_morton(points)
+    morton, inverse, counts = np.unique(codes, return_inverse=True, return_counts=True)
+    octree = points_to_octree(morton_to_points(morton), level)
+    if attributes is None:
+        return octree
+    a = np.asarray(attributes, dtype=F32)
+    att = np.zeros((morton.shape[0], a.shape[1]), dtype=F32)
+    for i in range(a.shape[0]):                                   # index_add_ on the CPU adds in input order
+        att[inverse[i]] += a[i]
+    return octree, (att / counts[:, None].astype(F32)).astype(F32)
 
 
 # ----------------------------------------------------------------------------- query

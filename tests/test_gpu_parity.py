@@ -401,6 +401,26 @@ def test_raytrace_nugget_cache_and_level_extremes(cap, monkeypatch):
         assert np.array_equal(r0.cpu().numpy(), w0[0]) and np.array_equal(d0.cpu().numpy(), w0[2]) and int(p0.abs().max()) == 0
 
 
+def test_pointcloud_to_octree_on_device_matches_oracle_with_dilation_and_attributes():
+    """wisp.ops.spc.pointcloud_to_octree / dilate_points on device tensors against the oracle (which the CPU suite pins to the
+    reference's function bodies, conversions.py:15-48 + processing.py:13-47 - including the reference's 23-offset dilation: no centre,
+    no -x-y / -x-z / -y-z edge)."""
+    import wisp.ops.spc as pspc
+    rng = np.random.default_rng(404)
+    cloud = rng.uniform(-1, 1, (5000, 3)).astype(np.float32)
+    cloud[:500] = cloud[500:1000]
+    att = rng.normal(size=(5000, 3)).astype(np.float32)
+    for level, rounds in ((5, 0), (5, 1), (4, 2)):
+        got = pspc.pointcloud_to_octree(cuda(cloud), level, dilate=rounds)
+        assert got.is_cuda and np.array_equal(got.cpu().numpy(), ospc.pointcloud_to_octree(cloud, level, dilate=rounds))
+    tree, mean = pspc.pointcloud_to_octree(cuda(cloud), 5, attributes=cuda(att))
+    want_tree, want_mean = ospc.pointcloud_to_octree(cloud, 5, attributes=att)
+    assert np.array_equal(tree.cpu().numpy(), want_tree)
+    np.testing.assert_allclose(mean.cpu().numpy(), want_mean, atol=2e-6, rtol=0)     # index_add_ on the device adds in free order
+    one = pspc.dilate_points(cuda(np.array([[9, 9, 9]], np.int16)), 5).cpu().numpy()
+    assert np.array_equal(one, ospc.dilate_points(np.array([[9, 9, 9]]), 5)) and one.shape[0] == 23
+
+
 @pytest.mark.parametrize("level,n", [(1, 3), (3, 40), (5, 3000), (7, 60000), (8, 200000)])
 def test_device_spc_build_matches_oracle(level, n):
     """csrc/spc.hip 'SPC build on the device' (dense Morton mask -> node bytes -> one stream compaction) against the oracle's

@@ -1164,3 +1164,89 @@ def test_oracle_ray_generation_equals_the_reference_function_bodies(ortho):
         np.testing.assert_allclose(rays.origins.numpy(), o, atol=2e-6, rtol=0)
         np.testing.assert_allclose(rays.dirs.numpy(), d, atol=2e-6, rtol=0)
     assert float(np.abs(d - d[0]).max()) == 0.0 if ortho else float(np.abs(d - d[0]).max()) > 0.1
+
+
+def _kaolin_spc_leaves():
+    """kaolin.ops.spc as the oracle restates it (torch in, torch out) - the leaves under the reference's SPC builders."""
+    from oracle import spc as ospc
+    t = torch.from_numpy
+
+    def scan_octrees(octree, lengths):
+        lvl, pyramid, exsum = ospc.scan_octree(octree.numpy())
+        return torch.tensor([lvl]), t(np.asarray(pyramid))[None], t(np.asarray(exsum))
+
+    def make_trinkets(points, pyramid, pd, pyd):
+        tr, par = ospc.make_trinkets(points.numpy(), pyramid.numpy(), pd.numpy(), pyd.numpy())
+        return t(np.asarray(tr)), t(np.asarray(par))
+
+    return types.SimpleNamespace(
+        quantize_points=lambda x, level: t(ospc.quantize_points(x.numpy(), level)),
+        points_to_morton=lambda p: t(ospc.points_to_morton(p.numpy())),
+        morton_to_points=lambda m: t(ospc.morton_to_points(m.numpy())),
+        unbatched_points_to_octree=lambda p, level, sorted=False: t(ospc.points_to_octree(p.numpy(), level)),
+        scan_octrees=scan_octrees,
+        generate_points=lambda octree, pyramid, exsum: t(ospc.generate_points(octree.numpy(), pyramid[0].numpy(), exsum.numpy())),
+        unbatched_make_dual=lambda p, pyr: tuple(t(np.asarray(a)) for a in ospc.make_dual(p.numpy(), pyr.numpy())),
+        unbatched_make_trinkets=make_trinkets)
+
+
+def test_oracle_and_package_spc_builders_equal_the_reference_function_bodies(monkeypatch):
+    """create_dense_octree, make_trilinear_spc (ops/spc/constructors.py:14-47), pointcloud_to_octree, octree_to_spc
+    (conversions.py:15-48,72-88) and dilate_points (processing.py:13-47) compiled from the reference files over the oracle's restatement
+    of the Kaolin leaves - against the oracle's own builders AND this package's wisp.ops.spc on the same inputs: dense trees, the
+    dilation as the reference's list spells it (23 neighbours: no centre, no -x-y / -x-z / -y-z edge; a corner cell survives through
+    clipping), repeated dilation, duplicate points, per-cell attribute means in morton order."""
+    from oracle import spc as ospc
+    import wisp.ops.spc as pspc
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)          # the reference moves its inputs to the GPU
+    leaves = _kaolin_spc_leaves()
+    glb = dict(torch=torch, np=np, spc_ops=leaves)
+    dilate = glb["dilate_points"] = _reference_function("ops/spc/processing.py", "dilate_points", glb)
+    to_octree = _reference_function("ops/spc/conversions.py", "pointcloud_to_octree", glb)
+    to_spc = _reference_function("ops/spc/conversions.py", "octree_to_spc", glb)
+    dense = _reference_function("ops/spc/constructors.py", "create_dense_octree", glb)
+    trilinear = _reference_function("ops/spc/constructors.py", "make_trilinear_spc", glb)
+
+    for level in (1, 2, 3):
+        want = ospc.create_dense_octree(level)
+        assert np.array_equal(dense(level).numpy(), want)
+        assert np.array_equal(pspc.create_dense_octree(level).cpu().numpy(), want)
+
+    for pts, level in ((np.array([[4, 4, 4]]), 3), (np.array([[0, 0, 0], [7, 7, 0]]), 3), (np.array([[1, 2, 3], [1, 2, 4], [9, 9, 9]]), 4)):
+        want = ospc.dilate_points(pts, level)
+        got_ref = dilate(torch.from_numpy(pts).short(), level).numpy()
+        got_pkg = pspc.dilate_points(torch.from_numpy(pts).short(), level).cpu().numpy()
+        assert np.array_equal(got_ref, want) and np.array_equal(got_pkg, want)
+    shell = {tuple(r) for r in (ospc.dilate_points(np.array([[4, 4, 4]]), 3).astype(int) - 4).tolist()}
+    assert len(shell) == 23 and not shell & {(0, 0, 0), (-1, -1, 0), (-1, 0, -1), (0, -1, -1)}
+
+    rng = np.random.default_rng(41)
+    cloud = rng.uniform(-1, 1, (400, 3)).astype(np.float32)
+    cloud[:50] = cloud[50:100]                                                    # duplicates: several inputs per cell
+    cloud[0] = (1.0, -1.0, 1.0)                                                   # the clamp at the upper face
+    for level, rounds, width in ((4, 0, 3), (4, 1, 3), (3, 2, 3), (5, 0, 5)):
+        att = rng.normal(size=(400, width)).astype(np.float32)
+        want = ospc.pointcloud_to_octree(cloud, level, dilate=rounds)
+        want_tree, want_att = ospc.pointcloud_to_octree(cloud, level, attributes=att, dilate=0)
+        C, A = torch.from_numpy(cloud), torch.from_numpy(att)
+        assert np.array_equal(pspc.pointcloud_to_octree(C, level, dilate=rounds).cpu().numpy(), want)
+        tree, mean = pspc.pointcloud_to_octree(C, level, attributes=A)
+        assert np.array_equal(tree.cpu().numpy(), want_tree)
+        np.testing.assert_allclose(mean.cpu().numpy(), want_att, atol=1e-6, rtol=0)
+        assert np.array_equal(to_octree(C, level, dilate=rounds).numpy(), want)
+        if width == 3:                                                            # the reference's accumulator is zeros_like(unique): F == 3
+            tree, mean = to_octree(C, level, attributes=A)
+            assert np.array_equal(tree.numpy(), want_tree)
+            np.testing.assert_allclose(mean.numpy(), want_att, atol=1e-6, rtol=0)
+        assert want_att.shape[0] == ospc.octree_to_spc(want_tree)[1][0, level] < 400
+
+    tree = torch.from_numpy(ospc.pointcloud_to_octree(cloud, 4, dilate=1))
+    pts, pyr, ex = ospc.octree_to_spc(tree.numpy())
+    for got in (to_spc(tree), pspc.octree_to_spc(tree)):
+        assert np.array_equal(got[0].cpu().numpy(), pts) and np.array_equal(got[1].cpu().numpy(), pyr)
+        assert np.array_equal(got[2].cpu().numpy(), ex)
+    pd, pyd = ospc.make_dual(pts, pyr)
+    tr, par = ospc.make_trinkets(pts, pyr, pd, pyd)
+    for got in (trilinear(torch.from_numpy(pts), torch.from_numpy(pyr)), pspc.make_trilinear_spc(torch.from_numpy(pts), torch.from_numpy(pyr))):
+        for a, b in zip(got, (pd, pyd, tr, par)):
+            assert np.array_equal(a.cpu().numpy(), np.asarray(b))
