@@ -1250,3 +1250,53 @@ def test_oracle_and_package_spc_builders_equal_the_reference_function_bodies(mon
     for got in (trilinear(torch.from_numpy(pts), torch.from_numpy(pyr)), pspc.make_trilinear_spc(torch.from_numpy(pts), torch.from_numpy(pyr))):
         for a, b in zip(got, (pd, pyd, tr, par)):
             assert np.array_equal(a.cpu().numpy(), np.asarray(b))
+
+
+def test_validation_metric_and_log_line_are_what_the_reference_computes_and_parses():
+    """(1) psnr (ops/image/metrics.py:19-37), the function body compiled from the reference file (its module imports skimage), equals
+    this package's wisp.ops.image.psnr and the oracle's, including the range asserts.  (2) evaluate_psnr's log line goes through the
+    reference tests' OWN scraper (tests/test_utils.py:55-92, executed from where it lies) and comes back as the same epoch and value -
+    the contract the reference's PSNR-floor tests (tests/apps/test_nerf.py) rest on.  (3) the chunked render concatenates like
+    OfflineRenderer.render (tracker/offline_renderer.py:170-191): any chunk size, same image."""
+    from oracle import nerf as onerf
+    from wisp.core import Rays, RenderBuffer
+    from wisp.ops.image import psnr
+    from wisp.trainers import evaluate_psnr, render
+    ref_psnr = _reference_function("ops/image/metrics.py", "psnr", dict(torch=torch, np=np))
+    rng = np.random.default_rng(51)
+    a, b = torch.from_numpy(rng.uniform(0, 1, (20, 30, 3)).astype(np.float32)), torch.from_numpy(rng.uniform(0, 1, (20, 30, 3)).astype(np.float32))
+    assert ref_psnr(a, b) == psnr(a, b) == onerf.psnr(a, b) and 5.0 < psnr(a, b) < 12.0
+    for bad in (a + 0.2, a - 0.2):
+        for fn in (ref_psnr, psnr):
+            with pytest.raises(AssertionError):
+                fn(bad, b)
+
+    def _image(rays):          # exactly rounded ops only: a chunk must give the same bits as the whole (CPU sigmoid is length dependent)
+        return (rays.origins * 0.125 + rays.dirs * 0.0625 + 0.5).clamp(0.0, 1.0)
+
+    class Tracer:
+        def __call__(self, nef, rays=None, lod_idx=None, channels=None):
+            return RenderBuffer(rgb=_image(rays), alpha=rays.dirs[:, :1].abs())
+
+    pipe = types.SimpleNamespace(tracer=Tracer(), nef=types.SimpleNamespace(grid=types.SimpleNamespace(num_lods=16)),
+                                 eval=lambda: None, train=lambda: None)
+    views = []
+    for v in range(3):
+        rays = Rays(torch.from_numpy(rng.normal(size=(600, 3)).astype(np.float32)), torch.from_numpy(rng.normal(size=(600, 3)).astype(np.float32)))
+        views.append((rays, (_image(rays) + 0.02 * torch.from_numpy(rng.normal(size=(600, 3)).astype(np.float32))).clamp(0, 1)))
+    whole = render(pipe, views[0][0], render_batch=0)
+    for chunk in (1000, 600, 599, 7):
+        part = render(pipe, views[0][0], render_batch=chunk)
+        assert torch.equal(part.rgb, whole.rgb) and torch.equal(part.alpha, whole.alpha)
+    mean, line = evaluate_psnr(pipe, views, epoch=40, max_epochs=50, render_batch=256)
+    assert abs(mean - np.mean([ref_psnr(_image(r), g) for r, g in views])) < 1e-9 and 30.0 < mean < 40.0
+    scraper = {"re": __import__("re"), "defaultdict": __import__("collections").defaultdict}
+    for fn in ("_get_metric_from_log_line", "collect_metrics_from_log"):
+        path = "/root/reference/tests/test_utils.py"
+        import ast
+        tree = ast.parse(open(path).read(), path)
+        node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == fn)
+        exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), scraper)
+    log = "some other output\n" + line + "\nEPOCH 50/50 | lod15 psnr: 12.34\n"
+    got = scraper["collect_metrics_from_log"](log, ["psnr"])
+    assert got[40]["psnr"] == "{:.2f}".format(mean) and got[50]["psnr"] == "12.34" and set(got) == {40, 50}
