@@ -24,6 +24,10 @@ class RenderBuffer:
         return ch.get(item, None)                       # unknown channels read as None (render_buffer.py:92-97)
 
     def __setattr__(self, key, value):
+        if key == "rgba":                               # render_buffer.py:110-118: sets rgb and alpha together
+            self._ch["rgb"] = None if value is None else value[..., 0:-1]
+            self._ch["alpha"] = None if value is None else value[..., -1:]
+            return
         self._ch[key] = value
 
     def __iter__(self) -> Iterator[Tuple[str, Optional[torch.Tensor]]]:
@@ -45,10 +49,6 @@ class RenderBuffer:
             return None
         return torch.cat((self.rgb, self.alpha), dim=-1)
 
-    @rgba.setter
-    def rgba(self, val):
-        self._ch["rgb"] = None if val is None else val[..., 0:-1]
-        self._ch["alpha"] = None if val is None else val[..., -1:]
 
     @property
     def channels(self) -> Set[str]:
@@ -76,6 +76,10 @@ class RenderBuffer:
                 return y
             if y is None:
                 return x
+            if x.ndim == y.ndim + 1 and x.shape[-1] == 1:       # [.., 1] meets [..]: give the flat one its unit axis (:188-192)
+                y = y.unsqueeze(-1)
+            elif y.ndim == x.ndim + 1 and y.shape[-1] == 1:
+                x = x.unsqueeze(-1)
             return torch.cat((x, y), dim=dim)
         return RenderBuffer._apply_on_pair(self, other, _cat)
 
@@ -84,27 +88,48 @@ class RenderBuffer:
 
     @staticmethod
     def mean(*rblst) -> RenderBuffer:
+        """Per-channel mean of several buffers (render_buffer.py:367-394): a channel missing from a buffer adds nothing but still
+        counts in the divisor; channels are summed in their own dtype (boolean `hit` adds as logical or) and divided by the count."""
         def _sum(pair):
             x, y = pair
-            if x is None or y is None:
-                return None
-            return x.float() + y.float()
-        total = rblst[0]
-        for rb in rblst[1:]:
+            if x is None:
+                return y
+            if y is None:
+                return x
+            return x + y
+        total = RenderBuffer()
+        for rb in rblst:
             total = RenderBuffer._apply_on_pair(total, rb, _sum)
-        return total._apply(lambda x: x / float(len(rblst)))
+        n = float(len(rblst))
+        return total._apply(lambda x: torch.div(x, n))
 
     def blend(self, other: RenderBuffer, channel_kit=None) -> RenderBuffer:
-        """Depth-ordered blend of two buffers (viewer feature; only the default 'closest wins' rule is offered)."""
-        if self.depth is None or other.depth is None:
-            return self
-        closer = (self.depth <= other.depth)
-        def _pick(pair):
-            x, y = pair
+        """Depth-ordered blend of two buffers (render_buffer.py:204-260; a viewer feature).  Per channel present in both: the
+        nearer buffer's value is c1; when both buffers carry alpha, `channel_kit[name].blend_fn(c1, c2, alpha1, alpha2)` decides
+        (channels without an entry: alpha-composite 'over'), otherwise the nearer value wins.  `channel_kit`: mapping name -> object
+        with a `blend_fn` attribute (the reference's wisp.core.channels.Channel)."""
+        assert self.depth is not None and other.depth is not None, "Cannot blend renderbuffers without depth values."
+        nearer = self.depth <= other.depth
+        a1, a2 = self.alpha, other.alpha
+        with_alpha = a1 is not None and a2 is not None
+
+        def over(c1, c2, alpha1, alpha2):               # channel_fn.py:160-179
+            alpha_out = alpha1 + alpha2 * (1.0 - alpha1)
+            return torch.where(alpha_out > 0, (c1 * alpha1 + c2 * alpha2 * (1.0 - alpha1)) / alpha_out, torch.zeros_like(c1))
+
+        out = {}
+        for name in list(dict.fromkeys(list(self._ch.keys()) + list(other._ch.keys()))):
+            x, y = self._ch.get(name), other._ch.get(name)
             if x is None or y is None:
-                return x if y is None else y
-            return torch.where(closer.expand_as(x) if closer.shape[-1] == 1 else closer, x, y)
-        return RenderBuffer._apply_on_pair(self, other, _pick)
+                out[name] = y if x is None else x
+            elif with_alpha:
+                entry = None if channel_kit is None else channel_kit.get(name)
+                fn = over if entry is None else entry.blend_fn
+                out[name] = fn(torch.where(nearer, x, y), torch.where(nearer, y, x),
+                               torch.where(nearer, a1, a2), torch.where(nearer, a2, a1))
+            else:
+                out[name] = torch.where(nearer, x, y)
+        return RenderBuffer(**out)
 
     def transpose(self) -> RenderBuffer:
         return self._apply(lambda x: x.permute(1, 0, *tuple(range(2, x.ndim))))
@@ -121,22 +146,27 @@ class RenderBuffer:
         return {k: v.detach().cpu().numpy() for k, v in self._ch.items() if v is not None}
 
     def exr_dict(self) -> Dict[str, torch.Tensor]:
-        out = {}
-        for k, v in self.numpy_dict().items():
-            out[k] = v
+        """numpy_dict with `rgb` under the name `default`, the layer EXR viewers open first (render_buffer.py:311-324)."""
+        out = self.numpy_dict()
+        if 'rgb' in out:
+            out['default'] = out.pop('rgb')
         return out
 
     def image(self) -> RenderBuffer:
-        """Channels normalised for display: floats scaled to [0,255], hit expanded, depth normalised."""
-        def _img(name, x):
-            x = x.float()
-            if name == "depth":
-                rng = torch.clamp(x.max() - x.min(), min=1e-8)
-                x = (x - x.min()) / rng
-            if x.shape[-1] == 1:
-                x = x.expand(*x.shape[:-1], 3)
-            return torch.clamp(x, 0.0, 1.0) * 255.0
-        return RenderBuffer(**{k: (None if v is None else _img(k, v)) for k, v in self._ch.items()})
+        """8-bit-range copy for saving (render_buffer.py:326-365): rgb and alpha times 255; depth relative to its maximum, repeated
+        to three channels; `hit` repeated to three channels; `normal` mapped from [-1,1] to [0,1]; nothing else is kept."""
+        def gray3(x):
+            return torch.cat([x] * 3, dim=-1)
+        out = {}
+        if self.rgb is not None:
+            out['rgb'] = self.rgb * 255.0
+        if self.alpha is not None:
+            out['alpha'] = self.alpha * 255.0
+        if self.depth is not None:
+            out['depth'] = gray3(self.depth / (torch.max(self.depth) + 1e-8)) * 255.0
+        out['hit'] = None if self.hit is None else gray3(self.hit) * 255.0
+        out['normal'] = None if self.normal is None else ((self.normal + 1.0) / 2.0) * 255.0
+        return RenderBuffer(**out)
 
     def reshape(self, *dims) -> RenderBuffer:
         return self._apply(lambda x: x.reshape(*dims))

@@ -1300,3 +1300,96 @@ def test_validation_metric_and_log_line_are_what_the_reference_computes_and_pars
     log = "some other output\n" + line + "\nEPOCH 50/50 | lod15 psnr: 12.34\n"
     got = scraper["collect_metrics_from_log"](log, ["psnr"])
     assert got[40]["psnr"] == "{:.2f}".format(mean) and got[50]["psnr"] == "12.34" and set(got) == {40, 50}
+
+
+def test_render_buffer_behaves_like_the_reference_class(monkeypatch):
+    """wisp.core.RenderBuffer against the reference class (core/render_buffer.py:21-439) executed where it lies, its channel
+    definitions (core/channels.py, core/channel_fn.py) registered for the duration of the test: construction with custom channels,
+    iteration order, channel queries, rgba get / set, `+` / cat incl. a channel missing on one side, custom channels on one side and
+    [N,1] meeting [N], mean (boolean `hit` included), reshape / transpose / scale, dtype and device moves, numpy_dict, exr_dict
+    (`rgb` becomes `default`), image(), and the depth-ordered blend with and without alpha - identical channel sets, shapes, dtypes
+    and values."""
+    import wisp.core                                                               # noqa: F401  (parent package of the registered modules)
+    from wisp.core import RenderBuffer as Mine
+
+    def load(name, rel):
+        mod = types.ModuleType(name)
+        mod.__file__ = os.path.join(REF, rel)
+        monkeypatch.setitem(sys.modules, name, mod)
+        exec(compile(open(mod.__file__).read(), mod.__file__, "exec"), mod.__dict__)
+        return mod
+
+    load("wisp.core.channel_fn", "core/channel_fn.py")
+    kit = load("wisp.core.channels", "core/channels.py").channels_starter_kit()
+    Ref = _exec_reference("core/render_buffer.py")["RenderBuffer"]
+
+    def make(cls, n=12, extra=True, depth=True, seed=0, alpha=True):
+        g = torch.Generator().manual_seed(seed)
+        kw = dict(rgb=torch.rand(n, 3, generator=g))
+        if alpha:
+            kw["alpha"] = torch.rand(n, 1, generator=g)
+        if depth:
+            kw["depth"] = torch.rand(n, 1, generator=g)
+        if extra:
+            kw.update(hit=torch.rand(n, 1, generator=g) > 0.5, normal=torch.randn(n, 3, generator=g))
+        return cls(**kw)
+
+    def live(rb):
+        return {k: v for k, v in iter(rb) if v is not None}
+
+    def check(fn, what):
+        torch.manual_seed(77)
+        a = live(fn(Ref))
+        torch.manual_seed(77)                       # some cases draw fresh channels: the same draws for both classes
+        b = live(fn(Mine))
+        assert set(a) == set(b), (what, sorted(a), sorted(b))
+        for k in a:
+            assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), (what, k)
+
+    a, b = make(Ref), make(Mine)
+    assert [k for k, _ in iter(a)] == [k for k, _ in iter(b)] and a.channels == b.channels
+    assert a.has_channel("hit") and b.has_channel("hit") and not a.has_channel("zz") and not b.has_channel("zz")
+    assert a.get_channel("zz") is None and b.get_channel("zz") is None and b.zz is None
+    assert torch.equal(a.rgba, b.rgba) and make(Ref, alpha=False).rgba is None and make(Mine, alpha=False).rgba is None
+
+    def set_rgba(cls):
+        rb = make(cls)
+        rb.rgba = torch.full((12, 4), 0.25)
+        return rb
+
+    flat_hit = lambda cls: cls(rgb=torch.ones(5, 3), hit=torch.ones(5, dtype=torch.bool))
+    cases = {
+        "construct": make,
+        "rgba setter": set_rgba,
+        "add": lambda c: make(c) + make(c, seed=1),
+        "add to empty": lambda c: c() + make(c),
+        "add empty": lambda c: make(c) + c(),
+        "add, depth missing on one side": lambda c: make(c, depth=False) + make(c, seed=1),
+        "add, custom channels on one side": lambda c: make(c, extra=False) + make(c, seed=1),
+        "cat [N,1] with [N]": lambda c: make(c, 5).cat(flat_hit(c)),
+        "cat [N] with [N,1]": lambda c: flat_hit(c).cat(make(c, 5)),
+        "cat dim 1": lambda c: make(c).reshape(3, 4, -1).cat(make(c, seed=1).reshape(3, 4, -1), dim=1),
+        "mean": lambda c: c.mean(make(c), make(c, seed=1), make(c, seed=2, depth=False)),
+        "reshape": lambda c: make(c).reshape(3, 4, -1),
+        "transpose": lambda c: make(c).reshape(3, 4, -1).transpose(),
+        "scale": lambda c: make(c, extra=False).reshape(3, 4, -1).scale((6, 8)),
+        "image": lambda c: make(c).reshape(3, 4, -1).image(),
+        "image without hit / normal": lambda c: make(c, extra=False).image(),
+        "byte": lambda c: make(c).byte(), "half": lambda c: make(c).half(), "float": lambda c: make(c).half().float(),
+        "double": lambda c: make(c).double(), "detach": lambda c: make(c).detach(), "cpu": lambda c: make(c).cpu(),
+        "to": lambda c: make(c).to(torch.float64),
+        "blend, starter kit": lambda c: make(c, extra=False).blend(make(c, extra=False, seed=1), channel_kit=kit),
+        "blend, default rule": lambda c: make(c, extra=False).blend(make(c, extra=False, seed=1), channel_kit={}),
+        "blend without alpha": lambda c: make(c, extra=False, alpha=False).blend(make(c, extra=False, seed=1, alpha=False), channel_kit=kit),
+        "blend, channel on one side": lambda c: make(c, extra=False).blend(c(depth=torch.rand(12, 1), alpha=torch.rand(12, 1), err=torch.rand(12, 2)),
+                                                                           channel_kit=kit),
+    }
+    for what, fn in cases.items():
+        check(fn, what)
+    for cls in (Ref, Mine):
+        with pytest.raises(AssertionError):
+            make(cls, depth=False).blend(make(cls), channel_kit=kit)
+    na, nb = make(Ref).numpy_dict(), make(Mine).numpy_dict()
+    ea, eb = make(Ref).exr_dict(), make(Mine).exr_dict()
+    assert sorted(na) == sorted(nb) and sorted(ea) == sorted(eb) and "default" in eb and "rgb" not in eb
+    assert all(np.array_equal(na[k], nb[k]) for k in na) and all(np.array_equal(ea[k], eb[k]) for k in ea)
