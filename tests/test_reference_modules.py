@@ -1393,3 +1393,83 @@ def test_render_buffer_behaves_like_the_reference_class(monkeypatch):
     ea, eb = make(Ref).exr_dict(), make(Mine).exr_dict()
     assert sorted(na) == sorted(nb) and sorted(ea) == sorted(eb) and "default" in eb and "rgb" not in eb
     assert all(np.array_equal(na[k], nb[k]) for k in na) and all(np.array_equal(ea[k], eb[k]) for k in ea)
+
+
+def test_neural_field_dispatch_behaves_like_the_reference_base_class():
+    """BaseNeuralField (models/nefs/base_nef.py:16-202) executed where it lies against wisp.models.nefs.BaseNeuralField, the same toy
+    field subclassed from each: which functions run for which requested channels (the one covering most channels first, each at most
+    once), required / optional argument forwarding by signature, the return type by the TYPE of `channels` (str -> tensor, list -> list
+    in order, set / None -> dict), get_forward_function, and the four error cases with their messages."""
+    from wisp.models.nefs import BaseNeuralField as Mine
+    Ref = _exec_reference("models/nefs/base_nef.py")["BaseNeuralField"]
+    calls = []
+
+    def field(base):
+        class Toy(base):
+            def register_forward_functions(self):
+                self._register_forward_function(self.rgba, ["density", "rgb"])
+                self._register_forward_function(self.sdf, "sdf")
+                self._register_forward_function(self.both, ["rgb", "normal", "extra"])
+
+            def rgba(self, coords, ray_d, lod_idx=None):
+                calls.append(("rgba", lod_idx))
+                return dict(rgb=coords + ray_d, density=coords.sum(-1, keepdim=True) * (1 if lod_idx is None else lod_idx))
+
+            def sdf(self, coords, scale=2.0):
+                calls.append(("sdf", scale))
+                return dict(sdf=coords.norm(dim=-1, keepdim=True) * scale)
+
+            def both(self, coords):
+                calls.append(("both", None))
+                return dict(rgb=-coords, normal=coords * 2, extra=coords[:, :1])
+        return Toy()
+
+    x, d = torch.arange(12.0).reshape(4, 3), torch.ones(4, 3)
+
+    def run(nef, **kw):
+        calls.clear()
+        try:
+            out = nef(**kw)
+        except Exception as e:                                   # noqa: BLE001 - the reference raises bare Exception
+            return ("raised", type(e).__name__, str(e)), list(calls)
+        return out, list(calls)
+
+    def same(a, b):
+        if isinstance(a, torch.Tensor):
+            return isinstance(b, torch.Tensor) and torch.equal(a, b)
+        if isinstance(a, dict):
+            return isinstance(b, dict) and set(a) == set(b) and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, list):
+            return isinstance(b, list) and len(a) == len(b) and all(same(p, q) for p, q in zip(a, b))
+        return type(a) is type(b) and a == b
+
+    ref, mine = field(Ref), field(Mine)
+    assert ref.get_supported_channels() == mine.get_supported_channels() == {"density", "rgb", "sdf", "normal", "extra"}
+    requests = [
+        dict(channels="rgb", coords=x, ray_d=d), dict(channels="density", coords=x, ray_d=d, lod_idx=3),
+        dict(channels=["rgb", "density"], coords=x, ray_d=d), dict(channels=["density", "rgb"], coords=x, ray_d=d),
+        dict(channels={"rgb", "density"}, coords=x, ray_d=d), dict(channels=None, coords=x, ray_d=d, scale=0.5),
+        dict(channels="sdf", coords=x), dict(channels="sdf", coords=x, scale=3.0, unused=1),
+        dict(channels=["normal", "rgb", "extra"], coords=x, ray_d=d),          # `both` covers three: runs first, rgba not needed
+        dict(channels=["normal", "density"], coords=x, ray_d=d), dict(channels={"sdf", "normal"}, coords=x),
+        dict(channels=["rgb"], coords=x),                                         # rgba lacks ray_d ...
+        dict(channels="density", coords=x),                                      # ... required argument missing
+        dict(channels="colour", coords=x, ray_d=d),                              # unsupported channel
+        dict(channels=("rgb",), coords=x, ray_d=d),                              # tuple: invalid type
+        dict(channels=[], coords=x),
+    ]
+    for kw in requests:
+        (ra, ca), (rb, cb) = run(ref, **kw), run(mine, **kw)
+        assert ca == cb, (kw["channels"], ca, cb)
+        if isinstance(ra, tuple) and ra and ra[0] == "raised":
+            assert isinstance(rb, tuple) and rb[0] == "raised" and rb[1] == ra[1], (kw["channels"], ra, rb)
+            assert ra[2].replace("Toy", "") == rb[2].replace("Toy", ""), (ra[2], rb[2])
+        else:
+            assert same(ra, rb), (kw["channels"], ra, rb)
+    for ch in ("rgb", "sdf", "normal"):
+        fa, fb = ref.get_forward_function(ch), mine.get_forward_function(ch)
+        kw = dict(coords=x) if ch != "rgb" else dict(coords=x, ray_d=d)
+        assert torch.equal(fa(**kw), fb(**kw))
+    for nef in (ref, mine):
+        with pytest.raises(Exception, match="not supported"):
+            nef.get_forward_function("colour")
