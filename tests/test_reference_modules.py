@@ -1473,3 +1473,56 @@ def test_neural_field_dispatch_behaves_like_the_reference_base_class():
     for nef in (ref, mine):
         with pytest.raises(Exception, match="not supported"):
             nef.get_forward_function("colour")
+
+
+def test_batch_types_and_ray_sampler_behave_like_the_reference(monkeypatch):
+    """Batch / MultiviewBatch / SDFBatch (datasets/batch.py:19-110) executed where they lie (attrdict.AttrDict and kaolin's Camera, third
+    party, stubbed: a dict whose items also read as attributes) and SampleRays.__call__ (datasets/transforms/ray_sampler.py:24-35), the
+    method body compiled from the reference file - against wisp.datasets: field lists and order, attribute access, ray_values /
+    coord_values, and - with the same seed of the global generator - the very same sampled rays and colours."""
+    from wisp.core import Rays
+    from wisp.datasets import Batch as MyBatch, MultiviewBatch as MyMV, SDFBatch as MySDF, SampleRays as MySampler
+
+    class AttrDict(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    monkeypatch.setitem(sys.modules, "attrdict", types.SimpleNamespace(AttrDict=AttrDict))
+    cam_mod = types.SimpleNamespace(Camera=object)
+    for name in ("kaolin", "kaolin.render", "kaolin.render.camera"):
+        monkeypatch.setitem(sys.modules, name, types.SimpleNamespace(render=types.SimpleNamespace(camera=cam_mod), camera=cam_mod, Camera=object))
+    ref = _exec_reference("datasets/batch.py")
+    g = torch.Generator().manual_seed(2)
+    rays = Rays(torch.rand(500, 3, generator=g), torch.rand(500, 3, generator=g), dist_min=0.5, dist_max=6.0)
+    rgb = torch.rand(500, 3, generator=g)
+    for cams in (None, ["cam0"]):
+        a, b = ref["MultiviewBatch"](rays=rays, cameras=cams, rgb=rgb), MyMV(rays=rays, cameras=cams, rgb=rgb)
+        assert a.fields == b.fields == ["rays", "cameras", "rgb"] and list(a.ray_values()) == list(b.ray_values()) == ["rgb"]
+        assert b.rays is rays and b["rgb"] is b.rgb is a.rgb and b.cameras == a.cameras
+    assert ref["MultiviewBatch"](rays=rays).ray_values() == MyMV(rays=rays).ray_values() == {}
+    b = MyMV(rays=rays, rgb=rgb)
+    b.depth = rgb[:, :1]                                                           # attribute writes are item writes
+    assert b["depth"] is rgb[:, :1] or torch.equal(b["depth"], rgb[:, :1])
+    with pytest.raises(AttributeError):
+        b.nothing_here
+    co, sd, nrm = torch.rand(40, 3, generator=g), torch.rand(40, 1, generator=g), torch.rand(40, 3, generator=g)
+    for kw in (dict(), dict(rgb=co * 0.5), dict(normals=nrm), dict(rgb=co * 0.5, normals=nrm)):
+        a, b = ref["SDFBatch"](coords=co, sdf=sd, **kw), MySDF(coords=co, sdf=sd, **kw)
+        assert a.fields == b.fields == ["coords", "sdf", "rgb", "normals"] and list(a.coord_values()) == list(b.coord_values())
+        assert all(a.coord_values()[k] is b.coord_values()[k] for k in a.coord_values()) and b.coords is co and b.sdf is sd
+    assert ref["Batch"](x=1, y=2).fields == MyBatch(x=1, y=2).fields == ["x", "y"] and MyBatch({"q": 3}).q == 3
+
+    call = _reference_method("datasets/transforms/ray_sampler.py", "SampleRays", "__call__",
+                             dict(torch=torch, MultiviewBatch=ref["MultiviewBatch"]))
+    for n in (64, 500, 1200):                                                       # fewer, as many, more than the view has (with repeats)
+        torch.manual_seed(123)
+        want = call(types.SimpleNamespace(num_samples=n), ref["MultiviewBatch"](rays=rays, rgb=rgb))
+        torch.manual_seed(123)
+        got = MySampler(n)(MyMV(rays=rays, rgb=rgb))
+        assert list(want) == list(got) == ["rays", "rgb"] and got["rgb"].shape == (n, 3) and got["rgb"].is_contiguous()
+        assert torch.equal(got["rgb"], want["rgb"]) and torch.equal(got["rays"].origins, want["rays"].origins)
+        assert torch.equal(got["rays"].dirs, want["rays"].dirs)
+        assert (got["rays"].dist_min, got["rays"].dist_max) == (want["rays"].dist_min, want["rays"].dist_max) == (0.5, 6.0)
+    s = MySampler(8)
+    s.set_num_samples(32)
+    assert s.num_samples == 32
