@@ -37,17 +37,27 @@ def normalize(V: torch.Tensor, F: torch.Tensor, mode: str):
     if mode == 'sphere':
         centre = (V.max(dim=0)[0] + V.min(dim=0)[0]) / 2.0
         V = V - centre
-        return V / torch.sqrt((V ** 2).sum(-1).max()), F
+        return V * (1.0 / torch.sqrt((V ** 2).sum(-1).max())), F
     if mode == 'aabb':
         V = V - V.min(dim=0)[0]
-        return V / V.max() * 2.0 - 1.0, F
+        return V * (1.0 / V.max()) * 2.0 - 1.0, F
+    if mode == 'planar':                    # x and z fill [-1, 1] on their own, y keeps the common scale and starts at 0
+        V = V - V.min(dim=0)[0]
+        V[..., 0] *= 1.0 / V[..., 0].max()
+        V[..., 2] *= 1.0 / V[..., 2].max()
+        V[..., 1] *= 1.0 / V.max()
+        V = V * 2.0 - 1.0
+        V[..., 1] -= V[..., 1].min()
+        return V, F
+    if mode == 'none':
+        return V, F
     raise ValueError(f"normalize: unsupported mode {mode!r}")
 
 
 def per_face_normals(V: torch.Tensor, F: torch.Tensor):
     """Unnormalised face normals [F,3] (their length is twice the triangle area)."""
     tri = V[F]
-    return torch.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], dim=1)
+    return torch.cross(tri[:, 0] - tri[:, 1], tri[:, 1] - tri[:, 2], dim=1)     # the reference's edge pair (per_face_normals.py:24-27)
 
 
 def area_weighted_distribution(V: torch.Tensor, F: torch.Tensor, normals: torch.Tensor = None):
@@ -74,3 +84,46 @@ def sample_surface(V: torch.Tensor, F: torch.Tensor, num_samples: int, distrib=N
     u = torch.sqrt(torch.rand(num_samples, 1, device=V.device))
     v = torch.rand(num_samples, 1, device=V.device)
     return (1 - u) * tri[:, 0] + (u * (1 - v)) * tri[:, 1] + (u * v) * tri[:, 2], normals
+
+
+def sample_near_surface(V: torch.Tensor, F: torch.Tensor, num_samples: int, variance: float = 0.01, distrib=None):
+    """Surface samples pushed off the surface by gaussian noise of standard deviation `variance`
+    (wisp/ops/mesh/sample_near_surface.py:13-34)."""
+    if distrib is None:
+        distrib = area_weighted_distribution(V, F)
+    samples = sample_surface(V, F, num_samples, distrib)[0]
+    return samples + torch.randn_like(samples) * variance
+
+
+def sample_uniform(num_samples: int):
+    """Uniform samples in [-1, 1]^3, on the host like the reference (sample_uniform.py:11-19)."""
+    return torch.rand(num_samples, 3) * 2.0 - 1.0
+
+
+def point_sample(V: torch.Tensor, F: torch.Tensor, techniques: list, num_samples: int):
+    """`num_samples` points per entry of `techniques`, concatenated in order: 'trace' = on the surface, 'near' = near it,
+    'rand' = uniform in the cube; unknown names are skipped (point_sample.py:15-48)."""
+    distrib = area_weighted_distribution(V, F) if ('trace' in techniques or 'near' in techniques) else None
+    parts = []
+    for technique in techniques:
+        if technique == 'trace':
+            parts.append(sample_surface(V, F, num_samples, distrib=distrib)[0])
+        elif technique == 'near':
+            parts.append(sample_near_surface(V, F, num_samples, distrib=distrib))
+        elif technique == 'rand':
+            parts.append(sample_uniform(num_samples).to(V.device))
+    return torch.cat(parts, dim=0)
+
+
+def barycentric_coordinates(points: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor):
+    """Barycentric coordinates [N,3] of `points` in the triangles (A, B, C), each clipped to [0, 1]
+    (barycentric_coordinates.py:11-45)."""
+    e0, e1, rel = B - A, C - A, points - A
+    d00, d01, d11 = (e0 * e0).sum(-1), (e0 * e1).sum(-1), (e1 * e1).sum(-1)
+    d20, d21 = (rel * e0).sum(-1), (rel * e1).sum(-1)
+    denom = d00 * d11 - d01 * d01
+    out = torch.zeros(points.shape[0], 3, device=points.device)
+    out[..., 1] = torch.clip((d11 * d20 - d01 * d21) / denom, 0.0, 1.0)
+    out[..., 2] = torch.clip((d00 * d21 - d01 * d20) / denom, 0.0, 1.0)
+    out[..., 0] = torch.clip(1.0 - (out[..., 1] + out[..., 2]), 0.0, 1.0)
+    return out

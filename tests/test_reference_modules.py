@@ -1526,3 +1526,48 @@ def test_batch_types_and_ray_sampler_behave_like_the_reference(monkeypatch):
     s = MySampler(8)
     s.set_num_samples(32)
     assert s.num_samples == 32
+
+
+def test_mesh_helpers_equal_the_reference_function_bodies():
+    """per_face_normals, area_weighted_distribution, random_face, sample_surface, sample_near_surface, sample_uniform, point_sample,
+    normalize (all four modes) and barycentric_coordinates (wisp/ops/mesh/*.py), each function compiled from its reference file -
+    against wisp.ops.mesh on an octahedron with unequal faces, same seed of the global generator: identical normals, face
+    probabilities, drawn faces, surface / near-surface / uniform samples and their order in point_sample, normalised vertices,
+    barycentric coordinates (inside, outside and on an edge)."""
+    from wisp.ops import mesh as mine
+    glb = dict(torch=torch)
+    for name in ("per_face_normals", "area_weighted_distribution", "random_face", "sample_surface", "sample_near_surface",
+                 "sample_uniform", "point_sample", "normalize", "barycentric_coordinates"):
+        glb[name] = _reference_function(f"ops/mesh/{name}.py", name, glb)
+    V = torch.tensor([[1.3, 0.1, 0.0], [-0.7, 0.0, 0.2], [0.0, 2.1, 0.1], [0.1, -0.9, 0.0], [0.0, 0.2, 0.8], [0.2, 0.0, -1.7]])
+    F = torch.tensor([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]])
+
+    def both(fn, *args, **kw):
+        torch.manual_seed(5)
+        a = glb[fn](*args, **kw)
+        torch.manual_seed(5)
+        return a, getattr(mine, fn)(*args, **kw)
+
+    a, b = both("per_face_normals", V, F)
+    assert torch.equal(a, b) and float(a.norm(dim=1).min()) > 0.5
+    a, b = both("area_weighted_distribution", V, F)
+    assert torch.equal(a.probs, b.probs) and float(a.probs.max() / a.probs.min()) > 2.0
+    for fn, args in (("random_face", (V, F, 300)), ("sample_surface", (V, F, 300))):
+        a, b = both(fn, *args)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    a, b = both("sample_near_surface", V, F, 300, variance=0.05)
+    assert torch.equal(a, b)
+    a, b = both("sample_uniform", 200)
+    assert torch.equal(a, b) and a.shape == (200, 3) and float(a.abs().max()) <= 1.0
+    for techniques in (["trace"], ["rand"], ["near", "trace", "rand"], ["rand", "unknown", "near"]):
+        a, b = both("point_sample", V, F, techniques, 100)
+        assert torch.equal(a, b) and a.shape[0] == 100 * sum(t in ("trace", "near", "rand") for t in techniques)
+    for mode in ("sphere", "aabb", "planar", "none"):
+        a, b = both("normalize", V.clone(), F, mode)
+        assert torch.equal(a[0], b[0]) and a[1] is F and b[1] is F, mode
+    assert abs(float(glb["normalize"](V.clone(), F, "sphere")[0].norm(dim=1).max()) - 1.0) < 1e-6
+    tri = V[F[torch.tensor([0, 3, 5, 6])]]
+    w = torch.tensor([[0.2, 0.3, 0.5], [1.4, -0.2, -0.2], [0.5, 0.5, 0.0], [-0.3, 0.9, 0.4]])
+    pts = (tri * w[:, :, None]).sum(1)
+    a, b = both("barycentric_coordinates", pts, tri[:, 0], tri[:, 1], tri[:, 2])
+    assert torch.equal(a, b) and torch.allclose(a[0], w[0], atol=1e-5) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
