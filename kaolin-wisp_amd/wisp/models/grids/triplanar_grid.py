@@ -105,12 +105,16 @@ class TriplanarGrid(BLASGrid):
         self.features.requires_grad_(False)
 
     def interpolate(self, coords, lod_idx):
-        """coords [batch, num_samples, 3] or [batch, 3] -> [..., feature_dim] ('sum') or [..., (lod_idx+1) * feature_dim]."""
+        """coords [batch, num_samples, 3] or [batch, 3] -> [..., feature_dim] ('sum') or [..., (lod_idx+1) * feature_dim] ('cat').
+        Like the reference (triplanar_grid.py:110-122), which inflates [batch, 3] to [batch, 1, 3] and restores the caller's shape in
+        its 'sum' branch only, 'cat' answers a [batch, 3] query with [batch, 1, width]; NeuralRadianceField.rgba reshapes either."""
         if self.interpolation_type != 'linear':
             raise ValueError(f"Interpolation mode '{self.interpolation_type}' is not supported")
         output_shape = coords.shape[:-1]
         feats = triplane_lookup(coords.reshape(-1, 3), [self.features[i] for i in range(lod_idx + 1)],
                                 self.multiscale_type == 'sum')
+        if self.multiscale_type != 'sum' and coords.ndim < 3:
+            return feats.reshape(coords.shape[0], 1, feats.shape[-1])
         return feats.reshape(*output_shape, feats.shape[-1])
 
     def _interpolate(self, coords, feats, lod_idx):

@@ -1571,3 +1571,46 @@ def test_mesh_helpers_equal_the_reference_function_bodies():
     pts = (tri * w[:, :, None]).sum(1)
     a, b = both("barycentric_coordinates", pts, tri[:, 0], tri[:, 1], tri[:, 2])
     assert torch.equal(a, b) and torch.allclose(a[0], w[0], atol=1e-5) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+
+
+@pytest.mark.parametrize("multiscale", ["cat", "sum"])
+def test_oracle_triplanar_grid_equals_the_reference_methods(multiscale):
+    """TriplanarFeatureVolume.forward and TriplanarGrid.interpolate / _interpolate (models/grids/triplanar_grid.py:98-143,205-233),
+    the method bodies compiled from the reference file and run on the CPU (the reference's arithmetic here IS torch's grid_sample) -
+    against oracle.triplanar.interpolate, what the one-launch HIP triplanar kernel is compared with: which coordinate pair addresses
+    which plane, reflection padding outside [-1, 1], the plane-major [x | y | z] feature layout after stack / permute / reshape,
+    'cat' / 'sum' over levels, [B,3] and [B,S,3] inputs."""
+    import torch.nn.functional as F_
+    from oracle import triplanar as otri
+    glb = dict(torch=torch, F=F_)
+    forward = _reference_method("models/grids/triplanar_grid.py", "TriplanarFeatureVolume", "forward", glb)
+    interp_one = _reference_method("models/grids/triplanar_grid.py", "TriplanarGrid", "_interpolate", glb)
+    interp = _reference_method("models/grids/triplanar_grid.py", "TriplanarGrid", "interpolate", glb)
+    torch.manual_seed(61)
+    fdim, sizes = 4, (8, 16, 32)
+    volumes = [tuple(torch.randn(1, fdim, s + 1, s + 1) for _ in range(3)) for s in sizes]
+
+    class Volume:
+        def __init__(self, planes):
+            self.fmx, self.fmy, self.fmz = planes
+            self.fdim, self.padding_mode = fdim, 'reflection'
+
+        def __call__(self, x):
+            return forward(self, x)
+
+    me = types.SimpleNamespace(features=[Volume(v) for v in volumes], multiscale_type=multiscale, interpolation_type='linear')
+    me._interpolate = lambda coords, feats, lod_idx: interp_one(me, coords, feats, lod_idx)
+    rng = np.random.default_rng(62)
+    x = torch.from_numpy(rng.uniform(-1.2, 1.2, (240, 3)).astype(np.float32))           # some beyond the planes: reflection
+    for lod_idx in (0, 2):
+        width = 3 * fdim * (1 if multiscale == 'sum' else lod_idx + 1)
+        want = otri.interpolate(volumes, x, lod_idx, multiscale)
+        for coords in (x, x.reshape(48, 5, 3)):
+            got = interp(me, coords, lod_idx)
+            # [B,3] is inflated to [B,1,3]; only the 'sum' branch restores the caller's shape (a reference quirk this package keeps)
+            assert got.shape == ((*coords.shape[:-1], width) if (multiscale == 'sum' or coords.ndim == 3) else (coords.shape[0], 1, width))
+            assert torch.allclose(got.reshape(-1, width), want, atol=1e-6, rtol=0), float((got.reshape(-1, width) - want).abs().max())
+    one = forward(me.features[0], x[:7, None, :])                                          # [N, 1, 3, fdim]: plane axis before features
+    ref_planes = otri.volume_forward(*volumes[0], x[:7])
+    assert one.shape == (7, 1, 3, fdim) and torch.allclose(one[:, 0], ref_planes, atol=1e-6)
+    assert not torch.allclose(ref_planes[:, 0], ref_planes[:, 1], atol=1e-3)              # the three planes really differ
