@@ -10,6 +10,8 @@ Outputs (small, committed):
   hashgrid_query_ref.npz - inputs + outputs of the reference hashgrid_query forward/backward kernels (probe_bitwidth 0 and 1)
   uniform_ref.npz    - inputs + outputs of the reference uniform_sample kernel
   depth_bound_ref_{a,b}.npz - inputs + outputs of the reference find_depth_bound kernel (SDF tracer)
+  spc_builders_ref.npz / raygen_ref.npz - outputs of the reference's pointcloud_to_octree / dilate_points and ray-generation
+                       FUNCTION BODIES (compiled from the reference files; Kaolin leaves restated by the oracle)
   spc_kats.npz       - hand-checkable SPC cases (dense level-2 tree, 3-point sparse tree, query / raytrace answers)
                        produced by oracle/spc.py and verified inside this script against brute force in float64
 """
@@ -135,6 +137,77 @@ def depth_bound_vectors():
         np.savez_compressed(os.path.join(OUT, "depth_bound_ref_%s.npz" % name), query=q, curr=cur, depth=depth, out=out)
 
 
+def _reference_bodies():
+    """the helpers of tests/test_reference_modules.py that compile single functions out of the reference files"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "kaolin-wisp_amd"))
+    import test_reference_modules as T
+    return T
+
+
+def spc_builder_vectors():
+    """spc_builders_ref.npz: the reference's pointcloud_to_octree / dilate_points function bodies (ops/spc/conversions.py:15-48,
+    processing.py:13-47) run over the oracle's restatement of the Kaolin leaves: octrees for 0 / 1 / 2 dilation rounds, per-cell
+    attribute means, and the dilation of single cells (interior, corner) - the reference's list yields 23 neighbours, not 26."""
+    import torch
+    T = _reference_bodies()
+    torch.Tensor.cuda = lambda self, *a, **k: self                                  # the reference moves its inputs to the GPU
+    glb = dict(torch=torch, np=np, spc_ops=T._kaolin_spc_leaves())
+    dilate = glb["dilate_points"] = T._reference_function("ops/spc/processing.py", "dilate_points", glb)
+    to_octree = T._reference_function("ops/spc/conversions.py", "pointcloud_to_octree", glb)
+    rng = np.random.default_rng(2024)
+    cloud = rng.uniform(-1, 1, (600, 3)).astype(np.float32)
+    cloud[:80] = cloud[80:160]
+    cloud[0] = (1.0, -1.0, 1.0)
+    att = rng.normal(size=(600, 3)).astype(np.float32)
+    out = dict(cloud=cloud, attributes=att, cases=np.array([[4, 0], [4, 1], [3, 2], [5, 1]]))
+    for level, rounds in out["cases"]:
+        out[f"octree_l{level}_d{rounds}"] = to_octree(torch.from_numpy(cloud), int(level), dilate=int(rounds)).numpy()
+    tree, mean = to_octree(torch.from_numpy(cloud), 5, attributes=torch.from_numpy(att))
+    out["att_octree_l5"], out["att_mean_l5"] = tree.numpy(), mean.numpy()
+    cells = np.array([[9, 9, 9], [0, 0, 0], [31, 0, 17]], dtype=np.int16)
+    out["cells"] = cells
+    for i, c in enumerate(cells):
+        out[f"dilated_{i}"] = dilate(torch.from_numpy(c[None]), 5).numpy()
+    np.savez_compressed(os.path.join(OUT, "spc_builders_ref.npz"), **out)
+
+
+def raygen_vectors():
+    """raygen_ref.npz: the reference's generate_pinhole_rays / generate_ortho_rays function bodies (ops/raygen/raygen.py:40-119) on a
+    40 x 24 look-at camera with an off-centre principal point (Kaolin's inv_transform_rays restated as R^T (x - t))."""
+    import types
+    import torch
+    T = _reference_bodies()
+    from wisp.core import Rays
+    from wisp.ops.raygen import LookAtCamera
+    W, H = 40, 24
+    cam = LookAtCamera(eye=(1.5, 0.8, 2.5), at=(0.1, -0.2, 0.0), up=(0, 1, 0), fov=0.6911112, width=W, height=H, near=0.5, far=7.0,
+                       x0=1.75, y0=-0.6, fov_distance=1.3)
+    m = cam.view_matrix()[0]
+    R, t = m[:3, :3], m[:3, 3]
+
+    class Extrinsics:
+        @staticmethod
+        def inv_transform_rays(orig, dirs):
+            return ((orig - t) @ R)[None], (dirs @ R)[None]
+
+    kcam = types.SimpleNamespace(device=torch.device('cpu'), dtype=torch.float32, width=W, height=H, x0=cam.x0, y0=cam.y0,
+                                 near=cam.near, far=cam.far, fov_distance=cam.fov_distance, extrinsics=Extrinsics,
+                                 tan_half_fov=lambda axis: cam.tan_half_fov(axis))
+    glb = dict(torch=torch, Rays=Rays, CameraFOV=types.SimpleNamespace(HORIZONTAL='horizontal', VERTICAL='vertical'), Camera=object)
+    glb["generate_default_grid"] = T._reference_function("ops/raygen/raygen.py", "generate_default_grid", glb)
+    glb["_to_ndc_coords"] = T._reference_function("ops/raygen/raygen.py", "_to_ndc_coords", glb)
+    grid = T._reference_function("ops/raygen/raygen.py", "generate_centered_pixel_coords", glb)
+    py, px = grid(W, H, W, H)
+    out = dict(width=W, height=H, x0=cam.x0, y0=cam.y0, fov_distance=cam.fov_distance, tan_h=cam.tan_half_fov('horizontal'),
+               tan_v=cam.tan_half_fov('vertical'), rotation=R.numpy(), translation=t.numpy(), pixel_y=py.numpy(), pixel_x=px.numpy(),
+               eye=np.asarray(cam.eye, np.float64), at=np.asarray(cam.at, np.float64), fov=cam.fov)
+    for name in ("pinhole", "ortho"):
+        rays = T._reference_function("ops/raygen/raygen.py", f"generate_{name}_rays", glb)(kcam, (py, px))
+        out[f"{name}_origins"], out[f"{name}_dirs"] = rays.origins.numpy(), rays.dirs.numpy()
+    np.savez_compressed(os.path.join(OUT, "raygen_ref.npz"), **out)
+
+
 def spc_vectors():
     out = {}
     # sparse 3-point tree at level 2: points (0,0,0), (3,3,3), (2,1,0)
@@ -177,5 +250,7 @@ if __name__ == "__main__":
     query_vectors()
     uniform_vectors()
     depth_bound_vectors()
+    spc_builder_vectors()
+    raygen_vectors()
     spc_vectors()
     print("golden vectors written to", OUT)

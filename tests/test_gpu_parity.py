@@ -401,6 +401,32 @@ def test_raytrace_nugget_cache_and_level_extremes(cap, monkeypatch):
         assert np.array_equal(r0.cpu().numpy(), w0[0]) and np.array_equal(d0.cpu().numpy(), w0[2]) and int(p0.abs().max()) == 0
 
 
+def test_spc_builders_and_ray_generation_golden_reference_vectors(golden_dir):
+    """The package on the device against outputs of the reference's own function bodies (tests/golden/make_golden.py):
+    pointcloud_to_octree / dilate_points (spc_builders_ref.npz) and generate_pinhole_rays / generate_ortho_rays (raygen_ref.npz)."""
+    import wisp.ops.spc as pspc
+    from wisp.ops.raygen import LookAtCamera, generate_centered_pixel_coords, generate_ortho_rays, generate_pinhole_rays
+    g = np.load(os.path.join(golden_dir, "spc_builders_ref.npz"))
+    for level, rounds in g["cases"]:
+        got = pspc.pointcloud_to_octree(cuda(g["cloud"]), int(level), dilate=int(rounds))
+        assert np.array_equal(got.cpu().numpy(), g[f"octree_l{level}_d{rounds}"])
+    tree, mean = pspc.pointcloud_to_octree(cuda(g["cloud"]), 5, attributes=cuda(g["attributes"]))
+    assert np.array_equal(tree.cpu().numpy(), g["att_octree_l5"])
+    np.testing.assert_allclose(mean.cpu().numpy(), g["att_mean_l5"], atol=2e-6, rtol=0)
+    for i, cell in enumerate(g["cells"]):
+        assert np.array_equal(pspc.dilate_points(cuda(cell[None]), 5).cpu().numpy(), g[f"dilated_{i}"])
+    r = np.load(os.path.join(golden_dir, "raygen_ref.npz"))
+    W, H = int(r["width"]), int(r["height"])
+    cam = LookAtCamera(eye=tuple(r["eye"]), at=tuple(r["at"]), up=(0, 1, 0), fov=float(r["fov"]), width=W, height=H, near=0.5, far=7.0,
+                       x0=float(r["x0"]), y0=float(r["y0"]), fov_distance=float(r["fov_distance"]))
+    py, px = generate_centered_pixel_coords(W, H, W, H, device=DEV)
+    assert np.array_equal(py.cpu().numpy(), r["pixel_y"]) and np.array_equal(px.cpu().numpy(), r["pixel_x"])
+    for name, gen in (("pinhole", generate_pinhole_rays), ("ortho", generate_ortho_rays)):
+        rays = gen(cam, (py, px))
+        np.testing.assert_allclose(rays.origins.cpu().numpy(), r[f"{name}_origins"], atol=3e-6, rtol=0)
+        np.testing.assert_allclose(rays.dirs.cpu().numpy(), r[f"{name}_dirs"], atol=3e-6, rtol=0)
+
+
 def test_pointcloud_to_octree_on_device_matches_oracle_with_dilation_and_attributes():
     """wisp.ops.spc.pointcloud_to_octree / dilate_points on device tensors against the oracle (which the CPU suite pins to the
     reference's function bodies, conversions.py:15-48 + processing.py:13-47 - including the reference's 23-offset dilation: no centre,

@@ -90,6 +90,39 @@ def test_depth_bound_search_matches_reference_kernel(golden_dir, name):
         assert g["curr"][-1] >= len(g["curr"]) and g["out"][-1] == -1
 
 
+def test_spc_builders_match_reference_function_bodies(golden_dir):
+    """oracle.spc.pointcloud_to_octree / dilate_points against outputs of the reference's own function bodies
+    (ops/spc/conversions.py:15-48, processing.py:13-47; tests/golden/make_golden.py): 0 / 1 / 2 dilation rounds, per-cell attribute
+    means in morton order, and single cells - an interior cell grows into 23 neighbours (no centre, no -x-y / -x-z / -y-z edge)."""
+    g = np.load(os.path.join(golden_dir, "spc_builders_ref.npz"))
+    for level, rounds in g["cases"]:
+        assert np.array_equal(spc.pointcloud_to_octree(g["cloud"], int(level), dilate=int(rounds)), g[f"octree_l{level}_d{rounds}"])
+    tree, mean = spc.pointcloud_to_octree(g["cloud"], 5, attributes=g["attributes"])
+    assert np.array_equal(tree, g["att_octree_l5"])
+    np.testing.assert_allclose(mean, g["att_mean_l5"], atol=1e-6, rtol=0)
+    for i, cell in enumerate(g["cells"]):
+        assert np.array_equal(spc.dilate_points(cell[None], 5), g[f"dilated_{i}"])
+    assert g["dilated_0"].shape[0] == 23 and g["cells"][0].tolist() not in g["dilated_0"].tolist()
+
+
+def test_ray_generation_matches_reference_function_bodies(golden_dir):
+    """oracle.raygen against outputs of the reference's generate_pinhole_rays / generate_ortho_rays function bodies
+    (ops/raygen/raygen.py:40-119): 40 x 24 image, off-centre principal point."""
+    from oracle import raygen
+    g = np.load(os.path.join(golden_dir, "raygen_ref.npz"))
+    W, H = int(g["width"]), int(g["height"])
+    py, px = raygen.centered_pixel_coords(W, H)
+    assert np.array_equal(py, g["pixel_y"]) and np.array_equal(px, g["pixel_x"])
+    o, d = raygen.generate_rays(px, py, False, float(g["x0"]), float(g["y0"]), W, H, float(g["tan_h"]), float(g["tan_v"]),
+                                g["rotation"], g["translation"])
+    np.testing.assert_allclose(o, g["pinhole_origins"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(d, g["pinhole_dirs"], atol=2e-6, rtol=0)
+    sx = np.float32(float(g["fov_distance"])) * np.float32(W / H)
+    o, d = raygen.generate_rays(px, py, True, 0.0, 0.0, W, H, sx, float(g["fov_distance"]), g["rotation"], g["translation"])
+    np.testing.assert_allclose(o, g["ortho_origins"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(d, g["ortho_dirs"], atol=2e-6, rtol=0)
+
+
 @pytest.mark.skipif(not ref_lib.available(), reason="oracle/_ref not built (needs /root/reference)")
 def test_oracle_vs_live_reference_kernels_nerf_hash_shape():
     """nerf_hash.yaml shape (L=16, T=2^19, res 16..512) on fresh random inputs, forward bit-exact."""
