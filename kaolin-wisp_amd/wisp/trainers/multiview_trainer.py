@@ -11,6 +11,7 @@ weight decay, names containing 'grid' get lr * grid_lr_weight; MultiStepLR).  MI
 """
 import math
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -206,6 +207,26 @@ def _decoder_tensors(nef):
     return dt(nef)
 
 
+class _StaleMasterGuard:
+    """state_dict pre-hook of the sharded optimizer.  Holds the trainer weakly and pickles to an inert object, so that a pipeline
+    saved whole (`torch.save(pipeline)`, the reference's 'full' format) does not drag the trainer along."""
+
+    def __init__(self, trainer):
+        self._trainer = weakref.ref(trainer)
+
+    def __call__(self, module, prefix, keep_vars):
+        trainer = self._trainer()
+        if trainer is not None and trainer._master_stale:
+            raise RuntimeError("sharded optimizer: the fp32 table rows owned by other ranks are stale on this rank (only their bf16 "
+                               "shadow travelled); call sync_master() on EVERY rank before state_dict() / saving a checkpoint")
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self._trainer = lambda: None
+
+
 class MultiviewTrainStep:
     def __init__(self, pipeline, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, betas=(0.9, 0.999),
                  rgb_loss_type='huber', prune_every=100, target_sample_size=2 ** 18, max_rays=2 ** 18,
@@ -255,6 +276,10 @@ class MultiviewTrainStep:
         self._master_stale = False
         self._stage = {}
         self._plan = None
+        if self.sharded_optimizer:
+            # a state_dict taken while other ranks' slices of the fp32 table are stale would be a silently wrong checkpoint; the
+            # hook cannot run the collective itself (a checkpoint is usually written by one rank), so it refuses instead
+            pipeline.nef.register_state_dict_pre_hook(_StaleMasterGuard(self))
         # (single GPU: putting the optimizer launch on the side stream too, under the next step's raymarch, was measured
         # neutral - 1.270 vs 1.284 ms/step - so one rank keeps everything on one stream)
         # specialised issue order for the flagship pipeline shape (WISP_DIRECT_STEP=0 keeps the modular path)

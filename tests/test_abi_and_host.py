@@ -453,3 +453,35 @@ def test_octree_from_mesh_covers_the_surface(tmp_path):
     assert blas.extent['vertices'].shape == (8, 3) and blas.max_level == 4
     with pytest.raises(NotImplementedError):
         OctreeAS.from_mesh(str(obj), level=3, sample_tex=True)
+
+
+def test_sharded_optimizer_state_dict_guard_is_weak_and_pickles_inert():
+    """The state_dict pre-hook of the opt-in sharded optimizer refuses a checkpoint while other ranks' table slices are stale, does
+    not keep the trainer alive, and a module carrying it still pickles (torch.save(pipeline), the reference's 'full' format) - the
+    copy that comes back carries an inert guard."""
+    import gc
+    import io
+    import pickle
+    import weakref
+    from wisp.trainers.multiview_trainer import _StaleMasterGuard
+
+    class Trainer:
+        _master_stale = True
+
+    t = Trainer()
+    mod = torch.nn.Linear(2, 2)
+    mod.register_state_dict_pre_hook(_StaleMasterGuard(t))
+    with pytest.raises(RuntimeError, match="sync_master"):
+        mod.state_dict()
+    t._master_stale = False
+    assert len(mod.state_dict()) == 2
+    t._master_stale = True
+    buf = io.BytesIO()
+    torch.save(mod, buf)                                           # pickles the hook table with the module
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert len(back.state_dict()) == 2 and b"Trainer" not in pickle.dumps(_StaleMasterGuard(t))
+    alive = weakref.ref(t)
+    del t
+    gc.collect()
+    assert alive() is None and len(mod.state_dict()) == 2         # trainer gone: the guard steps aside

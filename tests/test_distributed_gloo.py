@@ -241,7 +241,13 @@ def _sharded_worker(rank, world, port, out):
                 other = slice(ga, plan["lo"]) if rank == world - 1 else slice(plan["hi"], min(ga + plan["npad"], gb))
                 ok = ok and tr._master_stale and not torch.equal(tr.flat.data[other], ref.flat.data[other])   # really stale ...
                 ok = ok and torch.equal(tr.flat.shadow, ref.flat.shadow)                                       # ... shadow is not
+                try:                                                     # a checkpoint taken now would be silently wrong: refused
+                    tr.pipeline.state_dict()
+                    ok = False
+                except RuntimeError as e:
+                    ok = ok and "sync_master()" in str(e)
                 tr.sync_master()
+                ok = ok and len(tr.pipeline.state_dict()) > 0
             ok = ok and not tr._master_stale and torch.equal(tr.flat.data, ref.flat.data)      # bit for bit the all-reduce run
             ok = ok and float(tr.flat.grad.abs().max()) == 0.0                                 # every gradient consumed
             own = torch.zeros_like(tr.flat.exp_avg_sq, dtype=torch.bool)
