@@ -1614,3 +1614,46 @@ def test_oracle_triplanar_grid_equals_the_reference_methods(multiscale):
     ref_planes = otri.volume_forward(*volumes[0], x[:7])
     assert one.shape == (7, 1, 3, fdim) and torch.allclose(one[:, 0], ref_planes, atol=1e-6)
     assert not torch.allclose(ref_planes[:, 0], ref_planes[:, 1], atol=1e-3)              # the three planes really differ
+
+
+def test_octree_as_construction_and_bookkeeping_equal_the_reference_class(monkeypatch):
+    """The reference's OWN OctreeAS (accelstructs/octree_as.py:37-144,431-441) executed where it lies - over this package's
+    wisp.ops.spc / base_as and the oracle's restatement of kaolin's unbatched_points_to_octree - against wisp.accelstructs.OctreeAS:
+    __init__, make_dense, from_quantized_points (unsorted, with duplicates), from_pointcloud, and AxisAlignedBBoxAS; octree bytes,
+    point hierarchy, pyramid, prefix sums, max_level, occupancy(), capacity(), name(), the empty `extent`."""
+    from oracle import spc as ospc
+    import wisp.accelstructs as mine
+    stubs = _kaolin_stub()
+    stubs["kaolin.ops.spc"].unbatched_points_to_octree = lambda p, level, sorted=False: torch.from_numpy(
+        ospc.points_to_octree(p.cpu().numpy(), level))
+    stubs["kaolin"].render = types.ModuleType("kaolin.render")
+    stubs["kaolin.render"] = stubs["kaolin"].render
+    stubs["kaolin.render.spc"] = stubs["kaolin"].render.spc = types.ModuleType("kaolin.render.spc")
+    for name, mod in stubs.items():
+        monkeypatch.setitem(sys.modules, name, mod)
+    ref = _exec_reference("accelstructs/octree_as.py")
+    Ref, Mine = ref["OctreeAS"], mine.OctreeAS
+    rng = np.random.default_rng(71)
+    q = torch.from_numpy(rng.integers(0, 32, size=(400, 3)).astype(np.int16))
+    q[:40] = q[40:80]
+    cloud = torch.from_numpy(rng.uniform(-1, 1, (500, 3)).astype(np.float32))
+    builds = {
+        "make_dense(2)": lambda c: c.make_dense(2),
+        "from_quantized_points": lambda c: c.from_quantized_points(q, 5),
+        "from_pointcloud": lambda c: c.from_pointcloud(cloud, 4),
+        "__init__": lambda c: c(torch.from_numpy(ospc.points_to_octree(q.numpy(), 5))),
+    }
+    for what, build in builds.items():
+        a, b = build(Ref), build(Mine)
+        assert isinstance(a, Ref) and isinstance(b, Mine), what
+        for field in ("octree", "points", "pyramid", "prefix"):
+            x, y = getattr(a, field).cpu(), getattr(b, field).cpu()
+            assert x.shape == y.shape and torch.equal(x.long(), y.long()), (what, field)
+        assert a.max_level == b.max_level and a.occupancy() == b.occupancy() and a.capacity() == b.capacity(), what
+        assert a.name() == b.name() == "Octree" and a.extent == b.extent == {}
+    dense = builds["make_dense(2)"](Mine)
+    assert dense.occupancy() == [1, 8] and dense.capacity() == [1, 8] and dense.max_level == 2
+    exec(compile(open(os.path.join(REF, "accelstructs/aabb_as.py")).read(), "aabb_as.py", "exec"),
+         box := {"__name__": "reference_aabb"})                        # its `from wisp.accelstructs.octree_as import OctreeAS` = this package's
+    a, b = box["AxisAlignedBBoxAS"](), mine.AxisAlignedBBoxAS()
+    assert a.name() == b.name() == "AABB" and torch.equal(a.octree.cpu(), b.octree.cpu()) and a.max_level == b.max_level == 1
