@@ -1657,3 +1657,94 @@ def test_octree_as_construction_and_bookkeeping_equal_the_reference_class(monkey
          box := {"__name__": "reference_aabb"})                        # its `from wisp.accelstructs.octree_as import OctreeAS` = this package's
     a, b = box["AxisAlignedBBoxAS"](), mine.AxisAlignedBBoxAS()
     assert a.name() == b.name() == "AABB" and torch.equal(a.octree.cpu(), b.octree.cpu()) and a.max_level == b.max_level == 1
+
+
+def test_oracle_render_equals_the_whole_reference_stack_on_the_host(monkeypatch):
+    """End to end on the CPU with the reference's OWN classes wired together as an application would: OctreeAS
+    (accelstructs/octree_as.py) -> HashGrid.from_geometric (models/grids/hash_grid.py) over the reference's ops/grid.py and its hash-grid
+    kernel bodies built for the host (oracle/_ref) -> NeuralRadianceField (models/nefs/nerf.py) -> PackedRFTracer
+    (tracers/packed_rf_tracer.py), every module executed where it lies; supplied from outside: the Kaolin leaves (the oracle's
+    restatements) and the jitter draw.  Against oracle.nerf.trace with the same parameters - the tracer every GPU end-to-end test is
+    compared with.  The pieces are pinned one by one elsewhere; this pins the glue: BaseTracer's argument plumbing, the field's channel
+    dispatch, the level the grid marches at, the default lod_idx, table layout and state-dict names."""
+    from oracle import nerf as onerf, render as orender, spc as ospc, ref_lib
+    if not ref_lib.available():
+        pytest.skip("oracle/_ref not built")
+    import wisp
+    import wisp.ops
+    from wisp.core import Rays
+    t = torch.from_numpy
+
+    # ---- Kaolin leaves = the oracle's restatements
+    stubs = _kaolin_stub()
+    kspc = stubs["kaolin.ops.spc"]
+    kspc.unbatched_points_to_octree = lambda p, level, sorted=False: t(ospc.points_to_octree(p.cpu().numpy(), level))
+    kspc.unbatched_query = lambda octree, prefix, coords, level, with_parents=False: t(
+        ospc.query(octree.numpy(), prefix.numpy(), coords.detach().numpy(), level, with_parents=with_parents))
+    krender = types.ModuleType("kaolin.render")
+    krs = types.ModuleType("kaolin.render.spc")
+    krs.mark_pack_boundaries = lambda ridx: t(ospc.mark_pack_boundaries(ridx.numpy()))
+    krs.exponential_integration = orender.exponential_integration
+    krs.sum_reduce = orender.sum_reduce
+    krender.spc = stubs["kaolin"].render = krs
+    stubs["kaolin"].render = krender
+    stubs.update({"kaolin.render": krender, "kaolin.render.spc": krs})
+
+    # ---- wisp._C = the reference's hash-grid kernel bodies built for the host
+    def fwd(coords, codebook, first_idx, resolution, bitwidth):
+        res = [int(r) for r in resolution.reshape(-1).tolist()]
+        return t(ref_lib.hashgrid_forward(coords.numpy(), codebook.detach().numpy(), first_idx.numpy(), res, int(bitwidth)))
+    native = types.ModuleType("wisp._C")
+    native.ops = types.SimpleNamespace(hashgrid_interpolate_cuda=fwd)
+    stubs["wisp._C"] = native
+    for name, mod in stubs.items():
+        monkeypatch.setitem(sys.modules, name, mod)
+    monkeypatch.setattr(wisp, "_C", native, raising=False)
+    grid_mod = types.ModuleType("wisp.ops.grid")
+    grid_mod.__dict__.update(_exec_reference("ops/grid.py"))                       # `import wisp._C as wisp_C` -> the host build
+    monkeypatch.setitem(sys.modules, "wisp.ops.grid", grid_mod)
+    monkeypatch.setattr(wisp.ops, "grid", grid_mod, raising=False)                 # `import wisp.ops.grid as grid_ops` walks attributes
+
+    blas_mod = _exec_reference("accelstructs/octree_as.py")
+    RefGrid = _exec_reference("models/grids/hash_grid.py")["HashGrid"]
+    RefField = _exec_reference("models/nefs/nerf.py")["NeuralRadianceField"]
+    RefTracer = _exec_reference("tracers/packed_rf_tracer.py")["PackedRFTracer"]
+
+    rng = np.random.default_rng(81)
+    pts = rng.integers(0, 16, size=(500, 3))
+    steps, R, bg = 96, 140, (0.2, 0.5, 0.7)
+    blas = blas_mod["OctreeAS"].from_quantized_points(t(pts.astype(np.int16)), 4)
+    torch.manual_seed(82)
+    grid = RefGrid.from_geometric(blas, feature_dim=2, num_lods=4, multiscale_type='cat', feature_std=0.3, codebook_bitwidth=10,
+                                  min_grid_res=8, max_grid_res=64)
+    nef = RefField(grid, view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1, bias=True)
+    tracer = RefTracer(raymarch_type='ray', num_steps=steps, bg_color=bg)
+    o = rng.normal(size=(R, 3)).astype(np.float32)
+    o = 3.0 * o / np.linalg.norm(o, axis=1, keepdims=True)
+    d = -o + rng.normal(size=o.shape).astype(np.float32) * 0.4
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    jit = rng.uniform(size=(R, steps)).astype(np.float32)
+    blas_mod["torch"] = _TorchWithDraws(t(jit))                                     # OctreeAS._raymarch_ray's torch.rand(R, N)
+    with torch.no_grad():
+        rb = tracer(nef, rays=Rays(t(o), t(d), dist_min=1.0, dist_max=5.0), channels={"rgb", "depth", "alpha", "hit"})
+
+    # ---- the oracle with the very same parameters
+    res = [int(r) for r in grid.resolutions]
+    onef = onerf.OracleNeRF(res, 2, 10, 'cat', 0.3, 64, 1, True, 4)
+    missing = onef.load_state_dict(nef.state_dict(), strict=False)
+    # every learnable tensor has its counterpart under the same name; what the oracle does not keep are the reference's buffers
+    assert not missing.missing_keys and set(missing.unexpected_keys) == {"view_embedder.bands", "grid.codebook.begin_idxes",
+                                                                         "grid.codebook.num_feats"}, missing
+    assert torch.equal(nef.state_dict()["grid.codebook.begin_idxes"].long(), torch.as_tensor(onef.begin_idxes).long())
+    oblas = onerf.OracleBLAS.from_quantized_points(pts, 4)
+    assert np.array_equal(oblas.octree, blas.octree.numpy()) and len(res) == 4 and res[0] == 8 and res[-1] == 64
+    with torch.no_grad():
+        want = onerf.trace(onef, oblas, t(o), t(d), 1.0, 5.0, steps, jit, bg, 'ray', with_depth=True)
+    assert tracer.prev_num_samples == want["raymarch"]["ridx"].shape[0] > 500
+    assert torch.equal(rb.hit, want["hit"]) and 20 < int(rb.hit.sum()) < R
+    # sample depths differ in the last bit (the oracle restates them as the GPU evaluates them, torch's CPU kernels order a few
+    # operations differently: 1e-6, see the raymarch pin above); depth = sum of weight x sample depth carries that relatively
+    for name, rtol in (("rgb", 0.0), ("alpha", 0.0), ("depth", 2e-6)):
+        got, ref = getattr(rb, name), want[name]
+        assert got.shape == ref.shape and torch.allclose(got, ref, atol=2e-6, rtol=rtol), (name, float((got - ref).abs().max()))
+    assert float(rb.rgb.std()) > 0.05 and float(rb.depth.max()) > 1.0
