@@ -1659,14 +1659,10 @@ def test_octree_as_construction_and_bookkeeping_equal_the_reference_class(monkey
     assert a.name() == b.name() == "AABB" and torch.equal(a.octree.cpu(), b.octree.cpu()) and a.max_level == b.max_level == 1
 
 
-def test_oracle_render_equals_the_whole_reference_stack_on_the_host(monkeypatch):
-    """End to end on the CPU with the reference's OWN classes wired together as an application would: OctreeAS
-    (accelstructs/octree_as.py) -> HashGrid.from_geometric (models/grids/hash_grid.py) over the reference's ops/grid.py and its hash-grid
-    kernel bodies built for the host (oracle/_ref) -> NeuralRadianceField (models/nefs/nerf.py) -> PackedRFTracer
-    (tracers/packed_rf_tracer.py), every module executed where it lies; supplied from outside: the Kaolin leaves (the oracle's
-    restatements) and the jitter draw.  Against oracle.nerf.trace with the same parameters - the tracer every GPU end-to-end test is
-    compared with.  The pieces are pinned one by one elsewhere; this pins the glue: BaseTracer's argument plumbing, the field's channel
-    dispatch, the level the grid marches at, the default lod_idx, table layout and state-dict names."""
+def _reference_nerf_stack(monkeypatch):
+    """The reference's own OctreeAS / HashGrid / NeuralRadianceField / PackedRFTracer modules executed where they lie, over the oracle's
+    Kaolin leaves and the reference's hash-grid kernel bodies built for the host (forward and backward).
+    -> (octree_as module namespace, HashGrid, NeuralRadianceField, PackedRFTracer)"""
     from oracle import nerf as onerf, render as orender, spc as ospc, ref_lib
     if not ref_lib.available():
         pytest.skip("oracle/_ref not built")
@@ -1695,7 +1691,13 @@ def test_oracle_render_equals_the_whole_reference_stack_on_the_host(monkeypatch)
         res = [int(r) for r in resolution.reshape(-1).tolist()]
         return t(ref_lib.hashgrid_forward(coords.numpy(), codebook.detach().numpy(), first_idx.numpy(), res, int(bitwidth)))
     native = types.ModuleType("wisp._C")
-    native.ops = types.SimpleNamespace(hashgrid_interpolate_cuda=fwd)
+
+    def bwd(coords, grad_output, codebook, first_idx, resolution, bitwidth, feature_dim, require_grad_coords):
+        res = [int(r) for r in resolution.reshape(-1).tolist()]
+        g = ref_lib.hashgrid_backward(coords.numpy(), grad_output.contiguous().numpy(), codebook.detach().numpy(), first_idx.numpy(), res,
+                                      int(bitwidth))
+        return [torch.empty(0), t(g)]
+    native.ops = types.SimpleNamespace(hashgrid_interpolate_cuda=fwd, hashgrid_interpolate_backward_cuda=bwd)
     stubs["wisp._C"] = native
     for name, mod in stubs.items():
         monkeypatch.setitem(sys.modules, name, mod)
@@ -1709,6 +1711,22 @@ def test_oracle_render_equals_the_whole_reference_stack_on_the_host(monkeypatch)
     RefGrid = _exec_reference("models/grids/hash_grid.py")["HashGrid"]
     RefField = _exec_reference("models/nefs/nerf.py")["NeuralRadianceField"]
     RefTracer = _exec_reference("tracers/packed_rf_tracer.py")["PackedRFTracer"]
+
+    return blas_mod, RefGrid, RefField, RefTracer
+
+
+def test_oracle_render_equals_the_whole_reference_stack_on_the_host(monkeypatch):
+    """End to end on the CPU with the reference's OWN classes wired together as an application would: OctreeAS
+    (accelstructs/octree_as.py) -> HashGrid.from_geometric (models/grids/hash_grid.py) over the reference's ops/grid.py and its hash-grid
+    kernel bodies built for the host (oracle/_ref) -> NeuralRadianceField (models/nefs/nerf.py) -> PackedRFTracer
+    (tracers/packed_rf_tracer.py), every module executed where it lies; supplied from outside: the Kaolin leaves (the oracle's
+    restatements) and the jitter draw.  Against oracle.nerf.trace with the same parameters - the tracer every GPU end-to-end test is
+    compared with.  The pieces are pinned one by one elsewhere; this pins the glue: BaseTracer's argument plumbing, the field's channel
+    dispatch, the level the grid marches at, the default lod_idx, table layout and state-dict names."""
+    from oracle import nerf as onerf
+    from wisp.core import Rays
+    t = torch.from_numpy
+    blas_mod, RefGrid, RefField, RefTracer = _reference_nerf_stack(monkeypatch)
 
     rng = np.random.default_rng(81)
     pts = rng.integers(0, 16, size=(500, 3))
@@ -1748,3 +1766,72 @@ def test_oracle_render_equals_the_whole_reference_stack_on_the_host(monkeypatch)
         got, ref = getattr(rb, name), want[name]
         assert got.shape == ref.shape and torch.allclose(got, ref, atol=2e-6, rtol=rtol), (name, float((got - ref).abs().max()))
     assert float(rb.rgb.std()) > 0.05 and float(rb.depth.max()) > 1.0
+
+
+def test_oracle_training_steps_equal_the_whole_reference_stack_on_the_host(monkeypatch):
+    """Three optimisation steps through the reference's own classes on the CPU: PackedRFTracer -> NeuralRadianceField -> HashGrid, the
+    gradient going back through the reference's HashGridInterpolate autograd function (ops/grid.py:77-126) into its backward kernel body
+    built for the host, its decoders and the compositing; huber loss over the rays; AdamW with the reference's parameter groups - next
+    to oracle.nerf.train_step from the same initial state, batches and jitter: the same loss at every step, the same gradient for every
+    parameter at the first step, the same parameters after the third."""
+    from oracle import nerf as onerf
+    from wisp.core import Rays
+    t = torch.from_numpy
+    blas_mod, RefGrid, RefField, RefTracer = _reference_nerf_stack(monkeypatch)
+    rng = np.random.default_rng(91)
+    pts = rng.integers(0, 16, size=(600, 3))
+    steps, R, bg = 64, 96, (0.0, 0.0, 0.0)
+    blas = blas_mod["OctreeAS"].from_quantized_points(t(pts.astype(np.int16)), 4)
+    torch.manual_seed(92)
+    grid = RefGrid.from_geometric(blas, feature_dim=2, num_lods=4, multiscale_type='cat', feature_std=0.3, codebook_bitwidth=10,
+                                  min_grid_res=8, max_grid_res=64)
+    nef = RefField(grid, view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1, bias=True)
+    tracer = RefTracer(raymarch_type='ray', num_steps=steps, bg_color=bg)
+    onef = onerf.OracleNeRF([int(r) for r in grid.resolutions], 2, 10, 'cat', 0.3, 64, 1, True, 4)
+    onef.load_state_dict(nef.state_dict(), strict=False)
+    oblas = onerf.OracleBLAS.from_quantized_points(pts, 4)
+    opt_ref = onerf.make_optimizer(nef, lr=1e-2, grid_lr_weight=10.0)             # groups by the 'decoder' / 'grid' names: same rule for both
+    opt_ora = onerf.make_optimizer(onef, lr=1e-2, grid_lr_weight=10.0)
+    names = [n for n, p in nef.named_parameters() if p.requires_grad]
+    assert names == [n for n, p in onef.named_parameters() if p.requires_grad] and "grid.codebook.feats" in names
+    before = {n: p.detach().clone() for n, p in nef.named_parameters()}
+    for step in range(3):
+        o = rng.normal(size=(R, 3)).astype(np.float32)
+        o = 3.0 * o / np.linalg.norm(o, axis=1, keepdims=True)
+        d = -o + rng.normal(size=o.shape).astype(np.float32) * 0.4
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        gts = t(rng.uniform(0, 1, (R, 3)).astype(np.float32))
+        jit = rng.uniform(size=(R, steps)).astype(np.float32)
+        blas_mod["torch"] = _TorchWithDraws(t(jit))
+        opt_ref.zero_grad()
+        rb = tracer(nef, rays=Rays(t(o), t(d), dist_min=1.0, dist_max=5.0), channels=["rgb"])
+        loss = torch.nn.functional.smooth_l1_loss(rb.rgb, gts, reduction='none').mean()   # multiview_trainer.py:149-154 (pinned elsewhere)
+        loss.backward()
+        if step == 0:
+            grads_ref = {n: p.grad.detach().clone() for n, p in nef.named_parameters() if p.grad is not None}
+        opt_ref.step()
+        if step == 0:                                                              # the oracle's gradient, before its own step changes anything
+            probe = onerf.OracleNeRF([int(r) for r in grid.resolutions], 2, 10, 'cat', 0.3, 64, 1, True, 4)
+            probe.load_state_dict({k: v for k, v in before.items()}, strict=False)
+            res = onerf.trace(probe, oblas, t(o), t(d), 1.0, 5.0, steps, jit, bg, 'ray', with_depth=False)
+            torch.nn.functional.smooth_l1_loss(res["rgb"], gts, reduction='none').mean().backward()
+            for n, p in probe.named_parameters():
+                if p.requires_grad:
+                    assert n in grads_ref and float(grads_ref[n].abs().max()) > 0, n
+                    scale = float(grads_ref[n].abs().max())
+                    assert torch.allclose(p.grad, grads_ref[n], atol=3e-5 * scale + 1e-9, rtol=0), (n, float((p.grad - grads_ref[n]).abs().max()), scale)
+        want_loss, want_samples = onerf.train_step(onef, oblas, opt_ora, t(o), t(d), gts, 1.0, 5.0, steps, jit, bg, 'ray', 'huber')
+        assert tracer.prev_num_samples == want_samples > 300
+        assert abs(float(loss) - want_loss) < 2e-6, (step, float(loss), want_loss)
+    moved = 0.0
+    theirs = dict(onef.named_parameters())
+    for n, p in nef.named_parameters():
+        if not p.requires_grad:                                                    # the reference's frozen `view_embedder.bands`
+            continue
+        diff, travelled = (p - theirs[n]).abs(), (p - before[n]).abs()
+        # Adam divides by sqrt(v): where a gradient is at add-order-noise level the normalised step amplifies that noise, so a few
+        # entries of the table differ by more than the bulk - never by more than a fraction of a percent of their own movement
+        assert float((diff > 2e-5).float().mean()) < 1e-3 and float(diff.max()) < 1e-4, (n, float(diff.max()))
+        assert float((diff / travelled.clamp_min(1e-9)).max()) < 5e-3 or float(diff.max()) < 2e-6, n
+        moved = max(moved, float(travelled.max()))
+    assert moved > 5e-3                                                            # three real AdamW steps at lr 1e-2
