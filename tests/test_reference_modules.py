@@ -1835,3 +1835,93 @@ def test_oracle_training_steps_equal_the_whole_reference_stack_on_the_host(monke
         assert float((diff / travelled.clamp_min(1e-9)).max()) < 5e-3 or float(diff.max()) < 2e-6, n
         moved = max(moved, float(travelled.max()))
     assert moved > 5e-3                                                            # three real AdamW steps at lr 1e-2
+
+
+def test_oracle_sdf_render_equals_the_whole_reference_stack_on_the_host(monkeypatch):
+    """The C3 path end to end on the CPU with the reference's OWN classes: OctreeAS -> OctreeGrid (models/grids/octree_grid.py) ->
+    NeuralSDF (models/nefs/neural_sdf.py) -> PackedSDFTracer (tracers/packed_sdf_tracer.py) with the reference's find_depth_bound
+    wrapper over its kernel body built for the host, every module executed where it lies, only the Kaolin leaves supplied - against
+    oracle.sdf.sphere_trace over the oracle's octree-grid lookup and decoder with the same parameters.  The decoder is set to an
+    octahedron-like distance (0.6 |x|_1 - 0.5 from ReLU pairs) plus small grid-feature terms, the occupancy is a shell of level-5 cells
+    around that surface, so rays hit, graze and miss."""
+    from oracle import nerf as onerf, octree_grid as og, sdf as osdf, spc as ospc, ref_lib
+    if not ref_lib.available():
+        pytest.skip("oracle/_ref not built")
+    import wisp.ops.geometric as geometric
+    from wisp.core import Rays
+    t = torch.from_numpy
+    stubs = _kaolin_stub()
+    kspc = stubs["kaolin.ops.spc"]
+    kspc.unbatched_points_to_octree = lambda p, level, sorted=False: t(ospc.points_to_octree(p.cpu().numpy(), level))
+    kspc.unbatched_query = lambda octree, prefix, coords, level, with_parents=False: t(
+        ospc.query(octree.numpy(), prefix.numpy(), coords.detach().numpy(), level, with_parents=with_parents))
+    kspc.unbatched_interpolate_trilinear = lambda c, pidx, pts, tr, f, lod: og.interpolate_trilinear(c, pidx.long(), pts, tr, f.float(), lod,
+                                                                                                      half_round=True)
+    krender, krs = types.ModuleType("kaolin.render"), types.ModuleType("kaolin.render.spc")
+    krs.mark_pack_boundaries = lambda ridx: t(ospc.mark_pack_boundaries(ridx.numpy()))
+
+    def raytrace(octree, points, pyramid, prefix, origins, dirs, level, return_depth=True, with_exit=False):
+        ridx, pidx, depth = ospc.raytrace(octree.numpy(), points.numpy(), pyramid.numpy(), prefix.numpy(), origins.numpy(), dirs.numpy(),
+                                          level, with_exit=with_exit)
+        return t(ridx), t(pidx), t(depth.copy())
+    krs.unbatched_raytrace = raytrace
+    krender.spc = krs
+    stubs["kaolin"].render = krender
+    stubs.update({"kaolin.render": krender, "kaolin.render.spc": krs})
+    for name, mod in stubs.items():
+        monkeypatch.setitem(sys.modules, name, mod)
+    c_ext = types.SimpleNamespace(render=types.SimpleNamespace(find_depth_bound_cuda=lambda q, cur, dep: t(
+        ref_lib.find_depth_bound(q.numpy(), cur.numpy(), dep.numpy()))))
+    monkeypatch.setattr(geometric, "find_depth_bound",
+                        _reference_function("ops/geometric.py", "find_depth_bound", dict(torch=torch, _C=c_ext)))
+    RefAS = _exec_reference("accelstructs/octree_as.py")["OctreeAS"]
+    RefGrid = _exec_reference("models/grids/octree_grid.py")["OctreeGrid"]
+    RefField = _exec_reference("models/nefs/neural_sdf.py")["NeuralSDF"]
+    RefTracer = _exec_reference("tracers/packed_sdf_tracer.py")["PackedSDFTracer"]
+
+    level, F = 5, 4
+    cells = np.stack(np.meshgrid(*[np.arange(32)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    centre = (cells + 0.5) / 16.0 - 1.0
+    shell = cells[np.abs(0.6 * np.abs(centre).sum(1) - 0.5) < 0.08]
+    blas = RefAS.from_quantized_points(t(shell.astype(np.int16)), level)
+    torch.manual_seed(95)
+    grid = RefGrid(blas, feature_dim=F, num_lods=3, interpolation_type='linear', multiscale_type='sum', feature_std=0.05)
+    nef = RefField(grid, pos_embedder='none', position_input=True, hidden_dim=32, num_layers=1)
+    assert grid.active_lods == [3, 4, 5] and nef.decoder.layers[0].weight.shape == (32, 3 + F)
+    with torch.no_grad():                                            # hidden 0..5 = relu(+-x_i): 0.6 |x|_1 - 0.5; the rest: small feature terms
+        w1, b1, w2, b2 = nef.decoder.layers[0].weight, nef.decoder.layers[0].bias, nef.decoder.lout.weight, nef.decoder.lout.bias
+        w1[:6].zero_(); b1.zero_(); w1[6:, :3].zero_()
+        for i in range(3):
+            w1[2 * i, i], w1[2 * i + 1, i] = 1.0, -1.0
+        w2[0, :6] = 0.6
+        w2[0, 6:] *= 0.05
+        b2.fill_(-0.5)
+    tracer = RefTracer(num_steps=40, step_size=0.8, min_dis=3e-4)
+    rng = np.random.default_rng(96)
+    o = rng.normal(size=(150, 3)).astype(np.float32)
+    o = (2.5 * o / np.linalg.norm(o, axis=1, keepdims=True)).astype(np.float32)
+    d = -o + rng.normal(size=o.shape).astype(np.float32) * 0.5
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rb = tracer(nef, rays=Rays(t(o), t(d), dist_min=0.0, dist_max=6.0), channels={"rgb", "normal", "depth", "hit"})
+
+    oblas = onerf.OracleBLAS.from_quantized_points(shell, level)
+    assert np.array_equal(oblas.octree, blas.octree.numpy())
+    pd, pyd = ospc.make_dual(oblas.points, oblas.pyramid)
+    trinkets, _ = ospc.make_trinkets(oblas.points, oblas.pyramid, pd, pyd)
+    assert np.array_equal(np.asarray(trinkets), grid.trinkets.numpy())
+    dec = onerf.OracleDecoder(3 + F, 1, 32, 1, True)
+    dec.load_state_dict(nef.decoder.state_dict())
+    feats = [f.detach() for f in grid.features]
+
+    def field(x):
+        with torch.no_grad():
+            f = og.octree_grid_interpolate(oblas, trinkets, feats, x, 2, grid.base_lod, grid.active_lods, 'sum', F, half_round=True)
+            return dec(torch.cat([x, f], -1))
+    want = osdf.sphere_trace(field, oblas, t(o), t(d), 6.0, level, 40, 0.8, 3e-4)
+    hits = int(rb.hit.sum())
+    assert torch.equal(rb.hit, want["hit"]) and 25 < hits < 150, hits
+    for name in ("xyz", "depth", "normal", "rgb", "alpha"):
+        got, ref = getattr(rb, name), want[name]
+        assert got.shape == ref.shape and torch.allclose(got, ref, atol=2e-6, rtol=0), (name, float((got - ref).abs().max()))
+    on_surface = field(rb.xyz[rb.hit]).abs()
+    assert float(on_surface.max()) < 5e-3                             # the hits really sit on the zero level of the field
