@@ -1679,7 +1679,13 @@ def _reference_nerf_stack(monkeypatch):
         ospc.query(octree.numpy(), prefix.numpy(), coords.detach().numpy(), level, with_parents=with_parents))
     krender = types.ModuleType("kaolin.render")
     krs = types.ModuleType("kaolin.render.spc")
-    krs.mark_pack_boundaries = lambda ridx: t(ospc.mark_pack_boundaries(ridx.numpy()))
+    krs.mark_pack_boundaries = krs.mark_first_hit = lambda ridx: t(ospc.mark_pack_boundaries(ridx.numpy()))
+
+    def raytrace(octree, points, pyramid, prefix, origins, dirs, level, return_depth=True, with_exit=False):
+        ridx, pidx, depth = ospc.raytrace(octree.numpy(), points.numpy(), pyramid.numpy(), prefix.numpy(), origins.numpy(), dirs.numpy(),
+                                          level, with_exit=with_exit)
+        return t(ridx), t(pidx), t(depth.copy())
+    krs.unbatched_raytrace = raytrace
     krs.exponential_integration = orender.exponential_integration
     krs.sum_reduce = orender.sum_reduce
     krender.spc = stubs["kaolin"].render = krs
@@ -1715,7 +1721,8 @@ def _reference_nerf_stack(monkeypatch):
     return blas_mod, RefGrid, RefField, RefTracer
 
 
-def test_oracle_render_equals_the_whole_reference_stack_on_the_host(monkeypatch):
+@pytest.mark.parametrize("mode,steps", [("ray", 96), ("voxel", 6)])
+def test_oracle_render_equals_the_whole_reference_stack_on_the_host(monkeypatch, mode, steps):
     """End to end on the CPU with the reference's OWN classes wired together as an application would: OctreeAS
     (accelstructs/octree_as.py) -> HashGrid.from_geometric (models/grids/hash_grid.py) over the reference's ops/grid.py and its hash-grid
     kernel bodies built for the host (oracle/_ref) -> NeuralRadianceField (models/nefs/nerf.py) -> PackedRFTracer
@@ -1730,19 +1737,36 @@ def test_oracle_render_equals_the_whole_reference_stack_on_the_host(monkeypatch)
 
     rng = np.random.default_rng(81)
     pts = rng.integers(0, 16, size=(500, 3))
-    steps, R, bg = 96, 140, (0.2, 0.5, 0.7)
+    R, bg = 140, (0.2, 0.5, 0.7)
     blas = blas_mod["OctreeAS"].from_quantized_points(t(pts.astype(np.int16)), 4)
     torch.manual_seed(82)
     grid = RefGrid.from_geometric(blas, feature_dim=2, num_lods=4, multiscale_type='cat', feature_std=0.3, codebook_bitwidth=10,
                                   min_grid_res=8, max_grid_res=64)
     nef = RefField(grid, view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1, bias=True)
-    tracer = RefTracer(raymarch_type='ray', num_steps=steps, bg_color=bg)
+    tracer = RefTracer(raymarch_type=mode, num_steps=steps, bg_color=bg)
     o = rng.normal(size=(R, 3)).astype(np.float32)
     o = 3.0 * o / np.linalg.norm(o, axis=1, keepdims=True)
     d = -o + rng.normal(size=o.shape).astype(np.float32) * 0.4
     d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
-    jit = rng.uniform(size=(R, steps)).astype(np.float32)
-    blas_mod["torch"] = _TorchWithDraws(t(jit))                                     # OctreeAS._raymarch_ray's torch.rand(R, N)
+    oblas = onerf.OracleBLAS.from_quantized_points(pts, 4)
+    if mode == "ray":
+        jit = rng.uniform(size=(R, steps)).astype(np.float32)
+        blas_mod["torch"] = _TorchWithDraws(t(jit))                                 # OctreeAS._raymarch_ray's torch.rand(R, N)
+    else:                                                                           # 'voxel': N jittered samples in every intersected cell
+        from oracle import spc as ospc
+        import wisp.ops.spc as package_spc
+        nuggets = ospc.raytrace(oblas.octree, oblas.points, oblas.pyramid, oblas.exsum, o, d, 4, True)[0].shape[0]
+        jit = rng.uniform(size=(nuggets, steps)).astype(np.float32)
+        sampling = _exec_reference("ops/spc/sampling.py")                           # the reference's own helpers, their rand_like injected
+        sampling["torch"] = _TorchWithDraws(t(jit))
+
+        class SpcOps:
+            sample_from_depth_intervals = staticmethod(sampling["sample_from_depth_intervals"])
+            expand_pack_boundary = staticmethod(sampling["expand_pack_boundary"])
+
+            def __getattr__(self, name):
+                return getattr(package_spc, name)
+        blas_mod["wisp_spc_ops"] = SpcOps()
     with torch.no_grad():
         rb = tracer(nef, rays=Rays(t(o), t(d), dist_min=1.0, dist_max=5.0), channels={"rgb", "depth", "alpha", "hit"})
 
@@ -1754,10 +1778,9 @@ def test_oracle_render_equals_the_whole_reference_stack_on_the_host(monkeypatch)
     assert not missing.missing_keys and set(missing.unexpected_keys) == {"view_embedder.bands", "grid.codebook.begin_idxes",
                                                                          "grid.codebook.num_feats"}, missing
     assert torch.equal(nef.state_dict()["grid.codebook.begin_idxes"].long(), torch.as_tensor(onef.begin_idxes).long())
-    oblas = onerf.OracleBLAS.from_quantized_points(pts, 4)
     assert np.array_equal(oblas.octree, blas.octree.numpy()) and len(res) == 4 and res[0] == 8 and res[-1] == 64
     with torch.no_grad():
-        want = onerf.trace(onef, oblas, t(o), t(d), 1.0, 5.0, steps, jit, bg, 'ray', with_depth=True)
+        want = onerf.trace(onef, oblas, t(o), t(d), 1.0, 5.0, steps, jit, bg, mode, with_depth=True)
     assert tracer.prev_num_samples == want["raymarch"]["ridx"].shape[0] > 500
     assert torch.equal(rb.hit, want["hit"]) and 20 < int(rb.hit.sum()) < R
     # sample depths differ in the last bit (the oracle restates them as the GPU evaluates them, torch's CPU kernels order a few
