@@ -1317,6 +1317,14 @@ def test_image_field_config_c1_fits_and_matches_oracle_2d():
     want = ohash.grid_interpolate(coords.cpu(), 15, 'cat', 2, grid.resolutions, 14, grid.codebook.feats.detach().cpu(),
                                   grid.codebook.begin_idxes.cpu())
     np.testing.assert_allclose(feats.detach().cpu().numpy(), want.numpy(), atol=1e-7)
+    # the whole field against the oracle composition (which the CPU suite pins to the reference's own ImageNeuralField over its own
+    # HashGrid and 2-D kernel bodies): sigmoid(decoder(cat([grid features, 3-octave embedding of the pixel coordinate])))
+    dec = onerf.OracleDecoder(46, 3, 64, 1, True)
+    dec.load_state_dict({k: v.detach().cpu() for k, v in nef.decoder.state_dict().items()})
+    with torch.no_grad():
+        want_rgb = torch.sigmoid(dec(torch.cat([want, onerf.positional_embed(coords.cpu(), 3, include_input=True)], -1)))
+        got_rgb = nef.rgb(coords)
+    np.testing.assert_allclose(got_rgb.cpu().numpy(), want_rgb.numpy(), atol=3e-6)
     opt = torch.optim.Adam([{"params": grid.parameters(), "lr": 0.05}, {"params": nef.decoder.parameters(), "lr": 1e-3}], eps=1e-15)
     first = None
     for it in range(150):

@@ -1948,3 +1948,55 @@ def test_oracle_sdf_render_equals_the_whole_reference_stack_on_the_host(monkeypa
         assert got.shape == ref.shape and torch.allclose(got, ref, atol=2e-6, rtol=0), (name, float((got - ref).abs().max()))
     on_surface = field(rb.xyz[rb.hit]).abs()
     assert float(on_surface.max()) < 5e-3                             # the hits really sit on the zero level of the field
+
+
+def test_oracle_image_fit_equals_the_whole_reference_stack_on_the_host(monkeypatch):
+    """C1 (app/image, BASELINE configs[0]: the reference's own CPU-runnable case) with the reference's OWN classes on the CPU:
+    HashGrid.from_geometric(blas=None) over its ops/grid.py and its 2-D (bilinear) hash-grid kernel bodies built for the host ->
+    ImageNeuralField (models/nefs/image_nef.py), executed where they lie - against the oracle composition the GPU C1 test uses,
+    sigmoid(decoder(cat([2-D grid features, 3-octave embedding of the pixel coordinate]))): the forward over a 48 x 48 image and five Adam
+    steps of the fit (loss at every step, parameters afterwards)."""
+    from oracle import hashgrid as ohash, nerf as onerf
+    t = torch.from_numpy
+    _, RefGrid, _, _ = _reference_nerf_stack(monkeypatch)
+    RefImage = _exec_reference("models/nefs/image_nef.py")["ImageNeuralField"]
+    torch.manual_seed(101)
+    grid = RefGrid.from_geometric(None, feature_dim=2, num_lods=8, multiscale_type='cat', feature_std=0.05, codebook_bitwidth=12,
+                                  min_grid_res=8, max_grid_res=64)
+    nef = RefImage(grid, hidden_dim=32)
+    res = [int(r) for r in grid.resolutions]
+    assert nef.input_dim == 2 * 8 + 14 and grid.codebook.feats.shape[0] == sum(min(2 ** 12, r ** 3) for r in res)   # table sized for 3-D
+    H = 48
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, H), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(-1, 2)
+    img = torch.stack([0.5 + 0.5 * torch.sin(6 * xs), 0.5 + 0.5 * torch.cos(4 * ys), 0.5 + 0.5 * torch.sin(5 * xs * ys)], -1).reshape(-1, 3)
+
+    table = grid.codebook.feats.detach().clone().requires_grad_(True)
+    dec = onerf.OracleDecoder(nef.input_dim, 3, 32, 1, True)
+    dec.load_state_dict(nef.decoder.state_dict())
+
+    def oracle_rgb(x):
+        feats = ohash.grid_interpolate(x, len(res) - 1, 'cat', 2, res, 12, table, grid.codebook.begin_idxes)
+        return torch.sigmoid(dec(torch.cat([feats, onerf.positional_embed(x, 3, include_input=True)], -1)))
+
+    with torch.no_grad():
+        got, want = nef.rgb(coords), oracle_rgb(coords)          # called directly, as app/image does: rgb() returns a bare tensor, which
+                                                                 # BaseNeuralField.forward cannot index by channel (upstream too)
+    assert got.shape == (H * H, 3) and torch.allclose(got, want, atol=1e-6, rtol=0) and float(got.std()) > 1e-3
+    opt_ref = torch.optim.Adam([{"params": grid.parameters(), "lr": 0.05}, {"params": nef.decoder.parameters(), "lr": 1e-3}], eps=1e-15)
+    opt_ora = torch.optim.Adam([{"params": [table], "lr": 0.05}, {"params": dec.parameters(), "lr": 1e-3}], eps=1e-15)
+    g = torch.Generator().manual_seed(102)
+    losses = []
+    for step in range(5):
+        idx = torch.randint(0, coords.shape[0], (1024,), generator=g)
+        la = ((nef.rgb(coords[idx]) - img[idx]) ** 2).mean()
+        opt_ref.zero_grad(); la.backward(); opt_ref.step()
+        lb = ((oracle_rgb(coords[idx]) - img[idx]) ** 2).mean()
+        opt_ora.zero_grad(); lb.backward(); opt_ora.step()
+        assert abs(float(la) - float(lb)) < 2e-6, (step, float(la), float(lb))
+        losses.append(float(la))
+    assert losses[-1] < losses[0]
+    touched = (grid.codebook.feats.detach() - table.detach()).abs()
+    assert float((touched > 2e-5).float().mean()) < 1e-3 and float(touched.max()) < 2e-3      # Adam on noise-level gradients, see above
+    for p, q in zip(nef.decoder.parameters(), dec.parameters()):
+        assert torch.allclose(p, q, atol=1e-5, rtol=0)
