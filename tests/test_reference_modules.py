@@ -2000,3 +2000,69 @@ def test_oracle_image_fit_equals_the_whole_reference_stack_on_the_host(monkeypat
     assert float((touched > 2e-5).float().mean()) < 1e-3 and float(touched.max()) < 2e-3      # Adam on noise-level gradients, see above
     for p, q in zip(nef.decoder.parameters(), dec.parameters()):
         assert torch.allclose(p, q, atol=1e-5, rtol=0)
+
+
+def test_oracle_sdf_training_equals_the_whole_reference_stack_on_the_host(monkeypatch):
+    """C3 training on the CPU with the reference's OWN classes: NeuralSDF over OctreeGrid over OctreeAS, executed where they lie; the loss
+    of SDFTrainer.step (trainers/sdf_trainer.py:96-102: sum over the loss LODs of sum((pred - gts)^2)) over every level index, the
+    gradient flowing through OctreeGrid.interpolate / _interpolate into each level's feature table; Adam as nglod_octree.yaml sets it -
+    next to the oracle composition decoder(cat([position, oracle octree-grid lookup])) from the same state and batches: the same loss at
+    every step, the same gradient for every table and decoder tensor at the first step, the same parameters after four."""
+    from oracle import nerf as onerf, octree_grid as og, spc as ospc
+    t = torch.from_numpy
+    stubs = _kaolin_stub()
+    kspc = stubs["kaolin.ops.spc"]
+    kspc.unbatched_points_to_octree = lambda p, level, sorted=False: t(ospc.points_to_octree(p.cpu().numpy(), level))
+    kspc.unbatched_query = lambda octree, prefix, coords, level, with_parents=False: t(
+        ospc.query(octree.numpy(), prefix.numpy(), coords.detach().numpy(), level, with_parents=with_parents))
+    kspc.unbatched_interpolate_trilinear = lambda c, pidx, pts, tr, f, lod: og.interpolate_trilinear(c, pidx.long(), pts, tr, f.float(), lod,
+                                                                                                      half_round=True)
+    krender, krs = types.ModuleType("kaolin.render"), types.ModuleType("kaolin.render.spc")
+    krender.spc = krs
+    stubs["kaolin"].render = krender
+    stubs.update({"kaolin.render": krender, "kaolin.render.spc": krs})
+    for name, mod in stubs.items():
+        monkeypatch.setitem(sys.modules, name, mod)
+    RefAS = _exec_reference("accelstructs/octree_as.py")["OctreeAS"]
+    RefGrid = _exec_reference("models/grids/octree_grid.py")["OctreeGrid"]
+    RefField = _exec_reference("models/nefs/neural_sdf.py")["NeuralSDF"]
+    rng = np.random.default_rng(111)
+    level, F, lods = 5, 4, 3
+    cells = rng.integers(0, 32, size=(900, 3))
+    blas = RefAS.from_quantized_points(t(cells.astype(np.int16)), level)
+    torch.manual_seed(112)
+    grid = RefGrid(blas, feature_dim=F, num_lods=lods, interpolation_type='linear', multiscale_type='sum', feature_std=0.1)
+    nef = RefField(grid, pos_embedder='none', position_input=True, hidden_dim=32, num_layers=1)
+    oblas = onerf.OracleBLAS.from_quantized_points(cells, level)
+    pd, pyd = ospc.make_dual(oblas.points, oblas.pyramid)
+    trinkets, _ = ospc.make_trinkets(oblas.points, oblas.pyramid, pd, pyd)
+    tables = [f.detach().clone().requires_grad_(True) for f in grid.features]
+    dec = onerf.OracleDecoder(3 + F, 1, 32, 1, True)
+    dec.load_state_dict(nef.decoder.state_dict())
+
+    def oracle_sdf(x, lod_idx):
+        f = og.octree_grid_interpolate(oblas, trinkets, tables, x, lod_idx, grid.base_lod, grid.active_lods, 'sum', F, half_round=True)
+        return dec(torch.cat([x, f], -1))
+
+    opt_ref = torch.optim.Adam(nef.parameters(), lr=1e-3, eps=1e-15)                # nglod_octree.yaml: adam, lr 1e-3, eps 1e-15
+    opt_ora = torch.optim.Adam(tables + list(dec.parameters()), lr=1e-3, eps=1e-15)
+    leaf = (oblas.level_points().astype(np.float32) + 0.5) / 16.0 - 1.0            # sample inside occupied cells (+ a few outside)
+    for step in range(4):
+        pick = leaf[rng.integers(0, leaf.shape[0], 256)] + rng.uniform(-0.03, 0.03, (256, 3)).astype(np.float32)
+        pts = t(np.concatenate([pick, rng.uniform(-1, 1, (32, 3)).astype(np.float32)]).astype(np.float32))
+        gts = t(rng.normal(size=(288, 1)).astype(np.float32) * 0.1)
+        la = sum(((nef(coords=pts, lod_idx=i, channels="sdf") - gts) ** 2).sum() for i in range(lods))
+        opt_ref.zero_grad(); la.backward()
+        lb = sum(((oracle_sdf(pts, i) - gts) ** 2).sum() for i in range(lods))
+        opt_ora.zero_grad(); lb.backward()
+        assert abs(float(la) - float(lb)) < 2e-5 * max(1.0, abs(float(lb))), (step, float(la), float(lb))
+        if step == 0:
+            for i, (a, b) in enumerate(zip(grid.features, tables)):
+                scale = float(b.grad.abs().max())
+                assert scale > 0 and torch.allclose(a.grad, b.grad, atol=2e-5 * scale, rtol=0), (i, float((a.grad - b.grad).abs().max()), scale)
+            for a, b in zip(nef.decoder.parameters(), dec.parameters()):
+                assert torch.allclose(a.grad, b.grad, atol=2e-5 * float(b.grad.abs().max()) + 1e-9, rtol=0)
+        opt_ref.step(); opt_ora.step()
+    for a, b in zip(list(grid.features) + list(nef.decoder.parameters()), tables + list(dec.parameters())):
+        diff = (a.detach() - b.detach()).abs()
+        assert float((diff > 2e-6).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, float(diff.max())
