@@ -2066,3 +2066,78 @@ def test_oracle_sdf_training_equals_the_whole_reference_stack_on_the_host(monkey
     for a, b in zip(list(grid.features) + list(nef.decoder.parameters()), tables + list(dec.parameters())):
         diff = (a.detach() - b.detach()).abs()
         assert float((diff > 2e-6).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, float(diff.max())
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_oracle_codebook_render_equals_the_whole_reference_stack_on_the_host(monkeypatch, training):
+    """C5 (VQAD) end to end on the CPU with the reference's OWN classes: OctreeAS -> CodebookOctreeGrid (models/grids/codebook_grid.py,
+    with the OctreeGrid it derives from) -> NeuralRadianceField without biases (nerf_codebook.yaml) -> PackedRFTracer, 'voxel' march at
+    the grid's base level, executed where they lie; only the Kaolin leaves and the jitter draw supplied.  Against oracle.nerf.trace over
+    an adapter field built from oracle.octree_grid.codebook_grid_interpolate and the oracle decoders: eval mode (argmax rows of the
+    dictionary) and training mode (straight-through softmax keys)."""
+    from oracle import nerf as onerf, octree_grid as og, spc as ospc
+    from wisp.core import Rays
+    import wisp.ops.spc as package_spc
+    t = torch.from_numpy
+    blas_mod, _, RefField, RefTracer = _reference_nerf_stack(monkeypatch)
+    sys.modules["kaolin.ops.spc"].coords_to_trilinear_coeffs = lambda c, pts, lod: og.trilinear_coeffs(c, pts.long(), lod)
+    _exec_reference("models/grids/octree_grid.py")                                  # registers nothing; the codebook module imports the package's
+    RefGrid = _exec_reference("models/grids/codebook_grid.py")["CodebookOctreeGrid"]
+    rng = np.random.default_rng(121)
+    level, F, lods, K, steps, R, bg = 5, 5, 3, 16, 4, 130, (1.0, 1.0, 1.0)
+    cells = rng.integers(0, 32, size=(2500, 3))
+    blas = blas_mod["OctreeAS"].from_quantized_points(t(cells.astype(np.int16)), level)
+    torch.manual_seed(122)
+    grid = RefGrid(blas, feature_dim=F, num_lods=lods, interpolation_type='linear', multiscale_type='sum', feature_std=0.5,
+                   codebook_bitwidth=4)
+    nef = RefField(grid, view_embedder='positional', view_multires=4, hidden_dim=32, num_layers=1, bias=False)
+    nef.train(training)
+    assert grid.base_lod == 3 and grid.active_lods == [3, 4, 5] and nef.decoder_density.lout.bias is None
+    tracer = RefTracer(raymarch_type='voxel', num_steps=steps, bg_color=bg)
+    o = rng.normal(size=(R, 3)).astype(np.float32)
+    o = 3.0 * o / np.linalg.norm(o, axis=1, keepdims=True)
+    d = -o + rng.normal(size=o.shape).astype(np.float32) * 0.4
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    oblas = onerf.OracleBLAS.from_quantized_points(cells, level)
+    nuggets = ospc.raytrace(oblas.octree, oblas.points, oblas.pyramid, oblas.exsum, o, d, grid.base_lod, True)[0].shape[0]
+    jit = rng.uniform(size=(nuggets, steps)).astype(np.float32)
+    sampling = _exec_reference("ops/spc/sampling.py")
+    sampling["torch"] = _TorchWithDraws(t(jit))
+
+    class SpcOps:
+        sample_from_depth_intervals = staticmethod(sampling["sample_from_depth_intervals"])
+        expand_pack_boundary = staticmethod(sampling["expand_pack_boundary"])
+
+        def __getattr__(self, name):
+            return getattr(package_spc, name)
+    blas_mod["wisp_spc_ops"] = SpcOps()
+    with torch.no_grad():
+        rb = tracer(nef, rays=Rays(t(o), t(d), dist_min=1.0, dist_max=5.0), channels={"rgb", "depth", "alpha", "hit"})
+
+    # ---- oracle: the same arithmetic after the codebook lookup as OracleNeRF.rgba (nerf.py:245-264)
+    pd, pyd = ospc.make_dual(oblas.points, oblas.pyramid)
+    trinkets, _ = ospc.make_trinkets(oblas.points, oblas.pyramid, pd, pyd)
+    dd, dc = onerf.OracleDecoder(F, 16, 32, 1, False), onerf.OracleDecoder(15 + nef.view_embed_dim, 3, 32, 2, False)
+    dd.load_state_dict(nef.decoder_density.state_dict())
+    dc.load_state_dict(nef.decoder_color.state_dict())
+    logits, dictionary = [f.detach() for f in grid.features], [x.detach() for x in grid.dictionary]
+
+    class Field:
+        @staticmethod
+        def rgba(coords, ray_d, lod_idx=None):
+            lod_idx = lods - 1 if lod_idx is None else lod_idx
+            feats = og.codebook_grid_interpolate(oblas, trinkets, logits, dictionary, coords, lod_idx, grid.active_lods, 'sum', F, training)
+            y = dd(feats)
+            rgb = torch.sigmoid(dc(torch.cat([y, onerf.positional_embed(ray_d, 4, include_input=True)], -1)[..., 1:]))
+            return dict(rgb=rgb, density=torch.relu(y[..., 0:1]))
+
+    march_view = types.SimpleNamespace(octree=oblas.octree, points=oblas.points, pyramid=oblas.pyramid, exsum=oblas.exsum,
+                                       max_level=grid.base_lod)                      # OctreeGrid.raymarch marches at base_lod (:221-226)
+    with torch.no_grad():
+        want = onerf.trace(Field, march_view, t(o), t(d), 1.0, 5.0, steps, jit, bg, 'voxel', with_depth=True)
+    assert tracer.prev_num_samples == want["raymarch"]["ridx"].shape[0] == nuggets * steps > 800
+    assert torch.equal(rb.hit, want["hit"]) and 20 < int(rb.hit.sum()) <= R
+    for name, rtol in (("rgb", 0.0), ("alpha", 0.0), ("depth", 2e-6)):
+        got, ref = getattr(rb, name), want[name]
+        assert got.shape == ref.shape and torch.allclose(got, ref, atol=3e-6, rtol=rtol), (name, float((got - ref).abs().max()))
+    assert float(rb.rgb.std()) > 0.02
