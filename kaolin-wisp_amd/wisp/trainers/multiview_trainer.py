@@ -451,6 +451,18 @@ class MultiviewTrainStep:
         else:
             self._gather_grid(f.data[ga:gb], plan, "fp32")
 
+    def _refuse_stale_master_forward(self):
+        """While other ranks' slices of the fp32 table are stale here, the forward may only read the bf16 shadow.  If a torch-side write
+        (load_state_dict, an external optimizer, ...) has outdated the shadow, the ops would fall back to casting the master - stale
+        rows, silently.  Refuse instead."""
+        if not self._master_stale:
+            return
+        for p, _ in self.flat._grid_params:
+            if current_shadow(p, self.flat.shadow.dtype) is None:
+                raise RuntimeError("sharded optimizer: the bf16 shadow of the table was outdated by a write outside the trainer while the "
+                                   "fp32 master of other ranks' slices is stale; call sync_master() on every rank, then "
+                                   "flat.refresh_shadow(), before the next step")
+
     def sync_master(self):
         """Collective (every rank): bring the fp32 master weights of the other ranks' slices up to date after sharded steps
         that only exchanged the bf16 shadow.  Needed before anything reads the table in fp32: prune() (does it itself),
@@ -513,6 +525,7 @@ class MultiviewTrainStep:
         `prefetch` (optional): the Rays object the NEXT call will be given - the direct-issue path then runs their
         occupancy test early (a data-loader style look-ahead; results are the same with or without it)."""
         self.pre_step()
+        self._refuse_stale_master_forward()
         self.total_iterations += 1
         self._last_step_modular = not (self._direct is not None and self.pipeline.nef.training)
         if not self._last_step_modular:

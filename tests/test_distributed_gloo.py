@@ -260,6 +260,21 @@ def _sharded_worker(rank, world, port, out):
             dist.all_gather(gathered, tr.flat.data)
             ok = ok and all(torch.equal(gathered[0], t) for t in gathered)
             verdict[f"{name}/{'bf16' if shadow else 'fp32'}"] = bool(ok)
+    # a write outside the trainer outdates the shadow while the master is stale: the next step must refuse, not train on stale rows
+    pipe = _StubPipeline(64, None)
+    tr = MultiviewTrainStep(pipe, lr=1e-2, prune_every=-1, sharded_optimizer=True)
+    tr.flat.enable_bf16_shadow()
+    tr.step(Rays(O[lo:hi], D[lo:hi]), T[lo:hi])
+    with torch.no_grad():
+        pipe.nef.grid.weight.mul_(1.0)                                   # bumps the parameter's version: shadow no longer current
+    try:
+        tr.step(Rays(O[lo:hi], D[lo:hi]), T[lo:hi])
+        verdict["stale_forward_refused"] = False
+    except RuntimeError as e:
+        verdict["stale_forward_refused"] = "outdated by a write outside the trainer" in str(e)
+    tr.sync_master()                                                     # the documented way out (collective: every rank is here)
+    tr.flat.refresh_shadow()
+    tr.step(Rays(O[lo:hi], D[lo:hi]), T[lo:hi])
     # a step whose gradient reaches rows outside the partition fixed at the first step must not pass silently
     pipe = _StubPipeline(64, 49)
     tr = MultiviewTrainStep(pipe, lr=1e-2, prune_every=-1, sharded_optimizer=True)
@@ -286,5 +301,5 @@ def test_sharded_optimizer_world2_gloo_equals_the_allreduce_run_bit_for_bit():
     out = mgr.dict()
     mp.spawn(_sharded_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     want = {f"{n}/{m}": True for n in ("direct", "tail", "staged") for m in ("fp32", "bf16")}
-    want["loud"] = True
+    want["loud"] = want["stale_forward_refused"] = True
     assert dict(out) == {0: want, 1: want}
