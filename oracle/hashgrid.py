@@ -5,6 +5,10 @@ Restates wisp/csrc/ops/hashgrid_interpolate_cuda.cu:19-339 (kernels), wisp/csrc/
 wisp/ops/grid.py:77-144 (autograd wrapper) and wisp/models/grids/utils.py:13-67 (table layout),
 following the numerics contract in SURVEY.md Appendix B.  torch-CPU tensors; integer index math is
 bit-exact, the float blend is float32 accumulated corner by corner.
+
+Parity: PINNED to the reference's kernel bodies built for the host (oracle/_ref): forward bit-exact (3-D and 2-D), backward within fp32
+add-order noise, corner query bit-exact (tests/golden/hashgrid_ref.npz, hashgrid_query_ref.npz); grid_interpolate equals
+HashGrid.interpolate -> the reference's ops/grid.py -> those kernels bit for bit.
 """
 import numpy as np
 import torch

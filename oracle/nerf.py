@@ -6,6 +6,10 @@ wisp/models/embedders/positional_embedder.py:18-66, wisp/tracers/packed_rf_trace
 semantics of wisp/trainers/multiview_trainer.py:111-180 / wisp/trainers/base_trainer.py:205-246.
 Parameter names equal the reference's state-dict names so weights can be copied between this oracle and
 the HIP-backed classes with load_state_dict.
+
+Parity: PINNED to the reference's own code executed on the host - embedder / decoder modules, the rgba and prune method bodies, the
+trainer bodies, PackedRFTracer.trace, and end to end: render and three AdamW steps through the reference's OctreeAS -> HashGrid (its
+kernel bodies) -> NeuralRadianceField -> PackedRFTracer (tests/test_reference_modules.py) - over the unpinned Kaolin leaves.
 """
 import numpy as np
 import torch

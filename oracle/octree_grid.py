@@ -5,6 +5,10 @@ Restates kaolin.ops.spc.unbatched_interpolate_trilinear / coords_to_trilinear_co
 (wisp/models/grids/octree_grid.py:130-219, wisp/models/grids/codebook_grid.py:103-172; semantics SURVEY.md A.6).
 Kaolin is not available (parity unpinned for this leaf); the half-precision call `feats.half() ... .float()` of
 octree_grid.py:147-149 is modelled as: features rounded to fp16, fp32 accumulation, result rounded to fp16.
+
+Parity: the two leaves (interpolate_trilinear, trilinear_coeffs) are UNPINNED; everything built on them - octree_grid_interpolate,
+codebook_index_features, codebook_grid_interpolate - is PINNED to OctreeGrid.interpolate / _interpolate and CodebookOctreeGrid._index_features /
+_interpolate compiled from the reference files, and to whole-stack renders / training through the reference's classes.
 """
 import torch
 import torch.nn.functional as F

@@ -1,6 +1,8 @@
 """TEST INFRASTRUCTURE ONLY - CPU restatement of wisp/ops/raygen/raygen.py:16-119 in numpy float32, one rounding per op
 in the reference's order.  The camera transform is the part Kaolin owns (Camera.extrinsics.inv_transform_rays; source not
-in /root/reference): it is restated as origin' = R^T (o - t), dir' = R^T d for the view matrix [R | t] (parity unpinned)."""
+in /root/reference): it is restated as origin' = R^T (o - t), dir' = R^T d for the view matrix [R | t] (parity unpinned).
+Parity: everything but that one leaf is PINNED to generate_centered_pixel_coords / generate_pinhole_rays / generate_ortho_rays compiled
+from the reference file (tests/golden/raygen_ref.npz, 2e-6)."""
 import numpy as np
 
 f32 = np.float32

@@ -6,6 +6,10 @@ device and is unseeded; here the jitter tensor is an INPUT so that identical ray
 identical sample sets.  Every float32 operation is rounded separately (no FMA); the HIP kernels are
 compiled with -ffp-contract=off on these expressions so integer outputs (ridx, boundary, S) match
 bit for bit.
+
+Parity: PINNED - the three march modes against OctreeAS._raymarch_ray / _raymarch_voxel / _raymarch_uniform compiled from the
+reference file (same samples, order and pack boundaries; values 1e-6), uniform_sample against the reference kernel body built for the
+host (tests/golden/uniform_ref.npz, bit-exact) - over the unpinned Kaolin leaves of oracle/spc.py.
 """
 import numpy as np
 from . import spc

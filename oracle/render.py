@@ -4,6 +4,9 @@ Restates the Kaolin-Core 0.13 leaves kaolin.render.spc.{cumsum, sum_reduce, expo
 as used at wisp/tracers/packed_rf_tracer.py:143-165 (semantics: SURVEY.md Appendix A.4/A.5), and the
 tracer's compositing block itself.  Pure torch ops, so autograd provides the backward the HIP kernels
 are checked against.  Run in float64 for a tight reference, float32 for the timed CPU baseline.
+
+Parity: the leaves (cumsum, sum_reduce, exponential_integration) are UNPINNED restatements of Kaolin's published semantics, checked
+against a float64 python loop; the compositing block built on them is PINNED to PackedRFTracer.trace compiled from the reference file.
 """
 import torch
 

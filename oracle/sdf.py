@@ -1,6 +1,10 @@
 """Oracle (test infrastructure): sphere tracing of an SDF through octree nuggets, torch-CPU / numpy.
 Restates wisp/tracers/packed_sdf_tracer.py:57-174 and wisp/csrc/render/find_depth_bound_cuda.cu:16-45 (including its
-bounds quirks: pack i is searched up to the CURRENT index of pack i+1, the last pack up to num_packs)."""
+bounds quirks: pack i is searched up to the CURRENT index of pack i+1, the last pack up to num_packs).
+
+Parity: PINNED - find_depth_bound bit-exact against the reference kernel body built for the host (tests/golden/depth_bound_ref_*.npz),
+sphere_trace against PackedSDFTracer.trace compiled from the reference file and against the reference's whole OctreeGrid / NeuralSDF /
+PackedSDFTracer stack on the host - over the unpinned Kaolin leaves (raytrace, pack boundaries)."""
 import numpy as np
 import torch
 import torch.nn.functional as F

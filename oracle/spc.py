@@ -8,6 +8,12 @@ see oracle/__init__.py), at the call sites:
   * wisp/accelstructs/octree_as.py:146-186   (query, raytrace)
 Data model follows SURVEY.md Appendix A.1.  Integer outputs are the bit-exact contract of the HIP
 kernels; float depths are defined by the float32 operation order written in `slab_test`.
+
+Parity: the compositions built on the leaves - pointcloud_to_octree, dilate_points, create_dense_octree, octree_to_spc - are PINNED to the
+reference's function bodies (tests/test_reference_modules.py, tests/golden/spc_builders_ref.npz).  The Kaolin leaves themselves
+(points <-> morton, quantize_points, points_to_octree, scan / generate_points, query, raytrace, make_dual / make_trinkets) are
+UNPINNED: Kaolin's source is not available here; they are checked against hand-computed cases, float64 brute force and structural
+properties (tests/test_oracle_golden.py).
 """
 import numpy as np
 

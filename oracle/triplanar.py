@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE ONLY - TriplanarGrid on the CPU exactly as the reference evaluates it: three
 torch.nn.functional.grid_sample(align_corners=True, padding_mode='reflection') calls per level
 (wisp/models/grids/triplanar_grid.py:205-233), stacked [x | y | z], then cat / sum over levels (:97-124).  torch's CPU
-grid_sample IS the reference's arithmetic for this op, so parity here is pinned to it."""
+grid_sample IS the reference's arithmetic for this op, so parity here is pinned to it.  Also PINNED to TriplanarFeatureVolume.forward and
+TriplanarGrid.interpolate / _interpolate compiled from the reference file (plane addressing and layout; 1e-6)."""
 import torch
 import torch.nn.functional as F
 
