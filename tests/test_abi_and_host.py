@@ -485,3 +485,23 @@ def test_sharded_optimizer_state_dict_guard_is_weak_and_pickles_inert():
     del t
     gc.collect()
     assert alive() is None and len(mod.state_dict()) == 2         # trainer gone: the guard steps aside
+
+
+def test_bench_roofline_work_equals_surveys_algorithmic_figures():
+    """bench.py's `roofline.achieved` is algorithmic work per unit x units per launch / launch time: the per-sample figures must be
+    SURVEY.md 8(d)'s - hash_fwd = 12 + L*2^d*F*b + L*F*b (588 B at L=16, F=2, d=3, 16-bit), hash_bwd = 12 + L*F*b + 2*L*2^d*F*b
+    (1100 B), the decoder 20 096 FLOP forward and 3 x that backward - and the peaks the guide's (8 TB/s HBM; 2.5 PFLOP/s dense bf16)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)                                  # imports only; main() is guarded
+    L, F, corners = 16, 2, 8
+    for amp, b in ((True, 2), (False, 4)):
+        w = bench.work_table(amp, 64)
+        assert w["hashgrid_fwd"] == ("hbm", 12 + L * corners * F * b + L * F * b)
+        assert w["hashgrid_bwd"] == ("hbm", 12 + L * F * b + 2 * L * corners * F * b)
+        assert w["nerf_mlp_fwd"] == ("mfma", 20096) and w["nerf_mlp_bwd"] == ("mfma", 3 * 20096)
+    assert bench.work_table(True, 64)["hashgrid_fwd"][1] == 588 and bench.work_table(True, 64)["hashgrid_bwd"][1] == 1100
+    assert bench.work_table(True, 128)["nerf_mlp_fwd"][1] == 2 * (32 * 128 + 16 * 128 + 42 * 128 + 128 * 128 + 3 * 128)
+    assert bench.HBM_PEAK_GBS == 8000.0
+    assert set(bench.PMC_KERNELS) == set(bench.work_table(True))   # every rooflined kernel has its PMC kernel-name list
