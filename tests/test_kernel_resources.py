@@ -1,0 +1,64 @@
+"""CPU: register / scratch budgets of the hot kernels, read from the built library's code objects (tests/kernel_meta.py).  The measured
+numbers of DESIGN.md section 4 rest on these occupancies; a source or toolchain change that breaks one should fail here, at build time,
+not as an unexplained slowdown on the GPU box."""
+import os
+
+import pytest
+
+import kernel_meta
+
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kaolin-wisp_amd", "csrc", "libwisp_hip.so")
+pytestmark = pytest.mark.skipif(not kernel_meta.available(LIB), reason="libwisp_hip.so not built or llvm-readelf missing")
+
+
+@pytest.fixture(scope="module")
+def kern():
+    meta = kernel_meta.kernels(LIB)
+    names = kernel_meta.demangled(list(meta))
+    return {names[k]: v for k, v in meta.items()}
+
+
+def _pick(kern, *parts):
+    hits = {n: v for n, v in kern.items() if all(p in n for p in parts)}
+    assert hits, parts
+    return hits
+
+
+def test_every_code_object_is_read(kern):
+    assert len(kern) > 200 and all(v["wg"] in (64, 128, 256, 512, 1024) for v in kern.values())
+    assert all(v["agpr"] <= v["vgpr"] <= 512 for v in kern.values())          # vgpr_count is the unified total, accumulators included
+
+
+@pytest.mark.parametrize("dtype", ["__hip_bfloat16", "__half"])
+def test_flagship_step_kernels_keep_their_occupancy(kern, dtype):
+    """nerf_hash.yaml, 16-bit tables (the bench's default): 512-thread workgroups are 2 waves per SIMD each, so <= 128 VGPRs keep two
+    of them resident per CU (4 waves / SIMD) - what the queue emitter's capped grid and the decoder's PIN variant are sized for."""
+    for name, v in _pick(kern, "hashgrid_bwd_emit_q_kernel<" + dtype + ", 3>").items():
+        assert v["scratch"] == 0 and v["vgpr"] <= 96 and v["wg"] == 512, (name, v)           # measured: 87
+    # forward decoder, hidden 64: <TIO, NARROW=false, PIN=true, CODED=false|true>
+    for coded in ("false", "true"):
+        for name, v in _pick(kern, "mlp_fwd_kernel<" + dtype + ", false, true, " + coded + ">").items():
+            assert v["scratch"] == 0 and v["vgpr"] <= 128 and v["wg"] == 512, (name, v)       # measured: 118 / 122
+    for name, v in _pick(kern, "mlp_bwd_kernel<" + dtype + ", false,").items():
+        assert v["scratch"] == 0 and v["vgpr"] <= 256, (name, v)                               # one 512-thread workgroup per CU
+    for name, v in _pick(kern, "hashgrid_fwd_kernel<" + dtype + ", 16, 3>").items():
+        assert v["scratch"] == 0 and v["vgpr"] <= 128 and v["wg"] == 256, (name, v)           # measured: 124
+    for name, v in _pick(kern, "hashgrid_bwd_reduce_kernel<" + dtype + ", 2, AccFix64>").items():
+        assert v["scratch"] == 0 and v["vgpr"] <= 64 and v["wg"] == 1024, (name, v)           # measured: 40
+
+
+def test_spills_stay_off_the_measured_paths(kern):
+    """Some instantiations do spill (feature width 16 hash tables, the decoder without PIN, the pre-queue emitter); none of them is
+    launched by the configurations of BASELINE.json.  The list may shrink, not grow."""
+    spilling = sorted(n for n, v in kern.items() if v["scratch"] > 0)
+    allowed = ("hashgrid_bwd_emit_kernel<", "hashgrid_bwd_kernel<", "hashgrid_bwd_reduce_kernel<float, 16,", "hashgrid_bwd_reduce_kernel<__half, 16,",
+               "hashgrid_bwd_reduce_kernel<__hip_bfloat16, 16,", "mlp_fwd_kernel<float, false, false", "mlp_fwd_kernel<__half, false, false",
+               "mlp_fwd_kernel<__hip_bfloat16, false, false", "mlp_fwd_kernel<float, true, false", "mlp_fwd_kernel<__half, true, false",
+               "mlp_fwd_kernel<__hip_bfloat16, true, false")
+    for name in spilling:
+        assert any(a in name for a in allowed), name
+    assert len(spilling) <= 15 and max(kern[n]["scratch"] for n in spilling) <= 1024
+    hot = ("raymarch", "composite", "adamw", "optim", "spc_", "sdf_trace", "codebook", "trilinear", "gather_rows", "nerf_mlp_reduce", "wide")
+    for name, v in kern.items():
+        if any(h in name for h in hot):
+            assert v["scratch"] == 0, (name, v)
