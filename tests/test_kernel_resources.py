@@ -62,3 +62,37 @@ def test_spills_stay_off_the_measured_paths(kern):
     for name, v in kern.items():
         if any(h in name for h in hot):
             assert v["scratch"] == 0, (name, v)
+
+
+def test_hot_kernels_use_the_cdna4_instructions_the_design_names():
+    """ISA of the built library (llvm-objdump, no GPU): the decoders run on the matrix cores with gfx950's 16-deep bf16 MFMA and feed
+    them with 128-bit LDS reads; the queue emitter's segmented scan is DPP fused multiply-adds with packed fp32 products; the hash-grid
+    forward blends with packed FMAs; the 16-bit corner-query backward uses packed atomics.  Presence and order of magnitude only."""
+    isa = kernel_meta.instruction_counts(LIB, ("mlp_fwd_kernelI14__hip_bfloat16Lb0ELb1E", "mlp_bwd_kernelI14__hip_bfloat16Lb0E",
+                                               "wide_fwd_kernelILi128E14__hip_bfloat16", "wide_chain_kernelILi128E14__hip_bfloat16",
+                                               "wide_dw_kernelILi128E14__hip_bfloat16", "hashgrid_bwd_emit_q_kernelI14__hip_bfloat16Li3E",
+                                               "hashgrid_fwd_kernelI14__hip_bfloat16Li16ELi3E", "hashgrid_query_kernelI14__hip_bfloat16Lb1E",
+                                               "hashgrid_query_kernelI6__halfLb1E"))
+
+    def of(part):
+        hits = [c for n, c in isa.items() if part in n]
+        assert hits, part
+        return hits
+
+    def mfma(c):
+        return sum(v for k, v in c.items() if k.startswith("v_mfma_f32") and k.endswith("_bf16"))
+
+    for c in of("mlp_fwd_kernel"):
+        assert c["v_mfma_f32_32x32x16_bf16"] >= 20 and c["ds_read_b128"] >= 16 and not any(k.startswith("scratch_") for k in c)
+    for c in of("mlp_bwd_kernel"):
+        assert mfma(c) >= 60 and c["v_mfma_f32_16x16x32_bf16"] >= 20 and c["ds_read_b128"] >= 32
+    for part, least in (("wide_fwd_kernel", 48), ("wide_chain_kernel", 96), ("wide_dw_kernel", 96)):
+        for c in of(part):
+            assert mfma(c) >= least, (part, mfma(c))
+    for c in of("hashgrid_bwd_emit_q_kernel"):
+        dpp = sum(v for k, v in c.items() if k.endswith("_dpp"))
+        assert dpp >= 100 and c["v_pk_mul_f32"] >= 8 and not any(k.startswith("scratch_") for k in c)
+    for c in of("hashgrid_fwd_kernel"):
+        assert c["v_pk_fma_f32"] >= 32
+    assert all(c["global_atomic_pk_add_bf16"] >= 1 for c in of("hashgrid_query_kernelI14__hip_bfloat16"))
+    assert all(c["global_atomic_pk_add_f16"] >= 1 for c in of("hashgrid_query_kernelI6__half"))
