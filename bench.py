@@ -63,6 +63,9 @@ def parse():
                     help="nerf_hash = BASELINE.json's metric configuration (C2; the driver's line); v8 / vqad / nglod = the other "
                          "configs on their synthetic stand-ins (bench_configs.py), one GPU, secondary lines")
     ap.add_argument("--sdf-batch", type=int, default=512, help="nglod: coordinates per step (nglod_octree.yaml:78)")
+    ap.add_argument("--dropin-steps", type=int, default=100,
+                    help="timed iterations of the reference trainer's own step (fp16 autocast + GradScaler + torch.optim), reported "
+                         "as dropin_regime; 0 skips it")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -110,6 +113,54 @@ def cpu_baseline(blas_cells, hidden, num_steps, budget_s=20.0):
     return dict(value=R * n / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{n} oracle train steps of {R} rays x {num_steps} candidates ({samples // max(n,1)} packed samples/step), "
                        f"fp32, torch-CPU + numpy, {dt:.1f}s")
+
+
+def dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev):
+    """wisp.trainers.MultiviewTrainer - the mirror of the reference class, equal to its method bodies on the CPU
+    (tests/test_reference_modules.py::test_dropin_trainer_class_equals_the_reference_methods) - configured like nerf_hash.yaml's
+    `trainer:` block and driven through iterate() on a deep copy of the current model (learned occupancy, trained weights)."""
+    import copy
+    import synlego
+    from wisp.datasets import MultiviewTensorDataset, SampleRays
+    from wisp.trainers import MultiviewTrainer, ConfigMultiviewTrainer, ConfigAdamW
+    views = 8
+    per_view = bank_o.shape[0] // views
+    shape = (views, per_view, 3)
+    ds = MultiviewTensorDataset(bank_o[:views * per_view].view(shape), bank_d[:views * per_view].view(shape),
+                                bank_rgb[:views * per_view].view(shape), synlego.NEAR, synlego.FAR, transform=SampleRays(4096))
+    cfg = ConfigMultiviewTrainer(optimizer=ConfigAdamW(lr=1e-3, eps=1e-16, weight_decay=1e-6), grid_lr_weight=500.0, enable_amp=True,
+                                 scheduler=True, prune_every=100, rgb_loss_type='huber', rgb_loss_denom='rays', max_epochs=10 ** 6,
+                                 target_sample_size=args.ref_target_samples)
+    twin = copy.deepcopy(pipe)
+    twin.tracer.prev_num_samples = None                       # the trainer's first call is its warm-up raymarch
+    tr = MultiviewTrainer(cfg, twin, ds, device=dev)
+    tr.is_optimization_running = True
+    for _ in range(2 + min(args.warmup, 10)):
+        tr.iterate()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rays = samples = 0
+    for _ in range(args.dropin_steps):
+        rays += ds.transform.num_samples
+        tr.iterate()
+        samples += twin.tracer.get_prev_num_samples()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt, rays, samples], device=dev, dtype=torch.float64)
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        dt, rays, samples = float(t[0]), int(t[1]), int(t[2])
+    return {"value": rays / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / args.dropin_steps, "steps": args.dropin_steps,
+            "rays_per_step_per_gpu": rays / args.dropin_steps / world, "samples_per_step_per_gpu": samples / args.dropin_steps / world,
+            "loss_scale_at_end": float(tr.scaler.get_scale()), "dtype": "fp16 autocast + GradScaler (tables fp16, decoder bf16 MFMA)",
+            "note": "wisp.trainers.MultiviewTrainer.iterate(): the reference trainer's own step semantics (multiview_trainer.py:111-180, "
+                    "base_trainer.py:205-246,316-342) - autograd over the modular pipeline, torch.optim.AdamW, MultiStepLR, SampleRays, "
+                    "loss .item() read-backs; no gradient all-reduce (the reference has none): with N > 1 this is N independent replicas"}
 
 
 # algorithmic work per packed sample (SURVEY.md 8d / DESIGN.md 4): bytes for the HBM-bound kernels, flops for the decoder
@@ -301,6 +352,11 @@ def main():
     ref_samples_all = all_sum(ref_samples)
     trainer.target_sample_size = args.target_samples
 
+    # ---- the unchanged-application regime: the reference trainer's own step (multiview_trainer.py:111-180 through
+    # BaseTrainer.iterate, base_trainer.py:316-342) over a copy of the same model state: fp16 autocast + GradScaler, autograd over
+    # the modular pipeline, torch.optim.AdamW with the reference's parameter groups, SampleRays batches, two .item() per step
+    dropin = dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev) if args.dropin_steps > 0 else None
+
     # ---- one prune, timed on its own (it falls into the timed steps only every 100th iteration)
     torch.cuda.synchronize()
     tp = time.perf_counter()
@@ -372,6 +428,7 @@ def main():
                                  "ms_per_step": 1e3 * ref_elapsed / args.steps, "samples_per_sec": ref_samples_all / ref_elapsed,
                                  "prunes_inside_timed_steps": ref_prunes,
                                  "note": "multiview_trainer.py:58 default batch (2^18 packed samples per step), same run"},
+            "dropin_regime": dropin,
             "psnr_db": psnr, "optimisation_steps_before_psnr": trainer.total_iterations,
             "roofline": roofline,
         }

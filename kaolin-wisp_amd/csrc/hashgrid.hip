@@ -256,6 +256,7 @@ struct BinLevels {
     uint32_t entries[HG_MAX_LODS]; int32_t splits[HG_MAX_LODS];
     int32_t blk_base[HG_MAX_LODS + 1];      // reduce kernel: first workgroup of every level in the flattened 1-D grid
     int32_t rank_base[HG_MAX_LODS + 1];     // emit kernel: first LDS rank counter of every level
+    int64_t max_base;                       // count cell of emitting workgroup 0's largest record magnitude ([ntiles] cells)
 };
 
 template <typename T, int F, int DIM, bool MERGE>
@@ -397,17 +398,21 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 template <typename T, int F> struct RecordCodec {
     static constexpr bool COMPACT = (sizeof(T) == 2 && F == 2);
     static constexpr int RW = COMPACT ? 2 : 1 + F;
-    static __device__ __forceinline__ void store(uint32_t* dst, uint32_t idx, uint32_t local_mask, const float (&v)[F]) {
+    // -> the largest magnitude stored, as float bits (sign cleared): feeds the reduce kernel's fixed-point exponent
+    static __device__ __forceinline__ uint32_t store(uint32_t* dst, uint32_t idx, uint32_t local_mask, const float (&v)[F]) {
         if constexpr (COMPACT) {
             const uint32_t loc = idx & local_mask;
             uint2 w;
             w.x = ((__float_as_uint(v[0]) + 0x40u) & ~0x7fu) | (loc & 0x7fu);
             w.y = ((__float_as_uint(v[1]) + 0x40u) & ~0x7fu) | (loc >> 7);
             *reinterpret_cast<uint2*>(dst) = w;
+            return max(w.x & 0x7fffff80u, w.y & 0x7fffff80u);
         } else {
             dst[0] = idx;
+            uint32_t m = 0;
 #pragma unroll
-            for (int k = 0; k < F; ++k) dst[1 + k] = __float_as_uint(v[k]);
+            for (int k = 0; k < F; ++k) { dst[1 + k] = __float_as_uint(v[k]); m = max(m, __float_as_uint(v[k]) & 0x7fffffffu); }
+            return m;
         }
     }
     // -> entry index inside the bucket, values
@@ -445,7 +450,10 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
     extern __shared__ __attribute__((aligned(16))) uint32_t em_smem[];
     const int total_ranks = bins.rank_base[levels.n];
     uint32_t* s_rank = em_smem;                          // [total_ranks] records written so far per (level, bucket)
-    uint32_t* s_grad = em_smem + total_ranks;            // [EM_TILE][rowp] gradient rows of this tile
+    uint32_t* s_mx = em_smem + total_ranks;              // largest record magnitude of this workgroup (float bits)
+    uint32_t* s_grad = em_smem + total_ranks + 1;        // [EM_TILE][rowp] gradient rows of this tile
+    uint32_t mx = 0;
+    if (threadIdx.x == 0) *s_mx = 0;
     const int row_dw = num_lods * W;
     const int rowp = row_dw | 1;
     const int lane = threadIdx.x & 63;
@@ -510,7 +518,7 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
                 const uint32_t b = idx >> chunk_shift;
                 if (pos[j] < cap) {
                     uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos[j]) * RW);   // < 2^32 dwords (bin_plan)
-                    Codec::store(dst, idx, (1u << chunk_shift) - 1u, v[j]);
+                    mx = max(mx, Codec::store(dst, idx, (1u << chunk_shift) - 1u, v[j]));
                 } else {
                     // slot full, or a spill index: the memory-side atomic.  A spill lands where the reference's pointer
                     // arithmetic puts it (rows of the next level, .cu:124-161) unless that is past the whole table.
@@ -524,7 +532,9 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
             }
         }
     }
+    if (mx) atomicMax(s_mx, mx);
     __syncthreads();
+    if (threadIdx.x == 0) counts[bins.max_base + blockIdx.x] = *s_mx;
     for (int li = 0; li < levels.n; ++li) {
         const int chunks = bins.chunks[li];
         const uint32_t cap = bins.cap[li];
@@ -565,9 +575,12 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
     extern __shared__ __attribute__((aligned(16))) uint32_t em_smem[];
     const int total_ranks = bins.rank_base[levels.n];
     uint32_t* s_rank = em_smem;
+    uint32_t* s_mx = em_smem + total_ranks;              // largest record magnitude of this workgroup (float bits)
+    uint32_t mx = 0;
+    if (threadIdx.x == 0) *s_mx = 0;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    uint32_t* s_queue = em_smem + ((total_ranks + 3) & ~3) + wave * (64 * QROW);
+    uint32_t* s_queue = em_smem + ((total_ranks + 4) & ~3) + wave * (64 * QROW);
     const uint32_t ntiles = gridDim.x;
     const int64_t total_rows = first_idx[num_lods];
     for (int b = threadIdx.x; b < total_ranks; b += EM_THREADS) s_rank[b] = 0;
@@ -647,7 +660,7 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
                         const uint32_t pos = idx < owned ? atomicAdd(&rank_l[b], 1u) : 0xffffffffu;
                         if (pos < cap) {
                             uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos) * RW);   // < 2^32 dwords (bin_plan)
-                            Codec::store(dst, idx, (1u << chunk_shift) - 1u, val);
+                            mx = max(mx, Codec::store(dst, idx, (1u << chunk_shift) - 1u, val));
                         } else {
                             // slot full, or a spill index (lands where the reference's pointer arithmetic puts it, .cu:124-161,
                             // unless that is past the whole table)
@@ -665,7 +678,9 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
             }
         }
     }
+    if (mx) atomicMax(s_mx, mx);
     __syncthreads();
+    if (threadIdx.x == 0) counts[bins.max_base + blockIdx.x] = *s_mx;
     for (int li = 0; li < levels.n; ++li) {
         const int chunks = bins.chunks[li];
         const uint32_t cap = bins.cap[li];
@@ -680,7 +695,7 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
 
 // queue + rank counters
 static inline size_t queue_emitter_lds(int total_ranks, int dim) {
-    return ((size_t)((total_ranks + 3) & ~3) + (size_t)(EM_THREADS / 64) * 64 * (3 * (1 << dim) + 1)) * 4;
+    return ((size_t)((total_ranks + 4) & ~3) + (size_t)(EM_THREADS / 64) * 64 * (3 * (1 << dim) + 1)) * 4;
 }
 // Workgroups of the queue emitter one CU holds at once (registers + LDS; asked from the runtime, once per instance; the
 // half and bf16 instances are the same code).  The rank counters vary a little with the level layout: 1024 is a safe figure.
@@ -699,43 +714,46 @@ static int queue_emitter_residency() {
 
 // LDS accumulator of the reduce kernel.  LDS *float* atomics (ds_add_f32) turned out to retire roughly one lane per
 // ~3 clocks per CU on gfx950 (measured: 67 M lane-adds -> 0.6 ms); integer LDS atomics do not have that problem, so the
-// bucket is accumulated in 64-bit fixed point (2^-44 resolution, +-5e5 range): exact, order-independent (bitwise
-// reproducible gradients) and converted to fp32 once per table entry.
+// bucket is accumulated in 64-bit fixed point: exact, order-independent (bitwise reproducible gradients) and converted to
+// fp32 once per table entry.  The binary point is set PER LAUNCH from the largest record magnitude M the emit workgroups
+// reported (any gradient scale works: a GradScaler's 2^16 ... 2^24 as well as 1e-9 initial tables): with 2^(e-127) <= M <
+// 2^(e-126), values are held in units of 2^-s, s = 165 - e, so that 2^24 records of magnitude M still fit 63 bits
+// (resolution M * 2^-39: finer than the 16-bit mantissa of a compact record by 23 bits, than fp32 accumulation by 15).
+// A non-finite record (an overflowed fp16 gradient under a too-large loss scale) switches the workgroup to plain fp32
+// LDS atomics, which propagate inf / NaN into the table gradient exactly like the reference's float atomics do - the
+// GradScaler of an unchanged trainer then sees found_inf and skips the step.
 struct AccFix64 {
-    typedef unsigned long long type;
-    static __device__ __forceinline__ void add(type* acc, uint32_t i, float v) {
-        // trunc(v * 2^44) without fp64: |v| * 2^12 is exact, so are its floor (the high word) and the remainder in [0, 1)
-        // (the low word); the sign is applied to the 64-bit magnitude
-        const float a = fabsf(v) * 4096.0f;
+    unsigned long long* acc;
+    float mul;              // 2^(s - 32)
+    double inv;             // 2^-s
+    __device__ __forceinline__ void zero(uint32_t i) const { acc[i] = 0ull; }
+    __device__ __forceinline__ void add(uint32_t i, float v) const {
+        // trunc(v * 2^s) without fp64: a = |v| * 2^(s-32) is exact (power-of-two scaling) and below 2^8, so are its floor
+        // (the high word) and the remainder in [0, 1) (the low word); the sign is applied to the 64-bit magnitude
+        const float a = fabsf(v) * mul;
         const float h = floorf(a);
         const unsigned long long mag = ((unsigned long long)(uint32_t)h << 32) | (uint32_t)((a - h) * 4294967296.0f);
         const unsigned long long sgn = (unsigned long long)(long long)((int32_t)__float_as_uint(v) >> 31);   // 0 or ~0
         const unsigned long long q = (mag ^ sgn) - sgn;
         atomicAdd(acc + i, q);                                                                               // ds_add_u64
     }
-    static __device__ __forceinline__ float get(const type* acc, uint32_t i) {
-        return (float)((double)(long long)acc[i] * (1.0 / 17592186044416.0));
-    }
+    __device__ __forceinline__ float get(uint32_t i) const { return (float)((double)(long long)acc[i] * inv); }
+};
+struct AccF32 {             // the non-finite fallback
+    float* acc;
+    __device__ __forceinline__ void zero(uint32_t i) const { acc[i] = 0.0f; }
+    __device__ __forceinline__ void add(uint32_t i, float v) const { atomicAdd(acc + i, v); }
+    __device__ __forceinline__ float get(uint32_t i) const { return acc[i]; }
 };
 
 template <typename T, int F, typename ACC>
-__global__ void __launch_bounds__(RD_THREADS)
-hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList levels, int chunk_shift, BinLevels bins,
-                           uint32_t ntiles, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ records,
-                           float* __restrict__ grad_codebook) {
+static __device__ __forceinline__ void
+hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, const LevelList& levels, int chunk_shift,
+                         const BinLevels& bins, uint32_t ntiles, const uint32_t* __restrict__ counts,
+                         const uint32_t* __restrict__ records, float* __restrict__ grad_codebook, int li, int b, int z) {
     typedef RecordCodec<T, F> Codec;
     constexpr int RW = Codec::RW;
-    typedef typename ACC::type acc_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char rd_smem[];
-    acc_t* rd_acc = reinterpret_cast<acc_t*>(rd_smem);                  // [chunk entries * F]
-    // flattened (level, bucket, split) grid
-    // heaviest first: the fine (hashed) levels carry most of the records, the cheap coarse buckets fill the tail of the grid
-    const int bid = (int)(gridDim.x - 1u - blockIdx.x);
-    int li = 0;
-    while (li + 1 < levels.n && bid >= bins.blk_base[li + 1]) ++li;
     const int splits = bins.splits[li];
-    const int local = bid - bins.blk_base[li];
-    const int b = local / splits, z = local - b * splits;
     const int l = levels.lv[li];
     const uint32_t csize = 1u << chunk_shift;
     const uint32_t cap = bins.cap[li];
@@ -745,7 +763,7 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
     const int64_t rows_l = first_idx[l + 1] - first_idx[l];
     const uint32_t entries = (uint32_t)(rows_l < (int64_t)bins.entries[li] ? (rows_l < 0 ? 0 : rows_l) : (int64_t)bins.entries[li]);
     const uint32_t lim = (entries > first ? min(entries - first, csize) : 0u) * F;
-    for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) rd_acc[e] = (acc_t)0;
+    for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) A.zero(e);
     __syncthreads();
     const uint32_t* __restrict__ cnt = counts + bins.cnt_base[li] + (size_t)b * ntiles;
     const uint32_t* __restrict__ src = records + ((size_t)bins.rec_base[li] + (size_t)b * ntiles * cap) * RW;
@@ -791,7 +809,7 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
                     float val[F];
                     const uint32_t e = Codec::load(w[u], first, val);
 #pragma unroll
-                    for (int kk = 0; kk < F; ++kk) ACC::add(rd_acc, e * F + kk, val[kk]);
+                    for (int kk = 0; kk < F; ++kk) A.add(e * F + kk, val[kk]);
                 }
             }
         }
@@ -815,22 +833,60 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
                 const uint32_t i = threadIdx.x + q * RD_THREADS;
                 if (i < quads) {
                     float4 t = cur[q];
-                    t.x += ACC::get(rd_acc, 4 * i); t.y += ACC::get(rd_acc, 4 * i + 1);
-                    t.z += ACC::get(rd_acc, 4 * i + 2); t.w += ACC::get(rd_acc, 4 * i + 3);
+                    t.x += A.get(4 * i); t.y += A.get(4 * i + 1);
+                    t.z += A.get(4 * i + 2); t.w += A.get(4 * i + 3);
                     reinterpret_cast<float4*>(dst)[i] = t;
                 }
             }
         } else {
             for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
-                const float a = ACC::get(rd_acc, e);
+                const float a = A.get(e);
                 if (a != 0.0f) dst[e] += a;
             }
         }
     } else {
         for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
-            const float a = ACC::get(rd_acc, e);
+            const float a = A.get(e);
             if (a != 0.0f) atomicAdd(dst + e, a);         // coarse levels are split over several workgroups
         }
+    }
+}
+
+template <typename T, int F>
+__global__ void __launch_bounds__(RD_THREADS)
+hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList levels, int chunk_shift, BinLevels bins,
+                           uint32_t ntiles, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ records,
+                           float* __restrict__ grad_codebook) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rd_smem[];            // [chunk entries * F] accumulators
+    __shared__ uint32_t s_wave_max[RD_THREADS / 64];
+    // flattened (level, bucket, split) grid
+    // heaviest first: the fine (hashed) levels carry most of the records, the cheap coarse buckets fill the tail of the grid
+    const int bid = (int)(gridDim.x - 1u - blockIdx.x);
+    int li = 0;
+    while (li + 1 < levels.n && bid >= bins.blk_base[li + 1]) ++li;
+    const int splits = bins.splits[li];
+    const int local = bid - bins.blk_base[li];
+    const int b = local / splits, z = local - b * splits;
+    // largest record magnitude of the launch (float bits, sign cleared): max over the emitting workgroups' cells
+    uint32_t m = 0;
+    for (uint32_t t = threadIdx.x; t < ntiles; t += RD_THREADS) m = max(m, counts[bins.max_base + t]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    if ((threadIdx.x & 63) == 0) s_wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = s_wave_max[0];
+#pragma unroll
+    for (int w = 1; w < RD_THREADS / 64; ++w) m = max(m, s_wave_max[w]);
+    const int e = (int)(m >> 23);                          // biased exponent of the largest magnitude (wave- and block-uniform)
+    if (e < 255) {
+        int sh = 165 - e;                                  // see AccFix64
+        if (sh > 159) sh = 159;                            // 2^(sh - 32) must stay a normal float
+        AccFix64 A{reinterpret_cast<unsigned long long*>(rd_smem), __uint_as_float((uint32_t)(sh - 32 + 127) << 23),
+                   __longlong_as_double((long long)(1023 - sh) << 52)};
+        hashgrid_bwd_reduce_body<T, F>(A, first_idx, levels, chunk_shift, bins, ntiles, counts, records, grad_codebook, li, b, z);
+    } else {
+        AccF32 A{reinterpret_cast<float*>(rd_smem)};
+        hashgrid_bwd_reduce_body<T, F>(A, first_idx, levels, chunk_shift, bins, ntiles, counts, records, grad_codebook, li, b, z);
     }
 }
 
@@ -976,6 +1032,8 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
     }
     p.bins.blk_base[levels.n] = p.total_blocks;
     p.bins.rank_base[levels.n] = p.total_ranks;
+    p.bins.max_base = cnt;
+    cnt += p.ntiles;
     p.count_bytes = (cnt * 4 + 255) / 256 * 256;
     p.record_bytes = rec * rec_dwords * 4;
     return p;
@@ -1002,7 +1060,7 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     }
     const BinPlan plan = bin_plan(n, lv, active, F, (int64_t)tsize, DIM, RecordCodec<T, F>::RW, max_emitters);
     // emit kernel LDS: rank counters of every (level, bucket) + the tile's gradient rows
-    const size_t em_lds = ((size_t)plan.total_ranks + (size_t)EM_TILE * ((num_lods * ((F * (int)sizeof(T)) / 4)) | 1)) * 4;
+    const size_t em_lds = ((size_t)plan.total_ranks + 1 + (size_t)EM_TILE * ((num_lods * ((F * (int)sizeof(T)) / 4)) | 1)) * 4;
     const bool can_bin = merge && bwd_bin_enabled() && workspace && plan.ok && em_lds <= 150 * 1024 &&
                          plan.count_bytes + plan.record_bytes <= workspace_bytes && n >= 4096;
     if (!can_bin) {
@@ -1037,7 +1095,7 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
                            plan.chunk_shift, plan.bins, counts, records, grad_codebook);
     }
     const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 8;
-    auto rd = hashgrid_bwd_reduce_kernel<T, F, AccFix64>;
+    auto rd = hashgrid_bwd_reduce_kernel<T, F>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
     hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
                        plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook);

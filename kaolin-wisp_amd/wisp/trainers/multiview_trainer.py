@@ -9,9 +9,11 @@ weight decay, names containing 'grid' get lr * grid_lr_weight; MultiStepLR).  MI
     distributed path at all); rays are sharded across ranks, parameters and the occupancy octree are replicated;
   * bf16 autocast replaces the reference's fp16 autocast + GradScaler (no loss scaling needed).
 """
+import logging as log
 import math
 import os
 import weakref
+from dataclasses import dataclass
 from typing import Optional
 
 import torch
@@ -19,6 +21,7 @@ import torch.distributed as dist
 
 from wisp.core import Rays
 from wisp.ops.grid import current_shadow, mark_shadow_current, register_table_aux
+from wisp.trainers.base_trainer import BaseTrainer, ConfigBaseTrainer
 
 
 def _hip():
@@ -541,6 +544,120 @@ class MultiviewTrainStep:
         self.reduce_and_update()
         self.calc_adaptive_rays(rays.origins.shape[0])
         return loss.detach(), self.pipeline.tracer.get_prev_num_samples()
+
+
+@dataclass
+class ConfigMultiviewTrainer(ConfigBaseTrainer):
+    """Field names and defaults of wisp/trainers/multiview_trainer.py:33-63 (the YAML schema under `trainer:`)."""
+    start_prune: int = 1000
+    prune_every: int = 100
+    random_lod: bool = False
+    rgb_lambda: float = 1.0
+    opacity_loss: float = 0.0
+    rgb_loss_type: str = 'l2'
+    rgb_loss_denom: str = 'rays'
+    target_sample_size: int = 2 ** 18
+    save_valid_imgs: bool = False
+
+
+class MultiviewTrainer(BaseTrainer):
+    """The reference's multiview trainer as an application uses it (wisp/trainers/multiview_trainer.py:65-180; constructed
+    like app/nerf/main_nerf.py:110): the *unchanged-trainer* regime over this package's Pipeline - autograd through the
+    modular HIP ops, fp16 autocast + GradScaler, a torch.optim optimizer with the reference's parameter groups, two
+    `.item()` read-backs per step for the loss metrics.  Same events in the same order as the reference's step(); the fused
+    MI355X step that replaces all of this is MultiviewTrainStep (same losses, same parameters afterwards; tests/).
+    Validation renders through wisp.trainers.validation (PSNR only; lpips / ssim need packages that are out of scope)."""
+
+    def __init__(self, cfg, pipeline, train_dataset, validation_dataset=None, tracker=None, device='cuda', scene_state=None):
+        super().__init__(cfg=cfg, pipeline=pipeline, train_dataset=train_dataset, tracker=tracker, device=device,
+                         scene_state=scene_state)
+        self.validation_dataset = validation_dataset
+
+    def pre_step(self):
+        super().pre_step()
+        every = self.cfg.prune_every
+        if every > -1 and self.total_iterations > 1 and self.total_iterations % every == 0:
+            self.pipeline.nef.prune()
+
+    def calc_adaptive_rays(self, rays, warmup=False):
+        pipe = self.pipeline
+        if warmup:
+            marched = pipe.nef.grid.raymarch(rays, level=pipe.nef.grid.active_lods[-1], num_samples=pipe.tracer.num_steps,
+                                             raymarch_type=pipe.tracer.raymarch_type)
+            pipe.tracer.prev_num_samples = marched.samples.shape[0]
+        per_ray = pipe.tracer.get_prev_num_samples() / rays.shape[0]
+        num_rays = int(math.floor(min(self.cfg.target_sample_size / max(per_ray, 1), 2 ** 18)))
+        transform = getattr(self.train_dataset, 'transform', None)
+        if not hasattr(transform, 'set_num_samples') or type(transform).__name__ != 'SampleRays':
+            raise Exception("SampleRays should be used as the transform for the dataset")
+        transform.set_num_samples(num_rays)
+
+    def step(self, data):
+        rays = data['rays'].to(self.device).squeeze(0)
+        img_gts = data['rgb'].to(self.device).squeeze(0)
+        tracer = self.pipeline.tracer
+        if tracer.get_prev_num_samples() is None:
+            self.calc_adaptive_rays(rays, warmup=True)           # first call only sizes the batch, no optimisation
+            return
+        self.optimizer.zero_grad()
+        lod_idx = None
+        if self.cfg.random_lod:
+            import random
+            lods = self.pipeline.nef.grid.num_lods
+            total = float(sum(2 ** i for i in range(lods)))
+            lod_idx = random.choices(list(range(lods)), [2 ** i / total for i in range(lods)])[0]
+        rb = self.pipeline(rays=rays, lod_idx=lod_idx, channels=["rgb"])
+        kind = self.cfg.rgb_loss_type
+        if kind == 'l2':
+            per_elem = torch.nn.functional.mse_loss(rb.rgb, img_gts, reduction='none')
+        elif kind == 'l1':
+            per_elem = torch.abs(rb.rgb - img_gts)
+        elif kind == 'huber':
+            per_elem = torch.nn.functional.smooth_l1_loss(rb.rgb, img_gts, reduction='none')
+        else:
+            raise NotImplementedError
+        denom = self.cfg.rgb_loss_denom
+        if denom == 'samples':
+            rgb_loss = per_elem.sum() / tracer.prev_num_samples
+        elif denom == 'rays':
+            rgb_loss = per_elem.mean()
+        else:
+            raise NotImplementedError
+        loss = 0 + rgb_loss
+        if self.cfg.opacity_loss > 0.0 and self.total_iterations < 1000:
+            loss = loss + self.cfg.opacity_loss * ((1.0 - rb.alpha) ** 2).mean()
+        m = self.tracker.metrics
+        m.total_loss += loss.item()
+        m.rgb_loss += rgb_loss.item()
+        m.num_samples += 1
+        if self.cfg.enable_amp:
+            self.scaler.scale(loss).backward()
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
+        else:
+            loss.backward()
+            self.optimizer.step()
+        self.calc_adaptive_rays(rays, warmup=False)
+        if self.cfg.scheduler:
+            self.scheduler.step()
+
+    def log_console(self):
+        m = self.tracker.metrics
+        log.info('EPOCH {}/{} | total loss: {:>.3E} | rgb loss: {:>.3E}'.format(
+            self.epoch, self.max_epochs, m.average_metric('total_loss'), m.average_metric('rgb_loss')))
+
+    def validate(self):
+        """PSNR over the validation views (multiview_trainer.py:257-303 without image / table writers)."""
+        if self.validation_dataset is None:
+            return None
+        from wisp.trainers.validation import evaluate_psnr
+        data = self.validation_dataset.data
+        rays, rgb = data["rays"], data["rgb"]
+        views = [(rays[i], rgb[i]) for i in range(rays.origins.shape[0])]
+        mean, line = evaluate_psnr(self.pipeline, views, epoch=self.epoch, max_epochs=self.max_epochs)
+        log.info(line)
+        self.return_dict = {"psnr": mean}
+        return self.return_dict
 
 
 def shard_rays(num_rays: int, rank: int, world: int):

@@ -235,6 +235,67 @@ def test_hashgrid_backward_is_repeatable_and_race_free(res, bitwidth, n):
         print(f"n={n} {dt}: worst |grad - oracle| over {reps} repetitions = {worst:.3e} (scale {scale:.3f})")
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("log2_scale", [0, 16, 24, -30])
+def test_hashgrid_backward_is_exact_under_any_loss_scale(dtype, log2_scale):
+    """The unchanged-trainer regime hands this kernel gradients multiplied by a GradScaler's loss scale (2^16 at start, doubling
+    every 2000 clean steps: base_trainer.py:240).  The binned backward accumulates in 64-bit fixed point whose binary point is
+    set per launch from the largest record, so a power-of-two scale must change NOTHING but the exponent: the gradient of the
+    scaled input equals scale x the float64 oracle's gradient of the unscaled input, to the tolerance of the unscaled case -
+    no wrap-around at 2^16 / 2^24, no flush to zero at 2^-30 (a 1e-9-initialised table's first gradients)."""
+    rng = np.random.default_rng(77)
+    _, begin = ohash.table_layout(NGP_RES, 2 ** 19)
+    shape = (int(begin[-1]), 2)
+    n = 32768
+    coords = _ray_like_coords(rng, n)
+    base = torch.from_numpy((rng.normal(size=(n, 32)) * 3e-3).astype(np.float32)).to(dtype)      # realistic per-sample magnitudes
+    scale = 2.0 ** log2_scale
+    if dtype == torch.float16 and log2_scale < 0:
+        pytest.skip("2^-30 x 3e-3 is below fp16's range: nothing to test")
+    scaled = (base.float() * scale).to(dtype)
+    assert torch.isfinite(scaled.float()).all() and torch.equal(scaled.float(), base.float() * scale)   # exact power-of-two scaling
+    want = ohash.hashgrid_backward(torch.from_numpy(coords), base.float(), shape, torch.from_numpy(begin), NGP_RES, 19, torch.float64)
+    got = _C().hashgrid_interpolate_backward(cuda(coords), scaled.to(DEV), shape, cuda(begin), NGP_RES, 19)
+    ref_scale = float(want.abs().max())
+    err = float((got.double().cpu() / scale - want).abs().max())
+    assert err <= (4e-6 if dtype == torch.float32 else 3e-5) * ref_scale, (dtype, log2_scale, err, ref_scale)
+    # and bit-for-bit: the scaled run is the unscaled run times 2^k (the fixed-point grid moves with the data)
+    got1 = _C().hashgrid_interpolate_backward(cuda(coords), base.to(DEV), shape, cuda(begin), NGP_RES, 19)
+    if log2_scale >= 0 or dtype != torch.float16:
+        assert torch.equal(got, got1 * scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_hashgrid_backward_propagates_non_finite_gradients(dtype):
+    """An fp16 gradient that overflowed under a too-large loss scale arrives as +-inf (or NaN).  The reference's float atomics
+    carry it into the table gradient, where GradScaler.unscale_ finds it and skips the step (base_trainer.py:240,
+    multiview_trainer.py:168-171).  The fixed-point accumulation must not turn it into a finite number: every table entry a
+    poisoned sample touches is non-finite, every other entry keeps its exact finite value."""
+    rng = np.random.default_rng(78)
+    _, begin = ohash.table_layout(NGP_RES, 2 ** 19)
+    shape = (int(begin[-1]), 2)
+    n = 16384
+    coords = _ray_like_coords(rng, n)
+    go = torch.from_numpy(rng.normal(size=(n, 32)).astype(np.float32)).to(dtype)
+    clean = _C().hashgrid_interpolate_backward(cuda(coords), go.to(DEV), shape, cuda(begin), NGP_RES, 19)
+    bad = go.clone()
+    bad[5000, :] = float('inf')
+    bad[9000, 3] = float('nan')
+    got = _C().hashgrid_interpolate_backward(cuda(coords), bad.to(DEV), shape, cuda(begin), NGP_RES, 19)
+    # which entries do the two poisoned samples touch?  (gradient of a 0/1 indicator through the float64 oracle)
+    ind = torch.zeros(n, 32)
+    ind[5000, :] = 1.0
+    ind[9000, 3] = 1.0
+    touched = ohash.hashgrid_backward(torch.from_numpy(coords), ind, shape, torch.from_numpy(begin), NGP_RES, 19, torch.float64) != 0
+    fin = torch.isfinite(got).cpu()
+    assert not fin[touched].any(), "a poisoned contribution came out finite"
+    assert fin[~touched].all(), "inf / NaN leaked into entries the poisoned samples do not touch"
+    # untouched entries: same value as the clean run up to the fp32 atomics' add order (the fallback accumulates in fp32)
+    tol = 4e-6 if dtype == torch.float32 else 3e-5
+    sc = float(clean.abs().max())
+    assert float((got.cpu()[~touched] - clean.cpu()[~touched]).abs().max()) <= tol * sc
+
+
 def test_hashgrid_dense_level_spill_follows_reference_pointer_arithmetic():
     """A dense level with res >= 258 (needs T >= 2^25): the fp32 clamp bound res-1-1e-5 rounds to res-1, so a coordinate of
     exactly +1 gives corner `res` and an index past the level's res^3 rows.  The reference's pointer arithmetic
@@ -791,6 +852,108 @@ def test_tracer_end_to_end_matches_oracle(rtype, steps):
         assert n1 == n2
         scale = max(float(p2.grad.abs().max()), 1e-6)
         assert float((p1.grad.cpu() - p2.grad).abs().max()) <= 2e-4 * scale + 1e-7, n1
+
+
+def _dropin_trainer(pipe, amp, lr=1e-3, glw=500.0, loss='huber', rays_per_view=300):
+    """wisp.trainers.MultiviewTrainer as app/nerf/main_nerf.py:110 builds it (nerf_hash.yaml's trainer block), over `pipe`."""
+    from wisp.core import Rays
+    from wisp.datasets import MultiviewTensorDataset, SampleRays
+    from wisp.trainers import MultiviewTrainer, ConfigMultiviewTrainer, ConfigAdamW
+    o, d = make_rays(rays_per_view, 5)
+    ds = MultiviewTensorDataset(cuda(o)[None], cuda(d)[None], torch.rand(1, rays_per_view, 3, device=DEV), 1.0, 5.0,
+                                transform=SampleRays(rays_per_view))
+    cfg = ConfigMultiviewTrainer(optimizer=ConfigAdamW(lr=lr, eps=1e-16, weight_decay=1e-6), grid_lr_weight=glw, enable_amp=amp,
+                                 prune_every=-1, rgb_loss_type=loss, rgb_loss_denom='rays', max_epochs=10, scheduler=False)
+    return MultiviewTrainer(cfg, pipe, ds, device=DEV)
+
+
+def test_dropin_regime_fp16_autocast_gradscaler_matches_oracle():
+    """THE unchanged-application regime on the MI355X: wisp.trainers.MultiviewTrainer.step
+    - the mirror of multiview_trainer.py:111-180, proven equal to the reference's own method bodies on the CPU
+    (tests/test_reference_modules.py::test_dropin_trainer_class_equals_the_reference_methods) - run exactly as
+    BaseTrainer.iterate runs it (base_trainer.py:338: `torch.cuda.amp.autocast()` = fp16) with a GradScaler at its default
+    2^16 and torch.optim.AdamW over the reference's three parameter groups, autograd over the modular HIP pipeline.
+    Against the fp32 CPU oracle on the same rays and jitter: loss, every parameter's (unscaled) gradient, and the parameters
+    after three optimizer steps.  Tolerances are what fp16 tables / bf16 decoder arithmetic leave, stated below."""
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.tracers import PackedRFTracer
+    nef, onef, oblas = _build_pair()
+    R, steps = 300, 96
+    o, d = make_rays(R, 91)
+    rng = np.random.default_rng(92)
+    gts = rng.uniform(size=(R, 3)).astype(np.float32)
+    pipe = Pipeline(nef, PackedRFTracer(raymarch_type='ray', num_steps=steps, bg_color=(0.0, 0.0, 0.0)))
+    tr = _dropin_trainer(pipe, amp=True)
+    assert tr.scaler.is_enabled() and tr.scaler.get_scale() == 65536.0
+    opt = onerf.make_optimizer(onef, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0)
+    data = {"rays": Rays(cuda(o)[None], cuda(d)[None], dist_min=1.0, dist_max=5.0), "rgb": cuda(gts)[None]}
+    with torch.autocast('cuda', enabled=True):              # fp16: torch's default for 'cuda', as base_trainer.py:338
+        tr.step(data)                                        # warm-up call: sizes the batch, optimises nothing
+    assert tr.tracker.metrics.num_samples == 0 and pipe.tracer.get_prev_num_samples() > 0
+    for it in range(3):
+        jit = rng.uniform(size=(R, steps)).astype(np.float32)
+        pipe.tracer.jitter = cuda(jit)                       # BaseTracer.forward fills trace() arguments from instance attributes
+        before = tr.tracker.metrics.rgb_loss
+        with torch.autocast('cuda', enabled=True):
+            assert torch.get_autocast_dtype('cuda') == torch.float16
+            tr.step(data)
+        loss = tr.tracker.metrics.rgb_loss - before
+        opt.zero_grad()
+        want_loss, want_s = onerf.train_step(onef, oblas, opt, torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(gts),
+                                             1.0, 5.0, steps, jit)
+        assert pipe.tracer.get_prev_num_samples() == want_s                          # sample count is integer work: exact
+        assert abs(loss - want_loss) <= 2e-3 * abs(want_loss) + 1e-5, (it, loss, want_loss)
+        assert tr.scaler.get_scale() == 65536.0                                      # no overflow: the scale stands
+        # GradScaler.step unscaled the gradients in place before handing them to AdamW
+        for (n1, p1), (n2, p2) in zip(sorted(nef.named_parameters()), sorted(onef.named_parameters())):
+            if p2.grad is None:
+                continue
+            assert n1 == n2 and p1.grad is not None and p1.grad.dtype == torch.float32
+            sc = max(float(p2.grad.abs().max()), 1e-9)
+            err = float((p1.grad.cpu() - p2.grad).abs().max())
+            # bf16 decoder products (2^-9 relative) and fp16 features; sums over thousands of samples average it down
+            assert err <= 2e-2 * sc, (it, n1, err, sc)
+    # parameters after three AdamW steps: Adam normalises every entry's step to ~lr, so compare in units of the step taken
+    for (n1, p1), (n2, p2) in zip(sorted(nef.named_parameters()), sorted(onef.named_parameters())):
+        lr = 1e-3 * (500.0 if 'grid' in n1 else 1.0)
+        diff = (p1.detach().cpu() - p2.detach()).abs()
+        assert float(diff.max()) <= 3 * lr * 1.01, n1                                # never further than the steps themselves
+        assert float((diff <= 0.35 * lr).float().mean()) >= 0.95, (n1, float((diff <= 0.35 * lr).float().mean()))
+
+
+def test_dropin_regime_overflowing_loss_scale_skips_the_step_and_backs_off():
+    """found_inf handling end to end: with a loss scale of 2^40 the fp16 gradients entering the decoder / hash-grid backward
+    overflow; the table gradient must come out non-finite (not wrapped into a finite number by the fixed-point bins),
+    GradScaler.step must skip the optimizer (parameters bit-identical) and update() must halve the scale."""
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.tracers import PackedRFTracer
+    nef, _, _ = _build_pair()
+    R, steps = 300, 96
+    o, d = make_rays(R, 93)
+    gts = np.random.default_rng(94).uniform(size=(R, 3)).astype(np.float32)
+    pipe = Pipeline(nef, PackedRFTracer(raymarch_type='ray', num_steps=steps, bg_color=(0.0, 0.0, 0.0)))
+    tr = _dropin_trainer(pipe, amp=True)
+    tr.scaler = torch.amp.GradScaler('cuda', init_scale=2.0 ** 40)
+    data = {"rays": Rays(cuda(o)[None], cuda(d)[None], dist_min=1.0, dist_max=5.0), "rgb": cuda(gts)[None]}
+    with torch.autocast('cuda', enabled=True):
+        tr.step(data)
+        before = {n: p.detach().clone() for n, p in nef.named_parameters()}
+        tr.step(data)
+    table_grad = nef.grid.codebook.feats.grad
+    assert table_grad is not None and not bool(torch.isfinite(table_grad).all()), "overflow was laundered into finite numbers"
+    for n, p in nef.named_parameters():
+        assert torch.equal(p.detach(), before[n]), f"{n} moved although the step had to be skipped"
+    assert tr.scaler.get_scale() == 2.0 ** 39
+    # and the trainer recovers: after enough back-offs a step goes through
+    with torch.autocast('cuda', enabled=True):
+        for _ in range(40):
+            tr.step(data)
+            if any(not torch.equal(p.detach(), before[n]) for n, p in nef.named_parameters()):
+                break
+    assert any(not torch.equal(p.detach(), before[n]) for n, p in nef.named_parameters())
+    assert tr.scaler.get_scale() < 2.0 ** 39
 
 
 def test_prune_rebuilds_identical_octree():

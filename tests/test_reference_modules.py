@@ -539,6 +539,117 @@ def test_training_step_semantics_equal_the_reference_methods(loss_type):
     assert tr.num_rays == me.train_dataset.transform.num_samples                          # same adaptive ray count
 
 
+@pytest.mark.parametrize("amp", [False, True])
+def test_dropin_trainer_class_equals_the_reference_methods(amp):
+    """wisp.trainers.MultiviewTrainer (the unchanged-application regime: torch.optim groups from init_optimizer, GradScaler,
+    per-step metric read-backs, MultiStepLR) driven through its own BaseTrainer.iterate() - next to a trainer assembled from
+    the reference's OWN method bodies, compiled from the files where they lie: BaseTrainer.iterate / begin_epoch / end_epoch /
+    init_optimizer (base_trainer.py:205-342) and MultiviewTrainer.pre_step / step / calc_adaptive_rays
+    (multiview_trainer.py:85-180).  Same iteration numbering across epoch boundaries (the first step of a new epoch runs with
+    iteration 0), warm-up call, prune timing, losses, learning-rate schedule, parameters and adaptive ray count.  (On this
+    CPU box the GradScaler of either side is disabled, as torch does without a GPU; the enable_amp branch is still the one
+    executed.  The fp16 + scaler arithmetic itself runs under -m gpu.)"""
+    import math
+    import random
+    import time
+    import test_distributed_gloo as stub
+    from wisp.core import Rays
+    from wisp.datasets.transforms import SampleRays
+    from wisp.trainers import MultiviewTrainer, ConfigMultiviewTrainer, ConfigAdamW
+    g = torch.Generator().manual_seed(3)
+    V, P, STEPS = 5, 96, 13
+    O, D, T = torch.rand(V, P, 3, generator=g) * 2 - 1, torch.randn(V, P, 3, generator=g), torch.rand(V, P, 3, generator=g)
+
+    class _Views:                                              # whole views in a fixed order: both sides see identical batches
+        def __init__(self):
+            self.transform = SampleRays(P)
+        def __len__(self):
+            return V
+    class _Loader:
+        def __len__(self):
+            return V
+        def __iter__(self):
+            return iter([{"rays": Rays(O[i][None], D[i][None]), "rgb": T[i][None]} for i in range(V)])
+
+    def make_cfg():
+        return ConfigMultiviewTrainer(optimizer=ConfigAdamW(lr=1e-2, eps=1e-16, weight_decay=1e-6), grid_lr_weight=10.0,
+                                      max_epochs=3, enable_amp=amp, scheduler=True, scheduler_milestones=(0.3, 0.6),
+                                      scheduler_gamma=0.5, prune_every=2, rgb_loss_type='huber', target_sample_size=2 ** 12)
+
+    def make_pipe():
+        pipe = stub._StubPipeline()
+        pipe.tracer.raymarch_type, pipe.tracer.num_steps, pipe.tracer.prev_num_samples = 'ray', 64, None
+        pipe.nef.grid.raymarch = lambda rays, **kw: types.SimpleNamespace(samples=torch.zeros(64 * 7, 3))
+        pipe.nef.grid.active_lods = [0]
+        return pipe
+
+    # ---- this package's class through its own life cycle
+    pipe_m, prunes_m = make_pipe(), []
+    tr = MultiviewTrainer(make_cfg(), pipe_m, _Views(), device='cpu')
+    tr.train_data_loader = _Loader()
+    pipe_m.nef.prune = lambda: prunes_m.append(tr.total_iterations)
+    tr.is_optimization_running = True
+    losses_m, lrs_m, its_m = [], [], []
+    for _ in range(STEPS):
+        before = tr.tracker.metrics.rgb_loss
+        tr.iterate()
+        its_m.append((tr.epoch, tr.iteration))
+        losses_m.append(tr.tracker.metrics.rgb_loss - before)
+        lrs_m.append([g_["lr"] for g_ in tr.optimizer.param_groups])
+
+    # ---- a trainer made of the reference's method bodies
+    glb = dict(torch=_TorchWithoutNvtx(), math=math, random=random, SampleRays=SampleRays, time=time,
+               instantiate=lambda cfg, params: torch.optim.AdamW(params, lr=cfg.lr, eps=cfg.eps, weight_decay=cfg.weight_decay,
+                                                                 betas=cfg.betas))
+    class _Base:
+        def pre_step(self):
+            pass
+    glb["super"] = lambda: _Base()
+    body = {}
+    for m in ("iterate", "begin_epoch", "end_epoch", "is_first_iteration", "is_any_iterations_remaining", "reset_data_iterator",
+              "next_batch", "init_optimizer"):
+        body[m] = _reference_method("trainers/base_trainer.py", "BaseTrainer", m, glb)
+    for m in ("pre_step", "step", "calc_adaptive_rays"):
+        body[m] = _reference_method("trainers/multiview_trainer.py", "MultiviewTrainer", m, glb)
+    noop = lambda self, *a, **k: None
+    RefTrainer = type("RefTrainer", (), dict(
+        body, pre_training=noop, post_training=noop, post_epoch=noop, post_step=noop, validate=noop,
+        pre_epoch=lambda self: self.tracker.metrics.__dict__.update(total_loss=0.0, rgb_loss=0.0, num_samples=0),
+        total_iterations=property(lambda self: (self.epoch - 1) * self.iterations_per_epoch + self.iteration),   # base_trainer.py:562-567
+        max_iterations=property(lambda self: self.max_epochs * self.iterations_per_epoch)))                       # :583-586
+    pipe_r, prunes_r = make_pipe(), []
+    me = RefTrainer()
+    me.pipeline, me.device, me.cfg, me.enable_amp = pipe_r, 'cpu', make_cfg(), amp
+    me.tracker = types.SimpleNamespace(metrics=types.SimpleNamespace(total_loss=0.0, rgb_loss=0.0, num_samples=0),
+                                       log_metric=lambda *a, **k: None)
+    me.scene_state = types.SimpleNamespace(optimization=types.SimpleNamespace(elapsed_time=0.0, iterations_per_epoch=V))
+    me.train_dataset = _Views()
+    me.train_data_loader, me.train_data_loader_iter = _Loader(), None
+    me.epoch, me.iteration, me.iterations_per_epoch, me.max_epochs = 1, 0, V, me.cfg.max_epochs
+    me.is_optimization_running = True
+    me.init_optimizer()
+    pipe_r.nef.prune = lambda: prunes_r.append(me.total_iterations)
+    losses_r, lrs_r, its_r = [], [], []
+    for _ in range(STEPS):
+        before = me.tracker.metrics.rgb_loss
+        me.iterate()
+        its_r.append((me.epoch, me.iteration))
+        losses_r.append(me.tracker.metrics.rgb_loss - before)
+        lrs_r.append([g_["lr"] for g_ in me.optimizer.param_groups])
+
+    assert its_m == its_r and (2, 0) in its_r                        # iteration numbering incl. the epoch boundary quirk
+    assert prunes_m == prunes_r and len(prunes_r) >= 4
+    assert losses_m[0] == 0.0 and losses_r[0] == 0.0                 # the warm-up call optimises nothing
+    np.testing.assert_allclose(losses_m, losses_r, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(lrs_m, lrs_r, rtol=1e-12)
+    assert lrs_m[0] != lrs_m[-1]                                     # the schedule did fire
+    for (n1, p1), (n2, p2) in zip(pipe_r.nef.named_parameters(), pipe_m.nef.named_parameters()):
+        assert n1 == n2
+        np.testing.assert_allclose(p2.detach().numpy(), p1.detach().numpy(), rtol=1e-6, atol=1e-8, err_msg=n1)
+    assert tr.train_dataset.transform.num_samples == me.train_dataset.transform.num_samples
+    assert [g_["weight_decay"] for g_ in tr.optimizer.param_groups] == [g_["weight_decay"] for g_ in me.optimizer.param_groups]
+
+
 def _torch_optim_groups(kind, param, grad, s1, s2, groups, h0, h1, eps, step, grad_scale=1.0, zero_grad=False):
     """CPU stand-in for the fused optimizer launch (test infrastructure): csrc/misc.hip optim_groups_kernel, kind 'adam'."""
     assert kind == 'adam'
