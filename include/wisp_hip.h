@@ -74,6 +74,15 @@ int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, int feature_
                                           const int32_t* resolutions /* host */, int num_lods,
                                           int codebook_bitwidth);
 
+/* Diagnostic (no counterpart in the reference's bindings): the integer cell, the position inside it and the 2^d corner rows
+ * (relative to the level's first row) that ONE level assigns to every coordinate - the first lines of every reference
+ * hash-grid kernel (wisp/csrc/ops/hashgrid_interpolate_cuda.cu:40-66, hash_utils.cuh:17-105), evaluated by the device code all
+ * kernels of this library share.  cell i32 [n, coord_dim], frac f32 [n, coord_dim], corner_idx i32 [n, 2^coord_dim] or NULL;
+ * corner j = bit (coord_dim-1-a) of j selects the upper neighbour on axis a.  Parity tests compare it with the reference's
+ * kernel bodies on adversarial coordinates (cell faces +- ulps, |c| < 2^-18, +-1, denormals). */
+int wisp_hashgrid_cells(const float* coords, int64_t n, int coord_dim, int32_t resolution, int codebook_bitwidth,
+                        int32_t* cell, float* frac, int32_t* corner_idx, wisp_stream_t stream);
+
 /* Corner query without the blend: wisp._C.ops.hashgrid_query_cuda / hashgrid_query_backward_cuda
  * (wisp/csrc/ops/hashgrid_query_cuda.cu:19-186, hashgrid_query.cpp:41-97, bound in bindings.cpp:31-32; Python callers
  * wisp/ops/grid.py:169-245 - nothing else in the reference uses them).  One codebook [2^codebook_bitwidth, feature_dim] per

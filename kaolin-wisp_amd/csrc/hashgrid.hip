@@ -34,6 +34,7 @@ struct CornerSetup {
     int32_t idx[1 << DIM];
     float coef[1 << DIM];
     int32_t cell[DIM];          // integer coordinates of corner 0
+    float frac[DIM];            // position inside the cell (read by the diagnostic wisp_hashgrid_cells only)
 };
 
 // Position / coefficient / index computation shared by forward and backward.
@@ -55,6 +56,7 @@ static __device__ __forceinline__ void corner_setup(const float* __restrict__ c,
         pos[a] = (int32_t)p;
         cs.cell[a] = pos[a];
         f[a] = x - p;
+        cs.frac[a] = f[a];
         g[a] = 1.0f - f[a];
     }
     // Per-axis partial terms, shared by the corners: index terms for (pos, pos + 1) - (p + 1) * k == p * k + k in uint32
@@ -1287,6 +1289,49 @@ extern "C" int wisp_hashgrid_query_bwd(const float* coords, int64_t n, const voi
     for (int l = 0; l < num_lods; ++l) WISP_REQUIRE(grad_codebooks[l], "null gradient table");
     WISP_REQUIRE(launch_query<true>(coords, n, grad_codebooks, dtype, feature_dim, resolutions, num_lods, codebook_bitwidth,
                                     probe_bitwidth, const_cast<void*>(grad_feats), (hipStream_t)stream) == 0, "bad resolution");
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+// Diagnostic: what corner_setup - the code every hash-grid kernel shares - makes of a coordinate on one level.
+template <int DIM>
+__global__ void __launch_bounds__(256)
+hashgrid_cells_kernel(const float* __restrict__ coords, int64_t n, int32_t res, float hi, float hr, int dense, uint32_t tsize,
+                      int pow2, int32_t* __restrict__ cell, float* __restrict__ frac, int32_t* __restrict__ corner_idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float c[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) c[a] = coords[i * DIM + a];
+    CornerSetup<DIM> cs;
+    corner_setup<DIM>(c, res, hi, hr, dense != 0, tsize, pow2 != 0, cs);
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) { cell[i * DIM + a] = cs.cell[a]; frac[i * DIM + a] = cs.frac[a]; }
+    if (corner_idx) {
+#pragma unroll
+        for (int j = 0; j < (1 << DIM); ++j) corner_idx[i * (1 << DIM) + j] = cs.idx[j];
+    }
+}
+
+extern "C" int wisp_hashgrid_cells(const float* coords, int64_t n, int coord_dim, int32_t resolution, int codebook_bitwidth,
+                                   int32_t* cell, float* frac, int32_t* corner_idx, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0, "negative n");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(coords && cell && frac, "null pointer");
+    WISP_REQUIRE(coord_dim == 2 || coord_dim == 3, "coord_dim must be 2 or 3");
+    WISP_REQUIRE(codebook_bitwidth >= 1 && codebook_bitwidth <= 30, "codebook_bitwidth out of range");
+    HashLevels lv;
+    const int64_t tsize = (int64_t)1 << codebook_bitwidth;
+    WISP_REQUIRE(fill_levels(&resolution, 1, coord_dim, tsize, lv) == 0, "bad resolution");
+    const int pow2 = 1;
+    const dim3 grid((unsigned)ceil_div64(n, 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (coord_dim == 3)
+        hipLaunchKernelGGL(hashgrid_cells_kernel<3>, grid, block, 0, s, coords, n, lv.res[0], lv.hi[0], lv.hr[0], lv.dense[0],
+                           (uint32_t)tsize, pow2, cell, frac, corner_idx);
+    else
+        hipLaunchKernelGGL(hashgrid_cells_kernel<2>, grid, block, 0, s, coords, n, lv.res[0], lv.hi[0], lv.hr[0], lv.dense[0],
+                           (uint32_t)tsize, pow2, cell, frac, corner_idx);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }

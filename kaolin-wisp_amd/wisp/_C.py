@@ -34,6 +34,7 @@ SIGNATURES = {
     "wisp_hashgrid_interpolate_fwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_hashgrid_interpolate_bwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp],
     "wisp_hashgrid_bwd_workspace_bytes": [c_i64, c_i32, c_i32, c_vp, c_i32, c_i32],
+    "wisp_hashgrid_cells": [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
     "wisp_hashgrid_query_fwd": [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_hashgrid_query_bwd": [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_query": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
@@ -272,6 +273,18 @@ def hashgrid_interpolate_backward(coords, grad_feats, codebook_shape, first_idx,
 
 HASHGRID_BWD_WORKSPACE_LIMIT = 24 << 30          # bytes; 288 GB of HBM makes a multi-GB scratch a fair trade
 _bwd_ws = {}
+
+
+def hashgrid_cells(coords, resolution, codebook_bitwidth, with_corners=True):
+    """(cell i32 [N,d], frac f32 [N,d], corner rows i32 [N,2^d] | None) of one level - wisp_hashgrid_cells (diagnostic)."""
+    coords = _need(coords, torch.float32, "coords")
+    n, dim = coords.shape
+    cell = torch.empty(n, dim, dtype=torch.int32, device=coords.device)
+    frac = torch.empty(n, dim, dtype=torch.float32, device=coords.device)
+    corners = torch.empty(n, 1 << dim, dtype=torch.int32, device=coords.device) if with_corners else None
+    _check(lib.wisp_hashgrid_cells(_p(coords), n, dim, int(resolution), int(codebook_bitwidth), _p(cell), _p(frac),
+                                   _p(corners) if corners is not None else None, _stream()), "wisp_hashgrid_cells")
+    return cell, frac, corners
 
 
 def _bwd_workspace(device, nbytes):

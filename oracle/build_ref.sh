@@ -9,7 +9,11 @@ SRC="$REF/wisp/csrc/ops"
 [ -f "$SRC/hashgrid_interpolate_cuda.cu" ] || { echo "reference sources not present at $REF - skipping"; exit 0; }
 mkdir -p "$HERE/_ref"
 # kernels only: stop before the ATen launcher functions (which need CUDA's <<<>>> syntax)
-awk '/^void hashgrid_interpolate_cuda_impl\(/{exit} {print}' "$SRC/hashgrid_interpolate_cuda.cu" > "$HERE/_ref/hashgrid_kernels.inc"
+# (a tap macro after the line that floors the scaled position lets ref_wrap.cpp read the cell the kernel computed:
+#  REF_TAP expands to nothing unless a tap buffer is armed; the reference's own expressions are left untouched)
+awk '/^void hashgrid_interpolate_cuda_impl\(/{exit} {print}' "$SRC/hashgrid_interpolate_cuda.cu" \
+  | sed -e 's/^\( *\)int3 pos = make_int3(floor(x.x), floor(x.y), floor(x.z));$/&\n\1REF_TAP3(i, x, pos);/' > "$HERE/_ref/hashgrid_kernels.inc"
+grep -c "REF_TAP3" "$HERE/_ref/hashgrid_kernels.inc" > /dev/null || { echo "tap injection failed"; exit 1; }
 # uniform sampler: kernel only; give the per-thread body an explicit thread index (tidx is the kernel's only use of the grid)
 awk '/^std::vector<at::Tensor> uniform_sample_cuda_impl\(/{exit} {print}' "$SRC/uniform_sample_cuda.cu" \
   | sed -e 's/^uniform_sample_cuda_kernel(/uniform_sample_cuda_kernel_at(uint tidx_in,/' \

@@ -43,6 +43,26 @@ def clamp(x, a, b):
     return float(lib().ref_clamp(x, a, b))
 
 
+def cells_3d(coords, res, codebook_size=2 ** 19):
+    """(x f32 [N,3], pos i32 [N,3]): the clamped scaled position and its floor exactly as the reference's 3-D interpolation
+    kernel computes them (hashgrid_interpolate_cuda.cu:40-43) - its own code, tapped."""
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    n = coords.shape[0]
+    x = np.empty((n, 3), dtype=np.float32)
+    pos = np.empty((n, 3), dtype=np.int32)
+    lib().ref_cells_3d(ctypes.c_int64(n), ctypes.c_int32(int(res)), ctypes.c_int32(int(codebook_size)), _p(coords), _p(x), _p(pos))
+    return x, pos
+
+
+def fma_cells(coords, res):
+    """Host evaluation of csrc/hashgrid.hip's one-fma position formula (libm fmaf), any shape of float32 coordinates."""
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    x = np.empty(coords.shape, dtype=np.float32)
+    pos = np.empty(coords.shape, dtype=np.int32)
+    lib().fma_cells(ctypes.c_int64(coords.size), ctypes.c_int32(int(res)), _p(coords), _p(x), _p(pos))
+    return x, pos
+
+
 def hashgrid_forward(coords, table, begin_idxes, resolutions, codebook_bitwidth):
     """hashgrid_interpolate_cuda (hashgrid_interpolate.cpp:46-69) with the reference kernels, float32 tables."""
     coords = np.ascontiguousarray(coords, dtype=np.float32)

@@ -4,6 +4,16 @@
 // into oracle/_ref/*.inc (git-ignored; reference sources are never committed) and compiles this file against
 // them and against /root/reference/wisp/csrc/ops/hash_utils.cuh where it lies.
 #include <ATen/ATen.h>
+#include <cmath>
+// tap on the cell computation of the 3-D kernels (armed by ref_cells_3d only): x = the clamped scaled position (float3),
+// pos = its floor (int3), exactly as the reference kernel holds them after hashgrid_interpolate_cuda.cu:40-43
+static thread_local float* g_tap_x = nullptr;
+static thread_local int32_t* g_tap_pos = nullptr;
+#define REF_TAP3(i, x, pos)                                                                          \
+    if (g_tap_x) {                                                                                   \
+        g_tap_x[3 * (i)] = (x).x; g_tap_x[3 * (i) + 1] = (x).y; g_tap_x[3 * (i) + 2] = (x).z;      \
+        g_tap_pos[3 * (i)] = (pos).x; g_tap_pos[3 * (i) + 1] = (pos).y; g_tap_pos[3 * (i) + 2] = (pos).z; \
+    }
 #include "_ref/hashgrid_kernels.inc"
 }   // closes `namespace wisp` left open by the extracted fragment
 #include "_ref/uniform_kernels.inc"
@@ -23,6 +33,30 @@ int32_t ref_hash_index_2d(int x, int y, int32_t resolution, int32_t codebook_siz
     return wisp::hash_index_2d(make_int2(x, y), resolution, resolution, codebook_size);
 }
 float ref_clamp(float x, float a, float b) { return wisp::clamp(x, a, b); }
+
+// The cell arithmetic of the reference's 3-D interpolation kernel on `n` coordinates: its own code runs (feature_dim = 0, so the
+// blend loop has no iterations and no table is read); the tap reports x [n,3] and pos [n,3].
+void ref_cells_3d(int64_t n, int32_t resolution, int32_t codebook_size, const float* coords, float* x_out, int32_t* pos_out) {
+    const int64_t first_idx[2] = {0, 0};
+    g_tap_x = x_out; g_tap_pos = pos_out;
+    wisp::hashgrid_interpolate_3d_cuda_kernel<float>(n, codebook_size, 0, resolution, 0, 1, coords, (const float*)nullptr,
+                                                     first_idx, (float*)nullptr);
+    g_tap_x = nullptr; g_tap_pos = nullptr;
+}
+
+// Host evaluation of THIS package's device formula (csrc/hashgrid.hip corner_setup): ONE fp32 fma per axis instead of the
+// reference's double expression.  Not reference code: it is here because the correctly rounded fmaf lives in libm, and the
+// CPU suite compares it with ref_cells_3d on adversarial coordinates; the GPU suite compares the device with both.
+void fma_cells(int64_t n, int32_t resolution, const float* coords, float* x_out, int32_t* pos_out) {
+    const float hi = (float)((double)(resolution - 1) - 1e-5);
+    const float hr = 0.5f * (float)resolution;
+    for (int64_t i = 0; i < n; ++i) {
+        float x = fmaf(hr, coords[i], hr);
+        x = fmaxf(0.0f, fminf(hi, x));
+        x_out[i] = x;
+        pos_out[i] = (int32_t)floorf(x);
+    }
+}
 
 // one level, float tables: mirrors hashgrid_interpolate_cuda_impl's per-level launch (hashgrid_interpolate_cuda.cu:341-390)
 void ref_hashgrid_fwd_level(int64_t n, int32_t codebook_size, int64_t feature_dim, int32_t resolution, int32_t lod_idx,

@@ -12,6 +12,9 @@ Outputs (small, committed):
   depth_bound_ref_{a,b}.npz - inputs + outputs of the reference find_depth_bound kernel (SDF tracer)
   spc_builders_ref.npz / raygen_ref.npz - outputs of the reference's pointcloud_to_octree / dilate_points and ray-generation
                        FUNCTION BODIES (compiled from the reference files; Kaolin leaves restated by the oracle)
+  hashgrid_cells_ref.npz - the cell arithmetic of the reference's 3-D kernel (its own code, tapped after hashgrid_interpolate_cuda.cu:43)
+                       on the structured adversarial coordinates of tests/adversarial.py: floor(x) for all 16 NGP levels, x itself
+                       for four of them
   spc_kats.npz       - hand-checkable SPC cases (dense level-2 tree, 3-point sparse tree, query / raytrace answers)
                        produced by oracle/spc.py and verified inside this script against brute force in float64
 """
@@ -245,8 +248,25 @@ def spc_vectors():
     np.savez_compressed(os.path.join(OUT, "spc_kats.npz"), **out)
 
 
+def cell_vectors():
+    sys.path.insert(0, os.path.dirname(OUT))
+    import adversarial as adv
+    s = adv.structured_scalars()
+    pts = np.stack([s, s, s], axis=1)
+    pos_all, x_some, x_levels = [], [], [0, 8, 13, 15]
+    for l, res in enumerate(adv.NGP_RES):
+        x, pos = ref_lib.cells_3d(pts, res)
+        assert (pos[:, 0] == pos[:, 1]).all() and (pos[:, 0] == pos[:, 2]).all()
+        pos_all.append(pos[:, 0].astype(np.int16))
+        if l in x_levels:
+            x_some.append(x[:, 0])
+    np.savez_compressed(os.path.join(OUT, "hashgrid_cells_ref.npz"), scalars=s, res=np.asarray(adv.NGP_RES, dtype=np.int32),
+                        pos=np.stack(pos_all), x_levels=np.asarray(x_levels, dtype=np.int32), x=np.stack(x_some))
+
+
 if __name__ == "__main__":
     hashgrid_vectors()
+    cell_vectors()
     query_vectors()
     uniform_vectors()
     depth_bound_vectors()

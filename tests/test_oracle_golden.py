@@ -136,6 +136,58 @@ def test_oracle_vs_live_reference_kernels_nerf_hash_shape():
     assert np.array_equal(got.numpy(), want)
 
 
+def _oracle_cells(scalars, res):
+    """x and floor(x) the oracle's corner_setup holds (oracle/hashgrid.py: the double expression, rounded once)."""
+    c = torch.from_numpy(np.ascontiguousarray(scalars, dtype=np.float32))
+    x = ((c.double() * 0.5 + 0.5) * float(res)).float()
+    x = torch.clamp(x, min=0.0, max=float(np.float32(res - 1 - 1e-5)))
+    return x.numpy(), torch.floor(x).to(torch.int32).numpy()
+
+
+def test_oracle_cell_arithmetic_matches_reference_golden_cells(golden_dir):
+    """Portable pin: floor(x) (all 16 NGP levels) and x (four levels) of the reference's 3-D kernel - its own code, tapped - on
+    the structured adversarial coordinates (every cell face of every level +- 3 ulp, 2^-149 .. 2^1 of either sign, zeros,
+    +-1, beyond +-1): the oracle's restatement gives the same integers and the same floats, bit for bit."""
+    g = np.load(os.path.join(golden_dir, "hashgrid_cells_ref.npz"))
+    s = g["scalars"]
+    assert s.size > 16000
+    xl = {int(l): i for i, l in enumerate(g["x_levels"])}
+    for l, res in enumerate(g["res"]):
+        x, pos = _oracle_cells(s, int(res))
+        assert np.array_equal(pos.astype(np.int16), g["pos"][l]), res
+        if l in xl:
+            assert np.array_equal(x.view(np.uint32), g["x"][xl[l]].view(np.uint32)), res
+
+
+@pytest.mark.skipif(not ref_lib.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_one_fma_cell_formula_equals_reference_kernel_on_1e8_adversarial_coordinates():
+    """csrc/hashgrid.hip scales a coordinate with ONE fp32 fma, fma(res/2, c, res/2), where the reference evaluates
+    float(res * (c * 0.5 + 0.5)) in double (hashgrid_interpolate_cuda.cu:40-42, hash_utils.cuh:107-112).  The argument that the
+    two agree needs |c| >= 2^-18; below that it is a probability.  Here: the reference's own kernel code (tapped right after its
+    floor) against libm's correctly rounded fmaf on > 10^8 (coordinate, level) pairs concentrated where they could differ -
+    1.5 M log-uniform magnitudes in [2^-149, 2^-18) incl. denormals, every cell face of every level +- 3 ulp, powers of two,
+    +-1 and beyond, plus uniform draws - for all 16 NGP resolutions: the scaled position and its integer cell are IDENTICAL,
+    bit for bit, on every pair (so are the eight corner rows, which are integer functions of the cell).  The device side of
+    the claim - the GPU evaluates that fma - is tests/test_gpu_parity.py::test_hashgrid_cells_*."""
+    import adversarial as adv
+    s = np.concatenate([adv.structured_scalars(), adv.random_scalars(1_500_000, 500_000, 100_000, seed=1)])
+    pts = adv.points(s, seed=2)
+    pairs = 0
+    for res in adv.NGP_RES:
+        x, pos = ref_lib.cells_3d(pts, res)
+        fx, fpos = ref_lib.fma_cells(pts, res)
+        assert np.array_equal(pos, fpos), res
+        assert np.array_equal(x.view(np.uint32), fx.view(np.uint32)), res
+        pairs += pts.size
+    assert pairs >= 10 ** 8
+    # the oracle (what every GPU parity test compares with) on the structured part
+    st = adv.structured_scalars()
+    for res in adv.NGP_RES:
+        x, pos = ref_lib.cells_3d(np.stack([st, st, st], 1), res)
+        ox, opos = _oracle_cells(st, res)
+        assert np.array_equal(opos, pos[:, 0]) and np.array_equal(ox.view(np.uint32), x[:, 0].view(np.uint32))
+
+
 def test_spc_kats(golden_dir):
     k = np.load(os.path.join(golden_dir, "spc_kats.npz"))
     oc = spc.points_to_octree(np.array([[0, 0, 0], [3, 3, 3], [2, 1, 0]]), 2)
