@@ -687,7 +687,9 @@ __global__ void __launch_bounds__(256)
 spc_parent_bytes_kernel(const uint8_t* __restrict__ in, int64_t n_parents, uint8_t* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_parents) return;
-    const uint64_t w = *reinterpret_cast<const uint64_t*>(in + i * 8);
+    // a level starts at element (8^l - 1) / 7 of the dense array = 1 mod 8: the eight bytes are NOT 8-byte aligned
+    uint64_t w;
+    __builtin_memcpy(&w, in + i * 8, 8);
     uint32_t b = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) b |= (((w >> (8 * c)) & 0xffull) != 0 ? 1u : 0u) << c;

@@ -1047,16 +1047,30 @@ static size_t small_decoder_lds(int in_dim, int hidden, bool bwd) {
     return f * 4;
 }
 
+// Dynamic LDS beyond the 64 KB default has to be allowed per function AND per device; ask only for what a launch needs
+// (the NeuralSDF decoder needs ~12 KB) and remember the largest grant of every device.
+template <bool BWD>
+static hipError_t small_decoder_allow_lds(size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    static size_t granted[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (bytes <= granted[dev]) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(small_decoder_kernel<BWD>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) granted[dev] = bytes;
+    return e;
+}
+
 extern "C" int wisp_small_decoder_fwd(const float* x, int64_t n, int in_dim, int hidden, const float* w1, const float* b1,
                                       const float* w2, const float* b2, float* out, wisp_stream_t stream) {
     WISP_REQUIRE(n >= 0 && in_dim >= 1 && in_dim <= DEC_MAX_IN && hidden >= 1 && hidden <= SDF_MAX_HIDDEN, "bad sizes (in_dim <= 32, hidden <= 256)");
     if (n == 0) return WISP_OK;
     WISP_REQUIRE(x && w1 && b1 && w2 && b2 && out, "null pointer");
     const int64_t rounds = ceil_div64(n, 256 / SDF_GROUP);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(small_decoder_kernel<false>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (attr != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(attr));
-    hipLaunchKernelGGL(small_decoder_kernel<false>, dim3((unsigned)min64(rounds, 4096)), dim3(256), small_decoder_lds(in_dim, hidden, false),
+    const size_t lds = small_decoder_lds(in_dim, hidden, false);
+    if (const hipError_t attr = small_decoder_allow_lds<false>(lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(attr));
+    hipLaunchKernelGGL(small_decoder_kernel<false>, dim3((unsigned)min64(rounds, 4096)), dim3(256), lds,
                        (hipStream_t)stream, x, n, in_dim, hidden, w1, b1, w2, b2, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
@@ -1070,9 +1084,7 @@ extern "C" int wisp_small_decoder_bwd(const float* x, int64_t n, int in_dim, int
     WISP_REQUIRE(x && w1 && b1 && w2 && b2 && grad_out && grad_x && grad_w1 && grad_b1 && grad_w2 && grad_b2, "null pointer");
     const size_t lds = small_decoder_lds(in_dim, hidden, true);
     WISP_REQUIRE(lds <= 150 * 1024, "decoder too large for the LDS gradient copy");
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(small_decoder_kernel<true>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (attr != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(attr));
+    if (const hipError_t attr = small_decoder_allow_lds<true>(lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(attr));
     const int64_t rounds = ceil_div64(n, 256 / SDF_GROUP);
     // few, long-running workgroups: every one ends with hidden x in_dim global atomics
     hipLaunchKernelGGL(small_decoder_kernel<true>, dim3((unsigned)min64(rounds, 512)), dim3(256), lds, (hipStream_t)stream, x, n,

@@ -33,8 +33,9 @@ class OctreeAS(BaseAS):
         self.octree = octree
         parts = getattr(octree, '_wisp_spc_parts', None)     # set by the device build: hierarchy already derived
         if parts is not None:
-            del octree._wisp_spc_parts
-            self.points, self.pyramid, self.prefix = parts
+            del octree._wisp_spc_parts               # (the derived tensors do not stay attached to the caller's tensor)
+        if parts is not None and (len(parts) == 3 or parts[3] == octree._version):
+            self.points, self.pyramid, self.prefix = parts[:3]      # an in-place edit since the build bumps _version: re-derive
         else:
             self.points, self.pyramid, self.prefix = wisp_spc_ops.octree_to_spc(octree)
         self.max_level = self.pyramid.shape[-1] - 2
@@ -82,7 +83,7 @@ class OctreeAS(BaseAS):
 
     @classmethod
     def _from_spc(cls, octree, points, pyramid, prefix) -> OctreeAS:
-        octree._wisp_spc_parts = (points, pyramid, prefix)
+        octree._wisp_spc_parts = (points, pyramid, prefix, octree._version)
         return cls(octree)
 
     @classmethod

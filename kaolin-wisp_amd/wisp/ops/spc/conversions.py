@@ -52,7 +52,8 @@ def unbatched_points_to_octree(points, level, sorted=False):
     built = build_spc(level, points=points) if points.shape[0] else None
     if built is not None:
         octree = built[0]
-        octree._wisp_spc_parts = built[1:]          # OctreeAS(octree) picks the finished hierarchy up
+        # OctreeAS(octree) picks the finished hierarchy up - if the bytes are still the ones it was derived from
+        octree._wisp_spc_parts = built[1:] + (octree._version,)
         return octree
     m = points_to_morton(points)
     m = torch.unique(m)                     # sorted + deduplicated

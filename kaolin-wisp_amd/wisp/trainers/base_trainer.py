@@ -91,6 +91,13 @@ def instantiate_optimizer(cfg, params):
         ctor = _OPTIMIZERS[key]
     fields = vars(cfg) if not isinstance(cfg, dict) else cfg
     kwargs = {k: v for k, v in fields.items() if k != 'constructor' and not k.startswith('_')}
+    if ctor in (torch.optim.Adam, torch.optim.AdamW) and 'fused' not in kwargs and 'foreach' not in kwargs \
+            and os.environ.get("WISP_TORCH_FUSED_OPTIM", "1") != "0":
+        # torch's single-kernel Adam(W) (same update rule; takes the GradScaler's scale / found_inf inside the kernel) instead of
+        # its default ~12 multi-tensor passes over the 42 MB table: 0.51 -> 0.06 ms per step at nerf_hash.yaml's size on an MI355X
+        tensors = [p for g in params for p in g["params"]]
+        if tensors and all(p.is_cuda and p.dtype == torch.float32 for p in tensors):
+            kwargs['fused'] = True
     return ctor(params, **kwargs)
 
 

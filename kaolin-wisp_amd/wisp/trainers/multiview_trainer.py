@@ -352,6 +352,9 @@ class MultiviewTrainStep:
     def allreduce_grads(self):
         if self.world > 1 or self.force_allreduce:
             n = self._live_grad_numel()
+            if n < self.flat.grad.numel() and os.environ.get("WISP_CHECK_GRAD_TAIL", "0") == "1":
+                # debug switch (a host sync per step): the rows left out of the collective must not have received a gradient
+                assert float(self.flat.grad[n:].abs().max()) == 0.0, "a gradient reached table rows the all-reduce skips"
             dist.all_reduce(self.flat.grad[:n], op=dist.ReduceOp.SUM, group=self.group)     # RCCL over xGMI
 
     def reduce_and_update(self):

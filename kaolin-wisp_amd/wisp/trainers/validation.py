@@ -13,8 +13,21 @@ from wisp.core import Rays, RenderBuffer
 from wisp.ops.image import psnr
 
 
+def assert_master_current(module):
+    """Raise if a sharded-optimizer trainer has left fp32 table rows of `module` stale on this rank (only their bf16 shadow
+    travels between sync_master() calls).  The trainer's guard hangs on the field as a state_dict pre-hook; anything else that
+    reads the fp32 master - pickling the whole pipeline, fp32 evaluation - asks here."""
+    for m in module.modules():
+        for hook in getattr(m, "_state_dict_pre_hooks", {}).values():
+            fn = getattr(hook, "hook", hook)          # torch wraps hooks in a small record in some versions
+            if type(fn).__name__ == "_StaleMasterGuard":
+                fn(m, "", False)
+
+
 def render(pipeline, rays: Rays, lod_idx=None, render_batch=10000, channels=None, amp=False):
     """Full-resolution inference in chunks of `render_batch` rays; RenderBuffer channels concatenated along dim 0."""
+    if not amp:
+        assert_master_current(pipeline)               # fp32 inference reads the master weights, not the shadow
     kw = {} if channels is None else {"channels": channels}
     with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
         if render_batch > 0:
@@ -48,6 +61,7 @@ def save_pipeline(pipeline, path, model_format="full"):
     `pipeline.state_dict()` - the bare OrderedDict, byte-compatible with the reference's loaders
     (`pipeline.load_state_dict(torch.load(path))`).  The occupancy octree and the per-cell occupancy record, which the
     reference's state_dict mode silently drops (OctreeAS tensors are plain attributes), go to the sidecar `path + '.blas'`."""
+    assert_master_current(pipeline)                   # 'full' pickles the parameters directly: no state_dict hook would fire
     if model_format == "full":
         torch.save(pipeline, path)
         return

@@ -246,6 +246,17 @@ def _sharded_worker(rank, world, port, out):
                     ok = False
                 except RuntimeError as e:
                     ok = ok and "sync_master()" in str(e)
+                # ... and so are the paths that never call state_dict(): pickling the whole pipeline ('full' format,
+                # base_trainer.py:354-355) and an fp32 render
+                import io
+                from wisp.trainers import validation
+                for attempt in (lambda: validation.save_pipeline(tr.pipeline, io.BytesIO(), "full"),
+                                lambda: validation.render(tr.pipeline, None, amp=False)):
+                    try:
+                        attempt()
+                        ok = False
+                    except RuntimeError as e:
+                        ok = ok and "sync_master()" in str(e)
                 tr.sync_master()
                 ok = ok and len(tr.pipeline.state_dict()) > 0
             ok = ok and not tr._master_stale and torch.equal(tr.flat.data, ref.flat.data)      # bit for bit the all-reduce run

@@ -188,6 +188,33 @@ def test_one_fma_cell_formula_equals_reference_kernel_on_1e8_adversarial_coordin
         assert np.array_equal(opos, pos[:, 0]) and np.array_equal(ox.view(np.uint32), x[:, 0].view(np.uint32))
 
 
+def test_float_order_alternatives_rarely_move_a_raymarch_candidate(capsys):
+    """scripts/float_order_bound.py on a slice of the flagship shape (512 rays x 2048 candidates against the SynLego level-7
+    occupancy): of the orderings a different Kaolin build could use inside the leaves the oracle had to restate - an FMA'd sample
+    position, 0.5f*(x+1)*res or (x+1)*(res/2) or a double-precision scaling in the point query, |x| = 1 counted as outside - only
+    the FMA moves any candidate to another cell at all (about 2 in a million), and none of them changes an occupancy decision,
+    i.e. ridx / boundary / the sample count.  The full 33.5 M-candidate table is profiles/r03_float_order_bound.txt."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("float_order_bound", os.path.join(root, "scripts", "float_order_bound.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv, sys_argv = ["float_order_bound.py", "512"], __import__("sys").argv
+    __import__("sys").argv = argv
+    try:
+        mod.main()
+    finally:
+        __import__("sys").argv = sys_argv
+    rows = {}
+    for line in capsys.readouterr().out.splitlines()[2:]:
+        name, count, rate = line.rsplit(None, 2)
+        rows[name.strip()] = (int(count), float(rate))
+    assert rows["q1 0.5f*(x+1)*res: cell"][0] == 0 and rows["q2 (x+1)*(res/2): cell"][0] == 0     # power-of-two scalings commute with rounding
+    assert rows["pos_fma: cell"][1] < 2e-5 and rows["q3 double, one rounding: cell"][1] < 2e-5
+    for k in ("pos_fma: occupancy", "q1: occupancy", "q2: occupancy", "q3: occupancy", "x == +-1 outside: occupancy"):
+        assert rows[k][1] < 5e-6, (k, rows[k])
+
+
 def test_spc_kats(golden_dir):
     k = np.load(os.path.join(golden_dir, "spc_kats.npz"))
     oc = spc.points_to_octree(np.array([[0, 0, 0], [3, 3, 3], [2, 1, 0]]), 2)
