@@ -17,6 +17,8 @@ def assert_master_current(module):
     """Raise if a sharded-optimizer trainer has left fp32 table rows of `module` stale on this rank (only their bf16 shadow
     travels between sync_master() calls).  The trainer's guard hangs on the field as a state_dict pre-hook; anything else that
     reads the fp32 master - pickling the whole pipeline, fp32 evaluation - asks here."""
+    if not isinstance(module, torch.nn.Module):
+        return
     for m in module.modules():
         for hook in getattr(m, "_state_dict_pre_hooks", {}).values():
             fn = getattr(hook, "hook", hook)          # torch wraps hooks in a small record in some versions
