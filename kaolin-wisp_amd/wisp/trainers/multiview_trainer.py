@@ -16,6 +16,7 @@ import weakref
 from dataclasses import dataclass
 from typing import Optional
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -84,17 +85,23 @@ class FlatParams:
             mark_shadow_current(p)
 
 
-class _DirectHashNeRFStep:
-    """The forward + loss + backward of MultiviewTrainStep.step for the nerf_hash.yaml pipeline shape (OctreeAS 'ray' march,
-    'cat' HashGrid, the fused 64-wide decoder, PackedRFTracer without extra channels), issued as the same HIP launches in the
-    same order as Pipeline.forward + autograd would issue them - minus the nn.Module / channel-negotiation / autograd-engine
-    plumbing, which costs more host time per step than the GPU needs for a 2^18-sample batch.  Results are identical to the
-    modular path (tests/test_gpu_parity.py::test_direct_step_equals_modular_step)."""
+class _DirectNeRFStep:
+    """The forward + loss + backward of MultiviewTrainStep.step for NeuralRadianceField + PackedRFTracer pipelines over an
+    OctreeAS, issued as the same HIP launches in the same order as Pipeline.forward + autograd would issue them - minus the
+    nn.Module / channel-negotiation / RenderBuffer / autograd-engine plumbing, which costs more host time per step than the
+    GPU needs for a 2^18-sample batch (and left the GPU idle a quarter of the time in the 'voxel' configurations).
+
+    Two tiers:
+      * everything but the grid is always issued directly: raymarch ('ray' with a prefetched occupancy count, 'voxel' and
+        'uniform' through OctreeAS.raymarch), fused decoder forward / backward, compositing forward / backward, loss;
+      * the grid lookup is issued directly for the nerf_hash.yaml shape ('cat' HashGrid whose table gradient lives in the flat
+        buffer); any other grid of the plugin surface (OctreeGrid, CodebookOctreeGrid, TriplanarGrid, 'sum' HashGrid) keeps its own
+        `interpolate` - one small autograd graph whose backward is seeded with the decoder's input gradient.
+    Results are identical to the modular path (tests/test_gpu_parity.py::test_direct_step_equals_modular_step)."""
 
     @staticmethod
     def supports(pipeline):
         from wisp.accelstructs import OctreeAS
-        from wisp.models.grids import HashGrid
         from wisp.models.nefs import NeuralRadianceField
         from wisp.tracers import PackedRFTracer
         from wisp.ops.nerf_mlp import SUPPORTED
@@ -102,37 +109,68 @@ class _DirectHashNeRFStep:
         if type(nef) is not NeuralRadianceField or type(tracer) is not PackedRFTracer:
             return False
         grid = nef.grid
-        if type(grid) is not HashGrid or grid.multiscale_type != 'cat' or type(grid.blas) is not OctreeAS:
+        if grid is None or type(getattr(grid, 'blas', None)) is not OctreeAS or grid.blas.max_level > 10:
             return False
-        if getattr(tracer, 'raymarch_type', None) != 'ray' or grid.blas.max_level > 10:
+        if getattr(tracer, 'raymarch_type', None) not in ('ray', 'voxel', 'uniform'):
             return False
         return (nef.fused_decoder and nef.hidden_dim == SUPPORTED["hidden"] and nef.num_layers == 1      # (hidden 128: modular path)
                 and nef.view_multires == SUPPORTED["view_freqs"] and nef.pos_embedder is None
                 and nef.view_embedder_type == 'positional' and nef.activation_type == 'relu'
                 and nef.layer_type in ('linear', 'none') and 1 <= nef.effective_feature_dim() <= SUPPORTED["max_in_dim"]
-                and all(t is not None for t in _decoder_tensors(nef))
                 and getattr(nef, 'decoder_compute', 'auto') == 'auto')
 
     def __init__(self, trainer):
-        from wisp.ops.nerf_mlp import _flat_view, SUPPORTED
+        from wisp.models.grids import HashGrid
+        from wisp.ops.nerf_mlp import _flat_view, _pack, SUPPORTED
         self.t = trainer
         nef = trainer.pipeline.nef
         grid = nef.grid
-        self.shape = (nef.effective_feature_dim(), SUPPORTED["hidden"], SUPPORTED["view_freqs"])
+        H, I = SUPPORTED["hidden"], nef.effective_feature_dim()
+        self.shape = (I, H, SUPPORTED["view_freqs"])
+        self.param_shapes = ((H, I), (H,), (16, H), (16,), (H, 42), (H,), (H, H), (H,), (3, H), (3,))
         dec = _decoder_tensors(nef)
-        self.packed = _flat_view([p.detach() for p in dec])                  # zero-copy views of the flat buffers
-        self.packed_grad = _flat_view([p.grad for p in dec])
-        cb = grid.codebook
-        self.table = cb.feats
-        self.first_idx = cb.begin_idxes
-        self.res = [int(r) for r in cb.resolutions.reshape(-1).tolist()]
-        self.bitwidth = grid.codebook_bitwidth
-        # the tracer queries lod_idx = num_lods - 1 and 'cat' zeroes the columns from lod_idx * feature_dim on
-        # (reference hash_grid.py:226-229): the finest level's columns are zero, exactly as in the modular path
-        self.zero_from_col = (grid.num_lods - 1) * grid.feature_dim
-        self.ok = self.packed is not None and self.packed_grad is not None
+        self.dec = dec
+        self.biasless = any(t is None for t in dec)                          # nerf_codebook.yaml: decoders without bias
+        if not self.biasless:
+            self.packed = _flat_view([p.detach() for p in dec])              # zero-copy views of the flat buffers
+            self.packed_grad = _flat_view([p.grad for p in dec])
+            self.ok = self.packed is not None and self.packed_grad is not None
+        else:
+            # absent biases are zero rows of the packed parameter vector; their gradient slots are scratch
+            self.packed = self.packed_grad = None
+            self._scratch_grad = torch.zeros(sum(int(np.prod(sh)) for sh in self.param_shapes), dtype=torch.float32,
+                                             device=trainer.flat.data.device)
+            self.ok = all(p is None or p.grad is not None for p in dec)
+        self.hash_fast = type(grid) is HashGrid and grid.multiscale_type == 'cat' and grid.codebook.feats.grad is not None
+        if self.hash_fast:
+            cb = grid.codebook
+            self.table = cb.feats
+            self.first_idx = cb.begin_idxes
+            self.res = [int(r) for r in cb.resolutions.reshape(-1).tolist()]
+            self.bitwidth = grid.codebook_bitwidth
+            # the tracer queries lod_idx = num_lods - 1 and 'cat' zeroes the columns from lod_idx * feature_dim on
+            # (reference hash_grid.py:226-229): the finest level's columns are zero, exactly as in the modular path
+            self.zero_from_col = (grid.num_lods - 1) * grid.feature_dim
         self._pending = None
 
+    # ---- decoder parameters ------------------------------------------------------------------------------------------
+    def _params(self):
+        if not self.biasless:
+            return self.packed, self.packed_grad
+        from wisp.ops.nerf_mlp import _pack
+        self._scratch_grad.zero_()
+        return _pack(self.dec, self.param_shapes), self._scratch_grad
+
+    def _scatter_param_grads(self, g):
+        """bias-free decoders: the kernel wrote one packed gradient vector; add its weight segments to the parameters' .grad"""
+        off = 0
+        for p, sh in zip(self.dec, self.param_shapes):
+            n = int(np.prod(sh))
+            if p is not None:
+                p.grad.add_(g[off:off + n].view(sh))
+            off += n
+
+    # ---- raymarch ------------------------------------------------------------------------------------------------------
     def _count(self, rays, jitter, seed=None):
         C = _hip()
         pipe = self.t.pipeline
@@ -140,7 +178,8 @@ class _DirectHashNeRFStep:
         if torch.is_tensor(rays.dist_min) or torch.is_tensor(rays.dist_max):
             raise TypeError("'ray' raymarch needs scalar Rays.dist_min / dist_max (as the reference, octree_as.py:276-277)")
         blas._to_device(rays.origins.device)
-        level = blas.max_level
+        grid = pipe.nef.grid
+        level = grid.active_lods[grid.num_lods - 1]        # what PackedRFTracer.trace marches at (lod_idx = num_lods - 1)
         coarse, lc = blas._coarse_bitfield(rays, pipe.tracer.num_steps, level)
         st = C.raymarch_ray_count(blas._bitfield(level), blas.octree, blas.prefix, rays.origins, rays.dirs, rays.dist_min,
                                   rays.dist_max, pipe.tracer.num_steps, level, jitter,
@@ -148,46 +187,70 @@ class _DirectHashNeRFStep:
         st["rays"], st["blas"] = rays, blas
         return st
 
+    def _march(self, rays, jitter, prefetch, coded):
+        """-> ridx, samples, deltas, per-ray sample offsets, per-sample view directions (None when `coded`)"""
+        C = _hip()
+        pipe = self.t.pipeline
+        tracer, grid = pipe.tracer, pipe.nef.grid
+        blas = grid.blas
+        if tracer.raymarch_type == 'ray' and blas._bitfield(grid.active_lods[grid.num_lods - 1]) is not None:
+            st, self._pending = self._pending, None
+            if st is None or st["rays"] is not rays or jitter is not None:
+                st = self._count(rays, jitter)                # nothing was prefetched for this batch
+            elif st["blas"] is not blas:
+                st = self._count(rays, None, seed=st["seed"])  # the octree was pruned since: redo it (same jitter stream)
+            if coded:
+                ridx, samples, depths, deltas, boundary, offsets = C.raymarch_ray_finish(st)
+                dirs = None
+            else:
+                ridx, samples, depths, deltas, boundary, offsets, dirs = C.raymarch_ray_finish(st, with_dirs=True)
+            if prefetch is not None:
+                self._pending = self._count(prefetch, None)
+            return ridx, samples, deltas, offsets, dirs
+        self._pending = None
+        kw = {} if (jitter is None or tracer.raymarch_type == 'uniform') else {"jitter": jitter}
+        rm = grid.raymarch(rays, level=grid.active_lods[grid.num_lods - 1], num_samples=tracer.num_steps,
+                           raymarch_type=tracer.raymarch_type, **kw)
+        dirs = None if coded else rays.dirs.index_select(0, rm.ridx)
+        return rm.ridx, rm.samples, rm.deltas, rm.ray_offsets, dirs
+
     def run(self, rays, img_gts, jitter=None, prefetch=None):
-        """-> (loss tensor, num_samples); gradients are left accumulated in the flat gradient buffer.
-        `prefetch`: the Rays of the NEXT step; their parameter-free prefix (occupancy test + offsets) is issued now, behind
-        this step's own raymarch, so that the next step finds its sample count already computed instead of stalling the GPU
-        on the size read-back."""
+        """-> (loss tensor, num_samples); gradients are left accumulated in the parameters' .grad (the flat gradient buffer).
+        `prefetch`: the Rays of the NEXT step; with the 'ray' march their parameter-free prefix (occupancy test + offsets) is
+        issued now, behind this step's own raymarch, so that the next step finds its sample count already computed instead of
+        stalling the GPU on the size read-back."""
         C = _hip()
         t = self.t
         pipe = t.pipeline
         nef, tracer = pipe.nef, pipe.tracer
-        blas = nef.grid.blas
+        grid = nef.grid
         dev = rays.origins.device
         N = rays.origins.shape[0]
-        st, self._pending = self._pending, None
-        if st is None or st["rays"] is not rays or jitter is not None:
-            st = self._count(rays, jitter)                # nothing was prefetched for this batch
-        elif st["blas"] is not blas:
-            st = self._count(rays, None, seed=st["seed"])  # the octree was pruned since: redo it (same jitter stream)
         # view directions: encoded once per ray and gathered by ray index inside the decoder kernels where that variant exists
-        # (the training shape), else gathered per sample by the raymarch
+        # (the training shape), else gathered per sample
         i, h, f = self.shape
         coded = C.nerf_mlp_rays_supported(torch.bfloat16 if t.enable_amp else torch.float32, i, h, f, t.enable_amp)
-        if coded:
-            ridx, samples, depths, deltas, boundary, offsets = C.raymarch_ray_finish(st)
-            dirs, ray_code = None, None
-        else:
-            ridx, samples, depths, deltas, boundary, offsets, dirs = C.raymarch_ray_finish(st, with_dirs=True)
-            ray_code = None
-        if prefetch is not None:
-            self._pending = self._count(prefetch, None)
+        ridx, samples, deltas, offsets, dirs = self._march(rays, jitter, prefetch, coded)
         S = samples.shape[0]
         tracer.prev_num_samples = S
         t.wait_for_parameters()                 # everything above overlapped the previous step's all-reduce + update
-        table = self.table
-        if t.enable_amp:
-            shadow = current_shadow(table, torch.bfloat16)
-            table = shadow if shadow is not None else table.to(torch.bfloat16)
-        feats = C.hashgrid_interpolate(samples, table.detach(), self.first_idx, self.res, self.bitwidth, self.zero_from_col)
-        if coded:
-            ray_code = (ridx, C.nerf_mlp_dir_code(rays.dirs, f))
-        color, density = C.nerf_mlp_forward(feats, dirs, self.packed, i, h, f, t.enable_amp, ray_code=ray_code)
+        if self.hash_fast:
+            table = self.table
+            if t.enable_amp:
+                shadow = current_shadow(table, torch.bfloat16)
+                table = shadow if shadow is not None else table.to(torch.bfloat16)
+            feats = C.hashgrid_interpolate(samples, table.detach(), self.first_idx, self.res, self.bitwidth, self.zero_from_col)
+            feats_in = feats
+        else:
+            # any other grid: its own interpolate (one small autograd graph), evaluated like Pipeline.forward would
+            with torch.enable_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=t.enable_amp):
+                feats = grid.interpolate(samples, grid.num_lods - 1).reshape(S, i)
+            feats_in = feats.detach()
+            if not feats_in.is_contiguous():
+                feats_in = feats_in.contiguous()
+        packed, packed_grad = self._params()
+        ray_code = (ridx, C.nerf_mlp_dir_code(rays.dirs, f)) if coded else None
+        color, density = C.nerf_mlp_forward(feats_in, dirs, packed, i, h, f, t.enable_amp, ray_code=ray_code)
         if tracer.bg_color.device != dev:
             tracer.bg_color = tracer.bg_color.to(dev)
         bg = tracer._bg_host()
@@ -198,10 +261,15 @@ class _DirectHashNeRFStep:
         loss, g_rgb = C.rgb_loss(rgb, img_gts, t.rgb_loss_type)
         loss = loss[0]
         g_color, g_density = C.composite_bwd(g_rgb, None, None, color, density, deltas, None, None, offsets, bg)
-        g_feats, _ = C.nerf_mlp_backward(feats, dirs, self.packed, g_color, g_density, i, h, f, t.enable_amp,
-                                         grad_params=self.packed_grad, ray_code=ray_code)
-        C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res, self.bitwidth,
-                                        self.zero_from_col, out=self.table.grad)
+        g_feats, _ = C.nerf_mlp_backward(feats_in, dirs, packed, g_color, g_density, i, h, f, t.enable_amp,
+                                         grad_params=packed_grad, ray_code=ray_code)
+        if self.biasless:
+            self._scatter_param_grads(packed_grad)
+        if self.hash_fast:
+            C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res, self.bitwidth,
+                                            self.zero_from_col, out=self.table.grad)
+        elif feats.requires_grad:
+            feats.backward(g_feats.to(feats.dtype))
         return loss, S
 
 
@@ -288,8 +356,8 @@ class MultiviewTrainStep:
         # specialised issue order for the flagship pipeline shape (WISP_DIRECT_STEP=0 keeps the modular path)
         self._direct = None
         self._last_step_modular = True
-        if os.environ.get("WISP_DIRECT_STEP", "1") != "0" and _DirectHashNeRFStep.supports(pipeline):
-            d = _DirectHashNeRFStep(self)
+        if os.environ.get("WISP_DIRECT_STEP", "1") != "0" and _DirectNeRFStep.supports(pipeline):
+            d = _DirectNeRFStep(self)
             self._direct = d if d.ok else None
 
     # -------------------------------------------------------------------------------------------- schedule / groups
@@ -334,7 +402,7 @@ class MultiviewTrainStep:
         rows - the tail of the buffer when the table is its last tensor - never receive a gradient and need not travel:
         4 MB of the 41.8 MB of nerf_hash.yaml.  (Their weight decay is the same arithmetic on every rank.)"""
         f, d = self.flat, getattr(self, "_direct", None)
-        if d is None or getattr(self, "_last_step_modular", True):
+        if d is None or not d.hash_fast or getattr(self, "_last_step_modular", True):
             return f.grad.numel()
         a, b = f.ranges["grid"]
         ra, rb = f.ranges["rest"]

@@ -383,7 +383,7 @@ def test_allreduce_range_leaves_out_only_a_gradient_free_tail():
         m = Field(with_rest)
         t = MultiviewTrainStep.__new__(MultiviewTrainStep)
         t.flat = FlatParams(m)
-        t._direct = types.SimpleNamespace(table=m.grid_table, zero_from_col=2 * 2, res=[4, 8, 16],
+        t._direct = types.SimpleNamespace(hash_fast=True, table=m.grid_table, zero_from_col=2 * 2, res=[4, 8, 16],
                                           first_idx=torch.tensor([0, 10, 30, 60]))
         t._last_step_modular = False
         return t, m
@@ -399,6 +399,9 @@ def test_allreduce_range_leaves_out_only_a_gradient_free_tail():
     assert t._live_grad_numel() == t.flat.grad.numel()
     t2, _ = trainer(True)                                                               # a tensor after the table
     assert t2._live_grad_numel() == t2.flat.grad.numel()
+    t3, _ = trainer(False)
+    t3._direct.hash_fast = False                                                        # another grid's own backward: no assumption
+    assert t3._live_grad_numel() == t3.flat.grad.numel()
 
 
 def test_hashgrid_backward_workspace_query_is_sane_without_a_gpu():

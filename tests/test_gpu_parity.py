@@ -1245,6 +1245,77 @@ def test_direct_step_equals_modular_step(amp, monkeypatch):
         assert abs(float(l1) - float(l2)) <= 1e-3 * max(1.0, abs(float(l2)))
 
 
+@pytest.mark.parametrize("amp", [False, True])
+@pytest.mark.parametrize("march,steps", [("voxel", 6), ("uniform", 96), ("ray", 96)])
+@pytest.mark.parametrize("kind", ["hash", "octree", "codebook"])
+def test_direct_step_equals_modular_step_every_march_and_grid(kind, march, steps, amp, monkeypatch):
+    """The direct-issue step for everything else the plugin surface offers: the 'voxel' and 'uniform' marches
+    (octree_as.py:188-245, 311-374; BASELINE configs 4 and 5 march 'voxel') and the OctreeGrid / CodebookOctreeGrid fields
+    (nerf_octree.yaml, nerf_codebook.yaml: 5 'sum' features, the codebook one without decoder biases, RMSprop) - against the
+    modular Pipeline.forward + autograd step from the same state with the same in-kernel jitter seed: same sample count, loss,
+    and every gradient in the flat buffer."""
+    import copy
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.models.grids import CodebookOctreeGrid, OctreeGrid
+    from wisp.models.nefs import NeuralRadianceField
+    from wisp.tracers import PackedRFTracer
+    from wisp.trainers import MultiviewTrainStep
+    if kind == "hash":
+        if march == "ray":
+            pytest.skip("covered by test_direct_step_equals_modular_step")
+        nef, _, _ = _build_pair(lods=16)
+    else:
+        blas, _ = _sparse_blas(5, 3000, 131)
+        torch.manual_seed(3)
+        if kind == "octree":
+            grid = OctreeGrid(blas, feature_dim=5, num_lods=4, multiscale_type='sum', feature_std=0.5)
+        else:
+            grid = CodebookOctreeGrid(blas, feature_dim=5, num_lods=4, multiscale_type='sum', feature_std=0.7, codebook_bitwidth=4)
+        nef = NeuralRadianceField(grid, view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1,
+                                  bias=(kind == "octree")).to(DEV)
+        with torch.no_grad():
+            for n, p in nef.named_parameters():
+                if 'decoder' in n:
+                    p.mul_(2.0)
+    nef2 = copy.deepcopy(nef)
+    o, d = make_rays(400, 291)
+    gts = cuda(np.random.default_rng(293).uniform(size=(400, 3)).astype(np.float32))
+    rays = Rays(cuda(o), cuda(d), dist_min=1.0, dist_max=5.0)
+    opt = dict(optimizer='rmsprop', eps=1e-8, weight_decay=0.0, grid_lr_weight=100.0, rgb_loss_type='l2') if kind == "codebook" else {}
+    tr1 = MultiviewTrainStep(Pipeline(nef, PackedRFTracer(raymarch_type=march, num_steps=steps, bg_color=(1.0, 1.0, 1.0))),
+                             prune_every=-1, enable_amp=amp, **opt)
+    assert tr1._direct is not None and tr1._direct.hash_fast == (kind == "hash")
+    monkeypatch.setenv("WISP_DIRECT_STEP", "0")
+    tr2 = MultiviewTrainStep(Pipeline(nef2, PackedRFTracer(raymarch_type=march, num_steps=steps, bg_color=(1.0, 1.0, 1.0))),
+                             prune_every=-1, enable_amp=amp, **opt)
+    assert tr2._direct is None
+    grads = {}
+    for name, tr in (("direct", tr1), ("modular", tr2)):
+        def snap(tr=tr, name=name):
+            grads[name] = tr.flat.grad.clone()
+            tr.flat.grad.zero_()
+        tr.optimizer_step = snap
+    torch.manual_seed(11)
+    l1, s1 = tr1.step(rays, gts)
+    torch.manual_seed(11)                                   # the marches draw their jitter seed from torch's generator
+    l2, s2 = tr2.step(rays, gts)
+    assert s1 == s2 > 1000 and abs(float(l1) - float(l2)) <= 2e-6 * max(1.0, abs(float(l2)))
+    g1, g2 = grads["direct"].cpu().numpy(), grads["modular"].cpu().numpy()
+    scale = float(np.abs(g2).max())
+    assert scale > 0 and np.abs(g2).astype(bool).mean() > 0.001
+    np.testing.assert_allclose(g1, g2, rtol=0, atol=(2e-6 if not amp else 1e-5) * scale)
+    # and real optimisation steps stay together
+    del tr1.optimizer_step, tr2.optimizer_step
+    for k in range(3):
+        torch.manual_seed(20 + k)
+        l1, s1 = tr1.step(rays, gts)
+        torch.manual_seed(20 + k)
+        l2, s2 = tr2.step(rays, gts)
+        assert s1 == s2 and tr1.num_rays == tr2.num_rays
+        assert abs(float(l1) - float(l2)) <= 1e-3 * max(1.0, abs(float(l2)))
+
+
 def test_training_psnr_parity_with_oracle():
     """Same initial weights, same ray batches, same jitter: after 120 AdamW steps the HIP path and the CPU oracle reach
     the same PSNR on the training rays within 0.1 dB (north-star bound)."""
