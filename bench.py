@@ -63,6 +63,7 @@ def parse():
                     help="nerf_hash = BASELINE.json's metric configuration (C2; the driver's line); v8 / vqad / nglod = the other "
                          "configs on their synthetic stand-ins (bench_configs.py), one GPU, secondary lines")
     ap.add_argument("--sdf-batch", type=int, default=512, help="nglod: coordinates per step (nglod_octree.yaml:78)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short secondary-configuration runs (`configs` in the line)")
     ap.add_argument("--dropin-steps", type=int, default=100,
                     help="timed iterations of the reference trainer's own step (fp16 autocast + GradScaler + torch.optim), reported "
                          "as dropin_regime; 0 skips it")
@@ -113,6 +114,92 @@ def cpu_baseline(blas_cells, hidden, num_steps, budget_s=20.0):
     return dict(value=R * n / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{n} oracle train steps of {R} rays x {num_steps} candidates ({samples // max(n,1)} packed samples/step), "
                        f"fp32, torch-CPU + numpy, {dt:.1f}s")
+
+
+def collective_selftest(dev, rank):
+    """Every collective the training step will issue, once, on small tensors, checked against host arithmetic - BEFORE anything
+    is timed: the first multi-GPU run of this code must not be the first time RCCL sees these calls.  All ranks agree on the
+    verdict (an all-reduce of the flags).  -> dict(rccl_ranks, allreduce_ok, sharded_path_ok)."""
+    world = dist.get_world_size()
+    tri = world * (world + 1) / 2.0
+    ok = {}
+    x = torch.full((1024,), float(rank + 1), device=dev)
+    dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    ok["allreduce_ok"] = bool((x == tri).all())
+    try:
+        src = torch.arange(world * 256, device=dev, dtype=torch.float32) * float(rank + 1)
+        got = torch.empty(256, device=dev)
+        dist.reduce_scatter_tensor(got, src, op=dist.ReduceOp.SUM)
+        want = torch.arange(rank * 256, (rank + 1) * 256, device=dev, dtype=torch.float32) * tri
+        rs = bool(torch.equal(got, want))
+        own = torch.full((256,), float(rank), device=dev, dtype=torch.bfloat16)
+        full = torch.empty(world * 256, device=dev, dtype=torch.bfloat16)
+        dist.all_gather_into_tensor(full[:world * 256], own)
+        ag = bool(torch.equal(full.float().view(world, 256), torch.arange(world, device=dev, dtype=torch.float32)[:, None].expand(world, 256)))
+        ok["sharded_path_ok"] = rs and ag
+    except Exception as e:                                   # a hard RCCL failure would abort the process; this catches the soft ones
+        ok["sharded_path_ok"] = False
+        ok["sharded_path_error"] = f"{type(e).__name__}: {e}"
+    flags = torch.tensor([float(ok["allreduce_ok"]), float(ok["sharded_path_ok"])], device=dev)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    ok["allreduce_ok"], ok["sharded_path_ok"] = bool(flags[0] > 0), bool(flags[1] > 0)
+    ok["rccl_ranks"] = world
+    assert ok["allreduce_ok"], "RCCL all-reduce returned wrong sums"
+    return ok
+
+
+def hidden128_line(args, dev, pipe, batch, size_batch, steps=30):
+    """nerf_hash.yaml with hidden_dim 128 - the reference's best published row (docs/pages/app_nerf.md:185-192) - on the
+    occupancy the main run has learned: a fresh model of that width over a copy of the current octree, a few steps at the
+    headline batch size (modular issue: the direct step covers hidden 64)."""
+    from wisp.accelstructs import OctreeAS
+    from wisp.models import Pipeline
+    from wisp.models.grids import HashGrid
+    from wisp.models.nefs import NeuralRadianceField
+    from wisp.tracers import PackedRFTracer
+    from wisp.trainers import MultiviewTrainStep
+    import wisp._C as C
+    try:
+        blas = OctreeAS(pipe.nef.grid.blas.octree.clone())
+        torch.manual_seed(0)
+        grid = HashGrid.from_geometric(blas, **NGP)
+        nef = NeuralRadianceField(grid, pos_embedder='none', view_embedder='positional', view_multires=4, activation_type='relu',
+                                  layer_type='linear', hidden_dim=128, num_layers=1, bias=True, prune_density_decay=None,
+                                  prune_min_density=None).to(dev)
+        wide = Pipeline(nef, PackedRFTracer(raymarch_type='ray', num_steps=args.num_steps, step_size=1.0, bg_color=(0.0, 0.0, 0.0)))
+        tr = MultiviewTrainStep(wide, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, rgb_loss_type='huber',
+                                prune_every=-1, target_sample_size=args.target_samples, max_rays=2 ** 18, enable_amp=args.precision == "bf16")
+        probe, _ = batch(4096)
+        rm = grid.raymarch(probe, level=grid.active_lods[-1], num_samples=args.num_steps, raymarch_type='ray')
+        wide.tracer.prev_num_samples = rm.samples.shape[0]
+        R = max(256, tr.calc_adaptive_rays(4096))
+        for _ in range(5):
+            rays, gts = batch(R)
+            tr.step(rays, gts)
+        C.TIMING_ALL = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        samples = 0
+        for _ in range(steps):
+            rays, gts = batch(R)
+            _, ns = tr.step(rays, gts)
+            samples += ns
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sink, C.TIMING_ALL = C.TIMING_ALL, None
+        k = {n.replace("wisp_", ""): float(np.mean([a.elapsed_time(b) for a, b in ev])) for n, ev in sink.items()}
+        S = samples / steps
+        flop = 2 * (32 * 128 + 16 * 128 + 42 * 128 + 128 * 128 + 3 * 128)              # 56 576 per sample forward
+        roof = {}
+        for name, mult in (("nerf_mlp_fwd", 1), ("nerf_mlp_bwd", 3)):
+            if name in k:
+                tf = mult * flop * S / (k[name] * 1e-3) / 1e12
+                roof[name] = {"avg_ms": k[name], "bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}
+        return {"metric": "training rays/sec, HashGrid NeRF hidden 128", "value": R * steps / dt, "unit": "rays/s",
+                "ms_per_step": 1e3 * dt / steps, "steps": steps, "rays_per_step": R, "samples_per_step": S, "roofline": roof,
+                "top_launches": dict(sorted(k.items(), key=lambda kv: -kv[1])[:5])}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev):
@@ -240,6 +327,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)          # nccl == RCCL on ROCm
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    selftest = collective_selftest(dev, rank) if dist.is_initialized() else None
+    if selftest is not None and not selftest["sharded_path_ok"]:
+        os.environ["WISP_SHARDED_OPTIM"] = "0"             # reduce-scatter / all-gather misbehave here: keep the all-reduce path
 
     import synlego
     import wisp._C as C
@@ -337,7 +427,14 @@ def main():
         return v
 
     timing = {}                                           # HIP-event timing of the hot kernels, live, on the launch stream
+    if world > 1 or trainer.force_allreduce:
+        trainer.comm_timing = []                          # per-step events around the collectives and the optimizer (side stream)
     elapsed, total_samples, prunes_in = timed_steps(R, args.warmup, args.steps, timing)
+    comm = trainer.comm_summary()
+    trainer.comm_timing = None
+    if comm is not None:
+        comm["selftest"] = selftest
+        comm["grad_bytes_on_the_wire_per_step"] = 4 * min(trainer._live_grad_numel(), trainer.flat.grad.numel())
     total_samples_all = all_sum(total_samples)
     blas_now = pipe.nef.grid.blas
     cells_now = int(blas_now.pyramid[0, blas_now.max_level])          # leaf cells of the (pruned) octree
@@ -428,7 +525,7 @@ def main():
                                  "ms_per_step": 1e3 * ref_elapsed / args.steps, "samples_per_sec": ref_samples_all / ref_elapsed,
                                  "prunes_inside_timed_steps": ref_prunes,
                                  "note": "multiview_trainer.py:58 default batch (2^18 packed samples per step), same run"},
-            "dropin_regime": dropin,
+            "dropin_regime": dropin, "comm": comm,
             "psnr_db": psnr, "optimisation_steps_before_psnr": trainer.total_iterations,
             "roofline": roofline,
         }
@@ -436,6 +533,11 @@ def main():
             traffic, note = live_pmc_traffic(args, PMC_KERNELS[roofline["kernel"]])
             roofline["traffic"] = traffic
             roofline["traffic_note"] = note
+        if world == 1 and not args.no_configs:
+            # the other BASELINE.json configurations + the reference's best published row (hidden 128), a few steps each
+            import bench_configs
+            out["configs"] = bench_configs.secondary_lines(args, dev)
+            out["configs"]["hidden128"] = hidden128_line(args, dev, pipe, batch, size_batch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(true_cells, args.hidden, args.num_steps)
         print(json.dumps(out))

@@ -144,11 +144,24 @@ def run_vqad(args, dev):
     o, d, _ = synlego.ray_bank(1 << 20, res=400, seed=1000, device=dev, with_gt=False)
     bank = (o, d, synlego.render_gt_white(o, d))
     L = 4
-    # per sample and LOD: 8 corner logit rows of 16 fp32 (read; written again as gradients in the backward) + 8 trinket
-    # indices, + coordinates / voxel chain / one 5-wide output row
-    bytes_fn = lambda S, R: {"codebook_trilinear_fwd": (12 + 8 + 8 * 4 + 8 * 16 * 4 + 5 * 4) * S,
-                             "codebook_trilinear_bwd": (12 + 8 + 8 * 4 + 3 * 8 * 16 * 4 + 5 * 4) * S,
-                             "raymarch_voxel_emit": 37 * S, "composite_fwd": 25 * S, "composite_bwd": 41 * S}
+    rows = [int(f.shape[0]) for f in grid.features]            # corner rows (16 logits each) per LOD
+    D, F = 16, 5
+
+    def bytes_fn(S, R):
+        """Algorithmic bytes per launch, averaged over the four per-LOD launches of a step.  A corner row is shared by every
+        sample of the up to eight cells around it (16 samples per cell), so the rows are charged ONCE per launch - at most
+        min(8 S, rows of the LOD) of them - not once per sample: the per-sample model of round 2 charged 12 x more than the
+        two-pass backward moves and put this kernel at 123 % of the HBM peak.
+          decode_rows   reads the logits of every row, writes the decoded 5-vector
+          trilinear_fwd per sample: coordinates 12 + voxel 8 + 8 trinkets x 4 + 8 decoded rows x 20 (gathered) + output 20
+          bwd           per sample: coordinates 12 + voxel 8 + trinkets 32 + output gradient 20; per touched row: logits read
+                        64 + logit gradients written 64; dictionary gradient 16 x 5 x 4 (negligible)"""
+        touched = [min(8 * S, r) for r in rows]
+        return {"codebook_decode_rows": sum(r * (D * 4 + F * 4) for r in rows) / L,
+                "spc_trilinear_fwd": (12 + 8 + 8 * 4 + 8 * F * 4 + F * 4) * S,
+                "codebook_trilinear_fwd": (12 + 8 + 8 * 4 + F * 4) * S + sum(t * D * 4 for t in touched) / L,
+                "codebook_trilinear_bwd": (12 + 8 + 8 * 4 + F * 4) * S + sum(t * 2 * D * 4 for t in touched) / L + D * F * 4,
+                "raymarch_voxel_emit": 37 * S, "composite_fwd": 25 * S, "composite_bwd": 41 * S}
     return _nerf_run(args, dev, pipe, tr, bank, args.steps, args.warmup,
                      f"C5: VQAD CodebookOctreeGrid F=5, {L} LODs (levels 5-8), 4-bit codebooks over from_pointcloud(level 8) "
                      f"({int(blas.pyramid[0, 8])} cells), decoders hidden 64 without bias, 'voxel' 16, white background, RMSprop, L2",
@@ -208,6 +221,15 @@ def run_nglod(args, dev):
         loss = tr.step(x, y)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # Algorithmic bytes of the step's launches (B = 512 coordinates; 6 LODs of 16 fp32 features; decoder 19 -> 128 -> 1):
+    # lookups gather 8 corner rows of 64 B per LOD, the backward writes them back as gradients; the decoder reads its 2.7 K
+    # weights once per launch.  With 512 coordinates a launch moves ~1.7 MB: the step is bound by launch latency, which is what
+    # the small fractions below say (and why the step is replayed from a captured graph).
+    LODS, FW = 6, 16
+    nglod_bytes = {"spc_trilinear_multi_fwd": (12 + 8 * LODS + LODS * 8 * (4 + FW * 4) + FW * 4) * B,
+                   "spc_trilinear_multi_bwd": (12 + 8 * LODS + LODS * 8 * (4 + 2 * FW * 4) + FW * 4) * B,
+                   "small_decoder_fwd": (19 * 4 + 4) * B + (19 * 128 + 128 + 128 + 1) * 4,
+                   "small_decoder_bwd": (19 * 4 + 4 + 19 * 4) * B + 2 * (19 * 128 + 128 + 128 + 1) * 4}
     # rendering: 800x800-style rays around the body, 32 marching steps x 0.8 (nglod_octree.yaml tracer)
     o, d, _ = synlego.ray_bank(1 << 18, seed=5, device=dev, with_gt=False)
     rays = Rays(o, d, dist_min=0.0, dist_max=6.0)
@@ -237,7 +259,40 @@ def run_nglod(args, dev):
                        "hit_fraction": float(rb.hit.float().mean()), "marching_steps": 32,
                        "kernels": _kernel_table(rsink)},
             "gpu_busy_fraction_eager": sum(v["total_ms"] for v in kernels.values()) * 1e-3 / eager_elapsed,
-            "roofline": _roofline(kernels, {}, args.steps), "kernels": kernels}
+            "roofline": _roofline(kernels, nglod_bytes, args.steps), "kernels": kernels}
+
+
+def secondary_lines(args, dev, budget_s=6.0):
+    """Short in-process runs of the other BASELINE.json configurations for bench.py's default line (`configs`): same code as
+    `--config ...`, a handful of steps each, only the summary fields.  The full lines (kernel tables) come from `--config`."""
+    import copy
+    import types
+    out = {}
+    for name, fn, over in (("v8", run_v8, dict(pretrain=30, steps=30, warmup=3)),
+                           ("vqad", run_vqad, dict(pretrain=30, steps=30, warmup=3)),
+                           ("nglod", run_nglod, dict(pretrain=40, steps=200, warmup=5))):
+        a = types.SimpleNamespace(**vars(args))
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            r = fn(a, dev)
+        except Exception as e:                                  # a secondary line must not take the headline down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+            continue
+        top = list(r["kernels"].items())[:4]
+        line = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "roofline") if k in r}
+        line["workload"] = r["config"]["workload"]
+        for k in ("gpu_busy_fraction", "gpu_busy_fraction_eager", "samples_per_sec", "psnr_db_train_rays", "eager", "issue"):
+            if k in r:
+                line[k] = r[k]
+        if "render" in r:
+            line["render"] = {k: r["render"][k] for k in ("rays", "ms", "rays_per_sec", "marching_steps")}
+        line["top_launches"] = {k: {"avg_ms": v["avg_ms"], "share": v["share"], "launches": v["launches"]} for k, v in top}
+        line["wall_s"] = time.perf_counter() - t0
+        out[name] = line
+        torch.cuda.empty_cache()
+    return out
 
 
 def main(args, dev):

@@ -265,6 +265,7 @@ class _DirectNeRFStep:
                                          grad_params=packed_grad, ray_code=ray_code)
         if self.biasless:
             self._scatter_param_grads(packed_grad)
+        t.early_reduce_decoder()                # decoder gradients are final: their all-reduce runs under the grid backward
         if self.hash_fast:
             C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res, self.bitwidth,
                                             self.zero_from_col, out=self.table.grad)
@@ -338,11 +339,21 @@ class MultiviewTrainStep:
         self._prune_gen = torch.Generator(device=dev).manual_seed(seed)
         self._side_stream = None
         self._params_ready = None
-        # WISP_SHARDED_OPTIM=1 (or sharded_optimizer=True): reduce-scatter + optimizer on this rank's slice of the grid + all-gather
-        # instead of all-reduce + replicated optimizer (see _sharded_reduce_and_update).  Off by default: the all-reduce path is the
-        # one that has run on hardware with more than one rank.
-        want = sharded_optimizer if sharded_optimizer is not None else os.environ.get("WISP_SHARDED_OPTIM", "0") == "1"
+        # Gradient exchange with more than one rank (see _sharded_reduce_and_update): reduce-scatter + optimizer on this rank's
+        # slice of the grid + all-gather of the bf16 shadow, instead of all-reduce + replicated optimizer - 25 % fewer bytes on
+        # the wire (4 + 2 per element against 4 + 4) and the optimizer on 1/world of the table.  It is the default when there IS
+        # a shadow to gather (amp) and more than one rank; without amp the fp32 master would have to travel back and nothing is
+        # saved, so the all-reduce stays.  sharded_optimizer=True / False or WISP_SHARDED_OPTIM=1 / 0 force either path.
+        env = os.environ.get("WISP_SHARDED_OPTIM", "")
+        if sharded_optimizer is not None:
+            want = bool(sharded_optimizer)
+        elif env in ("0", "1"):
+            want = env == "1"
+        else:
+            want = bool(enable_amp) and self.world > 1
         self.sharded_optimizer = bool(want and dist.is_available() and dist.is_initialized())
+        self._decoder_reduced = False
+        self.comm_timing = None           # a list: reduce_and_update() appends (events...) per step on GPU runs (bench.py, world > 1)
         self.rank = dist.get_rank(process_group) if self.sharded_optimizer else 0
         self._master_stale = False
         self._stage = {}
@@ -417,8 +428,37 @@ class MultiviewTrainStep:
             first = d._first_idx_host = [int(v) for v in d.first_idx.detach().cpu().reshape(-1).tolist()]
         return f._grid_params[0][1] + first[live_levels] * F
 
+    def early_reduce_decoder(self):
+        """The decoder group's gradients are final as soon as the decoder backward has run - 0.4 ms (the hash-grid backward)
+        before the table's.  Their all-reduce (41 KB: pure latency) is issued right then on the side stream, so it is out of
+        the way when the grid's collective starts.  Called by the direct-issue step; the modular path reduces everything at the
+        end.  Sums are the same numbers as in the late reduction."""
+        if not (self.world > 1 or self.force_allreduce) or self._decoder_reduced:
+            return
+        a, b = self.flat.ranges["decoder"]
+        if b <= a:
+            return
+        if self.flat.data.is_cuda:
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
+        self._decoder_reduced = True
+
     def allreduce_grads(self):
         if self.world > 1 or self.force_allreduce:
+            if getattr(self, "_decoder_reduced", False):
+                # the decoder group went ahead (early_reduce_decoder): reduce what lies behind it
+                self._decoder_reduced = False
+                a = self.flat.ranges["decoder"][1]
+                n = max(self._live_grad_numel(), a)
+                if n > a:
+                    dist.all_reduce(self.flat.grad[a:n], op=dist.ReduceOp.SUM, group=self.group)
+                return
             n = self._live_grad_numel()
             if n < self.flat.grad.numel() and os.environ.get("WISP_CHECK_GRAD_TAIL", "0") == "1":
                 # debug switch (a host sync per step): the rows left out of the collective must not have received a gradient
@@ -436,15 +476,29 @@ class MultiviewTrainStep:
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream()
         self._side_stream.wait_stream(main)
+        timing = self.comm_timing
         with torch.cuda.stream(self._side_stream):
+            if timing is not None:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
+                self._timing_mark = ev[1]          # recorded between the collectives and the optimizer launch
             self._reduce_and_update_here()
-            self._params_ready = torch.cuda.Event()
+            self._params_ready = torch.cuda.Event(enable_timing=timing is not None)
             self._params_ready.record()
+            if timing is not None:
+                self._timing_mark = None
+                timing.append(dict(start=ev[0], comm_done=ev[1], done=self._params_ready, waited_at=None))
+
+    def _mark_comm_done(self):
+        m = getattr(self, "_timing_mark", None)
+        if m is not None:
+            m.record()
 
     def _reduce_and_update_here(self):
         plan = self._shard_plan() if (self.world > 1 or self.force_allreduce) else None
         if plan is None:
             self.allreduce_grads()
+            self._mark_comm_done()
             self.optimizer_step()
         else:
             self._sharded_reduce_and_update(plan)
@@ -506,8 +560,10 @@ class MultiviewTrainStep:
         to both."""
         f = self.flat
         ga, gb, c, npad, lo, hi = (plan[k] for k in ("ga", "gb", "c", "npad", "lo", "hi"))
-        for a, b in (f.ranges["decoder"], f.ranges["rest"]):
-            if b > a:
+        early, self._decoder_reduced = self._decoder_reduced, False
+        for name in ("decoder", "rest"):
+            a, b = f.ranges[name]
+            if b > a and not (name == "decoder" and early):
                 dist.all_reduce(f.grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
         if plan["direct"]:
             send = f.grad[ga:ga + npad]
@@ -518,6 +574,7 @@ class MultiviewTrainStep:
         dist.reduce_scatter_tensor(mine, send, op=dist.ReduceOp.SUM, group=self.group)
         f.grad[ga:min(ga + npad, gb)].zero_()             # the other ranks' slices of this rank's gradient are spent
         f.grad[lo:hi].copy_(mine[:hi - lo])
+        self._mark_comm_done()
         self.optimizer_step(grid_ranges=[(lo, hi), (min(ga + npad, gb), gb)])
         if f.shadow is not None:
             self._gather_grid(f.shadow, plan, "bf16")
@@ -554,10 +611,28 @@ class MultiviewTrainStep:
         """Order the current stream after the last reduce_and_update()."""
         ev = self._params_ready
         if ev is not None:
+            if self.comm_timing:
+                here = torch.cuda.Event(enable_timing=True)        # where the main stream stood when it had to have the parameters
+                here.record()
+                self.comm_timing[-1]["waited_at"] = here
             torch.cuda.current_stream().wait_event(ev)
             self._params_ready = None
 
     # -------------------------------------------------------------------------------------------- reference hooks
+    def comm_summary(self):
+        """Per-step milliseconds of the recorded steps (call after a synchronize): collectives, optimizer, and how long the main
+        stream really stood waiting for the parameters (what the overlap did not hide)."""
+        rows = [r for r in (self.comm_timing or []) if r["waited_at"] is not None]
+        if not rows:
+            return None
+        comm = [r["start"].elapsed_time(r["comm_done"]) for r in rows]
+        opt = [r["comm_done"].elapsed_time(r["done"]) for r in rows]
+        exposed = [max(0.0, r["waited_at"].elapsed_time(r["done"])) for r in rows]
+        n = len(rows)
+        return dict(steps=n, collective_ms=sum(comm) / n, optimizer_ms=sum(opt) / n, exposed_wait_ms=sum(exposed) / n,
+                    hidden_ms=max(0.0, (sum(comm) + sum(opt) - sum(exposed)) / n),
+                    path="reduce-scatter + sharded optimizer + all-gather" if self.sharded_optimizer else "all-reduce + replicated optimizer")
+
     def pre_step(self):
         """multiview_trainer.py:85-93."""
         if self.prune_every > -1 and self.total_iterations > 1 and self.total_iterations % self.prune_every == 0:

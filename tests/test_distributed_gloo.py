@@ -66,7 +66,13 @@ def _worker(rank, world, port, out):
     torch.nn.functional.smooth_l1_loss(model(O[lo:hi], D[lo:hi]), T[lo:hi], reduction='none').mean().backward()
     step = MultiviewTrainStep.__new__(MultiviewTrainStep)
     step.flat, step.world, step.group, step.force_allreduce = flat, world, None, False
-    step.allreduce_grads()
+    step._decoder_reduced, step._side_stream = False, None
+    before = flat.grad.clone()
+    step.early_reduce_decoder()                               # the decoder group goes first (what the direct-issue step does) ...
+    a, b = flat.ranges["decoder"]
+    early_ok = step._decoder_reduced and torch.equal(flat.grad[b:], before[b:]) and not torch.equal(flat.grad[a:b], before[a:b])
+    step.allreduce_grads()                                    # ... and the late collective covers exactly the rest
+    early_ok = early_ok and not step._decoder_reduced
     avg = flat.grad / world                                   # what adamw_step's grad_scale = 1/world applies
     ref100 = TinyField()
     torch.nn.functional.smooth_l1_loss(ref100(O[:100], D[:100]), T[:100], reduction='none').mean().backward()
@@ -82,7 +88,7 @@ def _worker(rank, world, port, out):
     same = all(torch.equal(gathered[0], t) for t in gathered)
     shards = [shard_rays(101, r, world) for r in range(world)]
     cover = shards[0][0] == 0 and shards[-1][1] == 101 and all(shards[i][1] == shards[i + 1][0] for i in range(world - 1))
-    out[rank] = bool(ok and same and cover)
+    out[rank] = bool(ok and same and cover and early_ok)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -213,6 +219,17 @@ def _sharded_worker(rank, world, port, out):
     O, D, T = torch.rand(96, 3, generator=g) * 2 - 1, torch.randn(96, 3, generator=g), torch.rand(96, 3, generator=g)
     lo, hi = shard_rays(96, rank, world)
     verdict = {}
+    # two ranks add the same two numbers in either collective; with more, gloo's reduce-scatter and all-reduce may associate the
+    # partial sums differently: equal up to one rounding of a sum of `world` terms
+    same = torch.equal if world == 2 else (lambda x, y: torch.allclose(x.float(), y.float(), rtol=0, atol=3e-6))
+    # which path a trainer picks by itself: sharded iff there is a bf16 shadow to gather (amp) and more than one rank
+    os.environ.pop("WISP_SHARDED_OPTIM", None)
+    verdict["default"] = (MultiviewTrainStep(_StubPipeline(), enable_amp=True).sharded_optimizer is True
+                          and MultiviewTrainStep(_StubPipeline(), enable_amp=False).sharded_optimizer is False
+                          and MultiviewTrainStep(_StubPipeline(), enable_amp=True, sharded_optimizer=False).sharded_optimizer is False)
+    os.environ["WISP_SHARDED_OPTIM"] = "0"
+    verdict["default"] = verdict["default"] and MultiviewTrainStep(_StubPipeline(), enable_amp=True).sharded_optimizer is False
+    os.environ.pop("WISP_SHARDED_OPTIM", None)
     # (table rows, highest row a gradient reaches, live elements of the grid group or None = all)
     for name, rows, max_cell, live in (("direct", 64, None, None), ("tail", 64, 49, 200), ("staged", 65, None, None)):
         for shadow in (False, True):
@@ -240,7 +257,8 @@ def _sharded_worker(rank, world, port, out):
             if shadow:
                 other = slice(ga, plan["lo"]) if rank == world - 1 else slice(plan["hi"], min(ga + plan["npad"], gb))
                 ok = ok and tr._master_stale and not torch.equal(tr.flat.data[other], ref.flat.data[other])   # really stale ...
-                ok = ok and torch.equal(tr.flat.shadow, ref.flat.shadow)                                       # ... shadow is not
+                ok = ok and (same(tr.flat.shadow, ref.flat.shadow) if world == 2 else                          # ... shadow is not
+                             float((tr.flat.shadow.float() - ref.flat.shadow.float()).abs().max()) <= 2e-2 * float(ref.flat.shadow.float().abs().max()))
                 try:                                                     # a checkpoint taken now would be silently wrong: refused
                     tr.pipeline.state_dict()
                     ok = False
@@ -259,14 +277,14 @@ def _sharded_worker(rank, world, port, out):
                         ok = ok and "sync_master()" in str(e)
                 tr.sync_master()
                 ok = ok and len(tr.pipeline.state_dict()) > 0
-            ok = ok and not tr._master_stale and torch.equal(tr.flat.data, ref.flat.data)      # bit for bit the all-reduce run
+            ok = ok and not tr._master_stale and same(tr.flat.data, ref.flat.data)             # the all-reduce run (bit for bit at world 2)
             ok = ok and float(tr.flat.grad.abs().max()) == 0.0                                 # every gradient consumed
             own = torch.zeros_like(tr.flat.exp_avg_sq, dtype=torch.bool)
             own[plan["lo"]:plan["hi"]] = True
             grid = torch.zeros_like(own)
             grid[ga:min(ga + plan["npad"], gb)] = True
             ok = ok and float(tr.flat.exp_avg_sq[grid & ~own].abs().max()) == 0.0              # no optimizer state off-slice
-            ok = ok and torch.equal(tr.flat.exp_avg_sq[own], ref.flat.exp_avg_sq[own])
+            ok = ok and same(tr.flat.exp_avg_sq[own], ref.flat.exp_avg_sq[own])
             gathered = [torch.zeros_like(tr.flat.data) for _ in range(world)]
             dist.all_gather(gathered, tr.flat.data)
             ok = ok and all(torch.equal(gathered[0], t) for t in gathered)
@@ -302,6 +320,24 @@ def _sharded_worker(rank, world, port, out):
     out[rank] = verdict
 
 
+import pytest
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_sharded_optimizer_shard_plan_world4_and_world8_gloo(world):
+    """The same run at 4 and 8 ranks (the node size the path is meant for): the cut of the grid group into `world` slices for the
+    three window shapes (fits / unreachable tail / staged through padded buffers: 256 or 260 table elements over 8 ranks give
+    slices of 32 and 36, the last ones partly or wholly past the live range), owner-only optimizer state, replicas identical,
+    stale-master refusals.  Against the all-reduce run to one rounding (more than two ranks: the collectives may associate sums
+    differently)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sharded_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    want = {f"{n}/{m}": True for n in ("direct", "tail", "staged") for m in ("fp32", "bf16")}
+    want["loud"] = want["stale_forward_refused"] = want["default"] = True
+    assert dict(out) == {r: want for r in range(world)}
+
+
 def test_sharded_optimizer_world2_gloo_equals_the_allreduce_run_bit_for_bit():
     """VERDICT r1 next-8c (opt-in, WISP_SHARDED_OPTIM=1): the real MultiviewTrainStep.step() with reduce-scatter + optimizer on the
     own slice + all-gather, against the same trainer on the all-reduce path, 5 steps with two prunes: identical master weights
@@ -312,5 +348,5 @@ def test_sharded_optimizer_world2_gloo_equals_the_allreduce_run_bit_for_bit():
     out = mgr.dict()
     mp.spawn(_sharded_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     want = {f"{n}/{m}": True for n in ("direct", "tail", "staged") for m in ("fp32", "bf16")}
-    want["loud"] = want["stale_forward_refused"] = True
+    want["loud"] = want["stale_forward_refused"] = want["default"] = True
     assert dict(out) == {0: want, 1: want}
