@@ -178,8 +178,7 @@ class _DirectNeRFStep:
         if torch.is_tensor(rays.dist_min) or torch.is_tensor(rays.dist_max):
             raise TypeError("'ray' raymarch needs scalar Rays.dist_min / dist_max (as the reference, octree_as.py:276-277)")
         blas._to_device(rays.origins.device)
-        grid = pipe.nef.grid
-        level = grid.active_lods[grid.num_lods - 1]        # what PackedRFTracer.trace marches at (lod_idx = num_lods - 1)
+        level = blas.max_level                             # where HashGrid.raymarch marches (hash_grid.py:235-240)
         coarse, lc = blas._coarse_bitfield(rays, pipe.tracer.num_steps, level)
         st = C.raymarch_ray_count(blas._bitfield(level), blas.octree, blas.prefix, rays.origins, rays.dirs, rays.dist_min,
                                   rays.dist_max, pipe.tracer.num_steps, level, jitter,
@@ -193,7 +192,10 @@ class _DirectNeRFStep:
         pipe = self.t.pipeline
         tracer, grid = pipe.tracer, pipe.nef.grid
         blas = grid.blas
-        if tracer.raymarch_type == 'ray' and blas._bitfield(grid.active_lods[grid.num_lods - 1]) is not None:
+        from wisp.models.grids import HashGrid
+        if tracer.raymarch_type == 'ray' and type(grid) is HashGrid and blas._bitfield(blas.max_level) is not None:
+            # (only the hash grid marches at the octree's finest level whatever the lod; every other grid picks its own level
+            #  inside grid.raymarch - octree_grid.py:221-226 marches at base_lod)
             st, self._pending = self._pending, None
             if st is None or st["rays"] is not rays or jitter is not None:
                 st = self._count(rays, jitter)                # nothing was prefetched for this batch
