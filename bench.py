@@ -222,7 +222,9 @@ def dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev):
     twin.tracer.prev_num_samples = None                       # the trainer's first call is its warm-up raymarch
     tr = MultiviewTrainer(cfg, twin, ds, device=dev)
     tr.is_optimization_running = True
-    for _ in range(2 + min(args.warmup, 10)):
+    # warm-up past the trainer's first prune (iteration 100): its first call pays one-time allocations that are not step cost;
+    # the timed iterations then contain the steady-state prunes, one per hundred
+    for _ in range(102 + min(args.warmup, 10)):
         tr.iterate()
     if world > 1:
         dist.barrier()

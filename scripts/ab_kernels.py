@@ -48,8 +48,13 @@ def timeit(fn, reps=20):
     return ts[len(ts) // 2]
 
 
-t = dict(
+code = C.nerf_mlp_dir_code(d, 4)
+mlp_fr = lambda: C.nerf_mlp_forward(g, None, params, 32, 64, 4, True, ray_code=(ridx, code))
+mlp_br = lambda: C.nerf_mlp_backward(g, None, params, gr, gd, 32, 64, 4, True, grad_params=gp, ray_code=(ridx, code))
+t = dict(mlp_fwd_rays=timeit(mlp_fr), mlp_bwd_rays=timeit(mlp_br),
     hg_fwd=timeit(lambda: C.hashgrid_interpolate(coords, table, begin, res, 19, 30)),
     hg_bwd=timeit(lambda: C.hashgrid_interpolate_backward(coords, g, grad.shape, begin, res, 19, zero_from_col=30, out=grad)),
     mlp_fwd=timeit(mlp_f), mlp_bwd=timeit(mlp_b))
+if os.environ.get("AB_ONLY"):
+    pass
 print(f"{os.path.basename(C.LIB_PATH):20s} S={S} " + "  ".join(f"{k} {v:7.1f} us" for k, v in t.items()), flush=True)

@@ -24,6 +24,15 @@ for _ in range(100):
     tr.iterate()
 torch.cuda.synchronize()
 print(f"iterate: {(time.perf_counter() - t0) * 10:.3f} ms/step, rays {ds.transform.num_samples}, samples {pipe.tracer.get_prev_num_samples()}")
+import cProfile, pstats, io
+pr = cProfile.Profile(); pr.enable()
+for _ in range(100):
+    tr.iterate()
+torch.cuda.synchronize(); pr.disable()
+for key in ("tottime", "cumulative"):
+    buf = io.StringIO(); pstats.Stats(pr, stream=buf).sort_stats(key).print_stats(40); print(buf.getvalue()[:7000])
+if os.environ.get("NO_TORCH_PROFILER"):
+    sys.exit(0)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     for _ in range(20):
