@@ -67,12 +67,28 @@ int wisp_hashgrid_interpolate_bwd(const float* coords, int64_t n, int coord_dim,
                                   const int64_t* first_idx, const int32_t* resolutions, int num_lods,
                                   int codebook_bitwidth, int zero_from_col,
                                   float* grad_codebook, void* workspace, int64_t workspace_bytes,
-                                  wisp_stream_t stream);
-/* Optional device scratch for the backward: with at least this many bytes the hashed levels are reduced through
- * binned (index, value) records + LDS accumulation instead of memory-side atomics (0 = binning not applicable). */
-int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, int feature_dim,
-                                          const int32_t* resolutions /* host */, int num_lods,
-                                          int codebook_bitwidth);
+                                  const float* level_cap_scale /* host [num_lods] or NULL */, wisp_stream_t stream);
+/* Optional device scratch for the backward: with at least this many bytes the levels are reduced through binned
+ * (index, value) records + LDS accumulation instead of memory-side atomics (0 = binning not applicable).
+ * level_cap_scale (host, one float in (0, 1] per level, NULL = all 1): shrinks the record slots of a level from the no-merge
+ * expectation they are sized for to what the caller has measured (wisp_hashgrid_bwd_slot_stats): consecutive samples of a ray
+ * that share a cell are merged before they are written, 2x on the finest levels and 20x on the coarsest, so the default
+ * slots are mostly air (2.5 GB of scratch for 0.43 GB of records at 2 M samples of nerf_hash.yaml).  The same scales must
+ * be passed to the size query and to the launch.  A slot that turns out too small is not an error: its excess records go
+ * through atomics. */
+int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, int dtype /* of grad_feats; -1 = enough for any */,
+                                          int feature_dim, const int32_t* resolutions /* host */, int num_lods,
+                                          int codebook_bitwidth, const float* level_cap_scale /* host or NULL */);
+/* After a wisp_hashgrid_interpolate_bwd launch with the same arguments, on the same stream, before the workspace is
+ * reused: the fill of the fullest record slot of every level and the number of records the level wrote -> max_fill (DEVICE
+ * u32 [2 * num_lods]: maxima, then totals; written by a small kernel), plus the slot capacity the launch used and the
+ * unscaled capacity (HOST i32 [num_lods] each, written at once).
+ * max_fill[l] == cap[l] means slots of level l overflowed into the atomic path.  Returns 0, or 1 when that launch was not
+ * binned (nothing is written then), or a negative error code. */
+int wisp_hashgrid_bwd_slot_stats(int64_t n, int coord_dim, int dtype, int feature_dim, const int32_t* resolutions /* host */,
+                                 int num_lods, int codebook_bitwidth, int zero_from_col, const float* level_cap_scale,
+                                 const void* workspace, int64_t workspace_bytes, uint32_t* max_fill, int32_t* cap_host,
+                                 int32_t* base_cap_host, wisp_stream_t stream);
 
 /* Diagnostic (no counterpart in the reference's bindings): the integer cell, the position inside it and the 2^d corner rows
  * (relative to the level's first row) that ONE level assigns to every coordinate - the first lines of every reference

@@ -966,9 +966,12 @@ static int64_t queue_emitter_grid_cap(int resident_per_cu) {
 }
 
 // bin geometry shared by the workspace query and the launcher
-struct BinPlan { int chunk_shift, max_chunks, max_splits, total_blocks, total_ranks; int64_t ntiles; BinLevels bins; int64_t count_bytes, record_bytes; bool ok; };
+struct BinPlan { int chunk_shift, max_chunks, max_splits, total_blocks, total_ranks; int64_t ntiles; BinLevels bins; int64_t count_bytes, record_bytes; bool ok;
+                 uint32_t base_cap[HG_MAX_LODS]; };
+// cap_scale (host, indexed by LEVEL, or nullptr = 1): the caller's measured ratio of what a slot of that level really receives
+// to the no-merge expectation the capacities start from - see wisp_hashgrid_bwd_slot_stats.
 static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels, int feature_dim, int64_t tsize, int dim,
-                        int rec_dwords, int64_t max_emitters = 0) {
+                        int rec_dwords, int64_t max_emitters = 0, const float* cap_scale = nullptr) {
     BinPlan p{};
     const int corners = 1 << dim;
     int64_t centries = 16384 / feature_dim;               // chunk entries: 64 KiB as fp32, 128 KiB as 64-bit fixed point
@@ -1007,6 +1010,12 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         if (cap < 128) cap = 128;
         if (lv.dense[l] && cap > 2048 * (tile_samples / EM_TILE)) cap = 2048 * (tile_samples / EM_TILE);
         if (cap > tile_samples * corners) cap = tile_samples * corners;
+        p.base_cap[li] = (uint32_t)cap;
+        if (cap_scale) {
+            float f = cap_scale[l];
+            if (!(f > 0.0f)) f = 1.0f;
+            if (f < 1.0f) { cap = (int64_t)((double)cap * f) + 1; if (cap < 32) cap = 32; }
+        }
         if (max_emitters > 0) {
             // slot stride = an ODD multiple of 32 records (256 B in the compact form): the workgroups of a capped grid run
             // roughly in step and write slot b at b * stride + (a common offset) - an even multiple would put them on a
@@ -1044,7 +1053,7 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
 template <typename T, int F, int DIM>
 static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, const int64_t* first_idx,
                       const HashLevels& lv, int num_lods, uint32_t tsize, int zero_from_col, float* grad_codebook,
-                      void* workspace, int64_t workspace_bytes, hipStream_t s) {
+                      void* workspace, int64_t workspace_bytes, const float* cap_scale, hipStream_t s) {
     const int pow2 = (tsize & (tsize - 1)) == 0;
     // the run merge carries 16 bits per cell coordinate (tail_compute); wide features would not fit the register budget
     bool merge = bwd_merge_enabled() && (F * (1 << DIM) <= 32);
@@ -1060,7 +1069,7 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
         queue_emitter = queue_emitter_enabled() && num_lods <= EQ_MAX_ROW;
         if (queue_emitter) max_emitters = queue_emitter_grid_cap(queue_emitter_residency<__hip_bfloat16, DIM>());   // (as the workspace query)
     }
-    const BinPlan plan = bin_plan(n, lv, active, F, (int64_t)tsize, DIM, RecordCodec<T, F>::RW, max_emitters);
+    const BinPlan plan = bin_plan(n, lv, active, F, (int64_t)tsize, DIM, RecordCodec<T, F>::RW, max_emitters, cap_scale);
     // emit kernel LDS: rank counters of every (level, bucket) + the tile's gradient rows
     const size_t em_lds = ((size_t)plan.total_ranks + 1 + (size_t)EM_TILE * ((num_lods * ((F * (int)sizeof(T)) / 4)) | 1)) * 4;
     const bool can_bin = merge && bwd_bin_enabled() && workspace && plan.ok && em_lds <= 150 * 1024 &&
@@ -1148,7 +1157,7 @@ extern "C" int wisp_hashgrid_interpolate_bwd(const float* coords, int64_t n, int
                                              int dtype, int feature_dim, const int64_t* first_idx,
                                              const int32_t* resolutions, int num_lods, int codebook_bitwidth,
                                              int zero_from_col, float* grad_codebook, void* workspace,
-                                             int64_t workspace_bytes, wisp_stream_t stream) {
+                                             int64_t workspace_bytes, const float* level_cap_scale, wisp_stream_t stream) {
     WISP_REQUIRE(n >= 0, "negative n");
     if (n == 0) return WISP_OK;
     WISP_REQUIRE(coords && grad_feats && first_idx && resolutions && grad_codebook, "null pointer");
@@ -1161,7 +1170,7 @@ extern "C" int wisp_hashgrid_interpolate_bwd(const float* coords, int64_t n, int
     WISP_REQUIRE(fill_levels(resolutions, num_lods, coord_dim, tsize, lv) == 0, "bad resolution");
     hipStream_t s = (hipStream_t)stream;
     HG_DISPATCH(launch_bwd, coords, n, grad_feats, first_idx, lv, num_lods, (uint32_t)tsize, zero_from_col,
-                grad_codebook, workspace, workspace_bytes, s)
+                grad_codebook, workspace, workspace_bytes, level_cap_scale, s)
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
@@ -1336,8 +1345,21 @@ extern "C" int wisp_hashgrid_cells(const float* coords, int64_t n, int coord_dim
     return WISP_OK;
 }
 
-extern "C" int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, int feature_dim,
-                                                     const int32_t* resolutions, int num_lods, int codebook_bitwidth) {
+// which plan a backward launch of this shape uses (mirrors launch_bwd): the queue emitter's capped grid for two 16-bit features
+static BinPlan plan_for(int64_t n, const HashLevels& lv, const LevelList& levels, int coord_dim, int feature_dim, int dtype,
+                        int64_t tsize, int num_lods, const float* cap_scale) {
+    const bool compact = dtype != WISP_F32 && feature_dim == 2;
+    int64_t max_emitters = 0;
+    if (compact && queue_emitter_enabled() && num_lods <= EQ_MAX_ROW) {
+        const int resident = coord_dim == 3 ? queue_emitter_residency<__hip_bfloat16, 3>() : queue_emitter_residency<__hip_bfloat16, 2>();
+        max_emitters = queue_emitter_grid_cap(resident);
+    }
+    return bin_plan(n, lv, levels, feature_dim, tsize, coord_dim, compact ? 2 : 1 + feature_dim, max_emitters, cap_scale);
+}
+
+extern "C" int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, int dtype, int feature_dim,
+                                                     const int32_t* resolutions, int num_lods, int codebook_bitwidth,
+                                                     const float* level_cap_scale) {
     if (n <= 0 || num_lods <= 0 || num_lods > HG_MAX_LODS || feature_dim <= 0 || !resolutions) return 0;
     if (coord_dim != 2 && coord_dim != 3) return 0;
     HashLevels lv;
@@ -1345,12 +1367,63 @@ extern "C" int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, i
     if (fill_levels(resolutions, num_lods, coord_dim, tsize, lv) != 0) return 0;
     LevelList all{0, {0}};
     for (int l = 0; l < num_lods; ++l) all.lv[all.n++] = l;
-    const BinPlan p = bin_plan(n, lv, all, feature_dim, tsize, coord_dim, 1 + feature_dim);   // widest record form
+    if (dtype == WISP_F32 || dtype == WISP_F16 || dtype == WISP_BF16) {                          // exactly the plan a launch of this dtype uses
+        const BinPlan e = plan_for(n, lv, all, coord_dim, feature_dim, dtype, tsize, num_lods, level_cap_scale);
+        return e.ok ? e.count_bytes + e.record_bytes : 0;
+    }
+    const BinPlan p = bin_plan(n, lv, all, feature_dim, tsize, coord_dim, 1 + feature_dim, 0, level_cap_scale);   // widest record form
     int64_t bytes = p.ok ? p.count_bytes + p.record_bytes : 0;
     if (feature_dim == 2 && num_lods <= EQ_MAX_ROW && queue_emitter_enabled()) {             // the queue emitter's capped grid
-        const int resident = coord_dim == 3 ? queue_emitter_residency<__hip_bfloat16, 3>() : queue_emitter_residency<__hip_bfloat16, 2>();
-        const BinPlan q = bin_plan(n, lv, all, feature_dim, tsize, coord_dim, 2, queue_emitter_grid_cap(resident));
+        const BinPlan q = plan_for(n, lv, all, coord_dim, feature_dim, WISP_BF16, tsize, num_lods, level_cap_scale);
         if (q.ok && q.count_bytes + q.record_bytes > bytes) bytes = q.count_bytes + q.record_bytes;
     }
     return bytes;
+}
+
+// Fullest slot and total record count of every level after a binned backward: one workgroup per active level goes over the
+// level's count cells ([bucket][emitting workgroup]) in the workspace the launch has just used.  stats = [max x L | sum x L].
+__global__ void __launch_bounds__(1024)
+hashgrid_bwd_slot_stats_kernel(LevelList levels, BinLevels bins, uint32_t ntiles, int num_lods, const uint32_t* __restrict__ counts,
+                               uint32_t* __restrict__ max_fill) {
+    __shared__ uint32_t s_max[16], s_sum[16];
+    const int li = blockIdx.x;
+    const uint32_t* __restrict__ c = counts + bins.cnt_base[li];
+    const int64_t cells = (int64_t)bins.chunks[li] * ntiles;
+    uint32_t m = 0, sum = 0;
+    for (int64_t e = threadIdx.x; e < cells; e += blockDim.x) { const uint32_t v = c[e]; m = max(m, v); sum += v; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, d, 64)); sum += (uint32_t)__shfl_xor((int)sum, d, 64); }
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = m; s_sum[threadIdx.x >> 6] = sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) { m = max(m, s_max[w]); sum += s_sum[w]; }
+        max_fill[levels.lv[li]] = m;
+        max_fill[num_lods + levels.lv[li]] = sum;
+    }
+}
+
+extern "C" int wisp_hashgrid_bwd_slot_stats(int64_t n, int coord_dim, int dtype, int feature_dim, const int32_t* resolutions,
+                                            int num_lods, int codebook_bitwidth, int zero_from_col, const float* level_cap_scale,
+                                            const void* workspace, int64_t workspace_bytes, uint32_t* max_fill,
+                                            int32_t* cap_host, int32_t* base_cap_host, wisp_stream_t stream) {
+    WISP_REQUIRE(n > 0 && resolutions && max_fill && cap_host && base_cap_host, "bad arguments");
+    WISP_REQUIRE(coord_dim == 2 || coord_dim == 3, "coord_dim must be 2 or 3");
+    WISP_REQUIRE(num_lods >= 1 && num_lods <= HG_MAX_LODS, "num_lods out of range");
+    HashLevels lv;
+    const int64_t tsize = (int64_t)1 << codebook_bitwidth;
+    WISP_REQUIRE(fill_levels(resolutions, num_lods, coord_dim, tsize, lv) == 0, "bad resolution");
+    LevelList active{0, {0}};
+    for (int l = 0; l < num_lods; ++l)
+        if (l * feature_dim < zero_from_col) active.lv[active.n++] = l;
+    for (int l = 0; l < num_lods; ++l) { cap_host[l] = 0; base_cap_host[l] = 0; }
+    const BinPlan plan = plan_for(n, lv, active, coord_dim, feature_dim, dtype, tsize, num_lods, level_cap_scale);
+    // the launch was binned iff it had a workspace that holds this plan (launch_bwd's test; the LDS limit never binds here)
+    if (!workspace || !plan.ok || plan.count_bytes + plan.record_bytes > workspace_bytes || n < 4096 || active.n == 0) return 1;
+    for (int li = 0; li < active.n; ++li) { cap_host[active.lv[li]] = (int32_t)plan.bins.cap[li]; base_cap_host[active.lv[li]] = (int32_t)plan.base_cap[li]; }
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(max_fill, 0, sizeof(uint32_t) * 2 * num_lods, s);
+    hipLaunchKernelGGL(hashgrid_bwd_slot_stats_kernel, dim3(active.n), dim3(1024), 0, s, active, plan.bins, (uint32_t)plan.ntiles,
+                       num_lods, (const uint32_t*)workspace, max_fill);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
 }

@@ -32,8 +32,9 @@ c_vp, c_i64, c_i32, c_f32, c_u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 # name -> argtypes (restype int unless listed in _RESTYPES); mirrors include/wisp_hip.h one to one
 SIGNATURES = {
     "wisp_hashgrid_interpolate_fwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
-    "wisp_hashgrid_interpolate_bwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp],
-    "wisp_hashgrid_bwd_workspace_bytes": [c_i64, c_i32, c_i32, c_vp, c_i32, c_i32],
+    "wisp_hashgrid_interpolate_bwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp],
+    "wisp_hashgrid_bwd_workspace_bytes": [c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp],
+    "wisp_hashgrid_bwd_slot_stats": [c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_hashgrid_cells": [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
     "wisp_hashgrid_query_fwd": [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_hashgrid_query_bwd": [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
@@ -260,19 +261,98 @@ def hashgrid_interpolate_backward(coords, grad_feats, codebook_shape, first_idx,
     res_arr, res_ptr = _host_i32(resolutions)
     grad = out if out is not None else torch.zeros(tuple(codebook_shape), dtype=torch.float32, device=coords.device)
     assert grad.dtype == torch.float32 and grad.is_contiguous()
-    # scratch for the binned reduction of the hashed levels (sized for the levels that are actually hashed)
-    ws_bytes = int(lib.wisp_hashgrid_bwd_workspace_bytes(n, dim, F, res_ptr, L, codebook_bitwidth))
+    dt = _DTYPE_CODE[grad_feats.dtype]
+    # scratch for the binned reduction; its record slots are sized from what earlier launches of this shape really filled
+    fit = _slot_fit(coords.device, dim, dt, F, tuple(int(r) for r in res_arr), codebook_bitwidth, zero_from_col) if n >= 4096 else None
+    scale_arr = fit.scales(n) if fit is not None else None
+    scale_ptr = None if scale_arr is None else ctypes.cast(scale_arr, ctypes.c_void_p)
+    ws_bytes = int(lib.wisp_hashgrid_bwd_workspace_bytes(n, dim, dt, F, res_ptr, L, codebook_bitwidth, scale_ptr))
     ws = _bwd_workspace(coords.device, ws_bytes) if 0 < ws_bytes <= HASHGRID_BWD_WORKSPACE_LIMIT else None
     with _timed("hashgrid_bwd", n):
-        _check(lib.wisp_hashgrid_interpolate_bwd(_p(coords), n, dim, _p(grad_feats), _DTYPE_CODE[grad_feats.dtype], F,
+        _check(lib.wisp_hashgrid_interpolate_bwd(_p(coords), n, dim, _p(grad_feats), dt, F,
                                                  _p(first_idx), res_ptr, L, codebook_bitwidth, zero_from_col, _p(grad),
-                                                 _p(ws), ws.numel() if ws is not None else 0, _stream()),
+                                                 _p(ws), ws.numel() if ws is not None else 0, scale_ptr, _stream()),
                "hashgrid_interpolate_bwd")
+    if fit is not None and ws is not None:
+        fit.after_launch(n, res_ptr, scale_arr, scale_ptr, ws, ws_bytes)
     return grad
 
 
 HASHGRID_BWD_WORKSPACE_LIMIT = 24 << 30          # bytes; 288 GB of HBM makes a multi-GB scratch a fair trade
 _bwd_ws = {}
+_slot_fits = {}
+# WISP_HG_SLOT_FIT=0: always the unscaled (no-merge expectation) slots
+SLOT_FIT_ENABLED = os.environ.get("WISP_HG_SLOT_FIT", "1") != "0"
+
+
+class _SlotFit:
+    """Per-level record-slot sizing of the binned hash-grid backward, learned from the launches themselves.
+    Every CHECK_EVERY-th launch of a shape is followed by wisp_hashgrid_bwd_slot_stats (one tiny kernel + a 64-byte copy to pinned
+    memory, never waited for); a later launch picks the result up once the copy has landed: a level whose fullest slot stayed
+    below its capacity gets slots of HEADROOM x that fill (as a fraction of the unscaled capacity, which follows the sample
+    count), a level that filled a slot completely - it overflowed into the atomic path - gets GROW x its previous size."""
+    CHECK_EVERY, HEADROOM, GROW, FLOOR = 32, 1.35, 1.6, 0.02
+
+    def __init__(self, device, dim, dt, F, res, bitwidth, zero_from_col):
+        self.key = (dim, dt, F, res, bitwidth, zero_from_col)
+        self.L = len(res)
+        self.scale = [1.0] * self.L
+        self.calls = 0
+        self.pending = None
+        self.last = None            # what the last evaluated check saw (tests, bench)
+        self.dev_fill = torch.zeros(2 * self.L, dtype=torch.int32, device=device)      # [fullest slot x L | records written x L]
+        self.host_fill = torch.zeros(2 * self.L, dtype=torch.int32).pin_memory()
+
+    def scales(self, n):
+        self._collect()
+        return (ctypes.c_float * self.L)(*self.scale)
+
+    def _collect(self):
+        p = self.pending
+        if p is None or not p["event"].query():
+            return
+        self.pending = None
+        both = self.host_fill.tolist()
+        fill, written = both[:self.L], both[self.L:]
+        for l in range(self.L):
+            cap, base = p["cap"][l], p["base"][l]
+            if base <= 0:
+                continue
+            if fill[l] >= cap:
+                self.scale[l] = min(1.0, max(self.scale[l], cap / base) * self.GROW)
+            else:
+                self.scale[l] = min(1.0, max(self.FLOOR, self.HEADROOM * fill[l] / base))
+        self.last = dict(fill=fill, records=written, cap=list(p["cap"]), base=list(p["base"]), scale=list(self.scale),
+                         workspace_bytes=p["ws_bytes"])
+
+    def after_launch(self, n, res_ptr, scale_arr, scale_ptr, ws, ws_bytes):
+        self.calls += 1
+        if self.pending is not None or (self.calls - 1) % self.CHECK_EVERY:
+            return
+        dim, dt, F, res, bitwidth, zero_from_col = self.key
+        cap = (ctypes.c_int32 * self.L)()
+        base = (ctypes.c_int32 * self.L)()
+        rc = lib.wisp_hashgrid_bwd_slot_stats(n, dim, dt, F, res_ptr, self.L, bitwidth, zero_from_col, scale_ptr, _p(ws), ws.numel(),
+                                              _p(self.dev_fill), ctypes.cast(cap, ctypes.c_void_p), ctypes.cast(base, ctypes.c_void_p),
+                                              _stream())
+        if rc < 0:
+            _check(rc, "hashgrid_bwd_slot_stats")
+        if rc != 0:
+            return                  # the launch was not binned: nothing to learn
+        self.host_fill.copy_(self.dev_fill, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = dict(event=ev, cap=list(cap), base=list(base), ws_bytes=int(ws_bytes))
+
+
+def _slot_fit(device, dim, dt, F, res, bitwidth, zero_from_col):
+    if not SLOT_FIT_ENABLED:
+        return None
+    key = (device, _stream().value, dim, dt, F, res, bitwidth, zero_from_col)
+    fit = _slot_fits.get(key)
+    if fit is None:
+        fit = _slot_fits[key] = _SlotFit(device, dim, dt, F, res, bitwidth, zero_from_col)
+    return fit
 
 
 def hashgrid_cells(coords, resolution, codebook_bitwidth, with_corners=True):
@@ -292,7 +372,7 @@ def _bwd_workspace(device, nbytes):
     side stream next to a second model) must not share records."""
     key = (device, _stream().value)
     buf = _bwd_ws.get(key)
-    if buf is None or buf.numel() < nbytes:
+    if buf is None or buf.numel() < nbytes or buf.numel() > 3 * nbytes + (64 << 20):    # grow, or give an oversized one back
         buf = None
         _bwd_ws[key] = None
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)

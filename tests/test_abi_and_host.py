@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     import wisp._C as C
     assert set(C.SIGNATURES) == declared           # the Python binding covers the whole header, nothing else
-    assert C.lib.wisp_abi_version() == 2
+    assert C.lib.wisp_abi_version() == 3
     assert C.lib.wisp_nerf_mlp_param_count(32, 64, 4) == 3152 + 7107    # decoder sizes of nerf_hash.yaml
 
 
@@ -411,11 +411,23 @@ def test_hashgrid_backward_workspace_query_is_sane_without_a_gpu():
     import wisp._C as C
     res = [16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406, 512]
     arr = (ctypes.c_int32 * len(res))(*res)
-    sizes = [int(C.lib.wisp_hashgrid_bwd_workspace_bytes(n, 3, 2, arr, len(res), 19)) for n in (4096, 1 << 16, 1 << 18, 1 << 21)]
+    sizes = [int(C.lib.wisp_hashgrid_bwd_workspace_bytes(n, 3, -1, 2, arr, len(res), 19, None)) for n in (4096, 1 << 16, 1 << 18, 1 << 21)]
     assert all(b > 0 for b in sizes) and sizes == sorted(sizes)
     assert (1 << 30) < sizes[-1] < (6 << 30)
-    assert int(C.lib.wisp_hashgrid_bwd_workspace_bytes(0, 3, 2, arr, len(res), 19)) == 0
-    assert int(C.lib.wisp_hashgrid_bwd_workspace_bytes(1 << 18, 4, 2, arr, len(res), 19)) == 0       # bad coord_dim
+    assert int(C.lib.wisp_hashgrid_bwd_workspace_bytes(0, 3, -1, 2, arr, len(res), 19, None)) == 0
+    assert int(C.lib.wisp_hashgrid_bwd_workspace_bytes(1 << 18, 4, -1, 2, arr, len(res), 19, None)) == 0       # bad coord_dim
+    # per-level slot scales (what wisp._C._SlotFit learns from the launches: the run merge leaves ~1/20 of the no-merge record
+    # count on the coarsest level and ~1/2 on the finest): the scratch follows them - VERDICT r2 #9 asks for <= 2 x what is written,
+    # 0.43 GB at this shape - and is monotone in every scale; scales of 1 are the unscaled plan
+    def scaled(v):
+        return int(C.lib.wisp_hashgrid_bwd_workspace_bytes(1 << 21, 3, C.BF16, 2, arr, len(res), 19, ctypes.cast((ctypes.c_float * 16)(*v), ctypes.c_void_p)))
+    ones = scaled([1.0] * 16)                                                                          # bf16: 8-byte records, capped grid
+    assert (2 << 30) < ones <= sizes[-1]
+    measured_like = [0.05, 0.05, 0.06, 0.07, 0.08, 0.1, 0.12, 0.15, 0.2, 0.25, 0.3, 0.35, 0.4, 0.5, 0.6, 0.7]
+    fitted = scaled([1.35 * f for f in measured_like])
+    assert fitted < 0.5 * ones and fitted < (1 << 30)
+    assert scaled([0.5] * 16) < ones and scaled([0.25] * 16) < scaled([0.5] * 16)
+    assert scaled([0.0] * 16) == ones and scaled([float('nan')] * 16) == ones                          # nonsense scales are ignored
 
 
 def test_octree_from_mesh_covers_the_surface(tmp_path):
