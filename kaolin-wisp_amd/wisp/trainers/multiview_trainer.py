@@ -481,27 +481,30 @@ class MultiviewTrainStep:
         timing = self.comm_timing
         with torch.cuda.stream(self._side_stream):
             if timing is not None:
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-                ev[0].record()
-                self._timing_mark = ev[1]          # recorded between the collectives and the optimizer launch
+                start = torch.cuda.Event(enable_timing=True)
+                start.record()
+                self._timing_marks = []            # (label, event) after every phase of _reduce_and_update_here
             self._reduce_and_update_here()
             self._params_ready = torch.cuda.Event(enable_timing=timing is not None)
             self._params_ready.record()
             if timing is not None:
-                self._timing_mark = None
-                timing.append(dict(start=ev[0], comm_done=ev[1], done=self._params_ready, waited_at=None))
+                marks, self._timing_marks = self._timing_marks, None
+                timing.append(dict(start=start, marks=marks, done=self._params_ready, waited_at=None))
 
-    def _mark_comm_done(self):
-        m = getattr(self, "_timing_mark", None)
-        if m is not None:
-            m.record()
+    def _mark(self, label):
+        marks = getattr(self, "_timing_marks", None)
+        if marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((label, ev))
 
     def _reduce_and_update_here(self):
         plan = self._shard_plan() if (self.world > 1 or self.force_allreduce) else None
         if plan is None:
             self.allreduce_grads()
-            self._mark_comm_done()
+            self._mark("all_reduce")
             self.optimizer_step()
+            self._mark("optimizer")
         else:
             self._sharded_reduce_and_update(plan)
 
@@ -576,13 +579,15 @@ class MultiviewTrainStep:
         dist.reduce_scatter_tensor(mine, send, op=dist.ReduceOp.SUM, group=self.group)
         f.grad[ga:min(ga + npad, gb)].zero_()             # the other ranks' slices of this rank's gradient are spent
         f.grad[lo:hi].copy_(mine[:hi - lo])
-        self._mark_comm_done()
+        self._mark("reduce_scatter")
         self.optimizer_step(grid_ranges=[(lo, hi), (min(ga + npad, gb), gb)])
+        self._mark("optimizer")
         if f.shadow is not None:
             self._gather_grid(f.shadow, plan, "bf16")
             self._master_stale = self.world > 1
         else:
             self._gather_grid(f.data[ga:gb], plan, "fp32")
+        self._mark("all_gather")
 
     def _refuse_stale_master_forward(self):
         """While other ranks' slices of the fp32 table are stale here, the forward may only read the bf16 shadow.  If a torch-side write
@@ -627,13 +632,21 @@ class MultiviewTrainStep:
         rows = [r for r in (self.comm_timing or []) if r["waited_at"] is not None]
         if not rows:
             return None
-        comm = [r["start"].elapsed_time(r["comm_done"]) for r in rows]
-        opt = [r["comm_done"].elapsed_time(r["done"]) for r in rows]
-        exposed = [max(0.0, r["waited_at"].elapsed_time(r["done"])) for r in rows]
         n = len(rows)
-        return dict(steps=n, collective_ms=sum(comm) / n, optimizer_ms=sum(opt) / n, exposed_wait_ms=sum(exposed) / n,
-                    hidden_ms=max(0.0, (sum(comm) + sum(opt) - sum(exposed)) / n),
-                    path="reduce-scatter + sharded optimizer + all-gather" if self.sharded_optimizer else "all-reduce + replicated optimizer")
+        phases = {}
+        for r in rows:
+            prev = r["start"]
+            for label, ev in r["marks"]:
+                phases[label] = phases.get(label, 0.0) + prev.elapsed_time(ev)
+                prev = ev
+        total = sum(r["start"].elapsed_time(r["done"]) for r in rows) / n
+        exposed = sum(max(0.0, r["waited_at"].elapsed_time(r["done"])) for r in rows) / n
+        out = dict(steps=n, side_stream_ms=total, exposed_wait_ms=exposed, hidden_ms=max(0.0, total - exposed),
+                   path="reduce-scatter + sharded optimizer + all-gather" if self.sharded_optimizer else "all-reduce + replicated optimizer")
+        for label, v in phases.items():
+            out[label + "_ms"] = v / n
+        out["collective_ms"] = sum(v for k, v in phases.items() if k != "optimizer") / n
+        return out
 
     def pre_step(self):
         """multiview_trainer.py:85-93."""

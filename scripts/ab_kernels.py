@@ -55,6 +55,10 @@ t = dict(mlp_fwd_rays=timeit(mlp_fr), mlp_bwd_rays=timeit(mlp_br),
     hg_fwd=timeit(lambda: C.hashgrid_interpolate(coords, table, begin, res, 19, 30)),
     hg_bwd=timeit(lambda: C.hashgrid_interpolate_backward(coords, g, grad.shape, begin, res, 19, zero_from_col=30, out=grad)),
     mlp_fwd=timeit(mlp_f), mlp_bwd=timeit(mlp_b))
-if os.environ.get("AB_ONLY"):
-    pass
+# the reference trainer's batch: 2^18 samples
+S2 = 1 << 18
+c2, g2 = coords[:S2].contiguous(), g[:S2].contiguous()
+t["hg_bwd_2p18"] = timeit(lambda: C.hashgrid_interpolate_backward(c2, g2, grad.shape, begin, res, 19, zero_from_col=30, out=grad))
+t["hg_fwd_2p18"] = timeit(lambda: C.hashgrid_interpolate(c2, table, begin, res, 19, 30))
+
 print(f"{os.path.basename(C.LIB_PATH):20s} S={S} " + "  ".join(f"{k} {v:7.1f} us" for k, v in t.items()), flush=True)
