@@ -525,12 +525,17 @@ def main():
             "reference_regime": {"target_samples_per_step": args.ref_target_samples, "rays_per_step_per_gpu": R_ref,
                                  "value": ref_rays_total / ref_elapsed, "unit": "rays/s",
                                  "ms_per_step": 1e3 * ref_elapsed / args.steps, "samples_per_sec": ref_samples_all / ref_elapsed,
-                                 "prunes_inside_timed_steps": ref_prunes,
+                                 "prunes_inside_timed_steps": ref_prunes, "hip_event_timing_inside_the_loop": False,
                                  "note": "multiview_trainer.py:58 default batch (2^18 packed samples per step), same run"},
             "dropin_regime": dropin, "comm": comm,
             "psnr_db": psnr, "optimisation_steps_before_psnr": trainer.total_iterations,
             "roofline": roofline,
         }
+        fits = [f.last for f in getattr(C, "_slot_fits", {}).values() if f.last]
+        if roofline and fits:
+            last = max(fits, key=lambda f: f["workspace_bytes"])
+            roofline["hashgrid_bwd_scratch"] = {"workspace_bytes": last["workspace_bytes"], "record_bytes_written": 8 * sum(last["records"]),
+                                                "per_level_scale": [round(x, 3) for x in last["scale"]]}
         if world == 1 and roofline and not args.no_pmc:
             traffic, note = live_pmc_traffic(args, PMC_KERNELS[roofline["kernel"]])
             roofline["traffic"] = traffic
