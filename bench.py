@@ -434,6 +434,13 @@ def main():
     elapsed, total_samples, prunes_in = timed_steps(R, args.warmup, args.steps, timing)
     comm = trainer.comm_summary()
     trainer.comm_timing = None
+    # scratch of the binned hash-grid backward in this regime (record slots sized from what earlier launches filled)
+    fits = [f.last for f in getattr(C, "_slot_fits", {}).values() if f.last]
+    scratch = None
+    if fits:
+        last = max(fits, key=lambda f: f["workspace_bytes"])
+        scratch = {"workspace_bytes": last["workspace_bytes"], "record_bytes_written": 8 * sum(last["records"]),
+                   "per_level_scale": [round(x, 3) for x in last["scale"]]}
     if comm is not None:
         comm["selftest"] = selftest
         comm["grad_bytes_on_the_wire_per_step"] = 4 * min(trainer._live_grad_numel(), trainer.flat.grad.numel())
@@ -531,11 +538,8 @@ def main():
             "psnr_db": psnr, "optimisation_steps_before_psnr": trainer.total_iterations,
             "roofline": roofline,
         }
-        fits = [f.last for f in getattr(C, "_slot_fits", {}).values() if f.last]
-        if roofline and fits:
-            last = max(fits, key=lambda f: f["workspace_bytes"])
-            roofline["hashgrid_bwd_scratch"] = {"workspace_bytes": last["workspace_bytes"], "record_bytes_written": 8 * sum(last["records"]),
-                                                "per_level_scale": [round(x, 3) for x in last["scale"]]}
+        if roofline and scratch:
+            roofline["hashgrid_bwd_scratch"] = scratch
         if world == 1 and roofline and not args.no_pmc:
             traffic, note = live_pmc_traffic(args, PMC_KERNELS[roofline["kernel"]])
             roofline["traffic"] = traffic
