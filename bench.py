@@ -461,6 +461,7 @@ def main():
     # ---- the unchanged-application regime: the reference trainer's own step (multiview_trainer.py:111-180 through
     # BaseTrainer.iterate, base_trainer.py:316-342) over a copy of the same model state: fp16 autocast + GradScaler, autograd over
     # the modular pipeline, torch.optim.AdamW with the reference's parameter groups, SampleRays batches, two .item() per step
+    trainer.sync_master()               # (sharded optimizer: the copy below must not start from rows that are stale on this rank)
     dropin = dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev) if args.dropin_steps > 0 else None
 
     # ---- one prune, timed on its own (it falls into the timed steps only every 100th iteration)
