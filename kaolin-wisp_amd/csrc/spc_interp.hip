@@ -431,8 +431,9 @@ extern "C" int wisp_codebook_decode_rows(const float* logits, const float* dicti
 // 8 * 2^bw global float atomics per sample: 2.7e8 per level at 2 M samples, i.e. 9.4 ms per level on MI355X, whose
 // memory-side atomic units retire ~1.8e10 /s; this pair takes ~0.4 ms.  G is accumulated in the first F floats of each
 // grad_logits row (zero on entry), which pass 2 overwrites with the row's gradient.
+#define CG_THREADS 128
 template <int F, typename I>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(CG_THREADS)
 codebook_corner_grad_kernel(const float* __restrict__ coords, const I* __restrict__ pidx, const int16_t* __restrict__ points,
                             const int32_t* __restrict__ trinkets, const float* __restrict__ grad_out, int64_t n, int spv, int K,
                             int level, float* __restrict__ grad_logits) {
@@ -473,13 +474,34 @@ codebook_corner_grad_kernel(const float* __restrict__ coords, const I* __restric
             }
         if (take) head |= hp;
     }
-    if (p >= 0 && (lane == 63 || next != key)) {                          // run tail holds the run total
+    // The run tails hold the run totals: 8 corners x F floats each, F consecutive floats per logits row.  Issued from the tail
+    // lanes that is 8 F atomic instructions with a handful of live lanes each, every lane on its own 64-byte row.  Instead the
+    // tails park their totals in the wave's LDS slice and ALL lanes walk the (tail, corner, feature) items, feature fastest:
+    // the F atomics of a row sit in neighbouring lanes of ONE instruction (one memory-side request per row instead of F), and
+    // a wave issues ceil(tails * 8 F / 64) atomic instructions instead of 8 F.
+    const bool tail = p >= 0 && (lane == 63 || next != key);
+    const uint64_t tmask = __ballot(tail);
+    if (tmask == 0) return;                                               // (wave-uniform)
+    __shared__ float s_val[CG_THREADS / 64][64][8 * F];
+    __shared__ int32_t s_row[CG_THREADS / 64][64][8];
+    const int wv = threadIdx.x >> 6;
+    if (tail) {
+        const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float* dst = grad_logits + (int64_t)trinkets[p * 8 + j] * K;
+            s_row[wv][rank][j] = trinkets[p * 8 + j];
 #pragma unroll
-            for (int f = 0; f < F; ++f) atomicAdd(dst + f, v[j][f]);
+            for (int f = 0; f < F; ++f) s_val[wv][rank][j * F + f] = v[j][f];
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int items = __popcll(tmask) * 8 * F;
+    for (int it = lane; it < items; it += 64) {
+        const int rank = it / (8 * F), rem = it - rank * (8 * F);
+        const int j = rem / F, f = rem - j * F;
+        atomicAdd(grad_logits + (int64_t)s_row[wv][rank][j] * K + f, s_val[wv][rank][rem]);
     }
 }
 
@@ -536,7 +558,7 @@ static void launch_codebook_bwd2(const float* coords, const void* pidx, int pidx
                                  int64_t num_voxels, int spv, int K, int level, int64_t num_rows, float* grad_logits,
                                  float* grad_dict, hipStream_t s) {
     const int64_t n = num_voxels * spv;
-    const dim3 grid((unsigned)ceil_div64(n, 256)), block(256);
+    const dim3 grid((unsigned)ceil_div64(n, CG_THREADS)), block(CG_THREADS);
     if (pidx_is_i64)
         hipLaunchKernelGGL((codebook_corner_grad_kernel<F, int64_t>), grid, block, 0, s, coords, (const int64_t*)pidx, points,
                            trinkets, grad_out, num_voxels, spv, K, level, grad_logits);
