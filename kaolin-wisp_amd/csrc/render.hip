@@ -470,9 +470,9 @@ extern "C" int wisp_generate_rays(const float* pixel_x, const float* pixel_y, in
 // d loss / d rgb = clamp(x, -1, 1) / N, 2 x / N, sign(x) / N for x = rgb - gt.  ONE launch: a grid-stride pass writes the
 // gradient and one partial sum per workgroup; the workgroup that finishes last (ticket counter in the workspace, which it
 // resets for the next call) adds the partials in index order - reproducible value, no second kernel.
-// (32 workgroups, not 256: the tickets are same-address memory-side atomics, which retire ~30 ns apart - 256 of them were
-//  8 of this launch's 11 µs at 40 K rays; 32 workgroups still stream the 0.5-3 MB of a batch in 1-2 µs)
-#define LOSS_BLOCKS 32
+// (measured in round 3: 32 workgroups instead of 256 - fewer tickets - 13 vs 11 µs at 40 K rays; ONE workgroup of 1024 threads
+//  without fence or ticket 29 µs: the launch is bound by streaming 1.4 MB through few CUs, not by the hand-over)
+#define LOSS_BLOCKS 256
 __global__ void __launch_bounds__(256)
 rgb_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ gt, int64_t n, int kind, float inv_n,
                 float* __restrict__ grad, float* __restrict__ partial, unsigned int* __restrict__ ticket,
