@@ -58,6 +58,16 @@ def test_forced_sharded_optimizer_on_one_gpu(amp):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (gpurun boxes have one)")
+def test_two_gpu_default_path_with_amp_is_the_sharded_one():
+    """No switch set: two ranks + amp pick reduce-scatter / sharded optimizer / all-gather by themselves, the decoder group's
+    all-reduce goes ahead of the grid's collective (early_reduce_decoder), and the replicas stay in lockstep."""
+    res = _launch(2, {"DP_AMP": "1"})
+    assert res["world"] == 2 and res["sharded"] and res["stale_before_sync"], res
+    assert res["direct"] and res["pruned"] and res["finite"] and res["identical"] and res["same_tree"], res
+    assert res["rel_l2_vs_single"] < 2e-2, res
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (gpurun boxes have one)")
 def test_two_gpu_sharded_optimizer_stays_in_lockstep():
     """Two ranks, WISP_SHARDED_OPTIM=1: each rank updates half of the live table rows; after sync_master() the replicas hold
     bit-identical master weights and octrees (the prunes inside the run read synced weights), the shadow mirrors the master,
@@ -74,7 +84,7 @@ def test_two_gpu_ray_sharded_training_stays_in_lockstep():
     """Two ranks over RCCL/xGMI: disjoint ray shards, one all-reduce of the flat gradient per step, identical prune draws -
     after 7 steps (two prunes) the replicas hold bit-identical parameters and octrees, and agree with a single-GPU run over
     the whole batch up to the order of the gradient sum."""
-    res = _launch(2, {"DP_AMP": "1"})
-    assert res["world"] == 2 and res["direct"] and res["pruned"] and res["finite"], res
+    res = _launch(2, {"DP_AMP": "1", "WISP_SHARDED_OPTIM": "0"})       # (with amp and two ranks the sharded path is the default)
+    assert res["world"] == 2 and not res["sharded"] and res["direct"] and res["pruned"] and res["finite"], res
     assert res["identical"] and res["same_tree"], res
     assert res["rel_l2_vs_single"] < 2e-2, res          # bf16 forward: sample-order dependent rounding in the decoder tiles
