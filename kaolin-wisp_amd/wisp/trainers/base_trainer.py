@@ -159,6 +159,12 @@ class _OneViewLoader:
         return len(self.dataset) // self.batch_size if len(self.dataset) >= self.batch_size else 1
 
     def __iter__(self):
+        if self.batch_size > 1 and hasattr(self.dataset, "get_batch"):
+            # coordinate datasets (SDF training: 512 points per batch): one indexed read instead of 512 items + a collate
+            order = torch.randperm(len(self.dataset), device=getattr(self.dataset, "device", "cpu"))
+            for i in range(0, len(self) * self.batch_size, self.batch_size):
+                yield self.dataset.get_batch(order[i:i + self.batch_size])
+            return
         order = torch.randperm(len(self.dataset)).tolist()
         for i in range(0, len(self) * self.batch_size, self.batch_size):
             items = [self.dataset[j] for j in order[i:i + self.batch_size]]

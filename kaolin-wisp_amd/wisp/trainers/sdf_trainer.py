@@ -5,8 +5,12 @@ plumbing - regression of a signed-distance field on (coordinate, distance) pairs
 
 Parameter groups, learning-rate weighting and the fused single-launch optimizer over one flat parameter buffer are the
 MultiviewTrainStep's (base_trainer.py:205-235); nglod_octree.yaml trains with Adam, lr 1e-3, eps 1e-15, grid lr x 1."""
+import logging as log
+from dataclasses import dataclass
+
 import torch
 
+from wisp.trainers.base_trainer import BaseTrainer, ConfigBaseTrainer
 from wisp.trainers.multiview_trainer import FlatParams
 
 
@@ -95,3 +99,81 @@ class SDFTrainStep:
         loss = self._forward_backward(coords, gts)
         self.optimizer_step()
         return loss
+
+
+@dataclass
+class ConfigSDFTrainer(ConfigBaseTrainer):
+    """Field names and defaults of wisp/trainers/sdf_trainer.py:20-29 (the YAML schema under `trainer:` of app/nglod)."""
+    log_2d: bool = False
+    only_last: bool = True
+    resample: bool = False
+
+
+class SDFTrainer(BaseTrainer):
+    """The reference's SDF trainer as app/nglod uses it (wisp/trainers/sdf_trainer.py:32-135): the unchanged-trainer regime for
+    signed-distance fields - BaseTrainer's life cycle (autocast around step() when enable_amp), autograd over the field, a
+    torch.optim optimizer with the name-matched parameter groups.  Events of step() in the reference's order: zero the
+    gradients, one field query per loss LOD, sum of squared errors (plus the colour term when the dataset samples textures),
+    three metric read-backs, division by the batch size, backward, optimizer step - no GradScaler here (the reference's SDF step
+    never scales, sdf_trainer.py:120-123).  SDFTrainStep is the fused MI355X step with the same arithmetic."""
+
+    def __init__(self, cfg, pipeline, train_dataset, tracker=None, device='cuda', scene_state=None):
+        super().__init__(cfg=cfg, pipeline=pipeline, train_dataset=train_dataset, tracker=tracker, device=device,
+                         scene_state=scene_state)
+
+    def pre_training(self):
+        super().pre_training()
+        self.tracker.metrics.define_metric('rgb_loss', aggregation_type=float)
+        self.tracker.metrics.define_metric('l2_loss', aggregation_type=float)
+
+    def pre_epoch(self):
+        super().pre_epoch()
+        lods = list(range(self.pipeline.nef.grid.num_lods))
+        self.loss_lods = lods[-1:] if self.cfg.only_last else lods
+
+    def post_epoch(self):
+        super().post_epoch()
+        if self.cfg.resample:
+            self.resample_dataset()
+
+    def step(self, data):
+        pts = data['coords'].to(self.device)
+        gts = data['sdf'].to(self.device)
+        with_colour = bool(getattr(self.train_dataset, 'sample_tex', False))
+        rgb = data['rgb'].to(self.device) if with_colour else None
+        batch_size = pts.shape[0]
+        self.pipeline.zero_grad()
+        nef = self.pipeline.nef
+        loss, l2_loss, rgb_loss = 0, 0.0, 0.0
+        last_l2, last_rgb = 0.0, None
+        if with_colour:
+            preds = [nef(coords=pts, lod_idx=lod_idx, channels=["rgb", "sdf"]) for lod_idx in self.loss_lods]
+            for colour, dist in preds:
+                last_rgb = ((colour - rgb[..., :3]) ** 2).sum()
+                rgb_loss += last_rgb
+                last_l2 = ((dist - 1.0 * gts) ** 2).sum()
+                l2_loss += last_l2
+                loss += rgb_loss                                    # (accumulated inside the loop, as the reference does)
+        else:
+            preds = [nef(coords=pts, lod_idx=lod_idx, channels=["sdf"])[0] for lod_idx in self.loss_lods]
+            for dist in preds:
+                last_l2 = ((dist - 1.0 * gts) ** 2).sum()
+                l2_loss += last_l2
+        loss += l2_loss
+        m = self.tracker.metrics
+        m.total_loss += loss.item()
+        m.l2_loss += last_l2.item()
+        if last_rgb is not None:
+            m.rgb_loss += last_rgb.item()
+        m.num_samples += batch_size
+        loss /= batch_size
+        loss.backward()
+        self.optimizer.step()
+
+    def validate(self):
+        return None
+
+    def log_console(self):
+        m = self.tracker.metrics
+        log.info('EPOCH {}/{} | total loss: {:>.3E} | l2 loss: {:>.3E} | rgb loss: {:>.3E}'.format(
+            self.epoch, self.max_epochs, m.average_metric('total_loss'), m.average_metric('l2_loss'), m.average_metric('rgb_loss')))

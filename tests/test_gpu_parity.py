@@ -1975,6 +1975,67 @@ def test_sdf_train_step_matches_torch_adam():
         _assert_same_adam_trajectory(p1, p2, n1, steps=4, max_lr=2e-3)
 
 
+@pytest.mark.parametrize("amp", [False, True])
+def test_dropin_sdf_trainer_class_on_the_gpu(amp):
+    """app/nglod's regime: wisp.trainers.SDFTrainer (the mirror of sdf_trainer.py:32-124, pinned to the reference's method bodies on
+    the host) over the real OctreeGrid + NeuralSDF, batches of 512 from an SDFTensorDataset in HBM, torch.optim.Adam built by
+    init_optimizer - and, with enable_amp (nglod_octree.yaml:68), fp16 autocast around step() as BaseTrainer.iterate applies it.
+    Against SDFTrainStep (the fused step) on the same batches: same losses, same parameter trajectory."""
+    import copy
+    from wisp.accelstructs import OctreeAS
+    from wisp.datasets import SDFTensorDataset
+    from wisp.models import Pipeline
+    from wisp.models.grids import OctreeGrid
+    from wisp.models.nefs import NeuralSDF
+    from wisp.trainers import SDFTrainer, SDFTrainStep, ConfigSDFTrainer, ConfigAdam, ConfigDataloader
+    rng = np.random.default_rng(141)
+    P = rng.integers(0, 32, size=(4000, 3))
+    blas = OctreeAS.from_quantized_points(cuda(P.astype(np.int16)), 5)
+    torch.manual_seed(5)
+    grid = OctreeGrid(blas, feature_dim=16, num_lods=3, multiscale_type='sum', feature_std=0.05)
+    nef = NeuralSDF(grid, pos_embedder='none', position_input=True, hidden_dim=128, num_layers=1).to(DEV)
+    twin = copy.deepcopy(nef)
+    n = 4 * 512
+    coords = cuda(((P[rng.integers(0, P.shape[0], n)] + rng.uniform(0.05, 0.95, (n, 3))) / 16 - 1).astype(np.float32))
+    gts = cuda(rng.normal(size=(n, 1)).astype(np.float32) * 0.1)
+    cfg = ConfigSDFTrainer(optimizer=ConfigAdam(lr=1e-3, eps=1e-15), dataloader=ConfigDataloader(batch_size=512), grid_lr_weight=2.0,
+                           max_epochs=2, enable_amp=amp, only_last=True)
+    tr = SDFTrainer(cfg, Pipeline(nef, None), SDFTensorDataset(coords, gts), device=DEV)
+    assert tr.iterations_per_epoch == 4
+    seen = []
+
+    class _Recording:                                   # the loader's own batches, recorded for the fused step
+        def __init__(self, inner):
+            self.inner = inner
+        def __len__(self):
+            return len(self.inner)
+        def __iter__(self):
+            for b in self.inner:
+                seen.append((b["coords"].clone(), b["sdf"].clone()))
+                yield b
+    tr.train_data_loader = _Recording(tr.train_data_loader)
+    tr.is_optimization_running = True
+    losses = []
+    inner_step = tr.step
+    def recording_step(data):                           # (the metrics are cleared at every epoch start, before the step)
+        before = tr.tracker.metrics.total_loss
+        inner_step(data)
+        losses.append(tr.tracker.metrics.total_loss - before)
+    tr.step = recording_step
+    for _ in range(6):
+        tr.iterate()
+    assert len(losses) == 6 and tr.epoch == 2
+    fused = SDFTrainStep(twin, lr=1e-3, eps=1e-15, grid_lr_weight=2.0, optimizer='adam')
+    want = [float(fused.step(x, y)) * 512 for x, y in seen[:6]]
+    assert all(x.shape == (512, 3) and x.is_cuda for x, _ in seen)
+    np.testing.assert_allclose(losses, want, rtol=(2e-5 if not amp else 2e-2))
+    if not amp:
+        for (n1, p1), (n2, p2) in zip(sorted(nef.named_parameters()), sorted(twin.named_parameters())):
+            _assert_same_adam_trajectory(p1, p2, n1, steps=6, max_lr=2e-3)
+    else:
+        assert all(torch.isfinite(p).all() for p in nef.parameters()) and losses[-1] < losses[0]
+
+
 def _assert_same_adam_trajectory(p1, p2, name, steps, max_lr):
     """Two runs of the same Adam steps whose gradients differ only by the summation order of float atomics.  With eps = 1e-15
     an element whose gradient is rounding noise (|g| ~ 1e-9: e.g. a weight of a mostly inactive relu unit) still moves by the

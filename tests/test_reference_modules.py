@@ -713,6 +713,104 @@ def test_sdf_training_step_semantics_equal_the_reference_method():
             np.testing.assert_allclose(p2.detach().numpy(), p1.detach().numpy(), rtol=1e-5, atol=2e-7, err_msg=n1)
 
 
+@pytest.mark.parametrize("only_last", [True, False])
+def test_dropin_sdf_trainer_class_equals_the_reference_methods(only_last):
+    """wisp.trainers.SDFTrainer (what app/nglod constructs) through its own BaseTrainer.iterate() - next to a trainer assembled
+    from the reference's method bodies compiled where they lie: BaseTrainer.iterate / begin_epoch / end_epoch / init_optimizer and
+    SDFTrainer.pre_epoch / step (sdf_trainer.py:51-124).  512-free: 64 coordinates per batch, 3 epochs of 4 batches, Adam with the
+    name-matched groups: the loss LODs chosen per epoch, per-step losses, the three metric sums and the parameters agree."""
+    import time
+    from wisp.datasets import SDFTensorDataset
+    from wisp.trainers import SDFTrainer, ConfigSDFTrainer, ConfigAdam, ConfigDataloader
+
+    class Field(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(8)
+            self.grid = torch.nn.Module()
+            self.grid.num_lods = 3
+            self.grid.feats = torch.nn.Parameter(torch.randn(3, 32, 4) * 0.1)
+            self.decoder = torch.nn.Linear(4 + 3, 1)
+
+        def forward(self, coords=None, lod_idx=None, channels=None):
+            cell = ((coords[:, 0] * 0.5 + 0.5) * 31).long().clamp(0, 31)
+            f = self.grid.feats[: lod_idx + 1, cell].sum(0)
+            out = self.decoder(torch.cat([f, coords], -1))
+            return [out] if isinstance(channels, (list, tuple)) else out
+
+    class Pipe(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.nef = Field()
+
+    g = torch.Generator().manual_seed(2)
+    X, Y = torch.rand(4 * 64, 3, generator=g) * 2 - 1, torch.randn(4 * 64, 1, generator=g) * 0.1
+
+    class _Loader:                                   # fixed order: both sides see the same batches
+        def __len__(self):
+            return 4
+        def __iter__(self):
+            return iter([{"coords": X[i * 64:(i + 1) * 64], "sdf": Y[i * 64:(i + 1) * 64]} for i in range(4)])
+
+    def make_cfg():
+        return ConfigSDFTrainer(optimizer=ConfigAdam(lr=1e-3, eps=1e-15), dataloader=ConfigDataloader(batch_size=64), grid_lr_weight=2.0,
+                                max_epochs=3, enable_amp=False, only_last=only_last)
+
+    pipe_m = Pipe()
+    tr = SDFTrainer(make_cfg(), pipe_m, SDFTensorDataset(X, Y), device='cpu')
+    assert tr.iterations_per_epoch == 4                                    # 256 coordinates / 64 per batch
+    tr.train_data_loader = _Loader()
+    tr.is_optimization_running = True
+    mine = []
+    for _ in range(11):
+        before = tr.tracker.metrics.total_loss if tr.iteration else 0.0
+        tr.iterate()
+        mine.append((tr.epoch, tr.iteration, list(tr.loss_lods), tr.tracker.metrics.total_loss, tr.tracker.metrics.l2_loss,
+                     tr.tracker.metrics.num_samples))
+
+    glb = dict(torch=_TorchWithoutNvtx(), time=time,
+               instantiate=lambda cfg, params: torch.optim.Adam(params, lr=cfg.lr, eps=cfg.eps, weight_decay=cfg.weight_decay, betas=cfg.betas))
+    class _Base:
+        def pre_epoch(self_inner):
+            me.pipeline.train()
+            me.tracker.metrics.__dict__.update(total_loss=0.0, l2_loss=0.0, rgb_loss=0.0, num_samples=0)
+    glb["super"] = lambda: _Base()
+    body = {m: _reference_method("trainers/base_trainer.py", "BaseTrainer", m, glb)
+            for m in ("iterate", "begin_epoch", "end_epoch", "is_first_iteration", "is_any_iterations_remaining", "reset_data_iterator",
+                      "next_batch", "init_optimizer")}
+    for m in ("pre_epoch", "step"):
+        body[m] = _reference_method("trainers/sdf_trainer.py", "SDFTrainer", m, glb)
+    noop = lambda self, *a, **k: None
+    RefTrainer = type("RefTrainer", (), dict(
+        body, pre_training=noop, post_training=noop, post_epoch=noop, post_step=noop, pre_step=noop, validate=noop,
+        total_iterations=property(lambda self: (self.epoch - 1) * self.iterations_per_epoch + self.iteration),
+        max_iterations=property(lambda self: self.max_epochs * self.iterations_per_epoch)))
+    pipe_r = Pipe()
+    me = RefTrainer()
+    me.pipeline, me.device, me.cfg, me.enable_amp = pipe_r, 'cpu', make_cfg(), False
+    me.tracker = types.SimpleNamespace(metrics=types.SimpleNamespace(total_loss=0.0, l2_loss=0.0, rgb_loss=0.0, num_samples=0),
+                                       log_metric=lambda *a, **k: None)
+    me.scene_state = types.SimpleNamespace(optimization=types.SimpleNamespace(elapsed_time=0.0, iterations_per_epoch=4))
+    me.train_dataset = [0] * 256
+    me.train_data_loader, me.train_data_loader_iter = _Loader(), None
+    me.epoch, me.iteration, me.iterations_per_epoch, me.max_epochs = 1, 0, 4, 3
+    me.is_optimization_running = True
+    me.init_optimizer()
+    me.train_dataset = types.SimpleNamespace()                              # (no sample_tex attribute: the plain branch)
+    theirs = []
+    for _ in range(11):
+        me.iterate()
+        theirs.append((me.epoch, me.iteration, list(me.loss_lods), me.tracker.metrics.total_loss, me.tracker.metrics.l2_loss,
+                       me.tracker.metrics.num_samples))
+    for a, b in zip(mine, theirs):
+        assert a[:3] == b[:3] and a[5] == b[5], (a, b)
+        np.testing.assert_allclose(a[3:5], b[3:5], rtol=2e-6)
+    assert mine[0][2] == ([2] if only_last else [0, 1, 2])
+    for (n1, p1), (n2, p2) in zip(pipe_r.nef.named_parameters(), pipe_m.nef.named_parameters()):
+        assert n1 == n2
+        np.testing.assert_allclose(p2.detach().numpy(), p1.detach().numpy(), rtol=1e-6, atol=1e-8, err_msg=n1)
+
+
 @pytest.mark.parametrize("mode,steps", [("ray", 96), ("voxel", 6)])
 def test_oracle_tracer_equals_the_reference_trace_body(mode, steps):
     """PackedRFTracer.trace (tracers/packed_rf_tracer.py:84-181), the method body compiled from the reference file, driven with
