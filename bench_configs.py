@@ -209,6 +209,26 @@ def run_nglod(args, dev):
     eager_elapsed = time.perf_counter() - t0
     sink, C.TIMING_ALL = C.TIMING_ALL, None
     kernels = _kernel_table(sink)
+    # the reference's own trainer class over this package (app/nglod unchanged): SDFTrainer.iterate(), torch.optim.Adam, fp16 autocast
+    import copy
+    from wisp.datasets import SDFTensorDataset
+    from wisp.models import Pipeline
+    from wisp.trainers import SDFTrainer, ConfigSDFTrainer, ConfigAdam, ConfigDataloader
+    twin = copy.deepcopy(nef)
+    dcfg = ConfigSDFTrainer(optimizer=ConfigAdam(lr=1e-3, eps=1e-15), dataloader=ConfigDataloader(batch_size=B), grid_lr_weight=1.0,
+                            max_epochs=10 ** 6, enable_amp=True, only_last=True)
+    dtr = SDFTrainer(dcfg, Pipeline(twin, None), SDFTensorDataset(coords, gts), device=dev)
+    dtr.is_optimization_running = True
+    for _ in range(20):
+        dtr.iterate()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dsteps = min(args.steps, 200)
+    for _ in range(dsteps):
+        dtr.iterate()
+    torch.cuda.synchronize()
+    dropin_elapsed = time.perf_counter() - t0
+    del dtr, twin
     # the same steps replayed from a captured HIP graph (fixed batch size: every shape of the step is static)
     tr.capture(B)
     for _ in range(args.warmup):
@@ -254,6 +274,9 @@ def run_nglod(args, dev):
                        "batch": B, "pretrain_steps": args.pretrain},
             "issue": "captured HIP graph (forward + loss + backward) + one optimizer launch per step",
             "eager": {"value": B * args.steps / eager_elapsed, "ms_per_step": 1e3 * eager_elapsed / args.steps},
+            "dropin_regime": {"value": B * dsteps / dropin_elapsed, "ms_per_step": 1e3 * dropin_elapsed / dsteps,
+                              "note": "wisp.trainers.SDFTrainer.iterate(): the reference trainer's own step (sdf_trainer.py:65-124) - fp16 "
+                                      "autocast, autograd, torch.optim.Adam, three .item() read-backs per step"},
             "mean_abs_sdf_error": err, "final_loss": float(loss),
             "render": {"rays": int(o.shape[0]), "ms": 1e3 * render_s, "rays_per_sec": o.shape[0] / render_s,
                        "hit_fraction": float(rb.hit.float().mean()), "marching_steps": 32,
@@ -283,7 +306,7 @@ def secondary_lines(args, dev, budget_s=6.0):
         top = list(r["kernels"].items())[:4]
         line = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "roofline") if k in r}
         line["workload"] = r["config"]["workload"]
-        for k in ("gpu_busy_fraction", "gpu_busy_fraction_eager", "samples_per_sec", "psnr_db_train_rays", "eager", "issue"):
+        for k in ("gpu_busy_fraction", "gpu_busy_fraction_eager", "samples_per_sec", "psnr_db_train_rays", "eager", "issue", "dropin_regime"):
             if k in r:
                 line[k] = r[k]
         if "render" in r:
