@@ -188,6 +188,22 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
                     // instead of a sign extension and a 64-bit add
                     const __amdgpu_buffer_rsrc_t rsrc =
                         __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(table), (short)0, (int)0x7fffffff, 0x00020000);
+                    if (W == 1 && dense && res < 258) {
+                        // Dense level: the row index is x + y res + z res^2, so a corner and its +x neighbour (j and j + half:
+                        // axis 0 is the top bit of j) are ADJACENT entries - one 8-byte load fetches both.  The kernel is bound
+                        // by the rate at which the texture-address path takes lane requests (a table that fits L2 eight times
+                        // over is only 8 % faster, scripts/exp_l2.py), and this halves them on the dense levels: 120 -> 88
+                        // gathers per sample at the nerf_hash shape.
+                        constexpr int half = 1 << (DIM - 1);
+                        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int j = 0; j < half; ++j) {
+                            const int voff = (int)((uint32_t)cs.idx[j] * (uint32_t)(F * sizeof(T)));
+                            const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0);
+                            *reinterpret_cast<uint32_t*>(&v[j][0]) = t[0];
+                            *reinterpret_cast<uint32_t*>(&v[j + half][0]) = t[1];
+                        }
+                    } else
 #pragma unroll
                     for (int j = 0; j < (1 << DIM); ++j) {
                         const int voff = (int)((uint32_t)cs.idx[j] * (uint32_t)(F * sizeof(T)));
