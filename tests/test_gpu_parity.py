@@ -1072,6 +1072,62 @@ def test_dropin_regime_overflowing_loss_scale_skips_the_step_and_backs_off():
     assert tr.scaler.get_scale() < 2.0 ** 39
 
 
+@pytest.mark.parametrize("kind,march,steps", [("hash", "voxel", 6), ("octree", "voxel", 6), ("codebook", "voxel", 6), ("codebook", "ray", 96)])
+def test_dropin_regime_other_configs_fp16_autocast_tracks_fp32(kind, march, steps):
+    """The unchanged trainer over the other BASELINE configurations' pieces (C4: hash grid + 'voxel' march; nerf_octree /
+    C5 VQAD: OctreeGrid / CodebookOctreeGrid, bias-free decoders, RMSprop): three iterations of wisp.trainers.MultiviewTrainer with
+    enable_amp (fp16 autocast + GradScaler) next to the same trainer without amp from the same state and the same in-kernel
+    jitter seeds: same sample counts, losses within fp16 / bf16-decoder tolerance, no overflow (the scale stands), finite
+    parameters - the kernels under the octree and codebook grids compute in fp32 whatever the ambient autocast dtype."""
+    import copy
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.models.grids import CodebookOctreeGrid, OctreeGrid
+    from wisp.models.nefs import NeuralRadianceField
+    from wisp.tracers import PackedRFTracer
+    from wisp.datasets import MultiviewTensorDataset, SampleRays
+    from wisp.trainers import MultiviewTrainer, ConfigMultiviewTrainer, ConfigAdamW, ConfigRMSprop
+    if kind == "hash":
+        nef, _, _ = _build_pair(lods=16)
+    else:
+        blas, _ = _sparse_blas(5, 3000, 131)
+        torch.manual_seed(3)
+        if kind == "octree":
+            grid = OctreeGrid(blas, feature_dim=5, num_lods=4, multiscale_type='sum', feature_std=0.5)
+        else:
+            grid = CodebookOctreeGrid(blas, feature_dim=5, num_lods=4, multiscale_type='sum', feature_std=0.7, codebook_bitwidth=4)
+        nef = NeuralRadianceField(grid, view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1,
+                                  bias=(kind != "codebook")).to(DEV)
+    R = 400
+    o, d = make_rays(R, 391)
+    gts = cuda(np.random.default_rng(393).uniform(size=(R, 3)).astype(np.float32))
+    data = {"rays": Rays(cuda(o)[None], cuda(d)[None], dist_min=1.0, dist_max=5.0), "rgb": gts[None]}
+    runs = {}
+    for amp in (False, True):
+        pipe = Pipeline(copy.deepcopy(nef), PackedRFTracer(raymarch_type=march, num_steps=steps, bg_color=(1.0, 1.0, 1.0)))
+        ds = MultiviewTensorDataset(cuda(o)[None], cuda(d)[None], gts[None], 1.0, 5.0, transform=SampleRays(R))
+        oc = ConfigRMSprop(lr=1e-3, eps=1e-8) if kind == "codebook" else ConfigAdamW(lr=1e-3, eps=1e-16, weight_decay=1e-6)
+        cfg = ConfigMultiviewTrainer(optimizer=oc, grid_lr_weight=100.0, enable_amp=amp, prune_every=-1,
+                                     rgb_loss_type='l2' if kind == "codebook" else 'huber', max_epochs=10)
+        tr = MultiviewTrainer(cfg, pipe, ds, device=DEV)
+        losses, counts = [], []
+        with torch.autocast('cuda', enabled=amp):
+            tr.step(data)                                            # warm-up call
+            for k in range(3):
+                torch.manual_seed(50 + k)                            # the marches draw their jitter seed from torch's generator
+                before = tr.tracker.metrics.rgb_loss
+                tr.step(data)
+                losses.append(tr.tracker.metrics.rgb_loss - before)
+                counts.append(pipe.tracer.get_prev_num_samples())
+        assert all(torch.isfinite(p).all() for p in pipe.nef.parameters())
+        if amp:
+            assert tr.scaler.get_scale() == 65536.0
+        runs[amp] = (losses, counts)
+    assert runs[True][1] == runs[False][1] and min(runs[True][1]) > 1000
+    np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=3e-2)
+    assert runs[False][0][2] < runs[False][0][0]                       # and it trains
+
+
 def test_prune_rebuilds_identical_octree():
     nef, onef, oblas = _build_pair()
     cells = nef.grid.dense_points.shape[0]
