@@ -497,6 +497,12 @@ def main():
                         avg_launch_ms=k["avg_ms"], units_per_launch=k["avg_units"], work_per_unit=work[dominant][1],
                         all_kernels={n: dict(avg_ms=v["avg_ms"], bound=rate(n, v)[0], achieved=rate(n, v)[1],
                                              frac=rate(n, v)[1] / peaks[rate(n, v)[0]][0]) for n, v in kern.items()})
+        if "hashgrid_fwd" in roofline["all_kernels"]:
+            roofline["all_kernels"]["hashgrid_fwd"]["note"] = (
+                "algorithmic bytes (SURVEY 8d: 588 B/sample incl. 512 gathered) over launch time; the 20.9 MB of tables are L2 / "
+                "Infinity-Cache resident, so HBM-side traffic is ~0.63 of that (profiles/r03_pmc_FETCH_SIZE.csv) and the fraction "
+                "can approach or pass 1: it says the gathers run as fast as if every byte came from HBM at peak, not that HBM bounds them "
+                "(the kernel is bound by the rate of gather requests: scripts/exp_l2.py)")
 
     out = None
     if rank == 0:
