@@ -1,6 +1,8 @@
 """Test infrastructure: ctypes access to oracle/_ref/libwisp_ref.so - the REFERENCE's own kernel bodies
 (wisp/csrc/ops/hashgrid_interpolate_cuda.cu:19-339, hash_utils.cuh:17-112, uniform_sample_cuda.cu:18-59)
-compiled for the host by oracle/build_ref.sh.  Used to pin oracle/hashgrid.py and oracle/raymarch.uniform_sample
+compiled for the host by oracle/build_ref.sh (the 3-D interpolation kernels carry a tap macro right after their floor() so that
+`cells_3d` can read the scaled position and integer cell the reference code computed; `fma_cells` is NOT reference code: libm's fmaf
+evaluation of this package's one-fma formula, kept here because the two are compared with each other).  Used to pin oracle/hashgrid.py and oracle/raymarch.uniform_sample
 against the real reference arithmetic and to generate tests/golden/*.npz.  Absent => `available()` is False.  Also holds the
 SDF tracer's find_depth_bound kernel body (render/find_depth_bound_cuda.cu:16-45) and the corner-query kernels (hashgrid_query_cuda.cu)."""
 import ctypes
