@@ -27,7 +27,9 @@ LEVEL, DECAY, MIN_DENSITY = 7, 0.95, 2.956033378250884
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--backend", choices=["hip", "oracle"])
+    ap.add_argument("--backend", choices=["hip", "dropin", "oracle"],
+                    help="hip = MultiviewTrainStep (fused step); dropin = wisp.trainers.MultiviewTrainer, the reference trainer's own step "
+                         "(fp16 autocast + GradScaler + torch.optim.AdamW over the modular pipeline); oracle = CPU restatement")
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--rays", type=int, default=256)
     ap.add_argument("--num-steps", type=int, default=2048)
@@ -35,6 +37,7 @@ def parse():
     ap.add_argument("--perturb", type=float, default=0.0,
                     help="relative N(0, perturb) noise on the initial decoder weights: a second run of the SAME backend with "
                          "e.g. 1e-6 measures how far two trajectories of this chaotic optimisation drift apart on their own")
+    ap.add_argument("--amp", action="store_true", help="hip backend: bf16 tables + bf16 decoder (the bench's default precision) instead of fp32")
     ap.add_argument("--out", default=None)
     ap.add_argument("--compare", nargs=2, default=None)
     return ap.parse_args()
@@ -102,19 +105,64 @@ def main():
         dev = torch.device("cuda", 0)
         nef = nef.to(dev)
         pipe = Pipeline(nef, PackedRFTracer(raymarch_type='ray', num_steps=args.num_steps, bg_color=(0.0, 0.0, 0.0)))
-        tr = MultiviewTrainStep(pipe, prune_every=100, lr=1e-3, grid_lr_weight=100.0, seed=0, prune_rng_device='cpu')
+        tr = MultiviewTrainStep(pipe, prune_every=100, lr=1e-3, grid_lr_weight=100.0, seed=0, prune_rng_device='cpu', enable_amp=args.amp)
 
         def evaluate():
-            with torch.no_grad():
+            with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=args.amp):
                 rb = pipe(rays=Rays(eo.to(dev), ed.to(dev), dist_min=1.0, dist_max=5.0), channels=["rgb"],
                           jitter=torch.from_numpy(eval_jit).to(dev))
-            mse = float(((rb.rgb.cpu() - egt) ** 2).mean())
+            mse = float(((rb.rgb.float().cpu() - egt) ** 2).mean())
             return 10 * np.log10(1.0 / mse), int(pipe.nef.grid.blas.pyramid[0, LEVEL])
 
         def step(idx, jit):
             loss, ns = tr.step(Rays(o[idx].to(dev), d[idx].to(dev), dist_min=1.0, dist_max=5.0), gt[idx].to(dev),
                                jitter=torch.from_numpy(jit).to(dev))
             return float(loss), ns
+    elif args.backend == "dropin":
+        # the unchanged-trainer regime on identical batches / jitter / prune draws: pre_step (prune timing) and step() of the class,
+        # called the way BaseTrainer.iterate calls them (pre_step outside, step inside `torch.autocast('cuda')` = fp16)
+        from wisp.core import Rays
+        from wisp.datasets import MultiviewTensorDataset, SampleRays
+        from wisp.models import Pipeline
+        from wisp.tracers import PackedRFTracer
+        from wisp.trainers import MultiviewTrainer, ConfigMultiviewTrainer, ConfigAdamW
+        dev = torch.device("cuda", 0)
+        nef = nef.to(dev)
+        pipe = Pipeline(nef, PackedRFTracer(raymarch_type='ray', num_steps=args.num_steps, bg_color=(0.0, 0.0, 0.0)))
+        ds = MultiviewTensorDataset(o[None, :args.rays].to(dev), d[None, :args.rays].to(dev), gt[None, :args.rays].to(dev), 1.0, 5.0,
+                                    transform=SampleRays(args.rays))
+        cfg = ConfigMultiviewTrainer(optimizer=ConfigAdamW(lr=1e-3, eps=1e-16, weight_decay=1e-6), grid_lr_weight=100.0, enable_amp=True,
+                                     scheduler=False, prune_every=100, rgb_loss_type='huber', rgb_loss_denom='rays', max_epochs=10 ** 6)
+        tr = MultiviewTrainer(cfg, pipe, ds, device=dev)
+        tr.iterations_per_epoch = 10 ** 9
+
+        def seeded_prune():                                   # the draws MultiviewTrainStep.prune makes with prune_rng_device='cpu'
+            cells = nef.grid.dense_points.shape[0]
+            unit = torch.rand(cells, 3, generator=prune_gen)
+            views = torch.nn.functional.normalize(torch.randn(cells, 3, generator=prune_gen), dim=1)
+            type(nef).prune(nef, unit_samples=unit, view_dirs=views)
+        nef.prune = seeded_prune
+        with torch.autocast('cuda', enabled=True):            # the trainer's first call only sizes the batch
+            tr.step({"rays": Rays(o[None, :args.rays].to(dev), d[None, :args.rays].to(dev), dist_min=1.0, dist_max=5.0),
+                     "rgb": gt[None, :args.rays].to(dev)})
+        count = {"it": 0}
+
+        def evaluate():
+            pipe.tracer.jitter = torch.from_numpy(eval_jit).to(dev)
+            with torch.no_grad():
+                rb = pipe(rays=Rays(eo.to(dev), ed.to(dev), dist_min=1.0, dist_max=5.0), channels=["rgb"])
+            mse = float(((rb.rgb.float().cpu() - egt) ** 2).mean())
+            return 10 * np.log10(1.0 / mse), int(pipe.nef.grid.blas.pyramid[0, LEVEL])
+
+        def step(idx, jit):
+            tr.iteration = count["it"]                        # 0-based like the other two backends: prunes before steps 101, 201, ...
+            count["it"] += 1
+            tr.pre_step()
+            pipe.tracer.jitter = torch.from_numpy(jit).to(dev)
+            before = tr.tracker.metrics.rgb_loss
+            with torch.autocast('cuda', enabled=True):
+                tr.step({"rays": Rays(o[idx][None].to(dev), d[idx][None].to(dev), dist_min=1.0, dist_max=5.0), "rgb": gt[idx][None].to(dev)})
+            return tr.tracker.metrics.rgb_loss - before, pipe.tracer.get_prev_num_samples()
     else:
         from oracle import nerf as onerf, spc as ospc
         res = [int(r) for r in grid.resolutions]
