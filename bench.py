@@ -151,7 +151,7 @@ def collective_selftest(dev, rank):
 def hidden128_line(args, dev, pipe, batch, size_batch, steps=30):
     """nerf_hash.yaml with hidden_dim 128 - the reference's best published row (docs/pages/app_nerf.md:185-192) - on the
     occupancy the main run has learned: a fresh model of that width over a copy of the current octree, a few steps at the
-    headline batch size (modular issue: the direct step covers hidden 64)."""
+    headline batch size (direct-issue step under amp, like the headline)."""
     from wisp.accelstructs import OctreeAS
     from wisp.models import Pipeline
     from wisp.models.grids import HashGrid

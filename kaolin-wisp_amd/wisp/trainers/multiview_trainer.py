@@ -104,7 +104,7 @@ class _DirectNeRFStep:
         from wisp.accelstructs import OctreeAS
         from wisp.models.nefs import NeuralRadianceField
         from wisp.tracers import PackedRFTracer
-        from wisp.ops.nerf_mlp import SUPPORTED
+        from wisp.ops.nerf_mlp import SUPPORTED, FUSED_HIDDEN
         nef, tracer = pipeline.nef, pipeline.tracer
         if type(nef) is not NeuralRadianceField or type(tracer) is not PackedRFTracer:
             return False
@@ -113,7 +113,7 @@ class _DirectNeRFStep:
             return False
         if getattr(tracer, 'raymarch_type', None) not in ('ray', 'voxel', 'uniform'):
             return False
-        return (nef.fused_decoder and nef.hidden_dim == SUPPORTED["hidden"] and nef.num_layers == 1      # (hidden 128: modular path)
+        return (nef.fused_decoder and nef.hidden_dim in FUSED_HIDDEN and nef.num_layers == 1             # (hidden 128: bf16 only, see __init__)
                 and nef.view_multires == SUPPORTED["view_freqs"] and nef.pos_embedder is None
                 and nef.view_embedder_type == 'positional' and nef.activation_type == 'relu'
                 and nef.layer_type in ('linear', 'none') and 1 <= nef.effective_feature_dim() <= SUPPORTED["max_in_dim"]
@@ -121,11 +121,11 @@ class _DirectNeRFStep:
 
     def __init__(self, trainer):
         from wisp.models.grids import HashGrid
-        from wisp.ops.nerf_mlp import _flat_view, _pack, SUPPORTED
+        from wisp.ops.nerf_mlp import _flat_view, _pack, SUPPORTED, BF16_ONLY_HIDDEN
         self.t = trainer
         nef = trainer.pipeline.nef
         grid = nef.grid
-        H, I = SUPPORTED["hidden"], nef.effective_feature_dim()
+        H, I = nef.hidden_dim, nef.effective_feature_dim()
         self.shape = (I, H, SUPPORTED["view_freqs"])
         self.param_shapes = ((H, I), (H,), (16, H), (16,), (H, 42), (H,), (H, H), (H,), (3, H), (3,))
         dec = _decoder_tensors(nef)
@@ -141,6 +141,8 @@ class _DirectNeRFStep:
             self._scratch_grad = torch.zeros(sum(int(np.prod(sh)) for sh in self.param_shapes), dtype=torch.float32,
                                              device=trainer.flat.data.device)
             self.ok = all(p is None or p.grad is not None for p in dec)
+        if H in BF16_ONLY_HIDDEN and not trainer.enable_amp:
+            self.ok = False                                                  # the wide decoder kernels compute in bf16 only
         self.hash_fast = type(grid) is HashGrid and grid.multiscale_type == 'cat' and grid.codebook.feats.grad is not None
         if self.hash_fast:
             cb = grid.codebook

@@ -1313,6 +1313,41 @@ def test_trainer_flat_params_step_matches_unfused_torch_path():
         assert float((diff > 3e-4).float().mean()) <= allowed and float(diff.median()) <= 1e-6, n1
 
 
+def test_direct_step_covers_hidden_128_under_amp(monkeypatch):
+    """hidden_dim 128 (the reference's best published nerf_hash row) through the direct-issue step - the wide decoder kernels compute
+    in bf16, so the direct path takes it under amp only - against the modular step from the same state: same sample count, loss
+    and gradients."""
+    import copy
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.tracers import PackedRFTracer
+    from wisp.trainers import MultiviewTrainStep
+    nef, _, _ = _build_pair(lods=16, hidden=128)
+    nef2 = copy.deepcopy(nef)
+    o, d = make_rays(500, 195)
+    jit = cuda(np.random.default_rng(196).uniform(size=(500, 96)).astype(np.float32))
+    gts = cuda(np.random.default_rng(197).uniform(size=(500, 3)).astype(np.float32))
+    rays = Rays(cuda(o), cuda(d), dist_min=1.0, dist_max=5.0)
+    assert MultiviewTrainStep(Pipeline(copy.deepcopy(nef), PackedRFTracer(raymarch_type='ray', num_steps=96)), prune_every=-1,
+                              enable_amp=False)._direct is None                    # fp32: stays modular
+    tr1 = MultiviewTrainStep(Pipeline(nef, PackedRFTracer(raymarch_type='ray', num_steps=96, bg_color=(0, 0, 0))), prune_every=-1, enable_amp=True)
+    assert tr1._direct is not None
+    monkeypatch.setenv("WISP_DIRECT_STEP", "0")
+    tr2 = MultiviewTrainStep(Pipeline(nef2, PackedRFTracer(raymarch_type='ray', num_steps=96, bg_color=(0, 0, 0))), prune_every=-1, enable_amp=True)
+    assert tr2._direct is None
+    grads = {}
+    for name, tr in (("direct", tr1), ("modular", tr2)):
+        def snap(tr=tr, name=name):
+            grads[name] = tr.flat.grad.clone()
+            tr.flat.grad.zero_()
+        tr.optimizer_step = snap
+    l1, s1 = tr1.step(rays, gts, jitter=jit)
+    l2, s2 = tr2.step(rays, gts, jitter=jit)
+    assert s1 == s2 and abs(float(l1) - float(l2)) <= 1e-6 * max(1.0, abs(float(l2)))
+    g1, g2 = grads["direct"].cpu().numpy(), grads["modular"].cpu().numpy()
+    np.testing.assert_allclose(g1, g2, rtol=0, atol=1e-5 * float(np.abs(g2).max()))
+
+
 @pytest.mark.parametrize("amp", [False, True])
 def test_direct_step_equals_modular_step(amp, monkeypatch):
     """The direct-issue step of MultiviewTrainStep (same launches, no module / autograd plumbing) against the modular
