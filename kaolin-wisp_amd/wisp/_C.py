@@ -521,9 +521,10 @@ RAYTRACE_CACHE_CAP = 64                  # nuggets per ray parked by the count p
 RAYTRACE_CACHE_LIMIT = 2 << 30           # bytes; beyond that the emit phase walks the octree again
 
 
-def spc_raytrace(octree, points, exsum, origins, dirs, level, with_exit=False):
-    """kaolin.render.spc.unbatched_raytrace (octree_as.py:183-185).
-    Returns (ridx i32 [M], pidx i32 [M], depth f32 [M,1|2], ray_offsets i64 [R+1])."""
+def spc_raytrace_begin(octree, points, exsum, origins, dirs, level):
+    """First half of spc_raytrace: per-ray nugget counts (their first RAYTRACE_CACHE_CAP nuggets parked) and the offsets.
+    Needs no field parameters and no host read-back - the total travels to pinned memory on a side stream - so a trainer can
+    issue it for the NEXT batch early (the 'voxel' / 'uniform' marches' equivalent of raymarch_ray_count)."""
     origins = _need(origins, torch.float32, "origins").reshape(-1, 3)
     dirs = _need(dirs, torch.float32, "dirs").reshape(-1, 3)
     octree = _need(octree, torch.uint8, "octree")
@@ -537,16 +538,32 @@ def spc_raytrace(octree, points, exsum, origins, dirs, level, with_exit=False):
     cache = torch.empty(R * cap * 3, dtype=torch.float32, device=dev) if cap else None
     _check(lib.wisp_spc_raytrace_count(_p(octree), _p(points), _p(exsum), _p(origins), _p(dirs), R, level, _p(counts),
                                        _p(cache), cap, _stream()), "spc_raytrace_count")
-    offsets = exclusive_scan(counts)
-    M = int(offsets[-1].item())                      # size read-back, as the reference's kaolin op does
+    st = dict(octree=octree, points=points, exsum=exsum, origins=origins, dirs=dirs, level=level, cache=cache, cap=cap,
+              offsets=exclusive_scan(counts))
+    if dev.type == "cuda":
+        _read_total_async(st)
+    return st
+
+
+def spc_raytrace_finish(st, with_exit=False):
+    """Second half: size read-back (as the reference's kaolin op does), allocation and emit."""
+    origins, offsets = st["origins"], st["offsets"]
+    R, dev = origins.shape[0], origins.device
+    M = _total(st)
     ridx = torch.empty(M, dtype=torch.int32, device=dev)
     pidx = torch.empty(M, dtype=torch.int32, device=dev)
     depth = torch.empty(M, 2 if with_exit else 1, dtype=torch.float32, device=dev)
     if M:
-        _check(lib.wisp_spc_raytrace_emit(_p(octree), _p(points), _p(exsum), _p(origins), _p(dirs), R, level,
-                                          _p(offsets), int(with_exit), _p(cache), cap, _p(ridx), _p(pidx), _p(depth),
-                                          _stream()), "spc_raytrace_emit")
+        _check(lib.wisp_spc_raytrace_emit(_p(st["octree"]), _p(st["points"]), _p(st["exsum"]), _p(origins), _p(st["dirs"]), R,
+                                          st["level"], _p(offsets), int(with_exit), _p(st["cache"]), st["cap"], _p(ridx),
+                                          _p(pidx), _p(depth), _stream()), "spc_raytrace_emit")
     return ridx, pidx, depth, offsets
+
+
+def spc_raytrace(octree, points, exsum, origins, dirs, level, with_exit=False):
+    """kaolin.render.spc.unbatched_raytrace (octree_as.py:183-185).
+    Returns (ridx i32 [M], pidx i32 [M], depth f32 [M,1|2], ray_offsets i64 [R+1])."""
+    return spc_raytrace_finish(spc_raytrace_begin(octree, points, exsum, origins, dirs, level), with_exit)
 
 
 def spc_trilinear_coeffs(coords, voxel_points, level):
@@ -613,11 +630,16 @@ def spc_trilinear_multi_forward(coords, chain, points, trinkets, feats_list, lev
     return out
 
 
-def spc_trilinear_multi_backward(coords, chain, points, trinkets, grad_out, feats_shapes, levels, sum_lods):
+def spc_trilinear_multi_backward(coords, chain, points, trinkets, grad_out, feats_shapes, levels, sum_lods, out=None):
+    """out: optional list of f32 tensors of feats_shapes the corner gradients are ADDED to (e.g. the parameters' .grad)."""
     coords = _need(coords, torch.float32, "coords")
     grad_out = _need(grad_out, torch.float32, "grad_out")
     N, L, C = coords.shape[0], len(feats_shapes), feats_shapes[0][1]
-    grads = [torch.zeros(tuple(sh), dtype=torch.float32, device=coords.device) for sh in feats_shapes]
+    if out is None:
+        grads = [torch.zeros(tuple(sh), dtype=torch.float32, device=coords.device) for sh in feats_shapes]
+    else:
+        grads = [_need(g, torch.float32, "out") for g in out]
+        assert len(grads) == L and all(tuple(g.shape) == tuple(sh) for g, sh in zip(grads, feats_shapes))
     garr, gptr = _ptr_array(grads)
     larr, lptr = _host_i32(levels)
     _check(lib.wisp_spc_trilinear_multi_bwd(_p(coords), _p(chain), chain.stride(0), _p(points), _p(trinkets), _p(grad_out), N, L,
@@ -667,10 +689,7 @@ def codebook_trilinear_forward(coords, pidx, points, trinkets, logits, dictionar
     K, F = dictionary.shape
     if CODEBOOK_DECODE_ROWS and V * S >= 4 * logits.shape[0]:
         # decode every logits row once, then the plain trilinear blend (bit-identical; see wisp_codebook_decode_rows)
-        decoded = torch.empty(logits.shape[0], F, dtype=torch.float32, device=coords.device)
-        _check(lib.wisp_codebook_decode_rows(_p(logits), _p(dictionary), logits.shape[0], K, F, int(training), _p(decoded),
-                                             _stream()), "codebook_decode_rows")
-        return spc_trilinear_forward(coords, pidx, points, trinkets, decoded, level)
+        return spc_trilinear_forward(coords, pidx, points, trinkets, codebook_decode_rows(logits, dictionary, training), level)
     out = torch.empty(V, S, F, dtype=torch.float32, device=coords.device)
     _check(lib.wisp_codebook_trilinear_fwd(_p(coords), _p(pidx), is64, _p(_need(points, torch.int16, "points")),
                                            _p(_need(trinkets, torch.int32, "trinkets")), _p(logits), _p(dictionary), V, S, K, F,
@@ -678,7 +697,22 @@ def codebook_trilinear_forward(coords, pidx, points, trinkets, logits, dictionar
     return out
 
 
-def codebook_trilinear_backward(coords, pidx, points, trinkets, logits, dictionary, grad_out, level):
+def codebook_decode_rows(logits, dictionary, training):
+    """The dictionary vector every logits row selects (straight-through softmax one-hot in training, argmax in eval):
+    logits [rows, K], dictionary [K, F] -> f32 [rows, F]; the plain trilinear blend over it equals the fused lookup bit for bit."""
+    logits = _need(logits, torch.float32, "logits")
+    dictionary = _need(dictionary, torch.float32, "dictionary")
+    K, F = dictionary.shape
+    decoded = torch.empty(logits.shape[0], F, dtype=torch.float32, device=logits.device)
+    _check(lib.wisp_codebook_decode_rows(_p(logits), _p(dictionary), logits.shape[0], K, F, int(training), _p(decoded),
+                                         _stream()), "codebook_decode_rows")
+    return decoded
+
+
+def codebook_trilinear_backward(coords, pidx, points, trinkets, logits, dictionary, grad_out, level, out=None):
+    """-> (grad logits, grad dictionary).  out: optional pair of f32 tensors that ARE ZERO (the kernels use the logits gradient as
+    their corner scratch): the result is written there instead of into fresh buffers - e.g. a parameter's .grad right after
+    zero_grad."""
     coords = _need(coords, torch.float32, "coords")
     pidx, is64 = _pidx_arg(pidx)
     logits = _need(logits, torch.float32, "logits")
@@ -686,8 +720,12 @@ def codebook_trilinear_backward(coords, pidx, points, trinkets, logits, dictiona
     grad_out = _need(grad_out, torch.float32, "grad_out")
     V, S = coords.shape[0], coords.shape[1]
     K, F = dictionary.shape
-    g_logits = torch.zeros_like(logits)
-    g_dict = torch.zeros_like(dictionary)
+    if out is None:
+        g_logits = torch.zeros_like(logits)
+        g_dict = torch.zeros_like(dictionary)
+    else:
+        g_logits, g_dict = _need(out[0], torch.float32, "out logits"), _need(out[1], torch.float32, "out dictionary")
+        assert g_logits.shape == logits.shape and g_dict.shape == dictionary.shape
     _check(lib.wisp_codebook_trilinear_bwd(_p(coords), _p(pidx), is64, _p(_need(points, torch.int16, "points")),
                                            _p(_need(trinkets, torch.int32, "trinkets")), _p(logits), _p(dictionary), _p(grad_out),
                                            V, S, K, F, level, logits.shape[0], _p(g_logits), _p(g_dict), _stream()),

@@ -128,13 +128,27 @@ class OctreeAS(BaseAS):
         self._to_device(coords.device)
         return ASQueryResults(pidx=_hip().spc_query(self.octree, self.prefix, coords, level, with_parents))
 
-    def raytrace(self, rays, level=None, with_exit=False) -> ASRaytraceResults:
-        """All ray / cell intersections at `level`, sorted by ray then front to back."""
+    def raytrace_begin(self, rays, level=None):
+        """The parameter-free, read-back-free first half of raytrace() (counts and offsets); hand the result to
+        raytrace(..., begun=...).  A trainer issues it one batch ahead so that the size read-back never drains the GPU."""
         if level is None:
             level = self.max_level
         self._to_device(rays.origins.device)
-        ridx, pidx, depth, offsets = _hip().spc_raytrace(self.octree, self.points, self.prefix, rays.origins,
-                                                         rays.dirs, level, with_exit)
+        st = _hip().spc_raytrace_begin(self.octree, self.points, self.prefix, rays.origins, rays.dirs, level)
+        st["blas"], st["rays"] = self, rays
+        return st
+
+    def _begun_fits(self, begun, rays, level):
+        return (begun is not None and begun.get("blas") is self and begun.get("rays") is rays and begun.get("level") == level
+                and "offsets" in begun)
+
+    def raytrace(self, rays, level=None, with_exit=False, begun=None) -> ASRaytraceResults:
+        """All ray / cell intersections at `level`, sorted by ray then front to back."""
+        if level is None:
+            level = self.max_level
+        if not self._begun_fits(begun, rays, level):      # nothing (valid) was issued ahead for these rays on this octree
+            begun = self.raytrace_begin(rays, level)
+        ridx, pidx, depth, offsets = _hip().spc_raytrace_finish(begun, with_exit)
         res = ASRaytraceResults(ridx=ridx, pidx=pidx, depth=depth)
         res.ray_offsets = offsets     # nugget range of every ray; used by 'uniform' raymarch
         return res
@@ -144,9 +158,9 @@ class OctreeAS(BaseAS):
     def _draw_seed():
         return int(torch.randint(0, 2 ** 62, (1,)).item())   # follows torch.manual_seed
 
-    def _raymarch_voxel(self, rays, num_samples, level=None, jitter=None) -> ASRaymarchResults:
+    def _raymarch_voxel(self, rays, num_samples, level=None, jitter=None, begun=None) -> ASRaymarchResults:
         """num_samples jittered samples inside every intersected cell (S = nuggets * num_samples)."""
-        rt = self.raytrace(rays, level, with_exit=True)
+        rt = self.raytrace(rays, level, with_exit=True, begun=begun)
         ridx, samples, depth, deltas, boundary = _hip().raymarch_voxel(
             rays.origins, rays.dirs, rt.ridx, rt.depth, num_samples, jitter, self._draw_seed())
         res = ASRaymarchResults(ridx=ridx, samples=samples, depth_samples=depth, deltas=deltas, boundary=boundary,
@@ -168,9 +182,9 @@ class OctreeAS(BaseAS):
         res.ray_offsets = offsets
         return res
 
-    def _raymarch_uniform(self, rays, num_samples, level=None) -> ASRaymarchResults:
+    def _raymarch_uniform(self, rays, num_samples, level=None, begun=None) -> ASRaymarchResults:
         """Fixed world-space lattice of spacing ~2*sqrt(3)/num_samples clipped to the intersected cells."""
-        rt = self.raytrace(rays, level, with_exit=True)
+        rt = self.raytrace(rays, level, with_exit=True, begun=begun)
         step_size = 2 * np.sqrt(3) / num_samples
         scale = int(np.ceil(1.0 / step_size))
         step_size = 1.0 / float(scale)
@@ -181,16 +195,21 @@ class OctreeAS(BaseAS):
         res.ray_offsets = sample_offsets.index_select(0, rt.ray_offsets)    # per-nugget sample offsets at each ray's first nugget
         return res
 
-    def raymarch(self, rays, raymarch_type, num_samples, level=None, jitter=None) -> ASRaymarchResults:
-        """Generate packed samples along `rays`; raymarch_type in {'voxel', 'ray', 'uniform'}."""
+    def raymarch(self, rays, raymarch_type, num_samples, level=None, jitter=None, begun=None, begin_only=False) -> ASRaymarchResults:
+        """Generate packed samples along `rays`; raymarch_type in {'voxel', 'ray', 'uniform'}.
+        begin_only: issue only the march's read-back-free prefix for `rays` (the cell intersection counts of 'voxel' and
+        'uniform') and return its state - or None where the march has none; `begun`: such a state, issued earlier for the same
+        Rays object (ignored when it does not fit: other rays, other level, an octree replaced by a prune)."""
         if level is None:
             level = self.max_level
+        if begin_only:
+            return self.raytrace_begin(rays, level) if raymarch_type in ('voxel', 'uniform') else None
         if raymarch_type == 'voxel':
-            return self._raymarch_voxel(rays=rays, num_samples=num_samples, level=level, jitter=jitter)
+            return self._raymarch_voxel(rays=rays, num_samples=num_samples, level=level, jitter=jitter, begun=begun)
         elif raymarch_type == 'ray':
             return self._raymarch_ray(rays=rays, num_samples=num_samples, level=level, jitter=jitter)
         elif raymarch_type == 'uniform':
-            return self._raymarch_uniform(rays=rays, num_samples=num_samples, level=level)
+            return self._raymarch_uniform(rays=rays, num_samples=num_samples, level=level, begun=begun)
         raise TypeError(f"Raymarch sampler type: {raymarch_type} is not supported by OctreeAS.")
 
     # ------------------------------------------------------------------ stats

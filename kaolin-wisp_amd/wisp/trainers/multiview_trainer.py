@@ -95,8 +95,10 @@ class _DirectNeRFStep:
       * everything but the grid is always issued directly: raymarch ('ray' with a prefetched occupancy count, 'voxel' and
         'uniform' through OctreeAS.raymarch), fused decoder forward / backward, compositing forward / backward, loss;
       * the grid lookup is issued directly for the nerf_hash.yaml shape ('cat' HashGrid whose table gradient lives in the flat
-        buffer); any other grid of the plugin surface (OctreeGrid, CodebookOctreeGrid, TriplanarGrid, 'sum' HashGrid) keeps its own
-        `interpolate` - one small autograd graph whose backward is seeded with the decoder's input gradient.
+        buffer) and for multi-level trilinear OctreeGrid / CodebookOctreeGrid fields (nerf_octree.yaml, nerf_codebook.yaml: one
+        launch for all levels forward, gradients written straight into the parameters' .grad); any other grid of the plugin
+        surface (TriplanarGrid, 'sum' HashGrid, one-level or 'closest' octree grids) keeps its own `interpolate` - one small
+        autograd graph whose backward is seeded with the decoder's input gradient.
     Results are identical to the modular path (tests/test_gpu_parity.py::test_direct_step_equals_modular_step)."""
 
     @staticmethod
@@ -153,24 +155,92 @@ class _DirectNeRFStep:
             # the tracer queries lod_idx = num_lods - 1 and 'cat' zeroes the columns from lod_idx * feature_dim on
             # (reference hash_grid.py:226-229): the finest level's columns are zero, exactly as in the modular path
             self.zero_from_col = (grid.num_lods - 1) * grid.feature_dim
+        self.octree_tier = None if self.hash_fast else self._octree_tier(grid)
         self._pending = None
+        if self.biasless:
+            # persistent packed parameter vector: bias slots stay zero, the weight segments are refreshed by one multi-tensor copy
+            self._packed = torch.zeros_like(self._scratch_grad)
+            off, self._w_dst, self._w_src, self._g_dst, self._g_src = 0, [], [], [], []
+            for prm, sh in zip(dec, self.param_shapes):
+                n = int(np.prod(sh))
+                if prm is not None:
+                    self._w_dst.append(self._packed[off:off + n].view(sh))
+                    self._w_src.append(prm.detach())
+                    self._g_dst.append(prm.grad)
+                    self._g_src.append(self._scratch_grad[off:off + n].view(sh))
+                off += n
+            self.ok = self.ok and all(a.shape == b.shape and b.dtype == torch.float32 for a, b in zip(self._w_dst, self._w_src))
+
+    # ---- octree / codebook feature grids ---------------------------------------------------------------------------------
+    @staticmethod
+    def _octree_tier(grid):
+        """'octree' | 'codebook' | None: which multi-level trilinear field the direct lookup below covers."""
+        from wisp.models.grids import CodebookOctreeGrid, OctreeGrid
+        if type(grid) not in (OctreeGrid, CodebookOctreeGrid) or grid.interpolation_type != 'linear' or grid.num_lods < 2 \
+                or grid.num_lods > 16 or grid.multiscale_type not in ('cat', 'sum'):
+            return None
+        prm = list(grid.features) + (list(grid.dictionary) if type(grid) is CodebookOctreeGrid else [])
+        if not all(q.is_cuda and q.dtype == torch.float32 and q.ndim == 2 and q.grad is not None and q.grad.is_contiguous()
+                   and q.grad.dtype == torch.float32 for q in prm):
+            return None                                  # frozen / baked / half tables: the grid's own interpolate handles them
+        if type(grid) is OctreeGrid:
+            return 'octree' if grid._fusable() else None
+        K, F = grid.dictionary[0].shape
+        return 'codebook' if (grid.fused and F <= K <= 256 and F <= 8) else None       # (the two-kernel backward's shapes)
+
+    def _octree_forward(self, samples):
+        """OctreeGrid.interpolate(samples, num_lods - 1) (octree_grid.py:183-219) / CodebookOctreeGrid's (codebook_grid.py:
+        103-172) without the autograd graph: cell chain query, (codebook: every logits row decoded once), all levels' trilinear
+        blends in one launch.  -> features f32 [S, F or L*F], context for _octree_backward."""
+        C = _hip()
+        grid = self.t.pipeline.nef.grid
+        L = grid.num_lods
+        grid._sync_device(samples.device)
+        tr = grid.trinkets if grid.trinkets.dtype == torch.int32 else grid.trinkets.int()
+        chain = grid.blas.query(samples, grid.active_lods[L - 1], with_parents=True).pidx[..., grid.base_lod:]
+        levels = grid.active_lods[:L]
+        summed = grid.multiscale_type == 'sum'
+        if self.octree_tier == 'codebook':
+            tables = [C.codebook_decode_rows(grid.features[i], grid.dictionary[i], True) for i in range(L)]
+            half = False
+        else:
+            tables = [grid.features[i].detach() for i in range(L)]
+            half = grid.half_features
+        feats = C.spc_trilinear_multi_forward(samples, chain, grid.blas.points, tr, tables, levels, half, summed)
+        return feats, (samples, chain, tr, levels, summed)
+
+    def _octree_backward(self, ctx, g_feats):
+        """Feature-table gradients, written straight into the parameters' .grad (zero since the last optimizer step)."""
+        C = _hip()
+        grid = self.t.pipeline.nef.grid
+        samples, chain, tr, levels, summed = ctx
+        L, F = grid.num_lods, grid.feature_dim
+        if g_feats.dtype != torch.float32:
+            g_feats = g_feats.float()
+        if self.octree_tier == 'octree':
+            C.spc_trilinear_multi_backward(samples, chain, grid.blas.points, tr, g_feats, [tuple(f.shape) for f in grid.features[:L]],
+                                           levels, summed, out=[f.grad for f in grid.features[:L]])
+            return
+        cells = chain[:, :L].t().contiguous()                     # one row of cell indices per level
+        coords = samples.view(-1, 1, 3)
+        for i in range(L):
+            g = g_feats if summed else g_feats[:, i * F:(i + 1) * F].contiguous()
+            C.codebook_trilinear_backward(coords, cells[i], grid.blas.points, tr, grid.features[i].detach(),
+                                          grid.dictionary[i].detach(), g.view(-1, 1, F), levels[i],
+                                          out=(grid.features[i].grad, grid.dictionary[i].grad))
 
     # ---- decoder parameters ------------------------------------------------------------------------------------------
     def _params(self):
         if not self.biasless:
             return self.packed, self.packed_grad
-        from wisp.ops.nerf_mlp import _pack
         self._scratch_grad.zero_()
-        return _pack(self.dec, self.param_shapes), self._scratch_grad
+        torch._foreach_copy_(self._w_dst, self._w_src)
+        return self._packed, self._scratch_grad
 
     def _scatter_param_grads(self, g):
         """bias-free decoders: the kernel wrote one packed gradient vector; add its weight segments to the parameters' .grad"""
-        off = 0
-        for p, sh in zip(self.dec, self.param_shapes):
-            n = int(np.prod(sh))
-            if p is not None:
-                p.grad.add_(g[off:off + n].view(sh))
-            off += n
+        assert g is self._scratch_grad
+        torch._foreach_add_(self._g_dst, self._g_src)
 
     # ---- raymarch ------------------------------------------------------------------------------------------------------
     def _count(self, rays, jitter, seed=None):
@@ -211,10 +281,18 @@ class _DirectNeRFStep:
             if prefetch is not None:
                 self._pending = self._count(prefetch, None)
             return ridx, samples, deltas, offsets, dirs
-        self._pending = None
+        st, self._pending = self._pending, None
         kw = {} if (jitter is None or tracer.raymarch_type == 'uniform') else {"jitter": jitter}
-        rm = grid.raymarch(rays, level=grid.active_lods[grid.num_lods - 1], num_samples=tracer.num_steps,
-                           raymarch_type=tracer.raymarch_type, **kw)
+        lvl = grid.active_lods[grid.num_lods - 1]
+        ahead = tracer.raymarch_type in ('voxel', 'uniform')            # (supports(): the blas is an OctreeAS)
+        if ahead and isinstance(st, dict) and st.get("rays") is rays:
+            kw["begun"] = st                              # (checked against octree and level again where it is used)
+        rm = grid.raymarch(rays, level=lvl, num_samples=tracer.num_steps, raymarch_type=tracer.raymarch_type, **kw)
+        if ahead and prefetch is not None:
+            # the next batch's cell intersection counts, behind this step's own march: its size read-back is long done when the
+            # next step asks for it, so the host never waits for the GPU to drain
+            self._pending = grid.raymarch(prefetch, level=lvl, num_samples=tracer.num_steps, raymarch_type=tracer.raymarch_type,
+                                          begin_only=True)
         dirs = None if coded else rays.dirs.index_select(0, rm.ridx)
         return rm.ridx, rm.samples, rm.deltas, rm.ray_offsets, dirs
 
@@ -245,7 +323,11 @@ class _DirectNeRFStep:
                 table = shadow if shadow is not None else table.to(torch.bfloat16)
             feats = C.hashgrid_interpolate(samples, table.detach(), self.first_idx, self.res, self.bitwidth, self.zero_from_col)
             feats_in = feats
+        elif self.octree_tier is not None and grid.training:
+            feats, octx = self._octree_forward(samples)
+            feats_in = feats
         else:
+            octx = None
             # any other grid: its own interpolate (one small autograd graph), evaluated like Pipeline.forward would
             with torch.enable_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=t.enable_amp):
                 feats = grid.interpolate(samples, grid.num_lods - 1).reshape(S, i)
@@ -273,6 +355,8 @@ class _DirectNeRFStep:
         if self.hash_fast:
             C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res, self.bitwidth,
                                             self.zero_from_col, out=self.table.grad)
+        elif self.octree_tier is not None and grid.training:
+            self._octree_backward(octx, g_feats)
         elif feats.requires_grad:
             feats.backward(g_feats.to(feats.dtype))
         return loss, S

@@ -1465,6 +1465,62 @@ def test_direct_step_equals_modular_step_every_march_and_grid(kind, march, steps
         assert abs(float(l1) - float(l2)) <= 1e-3 * max(1.0, abs(float(l2)))
 
 
+@pytest.mark.parametrize("march,steps", [("voxel", 6), ("uniform", 96)])
+def test_raytrace_issued_one_batch_ahead_changes_nothing(march, steps):
+    """'voxel' / 'uniform' marches with the one-batch look-ahead (step(..., prefetch=next rays)): the next batch's cell
+    intersection counts are issued a step early (OctreeAS.raytrace_begin) so the size read-back never drains the GPU.  Same
+    seeds, same batches -> bit-identical sample counts, losses and parameters as without look-ahead; a state issued for
+    another Rays object, another level or an octree a prune has since replaced is dropped, not used."""
+    import copy
+    from wisp.accelstructs import OctreeAS
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.models.grids import OctreeGrid
+    from wisp.models.nefs import NeuralRadianceField
+    from wisp.tracers import PackedRFTracer
+    from wisp.trainers import MultiviewTrainStep
+    blas, _ = _sparse_blas(5, 3000, 131)
+    torch.manual_seed(3)
+    grid = OctreeGrid(blas, feature_dim=5, num_lods=4, multiscale_type='sum', feature_std=0.5)
+    nef = NeuralRadianceField(grid, view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1).to(DEV)
+    nef2 = copy.deepcopy(nef)
+    rng = np.random.default_rng(301)
+    batches = []
+    for k in range(5):
+        o, d = make_rays(300, 310 + k)
+        batches.append((Rays(cuda(o), cuda(d), dist_min=1.0, dist_max=5.0), cuda(rng.uniform(size=(300, 3)).astype(np.float32))))
+    def trainer(n):
+        return MultiviewTrainStep(Pipeline(n, PackedRFTracer(raymarch_type=march, num_steps=steps, bg_color=(1.0, 1.0, 1.0))),
+                                  prune_every=-1, enable_amp=False)
+    tr1, tr2 = trainer(nef), trainer(nef2)
+    assert tr1._direct is not None
+    out = {1: [], 2: []}
+    for k, (rays, gts) in enumerate(batches):
+        nxt = batches[k + 1][0] if k + 1 < len(batches) else None
+        torch.manual_seed(40 + k)
+        out[1].append(tr1.step(rays, gts, prefetch=nxt))
+        if nxt is not None:
+            assert tr1._direct._pending is not None and tr1._direct._pending["rays"] is nxt
+        torch.manual_seed(40 + k)
+        out[2].append(tr2.step(rays, gts))
+        assert tr2._direct._pending is None
+    for (l1, s1), (l2, s2) in zip(out[1], out[2]):
+        assert s1 == s2 > 500 and abs(float(l1) - float(l2)) <= 1e-6 * max(1.0, abs(float(l2)))
+    # (not bitwise: the octree grid's backward adds with float atomics, whose order is free, and Adam turns a last-bit difference
+    #  of a near-zero gradient into a visible one of the step: all but a handful of elements agree to 2e-5, all to a step's size)
+    diff = (tr1.flat.data - tr2.flat.data).abs()
+    assert float((diff > 2e-5).float().mean()) < 1e-4 and float(diff.max()) < 5e-3
+    # a state that does not fit is ignored: other rays / other level / replaced octree
+    b = grid.blas
+    r0, r1 = batches[0][0], batches[1][0]
+    ref = b.raytrace(r0, 4, with_exit=True)
+    for begun in (b.raytrace_begin(r1, 4), b.raytrace_begin(r0, 3), OctreeAS(b.octree.clone()).raytrace_begin(r0, 4)):
+        got = b.raytrace(r0, 4, with_exit=True, begun=begun)
+        assert torch.equal(got.ridx, ref.ridx) and torch.equal(got.pidx, ref.pidx) and torch.equal(got.depth, ref.depth)
+    got = b.raytrace(r0, 4, with_exit=True, begun=b.raytrace_begin(r0, 4))
+    assert torch.equal(got.ridx, ref.ridx) and torch.equal(got.pidx, ref.pidx) and torch.equal(got.depth, ref.depth)
+
+
 def test_training_psnr_parity_with_oracle():
     """Same initial weights, same ray batches, same jitter: after 120 AdamW steps the HIP path and the CPU oracle reach
     the same PSNR on the training rays within 0.1 dB (north-star bound)."""
@@ -2253,9 +2309,11 @@ def test_grid_interpolate_follows_the_references_own_unit_test(dtype):
     assert torch.allclose(feat0, feat1, atol=atol, rtol=rtol) and torch.allclose(grad0, grad1, atol=atol, rtol=rtol)
 
 
-def test_hidden_128_pipeline_trains_through_the_fused_wide_decoder():
+def test_hidden_128_pipeline_trains_through_the_fused_wide_decoder(monkeypatch):
     """nerf_hash with hidden_dim=128 (the reference's best row) under bf16 autocast: the trainer's modular path must reach the
-    fused wide decoder (no nn.Linear launches) and the loss must go down."""
+    fused wide decoder (no nn.Linear launches) and the loss must go down.  (The direct-issue step takes this shape too:
+    test_direct_step_covers_hidden_128_under_amp.)"""
+    monkeypatch.setenv("WISP_DIRECT_STEP", "0")
     import synlego
     import wisp._C as C
     from wisp.accelstructs import OctreeAS
