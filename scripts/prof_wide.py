@@ -15,3 +15,14 @@ for _ in range(4):
     C.nerf_mlp_forward(feats, dirs, params, 32, H, 4, True)
     C.nerf_mlp_backward(feats, dirs, params, gr, gd, 32, H, 4, True)
 torch.cuda.synchronize()
+# plain event timing of the pair (no profiler needed)
+e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+e[0].record()
+for _ in range(10):
+    C.nerf_mlp_forward(feats, dirs, params, 32, H, 4, True)
+e[1].record()
+for _ in range(10):
+    C.nerf_mlp_backward(feats, dirs, params, gr, gd, 32, H, 4, True)
+e[2].record()
+torch.cuda.synchronize()
+print("hidden %d, %d samples: forward %.3f ms, backward %.3f ms" % (H, S, e[0].elapsed_time(e[1]) / 10, e[1].elapsed_time(e[2]) / 10))
