@@ -413,57 +413,42 @@ wide_dw_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
     G.dW1[0] = zero4(); G.dW1[1] = zero4();
     const int64_t rounds = (num_tiles + WD_TILES - 1) / WD_TILES;
     const bf16x8 zero8 = __builtin_bit_cast(bf16x8, (u32x4)(0u));
-    // one register set for both roles (a wave has one role): in the dY role the fetched operands live in the fields of A.
-    // The dY role runs one round ahead of itself: as soon as an operand block has been written into its LDS image the same
-    // registers are reloaded with the NEXT round's block, so the 26 KB of a tile stream in underneath the five stages instead
-    // of in front of them (the barriers wait for LDS only: no vmcnt in front of s_barrier outside tgsplit mode).
-    ActsW<HH> A;
-    bf16x8& r5 = A.x0[0];
-    bf16x8& r2 = A.x0[1];
-    bf16x8 (&r4)[NK] = A.h2;
-    bf16x8 (&r3)[NK] = A.h3;
-    bf16x8 (&r1)[NK] = A.h1;
-    // (the loads are unconditional - a tile past the end re-reads the last one and is replaced by zeros when it is stored:
-    //  a predicated load is a branch, and behind a branch the compiler no longer knows how many loads are in flight and
-    //  waits for all of them, vmcnt(0), in front of every LDS store)
-    const int64_t last_tile = num_tiles - 1;
-    if (!x_role) {
-        const int64_t tile0 = (int64_t)blockIdx.x * WD_TILES + my_tile;
-        const bf16x8* in0 = scratch + (tile0 < last_tile ? tile0 : last_tile) * (int64_t)(W::NSLOT * 64) + lane;
-#define LOAD0(slot) in0[(slot) * 64]
-        r5 = LOAD0(W::S5Y);
-#pragma unroll
-        for (int kb = 0; kb < NK; ++kb) r4[kb] = LOAD0(W::S4Y + kb);
-#pragma unroll
-        for (int kb = 0; kb < NK; ++kb) r3[kb] = LOAD0(W::S3Y + kb);
-        r2 = LOAD0(W::S2Y);
-#pragma unroll
-        for (int kb = 0; kb < NK; ++kb) r1[kb] = LOAD0(W::S1Y + kb);
-#undef LOAD0
-    }
     for (int64_t rd = blockIdx.x; rd < rounds; rd += gridDim.x) {
         const int64_t tile = rd * WD_TILES + my_tile;
         const bool have = tile < num_tiles;
-        const int64_t ntile = (rd + gridDim.x) * WD_TILES + my_tile;
-        const bf16x8* in = scratch + (ntile < last_tile ? ntile : last_tile) * (int64_t)(W::NSLOT * 64) + lane;
-#define LOADK(slot) in[(slot) * 64]
-#define LIVE(r) (have ? (r) : zero8)
+        const bf16x8* in = scratch + tile * (int64_t)(W::NSLOT * 64) + lane;
+#define LOADK(slot) ((have && !x_role) ? in[(slot) * 64] : zero8)
         // bias sum of the dY block held in operand `a` into row `row` of the shared block
 #define BIAS_ROW(a, row) { const unsigned one2 = (lane & 15) == (row) ? 0x3f803f80u : 0u; const u32x4 ones = {one2, one2, one2, one2}; \
                            G.db = mma16(__builtin_bit_cast(bf16x8, ones), (a), G.db); }
+        // one register set for both roles (a wave has one role): in the dY role the fetched operands live in the fields of A
+        ActsW<HH> A;
+        bf16x8& r5 = A.x0[0];
+        bf16x8& r2 = A.x0[1];
+        bf16x8 (&r4)[NK] = A.h2;
+        bf16x8 (&r3)[NK] = A.h3;
+        bf16x8 (&r1)[NK] = A.h1;
         if (x_role) {                                          // wave-uniform branch
             float d[3];
             const int64_t sidx = tile * TS + n;
             fetch_inputs_wide<TIO>(feats, dirs, sidx, have && sidx < num_samples, g, in_dim, A.x0, d);
             forward_tile_wide<HH>(L, d, A);
+        } else {                                               // all 26 operand blocks of the tile in flight at once
+            r5 = LOADK(W::S5Y);
+            r2 = LOADK(W::S2Y);
+#pragma unroll
+            for (int kb = 0; kb < NK; ++kb) r4[kb] = LOADK(W::S4Y + kb);
+#pragma unroll
+            for (int kb = 0; kb < NK; ++kb) r3[kb] = LOADK(W::S3Y + kb);
+#pragma unroll
+            for (int kb = 0; kb < NK; ++kb) r1[kb] = LOADK(W::S1Y + kb);
         }
         // ---------------- stage 5: dY5 natural [1 kb] x h3 chained [NK kb] -> dW5 (this wave: X block kt = wave)
         if (x_role) {
 #pragma unroll
             for (int kb = 0; kb < NK; ++kb) store_chained(imgX + wc_off, kb, A.h3[kb]);
         } else {
-            store_natural(imgY + wn_off, 0, LIVE(r5));
-            r5 = LOADK(W::S5Y);
+            store_natural(imgY + wn_off, 0, r5);
         }
         __syncthreads();
 #pragma unroll
@@ -480,7 +465,7 @@ wide_dw_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
             for (int kb = 0; kb < NK; ++kb) store_chained(imgX + wc_off, kb, A.h2[kb]);
         } else {
 #pragma unroll
-            for (int kb = 0; kb < NK; ++kb) { store_chained(imgY + wc_off, kb, LIVE(r4[kb])); r4[kb] = LOADK(W::S4Y + kb); }
+            for (int kb = 0; kb < NK; ++kb) store_chained(imgY + wc_off, kb, r4[kb]);
         }
         __syncthreads();
 #pragma unroll
@@ -499,7 +484,7 @@ wide_dw_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
             store_natural(imgX + wn_off, 2, A.x2[2]);
         } else {
 #pragma unroll
-            for (int kb = 0; kb < NK; ++kb) { store_chained(imgY + wc_off, kb, LIVE(r3[kb])); r3[kb] = LOADK(W::S3Y + kb); }
+            for (int kb = 0; kb < NK; ++kb) store_chained(imgY + wc_off, kb, r3[kb]);
         }
         __syncthreads();
 #pragma unroll
@@ -515,8 +500,7 @@ wide_dw_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
 #pragma unroll
             for (int kb = 0; kb < NK; ++kb) store_chained(imgX + wc_off, kb, A.h1[kb]);
         } else {
-            store_chained(imgY + wc_off, 0, LIVE(r2));
-            r2 = LOADK(W::S2Y);
+            store_chained(imgY + wc_off, 0, r2);
         }
         __syncthreads();
 #pragma unroll
@@ -533,7 +517,7 @@ wide_dw_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
             store_natural(imgX + wn_off, 1, A.x0[1]);
         } else {
 #pragma unroll
-            for (int kb = 0; kb < NK; ++kb) { store_chained(imgY + wc_off, kb, LIVE(r1[kb])); r1[kb] = LOADK(W::S1Y + kb); }
+            for (int kb = 0; kb < NK; ++kb) store_chained(imgY + wc_off, kb, r1[kb]);
         }
         __syncthreads();
 #pragma unroll
@@ -546,7 +530,6 @@ wide_dw_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
         }
         __syncthreads();
 #undef LOADK
-#undef LIVE
 #undef BIAS_ROW
     }
     // ---- the workgroup's partial row (canonical parameter order): every element has exactly one owner
