@@ -947,7 +947,7 @@ static int launch_fwd(const float* coords, int64_t n, const void* codebook, cons
     int row_shift = -1;
     if ((row_dw & (row_dw - 1)) == 0) { row_shift = 0; while ((1 << row_shift) < row_dw) ++row_shift; }
     auto kern = hashgrid_fwd_kernel<T, F, DIM>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) { if (const hipError_t e = WISP_ALLOW_LDS(kern, lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e)); }
     const int64_t tiles = ceil_div64(n, HG_TILE);
     int64_t g = ceil_div64(tiles, waves);
     if (g > 8192) g = 8192;                               // 256 CUs x 32; grid-stride beyond that
@@ -1107,7 +1107,7 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
         if (queue_emitter) {
             const size_t q_lds = queue_emitter_lds(plan.total_ranks, DIM);
             auto eq = hashgrid_bwd_emit_q_kernel<T, DIM>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds);
+            if (const hipError_t e = WISP_ALLOW_LDS(eq, q_lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
             hipLaunchKernelGGL(eq, dim3((unsigned)plan.ntiles), dim3(EM_THREADS), q_lds, s,
                                coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
                                plan.chunk_shift, plan.bins, counts, records, grad_codebook);
@@ -1116,14 +1116,14 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     }
     if (!launched) {
         auto em = hashgrid_bwd_emit_kernel<T, F, DIM>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)em_lds);
+        if (const hipError_t e = WISP_ALLOW_LDS(em, em_lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
         hipLaunchKernelGGL(em, dim3((unsigned)plan.ntiles), dim3(EM_THREADS), em_lds, s,
                            coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
                            plan.chunk_shift, plan.bins, counts, records, grad_codebook);
     }
     const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 8;
     auto rd = hashgrid_bwd_reduce_kernel<T, F>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds);
+    if (const hipError_t e = WISP_ALLOW_LDS(rd, rd_lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
     hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
                        plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook);
     return 0;

@@ -432,7 +432,7 @@ int launch(const void* feats, const float* dirs, int64_t s_total, int in_dim, co
            hipStream_t st) {
     const size_t lds = lds_bytes<TC>(WAVES, BWD);
     auto kern = nerf_mlp_kernel<TC, TIO, WAVES, BWD>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = WISP_ALLOW_LDS(kern, lds);
     if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp", hipGetErrorString(e));
     const int64_t ntiles = (s_total + TS - 1) / TS;
     int grid = (int)min64(ceil_div64(ntiles, WAVES), cu_count());

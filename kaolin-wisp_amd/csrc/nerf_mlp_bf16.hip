@@ -612,13 +612,13 @@ int launch_fwd(const void* feats, const float* dirs, const int64_t* ridx, int64_
     static const int pin = [] { const char* v = getenv("WISP_MLP_FWD_PIN"); return v && v[0] ? atoi(v) : 2; }();   // workgroups per CU; 0 = register-resident weights
     if (pin > 0 || CODED) {
         auto kern = mlp_fwd_kernel<TIO, NARROW, true, CODED>;
-        static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = WISP_ALLOW_LDS(kern, lds);
         if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
         const int grid = (int)min64(ceil_div64(ntiles, FWD_WAVES), (int64_t)(pin > 0 ? pin : 2) * cu_count());
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, ridx, S, in_dim, params, rgb, density);
     } else if constexpr (!CODED) {
         auto kern = mlp_fwd_kernel<TIO, NARROW, false, false>;
-        static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = WISP_ALLOW_LDS(kern, lds);
         if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
         const int grid = (int)min64(ceil_div64(ntiles, FWD_WAVES), cu_count());
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_WAVES * 64), lds, st, (const TIO*)feats, dirs, ridx, S, in_dim, params, rgb, density);
@@ -631,7 +631,7 @@ int launch_bwd(const void* feats, const float* dirs, const int64_t* ridx, int64_
                const float* grad_rgb, const float* grad_density, void* grad_feats, float* partials, int* partial_rows, hipStream_t st) {
     const size_t lds = BWD_LDS;
     auto kern = mlp_bwd_kernel<TIO, NARROW, CODED>;
-    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = WISP_ALLOW_LDS(kern, lds);
     if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_bf16", hipGetErrorString(e));
     const int64_t ntiles = (S + TS - 1) / TS;
     const int grid = (int)min64(ceil_div64(ntiles, BWD_PAIRS), cu_count());

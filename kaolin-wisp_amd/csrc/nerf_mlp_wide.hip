@@ -597,7 +597,7 @@ int wide_forward(const void* feats, const float* dirs, int64_t S, int in_dim, co
     typedef Wide<HH> W;
     const size_t lds = (size_t)W::L_FWD_END * 2 + (size_t)W::BIASV_FLOATS * 4;
     auto kern = wide_fwd_kernel<HH, TIO>;
-    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = WISP_ALLOW_LDS(kern, lds);
     if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_wide", hipGetErrorString(e));
     const int64_t ntiles = (S + TS - 1) / TS;
     const int grid = (int)min64(ceil_div64(ntiles, WF_WAVES), 2 * cu_count_w());      // 66 KB of LDS: two workgroups per CU
@@ -613,8 +613,8 @@ int wide_backward(const void* feats, const float* dirs, int64_t S, int in_dim, c
     const size_t lds_d = (size_t)W::L_FWD_END * 2 + (size_t)W::BIASV_FLOATS * 4 + (size_t)WD_TILES * 2 * W::IMG_BYTES;
     auto kc = wide_chain_kernel<HH, TIO>;
     auto kd = wide_dw_kernel<HH, TIO>;
-    static const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
-    static const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
+    const hipError_t e1 = WISP_ALLOW_LDS(kc, lds_c);
+    const hipError_t e2 = WISP_ALLOW_LDS(kd, lds_d);
     if (e1 != hipSuccess || e2 != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_wide", "hipFuncSetAttribute");
     const int cus = cu_count_w();
     float* partials = (float*)workspace;                                             // [cus][NPARAM_PAD]

@@ -28,6 +28,22 @@ static inline int wisp_fail(int code, const char* what, const char* detail) {
             return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e_)); \
     } while (0)
 
+// Dynamic LDS beyond the default limit has to be allowed per kernel AND per device (one process may drive several devices):
+// WISP_ALLOW_LDS(kernel, bytes) asks once per (call site = kernel instance, device) and remembers the grant.
+static inline hipError_t wisp_allow_lds_once(const void* fn, size_t bytes, size_t* granted /* [64] */) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (bytes <= granted[dev]) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) granted[dev] = bytes;
+    return e;
+}
+#define WISP_ALLOW_LDS(kern, bytes)                                                                     \
+    ([&]() -> hipError_t {                                                                              \
+        static size_t granted_[64] = {0};                                                               \
+        return wisp_allow_lds_once(reinterpret_cast<const void*>(kern), (size_t)(bytes), granted_);      \
+    })()
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t min64(int64_t a, int64_t b) { return a < b ? a : b; }
 
