@@ -173,19 +173,28 @@ def hidden128_line(args, dev, pipe, batch, size_batch, steps=30):
         rm = grid.raymarch(probe, level=grid.active_lods[-1], num_samples=args.num_steps, raymarch_type='ray')
         wide.tracer.prev_num_samples = rm.samples.shape[0]
         R = max(256, tr.calc_adaptive_rays(4096))
-        for _ in range(5):
-            rays, gts = batch(R)
-            tr.step(rays, gts)
-        C.TIMING_ALL = {}
+        state = {"rays": None, "gts": None}
+        state["rays"], state["gts"] = batch(R)
+
+        def loop(n):                                  # one-batch look-ahead, like the headline's timed loop
+            total = 0
+            for _ in range(n):
+                nrays, ngts = batch(R)
+                _, ns = tr.step(state["rays"], state["gts"], prefetch=nrays)
+                total += ns
+                state["rays"], state["gts"] = nrays, ngts
+            return total
+
+        loop(5)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        samples = 0
-        for _ in range(steps):
-            rays, gts = batch(R)
-            _, ns = tr.step(rays, gts)
-            samples += ns
+        samples = loop(steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # per-launch events in a second, short pass: a pair of events around every launch is not free (see bench_configs._nerf_run)
+        C.TIMING_ALL = {}
+        loop(8)
+        torch.cuda.synchronize()
         sink, C.TIMING_ALL = C.TIMING_ALL, None
         k = {n.replace("wisp_", ""): float(np.mean([a.elapsed_time(b) for a, b in ev])) for n, ev in sink.items()}
         S = samples / steps
