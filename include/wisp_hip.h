@@ -127,6 +127,16 @@ int wisp_spc_query(const uint8_t* octree, const int32_t* exsum, const float* coo
                    int level, int with_parents, int64_t* pidx /* [n] or [n, level+1] */,
                    wisp_stream_t stream);
 
+/* The columns first_level .. level of wisp_spc_query(with_parents = 1) only: chain i64 [n, level - first_level + 1]
+ * (what OctreeGrid.interpolate slices out of the query, wisp/models/grids/octree_grid.py:196-199).  hint_pidx (optional,
+ * i32 [ceil(n / hint_group)]): for every group of hint_group consecutive coordinates the cell of first_level a caller
+ * already knows, or -1 - e.g. the nuggets of the raytrace a 'voxel' march sampled (octree_as.py:213-245: hint_group samples
+ * per nugget).  A hint is used only where the coordinate really quantises into that cell; everywhere else the walk
+ * starts at the root, so the result does not depend on the hints.  `points` is only read with hints. */
+int wisp_spc_query_chain(const uint8_t* octree, const int32_t* exsum, const int16_t* points, const float* coords,
+                         int64_t n, int level, int first_level, const int32_t* hint_pidx, int hint_group,
+                         int64_t* chain, wisp_stream_t stream);
+
 /* Occupancy bitfield of one level: bit  x | y << level | z << 2 level  of bits[] is set iff the level-`level` cell
  * (x, y, z) exists.  bits: u32 [ceil(8^level / 32)], zeroed by the call. */
 int wisp_spc_build_bitfield(const int16_t* level_points, int64_t n_points, int level, uint32_t* bits,

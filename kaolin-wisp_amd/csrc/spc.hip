@@ -59,6 +59,64 @@ extern "C" int wisp_spc_query(const uint8_t* octree, const int32_t* exsum, const
     return WISP_OK;
 }
 
+// The parent chain of a query, levels first_level .. level only, optionally started from a HINT: the cell of `first_level` a
+// caller already knows for a group of consecutive coordinates (the 'voxel' march generates `group` samples inside every cell its
+// raytrace returned).  A hint is only trusted when the coordinate really quantises into that cell at first_level; otherwise (and
+// without hints) the walk starts at the root as in spc_query_kernel, so the result is the same numbers either way:
+// out[i][k] = spc_query(with_parents)[i][first_level + k].
+__global__ void __launch_bounds__(256)
+spc_query_chain_kernel(const uint8_t* __restrict__ octree, const int32_t* __restrict__ exsum, const int16_t* __restrict__ points,
+                       const float* __restrict__ coords, int64_t n, int level, int first_level,
+                       const int32_t* __restrict__ hint, int group, int64_t* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int width = level - first_level + 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int qx, qy, qz;
+        const bool inside = quantize_inside(coords[i * 3 + 0], coords[i * 3 + 1], coords[i * 3 + 2], level, qx, qy, qz);
+        int64_t node = inside ? 0 : -1;
+        int l = 0;
+        if (hint && inside) {
+            const int32_t h = hint[i / group];
+            if (h >= 0) {
+                const int sh = level - first_level;
+                const int16_t* pt = points + (int64_t)h * 3;
+                if ((qx >> sh) == (int)pt[0] && (qy >> sh) == (int)pt[1] && (qz >> sh) == (int)pt[2]) { node = h; l = first_level; }
+            }
+        }
+        for (; l < first_level; ++l) {
+            if (node >= 0) {
+                const int c = child_slot(qx, qy, qz, level - 1 - l);
+                const uint32_t bits = octree[node];
+                node = ((bits >> c) & 1u) ? (int64_t)exsum[node] + __popc(bits & ((2u << c) - 1u)) : -1;
+            }
+        }
+        int64_t* row = out + i * width;
+        row[0] = node;
+        for (; l < level; ++l) {
+            if (node >= 0) {
+                const int c = child_slot(qx, qy, qz, level - 1 - l);
+                const uint32_t bits = octree[node];
+                node = ((bits >> c) & 1u) ? (int64_t)exsum[node] + __popc(bits & ((2u << c) - 1u)) : -1;
+            }
+            row[l + 1 - first_level] = node;
+        }
+    }
+}
+
+extern "C" int wisp_spc_query_chain(const uint8_t* octree, const int32_t* exsum, const int16_t* points, const float* coords,
+                                    int64_t n, int level, int first_level, const int32_t* hint_pidx, int hint_group,
+                                    int64_t* chain, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0 && level >= 0 && level <= 15 && first_level >= 0 && first_level <= level, "bad n / levels");
+    WISP_REQUIRE(!hint_pidx || (hint_group >= 1 && points), "a hint needs its group size and the point hierarchy");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(exsum && coords && chain && (octree || level == 0), "null pointer");
+    const int grid = (int)min64(ceil_div64(n, 256), 8192);
+    hipLaunchKernelGGL(spc_query_chain_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, octree, exsum, points, coords, n,
+                       level, first_level, hint_pidx, hint_group > 0 ? hint_group : 1, chain);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- bitfield
 __global__ void __launch_bounds__(256)
 spc_bitfield_kernel(const int16_t* __restrict__ pts, int64_t n, int level, uint32_t* __restrict__ bits) {

@@ -39,6 +39,7 @@ SIGNATURES = {
     "wisp_hashgrid_query_fwd": [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_hashgrid_query_bwd": [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_query": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
+    "wisp_spc_query_chain": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp],
     "wisp_spc_build_bitfield": [c_vp, c_i64, c_i32, c_vp, c_vp],
     "wisp_spc_raytrace_count": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp],
     "wisp_spc_raytrace_emit": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp],
@@ -450,6 +451,24 @@ def spc_query(octree, exsum, coords, level, with_parents=False):
     _check(lib.wisp_spc_query(_p(octree), _p(exsum), _p(coords), n, level, int(with_parents), _p(pidx), _stream()),
            "spc_query")
     return pidx
+
+
+def spc_query_chain(octree, exsum, points, coords, level, first_level, hint=None, hint_group=1):
+    """Columns first_level .. level of spc_query(with_parents=True): int64 [Q, level - first_level + 1].  hint (optional): int32
+    [ceil(Q / hint_group)] cells of first_level known for groups of hint_group consecutive coordinates (-1 = none) - the
+    nuggets a 'voxel' march sampled; they shorten the walk where they are right and change nothing where they are not."""
+    coords = _need(coords, torch.float32, "coords").reshape(-1, 3)
+    octree = _need(octree, torch.uint8, "octree")
+    exsum = _need(exsum, torch.int32, "exsum")
+    n = coords.shape[0]
+    if hint is not None:
+        hint = _need(hint, torch.int32, "hint").reshape(-1)
+        assert hint_group >= 1 and hint.shape[0] * hint_group >= n, "one hint per group of coordinates"
+        points = _need(points, torch.int16, "points")
+    chain = torch.empty(n, level - first_level + 1, dtype=torch.int64, device=coords.device)
+    _check(lib.wisp_spc_query_chain(_p(octree), _p(exsum), _p(points if hint is not None else None), _p(coords), n, level,
+                                    first_level, _p(hint), int(hint_group), _p(chain), _stream()), "spc_query_chain")
+    return chain
 
 
 def spc_bitfield(level_points, level):

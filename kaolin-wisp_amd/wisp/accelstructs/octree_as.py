@@ -128,6 +128,15 @@ class OctreeAS(BaseAS):
         self._to_device(coords.device)
         return ASQueryResults(pidx=_hip().spc_query(self.octree, self.prefix, coords, level, with_parents))
 
+    def query_chain(self, coords, level=None, first_level=0, hint=None, hint_group=1):
+        """query(coords, level, with_parents=True).pidx[..., first_level:] without computing the columns in front of it: the
+        cell of every level first_level .. level ([N, level - first_level + 1], -1 = empty / outside).  hint: see
+        wisp_spc_query_chain (cells of first_level a march already knows; they never change the result)."""
+        if level is None:
+            level = self.max_level
+        self._to_device(coords.device)
+        return _hip().spc_query_chain(self.octree, self.prefix, self.points, coords, level, first_level, hint, hint_group)
+
     def raytrace_begin(self, rays, level=None):
         """The parameter-free, read-back-free first half of raytrace() (counts and offsets); hand the result to
         raytrace(..., begun=...).  A trainer issues it one batch ahead so that the size read-back never drains the GPU."""
@@ -166,6 +175,8 @@ class OctreeAS(BaseAS):
         res = ASRaymarchResults(ridx=ridx, samples=samples, depth_samples=depth, deltas=deltas, boundary=boundary,
                                 pack_info=None)
         res.ray_offsets = rt.ray_offsets * num_samples        # every nugget contributes exactly num_samples samples
+        # the cell every run of num_samples consecutive samples was generated in (a hint for spc_query_chain)
+        res.nugget_pidx, res.nugget_level, res.samples_per_nugget = rt.pidx, (self.max_level if level is None else level), num_samples
         return res
 
     def _raymarch_ray(self, rays, num_samples, level=None, jitter=None) -> ASRaymarchResults:

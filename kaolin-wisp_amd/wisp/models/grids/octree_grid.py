@@ -112,7 +112,12 @@ class OctreeGrid(BLASGrid):
             return feat.reshape(*output_shape, feat.shape[-1])
         num_feats = lod_idx + 1
         flat = coords.reshape(-1, 3)
-        chain = self.blas.query(flat, self.active_lods[lod_idx], with_parents=True).pidx[..., self.base_lod:]
+        # the cell of every active level; an accelerator that only has the reference's surface (BaseAS.query) gives the same columns
+        query_chain = getattr(self.blas, "query_chain", None)
+        if query_chain is not None:
+            chain = query_chain(flat, self.active_lods[lod_idx], self.base_lod)
+        else:
+            chain = self.blas.query(flat, self.active_lods[lod_idx], with_parents=True).pidx[..., self.base_lod:]
         if self._fusable():
             # all levels in one launch ('cat' row or the 'sum' written directly)
             self._sync_device(flat.device)

@@ -157,6 +157,7 @@ class _DirectNeRFStep:
             self.zero_from_col = (grid.num_lods - 1) * grid.feature_dim
         self.octree_tier = None if self.hash_fast else self._octree_tier(grid)
         self._pending = None
+        self._cells = (None, None, 1)
         if self.biasless:
             # persistent packed parameter vector: bias slots stay zero, the weight segments are refreshed by one multi-tensor copy
             self._packed = torch.zeros_like(self._scratch_grad)
@@ -197,7 +198,13 @@ class _DirectNeRFStep:
         L = grid.num_lods
         grid._sync_device(samples.device)
         tr = grid.trinkets if grid.trinkets.dtype == torch.int32 else grid.trinkets.int()
-        chain = grid.blas.query(samples, grid.active_lods[L - 1], with_parents=True).pidx[..., grid.base_lod:]
+        # the cell chain of the active levels; the 'voxel' march already knows every sample's cell at the level it marched
+        # (octree_grid.py:221-226: base_lod), which spares the walk down to there
+        blas = grid.blas
+        hint, hint_level, group = self._cells
+        if hint is None or hint_level != grid.base_lod or hint.shape[0] * group != samples.shape[0]:
+            hint, group = None, 1
+        chain = blas.query_chain(samples, grid.active_lods[L - 1], grid.base_lod, hint, group)
         levels = grid.active_lods[:L]
         summed = grid.multiscale_type == 'sum'
         if self.octree_tier == 'codebook':
@@ -294,6 +301,7 @@ class _DirectNeRFStep:
             self._pending = grid.raymarch(prefetch, level=lvl, num_samples=tracer.num_steps, raymarch_type=tracer.raymarch_type,
                                           begin_only=True)
         dirs = None if coded else rays.dirs.index_select(0, rm.ridx)
+        self._cells = (getattr(rm, "nugget_pidx", None), getattr(rm, "nugget_level", None), getattr(rm, "samples_per_nugget", 1))
         return rm.ridx, rm.samples, rm.deltas, rm.ray_offsets, dirs
 
     def run(self, rays, img_gts, jitter=None, prefetch=None):

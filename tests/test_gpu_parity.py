@@ -534,6 +534,41 @@ def test_query_bit_exact():
             assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), want)
 
 
+def test_query_chain_equals_the_query_columns_with_any_hint():
+    """wisp_spc_query_chain: columns first_level .. level of the parents query (the oracle's), with no hints, with the right cell of
+    first_level as hint, with wrong cells, with -1 and with hints for groups of consecutive coordinates - a hint may shorten the
+    walk, never change a result (points outside, on cell faces and NaN included)."""
+    oc, pts, pyr, ex = sparse_tree(6, 3000, 21)
+    rng = np.random.default_rng(23)
+    n = 60000
+    x = rng.uniform(-1.05, 1.05, (n, 3)).astype(np.float32)
+    x[:6] = [[1, 1, 1], [-1, -1, -1], [0, 0, 0], [np.nan, 0, 0], [1.0000001, 0, 0], [-0.0, 0.5, -0.5]]
+    x[6:1006] = (rng.integers(-64, 65, (1000, 3)) / 64.0).astype(np.float32)
+    # half of the coordinates inside occupied cells of level 6 (so that the deep columns are not all -1)
+    leaf = pts[pyr[1, 6]:pyr[1, 6] + pyr[0, 6]].astype(np.float32)
+    pick = leaf[rng.integers(0, leaf.shape[0], n // 2)]
+    x[n // 2:] = ((pick + rng.uniform(0.0, 1.0, pick.shape)) / 32.0 - 1.0).astype(np.float32)
+    C = _C()
+    for level, first in ((6, 3), (6, 6), (6, 0), (5, 2)):
+        want = ospc.query(oc, ex, x, level, with_parents=True)[:, first:]
+        got = C.spc_query_chain(cuda(oc), cuda(ex), cuda(pts), cuda(x), level, first)
+        assert got.dtype == torch.int64 and tuple(got.shape) == (n, level - first + 1) and np.array_equal(got.cpu().numpy(), want)
+        right = want[:, 0].astype(np.int32)
+        wrong = right.copy()
+        lo, cnt = int(pyr[1, first]), int(pyr[0, first])
+        flip = rng.uniform(size=n) < 0.3
+        wrong[flip] = rng.integers(lo, lo + cnt, int(flip.sum())).astype(np.int32)           # some other cell of that level
+        wrong[rng.uniform(size=n) < 0.1] = -1
+        for hint in (right, wrong, np.full(n, -1, np.int32)):
+            got = C.spc_query_chain(cuda(oc), cuda(ex), cuda(pts), cuda(x), level, first, hint=cuda(hint), hint_group=1)
+            assert np.array_equal(got.cpu().numpy(), want)
+        for group in (4, 16):                                 # one hint per run of `group` coordinates: right for some of them only
+            hint = right[::group].copy()
+            got = C.spc_query_chain(cuda(oc), cuda(ex), cuda(pts), cuda(x), level, first, hint=cuda(hint), hint_group=group)
+            assert np.array_equal(got.cpu().numpy(), want)
+    assert tuple(C.spc_query_chain(cuda(oc), cuda(ex), cuda(pts), cuda(x[:0]), 6, 3).shape) == (0, 4)
+
+
 def test_raytrace_bit_exact_sparse_and_dense():
     for (oc, pts, pyr, ex), level in ((sparse_tree(5, 2500, 31), 5), (sparse_tree(7, 40000, 32), 7),
                                       ((ospc.create_dense_octree(3),) + ospc.octree_to_spc(ospc.create_dense_octree(3)), 3)):
