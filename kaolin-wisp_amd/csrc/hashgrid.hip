@@ -203,6 +203,31 @@ hashgrid_fwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
                             *reinterpret_cast<uint32_t*>(&v[j][0]) = t[0];
                             *reinterpret_cast<uint32_t*>(&v[j + half][0]) = t[1];
                         }
+                    } else if (W == 1 && !dense && tsize_pow2 != 0 && tsize >= 2u) {
+                        // Hashed level, power-of-two table: the x term of the hash is x itself (prime 1) and the mask keeps its low
+                        // bit, so for an EVEN cell coordinate x the corner x + 1 = x ^ 1 is the other entry of the same aligned
+                        // pair: one 8-byte load per (y, z) serves both.  Lanes with an odd x fetch their +x corners afterwards
+                        // (four more loads, issued for those lanes only): 6 lane requests per sample and level on average
+                        // instead of 8.  Measured (scripts/bench_hashfwd.py, 2 M ray-ordered samples): 202 -> 153 us with tables
+                        // of 2^14 entries per level (cache resident: the request rate was the bound), 213 -> 213 us at the
+                        // 2^19 of nerf_hash.yaml - there the bound is the rate of LINE fills into the vector L1, and the
+                        // +x neighbour always came out of the line its partner had just brought in.
+                        constexpr int half = 1 << (DIM - 1);
+                        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int j = 0; j < half; ++j) {
+                            const uint32_t i0 = (uint32_t)cs.idx[j];
+                            const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((i0 & ~1u) * 4u), 0, 0);
+                            const bool upper = (i0 & 1u) != 0;
+                            *reinterpret_cast<uint32_t*>(&v[j][0]) = upper ? t[1] : t[0];
+                            *reinterpret_cast<uint32_t*>(&v[j + half][0]) = upper ? t[0] : t[1];       // entry i0 ^ 1
+                        }
+                        if (cs.cell[0] & 1) {
+#pragma unroll
+                            for (int j = half; j < (1 << DIM); ++j)
+                                *reinterpret_cast<uint32_t*>(&v[j][0]) =
+                                    __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)((uint32_t)cs.idx[j] * 4u), 0, 0);
+                        }
                     } else
 #pragma unroll
                     for (int j = 0; j < (1 << DIM); ++j) {
