@@ -376,6 +376,21 @@ int wisp_sdf_trace_step_fused(int64_t num_packs, int first, const float* nug_o, 
                               int num_lods, int channels, int half_round, const float* w1, const float* b1, const float* w2,
                               const float* b2, int hidden, float scale, int32_t* any_active, wisp_stream_t stream);
 
+/* Compositing + photometric loss + compositing backward of a TRAINING step in one launch (what
+ * wisp/tracers/packed_rf_tracer.py:143-165, wisp/trainers/multiview_trainer.py:140-154 and their autograd backward do in
+ * sequence): per ray rgb = bg (1 - sum w) + sum w c with w from exponential_integration (exclusive), loss = mean over the
+ * 3 num_rays elements of huber (kind 0) / l2 (1) / l1 (2) of rgb - gt, and d loss / d color [S,3], d loss / d density [S,1]
+ * (the gradients wisp_composite_bwd returns for grad_rgb = wisp_rgb_loss's gradient, no alpha / depth terms).
+ * ray_offsets: i64 [num_rays + 1] sample range of every ray (rays without samples see the background); out_rgb: optional
+ * f32 [num_rays,3]; loss: f32 [1]; workspace: f32 [workspace_floats] - one partial sum of the loss per wave; with
+ * workspace_floats >= num_rays every ray gets its own wave (best), fewer make the waves walk the rays with a stride; a
+ * second, one-workgroup launch adds the partial sums in index order (reproducible).  Results equal the three separate entry points' (loss to rounding: its terms are
+ * grouped per ray). */
+int wisp_composite_loss(const float* color, const float* density, const float* deltas, const int64_t* ray_offsets,
+                        int64_t num_rays, int64_t num_samples, const float* bg, const float* gt, int kind,
+                        float* grad_color, float* grad_density, float* out_rgb, float* loss, float* workspace,
+                        int64_t workspace_floats, wisp_stream_t stream);
+
 /* Photometric loss of MultiviewTrainer.step (wisp/trainers/multiview_trainer.py:140-154) and its gradient in one launch:
  * loss[0] = mean over the num_elements entries of huber(beta = 1) (kind 0) / squared (1) / absolute (2) error of rgb
  * against gt; grad[i] = d loss / d rgb[i].  rgb, gt, grad: f32 [num_elements]; loss: f32 [1];

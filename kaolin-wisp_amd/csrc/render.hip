@@ -508,6 +508,166 @@ rgb_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ gt, int
     if (threadIdx.x == 0) { loss[0] = t * inv_n; *ticket = 0u; }
 }
 
+// ---------------------------------------------------------------------------------------------- composite + loss + backward
+// The three launches a training step makes between the decoder's forward and backward - compositing (packed_rf_tracer.py:143-165),
+// the photometric loss with its gradient (multiview_trainer.py:140-154) and the compositing backward - as ONE pass per ray: a
+// wave composites its ray, forms the loss terms and d loss / d rgb of that ray on the spot and runs the backward recurrences
+// while the ray's samples are still in registers (rays of at most 64 samples, the usual case) or in cache (longer rays: the
+// same two extra passes as composite_bwd_kernel).  What the separate kernels wrote only for each other never reaches memory:
+// the weights, rgb / alpha / hit and the colour gradient per ray.  Same arithmetic, same order, per ray; the loss is the sum of
+// per-workgroup partials added in index order by a one-wave second launch (reproducible), its terms are grouped per ray
+// instead of per thread-strided element, so its value agrees with wisp_rgb_loss to rounding, not bit for bit.
+__global__ void __launch_bounds__(64)
+composite_loss_kernel(const float* __restrict__ color, const float* __restrict__ density, const float* __restrict__ deltas,
+                      const int64_t* __restrict__ offsets, int64_t num_rays, Bg bg, const float* __restrict__ gt, int kind,
+                      float inv_n, float* __restrict__ grad_color, float* __restrict__ grad_density, float* __restrict__ out_rgb,
+                      float* __restrict__ partial) {
+    const int lane = threadIdx.x;
+    float lacc = 0.0f;
+    for (int64_t r = blockIdx.x; r < num_rays; r += gridDim.x) {
+        const int64_t b = offsets[r], e = offsets[r + 1];
+        const bool single = e - b <= 64;
+        float carry = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f, sa = 0.0f;
+        float dl = 0.0f, T = 0.0f, et = 0.0f, w = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;     // the single chunk's values
+        for (int64_t k0 = b; k0 < e; k0 += 64) {
+            const int64_t i = k0 + lane;
+            const bool live = i < e;
+            dl = live ? deltas[i] : 0.0f;
+            const float tau = live ? density[i] * dl : 0.0f;
+            const float inc = wave_incl_scan_f(tau, lane);
+            const float excl = carry + (inc - tau);
+            carry += wave_last_f(inc);
+            T = 0.0f; et = 0.0f; w = 0.0f;
+            if (live) {
+                T = expf(-excl); et = expf(-tau);
+                w = T * (1.0f - et);
+                c0 = color[i * 3]; c1 = color[i * 3 + 1]; c2 = color[i * 3 + 2];
+                sr += w * c0; sg += w * c1; sb += w * c2;
+                sa += w;
+            }
+        }
+        if (b < e) { sr = wave_sum_f(sr); sg = wave_sum_f(sg); sb = wave_sum_f(sb); sa = wave_sum_f(sa); }
+        const float om = 1.0f - sa;
+        const float rgb[3] = {bg.r * om + sr, bg.g * om + sg, bg.b * om + sb};
+        float g[3], lsum[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = rgb[c] - gt[r * 3 + c];
+            float l, d;
+            if (kind == 0) { const float a = fabsf(x); l = a < 1.0f ? 0.5f * x * x : a - 0.5f; d = fminf(fmaxf(x, -1.0f), 1.0f); }
+            else if (kind == 1) { l = x * x; d = 2.0f * x; }
+            else { l = fabsf(x); d = (x > 0.0f) ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+            lsum[c] = l;
+            g[c] = d * inv_n;
+        }
+        lacc += (lsum[0] + lsum[1]) + lsum[2];
+        if (out_rgb && lane == 0) { out_rgb[r * 3] = rgb[0]; out_rgb[r * 3 + 1] = rgb[1]; out_rgb[r * 3 + 2] = rgb[2]; }
+        if (b == e) continue;
+        const float gr = g[0], gg = g[1], gb = g[2];
+        if (single) {
+            const int64_t i = b + lane;
+            const bool live = i < e;
+            const float G = live ? gr * (c0 - bg.r) + gg * (c1 - bg.g) + gb * (c2 - bg.b) : 0.0f;
+            const float gw = G * w;
+            const float ginc = wave_incl_scan_f(gw, lane);
+            const float tot = wave_last_f(ginc);
+            const float suffix = tot - ginc;
+            if (live) {
+                grad_color[i * 3] = w * gr; grad_color[i * 3 + 1] = w * gg; grad_color[i * 3 + 2] = w * gb;
+                grad_density[i] = (G * T * et - suffix) * dl;
+            }
+            continue;
+        }
+        // longer rays: as composite_bwd_kernel - the total of G w first, then the gradients with the suffix sums
+        carry = 0.0f;
+        float tot = 0.0f;
+        for (int64_t k0 = b; k0 < e; k0 += 64) {
+            const int64_t i = k0 + lane;
+            const bool live = i < e;
+            const float tau = live ? density[i] * deltas[i] : 0.0f;
+            const float inc = wave_incl_scan_f(tau, lane);
+            const float excl = carry + (inc - tau);
+            carry += wave_last_f(inc);
+            if (live) {
+                const float ww = expf(-excl) * (1.0f - expf(-tau));
+                const float G = gr * (color[i * 3] - bg.r) + gg * (color[i * 3 + 1] - bg.g) + gb * (color[i * 3 + 2] - bg.b);
+                tot += G * ww;
+            }
+        }
+        tot = wave_sum_f(tot);
+        carry = 0.0f;
+        float gcarry = 0.0f;
+        for (int64_t k0 = b; k0 < e; k0 += 64) {
+            const int64_t i = k0 + lane;
+            const bool live = i < e;
+            const float dd = live ? deltas[i] : 0.0f;
+            const float tau = live ? density[i] * dd : 0.0f;
+            const float inc = wave_incl_scan_f(tau, lane);
+            const float excl = carry + (inc - tau);
+            carry += wave_last_f(inc);
+            float TT = 0.0f, ee = 0.0f, ww = 0.0f, G = 0.0f;
+            if (live) {
+                TT = expf(-excl); ee = expf(-tau); ww = TT * (1.0f - ee);
+                G = gr * (color[i * 3] - bg.r) + gg * (color[i * 3 + 1] - bg.g) + gb * (color[i * 3 + 2] - bg.b);
+            }
+            const float gw = G * ww;
+            const float ginc = wave_incl_scan_f(gw, lane);
+            const float suffix = tot - (gcarry + ginc);
+            gcarry += wave_last_f(ginc);
+            if (live) {
+                grad_color[i * 3] = ww * gr; grad_color[i * 3 + 1] = ww * gg; grad_color[i * 3 + 2] = ww * gb;
+                grad_density[i] = (G * TT * ee - suffix) * dd;
+            }
+        }
+    }
+    // loss: one partial per workgroup (every lane holds the same sum); loss_sum_kernel adds them in index order.  (A last-
+    // workgroup-finishes reduction inside this kernel - device-scope fence + ticket per workgroup - took the launch from 36 to
+    // 238 us at 38 K rays: on this part a device-scope release / acquire writes back and invalidates the XCD's L2, 8192 times.)
+    if (lane == 0) partial[blockIdx.x] = lacc;
+}
+
+__global__ void __launch_bounds__(1024)
+loss_sum_kernel(const float* __restrict__ partial, int n, float inv_n, float* __restrict__ loss) {
+    __shared__ float part[16];
+    float t = 0.0f;
+    for (int base = 0; base < n; base += 8 * 1024) {      // eight loads of a thread in flight at once
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = base + threadIdx.x + k * 1024; v[k] = i < n ? partial[i] : 0.0f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += v[k];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += part[w];
+        loss[0] = s * inv_n;
+    }
+}
+
+extern "C" int wisp_composite_loss(const float* color, const float* density, const float* deltas, const int64_t* ray_offsets,
+                                   int64_t num_rays, int64_t num_samples, const float* bg, const float* gt, int kind,
+                                   float* grad_color, float* grad_density, float* out_rgb, float* loss, float* workspace,
+                                   int64_t workspace_floats, wisp_stream_t stream) {
+    WISP_REQUIRE(num_rays > 0 && num_samples >= 0 && bg && gt && ray_offsets && loss && workspace && workspace_floats >= 1, "bad arguments");
+    WISP_REQUIRE(kind >= 0 && kind <= 2, "kind: 0 huber, 1 l2, 2 l1");
+    WISP_REQUIRE(num_samples == 0 || (color && density && deltas && grad_color && grad_density), "null pointer");
+    const Bg b{bg[0], bg[1], bg[2]};
+    // one ray per wave when the workspace has a partial-sum cell for every ray (rays differ a lot in length: handing a wave
+    // several of them in a fixed order leaves the launch waiting for the unluckiest wave), else a grid-stride walk
+    const int groups = (int)min64(num_rays, min64(workspace_floats, (int64_t)1 << 22));
+    const float inv_n = 1.0f / (float)(num_rays * 3);
+    hipLaunchKernelGGL(composite_loss_kernel, dim3(groups), dim3(64), 0, (hipStream_t)stream, color, density, deltas, ray_offsets,
+                       num_rays, b, gt, kind, inv_n, grad_color, grad_density, out_rgb, workspace);
+    hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, workspace, groups, inv_n, loss);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
 extern "C" int wisp_rgb_loss(const float* rgb, const float* gt, int64_t num_elements, int kind, float* grad, float* loss,
                              float* workspace, wisp_stream_t stream) {
     WISP_REQUIRE(num_elements > 0 && rgb && gt && grad && loss && workspace, "bad arguments");

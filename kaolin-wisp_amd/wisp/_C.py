@@ -83,6 +83,7 @@ SIGNATURES = {
     "wisp_optim_step_groups": [c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp],
     "wisp_adamw_step_groups": [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp],
     "wisp_gather_rows": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "wisp_composite_loss": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "wisp_rgb_loss": [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
     "wisp_generate_rays": [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wisp_composite_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
@@ -1035,6 +1036,33 @@ def rgb_loss(rgb, gts, kind):
     _check(lib.wisp_rgb_loss(_p(rgb), _p(gts), rgb.numel(), _LOSS_KIND[kind], _p(grad), _p(loss), _p(ws), _stream()),
            "rgb_loss")
     return loss, grad
+
+
+_fused_ws = {}
+
+
+def composite_loss(color, density, deltas, ray_offsets, num_rays, bg, gts, kind, with_rgb=False):
+    """Compositing + rgb loss + compositing backward of a training step in one launch (see wisp_composite_loss):
+    -> (loss [1], d loss / d color [S,3], d loss / d density [S,1], rgb [R,3] or None)."""
+    color = _need(color, torch.float32, "color")
+    density = _need(density, torch.float32, "density")
+    deltas = _need(deltas, torch.float32, "deltas")
+    gts = _need(gts, torch.float32, "gts")
+    ray_offsets = _need(ray_offsets, torch.int64, "ray_offsets")
+    S, dev = color.shape[0], color.device
+    assert ray_offsets.shape[0] == num_rays + 1 and gts.numel() == num_rays * 3
+    g_color = torch.empty(S, 3, dtype=torch.float32, device=dev)
+    g_density = torch.empty(S, 1, dtype=torch.float32, device=dev)
+    rgb = torch.empty(num_rays, 3, dtype=torch.float32, device=dev) if with_rgb else None
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = _fused_ws.get(dev)
+    if ws is None or ws.numel() < num_rays:                                                      # one partial sum of the loss per ray
+        ws = _fused_ws[dev] = torch.empty(max(8192, 2 * num_rays), dtype=torch.float32, device=dev)
+    bg_arr, bg_ptr = _host_f32(bg)
+    _check(lib.wisp_composite_loss(_p(color), _p(density), _p(deltas), _p(ray_offsets), num_rays, S, bg_ptr, _p(gts),
+                                   _LOSS_KIND[kind], _p(g_color), _p(g_density), _p(rgb), _p(loss), _p(ws), ws.numel(), _stream()),
+           "composite_loss")
+    return loss, g_color, g_density, rgb
 
 
 def generate_rays(pixel_x, pixel_y, ortho, x0, y0, width, height, scale_x, scale_y, view_rotation, view_translation):

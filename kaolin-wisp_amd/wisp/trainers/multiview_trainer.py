@@ -85,6 +85,11 @@ class FlatParams:
             mark_shadow_current(p)
 
 
+# WISP_FUSED_COMPOSITE=0: the direct-issue step composites, takes the loss and back-propagates through the compositing with the
+# three separate launches of the modular path instead of wisp_composite_loss
+FUSED_COMPOSITE_LOSS = os.environ.get("WISP_FUSED_COMPOSITE", "1") != "0"
+
+
 class _DirectNeRFStep:
     """The forward + loss + backward of MultiviewTrainStep.step for NeuralRadianceField + PackedRFTracer pipelines over an
     OctreeAS, issued as the same HIP launches in the same order as Pipeline.forward + autograd would issue them - minus the
@@ -348,13 +353,18 @@ class _DirectNeRFStep:
         if tracer.bg_color.device != dev:
             tracer.bg_color = tracer.bg_color.to(dev)
         bg = tracer._bg_host()
-        rgb, _alpha, _depth, _hit, _w = C.composite_fwd(color, density, deltas, None, None, offsets, N, bg)
-        # loss and its gradient w.r.t. the composited colours (what autograd derives for loss_fn(...).mean()), one launch
         if t.rgb_loss_type not in ('huber', 'l2', 'l1'):
             raise NotImplementedError
-        loss, g_rgb = C.rgb_loss(rgb, img_gts, t.rgb_loss_type)
-        loss = loss[0]
-        g_color, g_density = C.composite_bwd(g_rgb, None, None, color, density, deltas, None, None, offsets, bg)
+        if FUSED_COMPOSITE_LOSS:
+            # compositing, the loss with its gradient w.r.t. the composited colours (what autograd derives for
+            # loss_fn(...).mean()) and the compositing backward: one launch, one pass per ray
+            loss, g_color, g_density, _ = C.composite_loss(color, density, deltas, offsets, N, bg, img_gts, t.rgb_loss_type)
+            loss = loss[0]
+        else:
+            rgb, _alpha, _depth, _hit, _w = C.composite_fwd(color, density, deltas, None, None, offsets, N, bg)
+            loss, g_rgb = C.rgb_loss(rgb, img_gts, t.rgb_loss_type)
+            loss = loss[0]
+            g_color, g_density = C.composite_bwd(g_rgb, None, None, color, density, deltas, None, None, offsets, bg)
         g_feats, _ = C.nerf_mlp_backward(feats_in, dirs, packed, g_color, g_density, i, h, f, t.enable_amp,
                                          grad_params=packed_grad, ray_code=ray_code)
         if self.biasless:

@@ -829,6 +829,52 @@ def _packs(lens, seed):
             rng.uniform(1e-3, 0.05, size=(S, 1)).astype(np.float32), rng.uniform(1, 5, size=(S, 1)).astype(np.float32))
 
 
+
+@pytest.mark.parametrize("kind", ["huber", "l2", "l1"])
+def test_composite_loss_in_one_launch_equals_the_three_launches(kind):
+    """wisp_composite_loss (compositing + photometric loss + compositing backward of a training step, one pass per ray) against
+    wisp_composite_fwd -> wisp_rgb_loss -> wisp_composite_bwd on the same packed samples: the composited colours and both
+    gradients bit for bit (same arithmetic in the same order per ray), the loss to rounding (its terms are grouped per ray);
+    rays without samples, with 1, 63, 64, 65 and several hundred samples, errors on both sides of the huber knee; and the value
+    is reproducible from call to call (ticket reduction in index order)."""
+    C = _C()
+    rng = np.random.default_rng(907)
+    lens = [0, 1, 63, 64, 65, 130, 700, 0, 5] + list(rng.integers(0, 90, 3000))
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    S, R = int(offs[-1]), len(lens)
+    color = rng.uniform(0, 1, (S, 3)).astype(np.float32)
+    dens = (rng.uniform(0, 30, (S, 1)) * (rng.uniform(size=(S, 1)) < 0.6)).astype(np.float32)
+    delt = rng.uniform(1e-3, 4e-2, (S, 1)).astype(np.float32)
+    gts = rng.uniform(-1.5, 2.5, (R, 3)).astype(np.float32)          # some |rgb - gt| > 1: the linear part of huber
+    bg = (0.2, 0.5, 0.9)
+    c, d, dl, o, g = cuda(color), cuda(dens), cuda(delt), cuda(offs), cuda(gts)
+    rgb, _a, _d, _h, _w = C.composite_fwd(c, d, dl, None, None, o, R, bg)
+    loss3, g_rgb = C.rgb_loss(rgb, g, kind)
+    gc3, gd3 = C.composite_bwd(g_rgb, None, None, c, d, dl, None, None, o, bg)
+    loss1, gc1, gd1, rgb1 = C.composite_loss(c, d, dl, o, R, bg, g, kind, with_rgb=True)
+    # (the density gradient to the last bit or two: the compiler contracts `G T e - suffix` into fused multiply-adds its own way
+    #  in each kernel)
+    assert torch.equal(rgb1, rgb) and torch.equal(gc1, gc3)
+    torch.testing.assert_close(gd1, gd3, rtol=2e-6, atol=1e-6 * float(gd3.abs().max()))
+    assert float(gd3.abs().max()) > 0 and abs(float(loss1) - float(loss3)) <= 2e-6 * abs(float(loss3))
+    for _ in range(3):
+        again = C.composite_loss(c, d, dl, o, R, bg, g, kind)
+        assert float(again[0]) == float(loss1) and torch.equal(again[1], gc1) and torch.equal(again[2], gd1) and again[3] is None
+    # more rays than workgroups (grid-stride over rays) and a single ray
+    big = np.concatenate([[0], np.cumsum(rng.integers(0, 6, 20000))]).astype(np.int64)
+    Sb = int(big[-1])
+    cb, db, dlb = cuda(rng.uniform(0, 1, (Sb, 3)).astype(np.float32)), cuda(rng.uniform(0, 20, (Sb, 1)).astype(np.float32)), cuda(np.full((Sb, 1), 0.01, np.float32))
+    gb = cuda(rng.uniform(0, 1, (20000, 3)).astype(np.float32))
+    rgbb = C.composite_fwd(cb, db, dlb, None, None, cuda(big), 20000, bg)[0]
+    l3, grb = C.rgb_loss(rgbb, gb, kind)
+    want = C.composite_bwd(grb, None, None, cb, db, dlb, None, None, cuda(big), bg)
+    got = C.composite_loss(cb, db, dlb, cuda(big), 20000, bg, gb, kind)
+    assert torch.equal(got[1], want[0]) and abs(float(got[0]) - float(l3)) <= 2e-6 * abs(float(l3))
+    torch.testing.assert_close(got[2], want[1], rtol=2e-6, atol=1e-6 * float(want[1].abs().max()))
+    one = C.composite_loss(c[:700], d[:700], dl[:700], cuda(np.int64([0, 700])), 1, bg, g[:1], kind, with_rgb=True)
+    assert np.isfinite(float(one[0])) and tuple(one[3].shape) == (1, 3)
+
+
 @pytest.mark.parametrize("lens", [[5, 1, 0, 64, 65, 3, 0, 200, 1, 1], list(np.random.default_rng(1).integers(0, 130, 3000))])
 def test_composite_forward_backward(lens):
     import wisp.ops.render as R
