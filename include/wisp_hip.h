@@ -394,8 +394,8 @@ int wisp_composite_loss(const float* color, const float* density, const float* d
 /* Photometric loss of MultiviewTrainer.step (wisp/trainers/multiview_trainer.py:140-154) and its gradient in one launch:
  * loss[0] = mean over the num_elements entries of huber(beta = 1) (kind 0) / squared (1) / absolute (2) error of rgb
  * against gt; grad[i] = d loss / d rgb[i].  rgb, gt, grad: f32 [num_elements]; loss: f32 [1];
- * workspace: 257 dwords that are ZERO before the first call and belong to this entry point afterwards (dword 0 is a ticket
- * counter the kernel resets itself; calls sharing a workspace must be stream-ordered). */
+ * workspace: 257 dwords that belong to this entry point (dword 0 unused since ABI 3 + this revision, dwords 1.. per-workgroup partial
+ * sums a one-workgroup second launch adds in index order; calls sharing a workspace must be stream-ordered). */
 int wisp_rgb_loss(const float* rgb, const float* gt, int64_t num_elements, int kind, float* grad, float* loss,
                   float* workspace, wisp_stream_t stream);
 

@@ -467,18 +467,15 @@ extern "C" int wisp_generate_rays(const float* pixel_x, const float* pixel_y, in
 // ---------------------------------------------------------------------------------------------- photometric loss
 // mean over all elements of huber (smooth-L1, beta = 1) / L2 / L1 between the composited colours and the ground truth
 // (MultiviewTrainer.step, wisp/trainers/multiview_trainer.py:140-154) together with its gradient w.r.t. the colours:
-// d loss / d rgb = clamp(x, -1, 1) / N, 2 x / N, sign(x) / N for x = rgb - gt.  ONE launch: a grid-stride pass writes the
-// gradient and one partial sum per workgroup; the workgroup that finishes last (ticket counter in the workspace, which it
-// resets for the next call) adds the partials in index order - reproducible value, no second kernel.
-// (measured in round 3: 32 workgroups instead of 256 - fewer tickets - 13 vs 11 µs at 40 K rays; ONE workgroup of 1024 threads
-//  without fence or ticket 29 µs: the launch is bound by streaming 1.4 MB through few CUs, not by the hand-over)
+// d loss / d rgb = clamp(x, -1, 1) / N, 2 x / N, sign(x) / N for x = rgb - gt.  A grid-stride pass writes the gradient and one
+// partial sum per workgroup; a one-workgroup second launch adds the partials in index order - reproducible value.
+// (Until round 3 the workgroup that finished last did that inside the first launch - device-scope fence + ticket per workgroup.
+//  On this part such a fence writes back and invalidates an XCD's L2; see composite_loss_kernel for what 8192 of them cost.)
 #define LOSS_BLOCKS 256
 __global__ void __launch_bounds__(256)
 rgb_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ gt, int64_t n, int kind, float inv_n,
-                float* __restrict__ grad, float* __restrict__ partial, unsigned int* __restrict__ ticket,
-                float* __restrict__ loss) {
+                float* __restrict__ grad, float* __restrict__ partial) {
     __shared__ float part[4];
-    __shared__ bool last;
     float acc = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float x = rgb[i] - gt[i];
@@ -493,19 +490,43 @@ rgb_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ gt, int
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
-        __threadfence();                                               // partial visible before the ticket is taken
-        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last || threadIdx.x >= 64) return;
-    __threadfence();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ void __launch_bounds__(1024)
+loss_sum_kernel(const float* __restrict__ partial, int n, float inv_n, float* __restrict__ loss) {
+    __shared__ float part[16];
     float t = 0.0f;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += 64) t += __hip_atomic_load(partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int base = 0; base < n; base += 8 * 1024) {      // eight loads of a thread in flight at once
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = base + threadIdx.x + k * 1024; v[k] = i < n ? partial[i] : 0.0f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += v[k];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-    if (threadIdx.x == 0) { loss[0] = t * inv_n; *ticket = 0u; }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += part[w];
+        loss[0] = s * inv_n;
+    }
+}
+
+extern "C" int wisp_rgb_loss(const float* rgb, const float* gt, int64_t num_elements, int kind, float* grad, float* loss,
+                             float* workspace, wisp_stream_t stream) {
+    WISP_REQUIRE(num_elements > 0 && rgb && gt && grad && loss && workspace, "bad arguments");
+    WISP_REQUIRE(kind >= 0 && kind <= 2, "kind: 0 huber, 1 l2, 2 l1");
+    const int blocks = (int)min64(ceil_div64(num_elements, 256), LOSS_BLOCKS);
+    const float inv_n = 1.0f / (float)num_elements;
+    hipLaunchKernelGGL(rgb_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rgb, gt, num_elements, kind, inv_n, grad,
+                       workspace + 1);
+    hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, workspace + 1, blocks, inv_n, loss);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- composite + loss + backward
@@ -626,29 +647,6 @@ composite_loss_kernel(const float* __restrict__ color, const float* __restrict__
     if (lane == 0) partial[blockIdx.x] = lacc;
 }
 
-__global__ void __launch_bounds__(1024)
-loss_sum_kernel(const float* __restrict__ partial, int n, float inv_n, float* __restrict__ loss) {
-    __shared__ float part[16];
-    float t = 0.0f;
-    for (int base = 0; base < n; base += 8 * 1024) {      // eight loads of a thread in flight at once
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const int i = base + threadIdx.x + k * 1024; v[k] = i < n ? partial[i] : 0.0f; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += v[k];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float s = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) s += part[w];
-        loss[0] = s * inv_n;
-    }
-}
-
 extern "C" int wisp_composite_loss(const float* color, const float* density, const float* deltas, const int64_t* ray_offsets,
                                    int64_t num_rays, int64_t num_samples, const float* bg, const float* gt, int kind,
                                    float* grad_color, float* grad_density, float* out_rgb, float* loss, float* workspace,
@@ -667,15 +665,3 @@ extern "C" int wisp_composite_loss(const float* color, const float* density, con
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
-
-extern "C" int wisp_rgb_loss(const float* rgb, const float* gt, int64_t num_elements, int kind, float* grad, float* loss,
-                             float* workspace, wisp_stream_t stream) {
-    WISP_REQUIRE(num_elements > 0 && rgb && gt && grad && loss && workspace, "bad arguments");
-    WISP_REQUIRE(kind >= 0 && kind <= 2, "kind: 0 huber, 1 l2, 2 l1");
-    const int blocks = (int)min64(ceil_div64(num_elements, 256), LOSS_BLOCKS);
-    hipLaunchKernelGGL(rgb_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rgb, gt, num_elements, kind,
-                       1.0f / (float)num_elements, grad, workspace + 1, reinterpret_cast<unsigned int*>(workspace), loss);
-    WISP_CHECK_LAUNCH();
-    return WISP_OK;
-}
-
