@@ -97,8 +97,9 @@ class _DirectNeRFStep:
     GPU needs for a 2^18-sample batch (and left the GPU idle a quarter of the time in the 'voxel' configurations).
 
     Two tiers:
-      * everything but the grid is always issued directly: raymarch ('ray' with a prefetched occupancy count, 'voxel' and
-        'uniform' through OctreeAS.raymarch), fused decoder forward / backward, compositing forward / backward, loss;
+      * everything but the grid is always issued directly: raymarch (its parameter-free half - the occupancy count of 'ray',
+        the cell intersection count of 'voxel' / 'uniform' - one batch ahead when the caller names the next batch), fused
+        decoder forward / backward, compositing + loss + compositing backward (one launch: wisp_composite_loss);
       * the grid lookup is issued directly for the nerf_hash.yaml shape ('cat' HashGrid whose table gradient lives in the flat
         buffer) and for multi-level trilinear OctreeGrid / CodebookOctreeGrid fields (nerf_octree.yaml, nerf_codebook.yaml: one
         launch for all levels forward, gradients written straight into the parameters' .grad); any other grid of the plugin
