@@ -873,6 +873,24 @@ def test_composite_loss_in_one_launch_equals_the_three_launches(kind):
     torch.testing.assert_close(got[2], want[1], rtol=2e-6, atol=1e-6 * float(want[1].abs().max()))
     one = C.composite_loss(c[:700], d[:700], dl[:700], cuda(np.int64([0, 700])), 1, bg, g[:1], kind, with_rgb=True)
     assert np.isfinite(float(one[0])) and tuple(one[3].shape) == (1, 3)
+    # and against the oracle itself: oracle.render.composite in float64 + the trainer's loss (multiview_trainer.py:140-154), autograd
+    ridx = np.repeat(np.arange(R), lens).astype(np.int64)
+    c64 = torch.from_numpy(color).double().requires_grad_(True)
+    d64 = torch.from_numpy(dens).double().requires_grad_(True)
+    b = torch.from_numpy(ospc.mark_pack_boundaries(ridx))
+    want = orender.composite(c64, d64, torch.from_numpy(delt), torch.from_numpy(delt), torch.from_numpy(ridx), b, R, bg, with_depth=False)
+    x = want["rgb"] - torch.from_numpy(gts).double()
+    if kind == "huber":
+        per = torch.where(x.abs() < 1.0, 0.5 * x * x, x.abs() - 0.5)
+    else:
+        per = x * x if kind == "l2" else x.abs()
+    ref_loss = per.mean()
+    ref_loss.backward()
+    assert abs(float(loss1) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    np.testing.assert_allclose(rgb1.cpu().numpy(), want["rgb"].detach().numpy(), rtol=0, atol=1e-5)     # contract: 1e-4
+    gc_ref, gd_ref = c64.grad.numpy(), d64.grad.numpy()
+    np.testing.assert_allclose(gc1.cpu().numpy(), gc_ref, rtol=0, atol=1e-5 * np.abs(gc_ref).max())
+    np.testing.assert_allclose(gd1.cpu().numpy(), gd_ref, rtol=0, atol=2e-5 * np.abs(gd_ref).max())     # (as test_composite_forward_backward)
 
 
 @pytest.mark.parametrize("lens", [[5, 1, 0, 64, 65, 3, 0, 200, 1, 1], list(np.random.default_rng(1).integers(0, 130, 3000))])
