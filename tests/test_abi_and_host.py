@@ -28,6 +28,33 @@ def test_library_exports_every_declared_symbol():
     assert C.lib.wisp_nerf_mlp_param_count(32, 64, 4) == 3152 + 7107    # decoder sizes of nerf_hash.yaml
 
 
+def test_ctypes_signatures_follow_the_header_argument_by_argument():
+    """Every declaration of include/wisp_hip.h against wisp._C.SIGNATURES: the same number of arguments, pointers bound as
+    c_void_p, 64-bit integers as c_int64, ints as c_int32, floats as c_float, the stream as c_void_p - a binding that drifts from
+    the header (an argument added on one side only) shifts every later argument silently at call time."""
+    import wisp._C as C
+    header = open(os.path.join(ROOT, "include", "wisp_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)                       # comments may hold commas and parentheses
+    header = re.sub(r"//[^\n]*", " ", header)
+    decls = re.findall(r"\b(?:int|int64_t|const char\s*\*)\s+(wisp_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header)
+    assert len(decls) == len(C.SIGNATURES)
+    kinds = {ctypes.c_void_p: "ptr", ctypes.c_int64: "i64", ctypes.c_int32: "i32", ctypes.c_float: "f32", ctypes.c_uint64: "u64",
+             ctypes.c_uint32: "u32", ctypes.c_double: "f64"}
+
+    def kind_of(arg):
+        arg = " ".join(arg.split())
+        if "*" in arg or arg.startswith("wisp_stream_t"):
+            return "ptr"
+        base = arg.rsplit(" ", 1)[0].replace("const ", "")
+        return {"int64_t": "i64", "uint64_t": "u64", "int": "i32", "int32_t": "i32", "uint32_t": "u32", "float": "f32", "double": "f64"}[base]
+
+    for name, args in decls:
+        args = [a for a in (x.strip() for x in args.split(",")) if a and a != "void"]
+        want = [kind_of(a) for a in args]
+        got = [kinds[t] for t in C.SIGNATURES[name]]
+        assert got == want, (name, got, want)
+
+
 def test_hot_path_refuses_cpu_tensors():
     import wisp._C as C
     with pytest.raises(RuntimeError, match="GPU tensor"):
