@@ -431,6 +431,59 @@ def test_allreduce_range_leaves_out_only_a_gradient_free_tail():
     assert t3._live_grad_numel() == t3.flat.grad.numel()
 
 
+def test_look_ahead_raytrace_state_is_only_used_where_it_fits(monkeypatch):
+    """OctreeAS.raytrace(..., begun=state) / raymarch(..., begin_only / begun): host plumbing of the one-batch look-ahead with the HIP
+    calls replaced by recorders - a state issued for the same Rays object, level and octree is finished as it is; one issued for
+    other rays, another level or another OctreeAS (a prune replaces the object) is dropped and the count redone; begin_only
+    returns the state for 'voxel' / 'uniform' and None for 'ray'; the voxel march hands the nuggets on as cell hints."""
+    import types
+    import wisp.accelstructs.octree_as as mod
+    from wisp.accelstructs import OctreeAS
+    from wisp.core import Rays
+    calls = []
+
+    def begin(octree, points, exsum, origins, dirs, level):
+        calls.append(("begin", level))
+        return dict(level=level, offsets=torch.zeros(origins.shape[0] + 1, dtype=torch.int64), tag=len(calls))
+
+    def finish(st, with_exit=False):
+        calls.append(("finish", st["tag"], with_exit))
+        n = 3
+        return (torch.zeros(n, dtype=torch.int32), torch.arange(n, dtype=torch.int32), torch.zeros(n, 2 if with_exit else 1), st["offsets"])
+
+    def voxel(origins, dirs, ridx, depth, num_samples, jitter, seed):
+        S = ridx.shape[0] * num_samples
+        return (torch.zeros(S, dtype=torch.int64), torch.zeros(S, 3), torch.zeros(S, 1), torch.zeros(S, 1), torch.zeros(S, dtype=torch.bool))
+
+    fake = types.SimpleNamespace(spc_raytrace_begin=begin, spc_raytrace_finish=finish, raymarch_voxel=voxel)
+    monkeypatch.setattr(mod, "_hip", lambda: fake)
+    oc, pts, pyr, ex = (torch.from_numpy(np.asarray(a)) for a in (lambda o: (o,) + ospc.octree_to_spc(o))(ospc.create_dense_octree(2)))
+    oc._wisp_spc_parts = (pts.short(), pyr.int(), ex.int())
+    blas = OctreeAS(oc)
+    monkeypatch.setattr(blas, "_to_device", lambda dev: None)
+    r0 = Rays(torch.zeros(4, 3), torch.ones(4, 3), dist_min=0.0, dist_max=1.0)
+    r1 = Rays(torch.zeros(4, 3), torch.ones(4, 3), dist_min=0.0, dist_max=1.0)
+    st = blas.raytrace_begin(r0, 2)
+    assert st["blas"] is blas and st["rays"] is r0 and calls == [("begin", 2)]
+    blas.raytrace(r0, 2, with_exit=True, begun=st)
+    assert calls[-1] == ("finish", 1, True) and len(calls) == 2                       # finished as issued, nothing recounted
+    for rays, level, owner in ((r1, 2, blas), (r0, 1, blas), (r0, 2, None)):
+        stale = blas.raytrace_begin(r0, 2)
+        if owner is None:
+            stale["blas"] = object()                                                   # an octree a prune has replaced
+        before = len(calls)
+        blas.raytrace(rays, level, begun=stale)
+        assert [c[0] for c in calls[before:]] == ["begin", "finish"] and calls[-1][1] != stale["tag"]
+    assert blas.raymarch(r0, 'ray', 8, level=2, begin_only=True) is None
+    st = blas.raymarch(r0, 'voxel', 4, level=2, begin_only=True)
+    assert st["level"] == 2 and st["rays"] is r0
+    before = len(calls)
+    monkeypatch.setattr(OctreeAS, "_draw_seed", staticmethod(lambda: 7))
+    rm = blas.raymarch(r0, 'voxel', 4, level=2, begun=st)
+    assert [c[0] for c in calls[before:]] == ["finish"] and rm.samples.shape[0] == 12
+    assert rm.nugget_level == 2 and rm.samples_per_nugget == 4 and rm.nugget_pidx.shape[0] == 3
+
+
 def test_hashgrid_backward_workspace_query_is_sane_without_a_gpu():
     """wisp_hashgrid_bwd_workspace_bytes is pure host arithmetic (slot plan of the binned backward, incl. the capped grid of
     the queue emitter): callable without a device, monotone in the sample count, and a few GB at the nerf_hash shape."""
