@@ -32,7 +32,8 @@ enum {
 
 const char* wisp_last_error(void);
 /* ABI version of this library; bumped whenever a signature changes (1 = round 1; 2 = round 2: scratch arguments of the backward
- * passes, raytrace nugget cache, optimizer kinds, per-ray view codes, corner query, decoded codebook rows). */
+ * passes, raytrace nugget cache, optimizer kinds, per-ray view codes, corner query, decoded codebook rows; 3 = round 3: per-level
+ * slot scales of the hash-grid backward.  Entry points that are only ADDED - wisp_spc_query_chain, wisp_composite_loss - do not bump it). */
 int wisp_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
