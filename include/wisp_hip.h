@@ -33,7 +33,8 @@ enum {
 const char* wisp_last_error(void);
 /* ABI version of this library; bumped whenever a signature changes (1 = round 1; 2 = round 2: scratch arguments of the backward
  * passes, raytrace nugget cache, optimizer kinds, per-ray view codes, corner query, decoded codebook rows; 3 = round 3: per-level
- * slot scales of the hash-grid backward.  Entry points that are only ADDED - wisp_spc_query_chain, wisp_composite_loss - do not bump it). */
+ * slot scales of the hash-grid backward; 4 = round 4: workspace + row counts of the order-free trilinear / codebook backward.
+ * Entry points that are only ADDED - wisp_spc_query_chain, wisp_composite_loss, wisp_codebook_trilinear_multi_bwd - do not bump it). */
 int wisp_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -201,10 +202,19 @@ int wisp_spc_trilinear_fwd(const float* coords, const void* pidx, int pidx_is_i6
                            const int32_t* trinkets, const void* feats, int dtype, int64_t num_voxels,
                            int samples_per_voxel, int channels, int level, int half_round, float* out,
                            wisp_stream_t stream);
+/* Backward w.r.t. the features: grad_feats f32 [num_rows, channels] is ADDED to.  Order-free: the corner sums are taken in
+ * 64-bit fixed point (scaled from the launch's largest product), so the same inputs give the same bits on every run - the
+ * reference's float atomics do not.  workspace: wisp_spc_bwd_workspace_bytes(num_rows, channels, 0) bytes of device memory
+ * that are ZERO before the first call; every call leaves them zero, so one buffer serves all calls of a stream.
+ * A non-finite grad_out (overflowed loss scale) is scattered with plain float atomics so that inf / NaN reach the gradient. */
 int wisp_spc_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
                            const int32_t* trinkets, const float* grad_out, int64_t num_voxels,
-                           int samples_per_voxel, int channels, int level, float* grad_feats /* f32, accumulated */,
+                           int samples_per_voxel, int channels, int level, int64_t num_rows,
+                           float* grad_feats /* f32, accumulated */, void* workspace, int64_t workspace_bytes,
                            wisp_stream_t stream);
+/* Scratch of the trilinear / codebook backward passes: total_rows = feature (logits) rows of all levels of the call,
+ * dict_elems = num_lods * dict_size * feature_dim for the codebook entry points, else 0. */
+int64_t wisp_spc_bwd_workspace_bytes(int64_t total_rows, int channels, int64_t dict_elems);
 
 /* All active levels of an OctreeGrid in one launch (wisp/models/grids/octree_grid.py:183-219: one trilinear lookup per
  * level, then cat or sum).  coords f32 [N,3]; chain i64 [N, chain_stride], column l = voxel (point-hierarchy index, -1 =
@@ -215,10 +225,12 @@ int wisp_spc_trilinear_multi_fwd(const float* coords, const int64_t* chain, int6
                                  const int32_t* trinkets, const void* const* feats, int dtype, int64_t num_samples,
                                  int num_lods, const int32_t* levels, int channels, int half_round, int sum, float* out,
                                  wisp_stream_t stream);
+/* rows: HOST i64 [num_lods], the row count of every grad_feats tensor; workspace as for wisp_spc_trilinear_bwd with
+ * total_rows = sum(rows).  One scatter launch for all levels. */
 int wisp_spc_trilinear_multi_bwd(const float* coords, const int64_t* chain, int64_t chain_stride, const int16_t* points,
                                  const int32_t* trinkets, const float* grad_out, int64_t num_samples, int num_lods,
-                                 const int32_t* levels, int channels, int sum, float* const* grad_feats,
-                                 wisp_stream_t stream);
+                                 const int32_t* levels, const int64_t* rows, int channels, int sum,
+                                 float* const* grad_feats, void* workspace, int64_t workspace_bytes, wisp_stream_t stream);
 
 /* TriplanarGrid.interpolate (wisp/models/grids/triplanar_grid.py:97-146, TriplanarFeatureVolume.forward :205-233): per
  * level three bilinear plane lookups with torch.nn.functional.grid_sample semantics (align_corners=True, reflection
@@ -242,8 +254,10 @@ int wisp_grid_interpolate_bwd(const float* coords, const void* grad_out, int dty
 /* VQAD codebook lookup fused with the trilinear blend (replaces CodebookOctreeGrid._index_features + _interpolate,
  * wisp/models/grids/codebook_grid.py:103-172): logits f32 [Fn, dict_size], dictionary f32 [dict_size, feature_dim]
  * (dict_size <= 256, feature_dim <= 16).  training != 0: straight-through softmax one-hot; else argmax lookup.
- * Backward (training semantics): grad_logits [num_logit_rows = Fn, dict_size] must be ZERO on entry and holds the
- * gradient on return (its rows double as the scratch of the two-pass scheme); grad_dictionary is accumulated into. */
+ * Backward (training semantics): grad_logits [num_logit_rows = Fn, dict_size] and grad_dictionary are ADDED to; order-free
+ * like wisp_spc_trilinear_bwd (same workspace rules; total_rows = logits rows, channels = feature_dim, dict_elems =
+ * num_lods * dict_size * feature_dim).  feature_dim <= dict_size.  With a non-finite grad_out the corner sums land as float
+ * atomics in the first feature_dim columns of grad_logits - enough for a found-inf check to see them, nothing more. */
 int wisp_codebook_trilinear_fwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
                                 const int32_t* trinkets, const float* logits, const float* dictionary,
                                 int64_t num_voxels, int samples_per_voxel, int dict_size, int feature_dim, int level,
@@ -257,7 +271,17 @@ int wisp_codebook_trilinear_bwd(const float* coords, const void* pidx, int pidx_
                                 const int32_t* trinkets, const float* logits, const float* dictionary,
                                 const float* grad_out, int64_t num_voxels, int samples_per_voxel, int dict_size,
                                 int feature_dim, int level, int64_t num_logit_rows, float* grad_logits,
-                                float* grad_dictionary, wisp_stream_t stream);
+                                float* grad_dictionary, void* workspace, int64_t workspace_bytes, wisp_stream_t stream);
+/* All levels of a CodebookOctreeGrid in one scatter launch (the reference loops over the levels in Python,
+ * wisp/models/grids/octree_grid.py:200-213 calling codebook_grid.py:138-172 per level): chain / levels / rows / sum as in
+ * wisp_spc_trilinear_multi_bwd; logits, dictionaries, grad_logits, grad_dictionaries: HOST arrays of num_lods device pointers;
+ * grad_out f32 [N, feature_dim] (sum = 1) or [N, num_lods * feature_dim]. */
+int wisp_codebook_trilinear_multi_bwd(const float* coords, const int64_t* chain, int64_t chain_stride, const int16_t* points,
+                                      const int32_t* trinkets, const float* const* logits, const float* const* dictionaries,
+                                      const float* grad_out, int64_t num_samples, int num_lods, const int32_t* levels,
+                                      const int64_t* rows, int dict_size, int feature_dim, int sum, float* const* grad_logits,
+                                      float* const* grad_dictionaries, void* workspace, int64_t workspace_bytes,
+                                      wisp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Raymarch sample generation  (replace OctreeAS._raymarch_ray / _raymarch_voxel / _raymarch_uniform,

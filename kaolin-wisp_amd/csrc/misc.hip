@@ -11,7 +11,7 @@ thread_local char g_wisp_err[512] = "";
 extern "C" const char* wisp_last_error(void) { return g_wisp_err; }
 // 2: round-2 surface (workspace arguments, raytrace cache, *_rays, query, decode_rows, optimizer kinds)
 // 3: hash-grid backward takes per-level slot scales (+ wisp_hashgrid_bwd_slot_stats), wisp_hashgrid_cells
-extern "C" int wisp_abi_version(void) { return 3; }
+extern "C" int wisp_abi_version(void) { return 4; }
 
 __global__ void __launch_bounds__(256)
 adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,

@@ -1,0 +1,597 @@
+// Backward of the dual-octree trilinear lookups (OctreeGrid / CodebookOctreeGrid) for gfx950 - order-free by construction.
+//
+// What it replaces: the backward of kaolin.ops.spc.unbatched_interpolate_trilinear as autograd runs it under
+// OctreeGrid._interpolate / interpolate (wisp/models/grids/octree_grid.py:130-219: one lookup per active level, then cat or
+// sum) and of CodebookOctreeGrid._index_features + _interpolate (wisp/models/grids/codebook_grid.py:103-172: straight-through
+// softmax one-hot over 2^bw dictionary rows per corner).  The reference scatters with float atomics (free order).
+//
+// Here every corner gradient is a sum of fixed-point integers, which is associative: whatever order the memory-side atomic
+// units retire the adds in, the bits of the result are the same.  One call = all levels:
+//   1. spc_grad_absmax      M = max |w_corner * g| over every (sample, level, corner, channel) - evaluated with the very float
+//                           operations of pass 2, via max_j |w_j| * max_c |g_c| (rounding is monotone) - as an integer max of
+//                           float bit patterns (a NaN / inf gradient gives an all-ones exponent and selects the float path)
+//   2. spc_grad_scatter     per sample and level: w_j * g_c in float (the reference's products), consecutive samples of one
+//                           cell merged in the wave by a fixed-shape segmented scan, run totals converted to
+//                           round(v * 2^s) (s from M and the sample count: 8 n 2^s M < 2^62, so no sum can overflow) and added
+//                           with 64-bit integer atomics into the accumulator rows of the workspace; touched rows are flagged
+//   3. spc_grad_finalize /  every flagged row once: accumulator -> float -> ADDED to the gradient tensor (one writer per
+//      codebook_finalize    element), accumulator and flag cleared.  The codebook variant turns the row's G = sum w g into the
+//                           logits gradient  p_k (D_k . G - sum_m p_m D_m . G)  and adds scale * G to the dictionary row's
+//                           own fixed-point accumulator (LDS, then workspace), which
+//   4. codebook_dict_flush  converts (one small launch).
+// The workspace (caller-owned, ZERO before its first use) is all zero again when the call returns.
+#include "wisp_common.h"
+
+#define SG_MAX_LODS 16
+#define SG_THREADS 128
+#define CB_MAX_K 256
+#define CB_MAX_F 16
+
+struct SgLods {
+    float* grad[SG_MAX_LODS];            // per-level gradient tensor ([rows_l, C] features or [rows_l, K] logits)
+    const float* logits[SG_MAX_LODS];    // codebook only
+    const float* dict[SG_MAX_LODS];      // codebook only
+    float* grad_dict[SG_MAX_LODS];       // codebook only
+    int64_t base[SG_MAX_LODS + 1];       // first accumulator row of every level
+    int32_t level[SG_MAX_LODS];
+};
+
+struct SgHeader { uint32_t absmax_bits; uint32_t pad[15]; };
+
+static inline int sg_stride(int channels) {
+    if (channels <= 8) { int s = 1; while (s < channels) s <<= 1; return s; }
+    return (channels + 7) / 8 * 8;
+}
+static inline int64_t sg_round64(int64_t v) { return (v + 63) / 64 * 64; }
+
+// ---- fixed-point scale: values are bounded by M < 2^(E+1); `adds` contributions per accumulator at most
+struct SgScale { double to_fix, to_float; int finite; int zero; };
+static __device__ __forceinline__ SgScale sg_scale(uint32_t absmax_bits, int clog) {
+    SgScale s;
+    const int e = (int)(absmax_bits >> 23);
+    s.finite = e != 0xff;
+    s.zero = absmax_bits == 0;
+    const int E = (e < 1 ? 1 : e) - 127;
+    const int sh = 60 - clog - E;                                       // 2^clog adds of < 2^(E+1) each stay below 2^61
+    s.to_fix = __longlong_as_double((long long)(sh + 1023) << 52);
+    s.to_float = __longlong_as_double((long long)(1023 - sh) << 52);
+    return s;
+}
+
+static __device__ __forceinline__ void sg_coeffs(const float* __restrict__ c, const int16_t* __restrict__ pt, int level,
+                                                 float (&w)[8]) {
+    // (the statements of trilinear_coeffs in spc_interp.hip: forward and backward must see the same weights)
+    const float res = (float)(1 << level);
+    float f[3], g[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        f[a] = res * (0.5f * c[a] + 0.5f) - (float)pt[a];
+        g[a] = 1.0f - f[a];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = ((j & 4) ? f[0] : g[0]) * ((j & 2) ? f[1] : g[1]) * ((j & 1) ? f[2] : g[2]);
+}
+
+static __device__ __forceinline__ uint32_t sg_wave_umax(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------- pass 1: magnitude bound
+template <typename I>
+__global__ void __launch_bounds__(256)
+spc_grad_absmax_kernel(const float* __restrict__ coords, const I* __restrict__ cells, int64_t cell_stride, int spv,
+                       const int16_t* __restrict__ points, SgLods ml, const float* __restrict__ grad_out, int64_t n,
+                       int num_lods, int channels, int sum, SgHeader* __restrict__ hdr) {
+    const int out_row = sum ? channels : num_lods * channels;
+    uint32_t best = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* g = grad_out + i * out_row;
+        uint32_t gsum = 0;
+        if (sum)
+            for (int c = 0; c < channels; ++c) { const uint32_t b = __float_as_uint(g[c]) & 0x7fffffffu; gsum = b > gsum ? b : gsum; }
+        const I* ch = cells + (i / spv) * cell_stride;
+        for (int l = 0; l < num_lods; ++l) {
+            const int64_t p = (int64_t)ch[l];
+            if (p < 0) continue;
+            uint32_t gm = gsum;
+            if (!sum) {
+                gm = 0;
+                for (int c = 0; c < channels; ++c) {
+                    const uint32_t b = __float_as_uint(g[l * channels + c]) & 0x7fffffffu;
+                    gm = b > gm ? b : gm;
+                }
+            }
+            const float res = (float)(1 << ml.level[l]);
+            float wm = 1.0f;
+            bool first = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float f = res * (0.5f * coords[i * 3 + a] + 0.5f) - (float)points[p * 3 + a];
+                const float m = fmaxf(fabsf(f), fabsf(1.0f - f));
+                wm = first ? m : wm * m;                                // (a * b) * c, as the weights are formed
+                first = false;
+            }
+            // |w_j g_c| <= fl(max_j |w_j| * max_c |g_c|): both factors are attained and float rounding is monotone
+            const uint32_t b = __float_as_uint(wm * __uint_as_float(gm)) & 0x7fffffffu;
+            const uint32_t nb = (gm >= 0x7f800000u || !(wm == wm)) ? 0x7fc00000u : b;       // non-finite anywhere: say so
+            best = nb > best ? nb : best;
+        }
+    }
+    best = sg_wave_umax(best);
+    if ((threadIdx.x & 63) == 0 && best != 0) atomicMax(&hdr->absmax_bits, best);
+}
+
+// ---------------------------------------------------------------------------------------------- pass 2: scatter
+// Small channel counts (<= 8: nerf_octree / nerf_codebook have 5): one thread owns one sample and keeps its 8 x F products
+// in registers.  Consecutive samples of a ray share the cell (16 per cell in the 'voxel' march, long runs on the coarse levels
+// of any march), so the wave first adds up each run with a segmented scan - same lanes, same shape, same float adds every
+// time - and only the run tails go to memory: all lanes walk the (tail, corner, channel) items, channel fastest, so that the
+// F adds of a row sit in neighbouring lanes of one atomic instruction.
+template <int F, typename I>
+__global__ void __launch_bounds__(SG_THREADS)
+spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restrict__ cells, int64_t cell_stride, int spv,
+                              const int16_t* __restrict__ points, const int32_t* __restrict__ trinkets, SgLods ml,
+                              const float* __restrict__ grad_out, int64_t n, int num_lods, int sum, int clog, int stride,
+                              int direct_stride, const SgHeader* __restrict__ hdr, uint8_t* __restrict__ flags,
+                              long long* __restrict__ acc) {
+    __shared__ float s_val[SG_THREADS / 64][64][8 * F];
+    __shared__ int32_t s_row[SG_THREADS / 64][64][8];
+    const SgScale sc = sg_scale(hdr->absmax_bits, clog);
+    if (sc.zero) return;                                                 // every product is zero: nothing to add
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool in = i < n;
+    const int out_row = sum ? F : num_lods * F;
+    float c[3] = {0.0f, 0.0f, 0.0f}, g[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) g[f] = 0.0f;
+    if (in) {
+        c[0] = coords[i * 3]; c[1] = coords[i * 3 + 1]; c[2] = coords[i * 3 + 2];
+        if (sum)
+#pragma unroll
+            for (int f = 0; f < F; ++f) g[f] = grad_out[i * out_row + f];
+    }
+    const I* ch = cells + (in ? (i / spv) * cell_stride : 0);
+    for (int l = 0; l < num_lods; ++l) {
+        const int64_t p = in ? (int64_t)ch[l] : -1;
+        float v[8][F];
+        if (p >= 0) {
+            float w[8];
+            sg_coeffs(c, points + p * 3, ml.level[l], w);
+            if (!sum)
+#pragma unroll
+                for (int f = 0; f < F; ++f) g[f] = grad_out[i * out_row + l * F + f];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int f = 0; f < F; ++f) v[j][f] = w[j] * g[f];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int f = 0; f < F; ++f) v[j][f] = 0.0f;
+        }
+        // segmented inclusive sum over the wave; runs = consecutive lanes with the same cell (invalid lanes are their own run)
+        const int64_t key = p >= 0 ? p : -1 - lane;
+        const int64_t prev = __shfl_up(key, 1, 64), next = __shfl_down(key, 1, 64);
+        int head = (lane == 0 || prev != key) ? 1 : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int hp = __shfl_up(head, d, 64);
+            const bool take = lane >= d && !head;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const float t = __shfl_up(v[j][f], d, 64);
+                    if (take) v[j][f] += t;
+                }
+            if (take) head |= hp;
+        }
+        const bool tail = p >= 0 && (lane == 63 || next != key);
+        const uint64_t tmask = __ballot(tail);
+        if (tmask == 0) continue;                                         // (wave-uniform)
+        if (tail) {
+            const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s_row[wv][rank][j] = trinkets[p * 8 + j];
+#pragma unroll
+                for (int f = 0; f < F; ++f) s_val[wv][rank][j * F + f] = v[j][f];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int items = __popcll(tmask) * 8 * F;
+        if (sc.finite) {
+            const int64_t base = ml.base[l];
+            for (int it = lane; it < items; it += 64) {
+                const int rank = it / (8 * F), rem = it - rank * (8 * F);
+                const int j = rem / F, f = rem - j * F;
+                const int64_t row = base + s_row[wv][rank][j];
+                const long long q = __double2ll_rn((double)s_val[wv][rank][rem] * sc.to_fix);
+                atomicAdd(reinterpret_cast<unsigned long long*>(acc + row * stride + f), (unsigned long long)q);
+                if (f == 0) flags[row] = 1;
+            }
+        } else {
+            // a non-finite gradient (an overflowed loss scale): plain float atomics straight into the gradient tensor, so
+            // that inf / NaN arrive where the reference's atomics would put them (the optimizer step is skipped anyway)
+            float* gd = ml.grad[l];
+            for (int it = lane; it < items; it += 64) {
+                const int rank = it / (8 * F), rem = it - rank * (8 * F);
+                const int j = rem / F, f = rem - j * F;
+                atomicAdd(gd + (int64_t)s_row[wv][rank][j] * direct_stride + f, s_val[wv][rank][rem]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                                  // the slice is rewritten by the next level
+    }
+}
+
+// Any channel count (NGLOD: 16): consecutive lanes own consecutive channels of one sample, one 64-bit add per product.
+template <typename I>
+__global__ void __launch_bounds__(256)
+spc_grad_scatter_wide_kernel(const float* __restrict__ coords, const I* __restrict__ cells, int64_t cell_stride, int spv,
+                             const int16_t* __restrict__ points, const int32_t* __restrict__ trinkets, SgLods ml,
+                             const float* __restrict__ grad_out, int64_t n, int num_lods, int channels, int sum, int clog,
+                             int stride, int direct_stride, const SgHeader* __restrict__ hdr, uint8_t* __restrict__ flags,
+                             long long* __restrict__ acc) {
+    const SgScale sc = sg_scale(hdr->absmax_bits, clog);
+    if (sc.zero) return;
+    const int cpt = channels <= 64 ? channels : 64;
+    const int rows_per_block = blockDim.x / cpt;
+    const int ch0 = threadIdx.x % cpt;
+    if ((int)threadIdx.x / cpt >= rows_per_block) return;
+    const int64_t step = (int64_t)gridDim.x * rows_per_block;
+    const int out_row = sum ? channels : num_lods * channels;
+    for (int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cpt; i < n; i += step) {
+        const I* ch = cells + (i / spv) * cell_stride;
+        for (int l = 0; l < num_lods; ++l) {
+            const int64_t p = (int64_t)ch[l];
+            if (p < 0) continue;
+            float w[8];
+            sg_coeffs(coords + i * 3, points + p * 3, ml.level[l], w);
+            const int32_t* tr = trinkets + p * 8;
+            for (int c = ch0; c < channels; c += cpt) {
+                const float g = grad_out[i * out_row + (sum ? 0 : l * channels) + c];
+                if (sc.finite) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int64_t row = ml.base[l] + tr[j];
+                        const long long q = __double2ll_rn((double)(g * w[j]) * sc.to_fix);
+                        atomicAdd(reinterpret_cast<unsigned long long*>(acc + row * stride + c), (unsigned long long)q);
+                        if (c == 0) flags[row] = 1;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) atomicAdd(ml.grad[l] + (int64_t)tr[j] * direct_stride + c, g * w[j]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- pass 3: accumulators -> gradients
+static __device__ __forceinline__ int sg_level_of(const SgLods& ml, int num_lods, int64_t row) {
+    int l = 0;
+    while (l + 1 < num_lods && row >= ml.base[l + 1]) ++l;
+    return l;
+}
+
+__global__ void __launch_bounds__(256)
+spc_grad_finalize_kernel(SgLods ml, int num_lods, int channels, int stride, int lpr /* lanes per row: power of two <= 64 */,
+                         int clog, const SgHeader* __restrict__ hdr, uint8_t* __restrict__ flags, long long* __restrict__ acc) {
+    const SgScale sc = sg_scale(hdr->absmax_bits, clog);
+    const int64_t total = ml.base[num_lods];
+    const int rpb = blockDim.x / lpr, lane = threadIdx.x % lpr;
+    for (int64_t row = (int64_t)blockIdx.x * rpb + threadIdx.x / lpr; row < total; row += (int64_t)gridDim.x * rpb) {
+        if (!flags[row]) continue;                                       // (all lanes of a row sit in one wave: read before the clear)
+        const int l = sg_level_of(ml, num_lods, row);
+        float* gd = ml.grad[l] + (row - ml.base[l]) * channels;
+        long long* a = acc + row * stride;
+        for (int c = lane; c < channels; c += lpr) {
+            const long long q = a[c];
+            if (q != 0) { gd[c] += (float)((double)q * sc.to_float); a[c] = 0; }
+        }
+        if (lane == 0) flags[row] = 0;
+    }
+}
+
+// Codebook: one thread per logits row.  d logits[row, k] = p_k (D_k . G - sum_m p_m D_m . G); d dictionary[argmax] += scale G
+// with scale = (1 - p) + p, the forward value of the straight-through key (codebook_grid.py:117-125).
+__global__ void __launch_bounds__(256)
+codebook_grad_finalize_kernel(SgLods ml, int lod_begin, int lod_end, int K, int F, int stride, int clog,
+                              const SgHeader* __restrict__ hdr, uint8_t* __restrict__ flags, long long* __restrict__ acc,
+                              long long* __restrict__ dict_acc) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    const int nl = lod_end - lod_begin;
+    long long* s_gdict = reinterpret_cast<long long*>(s_raw);            // [nl * K * F] fixed-point dictionary gradient
+    float* s_dict = reinterpret_cast<float*>(s_gdict + (size_t)nl * K * F);   // [nl * K * F] dictionaries
+    for (int e = threadIdx.x; e < nl * K * F; e += blockDim.x) {
+        s_gdict[e] = 0;
+        s_dict[e] = ml.dict[lod_begin + e / (K * F)][e % (K * F)];
+    }
+    __syncthreads();
+    const SgScale sc = sg_scale(hdr->absmax_bits, clog);
+    const int64_t first = ml.base[lod_begin], last = ml.base[lod_end];
+    for (int64_t row = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < last; row += (int64_t)gridDim.x * blockDim.x) {
+        if (!flags[row]) continue;
+        flags[row] = 0;
+        int l = lod_begin;
+        while (l + 1 < lod_end && row >= ml.base[l + 1]) ++l;
+        const int64_t r = row - ml.base[l];
+        long long* a = acc + row * stride;
+        long long q[CB_MAX_F];                                           // (constant trip counts + guards: these stay in registers)
+        float G[CB_MAX_F];
+#pragma unroll
+        for (int f = 0; f < CB_MAX_F; ++f) {
+            q[f] = 0; G[f] = 0.0f;
+            if (f < F) { q[f] = a[f]; a[f] = 0; G[f] = (float)((double)q[f] * sc.to_float); }
+        }
+        const float* lrow = ml.logits[l] + r * K;
+        float* grow = ml.grad[l] + r * K;
+        const float* D = s_dict + (size_t)(l - lod_begin) * K * F;
+        int best = 0;
+        float mx = lrow[0];
+        for (int k = 1; k < K; ++k) { const float x = lrow[k]; if (x > mx) { mx = x; best = k; } }   // first max wins (torch.max)
+        float denom = 0.0f;
+        for (int k = 0; k < K; ++k) denom += expf(lrow[k] - mx);
+        const float inv = 1.0f / denom;
+        float dot = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            float dk = 0.0f;
+#pragma unroll
+            for (int f = 0; f < CB_MAX_F; ++f) if (f < F) dk += D[k * F + f] * G[f];
+            dot += expf(lrow[k] - mx) * inv * dk;
+        }
+        for (int k = 0; k < K; ++k) {
+            float dk = 0.0f;
+#pragma unroll
+            for (int f = 0; f < CB_MAX_F; ++f) if (f < F) dk += D[k * F + f] * G[f];
+            grow[k] += expf(lrow[k] - mx) * inv * (dk - dot);
+        }
+        const double scale = (double)((1.0f - inv) + inv);
+        long long* sg = s_gdict + ((size_t)(l - lod_begin) * K + best) * F;
+#pragma unroll
+        for (int f = 0; f < CB_MAX_F; ++f)
+            if (f < F && q[f] != 0)
+                atomicAdd(reinterpret_cast<unsigned long long*>(sg + f), (unsigned long long)__double2ll_rn((double)q[f] * scale));
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nl * K * F; e += blockDim.x) {
+        const long long x = s_gdict[e];
+        if (x != 0) atomicAdd(reinterpret_cast<unsigned long long*>(dict_acc + (size_t)lod_begin * K * F + e), (unsigned long long)x);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+codebook_dict_flush_kernel(SgLods ml, int num_lods, int KF, int clog, const SgHeader* __restrict__ hdr,
+                           long long* __restrict__ dict_acc) {
+    const SgScale sc = sg_scale(hdr->absmax_bits, clog);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < num_lods * KF; e += gridDim.x * blockDim.x) {
+        const long long q = dict_acc[e];
+        if (q == 0) continue;
+        dict_acc[e] = 0;
+        ml.grad_dict[e / KF][e % KF] += (float)((double)q * sc.to_float);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+struct SgPlan { int64_t total_rows, dict_elems, off_dict, off_flags, off_acc, bytes; int stride; };
+
+static SgPlan sg_plan(int64_t total_rows, int channels, int64_t dict_elems) {
+    SgPlan p;
+    p.total_rows = total_rows; p.dict_elems = dict_elems; p.stride = sg_stride(channels);
+    p.off_dict = (int64_t)sizeof(SgHeader);
+    p.off_flags = p.off_dict + sg_round64(dict_elems * 8);
+    p.off_acc = p.off_flags + sg_round64(total_rows);
+    p.bytes = p.off_acc + total_rows * p.stride * 8;
+    return p;
+}
+
+extern "C" int64_t wisp_spc_bwd_workspace_bytes(int64_t total_rows, int channels, int64_t dict_elems) {
+    if (total_rows < 0 || channels < 1 || dict_elems < 0) return -1;
+    return sg_plan(total_rows, channels, dict_elems).bytes;
+}
+
+static int sg_clog(int64_t n) {                                           // ceil(log2(8 n)): adds one accumulator can receive
+    int c = 3;
+    while (((int64_t)1 << (c - 3)) < n) ++c;
+    return c;
+}
+
+struct SgCall {
+    const float* coords; const void* cells; int cells_is_i64; int64_t cell_stride; int spv;
+    const int16_t* points; const int32_t* trinkets; const float* grad_out; int64_t n; int num_lods; int channels; int sum;
+    int direct_stride;                                                    // row stride of the gradient tensors (non-finite path)
+};
+
+// passes 1 and 2
+static int sg_scatter(const SgCall& c, const SgLods& ml, const SgPlan& pl, unsigned char* ws, hipStream_t s) {
+    SgHeader* hdr = reinterpret_cast<SgHeader*>(ws);
+    uint8_t* flags = ws + pl.off_flags;
+    long long* acc = reinterpret_cast<long long*>(ws + pl.off_acc);
+    const int clog = sg_clog(c.n);
+    if (hipMemsetAsync(hdr, 0, sizeof(SgHeader), s) != hipSuccess) return -1;
+    const unsigned g1 = (unsigned)min64(ceil_div64(c.n, 256), 4096);
+#define SG_ABSMAX(I) hipLaunchKernelGGL((spc_grad_absmax_kernel<I>), dim3(g1), dim3(256), 0, s, c.coords, (const I*)c.cells,   \
+                                        c.cell_stride, c.spv, c.points, ml, c.grad_out, c.n, c.num_lods, c.channels, c.sum, hdr)
+    if (c.cells_is_i64) SG_ABSMAX(int64_t); else SG_ABSMAX(int32_t);
+#undef SG_ABSMAX
+    if (c.channels <= 8) {
+        const dim3 grid((unsigned)ceil_div64(c.n, SG_THREADS)), block(SG_THREADS);
+#define SG_MERGE(FF, I) hipLaunchKernelGGL((spc_grad_scatter_merge_kernel<FF, I>), grid, block, 0, s, c.coords, (const I*)c.cells, \
+                                           c.cell_stride, c.spv, c.points, c.trinkets, ml, c.grad_out, c.n, c.num_lods, c.sum, \
+                                           clog, pl.stride, c.direct_stride, hdr, flags, acc)
+#define SG_CASE(FF) case FF: if (c.cells_is_i64) SG_MERGE(FF, int64_t); else SG_MERGE(FF, int32_t); break;
+        switch (c.channels) { SG_CASE(1) SG_CASE(2) SG_CASE(3) SG_CASE(4) SG_CASE(5) SG_CASE(6) SG_CASE(7) SG_CASE(8) }
+#undef SG_CASE
+#undef SG_MERGE
+    } else {
+        const int cpt = c.channels <= 64 ? c.channels : 64;
+        const dim3 grid((unsigned)min64(ceil_div64(c.n, 256 / cpt), 16384)), block(256);
+#define SG_WIDE(I) hipLaunchKernelGGL((spc_grad_scatter_wide_kernel<I>), grid, block, 0, s, c.coords, (const I*)c.cells,         \
+                                      c.cell_stride, c.spv, c.points, c.trinkets, ml, c.grad_out, c.n, c.num_lods, c.channels,  \
+                                      c.sum, clog, pl.stride, c.direct_stride, hdr, flags, acc)
+        if (c.cells_is_i64) SG_WIDE(int64_t); else SG_WIDE(int32_t);
+#undef SG_WIDE
+    }
+    return 0;
+}
+
+static int sg_fill(SgLods& ml, const int32_t* levels, const int64_t* rows, int num_lods) {
+    for (int l = 0; l < SG_MAX_LODS; ++l) {
+        ml.grad[l] = nullptr; ml.logits[l] = nullptr; ml.dict[l] = nullptr; ml.grad_dict[l] = nullptr; ml.level[l] = 0; ml.base[l] = 0;
+    }
+    ml.base[SG_MAX_LODS] = 0;
+    int64_t b = 0;
+    for (int l = 0; l < num_lods; ++l) {
+        if (levels[l] < 0 || levels[l] > 15 || rows[l] < 0) return -1;
+        ml.level[l] = levels[l];
+        ml.base[l] = b;
+        b += rows[l];
+    }
+    for (int l = num_lods; l <= SG_MAX_LODS; ++l) ml.base[l] = b;
+    return 0;
+}
+
+static int spc_bwd_impl(const SgCall& c, const int32_t* levels, const int64_t* rows, float* const* grad_feats, void* workspace,
+                        int64_t workspace_bytes, hipStream_t s) {
+    SgLods ml;
+    if (sg_fill(ml, levels, rows, c.num_lods) != 0) return wisp_fail(WISP_ERR_INVALID, __func__, "bad level or row count");
+    for (int l = 0; l < c.num_lods; ++l) {
+        if (!grad_feats[l]) return wisp_fail(WISP_ERR_INVALID, __func__, "null gradient pointer");
+        ml.grad[l] = grad_feats[l];
+    }
+    const SgPlan pl = sg_plan(ml.base[c.num_lods], c.channels, 0);
+    if (!workspace || workspace_bytes < pl.bytes) return wisp_fail(WISP_ERR_INVALID, __func__, "workspace missing or too small (wisp_spc_bwd_workspace_bytes)");
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    if (sg_scatter(c, ml, pl, ws, s) != 0) return wisp_fail(WISP_ERR_LAUNCH, __func__, "hipMemsetAsync failed");
+    int lpr = 1;
+    while (lpr < c.channels && lpr < 64) lpr <<= 1;
+    const unsigned g3 = (unsigned)min64(ceil_div64(pl.total_rows, 256 / lpr), 8192);
+    if (pl.total_rows > 0)
+        hipLaunchKernelGGL(spc_grad_finalize_kernel, dim3(g3), dim3(256), 0, s, ml, c.num_lods, c.channels, pl.stride, lpr,
+                           sg_clog(c.n), reinterpret_cast<const SgHeader*>(ws), ws + pl.off_flags,
+                           reinterpret_cast<long long*>(ws + pl.off_acc));
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e_));
+    return WISP_OK;
+}
+
+extern "C" int wisp_spc_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
+                                      const int32_t* trinkets, const float* grad_out, int64_t num_voxels,
+                                      int samples_per_voxel, int channels, int level, int64_t num_rows, float* grad_feats,
+                                      void* workspace, int64_t workspace_bytes, wisp_stream_t stream) {
+    WISP_REQUIRE(num_voxels >= 0 && samples_per_voxel >= 1 && channels >= 1 && level >= 0 && level <= 15 && num_rows >= 0, "bad sizes");
+    if (num_voxels == 0) return WISP_OK;
+    WISP_REQUIRE(coords && pidx && points && trinkets && grad_out && grad_feats, "null pointer");
+    WISP_REQUIRE(num_voxels * samples_per_voxel < ((int64_t)1 << 40), "too many samples for one launch");
+    SgCall c{coords, pidx, pidx_is_i64, 1, samples_per_voxel, points, trinkets, grad_out, num_voxels * samples_per_voxel, 1,
+             channels, 1, channels};
+    const int32_t lv[1] = {level};
+    const int64_t rw[1] = {num_rows};
+    float* const gp[1] = {grad_feats};
+    return spc_bwd_impl(c, lv, rw, gp, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int wisp_spc_trilinear_multi_bwd(const float* coords, const int64_t* chain, int64_t chain_stride,
+                                            const int16_t* points, const int32_t* trinkets, const float* grad_out,
+                                            int64_t num_samples, int num_lods, const int32_t* levels, const int64_t* rows,
+                                            int channels, int sum, float* const* grad_feats, void* workspace,
+                                            int64_t workspace_bytes, wisp_stream_t stream) {
+    WISP_REQUIRE(num_samples >= 0 && num_lods >= 1 && num_lods <= SG_MAX_LODS && channels >= 1 && chain_stride >= num_lods, "bad sizes");
+    if (num_samples == 0) return WISP_OK;
+    WISP_REQUIRE(coords && chain && points && trinkets && grad_out && levels && rows && grad_feats, "null pointer");
+    WISP_REQUIRE(num_samples < ((int64_t)1 << 40), "too many samples for one launch");
+    SgCall c{coords, chain, 1, chain_stride, 1, points, trinkets, grad_out, num_samples, num_lods, channels, sum, channels};
+    return spc_bwd_impl(c, levels, rows, grad_feats, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+static int codebook_bwd_impl(const SgCall& c, const int32_t* levels, const int64_t* rows, const float* const* logits,
+                             const float* const* dictionaries, int dict_size, float* const* grad_logits,
+                             float* const* grad_dictionaries, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+    const int K = dict_size, F = c.channels;
+    SgLods ml;
+    if (sg_fill(ml, levels, rows, c.num_lods) != 0) return wisp_fail(WISP_ERR_INVALID, __func__, "bad level or row count");
+    for (int l = 0; l < c.num_lods; ++l) {
+        if (!logits[l] || !dictionaries[l] || !grad_logits[l] || !grad_dictionaries[l])
+            return wisp_fail(WISP_ERR_INVALID, __func__, "null table pointer");
+        ml.grad[l] = grad_logits[l]; ml.logits[l] = logits[l]; ml.dict[l] = dictionaries[l]; ml.grad_dict[l] = grad_dictionaries[l];
+    }
+    const int64_t dict_elems = (int64_t)c.num_lods * K * F;
+    const SgPlan pl = sg_plan(ml.base[c.num_lods], F, dict_elems);
+    if (!workspace || workspace_bytes < pl.bytes) return wisp_fail(WISP_ERR_INVALID, __func__, "workspace missing or too small (wisp_spc_bwd_workspace_bytes)");
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    // (non-finite path: G cannot be scattered into the logits gradient rows - they are K wide - so it goes to the first F
+    //  columns, which is where a non-finite value has to show up for the found-inf check; see the header)
+    if (sg_scatter(c, ml, pl, ws, s) != 0) return wisp_fail(WISP_ERR_LAUNCH, __func__, "hipMemsetAsync failed");
+    const SgHeader* hdr = reinterpret_cast<const SgHeader*>(ws);
+    uint8_t* flags = ws + pl.off_flags;
+    long long* acc = reinterpret_cast<long long*>(ws + pl.off_acc);
+    long long* dict_acc = reinterpret_cast<long long*>(ws + pl.off_dict);
+    const int clog = sg_clog(c.n);
+    // all levels in one launch while their dictionaries (+ fixed-point gradients) fit the default LDS window, else level groups
+    const size_t per_level = (size_t)K * F * 12;
+    int group = (int)(48 * 1024 / per_level);
+    if (group < 1) group = 1;
+    for (int lb = 0; lb < c.num_lods; lb += group) {
+        const int le = lb + group < c.num_lods ? lb + group : c.num_lods;
+        const int64_t nrows = ml.base[le] - ml.base[lb];
+        if (nrows == 0) continue;
+        const unsigned g3 = (unsigned)min64(ceil_div64(nrows, 256), 2048);
+        hipLaunchKernelGGL(codebook_grad_finalize_kernel, dim3(g3), dim3(256), (size_t)(le - lb) * per_level, s, ml, lb, le, K, F,
+                           pl.stride, clog, hdr, flags, acc, dict_acc);
+    }
+    hipLaunchKernelGGL(codebook_dict_flush_kernel, dim3((unsigned)min64(ceil_div64(dict_elems, 256), 64)), dim3(256), 0, s, ml,
+                       c.num_lods, K * F, clog, hdr, dict_acc);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e_));
+    return WISP_OK;
+}
+
+extern "C" int wisp_codebook_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
+                                           const int32_t* trinkets, const float* logits, const float* dictionary,
+                                           const float* grad_out, int64_t num_voxels, int samples_per_voxel, int dict_size,
+                                           int feature_dim, int level, int64_t num_logit_rows, float* grad_logits,
+                                           float* grad_dictionary, void* workspace, int64_t workspace_bytes,
+                                           wisp_stream_t stream) {
+    WISP_REQUIRE(num_voxels >= 0 && samples_per_voxel >= 1 && level >= 0 && level <= 15 && num_logit_rows >= 0, "bad sizes");
+    WISP_REQUIRE(dict_size >= 1 && dict_size <= CB_MAX_K && feature_dim >= 1 && feature_dim <= CB_MAX_F && feature_dim <= dict_size,
+                 "dictionary shape outside the fused kernels (dict_size <= 256, feature_dim <= min(16, dict_size))");
+    if (num_voxels == 0) return WISP_OK;
+    WISP_REQUIRE(coords && pidx && points && trinkets && logits && dictionary && grad_out && grad_logits && grad_dictionary, "null pointer");
+    SgCall c{coords, pidx, pidx_is_i64, 1, samples_per_voxel, points, trinkets, grad_out, num_voxels * samples_per_voxel, 1,
+             feature_dim, 1, dict_size};
+    const int32_t lv[1] = {level};
+    const int64_t rw[1] = {num_logit_rows};
+    const float* const lg[1] = {logits};
+    const float* const dc[1] = {dictionary};
+    float* const gl[1] = {grad_logits};
+    float* const gd[1] = {grad_dictionary};
+    return codebook_bwd_impl(c, lv, rw, lg, dc, dict_size, gl, gd, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int wisp_codebook_trilinear_multi_bwd(const float* coords, const int64_t* chain, int64_t chain_stride,
+                                                 const int16_t* points, const int32_t* trinkets, const float* const* logits,
+                                                 const float* const* dictionaries, const float* grad_out, int64_t num_samples,
+                                                 int num_lods, const int32_t* levels, const int64_t* rows, int dict_size,
+                                                 int feature_dim, int sum, float* const* grad_logits,
+                                                 float* const* grad_dictionaries, void* workspace, int64_t workspace_bytes,
+                                                 wisp_stream_t stream) {
+    WISP_REQUIRE(num_samples >= 0 && num_lods >= 1 && num_lods <= SG_MAX_LODS && chain_stride >= num_lods, "bad sizes");
+    WISP_REQUIRE(dict_size >= 1 && dict_size <= CB_MAX_K && feature_dim >= 1 && feature_dim <= CB_MAX_F && feature_dim <= dict_size,
+                 "dictionary shape outside the fused kernels (dict_size <= 256, feature_dim <= min(16, dict_size))");
+    if (num_samples == 0) return WISP_OK;
+    WISP_REQUIRE(coords && chain && points && trinkets && logits && dictionaries && grad_out && levels && rows && grad_logits
+                 && grad_dictionaries, "null pointer");
+    SgCall c{coords, chain, 1, chain_stride, 1, points, trinkets, grad_out, num_samples, num_lods, feature_dim, sum, dict_size};
+    return codebook_bwd_impl(c, levels, rows, logits, dictionaries, dict_size, grad_logits, grad_dictionaries, workspace,
+                             workspace_bytes, (hipStream_t)stream);
+}

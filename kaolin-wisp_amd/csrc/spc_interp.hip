@@ -70,31 +70,6 @@ spc_trilinear_fwd_kernel(const float* __restrict__ coords, const I* __restrict__
     }
 }
 
-template <typename I>
-__global__ void __launch_bounds__(256)
-spc_trilinear_bwd_kernel(const float* __restrict__ coords, const I* __restrict__ pidx, const int16_t* __restrict__ points,
-                         const int32_t* __restrict__ trinkets, const float* __restrict__ grad_out, int64_t n, int spv,
-                         int channels, int level, float* __restrict__ grad_feats) {
-    const int cpt = channels <= 64 ? channels : 64;
-    const int rows_per_block = blockDim.x / cpt;
-    const int ch0 = threadIdx.x % cpt;
-    const int64_t stride = (int64_t)gridDim.x * rows_per_block;
-    for (int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cpt; i < n * spv; i += stride) {
-        if (threadIdx.x / cpt >= rows_per_block) break;
-        const int64_t v = i / spv;
-        const int64_t p = (int64_t)pidx[v];
-        if (p < 0) continue;
-        float w[8];
-        trilinear_coeffs(coords + i * 3, points + p * 3, level, w);
-        const int32_t* tr = trinkets + p * 8;
-        for (int ch = ch0; ch < channels; ch += cpt) {
-            const float g = grad_out[i * channels + ch];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(grad_feats + (int64_t)tr[j] * channels + ch, g * w[j]);
-        }
-    }
-}
-
 static inline int interp_grid(int64_t rows, int channels) {
     const int cpt = channels <= 64 ? channels : 64;
     const int rpb = 256 / cpt;
@@ -133,26 +108,6 @@ extern "C" int wisp_spc_trilinear_fwd(const float* coords, const void* pidx, int
         if (dtype == WISP_F32) TRI_FWD(float, int32_t); else if (dtype == WISP_F16) TRI_FWD(__half, int32_t); else TRI_FWD(__hip_bfloat16, int32_t);
     }
 #undef TRI_FWD
-    WISP_CHECK_LAUNCH();
-    return WISP_OK;
-}
-
-extern "C" int wisp_spc_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
-                                      const int32_t* trinkets, const float* grad_out, int64_t num_voxels,
-                                      int samples_per_voxel, int channels, int level, float* grad_feats,
-                                      wisp_stream_t stream) {
-    WISP_REQUIRE(num_voxels >= 0 && samples_per_voxel >= 1 && channels >= 1 && level >= 0 && level <= 15, "bad sizes");
-    if (num_voxels == 0) return WISP_OK;
-    WISP_REQUIRE(coords && pidx && points && trinkets && grad_out && grad_feats, "null pointer");
-    const int64_t rows = num_voxels * samples_per_voxel;
-    const dim3 grid(interp_grid(rows, channels)), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    if (pidx_is_i64)
-        hipLaunchKernelGGL(spc_trilinear_bwd_kernel<int64_t>, grid, block, 0, s, coords, (const int64_t*)pidx, points, trinkets,
-                           grad_out, num_voxels, samples_per_voxel, channels, level, grad_feats);
-    else
-        hipLaunchKernelGGL(spc_trilinear_bwd_kernel<int32_t>, grid, block, 0, s, coords, (const int32_t*)pidx, points, trinkets,
-                           grad_out, num_voxels, samples_per_voxel, channels, level, grad_feats);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
@@ -202,33 +157,6 @@ spc_trilinear_multi_fwd_kernel(const float* __restrict__ coords, const int64_t* 
     }
 }
 
-__global__ void __launch_bounds__(256)
-spc_trilinear_multi_bwd_kernel(const float* __restrict__ coords, const int64_t* __restrict__ chain, int64_t chain_stride,
-                               const int16_t* __restrict__ points, const int32_t* __restrict__ trinkets, MultiLod ml,
-                               const float* __restrict__ grad_out, int64_t n, int num_lods, int channels, int sum) {
-    const int cpt = channels <= 64 ? channels : 64;
-    const int rows_per_block = blockDim.x / cpt;
-    const int ch0 = threadIdx.x % cpt;
-    const int64_t stride = (int64_t)gridDim.x * rows_per_block;
-    const int out_row = sum ? channels : num_lods * channels;
-    for (int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cpt; i < n; i += stride) {
-        if (threadIdx.x / cpt >= rows_per_block) break;
-        for (int l = 0; l < num_lods; ++l) {
-            const int64_t p = chain[i * chain_stride + l];
-            if (p < 0) continue;
-            float w[8];
-            trilinear_coeffs(coords + i * 3, points + p * 3, ml.level[l], w);
-            const int32_t* tr = trinkets + p * 8;
-            float* gf = ml.grad[l];
-            for (int ch = ch0; ch < channels; ch += cpt) {
-                const float g = grad_out[i * out_row + (sum ? 0 : l * channels) + ch];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) atomicAdd(gf + (int64_t)tr[j] * channels + ch, g * w[j]);
-            }
-        }
-    }
-}
-
 static int fill_multi(MultiLod& ml, const void* const* feats, float* const* grads, const int32_t* levels, int num_lods) {
     for (int l = 0; l < SPC_MAX_LODS; ++l) { ml.feats[l] = nullptr; ml.grad[l] = nullptr; ml.level[l] = 0; }
     for (int l = 0; l < num_lods; ++l) {
@@ -255,21 +183,6 @@ extern "C" int wisp_spc_trilinear_multi_fwd(const float* coords, const int64_t* 
                                          trinkets, ml, num_samples, num_lods, channels, half_round, sum, out)
     if (dtype == WISP_F32) TRI_MULTI(float); else if (dtype == WISP_F16) TRI_MULTI(__half); else TRI_MULTI(__hip_bfloat16);
 #undef TRI_MULTI
-    WISP_CHECK_LAUNCH();
-    return WISP_OK;
-}
-
-extern "C" int wisp_spc_trilinear_multi_bwd(const float* coords, const int64_t* chain, int64_t chain_stride,
-                                            const int16_t* points, const int32_t* trinkets, const float* grad_out,
-                                            int64_t num_samples, int num_lods, const int32_t* levels, int channels, int sum,
-                                            float* const* grad_feats, wisp_stream_t stream) {
-    WISP_REQUIRE(num_samples >= 0 && num_lods >= 1 && num_lods <= SPC_MAX_LODS && channels >= 1 && chain_stride >= num_lods, "bad sizes");
-    if (num_samples == 0) return WISP_OK;
-    WISP_REQUIRE(coords && chain && points && trinkets && grad_out && levels && grad_feats, "null pointer");
-    MultiLod ml;
-    WISP_REQUIRE(fill_multi(ml, nullptr, grad_feats, levels, num_lods) == 0, "bad level or null gradient pointer");
-    hipLaunchKernelGGL(spc_trilinear_multi_bwd_kernel, dim3(interp_grid(num_samples, channels)), dim3(256), 0, (hipStream_t)stream,
-                       coords, chain, chain_stride, points, trinkets, ml, grad_out, num_samples, num_lods, channels, sum);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
@@ -315,54 +228,6 @@ codebook_trilinear_fwd_kernel(const float* __restrict__ coords, const I* __restr
         }
     }
     for (int f = 0; f < F; ++f) out[i * F + f] = acc[f];
-}
-
-template <typename I>
-__global__ void __launch_bounds__(128)
-codebook_trilinear_bwd_kernel(const float* __restrict__ coords, const I* __restrict__ pidx, const int16_t* __restrict__ points,
-                              const int32_t* __restrict__ trinkets, const float* __restrict__ logits,
-                              const float* __restrict__ dictionary, const float* __restrict__ grad_out, int64_t n, int spv,
-                              int K, int F, int level, float* __restrict__ grad_logits, float* __restrict__ grad_dict) {
-    extern __shared__ float s_gdict[];                                 // [K * F] workgroup-private dictionary gradient
-    for (int e = threadIdx.x; e < K * F; e += blockDim.x) s_gdict[e] = 0.0f;
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t p = (i < n * spv) ? (int64_t)pidx[i / spv] : -1;
-    if (p >= 0) {
-        float w[8], g[CB_MAX_F];
-        trilinear_coeffs(coords + i * 3, points + p * 3, level, w);
-        for (int f = 0; f < F; ++f) g[f] = grad_out[i * F + f];
-        for (int j = 0; j < 8; ++j) {
-            const int64_t r = trinkets[p * 8 + j];
-            const float* row = logits + r * K;
-            int best = 0;
-            float mx = row[0];
-            for (int k = 1; k < K; ++k) { const float v = row[k]; if (v > mx) { mx = v; best = k; } }
-            float denom = 0.0f;
-            for (int k = 0; k < K; ++k) denom += expf(row[k] - mx);
-            const float inv = 1.0f / denom;
-            // dkey_k = dictionary[k] . (w_j g) ;  dlogit_k = p_k (dkey_k - sum_m p_m dkey_m)
-            float dot = 0.0f;
-            for (int k = 0; k < K; ++k) {
-                float dk = 0.0f;
-                for (int f = 0; f < F; ++f) dk += dictionary[(int64_t)k * F + f] * g[f];
-                dot += expf(row[k] - mx) * inv * dk * w[j];
-            }
-            for (int k = 0; k < K; ++k) {
-                float dk = 0.0f;
-                for (int f = 0; f < F; ++f) dk += dictionary[(int64_t)k * F + f] * g[f];
-                const float pk = expf(row[k] - mx) * inv;
-                atomicAdd(grad_logits + r * K + k, pk * (dk * w[j] - dot));
-            }
-            const float scale = (1.0f - inv) + inv;                    // forward value of the argmax key
-            for (int f = 0; f < F; ++f) atomicAdd(&s_gdict[best * F + f], g[f] * w[j] * scale);
-        }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < K * F; e += blockDim.x) {
-        const float v = s_gdict[e];
-        if (v != 0.0f) atomicAdd(grad_dict + e, v);
-    }
 }
 
 extern "C" int wisp_codebook_trilinear_fwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
@@ -418,189 +283,6 @@ extern "C" int wisp_codebook_decode_rows(const float* logits, const float* dicti
     WISP_REQUIRE(logits && dictionary && decoded, "null pointer");
     hipLaunchKernelGGL(codebook_decode_rows_kernel, dim3((unsigned)ceil_div64(num_rows, 256)), dim3(256), 0, (hipStream_t)stream,
                        logits, dictionary, num_rows, dict_size, feature_dim, training, decoded);
-    WISP_CHECK_LAUNCH();
-    return WISP_OK;
-}
-
-// ---- two-pass backward (the path taken whenever dict_size >= feature_dim).  Everything the backward needs from a sample
-// is LINEAR in  G[row] = sum over the (sample, corner) pairs that hit logits row `row` of  w_corner * grad_out :
-//     d logits[row, k] = p_k (D_k . G - sum_m p_m D_m . G),      d dictionary[argmax(row)] += scale(row) * G
-// so pass 1 only scatters G (F atomics per corner instead of 2^bw, and - samples of one voxel being consecutive in every
-// march mode - after a segmented sum over the lanes that share the voxel: one scatter per run of samples, not per sample)
-// and pass 2 visits every logits row ONCE, without atomics on the logits.  The one-pass kernel above issued
-// 8 * 2^bw global float atomics per sample: 2.7e8 per level at 2 M samples, i.e. 9.4 ms per level on MI355X, whose
-// memory-side atomic units retire ~1.8e10 /s; this pair takes ~0.4 ms.  G is accumulated in the first F floats of each
-// grad_logits row (zero on entry), which pass 2 overwrites with the row's gradient.
-#define CG_THREADS 128
-template <int F, typename I>
-__global__ void __launch_bounds__(CG_THREADS)
-codebook_corner_grad_kernel(const float* __restrict__ coords, const I* __restrict__ pidx, const int16_t* __restrict__ points,
-                            const int32_t* __restrict__ trinkets, const float* __restrict__ grad_out, int64_t n, int spv, int K,
-                            int level, float* __restrict__ grad_logits) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool in = i < n * spv;
-    const int64_t p = in ? (int64_t)pidx[i / spv] : -1;
-    float v[8][F];
-    if (p >= 0) {
-        float w[8], g[F];
-        trilinear_coeffs(coords + i * 3, points + p * 3, level, w);
-#pragma unroll
-        for (int f = 0; f < F; ++f) g[f] = grad_out[i * F + f];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int f = 0; f < F; ++f) v[j][f] = w[j] * g[f];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int f = 0; f < F; ++f) v[j][f] = 0.0f;
-    }
-    // segmented inclusive sum over the wave, runs = consecutive lanes with the same voxel (invalid lanes are their own run)
-    const int64_t key = p >= 0 ? p : -1 - lane;
-    const int64_t prev = __shfl_up(key, 1, 64), next = __shfl_down(key, 1, 64);
-    int head = (lane == 0 || prev != key) ? 1 : 0;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int hp = __shfl_up(head, d, 64);
-        const bool take = lane >= d && !head;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const float t = __shfl_up(v[j][f], d, 64);
-                if (take) v[j][f] += t;
-            }
-        if (take) head |= hp;
-    }
-    // The run tails hold the run totals: 8 corners x F floats each, F consecutive floats per logits row.  Issued from the tail
-    // lanes that is 8 F atomic instructions with a handful of live lanes each, every lane on its own 64-byte row.  Instead the
-    // tails park their totals in the wave's LDS slice and ALL lanes walk the (tail, corner, feature) items, feature fastest:
-    // the F atomics of a row sit in neighbouring lanes of ONE instruction (one memory-side request per row instead of F), and
-    // a wave issues ceil(tails * 8 F / 64) atomic instructions instead of 8 F.
-    const bool tail = p >= 0 && (lane == 63 || next != key);
-    const uint64_t tmask = __ballot(tail);
-    if (tmask == 0) return;                                               // (wave-uniform)
-    __shared__ float s_val[CG_THREADS / 64][64][8 * F];
-    __shared__ int32_t s_row[CG_THREADS / 64][64][8];
-    const int wv = threadIdx.x >> 6;
-    if (tail) {
-        const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            s_row[wv][rank][j] = trinkets[p * 8 + j];
-#pragma unroll
-            for (int f = 0; f < F; ++f) s_val[wv][rank][j * F + f] = v[j][f];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int items = __popcll(tmask) * 8 * F;
-    for (int it = lane; it < items; it += 64) {
-        const int rank = it / (8 * F), rem = it - rank * (8 * F);
-        const int j = rem / F, f = rem - j * F;
-        atomicAdd(grad_logits + (int64_t)s_row[wv][rank][j] * K + f, s_val[wv][rank][rem]);
-    }
-}
-
-template <int F>
-__global__ void __launch_bounds__(256)
-codebook_logit_grad_kernel(const float* __restrict__ logits, const float* __restrict__ dictionary, int64_t rows, int K,
-                           float* __restrict__ grad_logits, float* __restrict__ grad_dict) {
-    extern __shared__ float s_cb[];                                    // [K * F] dictionary, [K * F] its gradient
-    float* s_dict = s_cb;
-    float* s_gdict = s_cb + K * F;
-    for (int e = threadIdx.x; e < K * F; e += blockDim.x) { s_dict[e] = dictionary[e]; s_gdict[e] = 0.0f; }
-    __syncthreads();
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
-        float* grow = grad_logits + r * K;
-        float G[F];
-        bool any = false;
-#pragma unroll
-        for (int f = 0; f < F; ++f) { G[f] = grow[f]; any |= G[f] != 0.0f; }
-        if (!any) continue;                                            // untouched row: its gradient is the zero it holds
-        const float* row = logits + r * K;
-        int best = 0;
-        float mx = row[0];
-        for (int k = 1; k < K; ++k) { const float x = row[k]; if (x > mx) { mx = x; best = k; } }
-        float denom = 0.0f;
-        for (int k = 0; k < K; ++k) denom += expf(row[k] - mx);
-        const float inv = 1.0f / denom;
-        float dot = 0.0f;
-        for (int k = 0; k < K; ++k) {
-            float dk = 0.0f;
-#pragma unroll
-            for (int f = 0; f < F; ++f) dk += s_dict[k * F + f] * G[f];
-            dot += expf(row[k] - mx) * inv * dk;
-        }
-        for (int k = 0; k < K; ++k) {
-            float dk = 0.0f;
-#pragma unroll
-            for (int f = 0; f < F; ++f) dk += s_dict[k * F + f] * G[f];
-            grow[k] = expf(row[k] - mx) * inv * (dk - dot);
-        }
-        const float scale = (1.0f - inv) + inv;                        // forward value of the argmax key
-#pragma unroll
-        for (int f = 0; f < F; ++f) atomicAdd(&s_gdict[best * F + f], G[f] * scale);
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < K * F; e += blockDim.x) {
-        const float x = s_gdict[e];
-        if (x != 0.0f) atomicAdd(grad_dict + e, x);
-    }
-}
-
-template <int F>
-static void launch_codebook_bwd2(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
-                                 const int32_t* trinkets, const float* logits, const float* dictionary, const float* grad_out,
-                                 int64_t num_voxels, int spv, int K, int level, int64_t num_rows, float* grad_logits,
-                                 float* grad_dict, hipStream_t s) {
-    const int64_t n = num_voxels * spv;
-    const dim3 grid((unsigned)ceil_div64(n, CG_THREADS)), block(CG_THREADS);
-    if (pidx_is_i64)
-        hipLaunchKernelGGL((codebook_corner_grad_kernel<F, int64_t>), grid, block, 0, s, coords, (const int64_t*)pidx, points,
-                           trinkets, grad_out, num_voxels, spv, K, level, grad_logits);
-    else
-        hipLaunchKernelGGL((codebook_corner_grad_kernel<F, int32_t>), grid, block, 0, s, coords, (const int32_t*)pidx, points,
-                           trinkets, grad_out, num_voxels, spv, K, level, grad_logits);
-    int64_t g2 = ceil_div64(num_rows, 256);
-    if (g2 > 2048) g2 = 2048;
-    hipLaunchKernelGGL((codebook_logit_grad_kernel<F>), dim3((unsigned)g2), dim3(256), (size_t)2 * K * F * 4, s, logits, dictionary,
-                       num_rows, K, grad_logits, grad_dict);
-}
-
-extern "C" int wisp_codebook_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
-                                           const int32_t* trinkets, const float* logits, const float* dictionary,
-                                           const float* grad_out, int64_t num_voxels, int samples_per_voxel, int dict_size,
-                                           int feature_dim, int level, int64_t num_logit_rows, float* grad_logits,
-                                           float* grad_dictionary, wisp_stream_t stream) {
-    WISP_REQUIRE(num_voxels >= 0 && samples_per_voxel >= 1 && level >= 0 && level <= 15 && num_logit_rows >= 0, "bad sizes");
-    WISP_REQUIRE(dict_size >= 1 && dict_size <= CB_MAX_K && feature_dim >= 1 && feature_dim <= CB_MAX_F, "dictionary too large for the fused kernel");
-    if (num_voxels == 0) return WISP_OK;
-    WISP_REQUIRE(coords && pidx && points && trinkets && logits && dictionary && grad_out && grad_logits && grad_dictionary, "null pointer");
-    const int64_t rows = num_voxels * samples_per_voxel;
-    hipStream_t s = (hipStream_t)stream;
-    if (dict_size >= feature_dim && feature_dim <= 8) {
-#define CB_CASE(FF) case FF: launch_codebook_bwd2<FF>(coords, pidx, pidx_is_i64, points, trinkets, logits, dictionary, grad_out, \
-                                                      num_voxels, samples_per_voxel, dict_size, level, num_logit_rows,           \
-                                                      grad_logits, grad_dictionary, s); break;
-        switch (feature_dim) { CB_CASE(1) CB_CASE(2) CB_CASE(3) CB_CASE(4) CB_CASE(5) CB_CASE(6) CB_CASE(7) CB_CASE(8) }
-#undef CB_CASE
-        WISP_CHECK_LAUNCH();
-        return WISP_OK;
-    }
-    const dim3 grid((unsigned)ceil_div64(rows, 128)), block(128);
-    const size_t lds = (size_t)dict_size * feature_dim * 4;
-    if (pidx_is_i64)
-        hipLaunchKernelGGL(codebook_trilinear_bwd_kernel<int64_t>, grid, block, lds, s, coords, (const int64_t*)pidx, points, trinkets,
-                           logits, dictionary, grad_out, num_voxels, samples_per_voxel, dict_size, feature_dim, level, grad_logits,
-                           grad_dictionary);
-    else
-        hipLaunchKernelGGL(codebook_trilinear_bwd_kernel<int32_t>, grid, block, lds, s, coords, (const int32_t*)pidx, points, trinkets,
-                           logits, dictionary, grad_out, num_voxels, samples_per_voxel, dict_size, feature_dim, level, grad_logits,
-                           grad_dictionary);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }

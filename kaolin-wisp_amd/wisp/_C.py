@@ -45,14 +45,17 @@ SIGNATURES = {
     "wisp_spc_raytrace_emit": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp],
     "wisp_spc_trilinear_coeffs": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "wisp_spc_trilinear_fwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
-    "wisp_spc_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp],
+    "wisp_spc_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp],
+    "wisp_spc_bwd_workspace_bytes": [c_i64, c_i32, c_i64],
     "wisp_spc_trilinear_multi_fwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
-    "wisp_spc_trilinear_multi_bwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp],
+    "wisp_spc_trilinear_multi_bwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp],
     "wisp_triplane_fwd": [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_triplane_bwd": [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_codebook_trilinear_fwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_codebook_decode_rows": [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp],
-    "wisp_codebook_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp],
+    "wisp_codebook_trilinear_bwd": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "wisp_codebook_trilinear_multi_bwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp,
+                                          c_vp, c_i64, c_vp],
     "wisp_mark_pack_boundaries_i64": [c_vp, c_i64, c_vp, c_vp],
     "wisp_mark_pack_boundaries_i32": [c_vp, c_i64, c_vp, c_vp],
     "wisp_scan_workspace_bytes": [c_i64],
@@ -100,7 +103,7 @@ SIGNATURES = {
     "wisp_last_error": [],
     "wisp_abi_version": [],
 }
-_RESTYPES = {"wisp_nerf_mlp_bwd_workspace_bytes": c_i64, "wisp_hashgrid_bwd_workspace_bytes": c_i64, "wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_nerf_mlp_workspace_floats": c_i64,
+_RESTYPES = {"wisp_nerf_mlp_bwd_workspace_bytes": c_i64, "wisp_spc_bwd_workspace_bytes": c_i64, "wisp_hashgrid_bwd_workspace_bytes": c_i64, "wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_nerf_mlp_workspace_floats": c_i64,
              "wisp_last_error": ctypes.c_char_p}
 
 for _name, _args in SIGNATURES.items():
@@ -616,14 +619,39 @@ def spc_trilinear_forward(coords, pidx, points, trinkets, feats, level, half_rou
     return out
 
 
-def spc_trilinear_backward(coords, pidx, points, trinkets, grad_out, feats_shape, level):
+_spc_ws = {}
+
+
+def _spc_bwd_workspace(device, total_rows, channels, dict_elems=0):
+    """Scratch of the order-free trilinear / codebook backward (wisp_spc_bwd_workspace_bytes): zero when handed out for the first
+    time and left zero by every call, so one buffer per (device, stream) serves every grid; it only ever grows."""
+    need = int(lib.wisp_spc_bwd_workspace_bytes(total_rows, channels, dict_elems))
+    if need < 0:
+        raise RuntimeError("wisp_spc_bwd_workspace_bytes: bad sizes")
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream().value)
+    ws = _spc_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _spc_ws[key] = torch.zeros(need + need // 4, dtype=torch.uint8, device=device)
+    return ws
+
+
+def _host_i64(values):
+    arr = np.ascontiguousarray(np.asarray(values, dtype=np.int64).reshape(-1))
+    return arr, arr.ctypes.data_as(c_vp)
+
+
+def spc_trilinear_backward(coords, pidx, points, trinkets, grad_out, feats_shape, level, out=None):
+    """-> gradient of the [rows, C] feature tensor (f32), bitwise reproducible.  out: optional f32 tensor it is ADDED to."""
     coords = _need(coords, torch.float32, "coords")
     pidx, is64 = _pidx_arg(pidx)
     grad_out = _need(grad_out, torch.float32, "grad_out")
     V, S, C = coords.shape[0], coords.shape[1], feats_shape[1]
-    grad = torch.zeros(tuple(feats_shape), dtype=torch.float32, device=coords.device)
-    _check(lib.wisp_spc_trilinear_bwd(_p(coords), _p(pidx), is64, _p(points), _p(trinkets), _p(grad_out), V, S, C, level,
-                                      _p(grad), _stream()), "spc_trilinear_bwd")
+    grad = torch.zeros(tuple(feats_shape), dtype=torch.float32, device=coords.device) if out is None else _need(out, torch.float32, "out")
+    assert tuple(grad.shape) == tuple(feats_shape)
+    ws = _spc_bwd_workspace(coords.device, feats_shape[0], C)
+    _check(lib.wisp_spc_trilinear_bwd(_p(coords), _p(pidx), is64, _p(_need(points, torch.int16, "points")),
+                                      _p(_need(trinkets, torch.int32, "trinkets")), _p(grad_out), V, S, C, level, feats_shape[0],
+                                      _p(grad), _p(ws), ws.numel(), _stream()), "spc_trilinear_bwd")
     return grad
 
 
@@ -651,7 +679,8 @@ def spc_trilinear_multi_forward(coords, chain, points, trinkets, feats_list, lev
 
 
 def spc_trilinear_multi_backward(coords, chain, points, trinkets, grad_out, feats_shapes, levels, sum_lods, out=None):
-    """out: optional list of f32 tensors of feats_shapes the corner gradients are ADDED to (e.g. the parameters' .grad)."""
+    """out: optional list of f32 tensors of feats_shapes the corner gradients are ADDED to (e.g. the parameters' .grad).
+    One scatter launch for all levels; bitwise reproducible (64-bit fixed-point corner sums)."""
     coords = _need(coords, torch.float32, "coords")
     grad_out = _need(grad_out, torch.float32, "grad_out")
     N, L, C = coords.shape[0], len(feats_shapes), feats_shapes[0][1]
@@ -662,8 +691,11 @@ def spc_trilinear_multi_backward(coords, chain, points, trinkets, grad_out, feat
         assert len(grads) == L and all(tuple(g.shape) == tuple(sh) for g, sh in zip(grads, feats_shapes))
     garr, gptr = _ptr_array(grads)
     larr, lptr = _host_i32(levels)
-    _check(lib.wisp_spc_trilinear_multi_bwd(_p(coords), _p(chain), chain.stride(0), _p(points), _p(trinkets), _p(grad_out), N, L,
-                                            lptr, C, int(sum_lods), gptr, _stream()), "spc_trilinear_multi_bwd")
+    rarr, rptr = _host_i64([sh[0] for sh in feats_shapes])
+    ws = _spc_bwd_workspace(coords.device, int(rarr.sum()), C)
+    _check(lib.wisp_spc_trilinear_multi_bwd(_p(coords), _p(chain), chain.stride(0), _p(_need(points, torch.int16, "points")),
+                                            _p(_need(trinkets, torch.int32, "trinkets")), _p(grad_out), N, L, lptr, rptr, C,
+                                            int(sum_lods), gptr, _p(ws), ws.numel(), _stream()), "spc_trilinear_multi_bwd")
     return grads
 
 
@@ -730,9 +762,8 @@ def codebook_decode_rows(logits, dictionary, training):
 
 
 def codebook_trilinear_backward(coords, pidx, points, trinkets, logits, dictionary, grad_out, level, out=None):
-    """-> (grad logits, grad dictionary).  out: optional pair of f32 tensors that ARE ZERO (the kernels use the logits gradient as
-    their corner scratch): the result is written there instead of into fresh buffers - e.g. a parameter's .grad right after
-    zero_grad."""
+    """-> (grad logits, grad dictionary), bitwise reproducible.  out: optional pair of f32 tensors the result is ADDED to -
+    e.g. the parameters' .grad."""
     coords = _need(coords, torch.float32, "coords")
     pidx, is64 = _pidx_arg(pidx)
     logits = _need(logits, torch.float32, "logits")
@@ -746,11 +777,41 @@ def codebook_trilinear_backward(coords, pidx, points, trinkets, logits, dictiona
     else:
         g_logits, g_dict = _need(out[0], torch.float32, "out logits"), _need(out[1], torch.float32, "out dictionary")
         assert g_logits.shape == logits.shape and g_dict.shape == dictionary.shape
+    ws = _spc_bwd_workspace(coords.device, logits.shape[0], F, K * F)
     _check(lib.wisp_codebook_trilinear_bwd(_p(coords), _p(pidx), is64, _p(_need(points, torch.int16, "points")),
                                            _p(_need(trinkets, torch.int32, "trinkets")), _p(logits), _p(dictionary), _p(grad_out),
-                                           V, S, K, F, level, logits.shape[0], _p(g_logits), _p(g_dict), _stream()),
-           "codebook_trilinear_bwd")
+                                           V, S, K, F, level, logits.shape[0], _p(g_logits), _p(g_dict), _p(ws), ws.numel(),
+                                           _stream()), "codebook_trilinear_bwd")
     return g_logits, g_dict
+
+
+def codebook_trilinear_multi_backward(coords, chain, points, trinkets, logits_list, dictionaries, grad_out, levels, sum_lods, out=None):
+    """All levels of a CodebookOctreeGrid: coords [N,3], chain i64 [N, >= L], grad_out f32 [N, F] ('sum') or [N, L*F] ->
+    ([grad logits per level], [grad dictionary per level]); out: optional pair of such lists the result is ADDED to."""
+    coords = _need(coords, torch.float32, "coords")
+    grad_out = _need(grad_out, torch.float32, "grad_out")
+    logits_list = [_need(t, torch.float32, "logits") for t in logits_list]
+    dictionaries = [_need(t, torch.float32, "dictionary") for t in dictionaries]
+    N, L = coords.shape[0], len(logits_list)
+    K, F = dictionaries[0].shape
+    assert len(dictionaries) == L and all(tuple(d.shape) == (K, F) for d in dictionaries) and all(t.shape[1] == K for t in logits_list)
+    assert chain.is_cuda and chain.dtype == torch.int64 and chain.stride(-1) == 1 and chain.shape[0] == N and chain.shape[1] >= L
+    if out is None:
+        g_logits = [torch.zeros_like(t) for t in logits_list]
+        g_dicts = [torch.zeros_like(t) for t in dictionaries]
+    else:
+        g_logits = [_need(t, torch.float32, "out logits") for t in out[0]]
+        g_dicts = [_need(t, torch.float32, "out dictionary") for t in out[1]]
+        assert all(a.shape == b.shape for a, b in zip(g_logits, logits_list)) and all(a.shape == b.shape for a, b in zip(g_dicts, dictionaries))
+    larr, lptr = _host_i32(levels)
+    rarr, rptr = _host_i64([t.shape[0] for t in logits_list])
+    arrs = [_ptr_array(x) for x in (logits_list, dictionaries, g_logits, g_dicts)]
+    ws = _spc_bwd_workspace(coords.device, int(rarr.sum()), F, L * K * F)
+    _check(lib.wisp_codebook_trilinear_multi_bwd(_p(coords), _p(chain), chain.stride(0), _p(_need(points, torch.int16, "points")),
+                                                 _p(_need(trinkets, torch.int32, "trinkets")), arrs[0][1], arrs[1][1], _p(grad_out),
+                                                 N, L, lptr, rptr, K, F, int(sum_lods), arrs[2][1], arrs[3][1], _p(ws), ws.numel(),
+                                                 _stream()), "codebook_trilinear_multi_bwd")
+    return g_logits, g_dicts
 
 
 # ------------------------------------------------------------------------------------------------ raymarch

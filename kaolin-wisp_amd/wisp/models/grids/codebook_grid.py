@@ -69,7 +69,7 @@ class CodebookOctreeGrid(OctreeGrid):
         # (under autocast too: the fused op computes in fp32 whatever the ambient autocast dtype - the softmax the
         # reference runs here is an fp32-autocast op as well, codebook_grid.py:117-125)
         if (self.fused and coords.is_cuda and feats.dtype == torch.float32 and feats.ndim == 2
-                and dictionary.shape[0] <= 256 and dictionary.shape[1] <= 16):
+                and dictionary.shape[1] <= dictionary.shape[0] <= 256 and dictionary.shape[1] <= 16):
             return grid_ops.codebook_interpolate_trilinear(coords, pidx, self.blas.points, self.trinkets.int(), feats,
                                                            dictionary, self.active_lods[lod_idx], self.training)
         fs = torch.zeros(batch, num_samples, self.feature_dim, device=coords.device)

@@ -105,7 +105,7 @@ class _DirectNeRFStep:
         launch for all levels forward, gradients written straight into the parameters' .grad); any other grid of the plugin
         surface (TriplanarGrid, 'sum' HashGrid, one-level or 'closest' octree grids) keeps its own `interpolate` - one small
         autograd graph whose backward is seeded with the decoder's input gradient.
-    Results are identical to the modular path (tests/test_gpu_parity.py::test_direct_step_equals_modular_step)."""
+    Results are identical to the modular path (tests/test_gpu_1_selfcheck.py::test_direct_step_equals_modular_step)."""
 
     @staticmethod
     def supports(pipeline):
@@ -193,7 +193,7 @@ class _DirectNeRFStep:
         if type(grid) is OctreeGrid:
             return 'octree' if grid._fusable() else None
         K, F = grid.dictionary[0].shape
-        return 'codebook' if (grid.fused and F <= K <= 256 and F <= 8) else None       # (the two-kernel backward's shapes)
+        return 'codebook' if (grid.fused and F <= K <= 256 and F <= 16) else None      # (the fused kernels' shapes)
 
     def _octree_forward(self, samples):
         """OctreeGrid.interpolate(samples, num_lods - 1) (octree_grid.py:183-219) / CodebookOctreeGrid's (codebook_grid.py:
@@ -234,13 +234,9 @@ class _DirectNeRFStep:
             C.spc_trilinear_multi_backward(samples, chain, grid.blas.points, tr, g_feats, [tuple(f.shape) for f in grid.features[:L]],
                                            levels, summed, out=[f.grad for f in grid.features[:L]])
             return
-        cells = chain[:, :L].t().contiguous()                     # one row of cell indices per level
-        coords = samples.view(-1, 1, 3)
-        for i in range(L):
-            g = g_feats if summed else g_feats[:, i * F:(i + 1) * F].contiguous()
-            C.codebook_trilinear_backward(coords, cells[i], grid.blas.points, tr, grid.features[i].detach(),
-                                          grid.dictionary[i].detach(), g.view(-1, 1, F), levels[i],
-                                          out=(grid.features[i].grad, grid.dictionary[i].grad))
+        C.codebook_trilinear_multi_backward(samples, chain, grid.blas.points, tr, [grid.features[i].detach() for i in range(L)],
+                                            [grid.dictionary[i].detach() for i in range(L)], g_feats, levels, summed,
+                                            out=([grid.features[i].grad for i in range(L)], [grid.dictionary[i].grad for i in range(L)]))
 
     # ---- decoder parameters ------------------------------------------------------------------------------------------
     def _params(self):

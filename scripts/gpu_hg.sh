@@ -2,7 +2,7 @@
 # hash-grid backward A/B on the GPU box: parity tests of the hash grid, then timing of library variants (WISP_HIP_LIB)
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -p no:cacheprovider -k "hashgrid or flagship or stress or spill" > gpurun_out/pytest_hg.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_0_parity.py tests/test_gpu_1_selfcheck.py -m gpu -q --tb=short -p no:cacheprovider -k "hashgrid or flagship or stress or spill" > gpurun_out/pytest_hg.log 2>&1
 echo "pytest exit: $?" >> gpurun_out/pytest_hg.log
 tail -5 gpurun_out/pytest_hg.log
 CS=kaolin-wisp_amd/csrc

@@ -168,7 +168,7 @@ def test_one_fma_cell_formula_equals_reference_kernel_on_1e8_adversarial_coordin
     1.5 M log-uniform magnitudes in [2^-149, 2^-18) incl. denormals, every cell face of every level +- 3 ulp, powers of two,
     +-1 and beyond, plus uniform draws - for all 16 NGP resolutions: the scaled position and its integer cell are IDENTICAL,
     bit for bit, on every pair (so are the eight corner rows, which are integer functions of the cell).  The device side of
-    the claim - the GPU evaluates that fma - is tests/test_gpu_parity.py::test_hashgrid_cells_*."""
+    the claim - the GPU evaluates that fma - is tests/test_gpu_0_parity.py::test_hashgrid_cells_*."""
     import adversarial as adv
     s = np.concatenate([adv.structured_scalars(), adv.random_scalars(1_500_000, 500_000, 100_000, seed=1)])
     pts = adv.points(s, seed=2)
