@@ -205,7 +205,8 @@ int wisp_spc_trilinear_fwd(const float* coords, const void* pidx, int pidx_is_i6
 /* Backward w.r.t. the features: grad_feats f32 [num_rows, channels] is ADDED to.  Order-free: the corner sums are taken in
  * 64-bit fixed point (scaled from the launch's largest product), so the same inputs give the same bits on every run - the
  * reference's float atomics do not.  workspace: wisp_spc_bwd_workspace_bytes(num_rows, channels, 0) bytes of device memory
- * that are ZERO before the first call; every call leaves them zero, so one buffer serves all calls of a stream.
+ * that are ZERO before the first call; every call leaves them zero (but for a 64-byte header it resets itself), so one
+ * buffer serves all calls of a stream.
  * A non-finite grad_out (overflowed loss scale) is scattered with plain float atomics so that inf / NaN reach the gradient. */
 int wisp_spc_trilinear_bwd(const float* coords, const void* pidx, int pidx_is_i64, const int16_t* points,
                            const int32_t* trinkets, const float* grad_out, int64_t num_voxels,

@@ -19,7 +19,8 @@
 //                           logits gradient  p_k (D_k . G - sum_m p_m D_m . G)  and adds scale * G to the dictionary row's
 //                           own fixed-point accumulator (LDS, then workspace), which
 //   4. codebook_dict_flush  converts (one small launch).
-// The workspace (caller-owned, ZERO before its first use) is all zero again when the call returns.
+// The workspace (caller-owned, ZERO before its first use) is all zero again when the call returns - except its 64-byte header,
+// which every call resets itself.
 #include "wisp_common.h"
 
 #define SG_MAX_LODS 16
@@ -72,6 +73,10 @@ static __device__ __forceinline__ void sg_coeffs(const float* __restrict__ c, co
     for (int j = 0; j < 8; ++j) w[j] = ((j & 4) ? f[0] : g[0]) * ((j & 2) ? f[1] : g[1]) * ((j & 1) ? f[2] : g[2]);
 }
 
+template <int CTRL> static __device__ __forceinline__ float sg_dpp(float v) {      // v of the lane the DPP control names
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 static __device__ __forceinline__ uint32_t sg_wave_umax(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -94,7 +99,7 @@ spc_grad_absmax_kernel(const float* __restrict__ coords, const I* __restrict__ c
         uint32_t gsum = 0;
         if (sum)
             for (int c = 0; c < channels; ++c) { const uint32_t b = __float_as_uint(g[c]) & 0x7fffffffu; gsum = b > gsum ? b : gsum; }
-        const I* ch = cells + (i / spv) * cell_stride;
+        const I* ch = cells + (spv == 1 ? i : i / spv) * cell_stride;
         for (int l = 0; l < num_lods; ++l) {
             const int64_t p = (int64_t)ch[l];
             if (p < 0) continue;
@@ -123,7 +128,9 @@ spc_grad_absmax_kernel(const float* __restrict__ coords, const I* __restrict__ c
         }
     }
     best = sg_wave_umax(best);
-    if ((threadIdx.x & 63) == 0 && best != 0) atomicMax(&hdr->absmax_bits, best);
+    // (32 k waves hammering one address cost 0.17 ms; a wave whose maximum is already covered has nothing to say - the plain read
+    //  may be stale, which only costs an atomic that changes nothing)
+    if ((threadIdx.x & 63) == 0 && best > __atomic_load_n(&hdr->absmax_bits, __ATOMIC_RELAXED)) atomicMax(&hdr->absmax_bits, best);
 }
 
 // ---------------------------------------------------------------------------------------------- pass 2: scatter
@@ -156,7 +163,7 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
 #pragma unroll
             for (int f = 0; f < F; ++f) g[f] = grad_out[i * out_row + f];
     }
-    const I* ch = cells + (in ? (i / spv) * cell_stride : 0);
+    const I* ch = cells + (in ? (spv == 1 ? i : i / spv) * cell_stride : 0);
     for (int l = 0; l < num_lods; ++l) {
         const int64_t p = in ? (int64_t)ch[l] : -1;
         float v[8][F];
@@ -176,57 +183,113 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
 #pragma unroll
                 for (int f = 0; f < F; ++f) v[j][f] = 0.0f;
         }
-        // segmented inclusive sum over the wave; runs = consecutive lanes with the same cell (invalid lanes are their own run)
-        const int64_t key = p >= 0 ? p : -1 - lane;
-        const int64_t prev = __shfl_up(key, 1, 64), next = __shfl_down(key, 1, 64);
-        int head = (lane == 0 || prev != key) ? 1 : 0;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int hp = __shfl_up(head, d, 64);
-            const bool take = lane >= d && !head;
+        // Runs.  The 'voxel' march emits 16 samples per cell, so very often every 16-lane row of the wave is ONE cell: then the row
+        // totals come from four DPP butterflies per value (no LDS traffic; every lane of the row ends with the same bits, the
+        // butterfly adds being commutative) and rows that continue the cell of the row before are added up when the totals are
+        // written out.  Anything else - the 'ray' / 'uniform' marches - takes the general segmented scan.
+        const int p32 = (int)p;
+        const bool row_uniform = p32 == __shfl(p32, lane & ~15, 64);
+        float (*sv)[8 * F] = s_val[wv];
+        int32_t (*sr)[8] = s_row[wv];
+        int items;
+        uint32_t tails = 0;                                               // aligned path: per tail 8 bits = last row | rows << 2
+        const bool aligned = __ballot(row_uniform) == ~0ull;
+        if (aligned) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int f = 0; f < F; ++f) {
-                    const float t = __shfl_up(v[j][f], d, 64);
-                    if (take) v[j][f] += t;
+                    float x = v[j][f];
+                    x += sg_dpp<0xB1>(x);                                 // quad_perm [1,0,3,2]
+                    x += sg_dpp<0x4E>(x);                                 // quad_perm [2,3,0,1]
+                    x += sg_dpp<0x141>(x);                                // row_half_mirror
+                    x += sg_dpp<0x140>(x);                                // row_mirror
+                    v[j][f] = x;
                 }
-            if (take) head |= hp;
-        }
-        const bool tail = p >= 0 && (lane == 63 || next != key);
-        const uint64_t tmask = __ballot(tail);
-        if (tmask == 0) continue;                                         // (wave-uniform)
-        if (tail) {
-            const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
+            int k[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                s_row[wv][rank][j] = trinkets[p * 8 + j];
+            for (int r = 0; r < 4; ++r) k[r] = __builtin_amdgcn_readlane(p32, 16 * r + 15);
+            int ntails = 0, len = 0;
 #pragma unroll
-                for (int f = 0; f < F; ++f) s_val[wv][rank][j * F + f] = v[j][f];
+            for (int r = 0; r < 4; ++r) {
+                len = (r > 0 && k[r] == k[r - 1]) ? len + 1 : 1;
+                const bool last = r == 3 || k[r + 1] != k[r];
+                if (k[r] >= 0 && last) { tails |= (uint32_t)(r | (len << 2)) << (8 * ntails); ++ntails; }
             }
+            if (ntails == 0) continue;                                    // (wave-uniform)
+            if ((lane & 15) == 15 && p >= 0) {
+                const int r = lane >> 4;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sr[r][j] = trinkets[p * 8 + j];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) sv[r][j * F + f] = v[j][f];
+                }
+            }
+            items = ntails * 8 * F;
+        } else {
+            // segmented inclusive sum over the wave; runs = consecutive lanes with the same cell (invalid lanes are their own run)
+            const int64_t key = p >= 0 ? p : -1 - lane;
+            const int64_t prev = __shfl_up(key, 1, 64), next = __shfl_down(key, 1, 64);
+            int head = (lane == 0 || prev != key) ? 1 : 0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int hp = __shfl_up(head, d, 64);
+                const bool take = lane >= d && !head;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        const float t = __shfl_up(v[j][f], d, 64);
+                        if (take) v[j][f] += t;
+                    }
+                if (take) head |= hp;
+            }
+            const bool tail = p >= 0 && (lane == 63 || next != key);
+            const uint64_t tmask = __ballot(tail);
+            if (tmask == 0) continue;                                     // (wave-uniform)
+            if (tail) {
+                const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sr[rank][j] = trinkets[p * 8 + j];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) sv[rank][j * F + f] = v[j][f];
+                }
+            }
+            items = __popcll(tmask) * 8 * F;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int items = __popcll(tmask) * 8 * F;
-        if (sc.finite) {
-            const int64_t base = ml.base[l];
-            for (int it = lane; it < items; it += 64) {
-                const int rank = it / (8 * F), rem = it - rank * (8 * F);
-                const int j = rem / F, f = rem - j * F;
-                const int64_t row = base + s_row[wv][rank][j];
-                const long long q = __double2ll_rn((double)s_val[wv][rank][rem] * sc.to_fix);
+        // all lanes walk the (tail, corner, channel) items, channel fastest: the F adds of a row sit in neighbouring lanes of ONE
+        // atomic instruction (the memory side takes them as one request per 64-byte line)
+        const int64_t base = ml.base[l];
+        float* gd = ml.grad[l];
+        for (int it = lane; it < items; it += 64) {
+            const int t = it / (8 * F), rem = it - t * (8 * F);
+            const int j = rem / F, f = rem - j * F;
+            int slot = t;
+            float total;
+            if (aligned) {
+                const uint32_t info = (tails >> (8 * t)) & 0xffu;
+                slot = (int)(info & 3u);
+                const int rows = (int)(info >> 2);
+                total = sv[slot - rows + 1][rem];
+                for (int q = rows - 2; q >= 0; --q) total += sv[slot - q][rem];          // earliest row first
+            } else {
+                total = sv[t][rem];
+            }
+            const int32_t crow = sr[slot][j];
+            if (sc.finite) {
+                const int64_t row = base + crow;
+                const long long q = __double2ll_rn((double)total * sc.to_fix);
                 atomicAdd(reinterpret_cast<unsigned long long*>(acc + row * stride + f), (unsigned long long)q);
                 if (f == 0) flags[row] = 1;
-            }
-        } else {
-            // a non-finite gradient (an overflowed loss scale): plain float atomics straight into the gradient tensor, so
-            // that inf / NaN arrive where the reference's atomics would put them (the optimizer step is skipped anyway)
-            float* gd = ml.grad[l];
-            for (int it = lane; it < items; it += 64) {
-                const int rank = it / (8 * F), rem = it - rank * (8 * F);
-                const int j = rem / F, f = rem - j * F;
-                atomicAdd(gd + (int64_t)s_row[wv][rank][j] * direct_stride + f, s_val[wv][rank][rem]);
+            } else {
+                // a non-finite gradient (an overflowed loss scale): plain float atomics straight into the gradient tensor, so
+                // that inf / NaN arrive where the reference's atomics would put them (the optimizer step is skipped anyway)
+                atomicAdd(gd + (int64_t)crow * direct_stride + f, total);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -251,7 +314,7 @@ spc_grad_scatter_wide_kernel(const float* __restrict__ coords, const I* __restri
     const int64_t step = (int64_t)gridDim.x * rows_per_block;
     const int out_row = sum ? channels : num_lods * channels;
     for (int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cpt; i < n; i += step) {
-        const I* ch = cells + (i / spv) * cell_stride;
+        const I* ch = cells + (spv == 1 ? i : i / spv) * cell_stride;
         for (int l = 0; l < num_lods; ++l) {
             const int64_t p = (int64_t)ch[l];
             if (p < 0) continue;

@@ -1116,9 +1116,10 @@ def composite_loss(color, density, deltas, ray_offsets, num_rays, bg, gts, kind,
     g_density = torch.empty(S, 1, dtype=torch.float32, device=dev)
     rgb = torch.empty(num_rays, 3, dtype=torch.float32, device=dev) if with_rgb else None
     loss = torch.empty(1, dtype=torch.float32, device=dev)
-    ws = _fused_ws.get(dev)
+    key = (dev, _stream().value)                         # per stream: two trainers on one device must not share the partials
+    ws = _fused_ws.get(key)
     if ws is None or ws.numel() < num_rays:                                                      # one partial sum of the loss per ray
-        ws = _fused_ws[dev] = torch.empty(max(8192, 2 * num_rays), dtype=torch.float32, device=dev)
+        ws = _fused_ws[key] = torch.empty(max(8192, 2 * num_rays), dtype=torch.float32, device=dev)
     bg_arr, bg_ptr = _host_f32(bg)
     _check(lib.wisp_composite_loss(_p(color), _p(density), _p(deltas), _p(ray_offsets), num_rays, S, bg_ptr, _p(gts),
                                    _LOSS_KIND[kind], _p(g_color), _p(g_density), _p(rgb), _p(loss), _p(ws), ws.numel(), _stream()),

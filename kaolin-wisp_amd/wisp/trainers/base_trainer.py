@@ -156,17 +156,19 @@ class _OneViewLoader:
         self.dataset, self.batch_size = dataset, max(int(batch_size), 1)
 
     def __len__(self):
-        return len(self.dataset) // self.batch_size if len(self.dataset) >= self.batch_size else 1
+        # torch's DataLoader with drop_last=False (base_trainer.py:197-203): the partial last batch counts
+        return max(-(-len(self.dataset) // self.batch_size), 1)
 
     def __iter__(self):
+        n = len(self.dataset)
         if self.batch_size > 1 and hasattr(self.dataset, "get_batch"):
             # coordinate datasets (SDF training: 512 points per batch): one indexed read instead of 512 items + a collate
-            order = torch.randperm(len(self.dataset), device=getattr(self.dataset, "device", "cpu"))
-            for i in range(0, len(self) * self.batch_size, self.batch_size):
+            order = torch.randperm(n, device=getattr(self.dataset, "device", "cpu"))
+            for i in range(0, n, self.batch_size):
                 yield self.dataset.get_batch(order[i:i + self.batch_size])
             return
-        order = torch.randperm(len(self.dataset)).tolist()
-        for i in range(0, len(self) * self.batch_size, self.batch_size):
+        order = torch.randperm(n).tolist()
+        for i in range(0, n, self.batch_size):
             items = [self.dataset[j] for j in order[i:i + self.batch_size]]
             yield _collate(items)
 

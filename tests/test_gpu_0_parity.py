@@ -843,7 +843,7 @@ def test_trainer_flat_params_step_matches_unfused_torch_path():
     pipe2 = Pipeline(nef2, PackedRFTracer(raymarch_type='ray', num_steps=96, bg_color=(0, 0, 0)))
     grads = []
     def snap(inner=tr.optimizer_step):                      # the gradients as the fused optimizer is about to see them
-        grads.append({n: p.grad.clone() for n, p in nef.named_parameters()})
+        grads.append({n: p.grad.clone() for n, p in nef.named_parameters() if p.grad is not None})
         inner()
     tr.optimizer_step = snap
     for it in range(3):
@@ -855,6 +855,9 @@ def test_trainer_flat_params_step_matches_unfused_torch_path():
         if it == 0:
             # same parameters on both sides: every gradient agrees to the summation order of the scatter / the GEMMs
             for n, q in nef2.named_parameters():
+                if q.grad is None:
+                    assert n not in grads[0]
+                    continue
                 sc = float(q.grad.abs().max())
                 margin(f"flat_vs_unfused grad {n}", float((grads[0][n] - q.grad).abs().max()), 2e-5 * sc + 1e-12)
         opt.step()
@@ -1047,7 +1050,7 @@ def test_octree_fields_one_launch_backward_matches_oracle(kind, mtype):
         for i in range(L):
             np.testing.assert_allclose((got[i] - 0.25).cpu().numpy(), feats_cpu[i].grad.numpy(), rtol=1e-4, atol=2e-5)
     ws = _C()._spc_bwd_workspace(torch.device(DEV), 1, 1)
-    assert int(ws.count_nonzero()) == 0, "the backward left its scratch dirty"
+    assert int(ws[64:].count_nonzero()) == 0, "the backward left its scratch dirty"     # (the 64-byte header is reset by every call)
 
 
 def test_octree_fields_backward_propagates_non_finite_gradients():
