@@ -50,7 +50,7 @@ struct SgScale { double to_fix, to_float; int finite; int zero; };
 static __device__ __forceinline__ SgScale sg_scale(uint32_t absmax_bits, int clog) {
     SgScale s;
     const int e = (int)(absmax_bits >> 23);
-    s.finite = e != 0xff;
+    s.finite = e < 0xf8;                  // (a sum of 64 such values must stay finite as a float too)
     s.zero = absmax_bits == 0;
     const int E = (e < 1 ? 1 : e) - 127;
     const int sh = 60 - clog - E;                                       // 2^clog adds of < 2^(E+1) each stay below 2^61
@@ -75,6 +75,10 @@ static __device__ __forceinline__ void sg_coeffs(const float* __restrict__ c, co
 
 template <int CTRL> static __device__ __forceinline__ float sg_dpp(float v) {      // v of the lane the DPP control names
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+template <int CTRL> static __device__ __forceinline__ int sg_dpp_i(int v, int fill) {   // lanes without a source lane get `fill`
+    return __builtin_amdgcn_update_dpp(fill, v, CTRL, 0xf, 0xf, false);
 }
 
 static __device__ __forceinline__ uint32_t sg_wave_umax(uint32_t v) {
@@ -148,6 +152,7 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
                               long long* __restrict__ acc) {
     __shared__ float s_val[SG_THREADS / 64][64][8 * F];
     __shared__ int32_t s_row[SG_THREADS / 64][64][8];
+    __shared__ int32_t s_info[SG_THREADS / 64][64];
     const SgScale sc = sg_scale(hdr->absmax_bits, clog);
     if (sc.zero) return;                                                 // every product is zero: nothing to add
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -183,112 +188,79 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
 #pragma unroll
                 for (int f = 0; f < F; ++f) v[j][f] = 0.0f;
         }
-        // Runs.  The 'voxel' march emits 16 samples per cell, so very often every 16-lane row of the wave is ONE cell: then the row
-        // totals come from four DPP butterflies per value (no LDS traffic; every lane of the row ends with the same bits, the
-        // butterfly adds being commutative) and rows that continue the cell of the row before are added up when the totals are
-        // written out.  Anything else - the 'ray' / 'uniform' marches - takes the general segmented scan.
-        const int p32 = (int)p;
-        const bool row_uniform = p32 == __shfl(p32, lane & ~15, 64);
-        float (*sv)[8 * F] = s_val[wv];
-        int32_t (*sr)[8] = s_row[wv];
-        int items;
-        uint32_t tails = 0;                                               // aligned path: per tail 8 bits = last row | rows << 2
-        const bool aligned = __ballot(row_uniform) == ~0ull;
-        if (aligned) {
+        // Runs of consecutive samples in one cell (16 per cell in the 'voxel' march, a few in the 'ray' march, long ones on the
+        // coarse levels) are added up before anything goes to memory.  Inside every 16-lane row: a segmented inclusive scan with
+        // DPP row shifts - no LDS traffic; per step one predicate for all 8 F values, applied as a 0 / 1 factor (x + t * 1 rounds
+        // once, like the add; x + t * 0 is x).  A run that continues across a row boundary leaves a partial total at lane 15;
+        // it is added to the run's final total when the totals are written out (`carry` / `dropped` below).  Same lanes, same
+        // order of adds every time: the float part of the sum is repeatable, the rest is integer.
+        const int lane16 = lane & 15;
+        const int key = p >= 0 ? (int)p : -1 - lane;                      // (invalid lanes are their own run)
+        const int prev = __shfl_up(key, 1, 64), next = __shfl_down(key, 1, 64);
+        const bool joins = lane > 0 && prev == key;                       // continues the run of the lane before
+        int head = (lane16 == 0 || !joins) ? 1 : 0;
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const float m = head ? 0.0f : 1.0f;
+            int hp;
+            if (step == 0) hp = sg_dpp_i<0x111>(head, 1); else if (step == 1) hp = sg_dpp_i<0x112>(head, 1);
+            else if (step == 2) hp = sg_dpp_i<0x114>(head, 1); else hp = sg_dpp_i<0x118>(head, 1);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int f = 0; f < F; ++f) {
-                    float x = v[j][f];
-                    x += sg_dpp<0xB1>(x);                                 // quad_perm [1,0,3,2]
-                    x += sg_dpp<0x4E>(x);                                 // quad_perm [2,3,0,1]
-                    x += sg_dpp<0x141>(x);                                // row_half_mirror
-                    x += sg_dpp<0x140>(x);                                // row_mirror
-                    v[j][f] = x;
+                    float t;
+                    if (step == 0) t = sg_dpp<0x111>(v[j][f]); else if (step == 1) t = sg_dpp<0x112>(v[j][f]);      // row_shr:1, :2
+                    else if (step == 2) t = sg_dpp<0x114>(v[j][f]); else t = sg_dpp<0x118>(v[j][f]);                // row_shr:4, :8
+                    v[j][f] = __builtin_fmaf(t, m, v[j][f]);
                 }
-            int k[4];
+            head |= hp;
+        }
+        const bool tail = p >= 0 && (lane16 == 15 || next != key);
+        const uint64_t tmask = __ballot(tail);
+        if (tmask == 0) continue;                                         // (wave-uniform)
+        const uint64_t cont = __ballot(joins && lane16 == 0);            // bit 16 r: row r starts inside the run row r-1 ended with
+        float (*sv)[8 * F] = s_val[wv];
+        int32_t (*sr)[8] = s_row[wv];
+        if (tail) {
+            const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
+            const int row0 = lane & ~15;
+            const bool first_in_row = ((tmask >> row0) & ((1ull << lane16) - 1ull)) == 0;
+            const bool carry = first_in_row && ((cont >> row0) & 1ull);                       // add the total parked by the tail before
+            const bool dropped = lane16 == 15 && lane < 63 && ((cont >> (row0 + 16)) & 1ull);  // a partial total: parked, not written out
+            s_info[wv][rank] = (carry ? 1 : 0) | (dropped ? 2 : 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) k[r] = __builtin_amdgcn_readlane(p32, 16 * r + 15);
-            int ntails = 0, len = 0;
+            for (int j = 0; j < 8; ++j) {
+                sr[rank][j] = trinkets[p * 8 + j];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                len = (r > 0 && k[r] == k[r - 1]) ? len + 1 : 1;
-                const bool last = r == 3 || k[r + 1] != k[r];
-                if (k[r] >= 0 && last) { tails |= (uint32_t)(r | (len << 2)) << (8 * ntails); ++ntails; }
+                for (int f = 0; f < F; ++f) sv[rank][j * F + f] = v[j][f];
             }
-            if (ntails == 0) continue;                                    // (wave-uniform)
-            if ((lane & 15) == 15 && p >= 0) {
-                const int r = lane >> 4;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    sr[r][j] = trinkets[p * 8 + j];
-#pragma unroll
-                    for (int f = 0; f < F; ++f) sv[r][j * F + f] = v[j][f];
-                }
-            }
-            items = ntails * 8 * F;
-        } else {
-            // segmented inclusive sum over the wave; runs = consecutive lanes with the same cell (invalid lanes are their own run)
-            const int64_t key = p >= 0 ? p : -1 - lane;
-            const int64_t prev = __shfl_up(key, 1, 64), next = __shfl_down(key, 1, 64);
-            int head = (lane == 0 || prev != key) ? 1 : 0;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int hp = __shfl_up(head, d, 64);
-                const bool take = lane >= d && !head;
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-#pragma unroll
-                    for (int f = 0; f < F; ++f) {
-                        const float t = __shfl_up(v[j][f], d, 64);
-                        if (take) v[j][f] += t;
-                    }
-                if (take) head |= hp;
-            }
-            const bool tail = p >= 0 && (lane == 63 || next != key);
-            const uint64_t tmask = __ballot(tail);
-            if (tmask == 0) continue;                                     // (wave-uniform)
-            if (tail) {
-                const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    sr[rank][j] = trinkets[p * 8 + j];
-#pragma unroll
-                    for (int f = 0; f < F; ++f) sv[rank][j * F + f] = v[j][f];
-                }
-            }
-            items = __popcll(tmask) * 8 * F;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // all lanes walk the (tail, corner, channel) items, channel fastest: the F adds of a row sit in neighbouring lanes of ONE
         // atomic instruction (the memory side takes them as one request per 64-byte line)
+        const int items = __popcll(tmask) * 8 * F;
         const int64_t base = ml.base[l];
         float* gd = ml.grad[l];
         for (int it = lane; it < items; it += 64) {
             const int t = it / (8 * F), rem = it - t * (8 * F);
             const int j = rem / F, f = rem - j * F;
-            int slot = t;
-            float total;
-            if (aligned) {
-                const uint32_t info = (tails >> (8 * t)) & 0xffu;
-                slot = (int)(info & 3u);
-                const int rows = (int)(info >> 2);
-                total = sv[slot - rows + 1][rem];
-                for (int q = rows - 2; q >= 0; --q) total += sv[slot - q][rem];          // earliest row first
-            } else {
-                total = sv[t][rem];
-            }
-            const int32_t crow = sr[slot][j];
+            int info = s_info[wv][t];
+            if (info & 2) continue;
+            float total = sv[t][rem];
+            for (int k = t; info & 1;) { --k; total += sv[k][rem]; info = s_info[wv][k]; }
+            const int32_t crow = sr[t][j];
             if (sc.finite) {
                 const int64_t row = base + crow;
                 const long long q = __double2ll_rn((double)total * sc.to_fix);
                 atomicAdd(reinterpret_cast<unsigned long long*>(acc + row * stride + f), (unsigned long long)q);
                 if (f == 0) flags[row] = 1;
             } else {
-                // a non-finite gradient (an overflowed loss scale): plain float atomics straight into the gradient tensor, so
-                // that inf / NaN arrive where the reference's atomics would put them (the optimizer step is skipped anyway)
+                // a non-finite (or nearly overflowing) gradient: plain float atomics straight into the gradient tensor, so that
+                // inf / NaN arrive where the reference's atomics would put them (the optimizer step is skipped anyway; the 0 / 1
+                // factors of the scan may have turned further lanes into NaN, which changes nothing about that)
                 atomicAdd(gd + (int64_t)crow * direct_stride + f, total);
             }
         }
