@@ -256,7 +256,7 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
                 const int64_t row = base + crow;
                 const long long q = __double2ll_rn((double)total * sc.to_fix);
                 atomicAdd(reinterpret_cast<unsigned long long*>(acc + row * stride + f), (unsigned long long)q);
-                if (f == 0) flags[row] = 1;
+                if (flags && f == 0) flags[row] = 1;
             } else {
                 // a non-finite (or nearly overflowing) gradient: plain float atomics straight into the gradient tensor, so that
                 // inf / NaN arrive where the reference's atomics would put them (the optimizer step is skipped anyway; the 0 / 1
@@ -301,7 +301,7 @@ spc_grad_scatter_wide_kernel(const float* __restrict__ coords, const I* __restri
                         const int64_t row = ml.base[l] + tr[j];
                         const long long q = __double2ll_rn((double)(g * w[j]) * sc.to_fix);
                         atomicAdd(reinterpret_cast<unsigned long long*>(acc + row * stride + c), (unsigned long long)q);
-                        if (c == 0) flags[row] = 1;
+                        if (flags && c == 0) flags[row] = 1;
                     }
                 } else {
 #pragma unroll
@@ -326,7 +326,7 @@ spc_grad_finalize_kernel(SgLods ml, int num_lods, int channels, int stride, int 
     const int64_t total = ml.base[num_lods];
     const int rpb = blockDim.x / lpr, lane = threadIdx.x % lpr;
     for (int64_t row = (int64_t)blockIdx.x * rpb + threadIdx.x / lpr; row < total; row += (int64_t)gridDim.x * rpb) {
-        if (!flags[row]) continue;                                       // (all lanes of a row sit in one wave: read before the clear)
+        if (flags && !flags[row]) continue;                              // (all lanes of a row sit in one wave: read before the clear)
         const int l = sg_level_of(ml, num_lods, row);
         float* gd = ml.grad[l] + (row - ml.base[l]) * channels;
         long long* a = acc + row * stride;
@@ -334,7 +334,7 @@ spc_grad_finalize_kernel(SgLods ml, int num_lods, int channels, int stride, int 
             const long long q = a[c];
             if (q != 0) { gd[c] += (float)((double)q * sc.to_float); a[c] = 0; }
         }
-        if (lane == 0) flags[row] = 0;
+        if (flags && lane == 0) flags[row] = 0;
     }
 }
 
@@ -356,12 +356,19 @@ codebook_grad_finalize_kernel(SgLods ml, int lod_begin, int lod_end, int K, int 
     const SgScale sc = sg_scale(hdr->absmax_bits, clog);
     const int64_t first = ml.base[lod_begin], last = ml.base[lod_end];
     for (int64_t row = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < last; row += (int64_t)gridDim.x * blockDim.x) {
-        if (!flags[row]) continue;
-        flags[row] = 0;
+        long long* a = acc + row * stride;
+        if (flags) {
+            if (!flags[row]) continue;
+            flags[row] = 0;
+        } else {
+            bool any = false;
+#pragma unroll
+            for (int f = 0; f < CB_MAX_F; ++f) if (f < F) any |= a[f] != 0;
+            if (!any) continue;                                          // untouched (or cancelled to exactly zero: nothing to add)
+        }
         int l = lod_begin;
         while (l + 1 < lod_end && row >= ml.base[l + 1]) ++l;
         const int64_t r = row - ml.base[l];
-        long long* a = acc + row * stride;
         long long q[CB_MAX_F];                                           // (constant trip counts + guards: these stay in registers)
         float G[CB_MAX_F];
 #pragma unroll
@@ -447,10 +454,15 @@ struct SgCall {
     int direct_stride;                                                    // row stride of the gradient tensors (non-finite path)
 };
 
+// Touched-row flags (one byte store per scattered row, one byte read per table row in pass 3) pay off when a launch reaches a
+// small part of a big table - NGLOD's 512 coordinates in a million rows; when most rows are touched anyway (a 2 M-sample NeRF
+// batch over 0.2 M rows) pass 3 reads the accumulators themselves and pass 2 saves its 2.5 M scattered byte stores.
+static bool sg_use_flags(const SgCall& c, const SgPlan& pl) { return c.n * 8 * c.num_lods < pl.total_rows; }
+
 // passes 1 and 2
 static int sg_scatter(const SgCall& c, const SgLods& ml, const SgPlan& pl, unsigned char* ws, hipStream_t s) {
     SgHeader* hdr = reinterpret_cast<SgHeader*>(ws);
-    uint8_t* flags = ws + pl.off_flags;
+    uint8_t* flags = sg_use_flags(c, pl) ? ws + pl.off_flags : nullptr;
     long long* acc = reinterpret_cast<long long*>(ws + pl.off_acc);
     const int clog = sg_clog(c.n);
     if (hipMemsetAsync(hdr, 0, sizeof(SgHeader), s) != hipSuccess) return -1;
@@ -513,7 +525,7 @@ static int spc_bwd_impl(const SgCall& c, const int32_t* levels, const int64_t* r
     const unsigned g3 = (unsigned)min64(ceil_div64(pl.total_rows, 256 / lpr), 8192);
     if (pl.total_rows > 0)
         hipLaunchKernelGGL(spc_grad_finalize_kernel, dim3(g3), dim3(256), 0, s, ml, c.num_lods, c.channels, pl.stride, lpr,
-                           sg_clog(c.n), reinterpret_cast<const SgHeader*>(ws), ws + pl.off_flags,
+                           sg_clog(c.n), reinterpret_cast<const SgHeader*>(ws), sg_use_flags(c, pl) ? ws + pl.off_flags : nullptr,
                            reinterpret_cast<long long*>(ws + pl.off_acc));
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e_));
@@ -568,7 +580,7 @@ static int codebook_bwd_impl(const SgCall& c, const int32_t* levels, const int64
     //  columns, which is where a non-finite value has to show up for the found-inf check; see the header)
     if (sg_scatter(c, ml, pl, ws, s) != 0) return wisp_fail(WISP_ERR_LAUNCH, __func__, "hipMemsetAsync failed");
     const SgHeader* hdr = reinterpret_cast<const SgHeader*>(ws);
-    uint8_t* flags = ws + pl.off_flags;
+    uint8_t* flags = sg_use_flags(c, pl) ? ws + pl.off_flags : nullptr;
     long long* acc = reinterpret_cast<long long*>(ws + pl.off_acc);
     long long* dict_acc = reinterpret_cast<long long*>(ws + pl.off_dict);
     const int clog = sg_clog(c.n);
