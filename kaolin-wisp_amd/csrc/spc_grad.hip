@@ -216,7 +216,11 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
                 }
             head |= hp;
         }
+#ifdef SG_EXP_FEWTAILS
+        const bool tail = p >= 0 && lane == 63;
+#else
         const bool tail = p >= 0 && (lane16 == 15 || next != key);
+#endif
         const uint64_t tmask = __ballot(tail);
         if (tmask == 0) continue;                                         // (wave-uniform)
         const uint64_t cont = __ballot(joins && lane16 == 0);            // bit 16 r: row r starts inside the run row r-1 ended with
@@ -255,7 +259,11 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
             if (sc.finite) {
                 const int64_t row = base + crow;
                 const long long q = __double2ll_rn((double)total * sc.to_fix);
+#ifdef SG_EXP_NOATOMIC
+                if (q == 0x7fffffffffffffffll) acc[row * stride + f] = q;
+#else
                 atomicAdd(reinterpret_cast<unsigned long long*>(acc + row * stride + f), (unsigned long long)q);
+#endif
                 if (flags && f == 0) flags[row] = 1;
             } else {
                 // a non-finite (or nearly overflowing) gradient: plain float atomics straight into the gradient tensor, so that
@@ -340,6 +348,7 @@ spc_grad_finalize_kernel(SgLods ml, int num_lods, int channels, int stride, int 
 
 // Codebook: one thread per logits row.  d logits[row, k] = p_k (D_k . G - sum_m p_m D_m . G); d dictionary[argmax] += scale G
 // with scale = (1 - p) + p, the forward value of the straight-through key (codebook_grid.py:117-125).
+template <int KR>
 __global__ void __launch_bounds__(256)
 codebook_grad_finalize_kernel(SgLods ml, int lod_begin, int lod_end, int K, int F, int stride, int clog,
                               const SgHeader* __restrict__ hdr, uint8_t* __restrict__ flags, long long* __restrict__ acc,
@@ -380,23 +389,60 @@ codebook_grad_finalize_kernel(SgLods ml, int lod_begin, int lod_end, int K, int 
         float* grow = ml.grad[l] + r * K;
         const float* D = s_dict + (size_t)(l - lod_begin) * K * F;
         int best = 0;
-        float mx = lrow[0];
-        for (int k = 1; k < K; ++k) { const float x = lrow[k]; if (x > mx) { mx = x; best = k; } }   // first max wins (torch.max)
-        float denom = 0.0f;
-        for (int k = 0; k < K; ++k) denom += expf(lrow[k] - mx);
-        const float inv = 1.0f / denom;
-        float dot = 0.0f;
-        for (int k = 0; k < K; ++k) {
-            float dk = 0.0f;
+        float inv;
+        if (KR > 0) {
+            // the row in registers (K <= KR, a multiple of four: 16-byte loads), every exponential and dictionary product once
+            float x[KR > 0 ? KR : 1], e[KR > 0 ? KR : 1];
 #pragma unroll
-            for (int f = 0; f < CB_MAX_F; ++f) if (f < F) dk += D[k * F + f] * G[f];
-            dot += expf(lrow[k] - mx) * inv * dk;
-        }
-        for (int k = 0; k < K; ++k) {
-            float dk = 0.0f;
+            for (int k4 = 0; k4 < KR; k4 += 4)
+                if (k4 < K) {
+                    const float4 t = *reinterpret_cast<const float4*>(lrow + k4);
+                    x[k4] = t.x; x[k4 + 1] = t.y; x[k4 + 2] = t.z; x[k4 + 3] = t.w;
+                }
+            float mx = x[0];
 #pragma unroll
-            for (int f = 0; f < CB_MAX_F; ++f) if (f < F) dk += D[k * F + f] * G[f];
-            grow[k] += expf(lrow[k] - mx) * inv * (dk - dot);
+            for (int k = 1; k < KR; ++k) if (k < K && x[k] > mx) { mx = x[k]; best = k; }    // first max wins (torch.max)
+            float denom = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KR; ++k) if (k < K) { e[k] = expf(x[k] - mx); denom += e[k]; }
+            inv = 1.0f / denom;
+            float dot = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KR; ++k)
+                if (k < K) {
+                    float dk = 0.0f;
+#pragma unroll
+                    for (int f = 0; f < CB_MAX_F; ++f) if (f < F) dk += D[k * F + f] * G[f];
+                    x[k] = dk;
+                    dot += e[k] * inv * dk;
+                }
+#pragma unroll
+            for (int k4 = 0; k4 < KR; k4 += 4)
+                if (k4 < K) {
+                    float4 t = *reinterpret_cast<float4*>(grow + k4);
+                    t.x += e[k4] * inv * (x[k4] - dot); t.y += e[k4 + 1] * inv * (x[k4 + 1] - dot);
+                    t.z += e[k4 + 2] * inv * (x[k4 + 2] - dot); t.w += e[k4 + 3] * inv * (x[k4 + 3] - dot);
+                    *reinterpret_cast<float4*>(grow + k4) = t;
+                }
+        } else {
+            float mx = lrow[0];
+            for (int k = 1; k < K; ++k) { const float x = lrow[k]; if (x > mx) { mx = x; best = k; } }   // first max wins (torch.max)
+            float denom = 0.0f;
+            for (int k = 0; k < K; ++k) denom += expf(lrow[k] - mx);
+            inv = 1.0f / denom;
+            float dot = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                float dk = 0.0f;
+#pragma unroll
+                for (int f = 0; f < CB_MAX_F; ++f) if (f < F) dk += D[k * F + f] * G[f];
+                dot += expf(lrow[k] - mx) * inv * dk;
+            }
+            for (int k = 0; k < K; ++k) {
+                float dk = 0.0f;
+#pragma unroll
+                for (int f = 0; f < CB_MAX_F; ++f) if (f < F) dk += D[k * F + f] * G[f];
+                grow[k] += expf(lrow[k] - mx) * inv * (dk - dot);
+            }
         }
         const double scale = (double)((1.0f - inv) + inv);
         long long* sg = s_gdict + ((size_t)(l - lod_begin) * K + best) * F;
@@ -588,13 +634,20 @@ static int codebook_bwd_impl(const SgCall& c, const int32_t* levels, const int64
     const size_t per_level = (size_t)K * F * 12;
     int group = (int)(48 * 1024 / per_level);
     if (group < 1) group = 1;
+    bool rows16 = true;                                                   // 16-byte loads of the logits rows need aligned tensors
+    for (int l = 0; l < c.num_lods; ++l)
+        rows16 = rows16 && ((reinterpret_cast<uintptr_t>(logits[l]) | reinterpret_cast<uintptr_t>(grad_logits[l])) & 15) == 0;
     for (int lb = 0; lb < c.num_lods; lb += group) {
         const int le = lb + group < c.num_lods ? lb + group : c.num_lods;
         const int64_t nrows = ml.base[le] - ml.base[lb];
         if (nrows == 0) continue;
         const unsigned g3 = (unsigned)min64(ceil_div64(nrows, 256), 2048);
-        hipLaunchKernelGGL(codebook_grad_finalize_kernel, dim3(g3), dim3(256), (size_t)(le - lb) * per_level, s, ml, lb, le, K, F,
-                           pl.stride, clog, hdr, flags, acc, dict_acc);
+        if (K % 4 == 0 && K <= 16 && rows16)
+            hipLaunchKernelGGL(codebook_grad_finalize_kernel<16>, dim3(g3), dim3(256), (size_t)(le - lb) * per_level, s, ml, lb, le, K, F,
+                               pl.stride, clog, hdr, flags, acc, dict_acc);
+        else
+            hipLaunchKernelGGL(codebook_grad_finalize_kernel<0>, dim3(g3), dim3(256), (size_t)(le - lb) * per_level, s, ml, lb, le, K, F,
+                               pl.stride, clog, hdr, flags, acc, dict_acc);
     }
     hipLaunchKernelGGL(codebook_dict_flush_kernel, dim3((unsigned)min64(ceil_div64(dict_elems, 256), 64)), dim3(256), 0, s, ml,
                        c.num_lods, K * F, clog, hdr, dict_acc);
