@@ -33,11 +33,12 @@ def _kernel_table(sink):
 
 
 def _busy_union_ms(sink):
-    """GPU-busy time of the event-bracketed launches as the UNION of their intervals: launches on side streams (look-ahead
-    raytrace counts, the optimizer) overlap the main stream's, and a sum of durations counts those stretches twice."""
+    """(GPU-busy ms, span ms) of the event-bracketed launches: busy = the UNION of their intervals - launches on side streams
+    (look-ahead raytrace counts, the optimizer) overlap the main stream's, and a sum of durations counts those stretches twice;
+    span = first launch start .. last launch end of the same pass."""
     pairs = [p for evs in sink.values() for p in evs]
     if not pairs:
-        return 0.0
+        return 0.0, 0.0
     ref = pairs[0][0]                                            # any event: only differences matter
     spans = sorted((ref.elapsed_time(a), ref.elapsed_time(b)) for a, b in pairs)
     busy, cur_s, cur_e = 0.0, spans[0][0], spans[0][1]
@@ -47,7 +48,7 @@ def _busy_union_ms(sink):
             cur_s, cur_e = s0, e0
         else:
             cur_e = max(cur_e, e0)
-    return busy + (cur_e - cur_s)
+    return busy + (cur_e - cur_s), max(e for _, e in spans) - spans[0][0]
 
 
 def _roofline(kernels, bytes_per_launch, steps):
@@ -131,7 +132,7 @@ def _nerf_run(args, dev, pipe, trainer, bank, steps, warmup, label, metric, byte
     torch.cuda.synchronize()
     sink, C.TIMING_ALL = C.TIMING_ALL, None
     kernels = _kernel_table(sink)
-    busy_ms = _busy_union_ms(sink)
+    busy_ms, span_ms = _busy_union_ms(sink)
     S = samples / steps
     with torch.no_grad():
         eo, ed, ergb = bank_o[:16384], bank_d[:16384], bank_rgb[:16384]
@@ -143,9 +144,10 @@ def _nerf_run(args, dev, pipe, trainer, bank, steps, warmup, label, metric, byte
             "config": {"workload": label, "rays_per_step_per_gpu": R, "samples_per_ray": S / R, "samples_per_step": S,
                        "pretrain_steps": args.pretrain},
             "samples_per_sec": samples / elapsed, "psnr_db_train_rays": psnr,
-            # union of the launch intervals of the event-timed pass over that pass's own span (<= 1 by construction)
-            "gpu_busy_fraction": min(1.0, busy_ms / psteps / (1e3 * elapsed / steps)),
-            "gpu_busy_note": "union of launch intervals per step (event-timed pass) / ms_per_step (timed pass without events)",
+            "gpu_busy_fraction": busy_ms / span_ms if span_ms > 0 else None,
+            "gpu_busy_note": "union of the launch intervals of the event-timed pass / that pass's own span, first launch to last (<= 1 by "
+                             "construction; the pair of event markers around every launch is inside the span, so this is a lower bound "
+                             "of the untimed-events steps' busy share)",
             "roofline": _roofline(kernels, bytes_fn(S, R), psteps), "kernels": kernels}
 
 
@@ -339,7 +341,7 @@ def run_nglod(args, dev):
             "render": {"rays": int(o.shape[0]), "ms": 1e3 * render_s, "rays_per_sec": o.shape[0] / render_s,
                        "hit_fraction": float(rb.hit.float().mean()), "marching_steps": 32,
                        "kernels": _kernel_table(rsink)},
-            "gpu_busy_fraction_eager": min(1.0, _busy_union_ms(sink) * 1e-3 / eager_elapsed),
+            "gpu_busy_fraction_eager": min(1.0, _busy_union_ms(sink)[0] * 1e-3 / eager_elapsed),
             "roofline": _latency_roofline(kernels, nglod_bytes, args.steps, 1e3 * elapsed / args.steps), "kernels": kernels}
 
 

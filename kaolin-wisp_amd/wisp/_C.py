@@ -111,6 +111,11 @@ for _name, _args in SIGNATURES.items():
     _fn.argtypes = _args
     _fn.restype = _RESTYPES.get(_name, c_i32)
 
+ABI_VERSION = 4                        # include/wisp_hip.h: wisp_abi_version(); the signatures above are this version's
+if lib.wisp_abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} implements ABI version {lib.wisp_abi_version()}, this binding is written for version "
+                      f"{ABI_VERSION}: rebuild the library (make -C {os.path.dirname(LIB_PATH)})")
+
 
 # Live HIP-event timing of selected kernels (bench.py sets TIMING = {} around its timed region).  Events are
 # recorded on the stream the kernel is launched on (torch's current stream).

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     import wisp._C as C
     assert set(C.SIGNATURES) == declared           # the Python binding covers the whole header, nothing else
-    assert C.lib.wisp_abi_version() == 4
+    assert C.lib.wisp_abi_version() == 4 == C.ABI_VERSION
     assert C.lib.wisp_nerf_mlp_param_count(32, 64, 4) == 3152 + 7107    # decoder sizes of nerf_hash.yaml
 
 
