@@ -446,6 +446,9 @@ template <typename T, int F> struct RecordCodec {
         if constexpr (COMPACT) {
             const uint32_t loc = idx & local_mask;
             uint2 w;
+            // (round to 17 bits.  The add cannot carry out of a NaN's mantissa into the sign: COMPACT records come from 16-bit
+            //  gradients, whose NaN payloads have zero low bits, and products / sums hand a NaN operand's payload on - or
+            //  produce the canonical 0x7fc00000; an inf stays inf)
             w.x = ((__float_as_uint(v[0]) + 0x40u) & ~0x7fu) | (loc & 0x7fu);
             w.y = ((__float_as_uint(v[1]) + 0x40u) & ~0x7fu) | (loc >> 7);
             *reinterpret_cast<uint2*>(dst) = w;
@@ -760,7 +763,8 @@ static int queue_emitter_residency() {
 // bucket is accumulated in 64-bit fixed point: exact, order-independent (bitwise reproducible gradients) and converted to
 // fp32 once per table entry.  The binary point is set PER LAUNCH from the largest record magnitude M the emit workgroups
 // reported (any gradient scale works: a GradScaler's 2^16 ... 2^24 as well as 1e-9 initial tables): with 2^(e-127) <= M <
-// 2^(e-126), values are held in units of 2^-s, s = 165 - e, so that 2^24 records of magnitude M still fit 63 bits
+// 2^(e-126), values are held in units of 2^-s, s = 165 - e (minus one per doubling of the launch beyond 2^21 samples), so that
+// the 2^24 records of magnitude M one entry can receive from 2^21 samples still fit 63 bits
 // (resolution M * 2^-39: finer than the 16-bit mantissa of a compact record by 23 bits, than fp32 accumulation by 15).
 // A non-finite record (an overflowed fp16 gradient under a too-large loss scale) switches the workgroup to plain fp32
 // LDS atomics, which propagate inf / NaN into the table gradient exactly like the reference's float atomics do - the
@@ -899,7 +903,7 @@ template <typename T, int F>
 __global__ void __launch_bounds__(RD_THREADS)
 hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList levels, int chunk_shift, BinLevels bins,
                            uint32_t ntiles, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ records,
-                           float* __restrict__ grad_codebook) {
+                           float* __restrict__ grad_codebook, int extra_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rd_smem[];            // [chunk entries * F] accumulators
     __shared__ uint32_t s_wave_max[RD_THREADS / 64];
     // flattened (level, bucket, split) grid
@@ -922,7 +926,7 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
     for (int w = 1; w < RD_THREADS / 64; ++w) m = max(m, s_wave_max[w]);
     const int e = (int)(m >> 23);                          // biased exponent of the largest magnitude (wave- and block-uniform)
     if (e < 255) {
-        int sh = 165 - e;                                  // see AccFix64
+        int sh = 165 - e - extra_bits;                     // see AccFix64; extra_bits: launches of more than 2^21 samples
         if (sh > 159) sh = 159;                            // 2^(sh - 32) must stay a normal float
         AccFix64 A{reinterpret_cast<unsigned long long*>(rd_smem), __uint_as_float((uint32_t)(sh - 32 + 127) << 23),
                    __longlong_as_double((long long)(1023 - sh) << 52)};
@@ -1149,8 +1153,12 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 8;
     auto rd = hashgrid_bwd_reduce_kernel<T, F>;
     if (const hipError_t e = WISP_ALLOW_LDS(rd, rd_lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
+    // one table entry can receive 2^DIM records per sample: 2^24 at the 2^21 samples the binary point is laid out for; beyond
+    // that the binary point moves up with the sample count so that no sum can leave its 63 bits
+    int extra_bits = 0;
+    while (((int64_t)1 << (21 + extra_bits)) < n) ++extra_bits;
     hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
-                       plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook);
+                       plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook, extra_bits);
     return 0;
 }
 
@@ -1458,8 +1466,16 @@ extern "C" int wisp_hashgrid_bwd_slot_stats(int64_t n, int coord_dim, int dtype,
         if (l * feature_dim < zero_from_col) active.lv[active.n++] = l;
     for (int l = 0; l < num_lods; ++l) { cap_host[l] = 0; base_cap_host[l] = 0; }
     const BinPlan plan = plan_for(n, lv, active, coord_dim, feature_dim, dtype, tsize, num_lods, level_cap_scale);
-    // the launch was binned iff it had a workspace that holds this plan (launch_bwd's test; the LDS limit never binds here)
-    if (!workspace || !plan.ok || plan.count_bytes + plan.record_bytes > workspace_bytes || n < 4096 || active.n == 0) return 1;
+    // the launch was binned iff launch_bwd's own test said so: switches, merge-able shape, a workspace that holds this plan,
+    // the emit kernel's LDS budget
+    bool merge = bwd_merge_enabled() && bwd_bin_enabled() && (feature_dim * (1 << coord_dim) <= 32);
+    for (int l = 0; l < num_lods; ++l)
+        if (lv.res[l] > 65536) merge = false;
+    const int elem = dtype == WISP_F32 ? 4 : 2;
+    const size_t em_lds = ((size_t)plan.total_ranks + 1 + (size_t)EM_TILE * ((num_lods * ((feature_dim * elem) / 4)) | 1)) * 4;
+    if (!merge || em_lds > 150 * 1024 || !workspace || !plan.ok || plan.count_bytes + plan.record_bytes > workspace_bytes || n < 4096 ||
+        active.n == 0)
+        return 1;
     for (int li = 0; li < active.n; ++li) { cap_host[active.lv[li]] = (int32_t)plan.bins.cap[li]; base_cap_host[active.lv[li]] = (int32_t)plan.base_cap[li]; }
     hipStream_t s = (hipStream_t)stream;
     (void)hipMemsetAsync(max_fill, 0, sizeof(uint32_t) * 2 * num_lods, s);

@@ -301,7 +301,7 @@ class _SlotFit:
     memory, never waited for); a later launch picks the result up once the copy has landed: a level whose fullest slot stayed
     below its capacity gets slots of HEADROOM x that fill (as a fraction of the unscaled capacity, which follows the sample
     count), a level that filled a slot completely - it overflowed into the atomic path - gets GROW x its previous size."""
-    CHECK_EVERY, HEADROOM, GROW, FLOOR = 32, 1.35, 1.6, 0.02
+    CHECK_EVERY, HEADROOM, GROW, FLOOR, ADOPT_AFTER = 32, 1.35, 1.6, 0.02, 8
 
     def __init__(self, device, dim, dt, F, res, bitwidth, zero_from_col):
         self.key = (dim, dt, F, res, bitwidth, zero_from_col)
@@ -319,8 +319,15 @@ class _SlotFit:
 
     def _collect(self):
         p = self.pending
-        if p is None or not p["event"].query():
+        if p is None:
             return
+        # A check is adopted at a FIXED launch number (ADOPT_AFTER launches after it was taken), not "whenever the copy happens to
+        # have landed": which launch first runs with the new slot sizes then does not depend on host timing, and neither does
+        # which records overflow a slot into the float-atomic path - same inputs, same bits, run after run.  The copy is long
+        # done by then (the wait below returns at once); WISP_HG_SLOT_FIT=0 switches the whole mechanism off.
+        if self.calls - p["at"] < self.ADOPT_AFTER:
+            return
+        p["event"].synchronize()
         self.pending = None
         both = self.host_fill.tolist()
         fill, written = both[:self.L], both[self.L:]
@@ -352,7 +359,7 @@ class _SlotFit:
         self.host_fill.copy_(self.dev_fill, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.pending = dict(event=ev, cap=list(cap), base=list(base), ws_bytes=int(ws_bytes))
+        self.pending = dict(event=ev, cap=list(cap), base=list(base), ws_bytes=int(ws_bytes), at=self.calls)
 
 
 def _slot_fit(device, dim, dt, F, res, bitwidth, zero_from_col):

@@ -75,20 +75,37 @@ class OracleNeRF(nn.Module):
         self.view_embed_dim = 3 + 3 * 2 * view_multires
         self.decoder_color = OracleDecoder(15 + self.view_embed_dim, 3, hidden_dim, num_layers + 1, bias)
 
-    def rgba(self, coords, ray_d, lod_idx=None):
-        """nerf.py:219-264."""
+    def rgba(self, coords, ray_d, lod_idx=None, autocast_half=False):
+        """nerf.py:219-264.  autocast_half: round where the reference rounds when BaseTrainer.iterate wraps the step in
+        `torch.cuda.amp.autocast()` (base_trainer.py:338, fp16): the table is cast to half and the lookup returns half
+        (ops/grid.py:77-89: custom_fwd + `codebook.half()`), every nn.Linear runs on half operands and returns half (torch's
+        autocast policy; relu / sigmoid follow their input), the view embedding stays fp32 and `cat` promotes.  The table
+        gradient is accumulated in fp32 from the half upstream gradient (the reference's __half2 atomics round every add in
+        an order nobody can restate)."""
         L = len(self.resolutions)
         if lod_idx is None:
             lod_idx = L - 1
+        table = self.grid.codebook.feats
+        if autocast_half:
+            table = table + (table.half().float() - table).detach()        # value of codebook.half(), gradient of the cast
         feats = hashgrid.grid_interpolate(coords, lod_idx, self.multiscale_type, self.feature_dim, self.resolutions,
-                                          self.bitwidth, self.grid.codebook.feats, self.begin_idxes)
-        feats = feats.to(self.decoder_density.lout.weight.dtype)
-        density_feats = self.decoder_density(feats)
-        emb = positional_embed(ray_d.to(feats.dtype), self.view_multires, include_input=True)
-        fdir = torch.cat([density_feats, emb], dim=-1)
-        colors = torch.sigmoid(self.decoder_color(fdir[..., 1:]))
-        density = torch.relu(density_feats[..., 0:1])
-        return dict(rgb=colors, density=density)
+                                          self.bitwidth, table, self.begin_idxes)
+        if not autocast_half:
+            feats = feats.to(self.decoder_density.lout.weight.dtype)
+            density_feats = self.decoder_density(feats)
+            emb = positional_embed(ray_d.to(feats.dtype), self.view_multires, include_input=True)
+            fdir = torch.cat([density_feats, emb], dim=-1)
+            colors = torch.sigmoid(self.decoder_color(fdir[..., 1:]))
+            density = torch.relu(density_feats[..., 0:1])
+            return dict(rgb=colors, density=density)
+        feats = feats.half()                                                  # the kernel's output dtype is the table's
+        with torch.autocast('cpu', dtype=torch.float16):
+            density_feats = self.decoder_density(feats)
+            emb = positional_embed(ray_d.float(), self.view_multires, include_input=True)
+            fdir = torch.cat([density_feats, emb], dim=-1)
+            colors = torch.sigmoid(self.decoder_color(fdir[..., 1:]))
+            density = torch.relu(density_feats[..., 0:1])
+        return dict(rgb=colors.float(), density=density.float())           # compositing runs in fp32 on the half values
 
 
 class OracleBLAS:
@@ -113,7 +130,7 @@ class OracleBLAS:
 
 
 def trace(nef, blas, origins, dirs, near, far, num_steps, jitter, bg_color=(0.0, 0.0, 0.0), raymarch_type='ray',
-          with_depth=True, lod_idx=None):
+          with_depth=True, lod_idx=None, autocast_half=False):
     """PackedRFTracer.trace (packed_rf_tracer.py:107-181) for channels rgb/alpha/depth/hit."""
     o = origins.detach().cpu().numpy()
     d = dirs.detach().cpu().numpy()
@@ -133,7 +150,7 @@ def trace(nef, blas, origins, dirs, near, far, num_steps, jitter, bg_color=(0.0,
     depths = torch.from_numpy(rm["depth_samples"])
     boundary = torch.from_numpy(rm["boundary"])
     hit_ray_d = dirs.index_select(0, ridx)
-    out = nef.rgba(samples, hit_ray_d, lod_idx)
+    out = nef.rgba(samples, hit_ray_d, lod_idx, autocast_half) if autocast_half else nef.rgba(samples, hit_ray_d, lod_idx)
     res = render.composite(out["rgb"], out["density"], deltas, depths, ridx, boundary, origins.shape[0], bg_color,
                            with_depth=with_depth)
     res["raymarch"] = rm
@@ -160,19 +177,47 @@ def make_optimizer(nef, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=50
     return torch.optim.AdamW(groups, lr=lr, eps=eps, weight_decay=weight_decay)
 
 
+def make_scaler(init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+    """The state of torch.cuda.amp.GradScaler at its defaults (base_trainer.py:190: `GradScaler()`)."""
+    return dict(scale=float(init_scale), growth=float(growth_factor), backoff=float(backoff_factor), interval=int(growth_interval),
+                good_steps=0, skipped=0)
+
+
 def train_step(nef, blas, optimizer, origins, dirs, gts, near, far, num_steps, jitter, bg_color=(0.0, 0.0, 0.0),
-               raymarch_type='ray', loss_type='huber'):
-    """MultiviewTrainer.step (multiview_trainer.py:111-180) without AMP: trace, loss over rays, backward, step."""
+               raymarch_type='ray', loss_type='huber', scaler=None):
+    """MultiviewTrainer.step (multiview_trainer.py:111-180): trace, loss over rays, backward, step.
+    scaler (make_scaler()): the enable_amp regime - the forward rounds where fp16 autocast rounds (OracleNeRF.rgba), the loss
+    is scaled, the gradients are unscaled in fp32, a non-finite gradient skips the step and halves the scale
+    (multiview_trainer.py:168-171 + GradScaler.step / update)."""
     optimizer.zero_grad()
-    res = trace(nef, blas, origins, dirs, near, far, num_steps, jitter, bg_color, raymarch_type, with_depth=False)
+    res = trace(nef, blas, origins, dirs, near, far, num_steps, jitter, bg_color, raymarch_type, with_depth=False,
+                autocast_half=scaler is not None)
     if loss_type == 'huber':
         loss = torch.nn.functional.smooth_l1_loss(res["rgb"], gts, reduction='none').mean()
     elif loss_type == 'l2':
         loss = torch.nn.functional.mse_loss(res["rgb"], gts, reduction='none').mean()
     else:
         loss = torch.abs(res["rgb"] - gts).mean()
-    loss.backward()
-    optimizer.step()
+    if scaler is None:
+        loss.backward()
+        optimizer.step()
+        return float(loss.detach()), int(res["raymarch"]["ridx"].shape[0])
+    (loss * scaler["scale"]).backward()
+    params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+    finite = all(bool(torch.isfinite(p.grad).all()) for p in params)
+    if finite:
+        inv = 1.0 / scaler["scale"]
+        for p in params:
+            p.grad.mul_(inv)
+        optimizer.step()
+        scaler["good_steps"] += 1
+        if scaler["good_steps"] == scaler["interval"]:
+            scaler["scale"] *= scaler["growth"]
+            scaler["good_steps"] = 0
+    else:
+        scaler["scale"] *= scaler["backoff"]
+        scaler["good_steps"] = 0
+        scaler["skipped"] += 1
     return float(loss.detach()), int(res["raymarch"]["ridx"].shape[0])
 
 

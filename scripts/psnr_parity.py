@@ -27,6 +27,9 @@ LEVEL, DECAY, MIN_DENSITY = 7, 0.95, 2.956033378250884
 
 def parse():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--oracle-half", action="store_true",
+                    help="oracle backend: the enable_amp regime - round where fp16 autocast rounds (tables and lookups half, nn.Linear on half "
+                         "operands), scaled loss, fp32 unscale, skipped steps: what the dropin backend is to be compared with")
     ap.add_argument("--backend", choices=["hip", "dropin", "oracle"],
                     help="hip = MultiviewTrainStep (fused step); dropin = wisp.trainers.MultiviewTrainer, the reference trainer's own step "
                          "(fp16 autocast + GradScaler + torch.optim.AdamW over the modular pipeline); oracle = CPU restatement")
@@ -171,6 +174,7 @@ def main():
         state = {"blas": onerf.OracleBLAS.make_dense(LEVEL), "occ": torch.zeros(128 ** 3), "it": 0}
         dense_points = state["blas"].level_points().copy()
         opt = onerf.make_optimizer(onef, lr=1e-3, grid_lr_weight=100.0)
+        scaler = onerf.make_scaler() if args.oracle_half else None
 
         def evaluate():
             with torch.no_grad():
@@ -188,7 +192,7 @@ def main():
                 if nb is not None:
                     state["blas"] = nb
             state["it"] += 1
-            return onerf.train_step(onef, state["blas"], opt, o[idx], d[idx], gt[idx], 1.0, 5.0, args.num_steps, jit)
+            return onerf.train_step(onef, state["blas"], opt, o[idx], d[idx], gt[idx], 1.0, 5.0, args.num_steps, jit, scaler=scaler)
 
     for it in range(1, args.steps + 1):
         idx = torch.from_numpy(rng.integers(0, o.shape[0], args.rays))

@@ -79,6 +79,7 @@ def test_hashgrid_backward_scratch_follows_what_the_launches_fill(monkeypatch):
     from wisp.core import Rays
     C = _C()
     monkeypatch.setattr(C._SlotFit, "CHECK_EVERY", 1)
+    monkeypatch.setattr(C._SlotFit, "ADOPT_AFTER", 0)         # adopt a check at the very next launch (production: 8 launches later)
     C._slot_fits.clear()
     cells = synlego.occupied_cells(7, device=DEV)
     blas = OctreeAS.from_quantized_points(cells, 7)
@@ -117,6 +118,7 @@ def test_hashgrid_backward_scratch_follows_what_the_launches_fill(monkeypatch):
     print(f"scratch: unscaled {full / 2**30:.2f} GiB -> fitted {fitted / 2**30:.2f} GiB for {written / 2**30:.2f} GiB of records; "
           f"scales {[round(x, 3) for x in fit.scale]}")
     # forced far too small: every slot overflows into atomics - same numbers - and the next check grows the slots again
+    fit.pending = None                                        # (drop the check of the last launch: it would replace the forced sizes)
     fit.scale = [0.02] * 16
     small = run()
     torch.cuda.synchronize()
