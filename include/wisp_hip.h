@@ -34,7 +34,8 @@ const char* wisp_last_error(void);
 /* ABI version of this library; bumped whenever a signature changes (1 = round 1; 2 = round 2: scratch arguments of the backward
  * passes, raytrace nugget cache, optimizer kinds, per-ray view codes, corner query, decoded codebook rows; 3 = round 3: per-level
  * slot scales of the hash-grid backward; 4 = round 4: workspace + row counts of the order-free trilinear / codebook backward.
- * Entry points that are only ADDED - wisp_spc_query_chain, wisp_composite_loss, wisp_codebook_trilinear_multi_bwd - do not bump it). */
+ * Entry points that are only ADDED - wisp_spc_query_chain, wisp_composite_loss, wisp_codebook_trilinear_multi_bwd,
+ * wisp_sdf_train_step - do not bump it). */
 int wisp_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -283,6 +284,24 @@ int wisp_codebook_trilinear_multi_bwd(const float* coords, const int64_t* chain,
                                       const int64_t* rows, int dict_size, int feature_dim, int sum, float* const* grad_logits,
                                       float* const* grad_dictionaries, void* workspace, int64_t workspace_bytes,
                                       wisp_stream_t stream);
+
+/* One optimisation step's forward + loss + backward of the reference's SDFTrainer (wisp/trainers/sdf_trainer.py:65-124 with
+ * only_last: loss = sum((pred - gt)^2) / n) for a NeuralSDF over an OctreeGrid (wisp/models/nefs/neural_sdf.py:102-155;
+ * app/nglod/configs/nglod_octree.yaml: 16 'sum' features on num_lods levels, decoder [position, features] -> Linear -> relu ->
+ * Linear(hidden, 1)) in four launches instead of the modular path's twenty (the reference: ~60): walk + lookups + decoder forward
+ * and backward per sample, a fixed-order sum of the decoder's weight gradients, the order-free corner scatter and its row pass.
+ *  coords f32 [n,3], gts f32 [n]; octree / exsum / points / trinkets as above; feats / grad_feats: HOST arrays of num_lods device
+ *  pointers (f32 [rows[l], 16]), levels strictly increasing (HOST), rows HOST i64; w1 f32 [hidden, 19], b1 [hidden], w2 [hidden],
+ *  b2 [1] and their gradients, which - like grad_feats - are ADDED to; loss f32 [1] is written.
+ *  scratch: wisp_sdf_train_scratch_bytes(...) bytes, contents irrelevant; workspace: as for wisp_spc_trilinear_multi_bwd.
+ * Bitwise repeatable: every sum has a fixed order or is an integer sum. */
+int64_t wisp_sdf_train_scratch_bytes(int64_t n, int num_lods, int channels, int hidden);
+int wisp_sdf_train_step(const float* coords, const float* gts, int64_t n, const uint8_t* octree, const int32_t* exsum,
+                        const int16_t* points, const int32_t* trinkets, const float* const* feats, const int32_t* levels,
+                        const int64_t* rows, int num_lods, int channels, int half_round, const float* w1, const float* b1,
+                        const float* w2, const float* b2, int hidden, float* const* grad_feats, float* grad_w1, float* grad_b1,
+                        float* grad_w2, float* grad_b2, float* loss, void* scratch, int64_t scratch_bytes, void* workspace,
+                        int64_t workspace_bytes, wisp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Raymarch sample generation  (replace OctreeAS._raymarch_ray / _raymarch_voxel / _raymarch_uniform,

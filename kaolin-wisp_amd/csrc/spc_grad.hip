@@ -695,3 +695,279 @@ extern "C" int wisp_codebook_trilinear_multi_bwd(const float* coords, const int6
     return codebook_bwd_impl(c, levels, rows, logits, dictionaries, dict_size, grad_logits, grad_dictionaries, workspace,
                              workspace_bytes, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------- fused SDF regression step
+// One optimisation step of the reference's SDFTrainer (wisp/trainers/sdf_trainer.py:65-124, only_last) for a NeuralSDF over an
+// OctreeGrid (wisp/models/nefs/neural_sdf.py:102-155; nglod_octree.yaml: 16 'sum' features on 6 levels, [position, features]
+// -> Linear(19, 128) -> relu -> Linear(128, 1), 512 coordinates per step):
+//     pred = decoder([x, sum_l trilinear_l(x)]) ;  loss = sum (pred - gt)^2 / B ;  backward
+// The reference issues ~60 kernels for it (a query, six trilinear lookups, two GEMMs with their elementwise companions, the
+// loss, and all of that again backwards); the modular path of this package 20.  At 512 coordinates every one of them is
+// launch latency.  Here:
+//   sdf_train_kernel     16 lanes own a sample (as in sdf_trace_fused_kernel, same statements for walk and interpolation:
+//                        bit-identical features): octree walk, the six trilinear lookups, decoder forward, d loss / d pred,
+//                        decoder backward.  Lane c keeps hidden units c, c + 16, ...; the gradient of the decoder input is
+//                        a column sum over LDS.  Per workgroup the weight gradients are summed over its 16 samples by the
+//                        thread that owns the entry, in sample order, and stored as one partial row - no atomics.  The
+//                        sample's feature gradient [16] and cell chain go to scratch; the workgroup's largest |w g| goes to
+//                        the header of the order-free scatter below, which therefore needs no magnitude pass of its own.
+//   sdf_train_reduce     adds the partial rows up in workgroup order, ADDS the sums to the decoder's gradient tensors, writes
+//                        the loss.
+//   spc_grad_scatter_wide + spc_grad_finalize   the corner sums of all six levels (64-bit fixed point, above).
+// Every sum has a fixed order or is an integer sum: the step is bitwise repeatable.
+#define ST_GROUP 16
+#define ST_GROUPS 16                       // samples per workgroup pass
+#define ST_MAX_HIDDEN 256
+#define ST_MAX_IN 32
+
+struct StField {
+    const float* feats[SG_MAX_LODS];
+    int32_t level[SG_MAX_LODS];
+    int num_lods, channels, half_round, hidden, max_level;
+    const float *w1, *b1, *w2, *b2;
+};
+
+static __device__ __forceinline__ int st_child_slot(int qx, int qy, int qz, int sh) {
+    return (((qx >> sh) & 1) << 2) | (((qy >> sh) & 1) << 1) | ((qz >> sh) & 1);
+}
+
+__global__ void __launch_bounds__(ST_GROUP * ST_GROUPS)
+sdf_train_kernel(const float* __restrict__ coords, const float* __restrict__ gts, int64_t n, const uint8_t* __restrict__ octree,
+                 const int32_t* __restrict__ exsum, const int16_t* __restrict__ points, const int32_t* __restrict__ trinkets,
+                 StField fld, float inv_batch, float* __restrict__ partials /* [grid][row] */, int row_stride,
+                 float* __restrict__ dfeat /* [n][channels] */, int64_t* __restrict__ chain /* [n][num_lods] */,
+                 SgHeader* __restrict__ hdr) {
+    extern __shared__ float s_st[];
+    const int C = fld.channels, H = fld.hidden;
+    const int in_dim = 3 + C;
+    const int in_pad = in_dim | 1;                      // odd row stride: the lanes of a group read different rows
+    float* s_w1 = s_st;                                 // [H][in_pad]
+    float* s_b1 = s_w1 + H * in_pad;                    // [H]
+    float* s_w2 = s_b1 + H;                             // [H]
+    float* s_in = s_w2 + H;                             // [groups][in_dim]     decoder inputs of the pass
+    float* s_ga = s_in + ST_GROUPS * in_dim;            // [groups][H]          d loss / d pre-activation
+    float* s_gr = s_ga + ST_GROUPS * H;                 // [groups][H]          d loss / d pred * relu output (for d w2)
+    float* s_g = s_gr + ST_GROUPS * H;                  // [groups]             d loss / d pred
+    float* s_sq = s_g + ST_GROUPS;                      // [groups]             squared error
+    for (int e = threadIdx.x; e < H * in_dim; e += blockDim.x) s_w1[(e / in_dim) * in_pad + e % in_dim] = fld.w1[e];
+    for (int e = threadIdx.x; e < H; e += blockDim.x) { s_b1[e] = fld.b1[e]; s_w2[e] = fld.w2[e]; }
+    const int c = threadIdx.x & (ST_GROUP - 1);
+    const int grp = threadIdx.x / ST_GROUP;
+    const int L = fld.max_level;
+    const float b2 = fld.b2[0];
+    // partial sums of the entries this thread owns: d W1 [H][in_dim], d b1 [H], d w2 [H], d b2, loss - in that order
+    const int n_entries = H * in_dim + 2 * H + 2;
+    constexpr int OWN = (ST_MAX_HIDDEN * (ST_MAX_IN + 2) + 2 + ST_GROUP * ST_GROUPS - 1) / (ST_GROUP * ST_GROUPS);
+    float own[OWN];
+#pragma unroll
+    for (int k = 0; k < OWN; ++k) own[k] = 0.0f;
+    uint32_t mbits = 0;
+    __syncthreads();
+    for (int64_t base = (int64_t)blockIdx.x * ST_GROUPS; base < n; base += (int64_t)gridDim.x * ST_GROUPS) {
+        const int64_t s = base + grp;
+        const bool live = s < n;
+        float* gin = s_in + grp * in_dim;
+        float* ga = s_ga + grp * H;
+        float* gr = s_gr + grp * H;
+        float wmax = 0.0f;
+        if (live) {
+            const float px = coords[s * 3], py = coords[s * 3 + 1], pz = coords[s * 3 + 2];
+            // ---- the cell of every active level (spc_query_kernel's walk) and the features
+            const bool inside = (fabsf(px) <= 1.0f) && (fabsf(py) <= 1.0f) && (fabsf(pz) <= 1.0f);
+            const float res = (float)(1 << L);
+            const int top = (1 << L) - 1;
+            const int qx = min((int)floorf(res * (0.5f * px + 0.5f)), top);
+            const int qy = min((int)floorf(res * (0.5f * py + 0.5f)), top);
+            const int qz = min((int)floorf(res * (0.5f * pz + 0.5f)), top);
+            const float pos[3] = {px, py, pz};
+            float feat = 0.0f;                               // channel c, summed over the levels
+            int64_t node = inside ? 0 : -1;
+            int li = 0;
+            for (int l = 0; l <= L && li < fld.num_lods; ++l) {
+                if (l == fld.level[li]) {
+                    float acc = 0.0f;
+                    if (node >= 0) {
+                        float w[8];
+                        sg_coeffs(pos, points + node * 3, l, w);
+                        float wm = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) wm = fmaxf(wm, fabsf(w[j]));
+                        wmax = fmaxf(wmax, wm);
+                        const int32_t* tr = trinkets + node * 8;
+                        const float* f = fld.feats[li];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float fv = f[(int64_t)tr[j] * C + c];
+                            if (fld.half_round) fv = __half2float(__float2half_rn(fv));
+                            acc += fv * w[j];
+                        }
+                        if (fld.half_round) acc = __half2float(__float2half_rn(acc));
+                    }
+                    if (c == 0) chain[s * fld.num_lods + li] = node;
+                    feat += acc;
+                    ++li;
+                }
+                if (l < L && node >= 0) {
+                    const int cs = st_child_slot(qx, qy, qz, L - 1 - l);
+                    const uint32_t bits = octree[node];
+                    node = ((bits >> cs) & 1u) ? (int64_t)exsum[node] + __popc(bits & ((2u << cs) - 1u)) : -1;
+                }
+            }
+            if (c < 3) gin[c] = pos[c];
+            gin[3 + c] = feat;
+        }
+        __builtin_amdgcn_wave_barrier();                 // a group's lanes are in one wave: LDS order suffices
+        float g = 0.0f;
+        if (live) {
+            // ---- decoder forward: in = [position, features] (neural_sdf.py: embedded position first)
+            float out = 0.0f;
+            for (int hh = c; hh < H; hh += ST_GROUP) {
+                const float* wr = s_w1 + hh * in_pad;
+                float a = s_b1[hh];
+                for (int i = 0; i < in_dim; ++i) a = __builtin_fmaf(wr[i], gin[i], a);
+                const float r = fmaxf(a, 0.0f);
+                out = __builtin_fmaf(s_w2[hh], r, out);
+                ga[hh] = a > 0.0f ? s_w2[hh] : 0.0f;    // finished below, once d loss / d pred is known
+                gr[hh] = r;
+            }
+#pragma unroll
+            for (int d = ST_GROUP / 2; d >= 1; d >>= 1) out += __shfl_xor(out, d, ST_GROUP);
+            const float diff = (out + b2) - gts[s];
+            g = 2.0f * diff * inv_batch;                 // d [sum (pred - gt)^2 / B] / d pred
+            for (int hh = c; hh < H; hh += ST_GROUP) { ga[hh] *= g; gr[hh] *= g; }
+            if (c == 0) { s_g[grp] = g; s_sq[grp] = diff * diff; }
+        } else {
+            for (int hh = c; hh < H; hh += ST_GROUP) { ga[hh] = 0.0f; gr[hh] = 0.0f; }
+            if (c < 3) gin[c] = 0.0f;
+            gin[3 + c] = 0.0f;
+            if (c == 0) { s_g[grp] = 0.0f; s_sq[grp] = 0.0f; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            // ---- gradient of the decoder input, feature columns only (nothing consumes d / d position)
+            float dx = 0.0f;
+            for (int hh = 0; hh < H; ++hh) dx = __builtin_fmaf(ga[hh], s_w1[hh * in_pad + 3 + c], dx);
+            dfeat[s * C + c] = dx;
+            const uint32_t b = __float_as_uint(wmax * fabsf(dx)) & 0x7fffffffu;
+            const uint32_t nb = (!(dx == dx) || !(wmax == wmax)) ? 0x7fc00000u : b;
+            mbits = nb > mbits ? nb : mbits;
+        }
+        __syncthreads();
+        // ---- weight gradients of this pass: the thread that owns an entry adds the samples up in order
+#pragma unroll
+        for (int k = 0; k < OWN; ++k) {
+            const int e = (int)threadIdx.x + k * (ST_GROUP * ST_GROUPS);
+            if (e >= n_entries) break;
+            float acc = 0.0f;
+            if (e < H * in_dim) {
+                const int hh = e / in_dim, i = e - hh * in_dim;
+#pragma unroll
+                for (int q = 0; q < ST_GROUPS; ++q) acc = __builtin_fmaf(s_ga[q * H + hh], s_in[q * in_dim + i], acc);
+            } else if (e < H * in_dim + H) {
+                const int hh = e - H * in_dim;
+#pragma unroll
+                for (int q = 0; q < ST_GROUPS; ++q) acc += s_ga[q * H + hh];
+            } else if (e < H * in_dim + 2 * H) {
+                const int hh = e - H * in_dim - H;
+#pragma unroll
+                for (int q = 0; q < ST_GROUPS; ++q) acc += s_gr[q * H + hh];
+            } else if (e == H * in_dim + 2 * H) {
+#pragma unroll
+                for (int q = 0; q < ST_GROUPS; ++q) acc += s_g[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < ST_GROUPS; ++q) acc += s_sq[q];
+            }
+            own[k] += acc;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < OWN; ++k) {
+        const int e = (int)threadIdx.x + k * (ST_GROUP * ST_GROUPS);
+        if (e < n_entries) partials[(int64_t)blockIdx.x * row_stride + e] = own[k];
+    }
+    mbits = sg_wave_umax(mbits);
+    if ((threadIdx.x & 63) == 0 && mbits > __atomic_load_n(&hdr->absmax_bits, __ATOMIC_RELAXED)) atomicMax(&hdr->absmax_bits, mbits);
+}
+
+__global__ void __launch_bounds__(256)
+sdf_train_reduce_kernel(const float* __restrict__ partials, int rows, int row_stride, int H, int in_dim, float* __restrict__ gw1,
+                        float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2, float* __restrict__ loss,
+                        float inv_batch) {
+    const int n_entries = H * in_dim + 2 * H + 2;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += gridDim.x * blockDim.x) {
+        float acc = 0.0f;
+        for (int r = 0; r < rows; ++r) acc += partials[(int64_t)r * row_stride + e];          // workgroup order
+        if (e < H * in_dim) gw1[e] += acc;
+        else if (e < H * in_dim + H) gb1[e - H * in_dim] += acc;
+        else if (e < H * in_dim + 2 * H) gw2[e - H * in_dim - H] += acc;
+        else if (e == H * in_dim + 2 * H) gb2[0] += acc;
+        else loss[0] = acc * inv_batch;
+    }
+}
+
+static inline int st_grid(int64_t n) { return (int)min64(ceil_div64(n, ST_GROUPS), 512); }
+static inline int st_row_stride(int hidden, int channels) { return (hidden * (3 + channels) + 2 * hidden + 2 + 15) / 16 * 16; }
+
+extern "C" int64_t wisp_sdf_train_scratch_bytes(int64_t n, int num_lods, int channels, int hidden) {
+    if (n < 0 || num_lods < 1 || channels < 1 || hidden < 1) return -1;
+    return (int64_t)st_grid(n) * st_row_stride(hidden, channels) * 4 + sg_round64(n * channels * 4) + n * num_lods * 8;
+}
+
+extern "C" int wisp_sdf_train_step(const float* coords, const float* gts, int64_t n, const uint8_t* octree, const int32_t* exsum,
+                                   const int16_t* points, const int32_t* trinkets, const float* const* feats,
+                                   const int32_t* levels, const int64_t* rows, int num_lods, int channels, int half_round,
+                                   const float* w1, const float* b1, const float* w2, const float* b2, int hidden,
+                                   float* const* grad_feats, float* grad_w1, float* grad_b1, float* grad_w2, float* grad_b2,
+                                   float* loss, void* scratch, int64_t scratch_bytes, void* workspace, int64_t workspace_bytes,
+                                   wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 1 && num_lods >= 1 && num_lods <= SG_MAX_LODS, "bad sizes");
+    WISP_REQUIRE(channels == ST_GROUP, "the fused SDF step is built for 16 feature channels (nglod_octree.yaml)");
+    WISP_REQUIRE(hidden >= 1 && hidden <= ST_MAX_HIDDEN, "hidden width out of range");
+    WISP_REQUIRE(coords && gts && octree && exsum && points && trinkets && feats && levels && rows && w1 && b1 && w2 && b2 &&
+                 grad_feats && grad_w1 && grad_b1 && grad_w2 && grad_b2 && loss && scratch && workspace, "null pointer");
+    WISP_REQUIRE(scratch_bytes >= wisp_sdf_train_scratch_bytes(n, num_lods, channels, hidden), "scratch too small (wisp_sdf_train_scratch_bytes)");
+    StField fld;
+    SgLods ml;
+    WISP_REQUIRE(sg_fill(ml, levels, rows, num_lods) == 0, "bad level or row count");
+    for (int l = 0; l < num_lods; ++l) {
+        WISP_REQUIRE(feats[l] && grad_feats[l] && (l == 0 || levels[l] > levels[l - 1]), "bad level list");
+        fld.feats[l] = feats[l]; fld.level[l] = levels[l]; ml.grad[l] = grad_feats[l];
+    }
+    fld.num_lods = num_lods; fld.channels = channels; fld.half_round = half_round; fld.hidden = hidden;
+    fld.max_level = levels[num_lods - 1];
+    fld.w1 = w1; fld.b1 = b1; fld.w2 = w2; fld.b2 = b2;
+    const SgPlan pl = sg_plan(ml.base[num_lods], channels, 0);
+    WISP_REQUIRE(workspace_bytes >= pl.bytes, "workspace too small (wisp_spc_bwd_workspace_bytes)");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    SgHeader* hdr = reinterpret_cast<SgHeader*>(ws);
+    const int grid = st_grid(n), row_stride = st_row_stride(hidden, channels), in_dim = 3 + channels;
+    float* partials = static_cast<float*>(scratch);
+    float* dfeat = partials + (size_t)grid * row_stride;
+    int64_t* chain = reinterpret_cast<int64_t*>(reinterpret_cast<unsigned char*>(dfeat) + sg_round64(n * channels * 4));
+    const size_t lds = ((size_t)hidden * (in_dim | 1) + 2 * hidden + (size_t)ST_GROUPS * (in_dim + 2 * hidden + 2)) * 4;
+    const float inv_batch = 1.0f / (float)n;
+    if (hipMemsetAsync(hdr, 0, sizeof(SgHeader), s) != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, "hipMemsetAsync failed");
+    if (const hipError_t e = WISP_ALLOW_LDS(sdf_train_kernel, lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
+    hipLaunchKernelGGL(sdf_train_kernel, dim3(grid), dim3(ST_GROUP * ST_GROUPS), lds, s, coords, gts, n, octree, exsum, points,
+                       trinkets, fld, inv_batch, partials, row_stride, dfeat, chain, hdr);
+    hipLaunchKernelGGL(sdf_train_reduce_kernel, dim3(min((hidden * in_dim + 2 * hidden + 2 + 255) / 256, 16)), dim3(256), 0, s,
+                       partials, grid, row_stride, hidden, in_dim, grad_w1, grad_b1, grad_w2, grad_b2, loss, inv_batch);
+    // the corner sums: the magnitude bound is in the header already (sdf_train_kernel), so only scatter + row pass
+    SgCall c{coords, chain, 1, num_lods, 1, points, trinkets, dfeat, n, num_lods, channels, 1, channels};
+    uint8_t* flags = sg_use_flags(c, pl) ? ws + pl.off_flags : nullptr;
+    long long* acc = reinterpret_cast<long long*>(ws + pl.off_acc);
+    const int clog = sg_clog(n);
+    hipLaunchKernelGGL((spc_grad_scatter_wide_kernel<int64_t>), dim3((unsigned)min64(ceil_div64(n, 256 / channels), 16384)), dim3(256), 0, s,
+                       coords, chain, (int64_t)num_lods, 1, points, trinkets, ml, dfeat, n, num_lods, channels, 1, clog, pl.stride,
+                       channels, hdr, flags, acc);
+    int lpr = 1;
+    while (lpr < channels && lpr < 64) lpr <<= 1;
+    if (pl.total_rows > 0)
+        hipLaunchKernelGGL(spc_grad_finalize_kernel, dim3((unsigned)min64(ceil_div64(pl.total_rows, 256 / lpr), 8192)), dim3(256), 0, s, ml,
+                           num_lods, channels, pl.stride, lpr, clog, hdr, flags, acc);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}

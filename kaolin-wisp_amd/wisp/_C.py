@@ -73,6 +73,9 @@ SIGNATURES = {
     "wisp_sdf_trace_step_fused": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                   c_vp, c_i32, c_f32, c_vp, c_vp],
+    "wisp_sdf_train_scratch_bytes": [c_i64, c_i32, c_i32, c_i32],
+    "wisp_sdf_train_step": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
+                            c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp],
     "wisp_grid_interpolate_fwd": [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp],
     "wisp_grid_interpolate_bwd": [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp],
     "wisp_small_decoder_fwd": [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
@@ -103,7 +106,7 @@ SIGNATURES = {
     "wisp_last_error": [],
     "wisp_abi_version": [],
 }
-_RESTYPES = {"wisp_nerf_mlp_bwd_workspace_bytes": c_i64, "wisp_spc_bwd_workspace_bytes": c_i64, "wisp_hashgrid_bwd_workspace_bytes": c_i64, "wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_nerf_mlp_workspace_floats": c_i64,
+_RESTYPES = {"wisp_nerf_mlp_bwd_workspace_bytes": c_i64, "wisp_spc_bwd_workspace_bytes": c_i64, "wisp_sdf_train_scratch_bytes": c_i64, "wisp_hashgrid_bwd_workspace_bytes": c_i64, "wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_nerf_mlp_workspace_floats": c_i64,
              "wisp_last_error": ctypes.c_char_p}
 
 for _name, _args in SIGNATURES.items():
@@ -1068,6 +1071,38 @@ def sdf_trace_step_fused(first, nug_o, nug_d, nug_depth, nug_pidx, dist_max, thr
                                          _p(points), _p(trinkets), fp, _DTYPE_CODE[feats[0].dtype], lv, n, feats[0].shape[1],
                                          int(half_round), _p(w1), _p(b1), _p(w2), _p(b2), w1.shape[0], float(np.float32(scale)),
                                          _p(any_active), _stream()), "sdf_trace_step_fused")
+
+
+_sdf_scratch = {}
+
+
+def sdf_train_step(coords, gts, octree, exsum, points, trinkets, feats, levels, half_round, w1, b1, w2, b2, grad_feats, grad_w1,
+                   grad_b1, grad_w2, grad_b2):
+    """Forward + loss + backward of one SDF regression step (wisp_sdf_train_step): coords [n,3], gts [n,1] -> loss f32 [1]
+    (= sum((pred - gt)^2) / n); the gradients are ADDED to grad_feats (list, one per level) and grad_w1 / b1 / w2 / b2."""
+    coords = _need(coords, torch.float32, "coords")
+    gts = _need(gts, torch.float32, "gts").reshape(-1)
+    n, L, C, H = coords.shape[0], len(feats), feats[0].shape[1], w1.shape[0]
+    dev = coords.device
+    assert gts.shape[0] == n and all(f.dtype == torch.float32 and f.is_contiguous() and f.shape[1] == C for f in feats)
+    assert all(g.dtype == torch.float32 and g.is_contiguous() and g.shape == f.shape for g, f in zip(grad_feats, feats))
+    need = int(lib.wisp_sdf_train_scratch_bytes(n, L, C, H))
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream().value)
+    scratch = _sdf_scratch.get(key)
+    if scratch is None or scratch.numel() < need:
+        scratch = _sdf_scratch[key] = torch.empty(need + need // 4, dtype=torch.uint8, device=dev)
+    rarr, rptr = _host_i64([f.shape[0] for f in feats])
+    ws = _spc_bwd_workspace(dev, int(rarr.sum()), C)
+    farr, fptr = _ptr_array(feats)
+    garr, gptr = _ptr_array(grad_feats)
+    larr, lptr = _host_i32(levels)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    _check(lib.wisp_sdf_train_step(_p(coords), _p(gts), n, _p(_need(octree, torch.uint8, "octree")), _p(_need(exsum, torch.int32, "exsum")),
+                                   _p(_need(points, torch.int16, "points")), _p(_need(trinkets, torch.int32, "trinkets")), fptr, lptr,
+                                   rptr, L, C, int(half_round), _p(w1), _p(b1), _p(w2), _p(b2), H, gptr, _p(grad_w1), _p(grad_b1),
+                                   _p(grad_w2), _p(grad_b2), _p(loss), _p(scratch), scratch.numel(), _p(ws), ws.numel(), _stream()),
+           "sdf_train_step")
+    return loss
 
 
 def small_decoder_forward(x, w1, b1, w2, b2):

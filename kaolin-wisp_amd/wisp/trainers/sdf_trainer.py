@@ -52,7 +52,52 @@ class SDFTrainStep:
             C.optim_step_groups(self.optimizer, f.data, f.grad, f.exp_avg, f.exp_avg_sq, groups, self.betas[0], self.betas[1],
                                 self.eps, self.opt_steps, zero_grad=True)
 
+    def _fused_field(self):
+        """What wisp_sdf_train_step needs, or None when this field is not its shape: NeuralSDF's decoder (one hidden relu layer,
+        biases, one output) over [position, 'sum' OctreeGrid features of 16 channels], fp32 parameters living in the flat
+        buffers, loss on the finest LOD only.  WISP_SDF_TRAIN_FUSED=0 keeps the modular launches."""
+        import os
+        cached = getattr(self, "_fused_cache", None)
+        if cached is not None:
+            return cached or None
+        self._fused_cache = False
+        if os.environ.get("WISP_SDF_TRAIN_FUSED", "1") == "0" or not self.only_last:
+            return None
+        from wisp.accelstructs import OctreeAS
+        from wisp.models.grids import OctreeGrid
+        from wisp.models.nefs._grid_mlp import _fusable_small_decoder
+        nef = self.nef
+        grid, dec = getattr(nef, "grid", None), getattr(nef, "decoder", None)
+        if type(grid) is not OctreeGrid or type(getattr(grid, "blas", None)) is not OctreeAS or dec is None:
+            return None
+        if not (grid.interpolation_type == 'linear' and grid.multiscale_type == 'sum' and grid.feature_dim == 16 and grid._fusable()
+                and 1 <= grid.num_lods <= 16 and type(getattr(nef, "pos_embedder", None)) is torch.nn.Identity
+                and getattr(nef, "position_input", False)):
+            return None
+        probe = torch.empty(1, 3 + grid.feature_dim, device=self.flat.data.device)
+        if not probe.is_cuda or not _fusable_small_decoder(dec, probe) or dec.layers[0].in_features != 3 + grid.feature_dim:
+            return None
+        prm = list(grid.features[:grid.num_lods]) + [dec.layers[0].weight, dec.layers[0].bias, dec.lout.weight, dec.lout.bias]
+        if not all(q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and q.grad is not None and q.grad.is_contiguous()
+                   and q.grad.dtype == torch.float32 for q in prm):
+            return None
+        self._fused_cache = dict(grid=grid, dec=dec)
+        return self._fused_cache
+
     def _forward_backward(self, coords, gts):
+        fused = self._fused_field() if coords.is_cuda and coords.ndim == 2 and coords.shape[0] > 0 else None
+        if fused is not None:
+            C = _hip()
+            grid, dec = fused["grid"], fused["dec"]
+            L = grid.num_lods
+            blas = grid.blas
+            grid._sync_device(coords.device)
+            tr = grid.trinkets if grid.trinkets.dtype == torch.int32 else grid.trinkets.int()
+            w1, b1, w2, b2 = dec.layers[0].weight, dec.layers[0].bias, dec.lout.weight, dec.lout.bias
+            loss = C.sdf_train_step(coords, gts, blas.octree, blas.prefix, blas.points, tr, [f.detach() for f in grid.features[:L]],
+                                    grid.active_lods[:L], grid.half_features, w1.detach(), b1.detach(), w2.detach(), b2.detach(),
+                                    [f.grad for f in grid.features[:L]], w1.grad, b1.grad, w2.grad, b2.grad)
+            return loss[0]
         loss = 0.0
         for lod_idx in self.loss_lods():
             pred = self.nef(coords=coords, lod_idx=lod_idx, channels="sdf")

@@ -976,3 +976,47 @@ def test_octree_fields_backward_is_bitwise_repeatable(kind):
             gi = C.spc_trilinear_backward(coords.view(-1, 1, 3), cell_i, blas.points, trk, g.view(-1, 1, F), tuple(grid.features[i].shape),
                                           levels[i])
             assert float((gi - first[i]).abs().max()) <= 2e-6 * float(first[i].abs().max())
+
+
+@pytest.mark.parametrize("batch", [512, 37, 5000])
+def test_fused_sdf_train_step_equals_the_modular_launches_and_repeats_bitwise(batch, monkeypatch):
+    """wisp_sdf_train_step (walk + lookups + decoder forward / backward per sample, fixed-order weight-gradient sums, order-free
+    corner scatter: four launches) against the modular step it replaces (query, multi-level lookup, small decoder, torch loss,
+    their backward passes) from the same parameters: same loss, same gradient in every parameter - and the same bits when run
+    again."""
+    import copy
+    from wisp.accelstructs import OctreeAS
+    from wisp.models.grids import OctreeGrid
+    from wisp.models.nefs import NeuralSDF
+    from wisp.trainers import SDFTrainStep
+    rng = np.random.default_rng(240 + batch)
+    P = rng.integers(0, 32, size=(4000, 3))
+    blas = OctreeAS.from_quantized_points(cuda(P.astype(np.int16)), 5)
+    torch.manual_seed(7)
+    grid = OctreeGrid(blas, feature_dim=16, num_lods=4, multiscale_type='sum', feature_std=0.05)
+    nef_a = NeuralSDF(grid, pos_embedder='none', position_input=True, hidden_dim=128, num_layers=1).to(DEV)
+    nef_b = copy.deepcopy(nef_a)
+    fused = SDFTrainStep(nef_a, lr=1e-3, eps=1e-15, grid_lr_weight=2.0)
+    assert fused._fused_field() is not None
+    monkeypatch.setenv("WISP_SDF_TRAIN_FUSED", "0")
+    modular = SDFTrainStep(nef_b, lr=1e-3, eps=1e-15, grid_lr_weight=2.0)
+    assert modular._fused_field() is None
+    inside = ((P[rng.integers(0, P.shape[0], batch)] + rng.uniform(0.02, 0.98, (batch, 3))) / 16 - 1).astype(np.float32)
+    inside[::11] = rng.uniform(-1.2, 1.2, (inside[::11].shape[0], 3))                 # some outside every cell / the unit cube
+    coords = cuda(inside)
+    gts = cuda(rng.normal(size=(batch, 1)).astype(np.float32) * 0.1)
+    la = fused._forward_backward(coords, gts)
+    lb = modular._forward_backward(coords, gts)
+    assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb)))
+    ga, gb = fused.flat.grad.clone(), modular.flat.grad.clone()
+    for (n1, p1), (n2, p2) in zip(nef_a.named_parameters(), nef_b.named_parameters()):
+        sc = max(float(p2.grad.abs().max()), 1e-12)
+        margin(f"fused sdf step grad {n1} B={batch}", float((p1.grad - p2.grad).abs().max()), 2e-5 * sc)
+    assert float(gb.abs().max()) > 0
+    for _ in range(5):                                        # same inputs, same bits
+        fused.flat.grad.zero_()
+        l2 = fused._forward_backward(coords, gts)
+        assert torch.equal(fused.flat.grad, ga) and float(l2) == float(la)
+    # and it trains: a few real steps bring the loss down
+    losses = [float(fused.step(coords, gts)) for _ in range(30)]
+    assert losses[-1] < 0.7 * losses[0]
