@@ -284,7 +284,7 @@ spc_grad_scatter_wide_kernel(const float* __restrict__ coords, const I* __restri
                              const int16_t* __restrict__ points, const int32_t* __restrict__ trinkets, SgLods ml,
                              const float* __restrict__ grad_out, int64_t n, int num_lods, int channels, int sum, int clog,
                              int stride, int direct_stride, const SgHeader* __restrict__ hdr, uint8_t* __restrict__ flags,
-                             long long* __restrict__ acc) {
+                             long long* __restrict__ acc, int split_lods) {
     const SgScale sc = sg_scale(hdr->absmax_bits, clog);
     if (sc.zero) return;
     const int cpt = channels <= 64 ? channels : 64;
@@ -293,9 +293,12 @@ spc_grad_scatter_wide_kernel(const float* __restrict__ coords, const I* __restri
     if ((int)threadIdx.x / cpt >= rows_per_block) return;
     const int64_t step = (int64_t)gridDim.x * rows_per_block;
     const int out_row = sum ? channels : num_lods * channels;
-    for (int64_t i = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cpt; i < n; i += step) {
+    const int64_t units = split_lods ? n * num_lods : n;                 // split_lods: one (sample, level) per lane group
+    for (int64_t u = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cpt; u < units; u += step) {
+        const int64_t i = split_lods ? u / num_lods : u;
+        const int l0 = split_lods ? (int)(u - i * num_lods) : 0, l1 = split_lods ? l0 + 1 : num_lods;
         const I* ch = cells + (spv == 1 ? i : i / spv) * cell_stride;
-        for (int l = 0; l < num_lods; ++l) {
+        for (int l = l0; l < l1; ++l) {
             const int64_t p = (int64_t)ch[l];
             if (p < 0) continue;
             float w[8];
@@ -505,6 +508,10 @@ struct SgCall {
 // batch over 0.2 M rows) pass 3 reads the accumulators themselves and pass 2 saves its 2.5 M scattered byte stores.
 static bool sg_use_flags(const SgCall& c, const SgPlan& pl) { return c.n * 8 * c.num_lods < pl.total_rows; }
 
+// few samples (an NGLOD step has 512): the levels of a sample go to different lane groups, or a handful of workgroups would walk
+// all levels one after the other with the rest of the chip idle
+static int sg_split_lods(const SgCall& c) { return c.num_lods > 1 && c.n * (c.channels <= 64 ? c.channels : 64) < (int64_t)256 * 1024; }
+
 // passes 1 and 2
 static int sg_scatter(const SgCall& c, const SgLods& ml, const SgPlan& pl, unsigned char* ws, hipStream_t s) {
     SgHeader* hdr = reinterpret_cast<SgHeader*>(ws);
@@ -528,10 +535,11 @@ static int sg_scatter(const SgCall& c, const SgLods& ml, const SgPlan& pl, unsig
 #undef SG_MERGE
     } else {
         const int cpt = c.channels <= 64 ? c.channels : 64;
-        const dim3 grid((unsigned)min64(ceil_div64(c.n, 256 / cpt), 16384)), block(256);
+        const int split = sg_split_lods(c);
+        const dim3 grid((unsigned)min64(ceil_div64(c.n * (split ? c.num_lods : 1), 256 / cpt), 16384)), block(256);
 #define SG_WIDE(I) hipLaunchKernelGGL((spc_grad_scatter_wide_kernel<I>), grid, block, 0, s, c.coords, (const I*)c.cells,         \
                                       c.cell_stride, c.spv, c.points, c.trinkets, ml, c.grad_out, c.n, c.num_lods, c.channels,  \
-                                      c.sum, clog, pl.stride, c.direct_stride, hdr, flags, acc)
+                                      c.sum, clog, pl.stride, c.direct_stride, hdr, flags, acc, split)
         if (c.cells_is_i64) SG_WIDE(int64_t); else SG_WIDE(int32_t);
 #undef SG_WIDE
     }
@@ -719,6 +727,7 @@ extern "C" int wisp_codebook_trilinear_multi_bwd(const float* coords, const int6
 #define ST_GROUPS 16                       // samples per workgroup pass
 #define ST_MAX_HIDDEN 256
 #define ST_MAX_IN 32
+#define ST_UNROLL_LODS 8
 
 struct StField {
     const float* feats[SG_MAX_LODS];
@@ -749,6 +758,7 @@ sdf_train_kernel(const float* __restrict__ coords, const float* __restrict__ gts
     float* s_gr = s_ga + ST_GROUPS * H;                 // [groups][H]          d loss / d pred * relu output (for d w2)
     float* s_g = s_gr + ST_GROUPS * H;                  // [groups]             d loss / d pred
     float* s_sq = s_g + ST_GROUPS;                      // [groups]             squared error
+    int32_t* s_nodes = reinterpret_cast<int32_t*>(s_sq + ST_GROUPS);   // [groups][SG_MAX_LODS]  the sample's cell on every level
     for (int e = threadIdx.x; e < H * in_dim; e += blockDim.x) s_w1[(e / in_dim) * in_pad + e % in_dim] = fld.w1[e];
     for (int e = threadIdx.x; e < H; e += blockDim.x) { s_b1[e] = fld.b1[e]; s_w2[e] = fld.w2[e]; }
     const int c = threadIdx.x & (ST_GROUP - 1);
@@ -780,21 +790,38 @@ sdf_train_kernel(const float* __restrict__ coords, const float* __restrict__ gts
             const int qy = min((int)floorf(res * (0.5f * py + 0.5f)), top);
             const int qz = min((int)floorf(res * (0.5f * pz + 0.5f)), top);
             const float pos[3] = {px, py, pz};
-            float feat = 0.0f;                               // channel c, summed over the levels
+            // the walk is a chain of dependent loads (one round trip per level); the lookups are not: their cells are parked
+            // first and then read with all loads of all levels in flight together
+            int32_t* s_node = s_nodes + grp * SG_MAX_LODS;
             int64_t node = inside ? 0 : -1;
             int li = 0;
             for (int l = 0; l <= L && li < fld.num_lods; ++l) {
                 if (l == fld.level[li]) {
+                    if (c == 0) { s_node[li] = (int32_t)node; chain[s * fld.num_lods + li] = node; }
+                    ++li;
+                }
+                if (l < L && node >= 0) {
+                    const int cs = st_child_slot(qx, qy, qz, L - 1 - l);
+                    const uint32_t bits = octree[node];
+                    node = ((bits >> cs) & 1u) ? (int64_t)exsum[node] + __popc(bits & ((2u << cs) - 1u)) : -1;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            float feat = 0.0f;                               // channel c, summed over the levels
+#pragma unroll
+            for (int q = 0; q < ST_UNROLL_LODS; ++q) {
+                if (q < fld.num_lods) {
+                    const int32_t nd = s_node[q];
                     float acc = 0.0f;
-                    if (node >= 0) {
+                    if (nd >= 0) {
                         float w[8];
-                        sg_coeffs(pos, points + node * 3, l, w);
+                        sg_coeffs(pos, points + (int64_t)nd * 3, fld.level[q], w);
                         float wm = 0.0f;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) wm = fmaxf(wm, fabsf(w[j]));
                         wmax = fmaxf(wmax, wm);
-                        const int32_t* tr = trinkets + node * 8;
-                        const float* f = fld.feats[li];
+                        const int32_t* tr = trinkets + (int64_t)nd * 8;
+                        const float* f = fld.feats[q];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             float fv = f[(int64_t)tr[j] * C + c];
@@ -803,15 +830,28 @@ sdf_train_kernel(const float* __restrict__ coords, const float* __restrict__ gts
                         }
                         if (fld.half_round) acc = __half2float(__float2half_rn(acc));
                     }
-                    if (c == 0) chain[s * fld.num_lods + li] = node;
                     feat += acc;
-                    ++li;
                 }
-                if (l < L && node >= 0) {
-                    const int cs = st_child_slot(qx, qy, qz, L - 1 - l);
-                    const uint32_t bits = octree[node];
-                    node = ((bits >> cs) & 1u) ? (int64_t)exsum[node] + __popc(bits & ((2u << cs) - 1u)) : -1;
+            }
+            for (int q = ST_UNROLL_LODS; q < fld.num_lods; ++q) {            // (more levels than the unrolled eight: one by one)
+                const int32_t nd = s_node[q];
+                float acc = 0.0f;
+                if (nd >= 0) {
+                    float w[8];
+                    sg_coeffs(pos, points + (int64_t)nd * 3, fld.level[q], w);
+                    float wm = 0.0f;
+                    for (int j = 0; j < 8; ++j) wm = fmaxf(wm, fabsf(w[j]));
+                    wmax = fmaxf(wmax, wm);
+                    const int32_t* tr = trinkets + (int64_t)nd * 8;
+                    const float* f = fld.feats[q];
+                    for (int j = 0; j < 8; ++j) {
+                        float fv = f[(int64_t)tr[j] * C + c];
+                        if (fld.half_round) fv = __half2float(__float2half_rn(fv));
+                        acc += fv * w[j];
+                    }
+                    if (fld.half_round) acc = __half2float(__float2half_rn(acc));
                 }
+                feat += acc;
             }
             if (c < 3) gin[c] = pos[c];
             gin[3 + c] = feat;
@@ -895,10 +935,17 @@ __global__ void __launch_bounds__(256)
 sdf_train_reduce_kernel(const float* __restrict__ partials, int rows, int row_stride, int H, int in_dim, float* __restrict__ gw1,
                         float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2, float* __restrict__ loss,
                         float inv_batch) {
+    // 16 lanes per entry: lane r adds rows r, r + 16, ... in order, then a fixed butterfly over the 16 lanes
     const int n_entries = H * in_dim + 2 * H + 2;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += gridDim.x * blockDim.x) {
+    const int r0 = threadIdx.x & 15;
+    for (int e = blockIdx.x * 16 + (threadIdx.x >> 4); e < n_entries + 15; e += gridDim.x * 16) {      // (whole groups stay together)
+        const bool in = e < n_entries;
         float acc = 0.0f;
-        for (int r = 0; r < rows; ++r) acc += partials[(int64_t)r * row_stride + e];          // workgroup order
+        if (in)
+            for (int r = r0; r < rows; r += 16) acc += partials[(int64_t)r * row_stride + e];
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 16);
+        if (!in || r0 != 0) continue;
         if (e < H * in_dim) gw1[e] += acc;
         else if (e < H * in_dim + H) gb1[e - H * in_dim] += acc;
         else if (e < H * in_dim + 2 * H) gw2[e - H * in_dim - H] += acc;
@@ -947,22 +994,24 @@ extern "C" int wisp_sdf_train_step(const float* coords, const float* gts, int64_
     float* partials = static_cast<float*>(scratch);
     float* dfeat = partials + (size_t)grid * row_stride;
     int64_t* chain = reinterpret_cast<int64_t*>(reinterpret_cast<unsigned char*>(dfeat) + sg_round64(n * channels * 4));
-    const size_t lds = ((size_t)hidden * (in_dim | 1) + 2 * hidden + (size_t)ST_GROUPS * (in_dim + 2 * hidden + 2)) * 4;
+    const size_t lds = ((size_t)hidden * (in_dim | 1) + 2 * hidden + (size_t)ST_GROUPS * (in_dim + 2 * hidden + 2 + SG_MAX_LODS)) * 4;
     const float inv_batch = 1.0f / (float)n;
     if (hipMemsetAsync(hdr, 0, sizeof(SgHeader), s) != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, "hipMemsetAsync failed");
     if (const hipError_t e = WISP_ALLOW_LDS(sdf_train_kernel, lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
     hipLaunchKernelGGL(sdf_train_kernel, dim3(grid), dim3(ST_GROUP * ST_GROUPS), lds, s, coords, gts, n, octree, exsum, points,
                        trinkets, fld, inv_batch, partials, row_stride, dfeat, chain, hdr);
-    hipLaunchKernelGGL(sdf_train_reduce_kernel, dim3(min((hidden * in_dim + 2 * hidden + 2 + 255) / 256, 16)), dim3(256), 0, s,
+    hipLaunchKernelGGL(sdf_train_reduce_kernel, dim3((hidden * in_dim + 2 * hidden + 2 + 15) / 16), dim3(256), 0, s,
                        partials, grid, row_stride, hidden, in_dim, grad_w1, grad_b1, grad_w2, grad_b2, loss, inv_batch);
     // the corner sums: the magnitude bound is in the header already (sdf_train_kernel), so only scatter + row pass
     SgCall c{coords, chain, 1, num_lods, 1, points, trinkets, dfeat, n, num_lods, channels, 1, channels};
     uint8_t* flags = sg_use_flags(c, pl) ? ws + pl.off_flags : nullptr;
     long long* acc = reinterpret_cast<long long*>(ws + pl.off_acc);
     const int clog = sg_clog(n);
-    hipLaunchKernelGGL((spc_grad_scatter_wide_kernel<int64_t>), dim3((unsigned)min64(ceil_div64(n, 256 / channels), 16384)), dim3(256), 0, s,
-                       coords, chain, (int64_t)num_lods, 1, points, trinkets, ml, dfeat, n, num_lods, channels, 1, clog, pl.stride,
-                       channels, hdr, flags, acc);
+    const int split = sg_split_lods(c);
+    hipLaunchKernelGGL((spc_grad_scatter_wide_kernel<int64_t>),
+                       dim3((unsigned)min64(ceil_div64(n * (split ? num_lods : 1), 256 / channels), 16384)), dim3(256), 0, s, coords, chain,
+                       (int64_t)num_lods, 1, points, trinkets, ml, dfeat, n, num_lods, channels, 1, clog, pl.stride, channels, hdr, flags,
+                       acc, split);
     int lpr = 1;
     while (lpr < channels && lpr < 64) lpr <<= 1;
     if (pl.total_rows > 0)
