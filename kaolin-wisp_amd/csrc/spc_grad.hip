@@ -712,11 +712,12 @@ extern "C" int wisp_codebook_trilinear_multi_bwd(const float* coords, const int6
 // The reference issues ~60 kernels for it (a query, six trilinear lookups, two GEMMs with their elementwise companions, the
 // loss, and all of that again backwards); the modular path of this package 20.  At 512 coordinates every one of them is
 // launch latency.  Here:
-//   sdf_train_kernel     16 lanes own a sample (as in sdf_trace_fused_kernel, same statements for walk and interpolation:
-//                        bit-identical features): octree walk, the six trilinear lookups, decoder forward, d loss / d pred,
-//                        decoder backward.  Lane c keeps hidden units c, c + 16, ...; the gradient of the decoder input is
-//                        a column sum over LDS.  Per workgroup the weight gradients are summed over its 16 samples by the
-//                        thread that owns the entry, in sample order, and stored as one partial row - no atomics.  The
+//   sdf_train_kernel     16 lanes per (sample, level) walk the octree to the level's cell and blend its corners (the statements
+//                        of sdf_trace_fused_kernel: bit-identical features; all levels of a sample at once, so the dependent
+//                        loads of the walk cost the deepest level's, not the sum); then 16 lanes per sample run the decoder
+//                        forward, d loss / d pred and the decoder backward: lane c keeps hidden units c, c + 16, ..., the
+//                        gradient of the decoder input is a column sum over LDS.  Per workgroup the weight gradients are
+//                        summed by the thread that owns the entry, in sample order, and stored as one partial row - no atomics.  The
 //                        sample's feature gradient [16] and cell chain go to scratch; the workgroup's largest |w g| goes to
 //                        the header of the order-free scatter below, which therefore needs no magnitude pass of its own.
 //   sdf_train_reduce     adds the partial rows up in workgroup order, ADDS the sums to the decoder's gradient tensors, writes
@@ -727,7 +728,6 @@ extern "C" int wisp_codebook_trilinear_multi_bwd(const float* coords, const int6
 #define ST_GROUPS 16                       // samples per workgroup pass
 #define ST_MAX_HIDDEN 256
 #define ST_MAX_IN 32
-#define ST_UNROLL_LODS 8
 
 struct StField {
     const float* feats[SG_MAX_LODS];
@@ -747,103 +747,64 @@ sdf_train_kernel(const float* __restrict__ coords, const float* __restrict__ gts
                  float* __restrict__ dfeat /* [n][channels] */, int64_t* __restrict__ chain /* [n][num_lods] */,
                  SgHeader* __restrict__ hdr) {
     extern __shared__ float s_st[];
-    const int C = fld.channels, H = fld.hidden;
+    const int C = fld.channels, H = fld.hidden, NL = fld.num_lods;
     const int in_dim = 3 + C;
     const int in_pad = in_dim | 1;                      // odd row stride: the lanes of a group read different rows
+    const int spb = ST_GROUPS / NL;                     // samples per workgroup pass: one lane group per (sample, level)
     float* s_w1 = s_st;                                 // [H][in_pad]
     float* s_b1 = s_w1 + H * in_pad;                    // [H]
     float* s_w2 = s_b1 + H;                             // [H]
-    float* s_in = s_w2 + H;                             // [groups][in_dim]     decoder inputs of the pass
-    float* s_ga = s_in + ST_GROUPS * in_dim;            // [groups][H]          d loss / d pre-activation
-    float* s_gr = s_ga + ST_GROUPS * H;                 // [groups][H]          d loss / d pred * relu output (for d w2)
-    float* s_g = s_gr + ST_GROUPS * H;                  // [groups]             d loss / d pred
-    float* s_sq = s_g + ST_GROUPS;                      // [groups]             squared error
-    int32_t* s_nodes = reinterpret_cast<int32_t*>(s_sq + ST_GROUPS);   // [groups][SG_MAX_LODS]  the sample's cell on every level
+    float* s_in = s_w2 + H;                             // [spb][in_dim]        decoder inputs of the pass
+    float* s_ga = s_in + ST_GROUPS * in_dim;            // [spb][H]             d loss / d pre-activation
+    float* s_gr = s_ga + ST_GROUPS * H;                 // [spb][H]             d loss / d pred * relu output (for d w2)
+    float* s_g = s_gr + ST_GROUPS * H;                  // [spb]                d loss / d pred
+    float* s_sq = s_g + ST_GROUPS;                      // [spb]                squared error
+    float* s_lev = s_sq + ST_GROUPS;                    // [groups][C]          one level's lookup of one sample
+    float* s_wm = s_lev + ST_GROUPS * ST_GROUP;         // [groups]             its largest corner weight
     for (int e = threadIdx.x; e < H * in_dim; e += blockDim.x) s_w1[(e / in_dim) * in_pad + e % in_dim] = fld.w1[e];
     for (int e = threadIdx.x; e < H; e += blockDim.x) { s_b1[e] = fld.b1[e]; s_w2[e] = fld.w2[e]; }
     const int c = threadIdx.x & (ST_GROUP - 1);
     const int grp = threadIdx.x / ST_GROUP;
     const int L = fld.max_level;
     const float b2 = fld.b2[0];
-    // partial sums of the entries this thread owns: d W1 [H][in_dim], d b1 [H], d w2 [H], d b2, loss - in that order
+    // partial sums of this workgroup: d W1 [H][in_dim], d b1 [H], d w2 [H], d b2, loss - in that order; every entry has one owner
     const int n_entries = H * in_dim + 2 * H + 2;
-    constexpr int OWN = (ST_MAX_HIDDEN * (ST_MAX_IN + 2) + 2 + ST_GROUP * ST_GROUPS - 1) / (ST_GROUP * ST_GROUPS);
-    float own[OWN];
-#pragma unroll
-    for (int k = 0; k < OWN; ++k) own[k] = 0.0f;
+    float* s_own = s_wm + ST_GROUPS;                    // [n_entries]
+    for (int e = threadIdx.x; e < n_entries; e += blockDim.x) s_own[e] = 0.0f;
     uint32_t mbits = 0;
+    const int my_si = grp / NL, my_li = grp - my_si * NL;                 // phase 1: this group's (sample of the pass, level)
     __syncthreads();
-    for (int64_t base = (int64_t)blockIdx.x * ST_GROUPS; base < n; base += (int64_t)gridDim.x * ST_GROUPS) {
-        const int64_t s = base + grp;
-        const bool live = s < n;
-        float* gin = s_in + grp * in_dim;
-        float* ga = s_ga + grp * H;
-        float* gr = s_gr + grp * H;
-        float wmax = 0.0f;
-        if (live) {
-            const float px = coords[s * 3], py = coords[s * 3 + 1], pz = coords[s * 3 + 2];
-            // ---- the cell of every active level (spc_query_kernel's walk) and the features
-            const bool inside = (fabsf(px) <= 1.0f) && (fabsf(py) <= 1.0f) && (fabsf(pz) <= 1.0f);
-            const float res = (float)(1 << L);
-            const int top = (1 << L) - 1;
-            const int qx = min((int)floorf(res * (0.5f * px + 0.5f)), top);
-            const int qy = min((int)floorf(res * (0.5f * py + 0.5f)), top);
-            const int qz = min((int)floorf(res * (0.5f * pz + 0.5f)), top);
-            const float pos[3] = {px, py, pz};
-            // the walk is a chain of dependent loads (one round trip per level); the lookups are not: their cells are parked
-            // first and then read with all loads of all levels in flight together
-            int32_t* s_node = s_nodes + grp * SG_MAX_LODS;
-            int64_t node = inside ? 0 : -1;
-            int li = 0;
-            for (int l = 0; l <= L && li < fld.num_lods; ++l) {
-                if (l == fld.level[li]) {
-                    if (c == 0) { s_node[li] = (int32_t)node; chain[s * fld.num_lods + li] = node; }
-                    ++li;
-                }
-                if (l < L && node >= 0) {
+    for (int64_t base = (int64_t)blockIdx.x * spb; base < n; base += (int64_t)gridDim.x * spb) {
+        // ---- phase 1: every (sample, level) pair on its own lane group: walk to the level's cell, trilinear lookup.  The walk
+        //      is a chain of dependent loads; six groups walking at once cost the time of the deepest one
+        {
+            const int64_t s = base + my_si;
+            float acc = 0.0f, wm = 0.0f;
+            if (my_si < spb && s < n) {
+                const float px = coords[s * 3], py = coords[s * 3 + 1], pz = coords[s * 3 + 2];
+                const bool inside = (fabsf(px) <= 1.0f) && (fabsf(py) <= 1.0f) && (fabsf(pz) <= 1.0f);
+                const float res = (float)(1 << L);
+                const int top = (1 << L) - 1;
+                const int qx = min((int)floorf(res * (0.5f * px + 0.5f)), top);
+                const int qy = min((int)floorf(res * (0.5f * py + 0.5f)), top);
+                const int qz = min((int)floorf(res * (0.5f * pz + 0.5f)), top);
+                const float pos[3] = {px, py, pz};
+                const int lv = fld.level[my_li];
+                int64_t node = inside ? 0 : -1;
+                for (int l = 0; l < lv && node >= 0; ++l) {               // (spc_query_kernel's walk)
                     const int cs = st_child_slot(qx, qy, qz, L - 1 - l);
                     const uint32_t bits = octree[node];
                     node = ((bits >> cs) & 1u) ? (int64_t)exsum[node] + __popc(bits & ((2u << cs) - 1u)) : -1;
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            float feat = 0.0f;                               // channel c, summed over the levels
-#pragma unroll
-            for (int q = 0; q < ST_UNROLL_LODS; ++q) {
-                if (q < fld.num_lods) {
-                    const int32_t nd = s_node[q];
-                    float acc = 0.0f;
-                    if (nd >= 0) {
-                        float w[8];
-                        sg_coeffs(pos, points + (int64_t)nd * 3, fld.level[q], w);
-                        float wm = 0.0f;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) wm = fmaxf(wm, fabsf(w[j]));
-                        wmax = fmaxf(wmax, wm);
-                        const int32_t* tr = trinkets + (int64_t)nd * 8;
-                        const float* f = fld.feats[q];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            float fv = f[(int64_t)tr[j] * C + c];
-                            if (fld.half_round) fv = __half2float(__float2half_rn(fv));
-                            acc += fv * w[j];
-                        }
-                        if (fld.half_round) acc = __half2float(__float2half_rn(acc));
-                    }
-                    feat += acc;
-                }
-            }
-            for (int q = ST_UNROLL_LODS; q < fld.num_lods; ++q) {            // (more levels than the unrolled eight: one by one)
-                const int32_t nd = s_node[q];
-                float acc = 0.0f;
-                if (nd >= 0) {
+                if (c == 0) chain[s * NL + my_li] = node;
+                if (node >= 0) {
                     float w[8];
-                    sg_coeffs(pos, points + (int64_t)nd * 3, fld.level[q], w);
-                    float wm = 0.0f;
+                    sg_coeffs(pos, points + node * 3, lv, w);
+#pragma unroll
                     for (int j = 0; j < 8; ++j) wm = fmaxf(wm, fabsf(w[j]));
-                    wmax = fmaxf(wmax, wm);
-                    const int32_t* tr = trinkets + (int64_t)nd * 8;
-                    const float* f = fld.feats[q];
+                    const int32_t* tr = trinkets + node * 8;
+                    const float* f = fld.feats[my_li];
+#pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         float fv = f[(int64_t)tr[j] * C + c];
                         if (fld.half_round) fv = __half2float(__float2half_rn(fv));
@@ -851,15 +812,31 @@ sdf_train_kernel(const float* __restrict__ coords, const float* __restrict__ gts
                     }
                     if (fld.half_round) acc = __half2float(__float2half_rn(acc));
                 }
-                feat += acc;
             }
-            if (c < 3) gin[c] = pos[c];
+            s_lev[grp * ST_GROUP + c] = acc;
+            if (c == 0) s_wm[grp] = wm;
+        }
+        __syncthreads();
+        // ---- phase 2: group si owns sample si of the pass: decoder forward, d loss / d pred, decoder backward
+        const int64_t s = base + grp;
+        const bool live = grp < spb && s < n;
+        float* gin = s_in + grp * in_dim;
+        float* ga = s_ga + grp * H;
+        float* gr = s_gr + grp * H;
+        float wmax = 0.0f;
+        if (live) {
+            float feat = 0.0f;                                            // channel c, summed over the levels in order
+            for (int li = 0; li < NL; ++li) {
+                feat += s_lev[(grp * NL + li) * ST_GROUP + c];
+                wmax = fmaxf(wmax, s_wm[grp * NL + li]);
+            }
+            if (c < 3) gin[c] = coords[s * 3 + c];
             gin[3 + c] = feat;
         }
         __builtin_amdgcn_wave_barrier();                 // a group's lanes are in one wave: LDS order suffices
         float g = 0.0f;
         if (live) {
-            // ---- decoder forward: in = [position, features] (neural_sdf.py: embedded position first)
+            // decoder forward: in = [position, features] (neural_sdf.py: embedded position first)
             float out = 0.0f;
             for (int hh = c; hh < H; hh += ST_GROUP) {
                 const float* wr = s_w1 + hh * in_pad;
@@ -876,7 +853,7 @@ sdf_train_kernel(const float* __restrict__ coords, const float* __restrict__ gts
             g = 2.0f * diff * inv_batch;                 // d [sum (pred - gt)^2 / B] / d pred
             for (int hh = c; hh < H; hh += ST_GROUP) { ga[hh] *= g; gr[hh] *= g; }
             if (c == 0) { s_g[grp] = g; s_sq[grp] = diff * diff; }
-        } else {
+        } else if (grp < spb) {
             for (int hh = c; hh < H; hh += ST_GROUP) { ga[hh] = 0.0f; gr[hh] = 0.0f; }
             if (c < 3) gin[c] = 0.0f;
             gin[3 + c] = 0.0f;
@@ -884,7 +861,7 @@ sdf_train_kernel(const float* __restrict__ coords, const float* __restrict__ gts
         }
         __builtin_amdgcn_wave_barrier();
         if (live) {
-            // ---- gradient of the decoder input, feature columns only (nothing consumes d / d position)
+            // gradient of the decoder input, feature columns only (nothing consumes d / d position)
             float dx = 0.0f;
             for (int hh = 0; hh < H; ++hh) dx = __builtin_fmaf(ga[hh], s_w1[hh * in_pad + 3 + c], dx);
             dfeat[s * C + c] = dx;
@@ -893,40 +870,28 @@ sdf_train_kernel(const float* __restrict__ coords, const float* __restrict__ gts
             mbits = nb > mbits ? nb : mbits;
         }
         __syncthreads();
-        // ---- weight gradients of this pass: the thread that owns an entry adds the samples up in order
-#pragma unroll
-        for (int k = 0; k < OWN; ++k) {
-            const int e = (int)threadIdx.x + k * (ST_GROUP * ST_GROUPS);
-            if (e >= n_entries) break;
+        // ---- phase 3: weight gradients of this pass: the thread that owns an entry adds the samples up in order
+        for (int e = threadIdx.x; e < n_entries; e += blockDim.x) {
             float acc = 0.0f;
             if (e < H * in_dim) {
                 const int hh = e / in_dim, i = e - hh * in_dim;
-#pragma unroll
-                for (int q = 0; q < ST_GROUPS; ++q) acc = __builtin_fmaf(s_ga[q * H + hh], s_in[q * in_dim + i], acc);
+                for (int q = 0; q < spb; ++q) acc = __builtin_fmaf(s_ga[q * H + hh], s_in[q * in_dim + i], acc);
             } else if (e < H * in_dim + H) {
                 const int hh = e - H * in_dim;
-#pragma unroll
-                for (int q = 0; q < ST_GROUPS; ++q) acc += s_ga[q * H + hh];
+                for (int q = 0; q < spb; ++q) acc += s_ga[q * H + hh];
             } else if (e < H * in_dim + 2 * H) {
                 const int hh = e - H * in_dim - H;
-#pragma unroll
-                for (int q = 0; q < ST_GROUPS; ++q) acc += s_gr[q * H + hh];
+                for (int q = 0; q < spb; ++q) acc += s_gr[q * H + hh];
             } else if (e == H * in_dim + 2 * H) {
-#pragma unroll
-                for (int q = 0; q < ST_GROUPS; ++q) acc += s_g[q];
+                for (int q = 0; q < spb; ++q) acc += s_g[q];
             } else {
-#pragma unroll
-                for (int q = 0; q < ST_GROUPS; ++q) acc += s_sq[q];
+                for (int q = 0; q < spb; ++q) acc += s_sq[q];
             }
-            own[k] += acc;
+            s_own[e] += acc;
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int k = 0; k < OWN; ++k) {
-        const int e = (int)threadIdx.x + k * (ST_GROUP * ST_GROUPS);
-        if (e < n_entries) partials[(int64_t)blockIdx.x * row_stride + e] = own[k];
-    }
+    for (int e = threadIdx.x; e < n_entries; e += blockDim.x) partials[(int64_t)blockIdx.x * row_stride + e] = s_own[e];
     mbits = sg_wave_umax(mbits);
     if ((threadIdx.x & 63) == 0 && mbits > __atomic_load_n(&hdr->absmax_bits, __ATOMIC_RELAXED)) atomicMax(&hdr->absmax_bits, mbits);
 }
@@ -954,12 +919,12 @@ sdf_train_reduce_kernel(const float* __restrict__ partials, int rows, int row_st
     }
 }
 
-static inline int st_grid(int64_t n) { return (int)min64(ceil_div64(n, ST_GROUPS), 512); }
+static inline int st_grid(int64_t n, int num_lods) { return (int)min64(ceil_div64(n, ST_GROUPS / num_lods), 1024); }
 static inline int st_row_stride(int hidden, int channels) { return (hidden * (3 + channels) + 2 * hidden + 2 + 15) / 16 * 16; }
 
 extern "C" int64_t wisp_sdf_train_scratch_bytes(int64_t n, int num_lods, int channels, int hidden) {
-    if (n < 0 || num_lods < 1 || channels < 1 || hidden < 1) return -1;
-    return (int64_t)st_grid(n) * st_row_stride(hidden, channels) * 4 + sg_round64(n * channels * 4) + n * num_lods * 8;
+    if (n < 0 || num_lods < 1 || num_lods > SG_MAX_LODS || channels < 1 || hidden < 1) return -1;
+    return (int64_t)st_grid(n, num_lods) * st_row_stride(hidden, channels) * 4 + sg_round64(n * channels * 4) + n * num_lods * 8;
 }
 
 extern "C" int wisp_sdf_train_step(const float* coords, const float* gts, int64_t n, const uint8_t* octree, const int32_t* exsum,
@@ -990,11 +955,12 @@ extern "C" int wisp_sdf_train_step(const float* coords, const float* gts, int64_
     hipStream_t s = (hipStream_t)stream;
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     SgHeader* hdr = reinterpret_cast<SgHeader*>(ws);
-    const int grid = st_grid(n), row_stride = st_row_stride(hidden, channels), in_dim = 3 + channels;
+    const int grid = st_grid(n, num_lods), row_stride = st_row_stride(hidden, channels), in_dim = 3 + channels;
     float* partials = static_cast<float*>(scratch);
     float* dfeat = partials + (size_t)grid * row_stride;
     int64_t* chain = reinterpret_cast<int64_t*>(reinterpret_cast<unsigned char*>(dfeat) + sg_round64(n * channels * 4));
-    const size_t lds = ((size_t)hidden * (in_dim | 1) + 2 * hidden + (size_t)ST_GROUPS * (in_dim + 2 * hidden + 2 + SG_MAX_LODS)) * 4;
+    const size_t lds = ((size_t)hidden * (in_dim | 1) + 2 * hidden + (size_t)ST_GROUPS * (in_dim + 2 * hidden + 2 + ST_GROUP + 1) +
+                        (size_t)hidden * in_dim + 2 * hidden + 2) * 4;
     const float inv_batch = 1.0f / (float)n;
     if (hipMemsetAsync(hdr, 0, sizeof(SgHeader), s) != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, "hipMemsetAsync failed");
     if (const hipError_t e = WISP_ALLOW_LDS(sdf_train_kernel, lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
