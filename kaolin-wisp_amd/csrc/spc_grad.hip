@@ -793,8 +793,10 @@ sdf_train_kernel(const float* __restrict__ coords, const float* __restrict__ gts
                 int64_t node = inside ? 0 : -1;
                 for (int l = 0; l < lv && node >= 0; ++l) {               // (spc_query_kernel's walk)
                     const int cs = st_child_slot(qx, qy, qz, L - 1 - l);
-                    const uint32_t bits = octree[node];
-                    node = ((bits >> cs) & 1u) ? (int64_t)exsum[node] + __popc(bits & ((2u << cs) - 1u)) : -1;
+                    const uint32_t bits = octree[node];                   // both loads of a level go out together: one round
+                    const int64_t first = (int64_t)exsum[node];           // trip per level, not two
+                    const int64_t child = first + __popc(bits & ((2u << cs) - 1u));
+                    node = ((bits >> cs) & 1u) ? child : -1;
                 }
                 if (c == 0) chain[s * NL + my_li] = node;
                 if (node >= 0) {
