@@ -11,6 +11,7 @@ import torch
 from wisp.core import RenderBuffer
 from wisp.tracers.base_tracer import BaseTracer
 import wisp.ops.render as render_ops
+from wisp.tracers import _fused_trace as _fused
 
 
 class PackedRFTracer(BaseTracer):
@@ -67,14 +68,18 @@ class PackedRFTracer(BaseTracer):
         self.prev_num_samples = num_samples
 
         hit_ray_d = rays.dirs.index_select(0, ridx)
-        color, density = nef(coords=samples, ray_d=hit_ray_d, lod_idx=lod_idx, channels=["rgb", "density"])
-        density = density.reshape(num_samples, 1)
         if self.bg_color.device != rays.origins.device:
             self.bg_color = self.bg_color.to(rays.origins.device)
         bg = self._bg_host()
-
         want_depth = "depth" in channels
         ray_offsets = getattr(rm, "ray_offsets", None)
+        if ray_offsets is not None and _fused.supports(nef, lod_idx, extra_channels):
+            # the shipped NeRF shape: lookup, decoder and compositing as ONE autograd node (same kernels, same numbers)
+            rgb, alpha, depth, hit = _fused.fused_trace(nef, samples, hit_ray_d, deltas, depths if want_depth else None, ray_offsets, N,
+                                                        bg, lod_idx)
+            return RenderBuffer(depth=depth, hit=hit, rgb=rgb, alpha=alpha)
+        color, density = nef(coords=samples, ray_d=hit_ray_d, lod_idx=lod_idx, channels=["rgb", "density"])
+        density = density.reshape(num_samples, 1)
         if ray_offsets is not None and not extra_channels:
             # every ray is its own (possibly empty) pack: no boundary compaction, no host read of the pack count
             rgb, alpha, depth, hit = render_ops.composite(color, density, deltas, depths if want_depth else None, None,

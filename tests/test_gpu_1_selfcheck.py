@@ -1020,3 +1020,55 @@ def test_fused_sdf_train_step_equals_the_modular_launches_and_repeats_bitwise(ba
     # and it trains: a few real steps bring the loss down
     losses = [float(fused.step(coords, gts)) for _ in range(30)]
     assert losses[-1] < 0.7 * losses[0]
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_tracer_as_one_autograd_node_equals_the_modular_graph_bit_for_bit(amp, monkeypatch):
+    """PackedRFTracer.trace with the shipped NeRF shape runs lookup, decoder and compositing as ONE autograd node
+    (wisp/tracers/_fused_trace.py: the three Functions' own forward / backward bodies back to back) - against the modular graph
+    (WISP_FUSED_TRACE=0) on an unchanged-trainer style model (separate parameter tensors, torch.optim): same rgb / alpha / depth /
+    hit, same gradient in every parameter, bit for bit, without and with fp16 autocast + a loss scale."""
+    import copy
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.tracers import PackedRFTracer, _fused_trace
+    nef, _, _ = _build_pair(lods=16)
+    nef2 = copy.deepcopy(nef)
+    o, d = make_rays(500, 391)
+    jit = cuda(np.random.default_rng(392).uniform(size=(500, 96)).astype(np.float32))
+    gts = cuda(np.random.default_rng(393).uniform(size=(500, 3)).astype(np.float32))
+    rays = Rays(cuda(o), cuda(d), dist_min=1.0, dist_max=5.0)
+    outs = {}
+    for name, model, enabled in (("fused", nef, True), ("modular", nef2, False)):
+        monkeypatch.setattr(_fused_trace, "ENABLED", enabled)
+        pipe = Pipeline(model, PackedRFTracer(raymarch_type='ray', num_steps=96, bg_color=(0.1, 0.2, 0.3)))
+        with torch.autocast('cuda', enabled=amp):
+            rb = pipe(rays=rays, channels=["rgb", "alpha", "depth", "hit"], jitter=jit)
+            loss = torch.nn.functional.smooth_l1_loss(rb.rgb, gts, reduction='none').mean() + 0.1 * ((1.0 - rb.alpha) ** 2).mean() \
+                + 1e-3 * rb.depth.mean()
+        node_names = set()
+        stack = [loss.grad_fn]
+        while stack:
+            fn = stack.pop()
+            if fn is None or fn in node_names:
+                continue
+            node_names.add(fn)
+            stack.extend(f for f, _ in fn.next_functions)
+        kinds = {type(f).__name__ for f in node_names}
+        (loss * (65536.0 if amp else 1.0)).backward()
+        outs[name] = (rb, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, kinds)
+    assert any("_FusedTrace" in k for k in outs["fused"][2]) and not any("_FusedTrace" in k for k in outs["modular"][2])
+    assert not any(k.startswith(("HashGridInterpolate", "_FusedDecoder", "_Composite")) for k in outs["fused"][2])
+    a, b = outs["fused"][0], outs["modular"][0]
+    for ch in ("rgb", "alpha", "depth", "hit"):
+        assert torch.equal(getattr(a, ch), getattr(b, ch)), ch
+    ga, gb = outs["fused"][1], outs["modular"][1]
+    assert set(ga) == set(gb) and len(ga) == 11
+    # (this batch is below the binned backward's size: the table gradient goes through float atomics on both sides, whose order is
+    #  free - everything else is bit-identical)
+    for n in ga:
+        if 'codebook' in n:
+            sc = float(gb[n].abs().max())
+            assert float((ga[n] - gb[n]).abs().max()) <= 2e-6 * sc, n
+        else:
+            assert torch.equal(ga[n], gb[n]), n
