@@ -278,8 +278,10 @@ def dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev):
             "rays_per_step_per_gpu": rays / args.dropin_steps / world, "samples_per_step_per_gpu": samples / args.dropin_steps / world,
             "loss_scale_at_end": float(tr.scaler.get_scale()), "dtype": "fp16 autocast + GradScaler (tables fp16, decoder bf16 MFMA)",
             "note": "wisp.trainers.MultiviewTrainer.iterate(): the reference trainer's own step semantics (multiview_trainer.py:111-180, "
-                    "base_trainer.py:205-246,316-342) - autograd over the modular pipeline, torch.optim.AdamW, MultiStepLR, SampleRays, "
-                    "loss .item() read-backs; no gradient all-reduce (the reference has none): with N > 1 this is N independent replicas"}
+                    "base_trainer.py:205-246,316-342) - autograd over the pipeline (PackedRFTracer.trace differentiates lookup + decoder + "
+                    "compositing as one node), torch.optim.AdamW, GradScaler, MultiStepLR, SampleRays, loss .item() read-backs, the prune "
+                    "every 100 iterations inside the timed ones; no gradient all-reduce (the reference has none): with N > 1 this is N "
+                    "independent replicas"}
 
 
 # algorithmic work per packed sample (SURVEY.md 8d / DESIGN.md 4): bytes for the HBM-bound kernels, flops for the decoder
@@ -620,6 +622,8 @@ def main(argv=None):
                                  "value": ref_rays_total / ref_elapsed, "unit": "rays/s",
                                  "ms_per_step": 1e3 * ref_elapsed / args.steps, "samples_per_sec": ref_samples_all / ref_elapsed,
                                  "prunes_inside_timed_steps": ref_prunes, "hip_event_timing_inside_the_loop": False,
+                                 # (what the prunes that fell into the window cost: round 3's 0.362 -> 0.389 ms was two of them)
+                                 "ms_per_step_without_its_prunes": 1e3 * (ref_elapsed - ref_prunes * prune_ms * 1e-3) / args.steps,
                                  "note": "multiview_trainer.py:58 default batch (2^18 packed samples per step), same run"},
             "dropin_regime": dropin, "comm": comm,
             "psnr_db": psnr, "optimisation_steps_before_psnr": trainer.total_iterations,

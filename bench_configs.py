@@ -51,11 +51,28 @@ def _busy_union_ms(sink):
     return busy + (cur_e - cur_s), max(e for _, e in spans) - spans[0][0]
 
 
+# entry points whose time is NOT set by HBM bytes, with what sets it (measured: profiles/); their byte model
+# is still reported, under `hbm_model`, because SURVEY 8(d) prescribes it
+NOT_HBM_BOUND = {
+    "codebook_trilinear_multi_bwd": (
+        "valu+atomics",
+        "tables of 0.2 M rows sit in L2 / Infinity Cache; the launch is the wave-level run merge (320 DPP / packed-fma instructions per "
+        "sample and level, ~115 us of its ~220 us scatter at 2 M samples) plus ~3 M row-wide 64-bit atomic requests retired on the memory "
+        "side (~95 us: the same kernel with the atomics compiled out, scripts/gpu_r4_c.sh), a magnitude pass (32 us) and the row pass (32 us)"),
+}
+
+
 def _roofline(kernels, bytes_per_launch, steps):
     """dominant C-ABI entry point of the step vs the HBM roofline, when its algorithmic bytes are known."""
     for name, v in kernels.items():
         if name in bytes_per_launch:
             achieved = bytes_per_launch[name] / (v["avg_ms"] * 1e-3) / 1e9
+            model = dict(achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                         algorithmic_bytes_per_launch=bytes_per_launch[name])
+            if name in NOT_HBM_BOUND:
+                bound, why = NOT_HBM_BOUND[name]
+                return dict(bound=bound, kernel=name, achieved=None, peak=None, unit=None, frac=None, traffic=None, avg_launch_ms=v["avg_ms"],
+                            share_of_kernel_time=v["share"], hbm_model=model, note=why)
             return dict(bound="hbm", kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                         traffic=None, avg_launch_ms=v["avg_ms"], algorithmic_bytes_per_launch=bytes_per_launch[name],
                         share_of_kernel_time=v["share"])
