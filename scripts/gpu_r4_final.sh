@@ -55,5 +55,5 @@ if has sq; then
     python scripts/pmc_summary.py /tmp/sq_$i > $OUT/r04_pmc_sq_group$i.csv 2>> $OUT/sq_$i.log
     wc -l $OUT/r04_pmc_sq_group$i.csv
   done
-  python scripts/sq_summary.py $OUT/r04_pmc_sq_group1.csv $OUT/r04_pmc_sq_group2.csv $OUT/r04_pmc_sq_group3.csv > $OUT/r04_sq_summary.txt 2>&1; head -30 $OUT/r04_sq_summary.txt
+  python scripts/sq_summary.py $OUT/r04_pmc_sq_group > $OUT/r04_sq_summary.txt 2>&1; head -30 $OUT/r04_sq_summary.txt
 fi
