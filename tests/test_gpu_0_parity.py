@@ -1053,6 +1053,39 @@ def test_octree_fields_one_launch_backward_matches_oracle(kind, mtype):
     assert int(ws[64:].count_nonzero()) == 0, "the backward left its scratch dirty"     # (the 64-byte header is reset by every call)
 
 
+@pytest.mark.parametrize("F", [5, 16])
+def test_kaolin_style_leaf_backward_with_several_samples_per_voxel_matches_oracle(F):
+    """The Kaolin-style leaf call - coords [V, S, 3] inside voxels pidx [V] of ONE level (octree_grid.py:147-149) - forward and
+    backward (wisp_spc_trilinear_fwd / _bwd with samples_per_voxel = 4: the thread-per-sample scatter for 5 channels, the
+    lanes-over-channels one for 16) against autograd through the oracle's interpolate_trilinear."""
+    from oracle import octree_grid as og
+    import wisp.ops.grid as G
+    blas, oblas = _sparse_blas(5, 3000, 161)
+    pd, pyd = ospc.make_dual(oblas.points, oblas.pyramid)
+    tr, _ = ospc.make_trinkets(oblas.points, oblas.pyramid, pd, pyd)
+    rng = np.random.default_rng(162)
+    level, V, S = 5, 900, 4
+    first = int(oblas.pyramid[1, level])
+    leaf = oblas.level_points().astype(np.float32)
+    pick = rng.integers(0, leaf.shape[0], V)
+    coords = ((leaf[pick][:, None] + rng.uniform(0, 1, (V, S, 3))) / 32.0 * 2 - 1).astype(np.float32)
+    pidx = (first + pick).astype(np.int64)
+    pidx[::17] = -1                                                        # some rows outside
+    rows = int(pyd[0, level])
+    feats = rng.normal(size=(rows, F)).astype(np.float32)
+    w = rng.normal(size=(V, S, F)).astype(np.float32)
+    f_gpu = cuda(feats).requires_grad_(True)
+    trk_local = cuda(tr.astype(np.int32))                                  # (corner indices are local to the level's dual block)
+    out = G.spc_interpolate_trilinear(cuda(coords), cuda(pidx), cuda(oblas.points.astype(np.int16)), trk_local, f_gpu, level,
+                                      half_round=False)
+    (out * cuda(w)).sum().backward()
+    f_cpu = torch.from_numpy(feats).requires_grad_(True)
+    ref = og.interpolate_trilinear(torch.from_numpy(coords), torch.from_numpy(pidx), oblas.points, tr, f_cpu, level)
+    (ref * torch.from_numpy(w)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=1e-5)
+    np.testing.assert_allclose(f_gpu.grad.cpu().numpy(), f_cpu.grad.numpy(), rtol=1e-4, atol=2e-5)
+
+
 def test_octree_fields_backward_propagates_non_finite_gradients():
     """An overflowed loss scale (inf / NaN in the upstream gradient) must reach the feature gradient - GradScaler's found-inf
     check reads it - instead of being wrapped into a finite fixed-point number; and the next, finite, call is unaffected."""
