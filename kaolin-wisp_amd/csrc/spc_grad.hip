@@ -152,7 +152,8 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
                               long long* __restrict__ acc) {
     __shared__ float s_val[SG_THREADS / 64][64][8 * F];
     __shared__ int32_t s_row[SG_THREADS / 64][64][8];
-    __shared__ int32_t s_info[SG_THREADS / 64][64];
+    __shared__ int32_t s_fwd[SG_THREADS / 64][64 * 8];
+    __shared__ int32_t s_bwd[SG_THREADS / 64][64 * 8];
     const SgScale sc = sg_scale(hdr->absmax_bits, clog);
     if (sc.zero) return;                                                 // every product is zero: nothing to add
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,7 +193,7 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
         // coarse levels) are added up before anything goes to memory.  Inside every 16-lane row: a segmented inclusive scan with
         // DPP row shifts - no LDS traffic; per step one predicate for all 8 F values, applied as a 0 / 1 factor (x + t * 1 rounds
         // once, like the add; x + t * 0 is x).  A run that continues across a row boundary leaves a partial total at lane 15;
-        // it is added to the run's final total when the totals are written out (`carry` / `dropped` below).  Same lanes, same
+        // it is added to the run's final total when the totals are written out (the corner links below).  Same lanes, same
         // order of adds every time: the float part of the sum is repeatable, the rest is integer.
         const int lane16 = lane & 15;
         const int key = p >= 0 ? (int)p : -1 - lane;                      // (invalid lanes are their own run)
@@ -223,16 +224,13 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
 #endif
         const uint64_t tmask = __ballot(tail);
         if (tmask == 0) continue;                                         // (wave-uniform)
-        const uint64_t cont = __ballot(joins && lane16 == 0);            // bit 16 r: row r starts inside the run row r-1 ended with
         float (*sv)[8 * F] = s_val[wv];
         int32_t (*sr)[8] = s_row[wv];
+        int32_t* fwd = s_fwd[wv];
+        int32_t* bwd = s_bwd[wv];
+        const int ntails = __popcll(tmask);
         if (tail) {
             const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
-            const int row0 = lane & ~15;
-            const bool first_in_row = ((tmask >> row0) & ((1ull << lane16) - 1ull)) == 0;
-            const bool carry = first_in_row && ((cont >> row0) & 1ull);                       // add the total parked by the tail before
-            const bool dropped = lane16 == 15 && lane < 63 && ((cont >> (row0 + 16)) & 1ull);  // a partial total: parked, not written out
-            s_info[wv][rank] = (carry ? 1 : 0) | (dropped ? 2 : 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 sr[rank][j] = trinkets[p * 8 + j];
@@ -240,21 +238,42 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
                 for (int f = 0; f < F; ++f) sv[rank][j * F + f] = v[j][f];
             }
         }
+        for (int e = lane; e < ntails * 8; e += 64) { fwd[e] = -1; bwd[e] = -1; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // Consecutive tails often name the same table row: the two halves of a run cut by a row boundary (all eight corners), and
+        // - mostly - neighbouring cells of a ray, which share a face (four corners).  A corner whose row reappears in the NEXT tail
+        // hands its total on instead of going to memory; the last tail of such a chain adds the chain up, in order.  What bounds
+        // this kernel is the number of atomic requests, and this removes a third of them.
+        for (int e = lane; e < (ntails - 1) * 8; e += 64) {
+            const int t = e >> 3;
+            const int32_t r = sr[t][e & 7];
+            int hit = -1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hit = sr[t + 1][q] == r ? q : hit;           // (the rows of one cell are distinct)
+            fwd[e] = hit;
+            if (hit >= 0) bwd[(t + 1) * 8 + hit] = e & 7;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // all lanes walk the (tail, corner, channel) items, channel fastest: the F adds of a row sit in neighbouring lanes of ONE
         // atomic instruction (the memory side takes them as one request per 64-byte line)
-        const int items = __popcll(tmask) * 8 * F;
+        const int items = ntails * 8 * F;
         const int64_t base = ml.base[l];
         float* gd = ml.grad[l];
         for (int it = lane; it < items; it += 64) {
             const int t = it / (8 * F), rem = it - t * (8 * F);
             const int j = rem / F, f = rem - j * F;
-            int info = s_info[wv][t];
-            if (info & 2) continue;
+            if (fwd[t * 8 + j] >= 0) continue;                            // handed on to the next tail
             float total = sv[t][rem];
-            for (int k = t; info & 1;) { --k; total += sv[k][rem]; info = s_info[wv][k]; }
+            for (int k = t, jj = j; k > 0;) {
+                const int b = bwd[k * 8 + jj];
+                if (b < 0) break;
+                --k; jj = b;
+                total += sv[k][jj * F + f];
+            }
             const int32_t crow = sr[t][j];
             if (sc.finite) {
                 const int64_t row = base + crow;
