@@ -25,6 +25,9 @@
 
 #define SG_MAX_LODS 16
 #define SG_THREADS 128
+#ifndef SG_LINK_TAILS
+#define SG_LINK_TAILS 8            // a wave links corners across tails when it has more tails than this (see spc_grad_scatter_merge_kernel)
+#endif
 #define CB_MAX_K 256
 #define CB_MAX_F 16
 
@@ -152,6 +155,7 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
                               long long* __restrict__ acc) {
     __shared__ float s_val[SG_THREADS / 64][64][8 * F];
     __shared__ int32_t s_row[SG_THREADS / 64][64][8];
+    __shared__ int32_t s_info[SG_THREADS / 64][64];
     __shared__ int32_t s_fwd[SG_THREADS / 64][64 * 8];
     __shared__ int32_t s_bwd[SG_THREADS / 64][64 * 8];
     const SgScale sc = sg_scale(hdr->absmax_bits, clog);
@@ -229,8 +233,21 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
         int32_t* fwd = s_fwd[wv];
         int32_t* bwd = s_bwd[wv];
         const int ntails = __popcll(tmask);
+        // Consecutive tails often name the same table row: the two halves of a run cut by a row boundary (all eight corners: `carry`
+        // / `dropped`, always honoured) and neighbouring cells of a ray, which share a face (four corners).  A corner whose row
+        // reappears in the NEXT tail can hand its total on instead of going to memory, and the last tail of such a chain adds the
+        // chain up, in order: a third fewer atomic requests - which is what bounds this kernel when runs are short ('ray' march,
+        // 5.7 samples per run: 460 -> 383 us), and costs more than it saves when a wave has a handful of tails ('voxel' march, 16
+        // samples per cell: 222 -> 264 us).  The wave decides by its tail count.
+        const bool links = ntails > SG_LINK_TAILS;
+        const uint64_t cont = __ballot(joins && lane16 == 0);            // bit 16 r: row r starts inside the run row r-1 ended with
         if (tail) {
             const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
+            const int row0 = lane & ~15;
+            const bool first_in_row = ((tmask >> row0) & ((1ull << lane16) - 1ull)) == 0;
+            const bool carry = first_in_row && ((cont >> row0) & 1ull);                       // add the total parked by the tail before
+            const bool dropped = lane16 == 15 && lane < 63 && ((cont >> (row0 + 16)) & 1ull);  // a partial total: parked, not written out
+            s_info[wv][rank] = (carry ? 1 : 0) | (dropped ? 2 : 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 sr[rank][j] = trinkets[p * 8 + j];
@@ -238,26 +255,25 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
                 for (int f = 0; f < F; ++f) sv[rank][j * F + f] = v[j][f];
             }
         }
-        for (int e = lane; e < ntails * 8; e += 64) { fwd[e] = -1; bwd[e] = -1; }
+        if (links)
+            for (int e = lane; e < ntails * 8; e += 64) { fwd[e] = -1; bwd[e] = -1; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // Consecutive tails often name the same table row: the two halves of a run cut by a row boundary (all eight corners), and
-        // - mostly - neighbouring cells of a ray, which share a face (four corners).  A corner whose row reappears in the NEXT tail
-        // hands its total on instead of going to memory; the last tail of such a chain adds the chain up, in order.  What bounds
-        // this kernel is the number of atomic requests, and this removes a third of them.
-        for (int e = lane; e < (ntails - 1) * 8; e += 64) {
-            const int t = e >> 3;
-            const int32_t r = sr[t][e & 7];
-            int hit = -1;
+        if (links) {
+            for (int e = lane; e < (ntails - 1) * 8; e += 64) {
+                const int t = e >> 3;
+                const int32_t r = sr[t][e & 7];
+                int hit = -1;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) hit = sr[t + 1][q] == r ? q : hit;           // (the rows of one cell are distinct)
-            fwd[e] = hit;
-            if (hit >= 0) bwd[(t + 1) * 8 + hit] = e & 7;
+                for (int q = 0; q < 8; ++q) hit = sr[t + 1][q] == r ? q : hit;       // (the rows of one cell are distinct)
+                fwd[e] = hit;
+                if (hit >= 0) bwd[(t + 1) * 8 + hit] = e & 7;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // all lanes walk the (tail, corner, channel) items, channel fastest: the F adds of a row sit in neighbouring lanes of ONE
         // atomic instruction (the memory side takes them as one request per 64-byte line)
         const int items = ntails * 8 * F;
@@ -266,13 +282,19 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
         for (int it = lane; it < items; it += 64) {
             const int t = it / (8 * F), rem = it - t * (8 * F);
             const int j = rem / F, f = rem - j * F;
-            if (fwd[t * 8 + j] >= 0) continue;                            // handed on to the next tail
             float total = sv[t][rem];
-            for (int k = t, jj = j; k > 0;) {
-                const int b = bwd[k * 8 + jj];
-                if (b < 0) break;
-                --k; jj = b;
-                total += sv[k][jj * F + f];
+            if (links) {
+                if (fwd[t * 8 + j] >= 0) continue;                        // handed on to the next tail
+                for (int k = t, jj = j; k > 0;) {
+                    const int b = bwd[k * 8 + jj];
+                    if (b < 0) break;
+                    --k; jj = b;
+                    total += sv[k][jj * F + f];
+                }
+            } else {
+                int info = s_info[wv][t];
+                if (info & 2) continue;
+                for (int k = t; info & 1;) { --k; total += sv[k][rem]; info = s_info[wv][k]; }
             }
             const int32_t crow = sr[t][j];
             if (sc.finite) {
