@@ -156,8 +156,8 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
     __shared__ float s_val[SG_THREADS / 64][64][8 * F];
     __shared__ int32_t s_row[SG_THREADS / 64][64][8];
     __shared__ int32_t s_info[SG_THREADS / 64][64];
-    __shared__ int32_t s_fwd[SG_THREADS / 64][64 * 8];
-    __shared__ int32_t s_bwd[SG_THREADS / 64][64 * 8];
+    __shared__ int8_t s_fwd[SG_THREADS / 64][64 * 8];    // (bytes: the slice must not cost the kernel a workgroup per CU)
+    __shared__ int8_t s_bwd[SG_THREADS / 64][64 * 8];
     const SgScale sc = sg_scale(hdr->absmax_bits, clog);
     if (sc.zero) return;                                                 // every product is zero: nothing to add
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -230,8 +230,8 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
         if (tmask == 0) continue;                                         // (wave-uniform)
         float (*sv)[8 * F] = s_val[wv];
         int32_t (*sr)[8] = s_row[wv];
-        int32_t* fwd = s_fwd[wv];
-        int32_t* bwd = s_bwd[wv];
+        int8_t* fwd = s_fwd[wv];
+        int8_t* bwd = s_bwd[wv];
         const int ntails = __popcll(tmask);
         // Consecutive tails often name the same table row: the two halves of a run cut by a row boundary (all eight corners: `carry`
         // / `dropped`, always honoured) and neighbouring cells of a ray, which share a face (four corners).  A corner whose row
@@ -267,8 +267,8 @@ spc_grad_scatter_merge_kernel(const float* __restrict__ coords, const I* __restr
                 int hit = -1;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) hit = sr[t + 1][q] == r ? q : hit;       // (the rows of one cell are distinct)
-                fwd[e] = hit;
-                if (hit >= 0) bwd[(t + 1) * 8 + hit] = e & 7;
+                fwd[e] = (int8_t)hit;
+                if (hit >= 0) bwd[(t + 1) * 8 + hit] = (int8_t)(e & 7);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
