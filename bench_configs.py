@@ -308,13 +308,19 @@ def run_nglod(args, dev):
     del dtr, twin
     # the same steps replayed from a captured HIP graph (fixed batch size: every shape of the step is static)
     tr.capture(B)
+    static = tr.static_inputs()
+
+    def batch_into_graph():                                  # the loader gathers straight into the captured graph's input buffers
+        idx = torch.randint(0, coords.shape[0], (B,), device=dev, generator=gen)
+        return C.gather_rows(idx, [coords, gts], out=list(static))
+
     for _ in range(args.warmup):
-        x, y = batch()
+        x, y = batch_into_graph()
         tr.step(x, y)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        x, y = batch()
+        x, y = batch_into_graph()
         loss = tr.step(x, y)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

@@ -1203,18 +1203,24 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_d
                                weight_decay, step, grad_scale, int(zero_grad), _p(bf16_shadow), _stream()), "adamw_step")
 
 
-def gather_rows(index, tensors):
+def gather_rows(index, tensors, out=None):
     """[t[index] for t in tensors] for up to 4 fp32 tensors with the same number of rows - one launch, one read of `index`
     (the ray-batch sampling of SampleRays, ray_sampler.py:25-35)."""
     index = _need(index, torch.int64, "index").reshape(-1)
     assert 1 <= len(tensors) <= 4
     rows = tensors[0].shape[0]
     srcs, outs = [], []
-    for t in tensors:
+    for k, t in enumerate(tensors):
         t = _need(t, torch.float32, "tensor")
         assert t.shape[0] == rows and t.is_contiguous()
         srcs.append(t)
-        outs.append(torch.empty((index.shape[0],) + tuple(t.shape[1:]), dtype=torch.float32, device=t.device))
+        shape = (index.shape[0],) + tuple(t.shape[1:])
+        if out is None:
+            outs.append(torch.empty(shape, dtype=torch.float32, device=t.device))
+        else:                                       # `out`: tensors to gather into (e.g. the static inputs of a captured graph)
+            o = out[k]
+            assert o.is_cuda and o.dtype == torch.float32 and o.is_contiguous() and tuple(o.shape) == shape
+            outs.append(o)
     n = len(srcs)
     widths = [int(t.numel() // max(rows, 1)) for t in srcs]
     src_p = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])

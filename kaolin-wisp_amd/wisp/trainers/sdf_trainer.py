@@ -126,18 +126,29 @@ class SDFTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         self.flat.grad.zero_()                                 # the warm-up passes accumulated gradients; parameters untouched
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # (captured on the warm-up stream: the per-(device, stream) scratch the ops keep was created - and zeroed - there; on another
+        #  stream they would allocate it anew INSIDE the capture, and every replay would zero a few MB again)
+        with torch.cuda.graph(graph, stream=side):
             self._g_loss = self._forward_backward(self._g_coords, self._g_gts)
         self.flat.grad.zero_()
         self._graph = graph
         return self
 
+    def static_inputs(self):
+        """(coords [B,3], gts [B,1]) buffers of the captured graph, or None: a loader that fills THESE and hands them to step()
+        spares the two device copies step() otherwise makes into them."""
+        if getattr(self, "_graph", None) is None:
+            return None
+        return self._g_coords, self._g_gts
+
     def step(self, coords, gts):
         """coords [B,3], gts [B,1] on the GPU -> loss tensor (already divided by the batch size, like the reference)."""
         graph = getattr(self, "_graph", None)
         if graph is not None and tuple(coords.shape) == tuple(self._g_coords.shape) and tuple(gts.shape) == tuple(self._g_gts.shape):
-            self._g_coords.copy_(coords)
-            self._g_gts.copy_(gts)
+            if coords is not self._g_coords:
+                self._g_coords.copy_(coords)
+            if gts is not self._g_gts:
+                self._g_gts.copy_(gts)
             graph.replay()
             self.optimizer_step()
             return self._g_loss.clone()
