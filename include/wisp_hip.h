@@ -490,8 +490,9 @@ int wisp_nerf_mlp_bwd(const void* feats, int dtype_io, const float* dirs, int64_
  * sample; the encoding depends on the ray only, so wisp_nerf_mlp_dir_code encodes every ray once
  * (code: bf16 [num_rays, 32], opaque layout) and the *_rays kernels gather the code by `ridx` (int64 [S], the ray of every
  * sample as the raymarch returns it).  Same arithmetic, bit-identical outputs to wisp_nerf_mlp_fwd / _bwd on gathered
- * directions.  Built for the training shape only: in_dim 32, hidden 64, view_freqs 4, f16 / bf16 features, bf16 compute;
- * anything else returns WISP_ERR_UNSUPPORTED (use the per-sample entry points). */
+ * directions.  For the bf16-compute hidden-64 kernels: 1 <= in_dim <= 32 (narrow rows of the octree / codebook / triplanar
+ * fields included since round 4), view_freqs 4, f32 / f16 / bf16 features; anything else returns WISP_ERR_UNSUPPORTED (use the
+ * per-sample entry points). */
 int wisp_nerf_mlp_dir_code(const float* ray_dirs /* [R,3] */, int64_t num_rays, int view_freqs, void* code, wisp_stream_t stream);
 int wisp_nerf_mlp_fwd_rays(const void* feats, int dtype_io, const void* dir_code, const int64_t* ridx, int64_t num_samples,
                            int in_dim, int hidden, int view_freqs, const float* params, float* rgb, float* density,

@@ -553,7 +553,7 @@ extern "C" int wisp_nerf_mlp_dir_code(const float* ray_dirs, int64_t num_rays, i
 
 static int check_rays_shape(int in_dim, int hidden, int view_freqs, int dtype_io) {
     if (hidden != H || view_freqs != NF || !wisp_mlp::bf16_rays_supported(dtype_io, in_dim))
-        return wisp_fail(WISP_ERR_UNSUPPORTED, "nerf_mlp_rays", "per-ray view codes: in_dim 32, hidden 64, view_freqs 4, f16 / bf16 features");
+        return wisp_fail(WISP_ERR_UNSUPPORTED, "nerf_mlp_rays", "per-ray view codes: 1 <= in_dim <= 32, hidden 64, view_freqs 4, f32 / f16 / bf16 features");
     return 0;
 }
 
@@ -564,7 +564,7 @@ extern "C" int wisp_nerf_mlp_fwd_rays(const void* feats, int dtype_io, const voi
     if (int rc = check_rays_shape(in_dim, hidden, view_freqs, dtype_io)) return rc;
     if (num_samples == 0) return WISP_OK;
     WISP_REQUIRE(feats && dir_code && ridx && params && rgb && density, "null pointer");
-    if (int rc = wisp_mlp::bf16_forward_rays(feats, dtype_io, dir_code, ridx, num_samples, params, rgb, density, (hipStream_t)stream))
+    if (int rc = wisp_mlp::bf16_forward_rays(feats, dtype_io, dir_code, ridx, num_samples, in_dim, params, rgb, density, (hipStream_t)stream))
         return rc;
     WISP_CHECK_LAUNCH();
     return WISP_OK;
@@ -580,7 +580,7 @@ extern "C" int wisp_nerf_mlp_bwd_rays(const void* feats, int dtype_io, const voi
     WISP_REQUIRE(feats && dir_code && ridx && params && grad_rgb && grad_density && grad_feats && grad_params && workspace, "null pointer");
     WISP_REQUIRE(workspace_bytes >= wisp_nerf_mlp_bwd_workspace_bytes(num_samples, hidden), "workspace too small (wisp_nerf_mlp_bwd_workspace_bytes)");
     int rows = 0;
-    if (int rc = wisp_mlp::bf16_backward_rays(feats, dtype_io, dir_code, ridx, num_samples, params, grad_rgb, grad_density, grad_feats,
+    if (int rc = wisp_mlp::bf16_backward_rays(feats, dtype_io, dir_code, ridx, num_samples, in_dim, params, grad_rgb, grad_density, grad_feats,
                                               workspace, &rows, (hipStream_t)stream))
         return rc;
     hipLaunchKernelGGL(nerf_mlp_reduce_kernel, dim3((NPARAM + 63) / 64), dim3(1024), 0, (hipStream_t)stream, workspace, rows, in_dim, grad_params);

@@ -223,11 +223,16 @@ dir_code_kernel(const float* __restrict__ dirs, int64_t num_rays, bf16x8* __rest
     code[e * 2] = k1;
     code[e * 2 + 1] = k2;
 }
-template <typename TIO>
+template <typename TIO, bool NARROW>
 DEV void fetch_inputs_coded(const TIO* __restrict__ feats, const bf16x8* __restrict__ code, const int64_t* __restrict__ ridx,
-                            int64_t s, bool live, int g, bf16x8 x0[2], bf16x8 k[2]) {
-    x0[0] = load_feats8<TIO>(feats + s * IN + 8 * g, live);
-    x0[1] = load_feats8<TIO>(feats + s * IN + 16 + 8 * g, live);
+                            int64_t s, bool live, int g, int in_dim, bf16x8 x0[2], bf16x8 k[2]) {
+    if (NARROW) {
+        x0[0] = load_feats8_narrow<TIO>(feats + s * in_dim, 8 * g, in_dim, live);
+        x0[1] = load_feats8_narrow<TIO>(feats + s * in_dim, 16 + 8 * g, in_dim, live);
+    } else {
+        x0[0] = load_feats8<TIO>(feats + s * IN + 8 * g, live);
+        x0[1] = load_feats8<TIO>(feats + s * IN + 16 + 8 * g, live);
+    }
     const int64_t r = live ? ridx[s] : 0;
     const bf16x8* cp = code + (r * 2 + g) * 2;
     k[0] = cp[0]; k[1] = cp[1];
@@ -244,7 +249,6 @@ __global__ void __launch_bounds__(FWD_WAVES * 64)
 mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, const int64_t* __restrict__ ridx,
                int64_t num_samples, int in_dim,
                const float* __restrict__ params, float* __restrict__ out_rgb, float* __restrict__ out_density) {
-    static_assert(!CODED || !NARROW, "the per-ray view code is built for 32-wide feature rows");
     const bf16x8* code = reinterpret_cast<const bf16x8*>(dirs);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16* sw = reinterpret_cast<__bf16*>(smem);
@@ -265,7 +269,7 @@ mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, co
     Acts A;
     float d[3] = {0.f, 0.f, 0.f};
     if (tile < ntiles) {
-        if constexpr (CODED) fetch_inputs_coded<TIO>(feats, code, ridx, tile * TS + L.n, tile * TS + L.n < num_samples, L.g, A.x0, &A.x2[1]);
+        if constexpr (CODED) fetch_inputs_coded<TIO, NARROW>(feats, code, ridx, tile * TS + L.n, tile * TS + L.n < num_samples, L.g, in_dim, A.x0, &A.x2[1]);
         else fetch_inputs<TIO, NARROW>(feats, dirs, tile * TS + L.n, tile * TS + L.n < num_samples, L.g, in_dim, A.x0, d);
     }
     for (; tile < ntiles; tile += stride) {
@@ -277,7 +281,7 @@ mlp_fwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, co
         const int64_t ns = (tile + stride) * TS + L.n;
         const bool more = tile + stride < ntiles;
         if (more) {
-            if constexpr (CODED) fetch_inputs_coded<TIO>(feats, code, ridx, ns, ns < num_samples, L.g, nx0, nk);
+            if constexpr (CODED) fetch_inputs_coded<TIO, NARROW>(feats, code, ridx, ns, ns < num_samples, L.g, in_dim, nx0, nk);
             else fetch_inputs<TIO, NARROW>(feats, dirs, ns, ns < num_samples, L.g, in_dim, nx0, nd);
         }
         forward_tile<PIN, PIN, CODED>(L, d, A);
@@ -450,7 +454,7 @@ mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, co
         float d[3] = {0.f, 0.f, 0.f};
         const bf16x8* code = reinterpret_cast<const bf16x8*>(dirs);
         if (tile < ntiles) {
-            if constexpr (CODED) fetch_inputs_coded<TIO>(feats, code, ridx, tile * TS + n, tile * TS + n < num_samples, g, A.x0, &A.x2[1]);
+            if constexpr (CODED) fetch_inputs_coded<TIO, NARROW>(feats, code, ridx, tile * TS + n, tile * TS + n < num_samples, g, in_dim, A.x0, &A.x2[1]);
             else fetch_inputs<TIO, NARROW>(feats, dirs, tile * TS + n, tile * TS + n < num_samples, g, in_dim, A.x0, d);
         }
         for (; tile < ntiles; tile += stride) {
@@ -463,7 +467,7 @@ mlp_bwd_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, co
             const int64_t ns = (tile + stride) * TS + n;
             const bool more = tile + stride < ntiles;
             if (more) {
-                if constexpr (CODED) fetch_inputs_coded<TIO>(feats, code, ridx, ns, ns < num_samples, g, nx0, nk);
+                if constexpr (CODED) fetch_inputs_coded<TIO, NARROW>(feats, code, ridx, ns, ns < num_samples, g, in_dim, nx0, nk);
                 else fetch_inputs<TIO, NARROW>(feats, dirs, ns, ns < num_samples, g, in_dim, nx0, nd);
             }
 
@@ -669,8 +673,11 @@ int bf16_backward(const void* feats, int dtype_io, const float* dirs, int64_t S,
 }
 #undef WISP_MLP_IO
 
-// per-ray view code variants: 32-wide 16-bit feature rows only (the training shape)
-bool bf16_rays_supported(int dtype_io, int in_dim) { return in_dim == IN && (dtype_io == WISP_F16 || dtype_io == WISP_BF16); }
+// per-ray view code variants: every feature width and I/O type the per-sample kernels take (round 4: the narrow fp32 rows of the
+// octree / codebook fields too - their decoder launches paid the in-kernel sin / cos encoding of 2 M directions twice per step)
+bool bf16_rays_supported(int dtype_io, int in_dim) {
+    return in_dim >= 1 && in_dim <= IN && (dtype_io == WISP_F32 || dtype_io == WISP_F16 || dtype_io == WISP_BF16);
+}
 
 void bf16_dir_code(const float* dirs, int64_t num_rays, void* code, hipStream_t st) {
     if (num_rays <= 0) return;
@@ -678,20 +685,30 @@ void bf16_dir_code(const float* dirs, int64_t num_rays, void* code, hipStream_t 
                        reinterpret_cast<bf16x8*>(code));
 }
 
-int bf16_forward_rays(const void* feats, int dtype_io, const void* code, const int64_t* ridx, int64_t S, const float* params,
-                      float* rgb, float* density, hipStream_t st) {
+#define WISP_MLP_IO_CODED(FN, ...)                                                                  \
+    if (in_dim == IN) switch (dtype_io) {                                                           \
+        case WISP_F32: return FN<float, false, true>(__VA_ARGS__);                                  \
+        case WISP_F16: return FN<__half, false, true>(__VA_ARGS__);                                 \
+        default: return FN<__hip_bfloat16, false, true>(__VA_ARGS__);                               \
+    }                                                                                               \
+    switch (dtype_io) {                                                                             \
+        case WISP_F32: return FN<float, true, true>(__VA_ARGS__);                                   \
+        case WISP_F16: return FN<__half, true, true>(__VA_ARGS__);                                  \
+        default: return FN<__hip_bfloat16, true, true>(__VA_ARGS__);                                \
+    }
+
+int bf16_forward_rays(const void* feats, int dtype_io, const void* code, const int64_t* ridx, int64_t S, int in_dim,
+                      const float* params, float* rgb, float* density, hipStream_t st) {
     const float* c = reinterpret_cast<const float*>(code);
-    if (dtype_io == WISP_F16) return launch_fwd<__half, false, true>(feats, c, ridx, S, IN, params, rgb, density, st);
-    return launch_fwd<__hip_bfloat16, false, true>(feats, c, ridx, S, IN, params, rgb, density, st);
+    WISP_MLP_IO_CODED(launch_fwd, feats, c, ridx, S, in_dim, params, rgb, density, st)
 }
 
-int bf16_backward_rays(const void* feats, int dtype_io, const void* code, const int64_t* ridx, int64_t S, const float* params,
-                       const float* grad_rgb, const float* grad_density, void* grad_feats, float* partials, int* partial_rows,
-                       hipStream_t st) {
+int bf16_backward_rays(const void* feats, int dtype_io, const void* code, const int64_t* ridx, int64_t S, int in_dim,
+                       const float* params, const float* grad_rgb, const float* grad_density, void* grad_feats, float* partials,
+                       int* partial_rows, hipStream_t st) {
     const float* c = reinterpret_cast<const float*>(code);
-    if (dtype_io == WISP_F16)
-        return launch_bwd<__half, false, true>(feats, c, ridx, S, IN, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st);
-    return launch_bwd<__hip_bfloat16, false, true>(feats, c, ridx, S, IN, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st);
+    WISP_MLP_IO_CODED(launch_bwd, feats, c, ridx, S, in_dim, params, grad_rgb, grad_density, grad_feats, partials, partial_rows, st)
 }
+#undef WISP_MLP_IO_CODED
 
 }  // namespace wisp_mlp

@@ -42,12 +42,12 @@ int bf16_backward(const void* feats, int dtype_io, const float* dirs, int64_t nu
                   hipStream_t st);
 
 // The same kernels with the view direction given per RAY: `code` = [num_rays][32] bf16 from bf16_dir_code (the encoded direction
-// of every ray, computed once), `ridx` = ray of every sample.  32-wide 16-bit feature rows only (bf16_rays_supported).
+// of every ray, computed once), `ridx` = ray of every sample.  Every feature width (1..32) and I/O type of the per-sample kernels (bf16_rays_supported).
 bool bf16_rays_supported(int dtype_io, int in_dim);
 void bf16_dir_code(const float* dirs, int64_t num_rays, void* code, hipStream_t st);
-int bf16_forward_rays(const void* feats, int dtype_io, const void* code, const int64_t* ridx, int64_t num_samples,
+int bf16_forward_rays(const void* feats, int dtype_io, const void* code, const int64_t* ridx, int64_t num_samples, int in_dim,
                       const float* params, float* rgb, float* density, hipStream_t st);
-int bf16_backward_rays(const void* feats, int dtype_io, const void* code, const int64_t* ridx, int64_t num_samples,
+int bf16_backward_rays(const void* feats, int dtype_io, const void* code, const int64_t* ridx, int64_t num_samples, int in_dim,
                        const float* params, const float* grad_rgb, const float* grad_density, void* grad_feats, float* partials,
                        int* partial_rows, hipStream_t st);
 

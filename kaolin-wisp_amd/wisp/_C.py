@@ -1291,6 +1291,8 @@ def nerf_mlp_forward(feats, dirs, params, in_dim, hidden, view_freqs, compute_bf
     rgb = torch.empty(S, 3, dtype=torch.float32, device=feats.device)
     density = torch.empty(S, 1, dtype=torch.float32, device=feats.device)
     if ray_code is not None:
+        if not compute_bf16:
+            raise RuntimeError("nerf_mlp_forward: per-ray view codes exist for the bf16-compute kernels only (nerf_mlp_rays_supported)")
         ridx, code = _need(ray_code[0], torch.int64, "ridx"), _need(ray_code[1], torch.bfloat16, "dir_code")
         if ridx.shape[0] != S:
             raise ValueError("ridx must have one entry per sample")
@@ -1315,8 +1317,9 @@ def nerf_mlp_dir_code(ray_dirs, view_freqs=4):
 
 
 def nerf_mlp_rays_supported(feats_dtype, in_dim, hidden, view_freqs, compute_bf16):
-    """the per-ray view code path exists for the training shape only"""
-    return bool(compute_bf16) and in_dim == 32 and hidden == 64 and view_freqs == 4 and feats_dtype in (torch.float16, torch.bfloat16)
+    """the per-ray view code path: the bf16-compute hidden-64 kernels, any feature width they take, any I/O type"""
+    return (bool(compute_bf16) and 1 <= in_dim <= 32 and hidden == 64 and view_freqs == 4
+            and feats_dtype in (torch.float32, torch.float16, torch.bfloat16))
 
 
 _mlp_workspace = {}
@@ -1343,6 +1346,8 @@ def nerf_mlp_backward(feats, dirs, params, grad_rgb, grad_density, in_dim, hidde
         _mlp_workspace[key] = None
         ws = _mlp_workspace[key] = torch.empty((need + 3) // 4 + 64, dtype=torch.float32, device=dev)
     if ray_code is not None:
+        if not compute_bf16:
+            raise RuntimeError("nerf_mlp_backward: per-ray view codes exist for the bf16-compute kernels only (nerf_mlp_rays_supported)")
         ridx, code = _need(ray_code[0], torch.int64, "ridx"), _need(ray_code[1], torch.bfloat16, "dir_code")
         if ridx.shape[0] != S:
             raise ValueError("ridx must have one entry per sample")

@@ -390,11 +390,14 @@ def test_dropin_regime_other_configs_fp16_autocast_tracks_fp32(kind, march, step
     assert runs[False][0][2] < runs[False][0][0]                       # and it trains
 
 
-@pytest.mark.parametrize("io_dtype", [torch.bfloat16, torch.float16])
-def test_decoder_with_per_ray_view_code_equals_per_sample_directions(io_dtype):
+@pytest.mark.parametrize("io_dtype,in_dim", [(torch.bfloat16, 32), (torch.float16, 32), (torch.float32, 32), (torch.float32, 5),
+                                             (torch.bfloat16, 12)])
+def test_decoder_with_per_ray_view_code_equals_per_sample_directions(io_dtype, in_dim):
     """wisp_nerf_mlp_{fwd,bwd}_rays: the view direction encoded once per ray (wisp_nerf_mlp_dir_code) and gathered by ray index
     inside the kernels must give exactly what the per-sample entry points give on directions gathered like
-    packed_rf_tracer.py:70-76 does - same arithmetic, so bit-identical outputs and gradients."""
+    packed_rf_tracer.py:70-76 does - same arithmetic, so bit-identical outputs and gradients.  Every row shape the per-sample
+    kernels take: the 32-wide 16-bit rows of nerf_hash, fp32 rows, and the narrow rows of the octree / codebook / triplanar
+    fields (5 and 12 features)."""
     C = _C()
     rng = np.random.default_rng(91)
     R, S = 4097, 200003
@@ -402,24 +405,24 @@ def test_decoder_with_per_ray_view_code_equals_per_sample_directions(io_dtype):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     ray_dirs = cuda(d)
     ridx = torch.from_numpy(np.sort(rng.integers(0, R, S))).to(DEV)
-    feats = torch.from_numpy(rng.normal(size=(S, 32)).astype(np.float32) * 0.5).to(DEV).to(io_dtype)
-    n = int(C.lib.wisp_nerf_mlp_param_count(32, 64, 4))
+    feats = torch.from_numpy(rng.normal(size=(S, in_dim)).astype(np.float32) * 0.5).to(DEV).to(io_dtype)
+    n = int(C.lib.wisp_nerf_mlp_param_count(in_dim, 64, 4))
     params = torch.from_numpy(rng.normal(size=n).astype(np.float32) * 0.2).to(DEV)
     g_rgb = torch.from_numpy(rng.normal(size=(S, 3)).astype(np.float32)).to(DEV)
     g_den = torch.from_numpy(rng.normal(size=(S, 1)).astype(np.float32)).to(DEV)
-    assert C.nerf_mlp_rays_supported(io_dtype, 32, 64, 4, True)
-    assert not C.nerf_mlp_rays_supported(torch.float32, 32, 64, 4, True)
+    assert C.nerf_mlp_rays_supported(io_dtype, in_dim, 64, 4, True)
+    assert not C.nerf_mlp_rays_supported(io_dtype, in_dim, 64, 4, False)          # fp32 compute: the exact kernels have no such variant
     code = C.nerf_mlp_dir_code(ray_dirs)
     sample_dirs = ray_dirs.index_select(0, ridx)
-    rgb_a, den_a = C.nerf_mlp_forward(feats, sample_dirs, params, 32, 64, 4, True)
-    rgb_b, den_b = C.nerf_mlp_forward(feats, None, params, 32, 64, 4, True, ray_code=(ridx, code))
+    rgb_a, den_a = C.nerf_mlp_forward(feats, sample_dirs, params, in_dim, 64, 4, True)
+    rgb_b, den_b = C.nerf_mlp_forward(feats, None, params, in_dim, 64, 4, True, ray_code=(ridx, code))
     assert torch.equal(rgb_a, rgb_b) and torch.equal(den_a, den_b)
-    gf_a, gp_a = C.nerf_mlp_backward(feats, sample_dirs, params, g_rgb, g_den, 32, 64, 4, True)
-    gf_b, gp_b = C.nerf_mlp_backward(feats, None, params, g_rgb, g_den, 32, 64, 4, True, ray_code=(ridx, code))
-    assert torch.equal(gf_a, gf_b)
+    gf_a, gp_a = C.nerf_mlp_backward(feats, sample_dirs, params, g_rgb, g_den, in_dim, 64, 4, True)
+    gf_b, gp_b = C.nerf_mlp_backward(feats, None, params, g_rgb, g_den, in_dim, 64, 4, True, ray_code=(ridx, code))
+    assert gf_a.shape == (S, in_dim) and torch.equal(gf_a, gf_b)
     assert torch.equal(gp_a, gp_b)
-    with pytest.raises(RuntimeError):                      # fp32 rows: no per-ray variant, the library says so
-        C.nerf_mlp_forward(feats.float(), None, params, 32, 64, 4, True, ray_code=(ridx, code))
+    with pytest.raises(RuntimeError):                      # the exact fp32 kernels: no per-ray variant, the library says so
+        C.nerf_mlp_forward(feats.float(), None, params, in_dim, 64, 4, False, ray_code=(ridx, code))
 
 
 def test_direct_step_covers_hidden_128_under_amp(monkeypatch):
