@@ -321,7 +321,7 @@ class _DirectNeRFStep:
         # view directions: encoded once per ray and gathered by ray index inside the decoder kernels where that variant exists
         # (the training shape), else gathered per sample
         i, h, f = self.shape
-        coded = C.nerf_mlp_rays_supported(torch.bfloat16 if t.enable_amp else torch.float32, i, h, f, t.enable_amp)
+        coded = C.nerf_mlp_rays_preferred(torch.bfloat16 if t.enable_amp else torch.float32, i, h, f, t.enable_amp)
         ridx, samples, deltas, offsets, dirs = self._march(rays, jitter, prefetch, coded)
         S = samples.shape[0]
         tracer.prev_num_samples = S
