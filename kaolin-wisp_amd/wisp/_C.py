@@ -1327,8 +1327,10 @@ def nerf_mlp_rays_preferred(feats_dtype, in_dim, hidden, view_freqs, compute_bf1
     backward -6 % at 2 M samples).  On the narrow fp32 rows of the octree / codebook fields it measured slower than encoding in the
     kernel (VQAD bench, 2 M samples: backward 0.320 -> 0.334 ms, forward 0.069 -> 0.078 ms), so a trainer keeps per-sample
     directions there; the entry points take every shape either way."""
-    return (nerf_mlp_rays_supported(feats_dtype, in_dim, hidden, view_freqs, compute_bf16) and in_dim == 32
-            and feats_dtype in (torch.float16, torch.bfloat16))
+    ok = nerf_mlp_rays_supported(feats_dtype, in_dim, hidden, view_freqs, compute_bf16)
+    if os.environ.get("WISP_MLP_RAYS") == "all":                  # (A/B switch: per-ray codes wherever the kernels take them)
+        return ok
+    return ok and in_dim == 32 and feats_dtype in (torch.float16, torch.bfloat16)
 
 
 _mlp_workspace = {}
