@@ -1323,14 +1323,15 @@ def nerf_mlp_rays_supported(feats_dtype, in_dim, hidden, view_freqs, compute_bf1
 
 
 def nerf_mlp_rays_preferred(feats_dtype, in_dim, hidden, view_freqs, compute_bf16):
-    """where the per-ray view code is also the FASTER way: the 32-wide 16-bit rows of the hash-grid field (forward 70 -> 59 us,
-    backward -6 % at 2 M samples).  On the narrow fp32 rows of the octree / codebook fields it measured slower than encoding in the
-    kernel (VQAD bench, 2 M samples: backward 0.320 -> 0.334 ms, forward 0.069 -> 0.078 ms), so a trainer keeps per-sample
-    directions there; the entry points take every shape either way."""
+    """where a trainer should hand the decoder per-ray view codes instead of per-sample directions: wherever the kernels take them.
+    On the 32-wide 16-bit rows of the hash-grid field the kernels themselves get faster (forward 70 -> 59 us, backward -6 % at
+    2 M samples); on the narrow fp32 rows of the octree / codebook fields they take the same time (A/B on one box, VQAD bench:
+    backward 0.311 / 0.312 ms, forward 0.068 / 0.067 ms - the in-kernel encoding is not what those kernels wait for) and the step
+    saves the per-sample direction gather: 1.069 -> 1.060 ms.  WISP_MLP_RAYS=wide restricts it to the 32-wide 16-bit rows."""
     ok = nerf_mlp_rays_supported(feats_dtype, in_dim, hidden, view_freqs, compute_bf16)
-    if os.environ.get("WISP_MLP_RAYS") == "all":                  # (A/B switch: per-ray codes wherever the kernels take them)
-        return ok
-    return ok and in_dim == 32 and feats_dtype in (torch.float16, torch.bfloat16)
+    if os.environ.get("WISP_MLP_RAYS") == "wide":
+        return ok and in_dim == 32 and feats_dtype in (torch.float16, torch.bfloat16)
+    return ok
 
 
 _mlp_workspace = {}

@@ -1,7 +1,7 @@
 #!/bin/bash
-# A/B inside one box: per-ray view codes for the narrow fp32 rows of the VQAD field (WISP_MLP_RAYS=all) vs per-sample directions
+# A/B inside one box: per-ray view codes for the narrow fp32 rows of the VQAD field (default) vs per-sample directions (WISP_MLP_RAYS=wide)
 export TMPDIR=/tmp
-for rep in 1 2; do for mode in default all; do
+for rep in 1 2; do for mode in wide default; do
   WISP_MLP_RAYS=$mode timeout 600 python bench.py --config vqad --steps 100 --pretrain 100 2>&1 | grep -v amdgpu.ids | tail -1 > /tmp/v.json
   python - $mode <<'PY'
 import json, sys
