@@ -1199,6 +1199,52 @@ def test_neural_sdf_and_sdf_tracer_match_oracle():
     np.testing.assert_allclose(rb.alpha.cpu().numpy(), want["alpha"].numpy())
 
 
+def test_fused_sdf_training_step_matches_the_cpu_oracle():
+    """wisp_sdf_train_step (forward + loss + backward of sdf_trainer.py:65-124 for NeuralSDF over an OctreeGrid, four launches)
+    against autograd through the CPU oracle - oracle.octree_grid.octree_grid_interpolate ('sum' over three LODs, the reference's
+    fp16 rounding of features and results) -> [position, features] -> Linear(19, 128) -> relu -> Linear(128, 1) ->
+    sum((pred - gt)^2) / B: the loss and every gradient (feature tables of all levels, both decoder layers)."""
+    from oracle import octree_grid as og
+    from wisp.accelstructs import OctreeAS
+    from wisp.models.grids import OctreeGrid
+    from wisp.models.nefs import NeuralSDF
+    from wisp.trainers import SDFTrainStep
+    level = 5
+    idx = np.stack(np.meshgrid(*[np.arange(32)] * 3, indexing='ij'), -1).reshape(-1, 3)
+    ctr = (idx + 0.5) / 16 - 1
+    shell = np.abs(np.linalg.norm(ctr, axis=1) - 0.55) < 0.12
+    P = idx[shell]
+    blas = OctreeAS.from_quantized_points(torch.from_numpy(P).short().to(DEV), level)
+    oblas = onerf.OracleBLAS(ospc.points_to_octree(P, level))
+    torch.manual_seed(13)
+    grid = OctreeGrid(blas, feature_dim=16, num_lods=3, multiscale_type='sum', feature_std=0.05).to(DEV)
+    nef = NeuralSDF(grid, pos_embedder='none', position_input=True, hidden_dim=128, num_layers=1).to(DEV)
+    pd, pyd = ospc.make_dual(oblas.points, oblas.pyramid)
+    tr, _ = ospc.make_trinkets(oblas.points, oblas.pyramid, pd, pyd)
+    rng = np.random.default_rng(222)
+    B = 700
+    c = (ctr[shell][rng.integers(0, P.shape[0], B)] + rng.uniform(-0.02, 0.02, (B, 3))).astype(np.float32)
+    c[::13] = rng.uniform(-1.1, 1.1, (c[::13].shape[0], 3))                       # some outside every cell / the unit cube
+    gt = rng.normal(size=(B, 1)).astype(np.float32) * 0.1
+    # oracle side
+    feats_cpu = [f.detach().cpu().clone().requires_grad_(True) for f in grid.features]
+    dec = onerf.OracleDecoder(19, 1, 128, 1, True)
+    dec.load_state_dict({k: v.detach().cpu() for k, v in nef.decoder.state_dict().items()})
+    f = og.octree_grid_interpolate(oblas, tr, feats_cpu, torch.from_numpy(c), 2, grid.base_lod, grid.active_lods, 'sum', 16, True)
+    want_loss = ((dec(torch.cat([torch.from_numpy(c), f], -1)) - torch.from_numpy(gt)) ** 2).sum() / B
+    want_loss.backward()
+    # the fused step (gradients land in the flat buffer; the optimizer is not run)
+    tr_step = SDFTrainStep(nef, lr=1e-3, eps=1e-15)
+    assert tr_step._fused_field() is not None
+    loss = tr_step._forward_backward(cuda(c), cuda(gt))
+    assert abs(float(loss) - float(want_loss)) <= 2e-5 * max(1.0, abs(float(want_loss)))
+    for i in range(3):
+        np.testing.assert_allclose(grid.features[i].grad.cpu().numpy(), feats_cpu[i].grad.numpy(), rtol=2e-3, atol=2e-5)
+    for (n1, p1), (n2, p2) in zip(nef.decoder.named_parameters(), dec.named_parameters()):
+        sc = float(p2.grad.abs().max())
+        assert float((p1.grad.cpu() - p2.grad).abs().max()) <= 2e-4 * sc + 1e-7, n1
+
+
 def test_image_field_config_c1_fits_and_matches_oracle_2d():
     """C1 (app/image): HashGrid with blas=None, 2-D coords, table sized with coord_dim=3 (main_image.py:63),
     ImageNeuralField 46 -> 64 -> 3.  Forward parity of the 2-D lookup with the oracle and a short fit that learns."""
