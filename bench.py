@@ -558,9 +558,15 @@ def main(argv=None):
     work = work_table(amp, args.hidden)
     peaks = {"hbm": (HBM_PEAK_GBS, "GB/s"), "mfma": (2500.0 if amp else 157.3, "TFLOP/s")}
 
+    # One GPU: the grid's AdamW step runs inside the hash-grid backward's reduce kernel (MultiviewTrainStep._fused_update_args), so
+    # that launch also does the optimizer's algorithmic work for the elements it updates: parameter and both moments read and
+    # written (24 B) + the bf16 copy (2 B); the gradient itself never leaves LDS.
+    fused_elems = int(getattr(trainer, "fused_elements_last", 0))
+    fused_opt_bytes = fused_elems * (24 + (2 if amp else 0))
+
     def rate(name, v):
         bound, per = work[name]
-        r = per * v["avg_units"] / (v["avg_ms"] * 1e-3)
+        r = (per * v["avg_units"] + (fused_opt_bytes if name == "hashgrid_bwd" else 0)) / (v["avg_ms"] * 1e-3)
         return bound, (r / 1e9 if bound == "hbm" else r / 1e12)
 
     kern = {n: v for n, v in kern.items() if n in work}
@@ -575,6 +581,17 @@ def main(argv=None):
                         avg_launch_ms=k["avg_ms"], units_per_launch=k["avg_units"], work_per_unit=work[dominant][1],
                         all_kernels={n: dict(avg_ms=v["avg_ms"], bound=rate(n, v)[0], achieved=rate(n, v)[1],
                                              frac=rate(n, v)[1] / peaks[rate(n, v)[0]][0]) for n, v in kern.items()})
+        if fused_opt_bytes and "hashgrid_bwd" in roofline["all_kernels"]:
+            k = kern["hashgrid_bwd"]
+            plain = work["hashgrid_bwd"][1] * k["avg_units"] / (k["avg_ms"] * 1e-3) / 1e9
+            roofline["all_kernels"]["hashgrid_bwd"]["fused_optimizer"] = {
+                "elements_updated_in_the_launch": fused_elems, "bytes_per_launch": fused_opt_bytes,
+                "achieved_on_the_backward_bytes_alone": plain, "frac_on_the_backward_bytes_alone": plain / HBM_PEAK_GBS,
+                "note": "the launch pair also performs torch.optim.AdamW's step for the table rows its reduce workgroups own "
+                        "(parameter + two moments read and written, bf16 copy written: 26 B per element, counted in `achieved`); "
+                        "the separate optimizer launch only covers the coarse levels, the frozen finest level and the decoder"}
+            if dominant == "hashgrid_bwd":
+                roofline["fused_optimizer"] = roofline["all_kernels"]["hashgrid_bwd"]["fused_optimizer"]
         if "hashgrid_fwd" in roofline["all_kernels"]:
             # SURVEY 8(d)'s algorithmic bytes (588 B/sample, 512 of them gathered table entries) over the launch time exceed the HBM
             # peak: the 20.9 MB of tables are re-read from L2 / Infinity Cache, so that figure is NOT an HBM fraction and is kept

@@ -189,7 +189,11 @@ def run_v8(args, dev):
     o, d, _ = synlego.ray_bank(1 << 20, res=400, seed=1000, device=dev, with_gt=False)
     bank = (o, d, synlego.render_gt_white(o, d))
     b = 2 if tr.enable_amp else 4
+    # (one GPU: the reduce kernel of the backward also runs AdamW for the table rows it owns - parameter and moments read and
+    #  written + the bf16 copy, 26 B per element updated there - see bench.py)
     bytes_fn = lambda S, R: {"hashgrid_interpolate_bwd": (12 + 32 * b + 2 * 16 * 8 * 2 * b) * S,
+                             "hashgrid_interpolate_bwd_adamw": (12 + 32 * b + 2 * 16 * 8 * 2 * b) * S
+                                                               + getattr(tr, "fused_elements_last", 0) * (24 + (2 if tr.enable_amp else 0)),
                              "hashgrid_interpolate_fwd": (12 + 16 * 8 * 2 * b + 32 * b) * S,
                              "raymarch_voxel_emit": 37 * S, "composite_fwd": 25 * S, "composite_bwd": 41 * S}
     return _nerf_run(args, dev, pipe, tr, bank, args.steps, args.warmup,

@@ -93,6 +93,25 @@ int wisp_hashgrid_bwd_slot_stats(int64_t n, int coord_dim, int dtype, int featur
                                  const void* workspace, int64_t workspace_bytes, uint32_t* max_fill, int32_t* cap_host,
                                  int32_t* base_cap_host, wisp_stream_t stream);
 
+/* wisp_hashgrid_interpolate_bwd with the table's AdamW step folded into it: where the reference runs
+ * hashgrid_interpolate_backward_cuda (.cu:109-196) and then the optimizer over the whole table (base_trainer.py:205-246,
+ * multiview_trainer.py:169-174), the reduce kernel's workgroup that OWNS a slice of the table has the slice's complete gradient
+ * in LDS and updates param / exp_avg / exp_avg_sq (and the bf16 copy, may be NULL) right there - the gradient of those rows is
+ * never written, read back or zeroed.  param, exp_avg, exp_avg_sq, bf16_shadow are indexed like grad_codebook; lr ... grad_scale
+ * as in wisp_adamw_step (same arithmetic, bit for bit).  covered_rows (HOST i64 [num_lods], written at once): per level, how many
+ * of its leading rows were updated that way; every other row still has its gradient ACCUMULATED in grad_codebook and is the
+ * caller's to update (wisp_adamw_step_groups over the remaining ranges).  Levels that were not binned or whose buckets are
+ * shared by several workgroups (the coarse ones) report 0; with feature_dim != 2 everything reports 0 (plain backward).
+ * Single-GPU only by construction: a data-parallel step has to exchange the gradient first. */
+int wisp_hashgrid_interpolate_bwd_adamw(const float* coords, int64_t n, int coord_dim,
+                                        const void* grad_feats, int dtype, int feature_dim,
+                                        const int64_t* first_idx, const int32_t* resolutions, int num_lods,
+                                        int codebook_bitwidth, int zero_from_col,
+                                        float* grad_codebook, void* workspace, int64_t workspace_bytes,
+                                        const float* level_cap_scale, float* param, float* exp_avg, float* exp_avg_sq,
+                                        void* bf16_shadow, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                        int64_t step, float grad_scale, int64_t* covered_rows /* host */, wisp_stream_t stream);
+
 /* Diagnostic (no counterpart in the reference's bindings): the integer cell, the position inside it and the 2^d corner rows
  * (relative to the level's first row) that ONE level assigns to every coordinate - the first lines of every reference
  * hash-grid kernel (wisp/csrc/ops/hashgrid_interpolate_cuda.cu:40-66, hash_utils.cuh:17-105), evaluated by the device code all
@@ -525,9 +544,10 @@ int wisp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float grad_scale, int zero_grad /* also zero grad[] */, void* bf16_shadow,
                     wisp_stream_t stream);
 /* The same update for up to 4 parameter groups of ONE flat buffer in one launch - the optimizer's param groups
- * ('decoder' / 'grid' / rest with their own learning rates, base_trainer.py:216-235).  group_begin / group_len (elements,
- * begin a multiple of 4), group_lr, group_weight_decay, group_bf16_shadow (device pointers, bf16 [len], or NULL entries /
- * a NULL array) are HOST arrays of num_groups entries. */
+ * ('decoder' / 'grid' / rest with their own learning rates, base_trainer.py:216-235).  group_begin / group_len (elements;
+ * a group that begins on a multiple of 4 is processed 16 bytes at a time, any other element by element), group_lr,
+ * group_weight_decay, group_bf16_shadow (device pointers, bf16 [len], or NULL entries / a NULL array) are HOST arrays of
+ * num_groups entries. */
 int wisp_adamw_step_groups(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int num_groups,
                            const int64_t* group_begin, const int64_t* group_len, const float* group_lr,
                            const float* group_weight_decay, void* const* group_bf16_shadow, float beta1, float beta2,

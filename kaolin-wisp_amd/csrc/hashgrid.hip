@@ -432,6 +432,9 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #endif
 #define RD_THREADS 1024
 #define BIN_MAX_CHUNKS 1024
+#ifndef HG_FLUSH_PAIRS
+#define HG_FLUSH_PAIRS 1       // (0: A/B builds of the reduce kernel's flush without its 8-byte path, scripts/gpu_r4_k.sh)
+#endif
 
 // Records.  Generic form: { index within the level table, F fp32 gradient values } = 1 + F dwords.  For two features coming
 // from a 16-bit gradient tensor (the bf16 / fp16 training path) the record is packed into TWO dwords: each value keeps
@@ -793,11 +796,21 @@ struct AccF32 {             // the non-finite fallback
     __device__ __forceinline__ float get(uint32_t i) const { return acc[i]; }
 };
 
-template <typename T, int F, typename ACC>
+// The optimizer folded into the reduce kernel's flush (wisp_hashgrid_interpolate_bwd_adamw): a workgroup that owns its slice of
+// the table (splits == 1) has the slice's complete gradient in LDS - instead of adding it to the gradient table for a separate
+// optimizer pass to read back (and zero), it updates parameters and moments right there.  Pointers are indexed like
+// grad_codebook (table element); shadow = bf16 copy of the parameters, or null.
+struct AdamFlush {
+    float* p; float* m; float* v; __hip_bfloat16* shadow;
+    float lr, wd, b1, b2, eps, bc1, bc2_sqrt, gscale;
+};
+
+template <typename T, int F, typename ACC, bool ADAM>
 static __device__ __forceinline__ void
 hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, const LevelList& levels, int chunk_shift,
                          const BinLevels& bins, uint32_t ntiles, const uint32_t* __restrict__ counts,
-                         const uint32_t* __restrict__ records, float* __restrict__ grad_codebook, int li, int b, int z) {
+                         const uint32_t* __restrict__ records, float* __restrict__ grad_codebook, int li, int b, int z,
+                         const AdamFlush& ad) {
     typedef RecordCodec<T, F> Codec;
     constexpr int RW = Codec::RW;
     const int splits = bins.splits[li];
@@ -862,7 +875,62 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
         }
     }
     __syncthreads();
-    float* __restrict__ dst = grad_codebook + (first_idx[l] + (int64_t)first) * F;
+    const int64_t slice = (first_idx[l] + (int64_t)first) * F;
+    float* __restrict__ dst = grad_codebook + slice;
+    if constexpr (ADAM) {
+        if (splits == 1) {
+            // gradient = what the atomic fall-backs of the emit kernel left in the table (slot overflow; normally zero, and
+            // put back to zero here like the optimizer's fused zeroing would) + this bucket's sum; AdamW's arithmetic is
+            // wisp_adamw_update, shared with the flat optimizer kernels: the same bits as flush + separate pass
+            float* __restrict__ pp = ad.p + slice;
+            float* __restrict__ pm = ad.m + slice;
+            float* __restrict__ pv = ad.v + slice;
+            __hip_bfloat16* __restrict__ ps = ad.shadow ? ad.shadow + slice : nullptr;
+            constexpr int PQ = 4;                                         // pairs per thread and round trip
+            const uint32_t pairs = lim >> 1;
+            if ((lim & 1u) == 0 && (((uintptr_t)dst | (uintptr_t)pp | (uintptr_t)pm | (uintptr_t)pv) & 7u) == 0) {
+                for (uint32_t i0 = threadIdx.x; i0 < pairs; i0 += PQ * RD_THREADS) {
+                    float2 cg[PQ], cp[PQ], cm[PQ], cv[PQ];
+#pragma unroll
+                    for (int q = 0; q < PQ; ++q) {
+                        const uint32_t i = i0 + q * RD_THREADS;
+                        if (i < pairs) {
+                            cg[q] = reinterpret_cast<const float2*>(dst)[i]; cp[q] = reinterpret_cast<const float2*>(pp)[i];
+                            cm[q] = reinterpret_cast<const float2*>(pm)[i]; cv[q] = reinterpret_cast<const float2*>(pv)[i];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < PQ; ++q) {
+                        const uint32_t i = i0 + q * RD_THREADS;
+                        if (i < pairs) {
+                            const bool dirty = cg[q].x != 0.0f || cg[q].y != 0.0f;
+                            const float g0 = cg[q].x + A.get(2 * i), g1 = cg[q].y + A.get(2 * i + 1);
+                            wisp_adamw_update(cp[q].x, cm[q].x, cv[q].x, g0 * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
+                            wisp_adamw_update(cp[q].y, cm[q].y, cv[q].y, g1 * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
+                            reinterpret_cast<float2*>(pp)[i] = cp[q];
+                            reinterpret_cast<float2*>(pm)[i] = cm[q];
+                            reinterpret_cast<float2*>(pv)[i] = cv[q];
+                            if (dirty) reinterpret_cast<float2*>(dst)[i] = make_float2(0.0f, 0.0f);
+                            if (ps) {
+                                const __hip_bfloat16 s0 = __float2bfloat16(cp[q].x), s1 = __float2bfloat16(cp[q].y);
+                                reinterpret_cast<uint32_t*>(ps)[i] = (uint32_t)__bfloat16_as_ushort(s0) | ((uint32_t)__bfloat16_as_ushort(s1) << 16);
+                            }
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
+                    const float c = dst[e];
+                    float x = pp[e], m1 = pm[e], m2 = pv[e];
+                    wisp_adamw_update(x, m1, m2, (c + A.get(e)) * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
+                    pp[e] = x; pm[e] = m1; pv[e] = m2;
+                    if (c != 0.0f) dst[e] = 0.0f;
+                    if (ps) ps[e] = __float2bfloat16(x);
+                }
+            }
+            return;
+        }
+    }
     if (splits == 1) {
         // this workgroup owns the slice: plain read-modify-write, four floats per thread and ALL of a thread's loads issued
         // before its first store (one memory round trip per workgroup instead of one per element)
@@ -885,6 +953,25 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
                     reinterpret_cast<float4*>(dst)[i] = t;
                 }
             }
+        } else if (HG_FLUSH_PAIRS && (lim >> 1) <= 2 * MAXQ * RD_THREADS && (lim & 1u) == 0 && ((uintptr_t)dst & 7u) == 0) {
+            // the same in pairs: a level whose first row is odd (nerf_hash.yaml: every level from the fourth on - 25^3 rows
+            // precede it) starts 8 bytes off a 16-byte boundary
+            const uint32_t pairs = lim >> 1;
+            float2 cur[2 * MAXQ];
+#pragma unroll
+            for (int q = 0; q < 2 * MAXQ; ++q) {
+                const uint32_t i = threadIdx.x + q * RD_THREADS;
+                if (i < pairs) cur[q] = reinterpret_cast<const float2*>(dst)[i];
+            }
+#pragma unroll
+            for (int q = 0; q < 2 * MAXQ; ++q) {
+                const uint32_t i = threadIdx.x + q * RD_THREADS;
+                if (i < pairs) {
+                    float2 t = cur[q];
+                    t.x += A.get(2 * i); t.y += A.get(2 * i + 1);
+                    reinterpret_cast<float2*>(dst)[i] = t;
+                }
+            }
         } else {
             for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
                 const float a = A.get(e);
@@ -899,11 +986,11 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
     }
 }
 
-template <typename T, int F>
+template <typename T, int F, bool ADAM>
 __global__ void __launch_bounds__(RD_THREADS)
 hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList levels, int chunk_shift, BinLevels bins,
                            uint32_t ntiles, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ records,
-                           float* __restrict__ grad_codebook, int extra_bits) {
+                           float* __restrict__ grad_codebook, int extra_bits, AdamFlush ad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rd_smem[];            // [chunk entries * F] accumulators
     __shared__ uint32_t s_wave_max[RD_THREADS / 64];
     // flattened (level, bucket, split) grid
@@ -930,10 +1017,10 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
         if (sh > 159) sh = 159;                            // 2^(sh - 32) must stay a normal float
         AccFix64 A{reinterpret_cast<unsigned long long*>(rd_smem), __uint_as_float((uint32_t)(sh - 32 + 127) << 23),
                    __longlong_as_double((long long)(1023 - sh) << 52)};
-        hashgrid_bwd_reduce_body<T, F>(A, first_idx, levels, chunk_shift, bins, ntiles, counts, records, grad_codebook, li, b, z);
+        hashgrid_bwd_reduce_body<T, F, AccFix64, ADAM>(A, first_idx, levels, chunk_shift, bins, ntiles, counts, records, grad_codebook, li, b, z, ad);
     } else {
         AccF32 A{reinterpret_cast<float*>(rd_smem)};
-        hashgrid_bwd_reduce_body<T, F>(A, first_idx, levels, chunk_shift, bins, ntiles, counts, records, grad_codebook, li, b, z);
+        hashgrid_bwd_reduce_body<T, F, AccF32, ADAM>(A, first_idx, levels, chunk_shift, bins, ntiles, counts, records, grad_codebook, li, b, z, ad);
     }
 }
 
@@ -1098,7 +1185,10 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
 template <typename T, int F, int DIM>
 static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, const int64_t* first_idx,
                       const HashLevels& lv, int num_lods, uint32_t tsize, int zero_from_col, float* grad_codebook,
-                      void* workspace, int64_t workspace_bytes, const float* cap_scale, hipStream_t s) {
+                      void* workspace, int64_t workspace_bytes, const float* cap_scale, hipStream_t s,
+                      const AdamFlush* adam = nullptr, int64_t* covered_rows = nullptr) {
+    // adam / covered_rows (host, [num_lods], zeroed by the caller): the optimizer folded into the reduce kernel's flush for the
+    // levels whose buckets have ONE owner; covered_rows[l] = rows at the start of level l that were updated there
     const int pow2 = (tsize & (tsize - 1)) == 0;
     // the run merge carries 16 bits per cell coordinate (tail_compute); wide features would not fit the register budget
     bool merge = bwd_merge_enabled() && (F * (1 << DIM) <= 32);
@@ -1151,14 +1241,20 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
                            plan.chunk_shift, plan.bins, counts, records, grad_codebook);
     }
     const size_t rd_lds = ((size_t)1 << plan.chunk_shift) * F * 8;
-    auto rd = hashgrid_bwd_reduce_kernel<T, F>;
+    constexpr bool CAN_ADAM = (F == 2);                    // the fused update exists for the two-feature tables
+    const bool fused = CAN_ADAM && adam != nullptr && covered_rows != nullptr;
+    auto rd = hashgrid_bwd_reduce_kernel<T, F, false>;
+    if constexpr (CAN_ADAM) { if (fused) rd = hashgrid_bwd_reduce_kernel<T, F, true>; }
     if (const hipError_t e = WISP_ALLOW_LDS(rd, rd_lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
+    if (fused)
+        for (int li = 0; li < active.n; ++li)
+            if (plan.bins.splits[li] == 1) covered_rows[active.lv[li]] = (int64_t)plan.bins.entries[li];
     // one table entry can receive 2^DIM records per sample: 2^24 at the 2^21 samples the binary point is laid out for; beyond
     // that the binary point moves up with the sample count so that no sum can leave its 63 bits
     int extra_bits = 0;
     while (((int64_t)1 << (21 + extra_bits)) < n) ++extra_bits;
     hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
-                       plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook, extra_bits);
+                       plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook, extra_bits, fused ? *adam : AdamFlush{});
     return 0;
 }
 
@@ -1220,6 +1316,41 @@ extern "C" int wisp_hashgrid_interpolate_bwd(const float* coords, int64_t n, int
     hipStream_t s = (hipStream_t)stream;
     HG_DISPATCH(launch_bwd, coords, n, grad_feats, first_idx, lv, num_lods, (uint32_t)tsize, zero_from_col,
                 grad_codebook, workspace, workspace_bytes, level_cap_scale, s)
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
+// The backward with torch.optim.AdamW's step on the table folded into it (MultiviewTrainStep on one GPU; base_trainer.py:205-246
+// configures the optimizer, multiview_trainer.py:169-174 steps it): see AdamFlush.  covered_rows (HOST, [num_lods]) receives,
+// per level, how many of its leading rows were updated in the flush; every other element of the table still has its gradient in
+// grad_codebook and is the caller's to update (wisp_adamw_step_groups).  Levels that were not binned, or whose buckets are split
+// over several workgroups (the coarse ones), report 0.
+extern "C" int wisp_hashgrid_interpolate_bwd_adamw(const float* coords, int64_t n, int coord_dim, const void* grad_feats,
+                                                   int dtype, int feature_dim, const int64_t* first_idx,
+                                                   const int32_t* resolutions, int num_lods, int codebook_bitwidth,
+                                                   int zero_from_col, float* grad_codebook, void* workspace,
+                                                   int64_t workspace_bytes, const float* level_cap_scale, float* param,
+                                                   float* exp_avg, float* exp_avg_sq, void* bf16_shadow, float lr, float beta1,
+                                                   float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                                                   int64_t* covered_rows, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0, "negative n");
+    WISP_REQUIRE(num_lods >= 1 && num_lods <= HG_MAX_LODS, "num_lods out of range");
+    WISP_REQUIRE(covered_rows && param && exp_avg && exp_avg_sq && step >= 1, "optimizer arguments missing");
+    for (int l = 0; l < num_lods; ++l) covered_rows[l] = 0;
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(coords && grad_feats && first_idx && resolutions && grad_codebook, "null pointer");
+    WISP_REQUIRE(coord_dim == 2 || coord_dim == 3, "coord_dim must be 2 or 3");
+    WISP_REQUIRE(codebook_bitwidth >= 1 && codebook_bitwidth <= 30, "codebook_bitwidth out of range");
+    WISP_REQUIRE(dtype == WISP_F32 || dtype == WISP_F16 || dtype == WISP_BF16, "bad dtype");
+    HashLevels lv;
+    const int64_t tsize = (int64_t)1 << codebook_bitwidth;
+    WISP_REQUIRE(fill_levels(resolutions, num_lods, coord_dim, tsize, lv) == 0, "bad resolution");
+    // bias corrections exactly as wisp_adamw_step_groups computes them
+    const AdamFlush ad{param, exp_avg, exp_avg_sq, (__hip_bfloat16*)bf16_shadow, lr, weight_decay, beta1, beta2, eps,
+                       1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), grad_scale};
+    hipStream_t s = (hipStream_t)stream;
+    HG_DISPATCH(launch_bwd, coords, n, grad_feats, first_idx, lv, num_lods, (uint32_t)tsize, zero_from_col,
+                grad_codebook, workspace, workspace_bytes, level_cap_scale, s, &ad, covered_rows)
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }

@@ -25,12 +25,7 @@ adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m
             float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float gr = gp[k] * gscale;
-                pp[k] *= (1.0f - lr * wd);                               // decoupled weight decay
-                mp[k] = b1 * mp[k] + (1.0f - b1) * gr;
-                vp[k] = b2 * vp[k] + (1.0f - b2) * gr * gr;
-                const float denom = sqrtf(vp[k]) / bc2_sqrt + eps;
-                pp[k] -= (lr / bc1) * (mp[k] / denom);
+                wisp_adamw_update(pp[k], mp[k], vp[k], gp[k] * gscale, lr, wd, b1, b2, eps, bc1, bc2_sqrt);
             }
             *reinterpret_cast<float4*>(p + i) = pv;
             *reinterpret_cast<float4*>(m + i) = mv;
@@ -42,12 +37,8 @@ adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m
             }
         } else {
             for (int64_t j = i; j < n; ++j) {
-                const float gr = g[j] * gscale;
-                float pj = p[j] * (1.0f - lr * wd);
-                const float mj = b1 * m[j] + (1.0f - b1) * gr;
-                const float vj = b2 * v[j] + (1.0f - b2) * gr * gr;
-                const float denom = sqrtf(vj) / bc2_sqrt + eps;
-                pj -= (lr / bc1) * (mj / denom);
+                float pj = p[j], mj = m[j], vj = v[j];
+                wisp_adamw_update(pj, mj, vj, g[j] * gscale, lr, wd, b1, b2, eps, bc1, bc2_sqrt);
                 p[j] = pj; m[j] = mj; v[j] = vj;
                 if (zero_grad) g[j] = 0.0f;
                 if (shadow) shadow[j] = __float2bfloat16(pj);
@@ -100,7 +91,10 @@ adamw_groups_kernel(float* __restrict__ p, float* __restrict__ g, float* __restr
         const float lr = gr.lr[k], wd = gr.wd[k];
         __hip_bfloat16* shadow = gr.shadow[k];
         float pv[4], gv[4], mv[4], vv[4];
-        if (cnt == 4) {
+        // (a group may start off a 16-byte boundary - the rows the hash-grid backward's fused update leaves over begin where a
+        //  level begins: such a group goes element by element)
+        const bool vec = cnt == 4 && (i & 3) == 0;
+        if (vec) {
             *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + i);
             *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + i);
             *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m + i);
@@ -111,14 +105,9 @@ adamw_groups_kernel(float* __restrict__ p, float* __restrict__ g, float* __restr
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float x = gv[e] * gscale;
-            pv[e] *= (1.0f - lr * wd);
-            mv[e] = b1 * mv[e] + (1.0f - b1) * x;
-            vv[e] = b2 * vv[e] + (1.0f - b2) * x * x;
-            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
-            pv[e] -= (lr / bc1) * (mv[e] / denom);
+            wisp_adamw_update(pv[e], mv[e], vv[e], gv[e] * gscale, lr, wd, b1, b2, eps, bc1, bc2_sqrt);
         }
-        if (cnt == 4) {
+        if (vec) {
             *reinterpret_cast<float4*>(p + i) = *reinterpret_cast<float4*>(pv);
             *reinterpret_cast<float4*>(m + i) = *reinterpret_cast<float4*>(mv);
             *reinterpret_cast<float4*>(v + i) = *reinterpret_cast<float4*>(vv);
@@ -148,7 +137,7 @@ extern "C" int wisp_adamw_step_groups(float* param, const float* grad, float* ex
     gr.n = num_groups;
     gr.chunk0[0] = 0;
     for (int k = 0; k < num_groups; ++k) {
-        WISP_REQUIRE(group_begin[k] >= 0 && group_len[k] >= 0 && group_begin[k] % 4 == 0, "group ranges must start on a 16-byte boundary");
+        WISP_REQUIRE(group_begin[k] >= 0 && group_len[k] >= 0, "negative group range");
         gr.begin[k] = group_begin[k]; gr.len[k] = group_len[k];
         gr.lr[k] = group_lr[k]; gr.wd[k] = group_weight_decay[k];
         gr.shadow[k] = group_bf16_shadow ? (__hip_bfloat16*)group_bf16_shadow[k] : nullptr;
@@ -203,7 +192,8 @@ optim_groups_kernel(float* __restrict__ p, float* __restrict__ g, float* __restr
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float x = gv[e] * gscale;
-            if (KIND == 0) pv[e] *= (1.0f - lr * wd); else x += wd * pv[e];
+            if (KIND == 0) { wisp_adamw_update(pv[e], av[e], bv[e], x, lr, wd, h0, h1, eps, bc1, bc2_sqrt); continue; }
+            x += wd * pv[e];
             if (KIND == 2) {
                 bv[e] = h0 * bv[e] + (1.0f - h0) * x * x;                  // square_avg
                 const float avg = sqrtf(bv[e]) + eps;

@@ -44,6 +44,20 @@ static inline hipError_t wisp_allow_lds_once(const void* fn, size_t bytes, size_
         return wisp_allow_lds_once(reinterpret_cast<const void*>(kern), (size_t)(bytes), granted_);      \
     })()
 
+// torch.optim.AdamW's update of ONE element (decoupled decay, torch/optim/adamw.py _single_tensor_adamw), written once: the flat
+// optimizer kernels (misc.hip) and the hash-grid reduce kernel's fused flush (hashgrid.hip) must produce the same bits.
+// bc1 = 1 - beta1^step, bc2_sqrt = sqrt(1 - beta2^step); g already carries the caller's gradient scale.
+static __device__ __forceinline__ void wisp_adamw_update(float& p, float& m, float& v, float g, float lr, float wd, float b1,
+                                                         float b2, float eps, float bc1, float bc2_sqrt) {
+    // Which products fuse into which sums is spelled out (and the compiler's own contraction switched off): left to itself it
+    // fused b1 * m + (1 - b1) * g one way in one kernel and the other way in the next.
+#pragma clang fp contract(off)
+    p = p * (1.0f - lr * wd);
+    m = __builtin_fmaf(b1, m, (1.0f - b1) * g);
+    v = __builtin_fmaf(b2, v, ((1.0f - b2) * g) * g);
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = __builtin_fmaf(-(lr / bc1), m / denom, p);
+}
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t min64(int64_t a, int64_t b) { return a < b ? a : b; }
 

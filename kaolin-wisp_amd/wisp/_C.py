@@ -33,6 +33,8 @@ c_vp, c_i64, c_i32, c_f32, c_u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 SIGNATURES = {
     "wisp_hashgrid_interpolate_fwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     "wisp_hashgrid_interpolate_bwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp],
+    "wisp_hashgrid_interpolate_bwd_adamw": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp,
+                                            c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32, c_vp, c_vp],
     "wisp_hashgrid_bwd_workspace_bytes": [c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp],
     "wisp_hashgrid_bwd_slot_stats": [c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_hashgrid_cells": [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
@@ -260,9 +262,13 @@ def hashgrid_interpolate(coords, codebook, first_idx, resolutions, codebook_bitw
 
 
 def hashgrid_interpolate_backward(coords, grad_feats, codebook_shape, first_idx, resolutions, codebook_bitwidth,
-                                  zero_from_col=None, out=None):
+                                  zero_from_col=None, out=None, adamw=None):
     """fp32 grad_codebook - wisp._C.ops.hashgrid_interpolate_backward_cuda (hashgrid_interpolate.cpp:71-105).
-    `out` (fp32, same shape) is accumulated into when given."""
+    `out` (fp32, same shape) is accumulated into when given.
+    adamw (needs `out`): dict(param, exp_avg, exp_avg_sq [fp32, the table's shape], shadow [bf16 or None], lr, beta1, beta2, eps,
+    weight_decay, step, grad_scale) - the table's AdamW step folded into the backward (wisp_hashgrid_interpolate_bwd_adamw);
+    returns (grad, covered) then, covered[l] = leading rows of level l that were updated inside the launch (their gradient is
+    not in `out`); all other rows are the caller's to update."""
     coords = _need(coords, torch.float32, "coords")
     grad_feats = _need(grad_feats, None, "grad_feats")
     first_idx = _need(first_idx, torch.int64, "codebook_first_idx")
@@ -281,14 +287,32 @@ def hashgrid_interpolate_backward(coords, grad_feats, codebook_shape, first_idx,
     scale_ptr = None if scale_arr is None else ctypes.cast(scale_arr, ctypes.c_void_p)
     ws_bytes = int(lib.wisp_hashgrid_bwd_workspace_bytes(n, dim, dt, F, res_ptr, L, codebook_bitwidth, scale_ptr))
     ws = _bwd_workspace(coords.device, ws_bytes) if 0 < ws_bytes <= HASHGRID_BWD_WORKSPACE_LIMIT else None
+    covered = None
     with _timed("hashgrid_bwd", n):
-        _check(lib.wisp_hashgrid_interpolate_bwd(_p(coords), n, dim, _p(grad_feats), dt, F,
-                                                 _p(first_idx), res_ptr, L, codebook_bitwidth, zero_from_col, _p(grad),
-                                                 _p(ws), ws.numel() if ws is not None else 0, scale_ptr, _stream()),
-               "hashgrid_interpolate_bwd")
+        if adamw is None:
+            _check(lib.wisp_hashgrid_interpolate_bwd(_p(coords), n, dim, _p(grad_feats), dt, F,
+                                                     _p(first_idx), res_ptr, L, codebook_bitwidth, zero_from_col, _p(grad),
+                                                     _p(ws), ws.numel() if ws is not None else 0, scale_ptr, _stream()),
+                   "hashgrid_interpolate_bwd")
+        else:
+            assert out is not None, "the fused update leaves the uncovered rows' gradient in `out`"
+            prm, m1, m2, sh = adamw["param"], adamw["exp_avg"], adamw["exp_avg_sq"], adamw.get("shadow")
+            for t in (prm, m1, m2):
+                assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == grad.numel()
+            assert sh is None or (sh.dtype == torch.bfloat16 and sh.is_contiguous() and sh.numel() == grad.numel())
+            cov = (ctypes.c_int64 * L)()
+            _check(lib.wisp_hashgrid_interpolate_bwd_adamw(_p(coords), n, dim, _p(grad_feats), dt, F,
+                                                           _p(first_idx), res_ptr, L, codebook_bitwidth, zero_from_col, _p(grad),
+                                                           _p(ws), ws.numel() if ws is not None else 0, scale_ptr,
+                                                           _p(prm), _p(m1), _p(m2), _p(sh), float(adamw["lr"]), float(adamw["beta1"]),
+                                                           float(adamw["beta2"]), float(adamw["eps"]), float(adamw["weight_decay"]),
+                                                           int(adamw["step"]), float(adamw.get("grad_scale", 1.0)),
+                                                           ctypes.cast(cov, ctypes.c_void_p), _stream()),
+                   "hashgrid_interpolate_bwd_adamw")
+            covered = list(cov)
     if fit is not None and ws is not None:
         fit.after_launch(n, res_ptr, scale_arr, scale_ptr, ws, ws_bytes)
-    return grad
+    return grad if adamw is None else (grad, covered)
 
 
 HASHGRID_BWD_WORKSPACE_LIMIT = 24 << 30          # bytes; 288 GB of HBM makes a multi-GB scratch a fair trade
@@ -1230,11 +1254,19 @@ def gather_rows(index, tensors, out=None):
     return outs
 
 
+ADAMW_MAX_GROUPS = 4            # misc.hip
+
+
 def adamw_step_groups(param, grad, exp_avg, exp_avg_sq, groups, beta1, beta2, eps, step, grad_scale=1.0, zero_grad=False):
     """One launch for several parameter groups of a flat buffer.  groups: list of (begin, length, lr, weight_decay,
-    bf16_shadow or None) with `begin` a multiple of 4 elements."""
+    bf16_shadow or None); a group whose `begin` is a multiple of 4 elements is processed 16 bytes at a time.  More than
+    ADAMW_MAX_GROUPS groups go out as several launches."""
     for t in (param, grad, exp_avg, exp_avg_sq):
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    if len(groups) > ADAMW_MAX_GROUPS:
+        for k in range(0, len(groups), ADAMW_MAX_GROUPS):
+            adamw_step_groups(param, grad, exp_avg, exp_avg_sq, groups[k:k + ADAMW_MAX_GROUPS], beta1, beta2, eps, step, grad_scale, zero_grad)
+        return
     n = len(groups)
     begin = (ctypes.c_int64 * n)(*[int(g[0]) for g in groups])
     length = (ctypes.c_int64 * n)(*[int(g[1]) for g in groups])

@@ -161,6 +161,7 @@ class _DirectNeRFStep:
             # the tracer queries lod_idx = num_lods - 1 and 'cat' zeroes the columns from lod_idx * feature_dim on
             # (reference hash_grid.py:226-229): the finest level's columns are zero, exactly as in the modular path
             self.zero_from_col = (grid.num_lods - 1) * grid.feature_dim
+            self._first_idx_host = [int(v) for v in cb.begin_idxes.detach().cpu().reshape(-1).tolist()]
         self.octree_tier = None if self.hash_fast else self._octree_tier(grid)
         self._pending = None
         self._cells = (None, None, 1)
@@ -306,8 +307,11 @@ class _DirectNeRFStep:
         self._cells = (getattr(rm, "nugget_pidx", None), getattr(rm, "nugget_level", None), getattr(rm, "samples_per_nugget", 1))
         return rm.ridx, rm.samples, rm.deltas, rm.ray_offsets, dirs
 
-    def run(self, rays, img_gts, jitter=None, prefetch=None):
+    def run(self, rays, img_gts, jitter=None, prefetch=None, fused_update=None):
         """-> (loss tensor, num_samples); gradients are left accumulated in the parameters' .grad (the flat gradient buffer).
+        `fused_update` (MultiviewTrainStep._fused_update_args; hash-grid tier only): the table's AdamW step is folded into the
+        grid backward for the rows whose reduce workgroup owns them - their gradient never reaches the flat buffer; which rows
+        those were is left in trainer._fused_cover for the optimizer step that follows to skip.
         `prefetch`: the Rays of the NEXT step; with the 'ray' march their parameter-free prefix (occupancy test + offsets) is
         issued now, behind this step's own raymarch, so that the next step finds its sample count already computed instead of
         stalling the GPU on the size read-back."""
@@ -368,8 +372,13 @@ class _DirectNeRFStep:
             self._scatter_param_grads(packed_grad)
         t.early_reduce_decoder()                # decoder gradients are final: their all-reduce runs under the grid backward
         if self.hash_fast:
-            C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res, self.bitwidth,
-                                            self.zero_from_col, out=self.table.grad)
+            if fused_update is not None:
+                _, t._fused_cover = C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res,
+                                                                    self.bitwidth, self.zero_from_col, out=self.table.grad,
+                                                                    adamw=fused_update)
+            else:
+                C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res, self.bitwidth,
+                                                self.zero_from_col, out=self.table.grad)
         elif self.octree_tier is not None and grid.training:
             self._octree_backward(octx, g_feats)
         elif feats.requires_grad:
@@ -470,14 +479,65 @@ class MultiviewTrainStep:
         # specialised issue order for the flagship pipeline shape (WISP_DIRECT_STEP=0 keeps the modular path)
         self._direct = None
         self._last_step_modular = True
+        # One GPU, AdamW, the nerf_hash.yaml table: the grid's optimizer step is folded into the hash-grid backward's reduce kernel
+        # (see _fused_update_args).  WISP_ADAM_IN_FLUSH=0 / fuse_grid_optimizer = False keep the separate pass.
+        self.fuse_grid_optimizer = os.environ.get("WISP_ADAM_IN_FLUSH", "1") != "0"
+        self._fused_cover = None
+        self.fused_elements_last = 0
         if os.environ.get("WISP_DIRECT_STEP", "1") != "0" and _DirectNeRFStep.supports(pipeline):
             d = _DirectNeRFStep(self)
             self._direct = d if d.ok else None
 
     # -------------------------------------------------------------------------------------------- schedule / groups
-    def _lr_scale(self):
-        k = sum(1 for m in self.milestones if self.opt_steps >= m)       # MultiStepLR
+    def _lr_scale(self, step=None):
+        step = self.opt_steps if step is None else step
+        k = sum(1 for m in self.milestones if step >= m)                 # MultiStepLR
         return self.gamma ** k
+
+    def _fused_update_args(self):
+        """Arguments of C.hashgrid_interpolate_backward(adamw=...) for the step that is about to run, or None when the grid's
+        optimizer step cannot be folded into its backward: more than one rank (the gradient is exchanged first), another
+        optimizer, another grid tier.  The update is optimizer_step's own for the grid group - same learning rate schedule,
+        same step count, same arithmetic (wisp_adamw_update) - applied by the reduce workgroup that owns a table slice instead
+        of by a second pass: 12 of the 42 bytes per parameter the two passes move stay in LDS, and the rest of the optimizer's
+        traffic runs under the reduce kernel's record walk."""
+        d, f = self._direct, self.flat
+        if (not self.fuse_grid_optimizer or d is None or not d.hash_fast or self.optimizer != 'adamw' or self.world > 1
+                or self.force_allreduce or not f.data.is_cuda or d.table.shape[1] != 2):
+            return None
+        if 'optimizer_step' in self.__dict__:
+            return None                         # someone replaced the optimizer step on this instance: it gets the whole gradient
+        off = next((o for p, o in f._grid_params if p is d.table), None)
+        if off is None:
+            return None
+        n = d.table.numel()
+        a, _ = f.ranges["grid"]
+        step = self.opt_steps + 1
+        return dict(param=d.table.detach(), exp_avg=f.exp_avg[off:off + n].view(d.table.shape),
+                    exp_avg_sq=f.exp_avg_sq[off:off + n].view(d.table.shape),
+                    shadow=None if f.shadow is None else f.shadow[off - a:off - a + n].view(d.table.shape),
+                    lr=self.lr * self.grid_lr_weight * self._lr_scale(step), beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                    weight_decay=self.weight_decay, step=step, grad_scale=1.0 / self.world)
+
+    def _uncovered_grid_ranges(self, covered):
+        """[lo, hi) element ranges of the flat buffer inside the grid group that the fused update did NOT touch."""
+        d, f = self._direct, self.flat
+        a, b = f.ranges["grid"]
+        off = next(o for p, o in f._grid_params if p is d.table)
+        F, first = d.table.shape[1], d._first_idx_host
+        out, at = [], a
+        for l, rows in enumerate(covered):
+            rows = min(int(rows), first[l + 1] - first[l])
+            if rows <= 0:
+                continue
+            lo, hi = off + first[l] * F, off + (first[l] + rows) * F
+            if lo > at:
+                out.append((at, lo))
+            at = max(at, hi)
+        if b > at:
+            out.append((at, b))
+        self.fused_elements_last = (b - a) - sum(hi - lo for lo, hi in out)      # (bench.py: the optimizer's share of the launch)
+        return out
 
     def optimizer_step(self, grid_ranges=None):
         """grid_ranges: None -> the whole grid group; else a list of [lo, hi) element ranges of the flat buffer inside the grid
@@ -604,7 +664,12 @@ class MultiviewTrainStep:
         if plan is None:
             self.allreduce_grads()
             self._mark("all_reduce")
-            self.optimizer_step()
+            cover, self._fused_cover = self._fused_cover, None
+            if cover is not None and any(cover):
+                self.optimizer_step(self._uncovered_grid_ranges(cover))
+            else:
+                self.fused_elements_last = 0
+                self.optimizer_step()
             self._mark("optimizer")
         else:
             self._sharded_reduce_and_update(plan)
@@ -795,7 +860,7 @@ class MultiviewTrainStep:
         self._last_step_modular = not (self._direct is not None and self.pipeline.nef.training)
         if not self._last_step_modular:
             with torch.no_grad():
-                loss, _ = self._direct.run(rays, img_gts, jitter, prefetch)
+                loss, _ = self._direct.run(rays, img_gts, jitter, prefetch, fused_update=self._fused_update_args())
         else:
             self.wait_for_parameters()
             kw = {} if jitter is None else {"jitter": jitter}

@@ -227,6 +227,76 @@ def test_hashgrid_backward_is_exact_under_any_loss_scale(dtype, log2_scale):
     assert float(same) >= 0.999, float(same)                         # (a slot overflow would go through atomics: none expected here)
 
 
+@pytest.mark.parametrize("amp", [True, False])
+def test_hashgrid_backward_with_the_adamw_step_folded_in_matches_oracle_gradient_and_torch_adamw(amp):
+    """wisp_hashgrid_interpolate_bwd_adamw: the reduce workgroup that owns a slice of the table applies torch.optim.AdamW's step
+    (base_trainer.py:205-246 configures it, multiview_trainer.py:169-174 steps it) to it instead of writing the gradient out.
+    Two steps.  Gradient path: the first moment is linear in the gradient, so it is held against the float64 oracle gradient
+    pushed through torch.optim.AdamW at the backward's own tolerance.  Update arithmetic: parameters against torch.optim.AdamW
+    (CPU) fed the gradient the plain backward produces for the same inputs.  Rows the launch reports as not covered keep their
+    parameters and hold the oracle's gradient; covered rows leave no gradient behind."""
+    rng = np.random.default_rng(1234)
+    _, begin = ohash.table_layout(NGP_RES, 2 ** 19)
+    shape = (int(begin[-1]), 2)
+    n = 24000
+    coords = _ray_like_coords(rng, n)
+    dt = torch.bfloat16 if amp else torch.float32
+    lr, b1, b2, eps, wd = 1e-2, 0.9, 0.999, 1e-15, 1e-2
+    table0 = torch.from_numpy(rng.uniform(-0.1, 0.1, shape).astype(np.float32))
+    ref_o = table0.clone().requires_grad_(True)          # driven by the oracle's gradient
+    ref_d = table0.clone().requires_grad_(True)          # driven by the device's plain-backward gradient
+    opt_o = torch.optim.AdamW([ref_o], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+    opt_d = torch.optim.AdamW([ref_d], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+    prm = table0.to(DEV).clone()
+    m1, m2 = torch.zeros_like(prm), torch.zeros_like(prm)
+    shadow = prm.bfloat16() if amp else None
+    grad = torch.zeros(shape, device=DEV)
+    cbegin = cuda(begin)
+    for step in (1, 2):
+        go = torch.from_numpy((rng.normal(size=(n, 32)) * 1e-3).astype(np.float32)).to(dt)
+        goz = go.float().clone()
+        goz[:, 30:] = 0
+        want = ohash.hashgrid_backward(torch.from_numpy(coords), goz, shape, torch.from_numpy(begin), NGP_RES, 19, torch.float64)
+        plain = _C().hashgrid_interpolate_backward(cuda(coords), go.to(DEV), shape, cbegin, NGP_RES, 19, zero_from_col=30).cpu()
+        before = prm.clone()
+        _, covered = _C().hashgrid_interpolate_backward(
+            cuda(coords), go.to(DEV), shape, cbegin, NGP_RES, 19, zero_from_col=30, out=grad,
+            adamw=dict(param=prm, exp_avg=m1, exp_avg_sq=m2, shadow=shadow, lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd,
+                       step=step, grad_scale=1.0))
+        assert len(covered) == 16 and covered[15] == 0 and all(covered[l] == int(begin[l + 1] - begin[l]) for l in range(7, 15)), covered
+        assert all(c == 0 for c in covered[:7])                      # coarse levels: buckets shared by several workgroups
+        mask = torch.zeros(shape[0], dtype=torch.bool)
+        for l, c in enumerate(covered):
+            mask[int(begin[l]):int(begin[l]) + c] = True
+        g_dev = grad.cpu()
+        gscale = float(want.abs().max())
+        tol = (3e-5 if amp else 4e-6) * gscale
+        assert float((plain.double() - want).abs().max()) <= tol
+        # not covered: parameters untouched, gradient = the oracle's; covered: nothing left in the gradient table
+        assert torch.equal(prm.cpu()[~mask], before.cpu()[~mask])
+        assert float((g_dev[~mask].double() - want[~mask]).abs().max()) <= tol
+        assert float(g_dev[mask].abs().max()) == 0.0
+        # the caller's share: AdamW over the rest (what MultiviewTrainStep.optimizer_step does with the uncovered ranges)
+        rest = [(int(begin[0]) * 2, int(begin[7]) * 2), (int(begin[15]) * 2, int(begin[16]) * 2)]
+        _C().adamw_step_groups(prm.view(-1), grad.view(-1), m1.view(-1), m2.view(-1),
+                               [(lo, hi - lo, lr, wd, None if shadow is None else shadow.view(-1)[lo:hi]) for lo, hi in rest],
+                               b1, b2, eps, step, zero_grad=True)
+        assert float(grad.abs().max()) == 0.0
+        # gradient path against the oracle, through the (linear) first moment: 0.1 x gradient after step 1, <= 0.19 x after step 2
+        ref_o.grad = want.float()
+        opt_o.step()
+        assert float((m1.cpu().double() - opt_o.state[ref_o]["exp_avg"].double()).abs().max()) <= 0.2 * tol
+        # update arithmetic against torch.optim.AdamW on the same gradient
+        ref_d.grad = plain.clone()
+        opt_d.step()
+        np.testing.assert_allclose(prm.cpu().numpy(), ref_d.detach().numpy(), rtol=0, atol=2e-6)
+        # (moments: 1 - beta is formed in fp32 here, in double by torch - 1.3e-5 relative on 1 - 0.999)
+        np.testing.assert_allclose(m1.cpu().numpy(), opt_d.state[ref_d]["exp_avg"].numpy(), rtol=1e-5, atol=1e-6 * gscale)
+        np.testing.assert_allclose(m2.cpu().numpy(), opt_d.state[ref_d]["exp_avg_sq"].numpy(), rtol=1e-4, atol=1e-6 * gscale * gscale)
+        if shadow is not None:
+            assert torch.equal(shadow, prm.bfloat16())
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
 def test_hashgrid_backward_propagates_non_finite_gradients(dtype):
     """An fp16 gradient that overflowed under a too-large loss scale arrives as +-inf (or NaN).  The reference's float atomics

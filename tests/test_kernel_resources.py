@@ -43,16 +43,18 @@ def test_flagship_step_kernels_keep_their_occupancy(kern, dtype):
         assert v["scratch"] == 0 and v["vgpr"] <= 256, (name, v)                               # one 512-thread workgroup per CU
     for name, v in _pick(kern, "hashgrid_fwd_kernel<" + dtype + ", 16, 3>").items():
         assert v["scratch"] == 0 and v["vgpr"] <= 128 and v["wg"] == 256, (name, v)           # measured: 124
-    for name, v in _pick(kern, "hashgrid_bwd_reduce_kernel<" + dtype + ", 2>").items():
+    for name, v in _pick(kern, "hashgrid_bwd_reduce_kernel<" + dtype + ", 2, false>").items():
         assert v["scratch"] == 0 and v["vgpr"] <= 64 and v["wg"] == 1024, (name, v)           # measured: 40
+    for name, v in _pick(kern, "hashgrid_bwd_reduce_kernel<" + dtype + ", 2, true>").items():     # with the AdamW step in its flush
+        assert v["scratch"] == 0 and v["vgpr"] <= 96 and v["wg"] == 1024, (name, v)           # measured: 68
 
 
 def test_spills_stay_off_the_measured_paths(kern):
     """Some instantiations do spill (feature width 16 hash tables, the decoder without PIN, the pre-queue emitter); none of them is
     launched by the configurations of BASELINE.json.  The list may shrink, not grow."""
     spilling = sorted(n for n, v in kern.items() if v["scratch"] > 0)
-    allowed = ("hashgrid_bwd_emit_kernel<", "hashgrid_bwd_kernel<", "hashgrid_bwd_reduce_kernel<float, 16>", "hashgrid_bwd_reduce_kernel<__half, 16>",
-               "hashgrid_bwd_reduce_kernel<__hip_bfloat16, 16>", "mlp_fwd_kernel<float, false, false", "mlp_fwd_kernel<__half, false, false",
+    allowed = ("hashgrid_bwd_emit_kernel<", "hashgrid_bwd_kernel<", "hashgrid_bwd_reduce_kernel<float, 16, false>", "hashgrid_bwd_reduce_kernel<__half, 16, false>",
+               "hashgrid_bwd_reduce_kernel<__hip_bfloat16, 16, false>", "mlp_fwd_kernel<float, false, false", "mlp_fwd_kernel<__half, false, false",
                "mlp_fwd_kernel<__hip_bfloat16, false, false", "mlp_fwd_kernel<float, true, false", "mlp_fwd_kernel<__half, true, false",
                "mlp_fwd_kernel<__hip_bfloat16, true, false")
     for name in spilling:
