@@ -886,7 +886,7 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
             float* __restrict__ pm = ad.m + slice;
             float* __restrict__ pv = ad.v + slice;
             __hip_bfloat16* __restrict__ ps = ad.shadow ? ad.shadow + slice : nullptr;
-            constexpr int PQ = 4;                                         // pairs per thread and round trip
+            constexpr int PQ = 4;                       // pairs per thread and round trip (8: 99 registers, the same time)
             const uint32_t pairs = lim >> 1;
             if ((lim & 1u) == 0 && (((uintptr_t)dst | (uintptr_t)pp | (uintptr_t)pm | (uintptr_t)pv) & 7u) == 0) {
                 for (uint32_t i0 = threadIdx.x; i0 < pairs; i0 += PQ * RD_THREADS) {
