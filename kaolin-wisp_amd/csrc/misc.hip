@@ -92,13 +92,23 @@ adamw_groups_kernel(float* __restrict__ p, float* __restrict__ g, float* __restr
         __hip_bfloat16* shadow = gr.shadow[k];
         float pv[4], gv[4], mv[4], vv[4];
         // (a group may start off a 16-byte boundary - the rows the hash-grid backward's fused update leaves over begin where a
-        //  level begins: such a group goes element by element)
+        //  level begins, i.e. on a multiple of the feature width: such a group goes in 8-byte halves, anything else element
+        //  by element)
         const bool vec = cnt == 4 && (i & 3) == 0;
+        const bool vec2 = cnt == 4 && (i & 3) == 2;
         if (vec) {
             *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + i);
             *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + i);
             *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m + i);
             *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v + i);
+        } else if (vec2) {
+#pragma unroll
+            for (int h = 0; h < 4; h += 2) {
+                *reinterpret_cast<float2*>(pv + h) = *reinterpret_cast<const float2*>(p + i + h);
+                *reinterpret_cast<float2*>(gv + h) = *reinterpret_cast<const float2*>(g + i + h);
+                *reinterpret_cast<float2*>(mv + h) = *reinterpret_cast<const float2*>(m + i + h);
+                *reinterpret_cast<float2*>(vv + h) = *reinterpret_cast<const float2*>(v + i + h);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { pv[e] = e < cnt ? p[i + e] : 0.f; gv[e] = e < cnt ? g[i + e] : 0.f; mv[e] = e < cnt ? m[i + e] : 0.f; vv[e] = e < cnt ? v[i + e] : 0.f; }
@@ -112,6 +122,14 @@ adamw_groups_kernel(float* __restrict__ p, float* __restrict__ g, float* __restr
             *reinterpret_cast<float4*>(m + i) = *reinterpret_cast<float4*>(mv);
             *reinterpret_cast<float4*>(v + i) = *reinterpret_cast<float4*>(vv);
             if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (vec2) {
+#pragma unroll
+            for (int h = 0; h < 4; h += 2) {
+                *reinterpret_cast<float2*>(p + i + h) = *reinterpret_cast<float2*>(pv + h);
+                *reinterpret_cast<float2*>(m + i + h) = *reinterpret_cast<float2*>(mv + h);
+                *reinterpret_cast<float2*>(v + i + h) = *reinterpret_cast<float2*>(vv + h);
+                if (zero_grad) *reinterpret_cast<float2*>(g + i + h) = make_float2(0.f, 0.f);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
