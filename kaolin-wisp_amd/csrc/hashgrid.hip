@@ -432,6 +432,9 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #endif
 #define RD_THREADS 1024
 #define BIN_MAX_CHUNKS 1024
+#ifndef HG_ACC_PLANES
+#define HG_ACC_PLANES 1        // (0: A/B builds with the bucket accumulators interleaved by feature, as they were)
+#endif
 #ifndef HG_FLUSH_PAIRS
 #define HG_FLUSH_PAIRS 1       // (0: A/B builds of the reduce kernel's flush without its 8-byte path, scripts/gpu_r4_k.sh)
 #endif
@@ -823,7 +826,18 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
     const int64_t rows_l = first_idx[l + 1] - first_idx[l];
     const uint32_t entries = (uint32_t)(rows_l < (int64_t)bins.entries[li] ? (rows_l < 0 ? 0 : rows_l) : (int64_t)bins.entries[li]);
     const uint32_t lim = (entries > first ? min(entries - first, csize) : 0u) * F;
-    for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) A.zero(e);
+    // Accumulator slot of table element x = entry * F + feature of this bucket: one PLANE per feature ([F][csize]).  With the
+    // features of an entry side by side ([csize][F]) the lanes of one ds_add_u64 - random entries, one feature - can only
+    // land on every F-th 8-byte slot, i.e. on a 1/F of the banks.  (Worth 3 of 420 us only: what the kernel waits for is the
+    // RATE of LDS atomic instructions, ~15 clocks each per CU whatever their lanes hit - DESIGN.md 8-1.)
+    auto ax = [&](uint32_t x) -> uint32_t {
+#if HG_ACC_PLANES
+        return (x % (uint32_t)F) * csize + x / (uint32_t)F;
+#else
+        return x;
+#endif
+    };
+    for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) A.zero(ax(e));
     __syncthreads();
     const uint32_t* __restrict__ cnt = counts + bins.cnt_base[li] + (size_t)b * ntiles;
     const uint32_t* __restrict__ src = records + ((size_t)bins.rec_base[li] + (size_t)b * ntiles * cap) * RW;
@@ -869,7 +883,12 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
                     float val[F];
                     const uint32_t e = Codec::load(w[u], first, val);
 #pragma unroll
-                    for (int kk = 0; kk < F; ++kk) A.add(e * F + kk, val[kk]);
+                    for (int kk = 0; kk < F; ++kk) {
+#ifdef HG_EXP_NOATOM        // (timing experiment, scripts/gpu_r4_o.sh: the record walk without its LDS atomics - results are wrong)
+                        if (e == 0xffffffffu && val[kk] == 123.0f)
+#endif
+                        A.add(ax(e * F + kk), val[kk]);
+                    }
                 }
             }
         }
@@ -904,7 +923,7 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
                         const uint32_t i = i0 + q * RD_THREADS;
                         if (i < pairs) {
                             const bool dirty = cg[q].x != 0.0f || cg[q].y != 0.0f;
-                            const float g0 = cg[q].x + A.get(2 * i), g1 = cg[q].y + A.get(2 * i + 1);
+                            const float g0 = cg[q].x + A.get(ax(2 * i)), g1 = cg[q].y + A.get(ax(2 * i + 1));
                             wisp_adamw_update(cp[q].x, cm[q].x, cv[q].x, g0 * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
                             wisp_adamw_update(cp[q].y, cm[q].y, cv[q].y, g1 * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
                             reinterpret_cast<float2*>(pp)[i] = cp[q];
@@ -922,7 +941,7 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
                 for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
                     const float c = dst[e];
                     float x = pp[e], m1 = pm[e], m2 = pv[e];
-                    wisp_adamw_update(x, m1, m2, (c + A.get(e)) * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
+                    wisp_adamw_update(x, m1, m2, (c + A.get(ax(e))) * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
                     pp[e] = x; pm[e] = m1; pv[e] = m2;
                     if (c != 0.0f) dst[e] = 0.0f;
                     if (ps) ps[e] = __float2bfloat16(x);
@@ -948,8 +967,8 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
                 const uint32_t i = threadIdx.x + q * RD_THREADS;
                 if (i < quads) {
                     float4 t = cur[q];
-                    t.x += A.get(4 * i); t.y += A.get(4 * i + 1);
-                    t.z += A.get(4 * i + 2); t.w += A.get(4 * i + 3);
+                    t.x += A.get(ax(4 * i)); t.y += A.get(ax(4 * i + 1));
+                    t.z += A.get(ax(4 * i + 2)); t.w += A.get(ax(4 * i + 3));
                     reinterpret_cast<float4*>(dst)[i] = t;
                 }
             }
@@ -968,19 +987,19 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
                 const uint32_t i = threadIdx.x + q * RD_THREADS;
                 if (i < pairs) {
                     float2 t = cur[q];
-                    t.x += A.get(2 * i); t.y += A.get(2 * i + 1);
+                    t.x += A.get(ax(2 * i)); t.y += A.get(ax(2 * i + 1));
                     reinterpret_cast<float2*>(dst)[i] = t;
                 }
             }
         } else {
             for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
-                const float a = A.get(e);
+                const float a = A.get(ax(e));
                 if (a != 0.0f) dst[e] += a;
             }
         }
     } else {
         for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
-            const float a = A.get(e);
+            const float a = A.get(ax(e));
             if (a != 0.0f) atomicAdd(dst + e, a);         // coarse levels are split over several workgroups
         }
     }

@@ -17,7 +17,7 @@ t = 2.4 + torch.rand(R, 1, device=dev) * 1.4 + torch.arange(40, device=dev).floa
 coords = (o[:, None, :] + d[:, None, :] * t[..., None]).reshape(-1, 3).clamp(-1, 1).contiguous()
 blas = OctreeAS.make_dense(level=2)
 grid = HashGrid.from_geometric(blas, feature_dim=2, num_lods=16, multiscale_type='cat', feature_std=0.1, codebook_bitwidth=19,
-                               min_grid_res=16, max_grid_res=2048).to(dev)
+                               min_grid_res=16, max_grid_res=512).to(dev)
 cb = grid.codebook
 res = [int(r) for r in cb.resolutions.reshape(-1).tolist()]
 g = (torch.randn(S, 32, device=dev) * 1e-3).to(torch.bfloat16)
