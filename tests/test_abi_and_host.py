@@ -431,6 +431,59 @@ def test_allreduce_range_leaves_out_only_a_gradient_free_tail():
     assert t3._live_grad_numel() == t3.flat.grad.numel()
 
 
+def test_folded_grid_optimizer_host_logic():
+    """MultiviewTrainStep._fused_update_args / _uncovered_grid_ranges (host logic of the AdamW step folded into the hash-grid
+    backward): the folded update is offered only where it is the optimizer's own step for the table - one rank, AdamW, the
+    two-feature hash tier, nobody having replaced optimizer_step - with the learning rate and step count of the step that is
+    about to run; and the ranges left to the separate pass are exactly the complement of what the launch reported."""
+    import types
+    from wisp.trainers import FlatParams, MultiviewTrainStep
+
+    class Field(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.decoder = torch.nn.Linear(4, 3)
+            self.grid_table = torch.nn.Parameter(torch.zeros(10 + 20 + 30 + 40, 2))      # four levels: 10, 20, 30, 40 rows
+            self.grid_other = torch.nn.Parameter(torch.zeros(6))                         # something else in the grid group
+
+    m = Field()
+    t = MultiviewTrainStep.__new__(MultiviewTrainStep)
+    t.flat = FlatParams(m)
+    first = [0, 10, 30, 60, 100]
+    t._direct = types.SimpleNamespace(hash_fast=True, table=m.grid_table, _first_idx_host=first)
+    t.fuse_grid_optimizer, t.optimizer, t.world, t.force_allreduce = True, 'adamw', 1, False
+    t.lr, t.grid_lr_weight, t.betas, t.eps, t.weight_decay = 1e-3, 100.0, (0.9, 0.999), 1e-15, 1e-6
+    t.milestones, t.gamma, t.opt_steps = [3], 0.5, 1
+    # (the flat buffers live on the CPU here: the one condition that cannot be met without a GPU is stubbed)
+    class CudaLike(torch.Tensor):
+        is_cuda = True
+    t.flat.data = t.flat.data.as_subclass(CudaLike)
+    a = t._fused_update_args()
+    off = (m.grid_table.data_ptr() - t.flat.data.data_ptr()) // 4
+    assert a is not None and a["step"] == 2 and abs(a["lr"] - 0.1) < 1e-12 and a["shadow"] is None and a["grad_scale"] == 1.0
+    assert a["param"].data_ptr() == m.grid_table.data_ptr() and a["exp_avg"].shape == m.grid_table.shape
+    assert a["exp_avg"].data_ptr() == t.flat.exp_avg.data_ptr() + 4 * off
+    t.opt_steps = 2                                           # the step about to run is the milestone step
+    assert abs(t._fused_update_args()["lr"] - 0.05) < 1e-12
+    for attr, bad in (("world", 2), ("optimizer", "rmsprop"), ("force_allreduce", True), ("fuse_grid_optimizer", False)):
+        good = getattr(t, attr)
+        setattr(t, attr, bad)
+        assert t._fused_update_args() is None, attr
+        setattr(t, attr, good)
+    t.optimizer_step = lambda *a, **k: None                    # a replaced optimizer step gets the whole gradient
+    assert t._fused_update_args() is None
+    del t.optimizer_step
+    assert t._fused_update_args() is not None
+    # complement of the covered rows inside the grid group (levels 1 and 3 covered, level 3 only partly)
+    ga, gb = t.flat.ranges["grid"]
+    left = t._uncovered_grid_ranges([0, 20, 0, 25])
+    assert left == [(ga, off + 10 * 2), (off + 30 * 2, off + 60 * 2), (off + 85 * 2, gb)]
+    assert t.fused_elements_last == (20 + 25) * 2
+    assert t._uncovered_grid_ranges([0, 0, 0, 0]) == [(ga, gb)] and t.fused_elements_last == 0
+    # a count beyond the level's rows is clipped (the library reports its plan, the table may own fewer rows)
+    assert t._uncovered_grid_ranges([99, 0, 0, 0])[0][0] == off + 10 * 2
+
+
 def test_look_ahead_raytrace_state_is_only_used_where_it_fits(monkeypatch):
     """OctreeAS.raytrace(..., begun=state) / raymarch(..., begin_only / begun): host plumbing of the one-batch look-ahead with the HIP
     calls replaced by recorders - a state issued for the same Rays object, level and octree is finished as it is; one issued for
