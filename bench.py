@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (N > 1 without a launcher: starts the N ranks itself, the same way)
 
 One "step" = one pass of the hot path over one batch of rays: on-device ray sampling from the bank, raymarch
 ('ray', 2048 candidates per ray against the level-7 occupancy octree), hash-grid interpolation (L=16, F=2, T=2^19),
@@ -285,13 +286,19 @@ def dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev):
 
 
 # algorithmic work per packed sample (SURVEY.md 8d / DESIGN.md 4): bytes for the HBM-bound kernels, flops for the decoder
-def work_table(amp, hidden=64):
+def work_table(amp, hidden=64, levels=16, live_levels=None):
+    """`live_levels`: the levels the kernels really process.  PackedRFTracer queries lod_idx = num_lods - 1 and 'cat' zeroes the
+    columns from lod_idx * F on (reference hash_grid.py:226-229), so with nerf_hash.yaml the FINEST level is neither gathered nor
+    given a gradient: 15 of 16 levels are work done, and only those are charged (556 / 1036 B per sample instead of SURVEY's
+    nominal 588 / 1100).  The output / incoming-gradient row keeps all `levels` columns (the zero columns are written / read).
+    The decoder's first layer multiplies the zero columns like any other: its flops are not reduced."""
     b = 2 if amp else 4
+    live = levels if live_levels is None else min(int(live_levels), levels)
     mlp_flop = 2 * (32 * hidden + 16 * hidden + 42 * hidden + hidden * hidden + 3 * hidden)     # 20 096 at hidden 64
-    return {"hashgrid_fwd": ("hbm", 12 + 16 * 8 * 2 * b + 16 * 2 * b),        # coords + 128 gathered entries + 32 outputs
-            # 12 + L*F*b + 2*L*2^d*F*b_acc with b_acc = the table element size (1100 B for 16-bit tables).
+    return {"hashgrid_fwd": ("hbm", 12 + live * 8 * 2 * b + levels * 2 * b),   # coords + 8 corners x F=2 per live level + the output row
+            # SURVEY 8(d): 12 + L*F*b + 2*L*2^d*F*b_acc with b_acc = the table element size (1100 B for 16 levels of 16-bit tables).
             # The kernels accumulate in fp32 / 64-bit fixed point and merge runs, so what they actually move is `traffic`.
-            "hashgrid_bwd": ("hbm", 12 + 16 * 2 * b + 2 * 16 * 8 * 2 * b),
+            "hashgrid_bwd": ("hbm", 12 + levels * 2 * b + 2 * live * 8 * 2 * b),
             "nerf_mlp_fwd": ("mfma", mlp_flop), "nerf_mlp_bwd": ("mfma", 3 * mlp_flop)}
 
 
@@ -366,6 +373,33 @@ def _device(local):
     return torch.device("cuda", local)
 
 
+def _device_count():
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def _self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed.run environment: start the N ranks ourselves - this very
+    script under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` - instead of silently
+    measuring one GPU and labelling it N.  Rank 0's JSON line passes through on stdout; the exit code is the launcher's."""
+    import socket
+    import subprocess
+    have = _device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(sys.argv[0])] + list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc != 0:
+        raise SystemExit(rc)
+    return None
+
+
 def _init_dist(dev):
     dist.init_process_group(backend="nccl", device_id=dev)              # nccl == RCCL on ROCm
 
@@ -402,12 +436,14 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = _device(local)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ       # started by torch.distributed.run
+    if args.gpus > 1 and not launched and world == 1:
+        return _self_launch(args, argv)                    # N ranks were asked for and nobody started them: do it here
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, launched by torch.distributed.run"
+    dev = _device(local)
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         _init_dist(dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     selftest = collective_selftest(dev, rank) if dist.is_initialized() else None
     if selftest is not None and not selftest["sharded_path_ok"]:
         os.environ["WISP_SHARDED_OPTIM"] = "0"             # reduce-scatter / all-gather misbehave here: keep the all-reduce path
@@ -555,18 +591,22 @@ def main(argv=None):
         ms = [a.elapsed_time(b) for a, b, _ in evs]
         units = [u for _, _, u in evs]
         kern[name] = dict(avg_ms=float(np.mean(ms)), launches=len(ms), avg_units=float(np.mean(units)), total_ms=float(np.sum(ms)))
-    work = work_table(amp, args.hidden)
+    d = getattr(trainer, "_direct", None)
+    hash_direct = d is not None and getattr(d, "hash_fast", False) and not getattr(trainer, "_last_step_modular", True)
+    live_levels = min(NGP["num_lods"], d.zero_from_col // NGP["feature_dim"]) if hash_direct else NGP["num_lods"]
+    work = work_table(amp, args.hidden, NGP["num_lods"], live_levels)
     peaks = {"hbm": (HBM_PEAK_GBS, "GB/s"), "mfma": (2500.0 if amp else 157.3, "TFLOP/s")}
 
     # One GPU: the grid's AdamW step runs inside the hash-grid backward's reduce kernel (MultiviewTrainStep._fused_update_args), so
-    # that launch also does the optimizer's algorithmic work for the elements it updates: parameter and both moments read and
-    # written (24 B) + the bf16 copy (2 B); the gradient itself never leaves LDS.
+    # that launch also does the optimizer's work for the elements it updates: parameter and both moments read and written (24 B) +
+    # the bf16 copy (2 B); the gradient itself never leaves LDS.  That is a DIFFERENT quantity from SURVEY 8(d)'s backward bytes:
+    # `achieved` / `frac` are the backward's algorithmic bytes alone; the variant with the optimizer's bytes has its own key.
     fused_elems = int(getattr(trainer, "fused_elements_last", 0))
     fused_opt_bytes = fused_elems * (24 + (2 if amp else 0))
 
     def rate(name, v):
         bound, per = work[name]
-        r = (per * v["avg_units"] + (fused_opt_bytes if name == "hashgrid_bwd" else 0)) / (v["avg_ms"] * 1e-3)
+        r = per * v["avg_units"] / (v["avg_ms"] * 1e-3)
         return bound, (r / 1e9 if bound == "hbm" else r / 1e12)
 
     kern = {n: v for n, v in kern.items() if n in work}
@@ -579,19 +619,25 @@ def main(argv=None):
         roofline = dict(bound=bound, kernel=dominant, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
                         traffic=None, traffic_note="not measured (--no-pmc, multi-GPU run or profiler unavailable); see profiles/",
                         avg_launch_ms=k["avg_ms"], units_per_launch=k["avg_units"], work_per_unit=work[dominant][1],
+                        levels_processed=live_levels, levels_of_the_table=NGP["num_lods"],
+                        work_note="algorithmic bytes of the levels the kernels process: lod_idx = 15 zeroes the finest level's columns "
+                                  "(hash_grid.py:226-229), so 15 of 16 levels are gathered / scattered; SURVEY 8(d)'s nominal 16-level "
+                                  f"figures would be {work_table(amp, args.hidden)['hashgrid_fwd'][1]} / "
+                                  f"{work_table(amp, args.hidden)['hashgrid_bwd'][1]} B per sample",
                         all_kernels={n: dict(avg_ms=v["avg_ms"], bound=rate(n, v)[0], achieved=rate(n, v)[1],
-                                             frac=rate(n, v)[1] / peaks[rate(n, v)[0]][0]) for n, v in kern.items()})
+                                             frac=rate(n, v)[1] / peaks[rate(n, v)[0]][0], work_per_unit=work[n][1])
+                                     for n, v in kern.items()})
         if fused_opt_bytes and "hashgrid_bwd" in roofline["all_kernels"]:
             k = kern["hashgrid_bwd"]
-            plain = work["hashgrid_bwd"][1] * k["avg_units"] / (k["avg_ms"] * 1e-3) / 1e9
-            roofline["all_kernels"]["hashgrid_bwd"]["fused_optimizer"] = {
-                "elements_updated_in_the_launch": fused_elems, "bytes_per_launch": fused_opt_bytes,
-                "achieved_on_the_backward_bytes_alone": plain, "frac_on_the_backward_bytes_alone": plain / HBM_PEAK_GBS,
-                "note": "the launch pair also performs torch.optim.AdamW's step for the table rows its reduce workgroups own "
-                        "(parameter + two moments read and written, bf16 copy written: 26 B per element, counted in `achieved`); "
-                        "the separate optimizer launch only covers the coarse levels, the frozen finest level and the decoder"}
+            both = (work["hashgrid_bwd"][1] * k["avg_units"] + fused_opt_bytes) / (k["avg_ms"] * 1e-3) / 1e9
+            roofline["all_kernels"]["hashgrid_bwd"]["with_fused_optimizer"] = {
+                "elements_updated_in_the_launch": fused_elems, "optimizer_bytes_per_launch": fused_opt_bytes,
+                "achieved": both, "frac": both / HBM_PEAK_GBS,
+                "note": "NOT the headline figure: backward bytes + what torch.optim.AdamW's step moves for the table rows the reduce "
+                        "workgroups own (parameter + two moments read and written, bf16 copy written: 26 B per element); the "
+                        "separate optimizer launch only covers the coarse levels, the frozen finest level and the decoder"}
             if dominant == "hashgrid_bwd":
-                roofline["fused_optimizer"] = roofline["all_kernels"]["hashgrid_bwd"]["fused_optimizer"]
+                roofline["with_fused_optimizer"] = roofline["all_kernels"]["hashgrid_bwd"]["with_fused_optimizer"]
         if "hashgrid_fwd" in roofline["all_kernels"]:
             # SURVEY 8(d)'s algorithmic bytes (588 B/sample, 512 of them gathered table entries) over the launch time exceed the HBM
             # peak: the 20.9 MB of tables are re-read from L2 / Infinity Cache, so that figure is NOT an HBM fraction and is kept
@@ -618,11 +664,17 @@ def main(argv=None):
             psnr = 10 * math.log10(1.0 / max(mse, 1e-12))
         rays_total = R * args.steps * world
         ref_rays_total = R_ref * args.steps * world
-        amort = elapsed + (args.steps / trainer.prune_every - prunes_in) * prune_ms * 1e-3   # exactly steps/100 prunes
+        # "prune amortised".  A window of K steps holds K/100 prunes on average but floor or ceil of that in fact
+        # (none at all in the driver's 20 steps): `value` and `ms_per_step` always charge exactly K/100 prunes, at the cost of
+        # the prune timed on its own below; the raw window is kept under `timed_window`.
+        amort = elapsed + (args.steps / trainer.prune_every - prunes_in) * prune_ms * 1e-3 if trainer.prune_every > 0 else elapsed
         out = {
             "metric": "training rays/sec, HashGrid NeRF (nerf_hash.yaml), synthetic Lego 800x800",
-            "value": rays_total / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": rays_total / amort, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * amort / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "timed_window": {"seconds": elapsed, "ms_per_step": 1e3 * elapsed / args.steps, "value": rays_total / elapsed,
+                             "prunes_inside": prunes_in, "prunes_charged": args.steps / trainer.prune_every if trainer.prune_every > 0 else 0.0,
+                             "note": "`value` = rays / (window seconds + (steps / prune_every - prunes_inside) x prune.ms)"},
             "dtype": "bf16" if amp else "f32", "data": "synthetic",
             "config": {"workload": "app/nerf nerf_hash.yaml: OctreeAS level 7, HashGrid L=16 F=2 T=2^19 res 16..512 'cat', "
                                    f"NeRF hidden {args.hidden}, 'ray' raymarch {args.num_steps} candidates/ray, huber, AdamW; "
@@ -633,12 +685,14 @@ def main(argv=None):
                        "occupied_cells": cells_now, "true_occupied_cells": int(true_cells.shape[0]),
                        "prunes_inside_timed_steps": prunes_in},
             "samples_per_sec": total_samples_all / elapsed,
-            "prune": {"ms": prune_ms, "every_steps": trainer.prune_every,
-                      "value_with_amortised_prune": rays_total / amort},
+            "prune": {"ms": prune_ms, "every_steps": trainer.prune_every, "value_without_any_prune":
+                      rays_total / max(elapsed - prunes_in * prune_ms * 1e-3, 1e-9)},
             "reference_regime": {"target_samples_per_step": args.ref_target_samples, "rays_per_step_per_gpu": R_ref,
                                  "value": ref_rays_total / ref_elapsed, "unit": "rays/s",
                                  "ms_per_step": 1e3 * ref_elapsed / args.steps, "samples_per_sec": ref_samples_all / ref_elapsed,
                                  "prunes_inside_timed_steps": ref_prunes, "hip_event_timing_inside_the_loop": False,
+                                 "value_with_amortised_prune": ref_rays_total / (ref_elapsed + (args.steps / trainer.prune_every - ref_prunes)
+                                                                                 * prune_ms * 1e-3) if trainer.prune_every > 0 else None,
                                  # (what the prunes that fell into the window cost: round 3's 0.362 -> 0.389 ms was two of them)
                                  "ms_per_step_without_its_prunes": 1e3 * (ref_elapsed - ref_prunes * prune_ms * 1e-3) / args.steps,
                                  "note": "multiview_trainer.py:58 default batch (2^18 packed samples per step), same run"},

@@ -69,13 +69,15 @@ def _packs(lens, seed):
 
 
 # ------------------------------------------------------------------------------------------------ end to end
-def _build_pair(level=4, bitwidth=12, lods=16, hidden=64):
+def _build_pair(level=4, bitwidth=12, lods=16, hidden=64, dense=False):
     from wisp.accelstructs import OctreeAS
     from wisp.models.grids import HashGrid
     from wisp.models.nefs import NeuralRadianceField
     torch.manual_seed(0)
     rng = np.random.default_rng(81)
     P = rng.integers(0, 2 ** level, size=(1500, 3))
+    if dense:                                        # every cell of the level (nerf_hash.yaml:16-17 starts like this, at level 7)
+        P = np.stack(np.meshgrid(*[np.arange(2 ** level)] * 3, indexing='ij'), -1).reshape(-1, 3)
     blas = OctreeAS.from_quantized_points(torch.from_numpy(P).short().to(DEV), level)
     grid = HashGrid.from_geometric(blas, feature_dim=2, num_lods=lods, multiscale_type='cat', feature_std=0.2,
                                    codebook_bitwidth=bitwidth, min_grid_res=4, max_grid_res=64)

