@@ -13,6 +13,7 @@ class SampleRays:
     def set_num_samples(self, num_samples: int):
         self.num_samples = num_samples
 
+    @torch.cuda.nvtx.range("SampleRays")              # (ray_sampler.py:24; roctx on ROCm)
     def __call__(self, inputs: MultiviewBatch, generator=None):
         rays = inputs['rays']
         ray_idx = torch.randint(0, rays.shape[0], [self.num_samples], device=rays.origins.device, generator=generator)

@@ -309,9 +309,12 @@ class BaseTrainer(ABC):
             self.post_step()
 
     def train(self):
-        self.is_optimization_running = True
-        while self.is_optimization_running:
-            self.iterate()
+        # base_trainer.py:368: torch's per-op profiler ranges (roctx on ROCm) unless cfg.profile_nvtx is off; the profiler state
+        # needs a GPU runtime, so a CPU-only process (the host-logic tests) skips it
+        with torch.autograd.profiler.emit_nvtx(enabled=bool(self.cfg.profile_nvtx) and torch.cuda.is_available()):
+            self.is_optimization_running = True
+            while self.is_optimization_running:
+                self.iterate()
         return self.return_dict
 
     def save_model(self):

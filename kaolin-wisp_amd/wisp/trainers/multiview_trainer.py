@@ -30,6 +30,15 @@ def _hip():
     return _C
 
 
+# profiler ranges at the sites the reference marks (torch.cuda.nvtx == roctx on ROCm; a no-op without a profiler attached)
+def _range_push(msg):
+    torch.cuda.nvtx.range_push(msg)
+
+
+def _range_pop():
+    torch.cuda.nvtx.range_pop()
+
+
 class FlatParams:
     """Re-homes the trainable parameters of `module` into one flat buffer, grouped like init_optimizer does."""
 
@@ -311,7 +320,9 @@ class _DirectNeRFStep:
         """-> (loss tensor, num_samples); gradients are left accumulated in the parameters' .grad (the flat gradient buffer).
         `fused_update` (MultiviewTrainStep._fused_update_args; hash-grid tier only): the table's AdamW step is folded into the
         grid backward for the rows whose reduce workgroup owns them - their gradient never reaches the flat buffer; which rows
-        those were is left in trainer._fused_cover for the optimizer step that follows to skip.
+        those were is left in trainer._fused_cover for the optimizer step that follows to skip.  A caller that passes
+        `fused_update` MUST call trainer.reduce_and_update() right after: those rows (parameter, moments, bf16 copy) have taken
+        step `opt_steps + 1` already and only that call advances opt_steps and steps the remaining rows.
         `prefetch`: the Rays of the NEXT step; with the 'ray' march their parameter-free prefix (occupancy test + offsets) is
         issued now, behind this step's own raymarch, so that the next step finds its sample count already computed instead of
         stalling the GPU on the size read-back."""
@@ -366,23 +377,27 @@ class _DirectNeRFStep:
             loss, g_rgb = C.rgb_loss(rgb, img_gts, t.rgb_loss_type)
             loss = loss[0]
             g_color, g_density = C.composite_bwd(g_rgb, None, None, color, density, deltas, None, None, offsets, bg)
-        g_feats, _ = C.nerf_mlp_backward(feats_in, dirs, packed, g_color, g_density, i, h, f, t.enable_amp,
-                                         grad_params=packed_grad, ray_code=ray_code)
-        if self.biasless:
-            self._scatter_param_grads(packed_grad)
-        t.early_reduce_decoder()                # decoder gradients are final: their all-reduce runs under the grid backward
-        if self.hash_fast:
-            if fused_update is not None:
-                _, t._fused_cover = C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res,
-                                                                    self.bitwidth, self.zero_from_col, out=self.table.grad,
-                                                                    adamw=fused_update)
-            else:
-                C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res, self.bitwidth,
-                                                self.zero_from_col, out=self.table.grad)
-        elif self.octree_tier is not None and grid.training:
-            self._octree_backward(octx, g_feats)
-        elif feats.requires_grad:
-            feats.backward(g_feats.to(feats.dtype))
+        _range_push("MultiviewTrainer.backward")
+        try:
+            g_feats, _ = C.nerf_mlp_backward(feats_in, dirs, packed, g_color, g_density, i, h, f, t.enable_amp,
+                                             grad_params=packed_grad, ray_code=ray_code)
+            if self.biasless:
+                self._scatter_param_grads(packed_grad)
+            t.early_reduce_decoder()                # decoder gradients are final: their all-reduce runs under the grid backward
+            if self.hash_fast:
+                if fused_update is not None:
+                    _, t._fused_cover = C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res,
+                                                                        self.bitwidth, self.zero_from_col, out=self.table.grad,
+                                                                        adamw=fused_update)
+                else:
+                    C.hashgrid_interpolate_backward(samples, g_feats, tuple(self.table.shape), self.first_idx, self.res, self.bitwidth,
+                                                    self.zero_from_col, out=self.table.grad)
+            elif self.octree_tier is not None and grid.training:
+                self._octree_backward(octx, g_feats)
+            elif feats.requires_grad:
+                feats.backward(g_feats.to(feats.dtype))
+        finally:
+            _range_pop()
         return loss, S
 
 
@@ -505,8 +520,9 @@ class MultiviewTrainStep:
         if (not self.fuse_grid_optimizer or d is None or not d.hash_fast or self.optimizer != 'adamw' or self.world > 1
                 or self.force_allreduce or not f.data.is_cuda or d.table.shape[1] != 2):
             return None
-        if 'optimizer_step' in self.__dict__:
-            return None                         # someone replaced the optimizer step on this instance: it gets the whole gradient
+        if 'optimizer_step' in self.__dict__ or type(self).optimizer_step is not MultiviewTrainStep.optimizer_step \
+                or type(self).reduce_and_update is not MultiviewTrainStep.reduce_and_update:
+            return None                         # someone replaced the optimizer step (instance or subclass): it gets the whole gradient
         off = next((o for p, o in f._grid_params if p is d.table), None)
         if off is None:
             return None
@@ -854,22 +870,31 @@ class MultiviewTrainStep:
         """One optimisation step on this rank's ray shard.  Returns (loss tensor, num_samples).
         `prefetch` (optional): the Rays object the NEXT call will be given - the direct-issue path then runs their
         occupancy test early (a data-loader style look-ahead; results are the same with or without it)."""
-        self.pre_step()
-        self._refuse_stale_master_forward()
-        self.total_iterations += 1
-        self._last_step_modular = not (self._direct is not None and self.pipeline.nef.training)
-        if not self._last_step_modular:
-            with torch.no_grad():
-                loss, _ = self._direct.run(rays, img_gts, jitter, prefetch, fused_update=self._fused_update_args())
-        else:
-            self.wait_for_parameters()
-            kw = {} if jitter is None else {"jitter": jitter}
-            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.enable_amp):
-                rb = self.pipeline(rays=rays, lod_idx=None, channels=["rgb"], **kw)
-                loss = self.loss_fn(rb.rgb.float(), img_gts)
-            loss.backward()
-        self.reduce_and_update()
-        self.calc_adaptive_rays(rays.origins.shape[0])
+        _range_push("MultiviewTrainer.step")                 # the reference's profiler ranges (multiview_trainer.py:111,169)
+        try:
+            self.pre_step()
+            self._refuse_stale_master_forward()
+            self.total_iterations += 1
+            self._fused_cover = None                         # (a step that raised between run() and optimizer_step leaves none behind)
+            self._last_step_modular = not (self._direct is not None and self.pipeline.nef.training)
+            if not self._last_step_modular:
+                with torch.no_grad():
+                    loss, _ = self._direct.run(rays, img_gts, jitter, prefetch, fused_update=self._fused_update_args())
+            else:
+                self.wait_for_parameters()
+                kw = {} if jitter is None else {"jitter": jitter}
+                with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.enable_amp):
+                    rb = self.pipeline(rays=rays, lod_idx=None, channels=["rgb"], **kw)
+                    loss = self.loss_fn(rb.rgb.float(), img_gts)
+                _range_push("MultiviewTrainer.backward")
+                try:
+                    loss.backward()
+                finally:
+                    _range_pop()
+            self.reduce_and_update()
+            self.calc_adaptive_rays(rays.origins.shape[0])
+        finally:
+            _range_pop()
         return loss.detach(), self.pipeline.tracer.get_prev_num_samples()
 
 
@@ -919,6 +944,7 @@ class MultiviewTrainer(BaseTrainer):
             raise Exception("SampleRays should be used as the transform for the dataset")
         transform.set_num_samples(num_rays)
 
+    @torch.cuda.nvtx.range("MultiviewTrainer.step")         # (multiview_trainer.py:111)
     def step(self, data):
         rays = data['rays'].to(self.device).squeeze(0)
         img_gts = data['rgb'].to(self.device).squeeze(0)
@@ -957,13 +983,14 @@ class MultiviewTrainer(BaseTrainer):
         m.total_loss += loss.item()
         m.rgb_loss += rgb_loss.item()
         m.num_samples += 1
-        if self.cfg.enable_amp:
-            self.scaler.scale(loss).backward()
-            self.scaler.step(self.optimizer)
-            self.scaler.update()
-        else:
-            loss.backward()
-            self.optimizer.step()
+        with torch.cuda.nvtx.range("MultiviewTrainer.backward"):       # (multiview_trainer.py:169-177)
+            if self.cfg.enable_amp:
+                self.scaler.scale(loss).backward()
+                self.scaler.step(self.optimizer)
+                self.scaler.update()
+            else:
+                loss.backward()
+                self.optimizer.step()
         self.calc_adaptive_rays(rays, warmup=False)
         if self.cfg.scheduler:
             self.scheduler.step()

@@ -10,6 +10,11 @@ the HIP-backed classes with load_state_dict.
 Parity: PINNED to the reference's own code executed on the host - embedder / decoder modules, the rgba and prune method bodies, the
 trainer bodies, PackedRFTracer.trace, and end to end: render and three AdamW steps through the reference's OctreeAS -> HashGrid (its
 kernel bodies) -> NeuralRadianceField -> PackedRFTracer (tests/test_reference_modules.py) - over the unpinned Kaolin leaves.
+The fp16-autocast emulation (rgba(autocast_half=True), train_step(scaler=...)) is pinned the same way: the same reference stack
+executed under torch.autocast('cpu', dtype=torch.float16) with HashGridInterpolate's `codebook.half()` branch taken - per-sample
+colours / densities bit for bit, loss, decoder gradients to one fp16 ulp (test_half_rounding_oracle_equals_the_reference_stack_
+under_fp16_autocast_on_the_host).  Deliberately different: the table gradient is accumulated in fp32 (the reference rounds every
+__half2 atomicAdd in arrival order, which nobody can restate).
 """
 import numpy as np
 import torch
