@@ -183,7 +183,40 @@ def last_error():
 
 def _check(rc, what):
     if rc != 0:
+        # a failed call may have stopped between a scatter pass and the pass that restores its scratch to zero: buffers that later
+        # calls rely on being all zero are dropped from their caches (ones baked into a captured graph stay alive, see _Scratch)
+        for cache in _ZEROED_SCRATCH:
+            cache.drop_all()
         raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+class _Scratch:
+    """Per-(device, stream) scratch buffers that only ever grow.  A buffer that was handed out while its stream was being captured
+    into a HIP graph has its address baked into that graph: it is kept alive for the life of the process and is never the one
+    that gets replaced or freed - a later call that needs more gets a NEW buffer for eager use while the captured one stays
+    where the graph expects it (and, for the zero-on-return kind, stays zero because only the graph writes to it)."""
+
+    def __init__(self, zeroed):
+        self.zeroed = zeroed
+        self.live = {}
+        self.captured = []                 # strong references: tensors some captured graph points into
+
+    def get(self, device, need):
+        key = (device.index if device.index is not None else torch.cuda.current_device(), _stream().value)
+        capturing = bool(torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+        buf = self.live.get(key)
+        if buf is None or buf.numel() < need:
+            make = torch.zeros if self.zeroed else torch.empty
+            buf = self.live[key] = make(need + need // 4, dtype=torch.uint8, device=device)
+        if capturing and not any(buf is c for c in self.captured):
+            self.captured.append(buf)
+        return buf
+
+    def drop_all(self):
+        self.live.clear()
+
+
+_ZEROED_SCRATCH = []
 
 
 try:
@@ -658,20 +691,18 @@ def spc_trilinear_forward(coords, pidx, points, trinkets, feats, level, half_rou
     return out
 
 
-_spc_ws = {}
+_spc_ws = _Scratch(zeroed=True)
+_ZEROED_SCRATCH.append(_spc_ws)
 
 
 def _spc_bwd_workspace(device, total_rows, channels, dict_elems=0):
     """Scratch of the order-free trilinear / codebook backward (wisp_spc_bwd_workspace_bytes): zero when handed out for the first
-    time and left zero by every call, so one buffer per (device, stream) serves every grid; it only ever grows."""
+    time and left zero by every call, so one buffer per (device, stream) serves every grid; it only ever grows (_Scratch: a
+    buffer a captured graph points into is never freed or replaced under it; a failed call drops the cache)."""
     need = int(lib.wisp_spc_bwd_workspace_bytes(total_rows, channels, dict_elems))
     if need < 0:
         raise RuntimeError("wisp_spc_bwd_workspace_bytes: bad sizes")
-    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream().value)
-    ws = _spc_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _spc_ws[key] = torch.zeros(need + need // 4, dtype=torch.uint8, device=device)
-    return ws
+    return _spc_ws.get(device, need)
 
 
 def _host_i64(values):
@@ -1097,7 +1128,7 @@ def sdf_trace_step_fused(first, nug_o, nug_d, nug_depth, nug_pidx, dist_max, thr
                                          _p(any_active), _stream()), "sdf_trace_step_fused")
 
 
-_sdf_scratch = {}
+_sdf_scratch = _Scratch(zeroed=False)      # (SDFTrainStep.capture bakes its address into a HIP graph: _Scratch keeps it alive)
 
 
 def sdf_train_step(coords, gts, octree, exsum, points, trinkets, feats, levels, half_round, w1, b1, w2, b2, grad_feats, grad_w1,
@@ -1111,10 +1142,7 @@ def sdf_train_step(coords, gts, octree, exsum, points, trinkets, feats, levels, 
     assert gts.shape[0] == n and all(f.dtype == torch.float32 and f.is_contiguous() and f.shape[1] == C for f in feats)
     assert all(g.dtype == torch.float32 and g.is_contiguous() and g.shape == f.shape for g, f in zip(grad_feats, feats))
     need = int(lib.wisp_sdf_train_scratch_bytes(n, L, C, H))
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream().value)
-    scratch = _sdf_scratch.get(key)
-    if scratch is None or scratch.numel() < need:
-        scratch = _sdf_scratch[key] = torch.empty(need + need // 4, dtype=torch.uint8, device=dev)
+    scratch = _sdf_scratch.get(dev, need)
     rarr, rptr = _host_i64([f.shape[0] for f in feats])
     ws = _spc_bwd_workspace(dev, int(rarr.sum()), C)
     farr, fptr = _ptr_array(feats)

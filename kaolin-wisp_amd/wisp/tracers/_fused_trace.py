@@ -82,6 +82,9 @@ class _FusedTrace(torch.autograd.Function):
 
 def fused_trace(nef, samples, dirs, deltas, depths, offsets, num_rays, bg, lod_idx):
     """-> (rgb [R,3], alpha [R,1], depth [R,1] or None, hit bool [R]) like wisp.ops.render.composite over nef.rgba's outputs."""
+    if samples.requires_grad or dirs.requires_grad:
+        raise NotImplementedError("fused_trace differentiates the table and the decoder only; coordinates / directions that require a "
+                                  "gradient go through the modular path (PackedRFTracer.trace picks it)")
     st = dict(nef=nef, samples=samples.contiguous(), dirs=dirs.contiguous().float(), deltas=deltas, depths=depths, offsets=offsets,
               num_rays=num_rays, bg=bg, lod_idx=lod_idx)
     rgb, alpha, depth, hit = _FusedTrace.apply(st, nef.grid.codebook.feats, *_decoder_tensors(nef))

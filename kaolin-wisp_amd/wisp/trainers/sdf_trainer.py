@@ -57,9 +57,16 @@ class SDFTrainStep:
         biases, one output) over [position, 'sum' OctreeGrid features of 16 channels], fp32 parameters living in the flat
         buffers, loss on the finest LOD only.  WISP_SDF_TRAIN_FUSED=0 keeps the modular launches."""
         import os
+        if getattr(self, "_fused_seen_only_last", None) != self.only_last:        # toggled since the decision was taken
+            self._fused_cache, self._fused_seen_only_last = None, self.only_last
         cached = getattr(self, "_fused_cache", None)
         if cached is not None:
-            return cached or None
+            # the expensive shape checks are cached; what can change under a live trainer is re-checked on every call: the loss
+            # selection, the field's grid / decoder objects, the number of levels, gradients set to None or re-homed
+            if cached and not self._fused_still_valid(cached):
+                cached = self._fused_cache = None                 # re-derive below
+            else:
+                return cached or None
         self._fused_cache = False
         if os.environ.get("WISP_SDF_TRAIN_FUSED", "1") == "0" or not self.only_last:
             return None
@@ -81,8 +88,23 @@ class SDFTrainStep:
         if not all(q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and q.grad is not None and q.grad.is_contiguous()
                    and q.grad.dtype == torch.float32 for q in prm):
             return None
-        self._fused_cache = dict(grid=grid, dec=dec)
+        self._fused_cache = dict(grid=grid, dec=dec, lods=grid.num_lods, prm=prm)
         return self._fused_cache
+
+    def _fused_still_valid(self, c):
+        nef = self.nef
+        grid, dec = c["grid"], c["dec"]
+        if not self.only_last or getattr(nef, "grid", None) is not grid or getattr(nef, "decoder", None) is not dec \
+                or grid.num_lods != c["lods"]:
+            return False
+        now = list(grid.features[:grid.num_lods]) + [dec.layers[0].weight, dec.layers[0].bias, dec.lout.weight, dec.lout.bias]
+        if len(now) != len(c["prm"]):
+            return False
+        for q, was in zip(now, c["prm"]):
+            g = q.grad
+            if q is not was or g is None or g.dtype != torch.float32 or not g.is_contiguous() or not q.is_contiguous():
+                return False
+        return True
 
     def _forward_backward(self, coords, gts):
         fused = self._fused_field() if coords.is_cuda and coords.ndim == 2 and coords.shape[0] > 0 else None
@@ -116,6 +138,7 @@ class SDFTrainStep:
         dev = self.flat.data.device
         if dev.type != 'cuda':
             raise RuntimeError("SDFTrainStep.capture needs the model on the GPU")
+        self._fused_cache = None                               # the graph bakes pointers in: decide afresh what gets captured
         self._g_coords = torch.zeros(batch_size, 3, dtype=torch.float32, device=dev)
         self._g_gts = torch.zeros(batch_size, 1, dtype=torch.float32, device=dev)
         side = torch.cuda.Stream()

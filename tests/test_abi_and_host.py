@@ -5,6 +5,7 @@ import inspect
 import os
 import pickle
 import re
+import types
 
 import numpy as np
 import pytest
@@ -664,3 +665,59 @@ def test_bench_roofline_work_equals_surveys_algorithmic_figures():
     # the headline fraction is on the backward's bytes alone: the folded optimizer's bytes have their own key
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"with_fused_optimizer"' in src and "fused_opt_bytes if name" not in src
+
+
+def test_sdf_fused_field_decision_is_rechecked_when_the_trainer_changes():
+    """SDFTrainStep._fused_field cached its yes/no for good at the first step.  The cheap conditions - only_last, the
+    field's grid / decoder objects, level count, gradients present - are re-validated on every call now."""
+    from wisp.trainers.sdf_trainer import SDFTrainStep
+    t = SDFTrainStep.__new__(SDFTrainStep)
+    t.only_last = True
+    w = [torch.nn.Parameter(torch.zeros(4, 2)) for _ in range(6)]
+    for q in w:
+        q.grad = torch.zeros_like(q)
+    grid = types.SimpleNamespace(features=w[:2], num_lods=2)
+    dec = types.SimpleNamespace(layers=[types.SimpleNamespace(weight=w[2], bias=w[3])], lout=types.SimpleNamespace(weight=w[4], bias=w[5]))
+    t.nef = types.SimpleNamespace(grid=grid, decoder=dec)
+    c = dict(grid=grid, dec=dec, lods=2, prm=list(w))
+    t._fused_cache, t._fused_seen_only_last = c, True
+    assert t._fused_still_valid(c) and t._fused_field() is c
+    w[3].grad = None                                             # zero_grad(set_to_none=True)
+    assert not t._fused_still_valid(c)
+    w[3].grad = torch.zeros_like(w[3])
+    t.nef.grid = types.SimpleNamespace(features=w[:2], num_lods=2)   # another grid object
+    assert not t._fused_still_valid(c)
+    t.nef.grid = grid
+    grid.num_lods = 1
+    assert not t._fused_still_valid(c)
+    grid.num_lods = 2
+    t.only_last = False                                          # the loss now covers every LOD: the fused (finest-LOD) path must step aside
+    assert t._fused_field() is None and t._fused_cache is False
+    t.only_last = True                                           # ... and is reconsidered when it is switched back (no GPU here: not fusable)
+    assert t._fused_cache is False and t._fused_field() is None and t._fused_seen_only_last is True
+
+
+def test_scratch_buffers_handed_to_a_graph_capture_are_never_replaced_under_it(monkeypatch):
+    """per-(device, stream) scratch that was handed out during a capture stays alive and in place; a bigger eager
+    request gets a new buffer; a failed call drops the zero-on-return caches."""
+    import wisp._C as C
+    s = C._Scratch(zeroed=True)
+    monkeypatch.setattr(C, "_stream", lambda: types.SimpleNamespace(value=7))
+    capturing = [True]
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: capturing[0])
+    dev = torch.device("cpu")
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    a = s.get(dev, 100)
+    assert a.numel() == 125 and bool((a == 0).all()) and s.captured == [a]
+    capturing[0] = False
+    assert s.get(dev, 120) is a                                   # fits: same buffer
+    b = s.get(dev, 1000)                                          # grows: a NEW buffer for eager use ...
+    assert b is not a and s.captured == [a] and s.live[(0, 7)] is b          # ... the captured one is still referenced
+    C._ZEROED_SCRATCH.append(s)
+    try:
+        with pytest.raises(RuntimeError):
+            C._check(-1, "some_kernel")
+    finally:
+        C._ZEROED_SCRATCH.remove(s)
+    assert s.live == {} and s.captured == [a]
