@@ -408,6 +408,36 @@ def _sync():
     torch.cuda.synchronize()
 
 
+SENTINEL_ELEMS = 1_000_003            # x (tag + 1) float64 elements: a fill launch no other code of the run issues
+REGIME_TAGS = {"headline": 0, "reference_regime": 1, "dropin_regime": 2}
+
+
+class _regime:
+    """Brackets one timed regime for the profiler: a roctx range (torch.cuda.nvtx is roctx on ROCm; `rocprofv3 --marker-trace`)
+    and - with WISP_BENCH_SENTINELS=1, set by scripts/regime_stats.sh - one float64 fill launch of a size unique to the regime on
+    either side, OUTSIDE the timed window, from which scripts/regime_stats.py cuts a kernel trace of the whole command into one
+    kernel-stats table per regime."""
+
+    def __init__(self, name, dev):
+        self.name, self.dev = name, dev
+        self.on = os.environ.get("WISP_BENCH_SENTINELS", "0") == "1" and dev.type == "cuda"
+
+    def _mark(self):
+        if self.on:
+            torch.empty(SENTINEL_ELEMS * (REGIME_TAGS[self.name] + 1), dtype=torch.float64, device=self.dev).fill_(0.0)
+            torch.cuda.synchronize()
+
+    def __enter__(self):
+        self._mark()
+        torch.cuda.nvtx.range_push("bench:" + self.name)
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.nvtx.range_pop()
+        self._mark()
+        return False
+
+
 def _gather_rows(idx, tensors):
     import wisp._C as C
     return C.gather_rows(idx, tensors)                                   # SampleRays: one launch for the three gathers
@@ -542,7 +572,8 @@ def main(argv=None):
     timing = {}                                           # HIP-event timing of the hot kernels, live, on the launch stream
     if world > 1 or trainer.force_allreduce:
         trainer.comm_timing = []                          # per-step events around the collectives and the optimizer (side stream)
-    elapsed, total_samples, prunes_in = timed_steps(R, args.warmup, args.steps, timing)
+    with _regime("headline", dev):
+        elapsed, total_samples, prunes_in = timed_steps(R, args.warmup, args.steps, timing)
     comm = trainer.comm_summary()
     trainer.comm_timing = None
     # scratch of the binned hash-grid backward in this regime (record slots sized from what earlier launches filled)
@@ -568,7 +599,8 @@ def main(argv=None):
 
     # ---- the reference trainer's own regime: 2^18 samples per step (multiview_trainer.py:58), same model state
     R_ref = size_batch(args.ref_target_samples)
-    ref_elapsed, ref_samples, ref_prunes = timed_steps(R_ref, min(args.warmup, 3), args.steps)
+    with _regime("reference_regime", dev):
+        ref_elapsed, ref_samples, ref_prunes = timed_steps(R_ref, min(args.warmup, 3), args.steps)
     ref_samples_all = all_sum(ref_samples)
     trainer.target_sample_size = args.target_samples
 
@@ -576,7 +608,8 @@ def main(argv=None):
     # BaseTrainer.iterate, base_trainer.py:316-342) over a copy of the same model state: fp16 autocast + GradScaler, autograd over
     # the modular pipeline, torch.optim.AdamW with the reference's parameter groups, SampleRays batches, two .item() per step
     trainer.sync_master()               # (sharded optimizer: the copy below must not start from rows that are stale on this rank)
-    dropin = dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev) if args.dropin_steps > 0 else None
+    with _regime("dropin_regime", dev):
+        dropin = dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev) if args.dropin_steps > 0 else None
 
     # ---- one prune, timed on its own (it falls into the timed steps only every 100th iteration)
     _sync()
