@@ -35,7 +35,7 @@ const char* wisp_last_error(void);
  * passes, raytrace nugget cache, optimizer kinds, per-ray view codes, corner query, decoded codebook rows; 3 = round 3: per-level
  * slot scales of the hash-grid backward; 4 = round 4: workspace + row counts of the order-free trilinear / codebook backward.
  * Entry points that are only ADDED - wisp_spc_query_chain, wisp_composite_loss, wisp_codebook_trilinear_multi_bwd,
- * wisp_sdf_train_step - do not bump it). */
+ * wisp_sdf_train_step, wisp_hashgrid_grad_coords - do not bump it). */
 int wisp_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -62,8 +62,7 @@ int wisp_hashgrid_interpolate_fwd(const float* coords, int64_t n, int coord_dim,
  *  grad_codebook f32 [sum_T, feature_dim]; ACCUMULATED into (caller zeroes it).  Always float32:
  *                the reference adds in the table dtype with __half2 atomics (.cu:138-150); fp32
  *                accumulation is a strict numerical improvement and is cast by the host if needed.
- *  Columns >= zero_from_col receive no gradient.  grad w.r.t. coords is not provided (the reference's
- *  is documented-broken, .cu:165-166,193-194, and no in-scope caller requests it).
+ *  Columns >= zero_from_col receive no gradient.  grad w.r.t. coords: wisp_hashgrid_grad_coords below.
  */
 int wisp_hashgrid_interpolate_bwd(const float* coords, int64_t n, int coord_dim,
                                   const void* grad_feats, int dtype, int feature_dim,
@@ -92,6 +91,17 @@ int wisp_hashgrid_bwd_slot_stats(int64_t n, int coord_dim, int dtype, int featur
                                  int num_lods, int codebook_bitwidth, int zero_from_col, const float* level_cap_scale,
                                  const void* workspace, int64_t workspace_bytes, uint32_t* max_fill, int32_t* cap_host,
                                  int32_t* base_cap_host, wisp_stream_t stream);
+
+/* Gradient w.r.t. the coordinates, as hashgrid_interpolate_backward_cuda(..., require_grad_coords = true) returns it
+ * (hashgrid_interpolate.cpp:69-100; kernel body hashgrid_interpolate_cuda.cu:163-196; requested by wisp/ops/grid.py:109-126 when
+ * `coords` needs a gradient).  grad_coords f32 [n, 3], OVERWRITTEN.  The reference's arithmetic is reproduced term by term,
+ * including what its source marks unfinished: every level reads the FIRST level's upstream gradient columns (.cu:165-166), the
+ * y derivative's last term subtracts corner 6 (.cu:185-186), no res / 2 chain-rule factor, and 2-D coordinates get zeros (the
+ * 2-D kernel ignores the flag).  grad_feats and codebook share `dtype`; all num_lods levels are visited (no zero_from_col: the
+ * reference's backward knows nothing of the 'cat' zeroing, the zero columns' upstream gradient is zero by autograd). */
+int wisp_hashgrid_grad_coords(const float* coords, int64_t n, int coord_dim, const void* grad_feats, const void* codebook,
+                              int dtype, int feature_dim, const int64_t* first_idx, const int32_t* resolutions /* host */,
+                              int num_lods, int codebook_bitwidth, float* grad_coords, wisp_stream_t stream);
 
 /* wisp_hashgrid_interpolate_bwd with the table's AdamW step folded into it: where the reference runs
  * hashgrid_interpolate_backward_cuda (.cu:109-196) and then the optimizer over the whole table (base_trainer.py:205-246,

@@ -1374,6 +1374,85 @@ extern "C" int wisp_hashgrid_interpolate_bwd_adamw(const float* coords, int64_t 
     return WISP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- gradient w.r.t. the coordinates
+// hashgrid_interpolate_backward_cuda(..., require_grad_coords = true) (hashgrid_interpolate.cpp:69-100, kernel body
+// hashgrid_interpolate_cuda.cu:163-196; requested through wisp/ops/grid.py:109-126 when the coordinates need a gradient).
+// What the reference computes is reproduced TERM BY TERM, including what its own comments call unfinished:
+//   * the upstream gradient of EVERY level is read from the first level's columns (grad_output[i * L * F + j], ".cu:165 FIX IN
+//     MASTER lod_idx");
+//   * the last term of the y derivative subtracts corner 6 where the trilinear formula has corner 5 (.cu:185-186);
+//   * the corner differences are not multiplied by d(cell position) / d(coordinate) = res / 2;
+//   * the 2-D kernel accepts the flag and writes nothing: the result stays the zero [n, 3] tensor of the ATen wrapper
+//     (hashgrid_interpolate.cpp:88-90 allocates [n, 3] whatever the coordinate dimension).
+// A drop-in answers what the reference answers; a caller that wants the analytic gradient differentiates the lookup itself.
+// One thread per sample, levels in order, features in order, fp32 - the reference's accumulation order.  Not a hot path.
+template <typename T>
+__global__ void __launch_bounds__(256)
+hashgrid_grad_coords_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ grad_feats,
+                            const T* __restrict__ codebook, const int64_t* __restrict__ first_idx, HashLevels lv, int num_lods,
+                            int F, uint32_t tsize, int pow2, float* __restrict__ grad_coords) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c[3] = {coords[i * 3], coords[i * 3 + 1], coords[i * 3 + 2]};
+    float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+    for (int l = 0; l < num_lods; ++l) {
+        CornerSetup<3> cs;
+        corner_setup<3>(c, lv.res[l], lv.hi[l], lv.hr[l], lv.dense[l] != 0, tsize, pow2 != 0, cs);
+        const int64_t base = first_idx[l];
+        const int64_t rows = first_idx[l + 1] - base;
+        const T* __restrict__ tab = codebook + base * F;
+        int64_t r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { int64_t q = cs.idx[k]; r[k] = (q < rows ? q : rows - 1) * F; }     // (res >= 258: the clamp bound can round up)
+        const float x_ = cs.frac[0], y_ = cs.frac[1], z_ = cs.frac[2];
+        const float _x = 1.0f - x_, _y = 1.0f - y_, _z = 1.0f - z_;
+        for (int j = 0; j < F; ++j) {
+            const float go = (float)grad_feats[i * (int64_t)num_lods * F + j];                    // .cu:165-166: level 0's columns
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (float)tab[r[k] + j];
+            gx += go * ((_y * _z) * (v[4] - v[0]) + (_y * z_) * (v[5] - v[1]) + (y_ * _z) * (v[6] - v[2]) + (y_ * z_) * (v[7] - v[3]));
+            gy += go * ((_x * _z) * (v[2] - v[0]) + (_x * z_) * (v[3] - v[1]) + (x_ * _z) * (v[6] - v[4]) + (x_ * z_) * (v[7] - v[6]));   // .cu:185-186
+            gz += go * ((_x * _y) * (v[1] - v[0]) + (_x * y_) * (v[3] - v[2]) + (x_ * _y) * (v[5] - v[4]) + (x_ * y_) * (v[7] - v[6]));
+        }
+    }
+    grad_coords[i * 3] = gx; grad_coords[i * 3 + 1] = gy; grad_coords[i * 3 + 2] = gz;
+}
+
+extern "C" int wisp_hashgrid_grad_coords(const float* coords, int64_t n, int coord_dim, const void* grad_feats, const void* codebook,
+                                         int dtype, int feature_dim, const int64_t* first_idx, const int32_t* resolutions,
+                                         int num_lods, int codebook_bitwidth, float* grad_coords, wisp_stream_t stream) {
+    WISP_REQUIRE(n >= 0, "negative n");
+    if (n == 0) return WISP_OK;
+    WISP_REQUIRE(coords && grad_feats && codebook && first_idx && resolutions && grad_coords, "null pointer");
+    WISP_REQUIRE(coord_dim == 2 || coord_dim == 3, "coord_dim must be 2 or 3");
+    WISP_REQUIRE(num_lods >= 1 && num_lods <= HG_MAX_LODS, "num_lods out of range");
+    WISP_REQUIRE(feature_dim >= 1, "feature_dim out of range");
+    WISP_REQUIRE(codebook_bitwidth >= 1 && codebook_bitwidth <= 30, "codebook_bitwidth out of range");
+    WISP_REQUIRE(dtype == WISP_F32 || dtype == WISP_F16 || dtype == WISP_BF16, "bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    if (coord_dim == 2) {                                   // the reference's 2-D kernel leaves the zero tensor untouched
+        if (const hipError_t e = hipMemsetAsync(grad_coords, 0, sizeof(float) * 3 * (size_t)n, s)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
+        return WISP_OK;
+    }
+    HashLevels lv;
+    const int64_t tsize = (int64_t)1 << codebook_bitwidth;
+    WISP_REQUIRE(fill_levels(resolutions, num_lods, coord_dim, tsize, lv) == 0, "bad resolution");
+    const dim3 grid((unsigned)ceil_div64(n, 256));
+    const int pow2 = 1;                                      // tsize = 2^bitwidth
+    if (dtype == WISP_F32)
+        hipLaunchKernelGGL(hashgrid_grad_coords_kernel<float>, grid, dim3(256), 0, s, coords, n, (const float*)grad_feats,
+                           (const float*)codebook, first_idx, lv, num_lods, feature_dim, (uint32_t)tsize, pow2, grad_coords);
+    else if (dtype == WISP_F16)
+        hipLaunchKernelGGL(hashgrid_grad_coords_kernel<__half>, grid, dim3(256), 0, s, coords, n, (const __half*)grad_feats,
+                           (const __half*)codebook, first_idx, lv, num_lods, feature_dim, (uint32_t)tsize, pow2, grad_coords);
+    else
+        hipLaunchKernelGGL(hashgrid_grad_coords_kernel<__hip_bfloat16>, grid, dim3(256), 0, s, coords, n, (const __hip_bfloat16*)grad_feats,
+                           (const __hip_bfloat16*)codebook, first_idx, lv, num_lods, feature_dim, (uint32_t)tsize, pow2, grad_coords);
+    WISP_CHECK_LAUNCH();
+    return WISP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- corner query (no blend)
 // wisp._C.ops.hashgrid_query_cuda / hashgrid_query_backward_cuda (wisp/csrc/ops/hashgrid_query_cuda.cu:19-186, bound in
 // bindings.cpp:31-32; Python side wisp/ops/grid.py:169-245).  Peripheral in the reference (nothing in wisp/ calls it), kept so

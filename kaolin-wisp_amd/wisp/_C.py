@@ -35,6 +35,7 @@ SIGNATURES = {
     "wisp_hashgrid_interpolate_bwd": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp],
     "wisp_hashgrid_interpolate_bwd_adamw": [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp,
                                             c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32, c_vp, c_vp],
+    "wisp_hashgrid_grad_coords": [c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp],
     "wisp_hashgrid_bwd_workspace_bytes": [c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp],
     "wisp_hashgrid_bwd_slot_stats": [c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
     "wisp_hashgrid_cells": [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
@@ -346,6 +347,28 @@ def hashgrid_interpolate_backward(coords, grad_feats, codebook_shape, first_idx,
     if fit is not None and ws is not None:
         fit.after_launch(n, res_ptr, scale_arr, scale_ptr, ws, ws_bytes)
     return grad if adamw is None else (grad, covered)
+
+
+def hashgrid_grad_coords(coords, grad_feats, codebook, first_idx, resolutions, codebook_bitwidth):
+    """f32 [n, 3]: what hashgrid_interpolate_backward_cuda(..., require_grad_coords=True) returns as grad_coords
+    (hashgrid_interpolate.cpp:88-90 + hashgrid_interpolate_cuda.cu:163-196, reproduced term by term - see include/wisp_hip.h).
+    grad_feats [n, L*F] and codebook [rows, F] must share a dtype (the reference dispatches on one scalar type, .cu:413)."""
+    coords = _need(coords, torch.float32, "coords")
+    codebook = _need(codebook, None, "codebook")
+    if grad_feats.dtype != codebook.dtype:
+        grad_feats = grad_feats.to(codebook.dtype)
+    grad_feats = _need(grad_feats, None, "grad_feats")
+    first_idx = _need(first_idx, torch.int64, "codebook_first_idx")
+    n, dim = coords.shape
+    L, F = len(resolutions), codebook.shape[1]
+    _check_first_idx(first_idx, L, codebook.shape[0])
+    if grad_feats.shape != (n, L * F):
+        raise ValueError(f"grad_feats must be [{n}, {L * F}], got {tuple(grad_feats.shape)}")
+    res_arr, res_ptr = _host_i32(resolutions)
+    out = torch.empty(n, 3, dtype=torch.float32, device=coords.device)
+    _check(lib.wisp_hashgrid_grad_coords(_p(coords), n, dim, _p(grad_feats), _p(codebook), _DTYPE_CODE[codebook.dtype], F,
+                                         _p(first_idx), res_ptr, L, int(codebook_bitwidth), _p(out), _stream()), "hashgrid_grad_coords")
+    return out
 
 
 HASHGRID_BWD_WORKSPACE_LIMIT = 24 << 30          # bytes; 288 GB of HBM makes a multi-GB scratch a fair trade
@@ -1462,14 +1485,17 @@ def _ref_hashgrid_interpolate_cuda(coords, codebook, codebook_first_idx, resolut
 def _ref_hashgrid_interpolate_backward_cuda(coords, grad_output, codebook, codebook_first_idx, resolution, codebook_bitwidth,
                                             feature_dim, require_grad_coords):
     """hashgrid_interpolate.h:25-33 -> [grad_coords (empty [0] unless requested), grad_codebook in codebook's dtype]."""
-    if require_grad_coords:
-        raise NotImplementedError("grad w.r.t. hash-grid coordinates: the reference's own kernel is known-broken "
-                                  "(hashgrid_interpolate_cuda.cu:165-166,193-194) and no in-scope caller requests it")
     assert int(feature_dim) == codebook.shape[-1]
     coords = coords.reshape(-1, coords.shape[-1])
-    grad = hashgrid_interpolate_backward(coords, grad_output.reshape(coords.shape[0], -1), tuple(codebook.shape),
-                                         codebook_first_idx, _resolution_list(resolution), int(codebook_bitwidth))
-    return [torch.empty(0, dtype=torch.float32, device=coords.device), grad.to(codebook.dtype)]
+    grad_output = grad_output.reshape(coords.shape[0], -1)
+    grad = hashgrid_interpolate_backward(coords, grad_output, tuple(codebook.shape), codebook_first_idx, _resolution_list(resolution),
+                                         int(codebook_bitwidth))
+    if require_grad_coords:                     # the reference's arithmetic, as is (hashgrid_interpolate_cuda.cu:163-196)
+        grad_coords = hashgrid_grad_coords(coords, grad_output, codebook, codebook_first_idx, _resolution_list(resolution),
+                                           int(codebook_bitwidth))
+    else:
+        grad_coords = torch.empty(0, dtype=torch.float32, device=coords.device)
+    return [grad_coords, grad.to(codebook.dtype)]
 
 
 def _ref_uniform_sample_cuda(scale, ridx, depth, insum):

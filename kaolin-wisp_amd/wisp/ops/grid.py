@@ -144,6 +144,7 @@ class HashGridInterpolate(torch.autograd.Function):
         feats = _hip().hashgrid_interpolate(coords.detach(), table.detach(), codebook_first_idx, res, codebook_bitwidth,
                                             zero_from_col)
         ctx.save_for_backward(coords, codebook_first_idx)
+        ctx.table = table.detach() if coords.requires_grad else None     # (grad w.r.t. coords reads the table the forward read)
         ctx.meta = (res, codebook_bitwidth, tuple(codebook.shape), codebook.dtype, zero_from_col)
         # a trainer may pre-allocate the fp32 gradient buffer of the table (flat-parameter layout): scatter into it
         ctx.grad_buffer = current_grad_buffer(codebook)
@@ -153,15 +154,22 @@ class HashGridInterpolate(torch.autograd.Function):
     def backward(ctx, grad_output):
         coords, first_idx = ctx.saved_tensors
         res, bitwidth, shape, dtype, zero_from_col = ctx.meta
+        grad_coords = None
         if ctx.needs_input_grad[0]:
-            raise NotImplementedError("gradients w.r.t. hash-grid coordinates are not provided (the reference's are "
-                                      "known-broken, hashgrid_interpolate_cuda.cu:165-166; no in-scope caller needs them)")
+            # what the reference returns for coords that require a gradient (grid.py:109-126 -> hashgrid_interpolate_cuda.cu:163-196),
+            # its arithmetic as is - see wisp_hashgrid_grad_coords in include/wisp_hip.h for what that arithmetic is and is not
+            if ctx.table is None:
+                raise RuntimeError("HashGridInterpolate: coords did not require a gradient in forward, but one is asked for now")
+            grad_coords = _hip().hashgrid_grad_coords(coords.detach().float(), grad_output.contiguous(), ctx.table, first_idx, res,
+                                                      bitwidth)
+            if coords.shape[-1] != 3:
+                grad_coords = grad_coords[:, :coords.shape[-1]]           # (2-D: the reference's [n, 3] zeros do not fit [n, 2] coords)
         buf = ctx.grad_buffer
         grad = _hip().hashgrid_interpolate_backward(coords.detach().float(), grad_output.contiguous(), shape, first_idx,
                                                     res, bitwidth, zero_from_col, out=buf)
         if buf is not None:
-            return None, None, None, None, None, None, None      # accumulated in place, nothing for autograd to add
-        return None, None, None, None, grad.to(dtype), None, None
+            return grad_coords, None, None, None, None, None, None      # accumulated in place, nothing for autograd to add
+        return grad_coords, None, None, None, grad.to(dtype), None, None
 
 
 def hashgrid(coords, codebook_bitwidth, lod_idx, codebook, zero_from_col=None):

@@ -120,6 +120,44 @@ def hashgrid_backward(coords, grad_out, table_shape, begin_idxes, resolutions, c
     return grad
 
 
+def hashgrid_grad_coords(coords, grad_out, table, begin_idxes, resolutions, codebook_bitwidth):
+    """grad_coords [N, 3] as hashgrid_interpolate_backward_cuda returns it with require_grad_coords (hashgrid_interpolate.cpp:
+    88-100, kernel body hashgrid_interpolate_cuda.cu:163-196), restated as the reference computes it - NOT as calculus would:
+      * every level reads the upstream gradient of the FIRST level's columns: grad_output[i*L*F + j] (.cu:165-166, the
+        source's own "FIX IN MASTER lod_idx");
+      * d/dy's last term is (x_.x * x_.z) * (corner 7 - corner 6); the trilinear formula has corner 5 there (.cu:185-186);
+      * no factor res / 2 for d(cell position) / d(coordinate);
+      * 2-D coordinates: the 2-D kernel takes the flag and writes nothing - zeros [N, 3].
+    float32, levels in order, features in order, the four products of a component summed left to right."""
+    coords = coords.float().reshape(-1, coords.shape[-1])
+    N, dim = coords.shape
+    L, F = len(resolutions), table.shape[1]
+    out = torch.zeros(N, 3, dtype=torch.float32)
+    if dim != 3:
+        return out
+    T = 2 ** codebook_bitwidth
+    tf = table.float()
+    go = grad_out.reshape(N, L * F).float()
+    for l, res in enumerate(resolutions):
+        res = int(res)
+        _, idx = corner_setup(coords, res, T)
+        x = ((coords.double() * 0.5 + 0.5) * float(res)).float()
+        x = torch.clamp(x, min=0.0, max=float(np.float32(res - 1 - 1e-5)))
+        f = x - torch.floor(x)                                     # x_
+        g = 1.0 - f                                                # _x
+        base = int(begin_idxes[l])
+        for j in range(F):
+            v = [tf[base + idx[:, k], j] for k in range(8)]
+            w = go[:, j]                                           # (level 0's columns, whatever l)
+            out[:, 0] += w * ((g[:, 1] * g[:, 2]) * (v[4] - v[0]) + (g[:, 1] * f[:, 2]) * (v[5] - v[1])
+                              + (f[:, 1] * g[:, 2]) * (v[6] - v[2]) + (f[:, 1] * f[:, 2]) * (v[7] - v[3]))
+            out[:, 1] += w * ((g[:, 0] * g[:, 2]) * (v[2] - v[0]) + (g[:, 0] * f[:, 2]) * (v[3] - v[1])
+                              + (f[:, 0] * g[:, 2]) * (v[6] - v[4]) + (f[:, 0] * f[:, 2]) * (v[7] - v[6]))
+            out[:, 2] += w * ((g[:, 0] * g[:, 1]) * (v[1] - v[0]) + (g[:, 0] * f[:, 1]) * (v[3] - v[2])
+                              + (f[:, 0] * g[:, 1]) * (v[5] - v[4]) + (f[:, 0] * f[:, 1]) * (v[7] - v[6]))
+    return out
+
+
 class HashGridInterpolate(torch.autograd.Function):
     """wisp/ops/grid.py:77-126 on the CPU oracle (no autocast branch; table dtype drives the output)."""
 

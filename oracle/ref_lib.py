@@ -96,6 +96,24 @@ def hashgrid_backward(coords, grad_out, table, begin_idxes, resolutions, codeboo
     return grad
 
 
+def hashgrid_grad_coords(coords, grad_out, table, begin_idxes, resolutions, codebook_bitwidth):
+    """grad_coords f32 [N, 3] of hashgrid_interpolate_backward_cuda(..., require_grad_coords=True) (hashgrid_interpolate.cpp:88-100):
+    the reference's backward kernels with the flag set, one launch per level accumulating into the zero [N, 3] tensor."""
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    grad_out = np.ascontiguousarray(grad_out, dtype=np.float32)
+    begin = np.ascontiguousarray(begin_idxes, dtype=np.int64)
+    n, dim = coords.shape
+    L, F = len(resolutions), table.shape[1]
+    grad = np.zeros_like(table)
+    gc = np.zeros((n, 3), dtype=np.float32)
+    for l, r in enumerate(resolutions):
+        lib().ref_hashgrid_bwd_level_coords(ctypes.c_int64(n), ctypes.c_int32(2 ** codebook_bitwidth), ctypes.c_int64(F),
+                                            ctypes.c_int32(int(r)), ctypes.c_int32(l), ctypes.c_int32(L), ctypes.c_int(dim),
+                                            _p(coords), _p(table), _p(begin), _p(grad_out), _p(grad), _p(gc))
+    return gc
+
+
 def hashgrid_query(coords, tables, resolutions, codebook_bitwidth, probe_bitwidth=0):
     """hashgrid_query_cuda (hashgrid_query.cpp:41-67) with the reference kernel, float32 tables (one per level):
     -> [N, 8, L, P, F]."""

@@ -83,6 +83,21 @@ void ref_hashgrid_bwd_level(int64_t n, int32_t codebook_size, int64_t feature_di
                                                                   grad_output, grad_codebook, nullptr);
 }
 
+// the same per-level launch with require_grad_coords = true (hashgrid_interpolate.cpp:88-97): grad_coords [n, 3] is ACCUMULATED
+// into by every level's launch, grad_codebook likewise (the caller zeroes both, like the ATen wrapper's at::zeros)
+void ref_hashgrid_bwd_level_coords(int64_t n, int32_t codebook_size, int64_t feature_dim, int32_t resolution, int32_t lod_idx,
+                                   int32_t num_lods, int coord_dim, const float* coords, const float* codebook,
+                                   const int64_t* first_idx, const float* grad_output, float* grad_codebook, float* grad_coords) {
+    if (coord_dim == 3)
+        wisp::hashgrid_interpolate_3d_backward_cuda_kernel<float>(n, codebook_size, feature_dim, resolution, lod_idx,
+                                                                  num_lods, true, coords, codebook, first_idx,
+                                                                  grad_output, grad_codebook, grad_coords);
+    else
+        wisp::hashgrid_interpolate_2d_backward_cuda_kernel<float>(n, codebook_size, feature_dim, resolution, lod_idx,
+                                                                  num_lods, true, coords, codebook, first_idx,
+                                                                  grad_output, grad_codebook, grad_coords);
+}
+
 // hashgrid_query_cuda_kernel / _backward_ (hashgrid_query_cuda.cu:19-66, :100-171), one level, float tables
 void ref_hashgrid_query_level(int64_t n, int32_t codebook_size, int32_t probe_size, int64_t feature_dim, int32_t resolution,
                               int32_t lod_idx, int32_t num_lods, const float* coords, const float* codebook, float* feats) {

@@ -7,6 +7,7 @@ by oracle/build_ref.sh):
 Outputs (small, committed):
   hashgrid_ref.npz   - inputs + outputs of the reference hashgrid forward/backward kernels (3-D and 2-D, float32),
                        hash-index known answers, the clamp bound probes of SURVEY.md Appendix B
+  hashgrid_gradcoords_ref.npz - grad_coords of the same kernels with require_grad_coords = true, on hashgrid_ref.npz's inputs
   hashgrid_query_ref.npz - inputs + outputs of the reference hashgrid_query forward/backward kernels (probe_bitwidth 0 and 1)
   uniform_ref.npz    - inputs + outputs of the reference uniform_sample kernel
   depth_bound_ref_{a,b}.npz - inputs + outputs of the reference find_depth_bound kernel (SDF tracer)
@@ -65,6 +66,18 @@ def hashgrid_vectors():
     probe = np.array([ref_lib.clamp(1e9, 0, r - 1 - 1e-5) for r in probe_res], dtype=np.float32)
     out.update(kat_in=kat_in, kat_out=kat_out, kat2_in=kat2_in, kat2_out=kat2_out, probe_res=probe_res, probe=probe)
     np.savez_compressed(os.path.join(OUT, "hashgrid_ref.npz"), **out)
+
+
+def gradcoords_vectors():
+    """grad_coords of the reference's backward kernels (require_grad_coords = true) on hashgrid_ref.npz's own inputs."""
+    assert ref_lib.available(), "run oracle/build_ref.sh first"
+    g = np.load(os.path.join(OUT, "hashgrid_ref.npz"))
+    out = {}
+    for s in ("3", "2"):
+        res, bw = [int(r) for r in g["res" + s]], int(g["bw" + s])
+        out["gcoords" + s] = ref_lib.hashgrid_grad_coords(g["coords" + s], g["grad" + s], g["table" + s], g["begin" + s], res, bw)
+    assert float(np.abs(out["gcoords3"]).max()) > 0.1 and not out["gcoords2"].any()
+    np.savez_compressed(os.path.join(OUT, "hashgrid_gradcoords_ref.npz"), **out)
 
 
 def query_vectors():
@@ -265,7 +278,11 @@ def cell_vectors():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gradcoords":          # only the vectors added in round 5 (the others stay byte-identical)
+        gradcoords_vectors()
+        sys.exit(0)
     hashgrid_vectors()
+    gradcoords_vectors()
     cell_vectors()
     query_vectors()
     uniform_vectors()

@@ -379,6 +379,46 @@ def test_hashgrid_dense_level_spill_follows_reference_pointer_arithmetic():
         _C().hashgrid_interpolate(cuda(coords), cuda(table), cuda(begin[:2]), res, bw)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 2e-6), (torch.bfloat16, 2e-6)])
+def test_hashgrid_grad_coords_matches_the_reference_kernel(golden_dir, dtype, tol):
+    """wisp_hashgrid_grad_coords = grad_coords of hashgrid_interpolate_backward_cuda(require_grad_coords=True): against the vectors
+    the reference's own backward kernel body produced (tests/golden/hashgrid_gradcoords_ref.npz; fp32), and against the oracle's
+    restatement - itself bit-identical to that kernel body on the CPU - at the nerf_hash.yaml level layout in every table dtype
+    (the 16-bit paths read 16-bit tables and gradients and compute in fp32, like the reference's static_cast<float>).  Tolerance:
+    fused multiply-adds against the host build's separate roundings, relative to the largest component."""
+    g = np.load(os.path.join(golden_dir, "hashgrid_ref.npz"))
+    gc = np.load(os.path.join(golden_dir, "hashgrid_gradcoords_ref.npz"))
+    if dtype == torch.float32:
+        for s in ("3", "2"):
+            res, bw = [int(r) for r in g["res" + s]], int(g["bw" + s])
+            got = _C().hashgrid_grad_coords(cuda(g["coords" + s]), cuda(g["grad" + s]), cuda(g["table" + s]), cuda(g["begin" + s]), res, bw)
+            assert got.shape == (g["coords" + s].shape[0], 3) and got.dtype == torch.float32
+            np.testing.assert_allclose(got.cpu().numpy(), gc["gcoords" + s], rtol=0, atol=tol * max(1.0, float(np.abs(gc["gcoords" + s]).max())))
+    rng = np.random.default_rng(61)
+    _, begin = ohash.table_layout(NGP_RES, 2 ** 19)
+    table = torch.from_numpy(rng.uniform(-0.1, 0.1, (int(begin[-1]), 2)).astype(np.float32)).to(dtype)
+    coords = rng.uniform(-1, 1, (20000, 3)).astype(np.float32)
+    coords[:4] = [[1, 1, 1], [-1, -1, -1], [0, 0, 0], [1.7, 0, -4]]
+    go = torch.from_numpy(rng.normal(size=(20000, 32)).astype(np.float32)).to(dtype)
+    got = _C().hashgrid_grad_coords(cuda(coords), go.to(DEV), table.to(DEV), cuda(begin), NGP_RES, 19)
+    want = ohash.hashgrid_grad_coords(torch.from_numpy(coords), go.float(), table.float(), begin, NGP_RES, 19)
+    sc = float(want.abs().max())
+    assert sc > 0.1
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=tol * sc)
+    # through the reference-named binding (hashgrid_interpolate.h:25-33) and through autograd (ops/grid.py:109-126)
+    import wisp._C as wisp_C
+    from wisp.ops.grid import HashGridInterpolate
+    resolutions = torch.tensor([[r] for r in NGP_RES], dtype=torch.int64)
+    gco, gtab = wisp_C.ops.hashgrid_interpolate_backward_cuda(cuda(coords), go.to(DEV), table.to(DEV), cuda(begin), resolutions, 19, 2, True)
+    assert torch.equal(gco, got) and gtab.dtype == dtype and tuple(gtab.shape) == tuple(table.shape)
+    if dtype == torch.float32:
+        c = cuda(coords).requires_grad_(True)
+        t = table.to(DEV).requires_grad_(True)
+        feats = HashGridInterpolate.apply(c, NGP_RES, 19, 15, t, cuda(begin))
+        feats.backward(go.to(DEV))
+        assert torch.equal(c.grad, got) and t.grad is not None and float(t.grad.abs().max()) > 0
+
+
 def test_reference_named_ops_follow_the_reference_call_pattern():
     """The calls wisp/ops/grid.py:92-96,117-121 and wisp/accelstructs/octree_as.py:336-353 make into `wisp._C`, made with the
     reference's own argument conventions (HOST int64 [L,1] resolutions, positional order) against this package's module."""

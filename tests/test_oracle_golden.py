@@ -56,6 +56,49 @@ def test_hashgrid_backward_matches_reference_kernels(hg, dim):
     np.testing.assert_allclose(g, hg["gtable" + s], rtol=0, atol=2e-5)   # reference adds sequentially in fp32
 
 
+def test_hashgrid_grad_coords_matches_reference_kernels(hg, golden_dir):
+    """grad_coords of hashgrid_interpolate_backward_cuda(require_grad_coords=True): the oracle restates the reference kernel's
+    arithmetic as it is (hashgrid_interpolate_cuda.cu:163-196) - bit for bit against the kernel body compiled for the host, on the
+    committed vectors and (where oracle/_ref is built) on a fresh case with hashed levels at T = 2^14; and it is NOT the analytic
+    derivative of the lookup (first-level columns for every level, corner 6 for 5, no res / 2), which the test pins as well so that
+    nobody "fixes" one side only."""
+    gc = np.load(os.path.join(golden_dir, "hashgrid_gradcoords_ref.npz"))
+    for s in ("3", "2"):
+        res, bw = [int(r) for r in hg["res" + s]], int(hg["bw" + s])
+        out = hashgrid.hashgrid_grad_coords(torch.from_numpy(hg["coords" + s]), torch.from_numpy(hg["grad" + s]),
+                                            torch.from_numpy(hg["table" + s]), hg["begin" + s], res, bw).numpy()
+        assert out.shape == gc["gcoords" + s].shape == (hg["coords" + s].shape[0], 3)
+        assert np.array_equal(out, gc["gcoords" + s])
+    assert not gc["gcoords2"].any() and float(np.abs(gc["gcoords3"]).max()) > 1.0      # 2-D: the flag is ignored (zeros)
+    # the analytic gradient of the oracle's own forward, by autograd over a torch restatement of the blend: a different function
+    res, bw = [int(r) for r in hg["res3"]], int(hg["bw3"])
+    c = torch.from_numpy(hg["coords3"][6:200]).clone().requires_grad_(True)
+    table, begin = torch.from_numpy(hg["table3"]), hg["begin3"]
+    feats = []
+    for l, r in enumerate(res):
+        x = torch.clamp((c.double() * 0.5 + 0.5) * float(r), 0.0, float(np.float32(r - 1 - 1e-5)))
+        pos = torch.floor(x).detach()
+        f = (x - pos).float()
+        _, idx = hashgrid.corner_setup(c.detach(), r, 2 ** bw)
+        acc = 0
+        for k in range(8):
+            w = (f[:, 0] if k & 4 else 1 - f[:, 0]) * (f[:, 1] if k & 2 else 1 - f[:, 1]) * (f[:, 2] if k & 1 else 1 - f[:, 2])
+            acc = acc + table[int(begin[l]) + idx[:, k]] * w[:, None]
+        feats.append(acc)
+    (torch.cat(feats, 1) * torch.from_numpy(hg["grad3"][6:200])).sum().backward()
+    assert float((c.grad - torch.from_numpy(gc["gcoords3"][6:200])).abs().max()) > 0.5
+    if ref_lib.available():
+        rng = np.random.default_rng(77)
+        res, bw = [8, 20, 33, 64, 100], 14
+        _, begin = hashgrid.table_layout(res, 2 ** bw, 3)
+        table = rng.uniform(-1, 1, (int(begin[-1]), 4)).astype(np.float32)
+        coords = rng.uniform(-1.05, 1.05, (700, 3)).astype(np.float32)
+        go = rng.normal(size=(700, len(res) * 4)).astype(np.float32)
+        want = ref_lib.hashgrid_grad_coords(coords, go, table, begin, res, bw)
+        got = hashgrid.hashgrid_grad_coords(torch.from_numpy(coords), torch.from_numpy(go), torch.from_numpy(table), begin, res, bw).numpy()
+        assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("pb", [0, 1])
 def test_hashgrid_query_matches_reference_kernels(golden_dir, pb):
     """oracle.hashgrid.hashgrid_query / _backward against the reference's own corner-query kernels (hashgrid_query_cuda.cu)."""
