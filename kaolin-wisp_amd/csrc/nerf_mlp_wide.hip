@@ -561,6 +561,325 @@ wide_dw_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------- backward: dW kernel, pipelined
+// Same job, same images, same scratch as wide_dw_kernel above, other division of labour (round 5).  There every round ran
+// [four waves recompute the forward while four wait for their loads] -> 5 x [store images | barrier | all eight waves multiply,
+// each LDS operand read right in front of the MFMA that needs it | barrier]: ~25 K cycles per 128 samples for ~4 K cycles of
+// MFMA.  Here the two halves of that work overlap:
+//   * producer waves 0..3 only recompute activations and store X images.  They run ONE ROUND AHEAD: while the consumers multiply
+//     stage s of round r, a producer computes the next piece of round r + 1's forward pass (layer 1 under stage 5, layers 2 + 3
+//     under stage 4, the two halves of layer 4 under stages 3 and 2; the colour output layer is not needed here and is skipped),
+//     holding both rounds' activations in registers (<= ~160 of them live at once: a stage's activations die with its store);
+//   * consumer waves 4..7 own ALL the dW blocks (wave c: dY blocks 2c, 2c + 1 of the 128-wide stages, X blocks 2c, 2c + 1 of the two
+//     16-wide ones: 30 blocks = 120 VGPRs), fetch the dY operands of "their" tile one stage ahead (global loads issued in front of
+//     a stage's MFMAs, stored to the Y image behind its second barrier) and read all LDS operands of a tile in one batch before
+//     its MFMAs.
+// One producer and one consumer per SIMD: the producer's 32x32x16 chain and the consumer's 16x16x32 products interleave on the
+// matrix pipe.  Barriers per round: the same ten (images are single-buffered: 65 KB of weights + 80 KB of images).
+// Numerics: identical products and identical per-block sums; a block's four tiles are added in the same order.
+template <int HH> struct GradW2 {
+    static constexpr int NK = Wide<HH>::NK;
+    static_assert(NK == 8, "block ownership below is written for hidden = 128: two dY blocks per consumer wave");
+    floatx4 dW5[2], dW4[2][NK], dW3[2][3], dW2[2], dW1[2][2];
+    floatx4 db;      // rows: 0,1 layer-4 blocks 2c, 2c+1; 2,3 layer-1 blocks 2c, 2c+1; 4 layer 2 (c == 0); 5 layer 5 (c == 0)
+};
+
+// pieces of forward_tile_wide (same instructions, same order inside a layer)
+template <int HH> DEV void fwd_l1(const LaneW<HH>& L, ActsW<HH>& A) {
+    typedef Wide<HH> W;
+    keep_lds_reads_here();
+#pragma unroll
+    for (int t = 0; t < W::NB; ++t) {
+        floatx16 acc = *reinterpret_cast<const floatx16*>(L.bias_lds + t * 32);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) acc = mma32(lds_a(L.w1, t * 32 * W::LD1 + 16 * kb), A.x0[kb], acc);
+        A.h1[2 * t] = pack8<0, true>(acc);
+        A.h1[2 * t + 1] = pack8<8, true>(acc);
+    }
+}
+template <int HH> DEV void fwd_l2_l3(const LaneW<HH>& L, const float d[3], ActsW<HH>& A) {
+    typedef Wide<HH> W;
+    keep_lds_reads_here();
+    {
+        floatx16 acc = zero16();
+#pragma unroll
+        for (int kb = 0; kb < W::NK; ++kb) acc = mma32(lds_a(L.w2, 16 * kb), A.h1[kb], acc);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] += L.b2[r];
+        A.y0 = acc[0];
+        if (L.g == 0) acc[0] = 0.0f;
+        A.x2[0] = pack8<0, false>(acc);
+    }
+    encode_dir(d, L.g, A.x2[1], A.x2[2]);
+    keep_lds_reads_here();
+#pragma unroll
+    for (int t = 0; t < W::NB; ++t) {
+        floatx16 acc = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) acc = mma32(lds_a(L.w3, t * 32 * W::LD3 + 16 * kb), A.x2[kb], acc);
+        A.h2[2 * t] = pack8<0, true>(acc);
+        A.h2[2 * t + 1] = pack8<8, true>(acc);
+    }
+}
+template <int HH, int T0, int T1> DEV void fwd_l4(const LaneW<HH>& L, ActsW<HH>& A) {
+    typedef Wide<HH> W;
+#pragma unroll
+    for (int t = T0; t < T1; ++t) {
+        keep_lds_reads_here();
+        floatx16 acc = *reinterpret_cast<const floatx16*>(L.bias_lds + 32 * W::NB + t * 32);
+#pragma unroll
+        for (int kb = 0; kb < W::NK; ++kb) acc = mma32(lds_a(L.w4, t * 32 * W::LD4 + 16 * kb), A.h2[kb], acc);
+        A.h3[2 * t] = pack8<0, true>(acc);
+        A.h3[2 * t + 1] = pack8<8, true>(acc);
+    }
+}
+
+// The two roles are two separate loops (each with the same ten barriers per round) so that a wave's registers hold only its own
+// role's state - one loop with role branches made the allocator keep both roles' state live (1 KB of spills per lane).
+template <int HH, typename TIO>
+DEV void dw2_producer(const LaneW<HH>& L, const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples,
+                      int in_dim, int64_t rounds, unsigned char* imgX, int my_tile, int lane) {
+    typedef Wide<HH> W;
+    constexpr int NK = W::NK;
+    const int n = lane & 31, g = lane >> 5;
+    const int wc_off = (2 * n + g) * 8, wn_off = g * TILE_REGION + n * 16;
+    // A = this round's activations (complete), N = the next round's (computed piece by piece under the consumers' stages),
+    // N.x0 / nd = the next round's inputs, fetched a round early
+    ActsW<HH> A, N;
+    float nd[3];
+    const int64_t rd0 = blockIdx.x, step = gridDim.x;
+    {
+        float d[3];
+        const int64_t s0 = (rd0 * WD_TILES + my_tile) * TS + n;
+        fetch_inputs_wide<TIO>(feats, dirs, s0, rd0 < rounds && s0 < num_samples, g, in_dim, A.x0, d);
+        fwd_l1<HH>(L, A);
+        fwd_l2_l3<HH>(L, d, A);
+        fwd_l4<HH, 0, W::NB>(L, A);
+        const int64_t s1 = ((rd0 + step) * WD_TILES + my_tile) * TS + n;
+        fetch_inputs_wide<TIO>(feats, dirs, s1, rd0 + step < rounds && s1 < num_samples, g, in_dim, N.x0, nd);
+    }
+    for (int64_t rd = rd0; rd < rounds; rd += step) {
+        // stage 5: X = h3 (chained); meanwhile layer 1 of the next round
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) store_chained(imgX + wc_off, kb, A.h3[kb]);
+        __syncthreads();
+        fwd_l1<HH>(L, N);
+        __syncthreads();
+        // stage 4: X = h2; meanwhile layers 2 + 3
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) store_chained(imgX + wc_off, kb, A.h2[kb]);
+        __syncthreads();
+        fwd_l2_l3<HH>(L, nd, N);
+        __syncthreads();
+        // stage 3: X = x2 (chained block 0, natural blocks 1, 2); meanwhile the first half of layer 4
+        store_chained(imgX + wc_off, 0, A.x2[0]);
+        store_natural(imgX + wn_off, 1, A.x2[1]);
+        store_natural(imgX + wn_off, 2, A.x2[2]);
+        __syncthreads();
+        fwd_l4<HH, 0, W::NB / 2>(L, N);
+        __syncthreads();
+        // stage 2: X = h1; meanwhile the second half of layer 4
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) store_chained(imgX + wc_off, kb, A.h1[kb]);
+        __syncthreads();
+        fwd_l4<HH, W::NB / 2, W::NB>(L, N);
+        __syncthreads();
+        // stage 1: X = x0 (natural, 2 blocks); meanwhile: hand over, fetch the inputs of the round after next
+        store_natural(imgX + wn_off, 0, A.x0[0]);
+        store_natural(imgX + wn_off, 1, A.x0[1]);
+        __syncthreads();
+        A = N;
+        const int64_t r2 = rd + 2 * step;
+        const int64_t s2 = (r2 * WD_TILES + my_tile) * TS + n;
+        fetch_inputs_wide<TIO>(feats, dirs, s2, r2 < rounds && s2 < num_samples, g, in_dim, N.x0, nd);
+        __syncthreads();
+    }
+}
+
+template <int HH>
+DEV void dw2_consumer(const bf16x8* __restrict__ scratch, int64_t num_tiles, int64_t rounds, unsigned char* smem, int c, int lane,
+                      int accumulate, float* __restrict__ partials) {
+    typedef Wide<HH> W;
+    constexpr int NK = W::NK;
+    const int n = lane & 31, g = lane >> 5;
+    const int wc_off = (2 * n + g) * 8, wn_off = g * TILE_REGION + n * 16;
+    const int tr_off = ((lane >> 1) & 1) * TILE_REGION + (8 * (lane >> 4) + 2 * ((lane >> 2) & 3) + (lane & 1)) * 8;
+    unsigned char* imgY = smem + (size_t)c * 2 * W::IMG_BYTES;
+    const bf16x8 zero8 = __builtin_bit_cast(bf16x8, (u32x4)(0u));
+    GradW2<HH> G;
+    G.dW5[0] = G.dW5[1] = G.dW2[0] = G.dW2[1] = zero4(); G.db = zero4();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) G.dW4[i][k] = zero4();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) G.dW3[i][k] = zero4();
+        G.dW1[i][0] = zero4(); G.dW1[i][1] = zero4();
+    }
+    bf16x8 yb[NK];                                              // the dY blocks of the NEXT stage of this wave's tile
+#define DY_PTR(rd_) (scratch + ((rd_) * WD_TILES + c) * (int64_t)(W::NSLOT * 64) + lane)
+#define DY_HAVE(rd_) ((rd_) < rounds && (rd_) * WD_TILES + c < num_tiles)
+#define BIAS_ROW(a, row) { const unsigned one2 = (lane & 15) == (row) ? 0x3f803f80u : 0u; const u32x4 ones = {one2, one2, one2, one2}; \
+                           G.db = mma16(__builtin_bit_cast(bf16x8, ones), (a), G.db); }
+    const int64_t rd0 = blockIdx.x, step = gridDim.x;
+    yb[0] = DY_HAVE(rd0) ? DY_PTR(rd0)[W::S5Y * 64] : zero8;
+    for (int64_t rd = rd0; rd < rounds; rd += step) {
+        const bool have = DY_HAVE(rd);
+        const bf16x8* in = DY_PTR(rd);
+        // ================= stage 5: dY5 (natural, 1 block) x h3 -> dW5, b5
+        store_natural(imgY + wn_off, 0, yb[0]);
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) yb[kb] = have ? in[(W::S4Y + kb) * 64] : zero8;
+#pragma unroll
+        for (int tl = 0; tl < WD_TILES; ++tl) {
+            const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
+            const bf16x8 a = load_transposed(img, 0);
+            const bf16x8 b0 = load_transposed(img + W::IMG_BYTES, 2 * c), b1 = load_transposed(img + W::IMG_BYTES, 2 * c + 1);
+            if (c == 0) BIAS_ROW(a, 5)
+            G.dW5[0] = mma16(a, b0, G.dW5[0]);
+            G.dW5[1] = mma16(a, b1, G.dW5[1]);
+        }
+        __syncthreads();
+        // ================= stage 4: dH3 x h2 -> dW4, b4
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) store_chained(imgY + wc_off, kb, yb[kb]);
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) yb[kb] = have ? in[(W::S3Y + kb) * 64] : zero8;
+#pragma unroll
+        for (int tl = 0; tl < WD_TILES; ++tl) {
+            const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
+            const bf16x8 a0 = load_transposed(img, 2 * c), a1 = load_transposed(img, 2 * c + 1);
+            bf16x8 b[NK];
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) b[kt] = load_transposed(img + W::IMG_BYTES, kt);
+            BIAS_ROW(a0, 0)
+            BIAS_ROW(a1, 1)
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) {
+                G.dW4[0][kt] = mma16(a0, b[kt], G.dW4[0][kt]);
+                G.dW4[1][kt] = mma16(a1, b[kt], G.dW4[1][kt]);
+            }
+        }
+        __syncthreads();
+        // ================= stage 3: dH2 x x2 -> dW3 (+ b3 on the ones slot)
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) store_chained(imgY + wc_off, kb, yb[kb]);
+        __syncthreads();
+        yb[0] = have ? in[W::S2Y * 64] : zero8;
+#pragma unroll
+        for (int tl = 0; tl < WD_TILES; ++tl) {
+            const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
+            const bf16x8 a0 = load_transposed(img, 2 * c), a1 = load_transposed(img, 2 * c + 1);
+            bf16x8 b[3];
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) b[kt] = load_transposed(img + W::IMG_BYTES, kt);
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                G.dW3[0][kt] = mma16(a0, b[kt], G.dW3[0][kt]);
+                G.dW3[1][kt] = mma16(a1, b[kt], G.dW3[1][kt]);
+            }
+        }
+        __syncthreads();
+        // ================= stage 2: dY2 (chained, 1 block) x h1 -> dW2, b2
+        store_chained(imgY + wc_off, 0, yb[0]);
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) yb[kb] = have ? in[(W::S1Y + kb) * 64] : zero8;
+#pragma unroll
+        for (int tl = 0; tl < WD_TILES; ++tl) {
+            const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
+            const bf16x8 a = load_transposed(img, 0);
+            const bf16x8 b0 = load_transposed(img + W::IMG_BYTES, 2 * c), b1 = load_transposed(img + W::IMG_BYTES, 2 * c + 1);
+            if (c == 0) BIAS_ROW(a, 4)
+            G.dW2[0] = mma16(a, b0, G.dW2[0]);
+            G.dW2[1] = mma16(a, b1, G.dW2[1]);
+        }
+        __syncthreads();
+        // ================= stage 1: dH1 x x0 (natural, 2 blocks) -> dW1, b1
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) store_chained(imgY + wc_off, kb, yb[kb]);
+        __syncthreads();
+        yb[0] = DY_HAVE(rd + step) ? DY_PTR(rd + step)[W::S5Y * 64] : zero8;
+#pragma unroll
+        for (int tl = 0; tl < WD_TILES; ++tl) {
+            const unsigned char* img = smem + (size_t)tl * 2 * W::IMG_BYTES + tr_off;
+            const bf16x8 a0 = load_transposed(img, 2 * c), a1 = load_transposed(img, 2 * c + 1);
+            const bf16x8 b0 = load_transposed(img + W::IMG_BYTES, 0), b1 = load_transposed(img + W::IMG_BYTES, 1);
+            BIAS_ROW(a0, 2)
+            BIAS_ROW(a1, 3)
+            G.dW1[0][0] = mma16(a0, b0, G.dW1[0][0]);
+            G.dW1[0][1] = mma16(a0, b1, G.dW1[0][1]);
+            G.dW1[1][0] = mma16(a1, b0, G.dW1[1][0]);
+            G.dW1[1][1] = mma16(a1, b1, G.dW1[1][1]);
+        }
+        __syncthreads();
+    }
+#undef DY_PTR
+#undef DY_HAVE
+#undef BIAS_ROW
+    // ---- the workgroup's partial row (canonical parameter order): every element has exactly one owner among the consumers
+    float* out = partials + (int64_t)blockIdx.x * W::NPARAM_PAD;
+    const int col = lane & 15, rg = lane >> 4;
+    auto put = [&](int idx, float v) { if (accumulate) out[idx] += v; else out[idx] = v; };
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = 4 * rg + rr;                                     // row inside a 16-row block
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int blk = 2 * c + i;
+            if (row < 3) put(W::OW5 + row * HH + 16 * blk + col, G.dW5[i][rr]);       // stages 5 / 2: owned X blocks
+            put(W::OW2 + row * HH + 16 * blk + col, G.dW2[i][rr]);
+            const int R = 16 * blk + row;                                // stages 4 / 3 / 1: owned dY blocks -> output neuron R
+#pragma unroll
+            for (int k2 = 0; k2 < NK; ++k2) put(W::OW4 + R * HH + 16 * k2 + col, G.dW4[i][k2][rr]);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) put(W::OW1 + R * IN + 16 * k2 + col, G.dW1[i][k2][rr]);
+#pragma unroll
+            for (int k2 = 0; k2 < 3; ++k2) {
+                const int u = 16 * k2 + col;                             // feature inside the 48-wide colour input
+                if (k2 == 0) { if (u >= 1) put(W::OW3 + R * X2 + u - 1, G.dW3[i][k2][rr]); }
+                else if (u < ONES_SLOT) put(W::OW3 + R * X2 + u - 1, G.dW3[i][k2][rr]);
+                else if (u == ONES_SLOT) put(W::OB3 + R, G.dW3[i][k2][rr]);
+            }
+        }
+        // shared bias block: row = combo, column = neuron inside its 16-block
+        if (row == 0) put(W::OB4 + 16 * (2 * c) + col, G.db[rr]);
+        else if (row == 1) put(W::OB4 + 16 * (2 * c + 1) + col, G.db[rr]);
+        else if (row == 2) put(W::OB1 + 16 * (2 * c) + col, G.db[rr]);
+        else if (row == 3) put(W::OB1 + 16 * (2 * c + 1) + col, G.db[rr]);
+        else if (c == 0 && row == 4) put(W::OB2 + col, G.db[rr]);
+        else if (c == 0 && row == 5 && col < 3) put(W::OB5 + col, G.db[rr]);
+    }
+}
+
+template <int HH, typename TIO>
+__global__ void __launch_bounds__(WD_WAVES * 64)
+wide_dw2_kernel(const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples, int in_dim,
+                const float* __restrict__ params, const bf16x8* __restrict__ scratch, int accumulate, float* __restrict__ partials) {
+    typedef Wide<HH> W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    __bf16* sw = reinterpret_cast<__bf16*>(smem_all);
+    float* biasv = reinterpret_cast<float*>(smem_all + (size_t)W::L_FWD_END * 2);
+    unsigned char* smem = smem_all + (size_t)W::L_FWD_END * 2 + (size_t)W::BIASV_FLOATS * 4;      // [4 tiles][Y image | X image]
+    stage_weights_wide<HH, false>(sw, biasv, params, in_dim, threadIdx.x, WD_WAVES * 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t num_tiles = (num_samples + TS - 1) / TS;
+    const int64_t rounds = (num_tiles + WD_TILES - 1) / WD_TILES;
+    const int my_tile = wave & (WD_TILES - 1);
+    if (wave < WD_TILES) {                                     // wave-uniform: whole waves take one side
+        LaneW<HH> L;
+        lane_const_wide<HH>(L, sw, biasv, params, in_dim, lane);
+        __syncthreads();
+        dw2_producer<HH, TIO>(L, feats, dirs, num_samples, in_dim, rounds, smem + (size_t)my_tile * 2 * W::IMG_BYTES + W::IMG_BYTES,
+                              my_tile, lane);
+    } else {
+        __syncthreads();
+        dw2_consumer<HH>(scratch, num_tiles, rounds, smem, my_tile, lane, accumulate, partials);
+    }
+}
+
 // grad_params[packed(j)] += sum over the workgroups' partial rows
 template <int HH>
 __global__ void __launch_bounds__(1024)
@@ -612,7 +931,9 @@ int wide_backward(const void* feats, const float* dirs, int64_t S, int in_dim, c
     const size_t lds_c = (size_t)W::L_BWD_END * 2 + (size_t)W::BIASV_FLOATS * 4;
     const size_t lds_d = (size_t)W::L_FWD_END * 2 + (size_t)W::BIASV_FLOATS * 4 + (size_t)WD_TILES * 2 * W::IMG_BYTES;
     auto kc = wide_chain_kernel<HH, TIO>;
-    auto kd = wide_dw_kernel<HH, TIO>;
+    // WISP_WIDE_DW=1: the barrier-per-stage kernel of rounds 2-4; default: the producer / consumer pipeline
+    static const bool old_dw = [] { const char* e = getenv("WISP_WIDE_DW"); return e && atoi(e) == 1; }();
+    auto kd = old_dw ? wide_dw_kernel<HH, TIO> : wide_dw2_kernel<HH, TIO>;
     const hipError_t e1 = WISP_ALLOW_LDS(kc, lds_c);
     const hipError_t e2 = WISP_ALLOW_LDS(kd, lds_d);
     if (e1 != hipSuccess || e2 != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, "nerf_mlp_wide", "hipFuncSetAttribute");

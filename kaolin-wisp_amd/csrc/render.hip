@@ -538,15 +538,22 @@ extern "C" int wisp_rgb_loss(const float* rgb, const float* gt, int64_t num_elem
 // the weights, rgb / alpha / hit and the colour gradient per ray.  Same arithmetic, same order, per ray; the loss is the sum of
 // per-workgroup partials added in index order by a one-wave second launch (reproducible), its terms are grouped per ray
 // instead of per thread-strided element, so its value agrees with wisp_rgb_loss to rounding, not bit for bit.
-__global__ void __launch_bounds__(64)
+// W waves per workgroup, each wave a "group" of its own (group v walks rays v, v + groups, ...: which rays a partial sum covers,
+// and hence the loss bits, do not depend on W).  W = 4: a quarter of the workgroups to dispatch for the same waves.
+template <int W>
+__global__ void __launch_bounds__(64 * W)
 composite_loss_kernel(const float* __restrict__ color, const float* __restrict__ density, const float* __restrict__ deltas,
-                      const int64_t* __restrict__ offsets, int64_t num_rays, Bg bg, const float* __restrict__ gt, int kind,
+                      const int64_t* __restrict__ offsets, int64_t num_rays, int groups, Bg bg, const float* __restrict__ gt, int kind,
                       float inv_n, float* __restrict__ grad_color, float* __restrict__ grad_density, float* __restrict__ out_rgb,
                       float* __restrict__ partial) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * W + (threadIdx.x >> 6);
+    if (v >= groups) return;
     float lacc = 0.0f;
-    for (int64_t r = blockIdx.x; r < num_rays; r += gridDim.x) {
+    for (int64_t r = v; r < num_rays; r += groups) {
         const int64_t b = offsets[r], e = offsets[r + 1];
+        // the ray's ground truth does not depend on anything computed below: ask for it now, not after the reductions
+        const float gt0 = gt[r * 3], gt1 = gt[r * 3 + 1], gt2 = gt[r * 3 + 2];
         const bool single = e - b <= 64;
         float carry = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f, sa = 0.0f;
         float dl = 0.0f, T = 0.0f, et = 0.0f, w = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;     // the single chunk's values
@@ -570,10 +577,11 @@ composite_loss_kernel(const float* __restrict__ color, const float* __restrict__
         if (b < e) { sr = wave_sum_f(sr); sg = wave_sum_f(sg); sb = wave_sum_f(sb); sa = wave_sum_f(sa); }
         const float om = 1.0f - sa;
         const float rgb[3] = {bg.r * om + sr, bg.g * om + sg, bg.b * om + sb};
+        const float gtc[3] = {gt0, gt1, gt2};
         float g[3], lsum[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float x = rgb[c] - gt[r * 3 + c];
+            const float x = rgb[c] - gtc[c];
             float l, d;
             if (kind == 0) { const float a = fabsf(x); l = a < 1.0f ? 0.5f * x * x : a - 0.5f; d = fminf(fmaxf(x, -1.0f), 1.0f); }
             else if (kind == 1) { l = x * x; d = 2.0f * x; }
@@ -644,7 +652,7 @@ composite_loss_kernel(const float* __restrict__ color, const float* __restrict__
     // loss: one partial per workgroup (every lane holds the same sum); loss_sum_kernel adds them in index order.  (A last-
     // workgroup-finishes reduction inside this kernel - device-scope fence + ticket per workgroup - took the launch from 36 to
     // 238 us at 38 K rays: on this part a device-scope release / acquire writes back and invalidates the XCD's L2, 8192 times.)
-    if (lane == 0) partial[blockIdx.x] = lacc;
+    if (lane == 0) partial[v] = lacc;
 }
 
 extern "C" int wisp_composite_loss(const float* color, const float* density, const float* deltas, const int64_t* ray_offsets,
@@ -659,8 +667,16 @@ extern "C" int wisp_composite_loss(const float* color, const float* density, con
     // several of them in a fixed order leaves the launch waiting for the unluckiest wave), else a grid-stride walk
     const int groups = (int)min64(num_rays, min64(workspace_floats, (int64_t)1 << 22));
     const float inv_n = 1.0f / (float)(num_rays * 3);
-    hipLaunchKernelGGL(composite_loss_kernel, dim3(groups), dim3(64), 0, (hipStream_t)stream, color, density, deltas, ray_offsets,
-                       num_rays, b, gt, kind, inv_n, grad_color, grad_density, out_rgb, workspace);
+    static const int waves = [] { const char* e = getenv("WISP_COMPOSITE_WAVES"); const int w = e ? atoi(e) : 4; return (w == 1 || w == 2) ? w : 4; }();
+    if (waves == 1)
+        hipLaunchKernelGGL(composite_loss_kernel<1>, dim3(groups), dim3(64), 0, (hipStream_t)stream, color, density, deltas, ray_offsets,
+                           num_rays, groups, b, gt, kind, inv_n, grad_color, grad_density, out_rgb, workspace);
+    else if (waves == 2)
+        hipLaunchKernelGGL(composite_loss_kernel<2>, dim3((groups + 1) / 2), dim3(128), 0, (hipStream_t)stream, color, density, deltas, ray_offsets,
+                           num_rays, groups, b, gt, kind, inv_n, grad_color, grad_density, out_rgb, workspace);
+    else
+        hipLaunchKernelGGL(composite_loss_kernel<4>, dim3((groups + 3) / 4), dim3(256), 0, (hipStream_t)stream, color, density, deltas, ray_offsets,
+                           num_rays, groups, b, gt, kind, inv_n, grad_color, grad_density, out_rgb, workspace);
     hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, workspace, groups, inv_n, loss);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
