@@ -581,8 +581,13 @@ def main(argv=None):
     scratch = None
     if fits:
         last = max(fits, key=lambda f: f["workspace_bytes"])
+        # per level: records written, slots (buckets x emitting workgroups), their capacity, the fullest slot.  A slot's fill is
+        # lumpy (a ray's records of one level go to few buckets: consecutive cells along x are consecutive table entries, hashed
+        # levels included - the hash's x prime is 1), so the fullest slot is ~3x the mean and the scratch ~4.5x the records.
         scratch = {"workspace_bytes": last["workspace_bytes"], "record_bytes_written": 8 * sum(last["records"]),
-                   "per_level_scale": [round(x, 3) for x in last["scale"]]}
+                   "per_level_scale": [round(x, 3) for x in last["scale"]],
+                   "per_level_records": list(last["records"]), "per_level_slot_capacity": list(last["cap"]),
+                   "per_level_fullest_slot": list(last["fill"])}
     if comm is None and selftest is not None:
         comm = {"note": "no per-phase events were recorded for the collectives in this run"}
     if comm is not None:

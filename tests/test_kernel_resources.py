@@ -72,7 +72,8 @@ def test_hot_kernels_use_the_cdna4_instructions_the_design_names():
     forward blends with packed FMAs; the 16-bit corner-query backward uses packed atomics.  Presence and order of magnitude only."""
     isa = kernel_meta.instruction_counts(LIB, ("mlp_fwd_kernelI14__hip_bfloat16Lb0ELb1E", "mlp_bwd_kernelI14__hip_bfloat16Lb0E",
                                                "wide_fwd_kernelILi128E14__hip_bfloat16", "wide_chain_kernelILi128E14__hip_bfloat16",
-                                               "wide_dw_kernelILi128E14__hip_bfloat16", "hashgrid_bwd_emit_q_kernelI14__hip_bfloat16Li3E",
+                                               "wide_dw_kernelILi128E14__hip_bfloat16", "wide_dw2_kernelILi128E14__hip_bfloat16",
+                                               "hashgrid_bwd_emit_q_kernelI14__hip_bfloat16Li3E",
                                                "hashgrid_fwd_kernelI14__hip_bfloat16Li16ELi3E", "hashgrid_query_kernelI14__hip_bfloat16Lb1E",
                                                "hashgrid_query_kernelI6__halfLb1E"))
 
@@ -88,9 +89,14 @@ def test_hot_kernels_use_the_cdna4_instructions_the_design_names():
         assert c["v_mfma_f32_32x32x16_bf16"] >= 20 and c["ds_read_b128"] >= 16 and not any(k.startswith("scratch_") for k in c)
     for c in of("mlp_bwd_kernel"):
         assert mfma(c) >= 60 and c["v_mfma_f32_16x16x32_bf16"] >= 20 and c["ds_read_b128"] >= 32
-    for part, least in (("wide_fwd_kernel", 48), ("wide_chain_kernel", 96), ("wide_dw_kernel", 96)):
+    for part, least in (("wide_fwd_kernel", 48), ("wide_chain_kernel", 96), ("wide_dw_kernel", 96), ("wide_dw2_kernel", 150)):
         for c in of(part):
             assert mfma(c) >= least, (part, mfma(c))
+    for c in of("wide_dw2_kernel"):
+        # the pipelined dW kernel (round 5): the producers' 32x32x16 chain (prologue + the pieces under the five stages) and the
+        # consumers' 120 16x16x32 products of a round, fed by transposing LDS reads; ten barriers per round + the prologue's
+        assert c["v_mfma_f32_16x16x32_bf16"] >= 120 and c["v_mfma_f32_32x32x16_bf16"] >= 100 and c["ds_read_b64_tr_b16"] >= 200
+        assert 20 <= c["s_barrier"] <= 26 and not any(k.startswith("scratch_") for k in c)
     for c in of("hashgrid_bwd_emit_q_kernel"):
         dpp = sum(v for k, v in c.items() if k.endswith("_dpp"))
         assert dpp >= 100 and c["v_pk_mul_f32"] >= 8 and not any(k.startswith("scratch_") for k in c)
