@@ -27,26 +27,34 @@ if len(pairs) < 6:
 steps = pairs[-6:-1]
 busy = idle = 0
 gap_by = collections.Counter(); time_by = collections.Counter(); n_by = collections.Counter()
+# (kernels of two streams overlap - the count read-back's copy runs beside the hash-grid forward: busy = the UNION of the kernel
+#  intervals, a gap = time in which NO kernel runs, charged to the kernel that ends it.  Until round 5 a gap was measured against the
+#  previous row's end, which counted the whole forward as "idle" behind the short copy: 108 of the 167 us reported then.)
 for a, b in steps:
+    horizon = rows[a][0]
     for i in range(a, b):
         s, e, name = rows[i]
         short = name.split("(")[0].split("<")[0].replace("void ", "").replace("(anonymous namespace)::", "")[-60:]
-        busy += e - s; time_by[short] += e - s; n_by[short] += 1
-        nxt = rows[i + 1]
-        g = max(0, nxt[0] - e)
-        idle += g
-        nshort = nxt[2].split("(")[0].split("<")[0].replace("void ", "").replace("(anonymous namespace)::", "")[-60:]
-        gap_by[nshort] += g
+        time_by[short] += e - s; n_by[short] += 1
+        if s > horizon:
+            idle += s - horizon; gap_by[short] += s - horizon
+        busy += max(0, e - max(s, horizon))
+        horizon = max(horizon, e)
+    if rows[b][0] > horizon:
+        nshort = rows[b][2].split("(")[0].split("<")[0].replace("void ", "").replace("(anonymous namespace)::", "")[-60:]
+        idle += rows[b][0] - horizon; gap_by[nshort] += rows[b][0] - horizon
 n = len(steps)
 print(f"steps {n}: wall {(busy + idle) / n / 1e3:.1f} us  busy {busy / n / 1e3:.1f} us  idle {idle / n / 1e3:.1f} us  launches/step {sum(n_by.values()) / n:.1f}")
-print("kernel".ljust(62), "calls/step   us/step   idle-before us/step")
+print("kernel".ljust(62), "calls/step   us/step   idle-before us/step   (busy = union of kernel intervals)")
 for k, t in time_by.most_common():
     print(k.ljust(62), f"{n_by[k] / n:9.1f} {t / n / 1e3:9.1f} {gap_by[k] / n / 1e3:12.1f}")
 # the last summarised step in launch order
 a, b = steps[-1]
 t0 = rows[a][0]
 print("\nlast step in order:  start us   dur us   gap-before us")
+horizon = rows[a][0]
 for i in range(a, b):
     s0, e0, name = rows[i]
     short = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[-70:]
-    print(f"  {short.ljust(70)} {(s0 - t0) / 1e3:9.1f} {(e0 - s0) / 1e3:8.1f} {max(0, s0 - rows[i - 1][1]) / 1e3:8.1f}")
+    print(f"  {short.ljust(70)} {(s0 - t0) / 1e3:9.1f} {(e0 - s0) / 1e3:8.1f} {max(0, s0 - horizon) / 1e3:8.1f}")
+    horizon = max(horizon, e0)
