@@ -807,6 +807,9 @@ struct AdamFlush {
     float* p; float* m; float* v; __hip_bfloat16* shadow;
     float lr, wd, b1, b2, eps, bc1, bc2_sqrt, gscale;
 };
+// levels [first_level, end_level) of the table that receive no gradient, stepped by `blocks` extra workgroups of the reduce launch
+#define HG_TAIL_ROWS 8192
+struct TailLevels { int first_level, end_level, blocks; };
 
 template <typename T, int F, typename ACC, bool ADAM>
 static __device__ __forceinline__ void
@@ -1009,12 +1012,34 @@ template <typename T, int F, bool ADAM>
 __global__ void __launch_bounds__(RD_THREADS)
 hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList levels, int chunk_shift, BinLevels bins,
                            uint32_t ntiles, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ records,
-                           float* __restrict__ grad_codebook, int extra_bits, AdamFlush ad) {
+                           float* __restrict__ grad_codebook, int extra_bits, AdamFlush ad, TailLevels tail) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rd_smem[];            // [chunk entries * F] accumulators
     __shared__ uint32_t s_wave_max[RD_THREADS / 64];
+    if constexpr (ADAM) {
+        // The levels no gradient can reach ('cat' zeroes the columns from zero_from_col on: the FINEST level of nerf_hash.yaml) still
+        // take the optimizer's step - weight decay moves them - and used to be why a separate optimizer launch streamed 2^19 rows.
+        // tail.blocks extra workgroups of this launch do it instead: 8192 rows each, the gradient read from the table (zero
+        // unless something else wrote there; put back to zero like the optimizer's fused zeroing), wisp_adamw_update as everywhere.
+        if (blockIdx.x < (unsigned)tail.blocks) {                // FIRST in dispatch order: short streaming workgroups that are gone
+            const int64_t k = (int64_t)blockIdx.x;               // before the record walks need the bandwidth (at the END of the grid
+                                                                 // they lengthened the launch by their own 6 us)
+            const int64_t lo = first_idx[tail.first_level] * F + k * (int64_t)(HG_TAIL_ROWS * F);
+            const int64_t end = first_idx[tail.end_level] * F;
+            const int64_t hi = lo + HG_TAIL_ROWS * F < end ? lo + HG_TAIL_ROWS * F : end;
+            for (int64_t e = lo + threadIdx.x; e < hi; e += RD_THREADS) {
+                const float c = grad_codebook[e];
+                float x = ad.p[e], m1 = ad.m[e], m2 = ad.v[e];
+                wisp_adamw_update(x, m1, m2, c * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
+                ad.p[e] = x; ad.m[e] = m1; ad.v[e] = m2;
+                if (c != 0.0f) grad_codebook[e] = 0.0f;
+                if (ad.shadow) ad.shadow[e] = __float2bfloat16(x);
+            }
+            return;
+        }
+    }
     // flattened (level, bucket, split) grid
     // heaviest first: the fine (hashed) levels carry most of the records, the cheap coarse buckets fill the tail of the grid
-    const int bid = (int)(gridDim.x - 1u - blockIdx.x);
+    const int bid = (int)(gridDim.x - 1u - blockIdx.x);          // (the tail workgroups took the first tail.blocks indices)
     int li = 0;
     while (li + 1 < levels.n && bid >= bins.blk_base[li + 1]) ++li;
     const int splits = bins.splits[li];
@@ -1265,15 +1290,33 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     auto rd = hashgrid_bwd_reduce_kernel<T, F, false>;
     if constexpr (CAN_ADAM) { if (fused) rd = hashgrid_bwd_reduce_kernel<T, F, true>; }
     if (const hipError_t e = WISP_ALLOW_LDS(rd, rd_lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
-    if (fused)
+    TailLevels tail{0, 0, 0};
+    if (fused) {
         for (int li = 0; li < active.n; ++li)
             if (plan.bins.splits[li] == 1) covered_rows[active.lv[li]] = (int64_t)plan.bins.entries[li];
+        // the trailing levels behind the last active one (WISP_ADAM_TAIL=0 leaves them to the caller's optimizer launch)
+        static const bool fold_tail = env_flag("WISP_ADAM_TAIL", true);
+        const int first_dead = active.lv[active.n - 1] + 1;
+        bool contiguous = true;                                // active = 0 .. first_dead - 1 (zero_from_col cuts a suffix)
+        for (int li = 0; li < active.n; ++li) contiguous = contiguous && active.lv[li] == li;
+        if (fold_tail && contiguous && first_dead < num_lods) {
+            int64_t rows = 0;
+            for (int l = first_dead; l < num_lods; ++l) {
+                int64_t entries = (int64_t)tsize;
+                if (lv.dense[l]) { entries = 1; for (int a = 0; a < DIM; ++a) entries *= (int64_t)lv.res[l]; }
+                if (entries > (int64_t)tsize) entries = (int64_t)tsize;
+                covered_rows[l] = entries;                     // (the caller clamps to first_idx[l + 1] - first_idx[l])
+                rows += entries;
+            }
+            tail = TailLevels{first_dead, num_lods, (int)ceil_div64(rows, HG_TAIL_ROWS)};
+        }
+    }
     // one table entry can receive 2^DIM records per sample: 2^24 at the 2^21 samples the binary point is laid out for; beyond
     // that the binary point moves up with the sample count so that no sum can leave its 63 bits
     int extra_bits = 0;
     while (((int64_t)1 << (21 + extra_bits)) < n) ++extra_bits;
-    hipLaunchKernelGGL(rd, dim3(plan.total_blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
-                       plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook, extra_bits, fused ? *adam : AdamFlush{});
+    hipLaunchKernelGGL(rd, dim3(plan.total_blocks + tail.blocks), dim3(RD_THREADS), rd_lds, s, first_idx, active, plan.chunk_shift,
+                       plan.bins, (uint32_t)plan.ntiles, counts, records, grad_codebook, extra_bits, fused ? *adam : AdamFlush{}, tail);
     return 0;
 }
 

@@ -263,8 +263,10 @@ def test_hashgrid_backward_with_the_adamw_step_folded_in_matches_oracle_gradient
             cuda(coords), go.to(DEV), shape, cbegin, NGP_RES, 19, zero_from_col=30, out=grad,
             adamw=dict(param=prm, exp_avg=m1, exp_avg_sq=m2, shadow=shadow, lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd,
                        step=step, grad_scale=1.0))
-        assert len(covered) == 16 and covered[15] == 0 and all(covered[l] == int(begin[l + 1] - begin[l]) for l in range(7, 15)), covered
+        assert len(covered) == 16 and all(covered[l] == int(begin[l + 1] - begin[l]) for l in range(7, 16)), covered
         assert all(c == 0 for c in covered[:7])                      # coarse levels: buckets shared by several workgroups
+        # (level 15 lies behind zero_from_col: no gradient reaches it, and since round 5 the launch's tail workgroups give it the
+        #  optimizer's step too - weight decay moves it - instead of leaving 2^19 rows to a separate optimizer launch)
         mask = torch.zeros(shape[0], dtype=torch.bool)
         for l, c in enumerate(covered):
             mask[int(begin[l]):int(begin[l]) + c] = True
@@ -277,7 +279,8 @@ def test_hashgrid_backward_with_the_adamw_step_folded_in_matches_oracle_gradient
         assert float((g_dev[~mask].double() - want[~mask]).abs().max()) <= tol
         assert float(g_dev[mask].abs().max()) == 0.0
         # the caller's share: AdamW over the rest (what MultiviewTrainStep.optimizer_step does with the uncovered ranges)
-        rest = [(int(begin[0]) * 2, int(begin[7]) * 2), (int(begin[15]) * 2, int(begin[16]) * 2)]
+        rest = [(int(begin[0]) * 2, int(begin[7]) * 2)]
+        assert float((prm.cpu()[int(begin[15]):] - before.cpu()[int(begin[15]):]).abs().max()) > 0          # decayed inside the launch
         _C().adamw_step_groups(prm.view(-1), grad.view(-1), m1.view(-1), m2.view(-1),
                                [(lo, hi - lo, lr, wd, None if shadow is None else shadow.view(-1)[lo:hi]) for lo, hi in rest],
                                b1, b2, eps, step, zero_grad=True)
