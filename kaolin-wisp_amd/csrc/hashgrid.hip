@@ -1205,7 +1205,10 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         p.bins.cnt_base[li] = cnt;
         p.bins.rec_base[li] = rec;
         p.bins.entries[li] = (uint32_t)entries;
-        int splits = (int)(64 / chunks);                      // ~64 reduce workgroups per coarse level (atomic flush)
+        // ~64 reduce workgroups per coarse level (atomic flush).  (Round 5 tried ONE owner per bucket from 16 buckets up, so that
+        // the 50^3 and 64^3 levels could take the optimizer's step in the flush too: their single workgroups walk 512 nearly empty
+        // slots each and became the launch's long pole - 0.41 -> 0.49 ms; profiles/r05_ab_single_owner_mid_levels.txt.)
+        int splits = (int)(64 / chunks);
         if (splits > p.ntiles) splits = (int)p.ntiles;
         p.bins.splits[li] = splits < 1 ? 1 : splits;
         if (chunks > p.max_chunks) p.max_chunks = (int)chunks;
