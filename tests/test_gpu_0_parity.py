@@ -461,8 +461,11 @@ def test_reference_named_ops_follow_the_reference_call_pattern():
     assert r2.dtype == torch.int64 and dep2.shape == (r2.shape[0], 1) and b2.dtype == torch.bool
     assert np.array_equal(r2.cpu().numpy(), want_u["ridx"]) and np.array_equal(b2.cpu().numpy(), want_u["boundary"])
     assert np.array_equal(dep2.cpu().numpy().reshape(-1), np.asarray(want_u["depth_samples"]).reshape(-1))
-    with pytest.raises(NotImplementedError):
-        wisp_C.ops.hashgrid_interpolate_backward_cuda(coords, go, codebook, first_idx, resolutions, bw, 2, True)
+    # require_grad_coords = True: the reference's grad_coords, its arithmetic as is (test_hashgrid_grad_coords_matches_the_reference_kernel)
+    gco, gtab = wisp_C.ops.hashgrid_interpolate_backward_cuda(coords, go, codebook, first_idx, resolutions, bw, 2, True)
+    want_c = ohash.hashgrid_grad_coords(coords.cpu(), go.cpu(), codebook.cpu(), begin, res, bw)
+    assert gco.shape == (5000, 3) and torch.equal(gtab, grad_codebook)
+    np.testing.assert_allclose(gco.cpu().numpy(), want_c.numpy(), rtol=0, atol=2e-6 * float(want_c.abs().max()))
 
 
 def test_hashgrid_autograd_module_cat_and_sum():
