@@ -464,7 +464,8 @@ def test_reference_named_ops_follow_the_reference_call_pattern():
     # require_grad_coords = True: the reference's grad_coords, its arithmetic as is (test_hashgrid_grad_coords_matches_the_reference_kernel)
     gco, gtab = wisp_C.ops.hashgrid_interpolate_backward_cuda(coords, go, codebook, first_idx, resolutions, bw, 2, True)
     want_c = ohash.hashgrid_grad_coords(coords.cpu(), go.cpu(), codebook.cpu(), begin, res, bw)
-    assert gco.shape == (5000, 3) and torch.equal(gtab, grad_codebook)
+    assert gco.shape == (5000, 3) and gtab.dtype == codebook.dtype
+    assert float((gtab.double().cpu() - wantg).abs().max()) <= 4e-6 * float(wantg.abs().max())      # (the same table gradient beside it)
     np.testing.assert_allclose(gco.cpu().numpy(), want_c.numpy(), rtol=0, atol=2e-6 * float(want_c.abs().max()))
 
 
