@@ -560,8 +560,12 @@ composite_loss_kernel(const float* __restrict__ color, const float* __restrict__
         for (int64_t k0 = b; k0 < e; k0 += 64) {
             const int64_t i = k0 + lane;
             const bool live = i < e;
+            // every load of the chunk is issued before the scan: with the colours fetched behind it (where they are first used) a
+            // ray paid one more memory round trip in its dependent chain
             dl = live ? deltas[i] : 0.0f;
-            const float tau = live ? density[i] * dl : 0.0f;
+            const float dn = live ? density[i] : 0.0f;
+            c0 = live ? color[i * 3] : 0.0f; c1 = live ? color[i * 3 + 1] : 0.0f; c2 = live ? color[i * 3 + 2] : 0.0f;
+            const float tau = live ? dn * dl : 0.0f;
             const float inc = wave_incl_scan_f(tau, lane);
             const float excl = carry + (inc - tau);
             carry += wave_last_f(inc);
@@ -569,7 +573,6 @@ composite_loss_kernel(const float* __restrict__ color, const float* __restrict__
             if (live) {
                 T = expf(-excl); et = expf(-tau);
                 w = T * (1.0f - et);
-                c0 = color[i * 3]; c1 = color[i * 3 + 1]; c2 = color[i * 3 + 2];
                 sr += w * c0; sg += w * c1; sb += w * c2;
                 sa += w;
             }
