@@ -101,16 +101,19 @@ raymarch_ray_count_kernel(const uint32_t* __restrict__ occ_bits, const uint8_t* 
                           const float* __restrict__ jitter, uint64_t seed, const uint32_t* __restrict__ coarse_bits,
                           int coarse_level, uint32_t* __restrict__ hitmask, int32_t* __restrict__ counts) {
     __shared__ uint32_t s_coarse[(1 << (3 * RM_COARSE_MAX_LEVEL)) / 32];
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // the ray is fetched together with the coarse occupancy words, in front of the staging barrier (behind it, a workgroup - one
+    // ray - paid a second memory round trip before its first useful instruction)
+    const int64_t rr = r < num_rays ? r : num_rays - 1;
+    const float o3[3] = {origins[rr * 3], origins[rr * 3 + 1], origins[rr * 3 + 2]};
+    const float d3[3] = {dirs[rr * 3], dirs[rr * 3 + 1], dirs[rr * 3 + 2]};
     if (coarse_bits) {
         const int cw = max(1, (1 << (3 * coarse_level)) >> 5);
         for (int e = threadIdx.x; e < cw; e += blockDim.x) s_coarse[e] = coarse_bits[e];
         __syncthreads();
     }
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= num_rays) return;
-    const float o3[3] = {origins[r * 3], origins[r * 3 + 1], origins[r * 3 + 2]};
-    const float d3[3] = {dirs[r * 3], dirs[r * 3 + 1], dirs[r * 3 + 2]};
     const float ox = o3[0], oy = o3[1], oz = o3[2], dx = d3[0], dy = d3[1], dz = d3[2];
     const float step = n > 1 ? __fdiv_rn(1.0f, (float)(n - 1)) : 0.0f;
     const float fn = (float)n;
@@ -187,10 +190,14 @@ raymarch_ray_emit_kernel(const float* __restrict__ origins, const float* __restr
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= num_rays) return;
-    const int64_t begin = offsets[r];
-    if (offsets[r + 1] == begin) return;
+    // offsets, the ray and the first 64 mask words in ONE memory round trip (the ray and the words used to wait for the offsets:
+    // rays without samples leave below, their 24 + 256 bytes are the price)
+    const int64_t begin = offsets[r], end = offsets[r + 1];
     const float ox = origins[r * 3], oy = origins[r * 3 + 1], oz = origins[r * 3 + 2];
     const float dx = dirs[r * 3], dy = dirs[r * 3 + 1], dz = dirs[r * 3 + 2];
+    const int words0 = (n + 31) >> 5;
+    const uint32_t first_words = lane < words0 ? hitmask[r * words0 + lane] : 0u;
+    if (end == begin) return;
     const float step = n > 1 ? __fdiv_rn(1.0f, (float)(n - 1)) : 0.0f;
     const float fn = (float)n;
     const int words = (n + 31) >> 5;
@@ -199,7 +206,7 @@ raymarch_ray_emit_kernel(const float* __restrict__ origins, const float* __restr
     // The ray's mask words are fetched 64 at a time with ONE coalesced load (lane = word) and only the 64-candidate chunks
     // that hold a hit are visited; walking the words one by one put a dependent load in front of every (mostly empty) chunk.
     for (int wg = 0; wg < words; wg += 64) {
-        const uint32_t mine = (wg + lane < words) ? hitmask[r * words + wg + lane] : 0u;
+        const uint32_t mine = wg == 0 ? first_words : ((wg + lane < words) ? hitmask[r * words + wg + lane] : 0u);
         const unsigned long long nz = __ballot(mine != 0u);
         unsigned long long pairs = (nz | (nz >> 1)) & 0x5555555555555555ull;     // bit 2c: chunk c of this group has a hit
         while (pairs) {
