@@ -928,7 +928,7 @@ def raymarch_coarse_level(near, far, num_samples, level):
 
 
 def raymarch_ray_count(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level, jitter=None, seed=0,
-                       coarse_bits=None, coarse_level=0):
+                       coarse_bits=None, coarse_level=0, read_total_async=True):
     """First half of OctreeAS._raymarch_ray (octree_as.py:247-309): occupancy test of every candidate + per-ray offsets.
     Needs no field parameters and no host read-back, so a trainer can issue it for the NEXT batch early.  Returns the state
     raymarch_ray_finish() expands into packed samples.  coarse_bits / coarse_level: optional bitfield of a coarser level
@@ -951,7 +951,8 @@ def raymarch_ray_count(occ_bits, octree, exsum, origins, dirs, near, far, num_sa
     offsets = exclusive_scan(counts)
     st = dict(origins=origins, dirs=dirs, near32=near32, range32=range32, num_samples=num_samples, jitter=jitter, seed=seed,
               hitmask=hitmask, offsets=offsets)
-    _read_total_async(st)
+    if read_total_async:                 # (a caller that finishes at once reads the total with a plain .item(): see raymarch_ray)
+        _read_total_async(st)
     return st
 
 
@@ -1011,8 +1012,10 @@ def raymarch_ray_finish(st, with_dirs=False):
 def raymarch_ray(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level, jitter=None, seed=0,
                  coarse_bits=None, coarse_level=0):
     """OctreeAS._raymarch_ray (octree_as.py:247-309).  Returns (ridx, samples, depth, deltas, boundary, ray_offsets)."""
+    # count and finish back to back: nothing is queued between the scan and the read-back, so the side-stream copy + two events of
+    # the look-ahead path would only add host time (the drop-in trainer's loop is host bound)
     return raymarch_ray_finish(raymarch_ray_count(occ_bits, octree, exsum, origins, dirs, near, far, num_samples, level,
-                                                  jitter, seed, coarse_bits, coarse_level))
+                                                  jitter, seed, coarse_bits, coarse_level, read_total_async=False))
 
 
 def raymarch_voxel(origins, dirs, nug_ridx, nug_depth, num_samples, jitter=None, seed=0):

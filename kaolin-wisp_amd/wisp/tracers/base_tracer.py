@@ -56,8 +56,11 @@ class BaseTracer(WispModule):
                 default = getattr(self, a, None)
                 if default is not None:
                     call[a] = default
-        with torch.cuda.nvtx.range("Tracer.trace"):
+        torch.cuda.nvtx.range_push("Tracer.trace")         # (base_tracer.py:160; push / pop: the context-manager form costs a generator
+        try:                                               #  round trip per call in the host-bound drop-in loop)
             return self.trace(nef, rays, requested, extra, **call)
+        finally:
+            torch.cuda.nvtx.range_pop()
 
     def _trace_arg_names(self):
         """names of trace()'s tracer-specific keyword arguments (introspected once per class, not per call)."""

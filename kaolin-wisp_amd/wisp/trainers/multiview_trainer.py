@@ -944,8 +944,16 @@ class MultiviewTrainer(BaseTrainer):
             raise Exception("SampleRays should be used as the transform for the dataset")
         transform.set_num_samples(num_rays)
 
-    @torch.cuda.nvtx.range("MultiviewTrainer.step")         # (multiview_trainer.py:111)
     def step(self, data):
+        # the reference's profiler range (multiview_trainer.py:111: @torch.cuda.nvtx.range("MultiviewTrainer.step")) as a push / pop
+        # pair - the decorator form costs a contextlib round trip per call in a host-bound loop
+        _range_push("MultiviewTrainer.step")
+        try:
+            return self._step(data)
+        finally:
+            _range_pop()
+
+    def _step(self, data):
         rays = data['rays'].to(self.device).squeeze(0)
         img_gts = data['rgb'].to(self.device).squeeze(0)
         tracer = self.pipeline.tracer
@@ -983,7 +991,8 @@ class MultiviewTrainer(BaseTrainer):
         m.total_loss += loss.item()
         m.rgb_loss += rgb_loss.item()
         m.num_samples += 1
-        with torch.cuda.nvtx.range("MultiviewTrainer.backward"):       # (multiview_trainer.py:169-177)
+        _range_push("MultiviewTrainer.backward")                        # (multiview_trainer.py:169-177)
+        try:
             if self.cfg.enable_amp:
                 self.scaler.scale(loss).backward()
                 self.scaler.step(self.optimizer)
@@ -991,6 +1000,8 @@ class MultiviewTrainer(BaseTrainer):
             else:
                 loss.backward()
                 self.optimizer.step()
+        finally:
+            _range_pop()
         self.calc_adaptive_rays(rays, warmup=False)
         if self.cfg.scheduler:
             self.scheduler.step()
