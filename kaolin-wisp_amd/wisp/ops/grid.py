@@ -143,8 +143,11 @@ class HashGridInterpolate(torch.autograd.Function):
         res = _as_int_list(resolutions)
         feats = _hip().hashgrid_interpolate(coords.detach(), table.detach(), codebook_first_idx, res, codebook_bitwidth,
                                             zero_from_col)
-        ctx.save_for_backward(coords, codebook_first_idx)
-        ctx.table = table.detach() if coords.requires_grad else None     # (grad w.r.t. coords reads the table the forward read)
+        # (grad w.r.t. coords reads the table the forward read - the low-precision copy under autocast - so it is saved with them)
+        if coords.requires_grad:
+            ctx.save_for_backward(coords, codebook_first_idx, table.detach())
+        else:
+            ctx.save_for_backward(coords, codebook_first_idx)
         ctx.meta = (res, codebook_bitwidth, tuple(codebook.shape), codebook.dtype, zero_from_col)
         # a trainer may pre-allocate the fp32 gradient buffer of the table (flat-parameter layout): scatter into it
         ctx.grad_buffer = current_grad_buffer(codebook)
@@ -152,16 +155,16 @@ class HashGridInterpolate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        coords, first_idx = ctx.saved_tensors
+        coords, first_idx = ctx.saved_tensors[:2]
         res, bitwidth, shape, dtype, zero_from_col = ctx.meta
         grad_coords = None
         if ctx.needs_input_grad[0]:
             # what the reference returns for coords that require a gradient (grid.py:109-126 -> hashgrid_interpolate_cuda.cu:163-196),
             # its arithmetic as is - see wisp_hashgrid_grad_coords in include/wisp_hip.h for what that arithmetic is and is not
-            if ctx.table is None:
+            if len(ctx.saved_tensors) < 3:
                 raise RuntimeError("HashGridInterpolate: coords did not require a gradient in forward, but one is asked for now")
-            grad_coords = _hip().hashgrid_grad_coords(coords.detach().float(), grad_output.contiguous(), ctx.table, first_idx, res,
-                                                      bitwidth)
+            grad_coords = _hip().hashgrid_grad_coords(coords.detach().float(), grad_output.contiguous(), ctx.saved_tensors[2], first_idx,
+                                                      res, bitwidth)
             if coords.shape[-1] != 3:
                 grad_coords = grad_coords[:, :coords.shape[-1]]           # (2-D: the reference's [n, 3] zeros do not fit [n, 2] coords)
         buf = ctx.grad_buffer

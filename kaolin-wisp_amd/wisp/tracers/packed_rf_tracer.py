@@ -73,8 +73,8 @@ class PackedRFTracer(BaseTracer):
         bg = self._bg_host()
         want_depth = "depth" in channels
         ray_offsets = getattr(rm, "ray_offsets", None)
-        # (samples / directions that require a gradient - pose or camera optimisation - stay on the modular path, whose
-        #  HashGridInterpolate.backward answers a coordinate-gradient request loudly instead of returning none)
+        # (samples / directions that require a gradient - pose or camera optimisation - stay on the modular path: its
+        #  HashGridInterpolate.backward returns the reference's grad_coords, the one-node trace differentiates table + decoder only)
         coords_need_grad = samples.requires_grad or hit_ray_d.requires_grad
         if ray_offsets is not None and not coords_need_grad and _fused.supports(nef, lod_idx, extra_channels):
             # the shipped NeRF shape: lookup, decoder and compositing as ONE autograd node (same kernels, same numbers)
