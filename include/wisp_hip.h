@@ -35,7 +35,7 @@ const char* wisp_last_error(void);
  * passes, raytrace nugget cache, optimizer kinds, per-ray view codes, corner query, decoded codebook rows; 3 = round 3: per-level
  * slot scales of the hash-grid backward; 4 = round 4: workspace + row counts of the order-free trilinear / codebook backward.
  * Entry points that are only ADDED - wisp_spc_query_chain, wisp_composite_loss, wisp_codebook_trilinear_multi_bwd,
- * wisp_sdf_train_step, wisp_hashgrid_grad_coords - do not bump it). */
+ * wisp_sdf_train_step, wisp_hashgrid_grad_coords, wisp_host_reader_* - do not bump it). */
 int wisp_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -582,6 +582,16 @@ int wisp_optim_step_groups(int kind, float* param, const float* grad, float* sta
  * HOST arrays of num_tensors device pointers / row widths. */
 int wisp_gather_rows(const int64_t* index, int64_t num, int64_t num_src_rows, int num_tensors, const float* const* src,
                      const int* width, float* const* dst, wisp_stream_t stream);
+
+/* Read-back of one int64 (a sample / nugget count) without draining the compute stream: where the reference syncs to learn a size
+ * (octree_as.py:288 `nonzero`, uniform_sample_cuda.cu:76 blocking cudaMemcpy), the value is copied to pinned memory on a side
+ * stream that only waits for the kernel that produced it; the host waits for that copy alone.  create (on the current device) ->
+ * issue (src: DEVICE int64, written by work already queued on `stream`) -> wait (blocks until the copy has landed, returns the
+ * value) ... -> destroy.  A reader carries one value at a time; pool them.  Added in round 5 (no signature changed). */
+void* wisp_host_reader_create(void);
+int wisp_host_reader_issue(void* reader, const int64_t* src, wisp_stream_t stream);
+int wisp_host_reader_wait(void* reader, int64_t* value /* HOST */);
+void wisp_host_reader_destroy(void* reader);
 
 #ifdef __cplusplus
 }

@@ -317,3 +317,65 @@ extern "C" int wisp_gather_rows(const int64_t* index, int64_t num, int64_t num_s
     WISP_CHECK_LAUNCH();
     return WISP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- small read-backs without a drain
+// A variable-length op has to learn a count on the host before it can allocate its outputs (the reference syncs at the same
+// places: nonzero in octree_as.py:288, the blocking cudaMemcpy of uniform_sample_cuda.cu:76).  Reading it on the compute stream
+// would drain everything queued there, so the value travels on a side stream that only waits for the kernel that produced it:
+// event on the compute stream -> side stream waits -> 8-byte copy to pinned memory -> event; the host later waits for that
+// event alone.  This used to be five torch calls per step (two Event objects, a stream context, wait_event, copy_): 25 us of
+// host time in a loop whose host side is critical at 2^18 samples per step.  One reader = one pinned word + two events + the
+// side stream of its device; readers are pooled by the caller.
+struct HostReader {
+    int64_t* host;
+    hipEvent_t ready, done;
+    hipStream_t side;
+    int device;
+};
+static hipStream_t g_reader_stream[64] = {nullptr};
+
+extern "C" void* wisp_host_reader_create(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    HostReader* r = new HostReader{nullptr, nullptr, nullptr, nullptr, dev};
+    if (!g_reader_stream[dev] && hipStreamCreateWithFlags(&g_reader_stream[dev], hipStreamNonBlocking) != hipSuccess) { delete r; return nullptr; }
+    r->side = g_reader_stream[dev];
+    if (hipHostMalloc((void**)&r->host, sizeof(int64_t), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->done, hipEventDisableTiming) != hipSuccess) {
+        if (r->host) (void)hipHostFree(r->host);
+        if (r->ready) (void)hipEventDestroy(r->ready);
+        delete r;
+        return nullptr;
+    }
+    return r;
+}
+
+extern "C" int wisp_host_reader_issue(void* reader, const int64_t* src, wisp_stream_t stream) {
+    WISP_REQUIRE(reader && src, "null pointer");
+    HostReader* r = (HostReader*)reader;
+    hipError_t e = hipEventRecord(r->ready, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(r->side, r->ready, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->host, src, sizeof(int64_t), hipMemcpyDeviceToHost, r->side);
+    if (e == hipSuccess) e = hipEventRecord(r->done, r->side);
+    if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
+    return WISP_OK;
+}
+
+extern "C" int wisp_host_reader_wait(void* reader, int64_t* value) {
+    WISP_REQUIRE(reader && value, "null pointer");
+    HostReader* r = (HostReader*)reader;
+    const hipError_t e = hipEventSynchronize(r->done);
+    if (e != hipSuccess) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
+    *value = *r->host;
+    return WISP_OK;
+}
+
+extern "C" void wisp_host_reader_destroy(void* reader) {
+    if (!reader) return;
+    HostReader* r = (HostReader*)reader;
+    (void)hipEventDestroy(r->ready);
+    (void)hipEventDestroy(r->done);
+    (void)hipHostFree(r->host);
+    delete r;
+}

@@ -106,11 +106,15 @@ SIGNATURES = {
     "wisp_nerf_mlp_bwd_workspace_bytes": [c_i64, c_i32],
     "wisp_nerf_mlp_workspace_floats": [],
     "wisp_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32, c_i32, c_vp, c_vp],
+    "wisp_host_reader_create": [],
+    "wisp_host_reader_issue": [c_vp, c_vp, c_vp],
+    "wisp_host_reader_wait": [c_vp, c_vp],
+    "wisp_host_reader_destroy": [c_vp],
     "wisp_last_error": [],
     "wisp_abi_version": [],
 }
 _RESTYPES = {"wisp_nerf_mlp_bwd_workspace_bytes": c_i64, "wisp_spc_bwd_workspace_bytes": c_i64, "wisp_sdf_train_scratch_bytes": c_i64, "wisp_hashgrid_bwd_workspace_bytes": c_i64, "wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_nerf_mlp_workspace_floats": c_i64,
-             "wisp_last_error": ctypes.c_char_p}
+             "wisp_last_error": ctypes.c_char_p, "wisp_host_reader_create": c_vp, "wisp_host_reader_destroy": None}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here == header/library mismatch: fail loudly
@@ -226,10 +230,13 @@ except AttributeError:                                         # pragma: no cove
     _raw_stream = None
 
 
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)       # (torch.cuda.current_device() walks through _lazy_init: 1 us per call)
+
+
 def _stream():
     """the HIP stream torch is currently launching on (the kernels must be ordered with torch's own work)."""
     if _raw_stream is not None:
-        return c_vp(_raw_stream(torch.cuda.current_device()))
+        return c_vp(_raw_stream(_raw_device() if _raw_device is not None else torch.cuda.current_device()))
     return c_vp(torch.cuda.current_stream().cuda_stream)
 
 
@@ -250,6 +257,20 @@ def _need(t, dtype=None, name="tensor"):
 def _host_i32(values):
     arr = np.ascontiguousarray(np.asarray(values, dtype=np.int32).reshape(-1))
     return arr, arr.ctypes.data_as(c_vp)
+
+
+_res_cache = {}
+
+
+def _host_res(resolutions):
+    """(tuple, numpy int32 array, pointer) of a level-resolution list - built once per distinct list: the per-step callers hand
+    in the same sixteen integers every time, and numpy + ctypes conversions were 10 us of host time per step."""
+    key = resolutions if type(resolutions) is tuple else tuple(int(r) for r in resolutions)
+    hit = _res_cache.get(key)
+    if hit is None:
+        arr, ptr = _host_i32(key)
+        hit = _res_cache[key] = (key, arr, ptr)
+    return hit
 
 
 def _host_f32(values):
@@ -286,7 +307,7 @@ def hashgrid_interpolate(coords, codebook, first_idx, resolutions, codebook_bitw
     _check_first_idx(first_idx, L, codebook.shape[0])
     if zero_from_col is None:
         zero_from_col = L * F
-    res_arr, res_ptr = _host_i32(resolutions)
+    _, res_arr, res_ptr = _host_res(resolutions)
     feats = torch.empty(n, L * F, dtype=codebook.dtype, device=coords.device)
     with _timed("hashgrid_fwd", n):
         _check(lib.wisp_hashgrid_interpolate_fwd(_p(coords), n, dim, _p(codebook), _DTYPE_CODE[codebook.dtype], F,
@@ -311,14 +332,13 @@ def hashgrid_interpolate_backward(coords, grad_feats, codebook_shape, first_idx,
     _check_first_idx(first_idx, L, codebook_shape[0])
     if zero_from_col is None:
         zero_from_col = L * F
-    res_arr, res_ptr = _host_i32(resolutions)
+    res_key, res_arr, res_ptr = _host_res(resolutions)
     grad = out if out is not None else torch.zeros(tuple(codebook_shape), dtype=torch.float32, device=coords.device)
     assert grad.dtype == torch.float32 and grad.is_contiguous()
     dt = _DTYPE_CODE[grad_feats.dtype]
     # scratch for the binned reduction; its record slots are sized from what earlier launches of this shape really filled
-    fit = _slot_fit(coords.device, dim, dt, F, tuple(int(r) for r in res_arr), codebook_bitwidth, zero_from_col) if n >= 4096 else None
-    scale_arr = fit.scales(n) if fit is not None else None
-    scale_ptr = None if scale_arr is None else ctypes.cast(scale_arr, ctypes.c_void_p)
+    fit = _slot_fit(coords.device, dim, dt, F, res_key, codebook_bitwidth, zero_from_col) if n >= 4096 else None
+    scale_arr, scale_ptr = fit.scales(n) if fit is not None else (None, None)
     ws_bytes = int(lib.wisp_hashgrid_bwd_workspace_bytes(n, dim, dt, F, res_ptr, L, codebook_bitwidth, scale_ptr))
     ws = _bwd_workspace(coords.device, ws_bytes) if 0 < ws_bytes <= HASHGRID_BWD_WORKSPACE_LIMIT else None
     covered = None
@@ -395,10 +415,15 @@ class _SlotFit:
         self.last = None            # what the last evaluated check saw (tests, bench)
         self.dev_fill = torch.zeros(2 * self.L, dtype=torch.int32, device=device)      # [fullest slot x L | records written x L]
         self.host_fill = torch.zeros(2 * self.L, dtype=torch.int32).pin_memory()
+        self._scale_c = None
 
     def scales(self, n):
+        """-> (ctypes float array, its pointer); rebuilt only when a check changed the scales"""
         self._collect()
-        return (ctypes.c_float * self.L)(*self.scale)
+        if self._scale_c is None or self._scale_c[2] != self.scale:
+            arr = (ctypes.c_float * self.L)(*self.scale)
+            self._scale_c = (arr, ctypes.cast(arr, ctypes.c_void_p), list(self.scale))
+        return self._scale_c[0], self._scale_c[1]
 
     def _collect(self):
         p = self.pending
@@ -960,35 +985,31 @@ def raymarch_ray_count(occ_bits, octree, exsum, origins, dirs, near, far, num_sa
 # stream would drain EVERYTHING queued there (with the trainer's one-batch look-ahead: the whole previous step) and leave
 # the GPU idle while the host wakes up and launches again (measured: 43 us per step).  Instead the total is copied to
 # pinned memory on a side stream that only waits for the scan; raymarch_ray_finish() waits for that copy alone.
-_copy_streams, _pinned_pool = {}, []
+_reader_pool = {}                       # device index -> idle HostReader handles (wisp_host_reader_*: csrc/misc.hip)
 
 
 def _read_total_async(st):
+    """Issue the read-back of offsets[-1] (the packed sample count): two C calls - event on the compute stream, side stream waits,
+    8-byte copy to pinned memory, event.  (Five torch calls until round 5: 25 us of host time per step.)"""
     offsets = st["offsets"]
-    dev = offsets.device
-    side = _copy_streams.get(dev)
-    if side is None:
-        side = _copy_streams[dev] = torch.cuda.Stream(dev)
-    host = _pinned_pool.pop() if _pinned_pool else torch.empty(1, dtype=torch.int64, pin_memory=True)
-    ready = torch.cuda.Event()
-    ready.record(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side):
-        side.wait_event(ready)
-        host.copy_(offsets[-1:], non_blocking=True)
-        done = torch.cuda.Event()
-        done.record(side)
-    st["total_host"], st["total_done"] = host, done
+    dev = offsets.device.index if offsets.device.index is not None else torch.cuda.current_device()
+    pool = _reader_pool.setdefault(dev, [])
+    reader = pool.pop() if pool else lib.wisp_host_reader_create()
+    if not reader:
+        raise RuntimeError(f"wisp_host_reader_create failed: {last_error()}")
+    _check(lib.wisp_host_reader_issue(reader, c_vp(offsets.data_ptr() + 8 * (offsets.numel() - 1)), _stream()), "host_reader_issue")
+    st["total_reader"] = (dev, reader)
 
 
 def _total(st):
-    done = st.pop("total_done", None)
-    if done is None:
+    pending = st.pop("total_reader", None)
+    if pending is None:
         return int(st["offsets"][-1].item())
-    done.synchronize()
-    host = st.pop("total_host")
-    total = int(host[0])
-    _pinned_pool.append(host)
-    return total
+    dev, reader = pending
+    value = ctypes.c_int64(0)
+    _check(lib.wisp_host_reader_wait(reader, ctypes.byref(value)), "host_reader_wait")
+    _reader_pool[dev].append(reader)
+    return int(value.value)
 
 
 def raymarch_ray_finish(st, with_dirs=False):

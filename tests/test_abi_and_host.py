@@ -37,7 +37,7 @@ def test_ctypes_signatures_follow_the_header_argument_by_argument():
     header = open(os.path.join(ROOT, "include", "wisp_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)                       # comments may hold commas and parentheses
     header = re.sub(r"//[^\n]*", " ", header)
-    decls = re.findall(r"\b(?:int|int64_t|const char\s*\*)\s+(wisp_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header)
+    decls = re.findall(r"\b(?:int|int64_t|const char\s*\*|void\s*\*|void)\s+(wisp_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header)
     assert len(decls) == len(C.SIGNATURES)
     kinds = {ctypes.c_void_p: "ptr", ctypes.c_int64: "i64", ctypes.c_int32: "i32", ctypes.c_float: "f32", ctypes.c_uint64: "u64",
              ctypes.c_uint32: "u32", ctypes.c_double: "f64"}
