@@ -300,7 +300,40 @@ struct BinLevels {
     int32_t blk_base[HG_MAX_LODS + 1];      // reduce kernel: first workgroup of every level in the flattened 1-D grid
     int32_t rank_base[HG_MAX_LODS + 1];     // emit kernel: first LDS rank counter of every level
     int64_t max_base;                       // count cell of emitting workgroup 0's largest record magnitude ([ntiles] cells)
+    // Bucket of a table row.  Hashed levels and one-bucket levels: bucket = row >> chunk_shift (8192 consecutive rows).  DENSE
+    // levels with several buckets (strip_magic != 0): a bucket of consecutive rows is a slab of space, a workgroup's rays cross
+    // few slabs, and its records of the level land in a few (bucket, workgroup) slots - fullest slot 3-8 x the mean, which is what
+    // the slot capacity (hence the scratch) has to follow, and whole buckets 3 x the mean load for the reduce kernel.  There the
+    // level is cut into STRIPS of 32 rows dealt round-robin to the buckets, the deal rotated by the round number so that rows a
+    // multiple of the bucket count apart (the next y row / z plane of a power-of-two grid) do not meet in one bucket:
+    //   strip = row >> 5, round = strip / buckets, bucket = (strip % buckets + (round & rot_mask)) mod buckets,
+    //   entry inside the bucket = round * 32 + (row & 31)            (fullest slot 1.3-2 x the mean, bucket loads within 15 %)
+    uint32_t strip_magic[HG_MAX_LODS];      // ceil(2^32 / buckets), 0 = consecutive rows
+    uint32_t rot_mask[HG_MAX_LODS];         // (largest power of two <= buckets) - 1
 };
+#define HG_STRIP_SHIFT 5
+// -> bucket and entry inside it (wave-uniform branch)
+static __device__ __forceinline__ void bucket_of(uint32_t idx, int chunk_shift, uint32_t magic, uint32_t buckets, uint32_t rot_mask,
+                                                 uint32_t& b, uint32_t& loc) {
+    if (magic == 0) {
+        b = idx >> chunk_shift;
+        loc = idx & ((1u << chunk_shift) - 1u);
+    } else {
+        const uint32_t strip = idx >> HG_STRIP_SHIFT;
+        const uint32_t round = __umulhi(strip, magic);           // exact: strip < 2^18, buckets <= 1024 (bin_plan)
+        uint32_t t = strip - __umul24(round, buckets) + (round & rot_mask);
+        b = t >= buckets ? t - buckets : t;
+        loc = (round << HG_STRIP_SHIFT) | (idx & ((1u << HG_STRIP_SHIFT) - 1u));
+    }
+}
+// the inverse: row of entry `loc` of bucket b (may lie past the level's last row: the caller checks)
+static __device__ __forceinline__ uint32_t bucket_row(uint32_t b, uint32_t loc, int chunk_shift, uint32_t magic, uint32_t buckets, uint32_t rot_mask) {
+    if (magic == 0) return (b << chunk_shift) + loc;
+    const uint32_t round = loc >> HG_STRIP_SHIFT;
+    const uint32_t rot = round & rot_mask;
+    const uint32_t r = b >= rot ? b - rot : b + buckets - rot;
+    return ((round * buckets + r) << HG_STRIP_SHIFT) | (loc & ((1u << HG_STRIP_SHIFT) - 1u));
+}
 
 template <typename T, int F, int DIM, bool MERGE>
 static __device__ __forceinline__ bool tail_compute(const float* c, bool live, int l, int32_t res, float hi, float hr, bool dense, uint32_t tsize,
@@ -430,6 +463,14 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #ifndef EM_MIN_WAVES
 #define EM_MIN_WAVES 2          // waves per SIMD the emit kernel is register-budgeted for
 #endif
+// Threads of the queue emitter's workgroup (the training shape).  512 = two workgroups per CU.  1024 (ONE per CU, one 64-sample group
+// per wave so that the piece stays EM_TILE samples) halves the number of (bucket, workgroup) slots and makes them twice as full:
+// the fullest slot of a hashed level is 1.6-2.1 x the mean instead of 1.9-2.6 x and the scratch falls from 1.12 to 0.92 GB at 2^21
+// samples - for +7 us on the pair (0.411 -> 0.419 ms, three A/B rounds inside one box: profiles/r05_ab_scratch_geometry.txt).
+// Speed was kept.
+#ifndef EQ_THREADS
+#define EQ_THREADS 512
+#endif
 #define RD_THREADS 1024
 #define BIN_MAX_CHUNKS 1024
 #ifndef HG_ACC_PLANES
@@ -439,7 +480,7 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #define HG_FLUSH_PAIRS 1       // (0: A/B builds of the reduce kernel's flush without its 8-byte path, scripts/gpu_r4_k.sh)
 #endif
 
-// Records.  Generic form: { index within the level table, F fp32 gradient values } = 1 + F dwords.  For two features coming
+// Records.  Generic form: { entry inside the bucket, F fp32 gradient values } = 1 + F dwords.  For two features coming
 // from a 16-bit gradient tensor (the bf16 / fp16 training path) the record is packed into TWO dwords: each value keeps
 // sign, exponent and 16 mantissa bits (rounded; 2^-17 relative - the values were products of a 16-bit gradient already)
 // and donates its low 7 bits to the index INSIDE the bucket (14 bits; a bucket has at most 8192 entries).  A third less
@@ -448,9 +489,8 @@ template <typename T, int F> struct RecordCodec {
     static constexpr bool COMPACT = (sizeof(T) == 2 && F == 2);
     static constexpr int RW = COMPACT ? 2 : 1 + F;
     // -> the largest magnitude stored, as float bits (sign cleared): feeds the reduce kernel's fixed-point exponent
-    static __device__ __forceinline__ uint32_t store(uint32_t* dst, uint32_t idx, uint32_t local_mask, const float (&v)[F]) {
+    static __device__ __forceinline__ uint32_t store(uint32_t* dst, uint32_t loc, const float (&v)[F]) {
         if constexpr (COMPACT) {
-            const uint32_t loc = idx & local_mask;
             uint2 w;
             // (round to 17 bits.  The add cannot carry out of a NaN's mantissa into the sign: COMPACT records come from 16-bit
             //  gradients, whose NaN payloads have zero low bits, and products / sums hand a NaN operand's payload on - or
@@ -460,7 +500,7 @@ template <typename T, int F> struct RecordCodec {
             *reinterpret_cast<uint2*>(dst) = w;
             return max(w.x & 0x7fffff80u, w.y & 0x7fffff80u);
         } else {
-            dst[0] = idx;
+            dst[0] = loc;
             uint32_t m = 0;
 #pragma unroll
             for (int k = 0; k < F; ++k) { dst[1 + k] = __float_as_uint(v[k]); m = max(m, __float_as_uint(v[k]) & 0x7fffffffu); }
@@ -468,7 +508,7 @@ template <typename T, int F> struct RecordCodec {
         }
     }
     // -> entry index inside the bucket, values
-    static __device__ __forceinline__ uint32_t load(const uint32_t (&w)[RW], uint32_t first, float (&v)[F]) {
+    static __device__ __forceinline__ uint32_t load(const uint32_t (&w)[RW], float (&v)[F]) {
         if constexpr (COMPACT) {
             v[0] = __uint_as_float(w[0] & ~0x7fu);
             v[1] = __uint_as_float(w[1] & ~0x7fu);
@@ -476,7 +516,7 @@ template <typename T, int F> struct RecordCodec {
         } else {
 #pragma unroll
             for (int k = 0; k < F; ++k) v[k] = __uint_as_float(w[1 + k]);
-            return w[0] - first;
+            return w[0];
         }
     }
 };
@@ -547,6 +587,7 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
         // rows this level owns (bounded by the plan's figure AND by the table the caller really passed)
         const int64_t rows_l = first_idx[l + 1] - first_idx[l];
         const uint32_t owned = (uint32_t)(rows_l < (int64_t)bins.entries[li] ? (rows_l < 0 ? 0 : rows_l) : (int64_t)bins.entries[li]);
+        const uint32_t magic = bins.strip_magic[li], nbuckets = (uint32_t)bins.chunks[li], rot_mask = bins.rot_mask[li];
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             const int sl = (wave * GROUPS + g) * 64 + lane;
@@ -562,15 +603,18 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
             for (int j = 0; j < NC; ++j) {
                 const uint32_t idx = (uint32_t)cs.idx[j];
                 // an index past the rows the level owns has no bucket (and no rank counter): straight to the atomic
-                pos[j] = idx < owned ? atomicAdd(&rank_l[idx >> chunk_shift], 1u) : 0xffffffffu;
+                uint32_t b, loc;
+                bucket_of(idx, chunk_shift, magic, nbuckets, rot_mask, b, loc);
+                pos[j] = idx < owned ? atomicAdd(&rank_l[b], 1u) : 0xffffffffu;
             }
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const uint32_t idx = (uint32_t)cs.idx[j];
-                const uint32_t b = idx >> chunk_shift;
+                uint32_t b, loc;
+                bucket_of(idx, chunk_shift, magic, nbuckets, rot_mask, b, loc);
                 if (pos[j] < cap) {
                     uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos[j]) * RW);   // < 2^32 dwords (bin_plan)
-                    mx = max(mx, Codec::store(dst, idx, (1u << chunk_shift) - 1u, v[j]));
+                    mx = max(mx, Codec::store(dst, loc, v[j]));
                 } else {
                     // slot full, or a spill index: the memory-side atomic.  A spill lands where the reference's pointer
                     // arithmetic puts it (rows of the next level, .cu:124-161) unless that is past the whole table.
@@ -612,7 +656,7 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
 //     hand-over needs no barrier.
 #define EQ_MAX_ROW 16
 template <typename T, int DIM>
-__global__ void __launch_bounds__(EM_THREADS, EM_MIN_WAVES)
+__global__ void __launch_bounds__(EQ_THREADS, EM_MIN_WAVES)
 hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ grad_feats,
                            const int64_t* __restrict__ first_idx, HashLevels lv, LevelList levels, int num_lods,
                            uint32_t tsize, int tsize_pow2, int zero_from_col, int chunk_shift, BinLevels bins,
@@ -622,7 +666,7 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
     typedef RecordCodec<T, F> Codec;
     static_assert(Codec::COMPACT, "two 16-bit features per level");
     constexpr int RW = Codec::RW;
-    constexpr int GROUPS = EM_TILE / EM_THREADS;
+    constexpr int GROUPS = EM_TILE / EQ_THREADS;
     constexpr int QROW = 3 * NC + 1;                     // dwords per parked tail
     extern __shared__ __attribute__((aligned(16))) uint32_t em_smem[];
     const int total_ranks = bins.rank_base[levels.n];
@@ -635,7 +679,7 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
     uint32_t* s_queue = em_smem + ((total_ranks + 4) & ~3) + wave * (64 * QROW);
     const uint32_t ntiles = gridDim.x;
     const int64_t total_rows = first_idx[num_lods];
-    for (int b = threadIdx.x; b < total_ranks; b += EM_THREADS) s_rank[b] = 0;
+    for (int b = threadIdx.x; b < total_ranks; b += EQ_THREADS) s_rank[b] = 0;
     __syncthreads();
     // lane -> (tail, corner) of a queue pass
     const uint32_t q_lane = (uint32_t)((lane / NC) * QROW + (lane % NC) * 3);
@@ -678,6 +722,7 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
             const int64_t base_l = first_idx[l];
             const int64_t rows_l = first_idx[l + 1] - base_l;
             const uint32_t owned = (uint32_t)(rows_l < (int64_t)bins.entries[li] ? (rows_l < 0 ? 0 : rows_l) : (int64_t)bins.entries[li]);
+            const uint32_t magic = bins.strip_magic[li], nbuckets = (uint32_t)bins.chunks[li], rot_mask = bins.rot_mask[li];
 #pragma unroll
             for (int g = 0; g < GROUPS; ++g) {
                 CornerSetup<DIM> cs;
@@ -707,12 +752,13 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
                         float val[F];
                         val[0] = __uint_as_float(q[1]);
                         val[1] = __uint_as_float(q[2]);
-                        const uint32_t b = idx >> chunk_shift;
+                        uint32_t b, loc;
+                        bucket_of(idx, chunk_shift, magic, nbuckets, rot_mask, b, loc);
                         // an index past the rows the level owns has no bucket (and no rank counter): straight to the atomic
                         const uint32_t pos = idx < owned ? atomicAdd(&rank_l[b], 1u) : 0xffffffffu;
                         if (pos < cap) {
                             uint32_t* dst = rec_l + (size_t)((b * bucket_stride + slot0 + pos) * RW);   // < 2^32 dwords (bin_plan)
-                            mx = max(mx, Codec::store(dst, idx, (1u << chunk_shift) - 1u, val));
+                            mx = max(mx, Codec::store(dst, loc, val));
                         } else {
                             // slot full, or a spill index (lands where the reference's pointer arithmetic puts it, .cu:124-161,
                             // unless that is past the whole table)
@@ -738,7 +784,7 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
         const uint32_t cap = bins.cap[li];
         const uint32_t* rank_l = s_rank + bins.rank_base[li];
         uint32_t* __restrict__ cnt_l = counts + bins.cnt_base[li];
-        for (int b = threadIdx.x; b < chunks; b += EM_THREADS) {
+        for (int b = threadIdx.x; b < chunks; b += EQ_THREADS) {
             const uint32_t cn = rank_l[b];
             cnt_l[(size_t)b * ntiles + blockIdx.x] = cn < cap ? cn : cap;
         }
@@ -747,7 +793,7 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
 
 // queue + rank counters
 static inline size_t queue_emitter_lds(int total_ranks, int dim) {
-    return ((size_t)((total_ranks + 4) & ~3) + (size_t)(EM_THREADS / 64) * 64 * (3 * (1 << dim) + 1)) * 4;
+    return ((size_t)((total_ranks + 4) & ~3) + (size_t)(EQ_THREADS / 64) * 64 * (3 * (1 << dim) + 1)) * 4;
 }
 // Workgroups of the queue emitter one CU holds at once (registers + LDS; asked from the runtime, once per instance; the
 // half and bf16 instances are the same code).  The rank counters vary a little with the level layout: 1024 is a safe figure.
@@ -758,7 +804,7 @@ static int queue_emitter_residency() {
         auto eq = hashgrid_bwd_emit_q_kernel<T, DIM>;
         const size_t lds = queue_emitter_lds(1024, DIM);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eq, EM_THREADS, lds) != hipSuccess || nb <= 0) nb = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eq, EQ_THREADS, lds) != hipSuccess || nb <= 0) nb = EQ_THREADS >= 1024 ? 1 : 2;
         return nb;
     }();
     return v;
@@ -828,7 +874,11 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
     // which is only race free while no other workgroup (of this or the next level) touches those addresses
     const int64_t rows_l = first_idx[l + 1] - first_idx[l];
     const uint32_t entries = (uint32_t)(rows_l < (int64_t)bins.entries[li] ? (rows_l < 0 ? 0 : rows_l) : (int64_t)bins.entries[li]);
-    const uint32_t lim = (entries > first ? min(entries - first, csize) : 0u) * F;
+    // strip-dealt buckets (BinLevels::strip_magic): entry e of the bucket is row bucket_row(e), valid while below `entries`
+    const uint32_t magic = bins.strip_magic[li], nbuckets = (uint32_t)bins.chunks[li], rot_mask = bins.rot_mask[li];
+    const bool strips = magic != 0;
+    const uint32_t strip_rounds = (((entries + (1u << HG_STRIP_SHIFT) - 1u) >> HG_STRIP_SHIFT) + nbuckets - 1u) / nbuckets;
+    const uint32_t lim = (strips ? min(strip_rounds << HG_STRIP_SHIFT, csize) : (entries > first ? min(entries - first, csize) : 0u)) * F;
     // Accumulator slot of table element x = entry * F + feature of this bucket: one PLANE per feature ([F][csize]).  With the
     // features of an entry side by side ([csize][F]) the lanes of one ds_add_u64 - random entries, one feature - can only
     // land on every F-th 8-byte slot, i.e. on a 1/F of the banks.  (Worth 3 of 420 us only: what the kernel waits for is the
@@ -884,7 +934,7 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
             for (int u = 0; u < INFLIGHT; ++u) {
                 if (act[u]) {
                     float val[F];
-                    const uint32_t e = Codec::load(w[u], first, val);
+                    const uint32_t e = Codec::load(w[u], val);
 #pragma unroll
                     for (int kk = 0; kk < F; ++kk) {
 #ifdef HG_EXP_NOATOM        // (timing experiment, scripts/gpu_r4_o.sh: the record walk without its LDS atomics - results are wrong)
@@ -897,6 +947,97 @@ hashgrid_bwd_reduce_body(const ACC A, const int64_t* __restrict__ first_idx, con
         }
     }
     __syncthreads();
+    if (strips) {
+        // rows of this bucket: strips of 32 (contiguous 32 * F floats each) spread over the level; addressed from the level's first row
+        float* __restrict__ dl = grad_codebook + first_idx[l] * F;
+        if constexpr (ADAM) {
+            if (splits == 1) {                            // (F == 2: an entry is one float2; the level starts on an even float)
+                const int64_t level0 = first_idx[l] * F;
+                float2* __restrict__ pg = reinterpret_cast<float2*>(dl);
+                float2* __restrict__ pp = reinterpret_cast<float2*>(ad.p + level0);
+                float2* __restrict__ pm = reinterpret_cast<float2*>(ad.m + level0);
+                float2* __restrict__ pv = reinterpret_cast<float2*>(ad.v + level0);
+                uint32_t* __restrict__ ps = ad.shadow ? reinterpret_cast<uint32_t*>(ad.shadow + level0) : nullptr;
+                constexpr int PQ = 4;
+                const uint32_t pairs = lim / F;
+                if ((((uintptr_t)grad_codebook | (uintptr_t)ad.p | (uintptr_t)ad.m | (uintptr_t)ad.v) & 7u) != 0) {
+                    for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {          // (a caller's oddly aligned tensors)
+                        const uint32_t row = bucket_row((uint32_t)b, e / (uint32_t)F, chunk_shift, magic, nbuckets, rot_mask);
+                        if (row >= entries) continue;
+                        const int64_t x = level0 + (int64_t)row * F + e % (uint32_t)F;
+                        const float c = grad_codebook[x];
+                        float w = ad.p[x], m1 = ad.m[x], m2 = ad.v[x];
+                        wisp_adamw_update(w, m1, m2, (c + A.get(ax(e))) * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
+                        ad.p[x] = w; ad.m[x] = m1; ad.v[x] = m2;
+                        if (c != 0.0f) grad_codebook[x] = 0.0f;
+                        if (ad.shadow) ad.shadow[x] = __float2bfloat16(w);
+                    }
+                    return;
+                }
+                for (uint32_t i0 = threadIdx.x; i0 < pairs; i0 += PQ * RD_THREADS) {
+                    float2 cg[PQ], cp[PQ], cm[PQ], cv[PQ];
+                    uint32_t row[PQ];
+#pragma unroll
+                    for (int q = 0; q < PQ; ++q) {
+                        const uint32_t i = i0 + q * RD_THREADS;
+                        row[q] = i < pairs ? bucket_row((uint32_t)b, i, chunk_shift, magic, nbuckets, rot_mask) : 0xffffffffu;
+                        if (row[q] < entries) { cg[q] = pg[row[q]]; cp[q] = pp[row[q]]; cm[q] = pm[row[q]]; cv[q] = pv[row[q]]; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < PQ; ++q) {
+                        const uint32_t i = i0 + q * RD_THREADS;
+                        if (row[q] < entries) {
+                            const bool dirty = cg[q].x != 0.0f || cg[q].y != 0.0f;
+                            const float g0 = cg[q].x + A.get(ax(2 * i)), g1 = cg[q].y + A.get(ax(2 * i + 1));
+                            wisp_adamw_update(cp[q].x, cm[q].x, cv[q].x, g0 * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
+                            wisp_adamw_update(cp[q].y, cm[q].y, cv[q].y, g1 * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
+                            pp[row[q]] = cp[q];
+                            pm[row[q]] = cm[q];
+                            pv[row[q]] = cv[q];
+                            if (dirty) pg[row[q]] = make_float2(0.0f, 0.0f);
+                            if (ps) {
+                                const __hip_bfloat16 s0 = __float2bfloat16(cp[q].x), s1 = __float2bfloat16(cp[q].y);
+                                ps[row[q]] = (uint32_t)__bfloat16_as_ushort(s0) | ((uint32_t)__bfloat16_as_ushort(s1) << 16);
+                            }
+                        }
+                    }
+                }
+                return;
+            }
+        }
+        // element e = entry * F + feature of the bucket -> table element; 0xffffffff past the level's last row
+        auto elem = [&](uint32_t e) -> uint32_t {
+            const uint32_t row = bucket_row((uint32_t)b, e / (uint32_t)F, chunk_shift, magic, nbuckets, rot_mask);
+            return row < entries ? row * (uint32_t)F + e % (uint32_t)F : 0xffffffffu;
+        };
+        if (splits == 1) {
+            // all of a thread's loads before its first store, as below
+            constexpr int MAXE = 16;                      // 16384 accumulators / 1024 threads
+            float cur[MAXE];
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q) {
+                const uint32_t e = threadIdx.x + q * RD_THREADS;
+                const uint32_t x = e < lim ? elem(e) : 0xffffffffu;
+                cur[q] = x != 0xffffffffu ? dl[x] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q) {
+                const uint32_t e = threadIdx.x + q * RD_THREADS;
+                const uint32_t x = e < lim ? elem(e) : 0xffffffffu;
+                if (x != 0xffffffffu) {
+                    const float a = A.get(ax(e));
+                    if (a != 0.0f) dl[x] = cur[q] + a;
+                }
+            }
+        } else {
+            for (uint32_t e = threadIdx.x; e < lim; e += RD_THREADS) {
+                const uint32_t x = elem(e);
+                const float a = A.get(ax(e));
+                if (x != 0xffffffffu && a != 0.0f) atomicAdd(dl + x, a);
+            }
+        }
+        return;
+    }
     const int64_t slice = (first_idx[l] + (int64_t)first) * F;
     float* __restrict__ dst = grad_codebook + slice;
     if constexpr (ADAM) {
@@ -1127,6 +1268,7 @@ static bool env_flag(const char* name, bool dflt) {
 static bool bwd_merge_enabled() { static const bool v = env_flag("WISP_HG_BWD_MERGE", true); return v; }
 static bool bwd_bin_enabled() { static const bool v = env_flag("WISP_HG_BWD_BIN", true); return v; }
 
+static bool strip_buckets_enabled() { static const bool v = env_flag("WISP_HG_STRIP_BUCKETS", true); return v; }
 static bool queue_emitter_enabled() { static const bool v = env_flag("WISP_HG_BWD_QUEUE", true); return v; }
 // workgroups of the queue emitter the chip holds at once; 0 = no cap
 static int64_t queue_emitter_grid_cap(int resident_per_cu) {
@@ -1201,6 +1343,13 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         }
         if (chunks > BIN_MAX_CHUNKS || entries > 0xffffffffLL || chunks * p.ntiles * cap * rec_dwords > 0xffffffffLL) p.ok = false;
         p.bins.chunks[li] = (int32_t)chunks;
+        // dense level with several buckets: strips of 32 rows dealt to the buckets (BinLevels::strip_magic)
+        p.bins.strip_magic[li] = 0; p.bins.rot_mask[li] = 0;
+        if (lv.dense[l] && chunks >= 2 && strip_buckets_enabled()) {
+            p.bins.strip_magic[li] = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)chunks - 1) / (uint64_t)chunks);
+            uint32_t pw = 1; while (pw * 2 <= (uint32_t)chunks) pw *= 2;
+            p.bins.rot_mask[li] = pw - 1;
+        }
         p.bins.cap[li] = (uint32_t)cap;
         p.bins.cnt_base[li] = cnt;
         p.bins.rec_base[li] = rec;
@@ -1274,7 +1423,7 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
             const size_t q_lds = queue_emitter_lds(plan.total_ranks, DIM);
             auto eq = hashgrid_bwd_emit_q_kernel<T, DIM>;
             if (const hipError_t e = WISP_ALLOW_LDS(eq, q_lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
-            hipLaunchKernelGGL(eq, dim3((unsigned)plan.ntiles), dim3(EM_THREADS), q_lds, s,
+            hipLaunchKernelGGL(eq, dim3((unsigned)plan.ntiles), dim3(EQ_THREADS), q_lds, s,
                                coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
                                plan.chunk_shift, plan.bins, counts, records, grad_codebook);
             launched = true;

@@ -404,7 +404,7 @@ class _SlotFit:
     memory, never waited for); a later launch picks the result up once the copy has landed: a level whose fullest slot stayed
     below its capacity gets slots of HEADROOM x that fill (as a fraction of the unscaled capacity, which follows the sample
     count), a level that filled a slot completely - it overflowed into the atomic path - gets GROW x its previous size."""
-    CHECK_EVERY, HEADROOM, GROW, FLOOR, ADOPT_AFTER = 32, 1.35, 1.6, 0.02, 8
+    CHECK_EVERY, HEADROOM, GROW, FLOOR, ADOPT_AFTER = 32, float(os.environ.get("WISP_HG_SLOT_HEADROOM", "1.2")), 1.6, 0.02, 8
 
     def __init__(self, device, dim, dt, F, res, bitwidth, zero_from_col):
         self.key = (dim, dt, F, res, bitwidth, zero_from_col)

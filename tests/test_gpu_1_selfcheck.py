@@ -107,12 +107,13 @@ def test_hashgrid_backward_scratch_follows_what_the_launches_fill(monkeypatch):
     fitted = int(C.lib.wisp_hashgrid_bwd_workspace_bytes(n, 3, C.BF16, 2, arr, 16, 19, ctypes.cast(scales, ctypes.c_void_p)))
     ws = C._bwd_ws[(torch.device(DEV), C._stream().value)]
     written = 8 * sum(st["records"])                          # compact records: 8 bytes each
-    # Capacity follows the FULLEST slot of a level (x 1.35), the bytes written are the sum over all slots: on the dense levels a
-    # bucket is a slab of space and the slabs the scene occupies receive several times the average, so the fitted scratch lands
-    # at ~5.5 x the records here, down from 7.7 x: the hashed levels shrink to about half, the dense ones hardly.  (Per-bucket
-    # capacities would close the rest; the <= 2 x the review asks for is not reached with one capacity per level.)
-    assert written > (100 << 20) and st["workspace_bytes"] <= 7 * written, (st["workspace_bytes"], written)
-    assert fitted <= 7 * written and fitted < 0.85 * full and ws.numel() <= 3 * fitted + (64 << 20), (fitted, full, ws.numel())
+    # Capacity follows the FULLEST slot of a level (x 1.2), the bytes written are the sum over all slots.  On dense levels a bucket
+    # of consecutive rows is a slab of space and the slabs a workgroup's rays cross receive several times the average: those
+    # levels deal strips of 32 rows to their buckets instead (BinLevels::strip_magic, round 5), which brought this shape from
+    # 5.5 x the records to 4 x (the bench's 2^21-sample step, with fuller slots: 4.6 x -> 3.1 x).  What remains is the clumped-
+    # Poisson spread of 100-250 records per slot on the hashed levels (fullest 1.9-2.6 x the mean).
+    assert written > (100 << 20) and st["workspace_bytes"] <= 5 * written, (st["workspace_bytes"], written)
+    assert fitted <= 5 * written and fitted < 0.7 * full and ws.numel() <= 3 * fitted + (64 << 20), (fitted, full, ws.numel())
     ref = first.double()
     assert float((got.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())          # same gradient before and after the fit
     print(f"scratch: unscaled {full / 2**30:.2f} GiB -> fitted {fitted / 2**30:.2f} GiB for {written / 2**30:.2f} GiB of records; "
