@@ -1357,6 +1357,8 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         // ~64 reduce workgroups per coarse level (atomic flush).  (Round 5 tried ONE owner per bucket from 16 buckets up, so that
         // the 50^3 and 64^3 levels could take the optimizer's step in the flush too: their single workgroups walk 512 nearly empty
         // slots each and became the launch's long pole - 0.41 -> 0.49 ms; profiles/r05_ab_single_owner_mid_levels.txt.)
+        // (64 is the measured optimum at 2^21 samples: 16 / 32 / 128 / 256 workgroups per coarse level run the pair in 0.445 / 0.431 /
+        //  0.426 / 0.456 ms against 0.416)
         int splits = (int)(64 / chunks);
         if (splits > p.ntiles) splits = (int)p.ntiles;
         p.bins.splits[li] = splits < 1 ? 1 : splits;
