@@ -373,6 +373,14 @@ def _device(local):
     return torch.device("cuda", local)
 
 
+def _bind_near_gpu(local):
+    """this rank's host threads onto the CPUs of its GPU's NUMA node (wisp._C.bind_host_near_device) -> what was bound, or None"""
+    if not torch.cuda.is_available():
+        return None
+    import wisp._C as C
+    return C.bind_host_near_device(local)
+
+
 def _device_count():
     return torch.cuda.device_count() if torch.cuda.is_available() else 0
 
@@ -471,6 +479,7 @@ def main(argv=None):
         return _self_launch(args, argv)                    # N ranks were asked for and nobody started them: do it here
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, launched by torch.distributed.run"
     dev = _device(local)
+    host_binding = _bind_near_gpu(local)
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         _init_dist(dev)
@@ -723,6 +732,7 @@ def main(argv=None):
                        "occupied_cells": cells_now, "true_occupied_cells": int(true_cells.shape[0]),
                        "prunes_inside_timed_steps": prunes_in},
             "samples_per_sec": total_samples_all / elapsed,
+            "host_binding": host_binding or "none (no NUMA topology to bind to, or WISP_NUMA_BIND=0)",
             "prune": {"ms": prune_ms, "every_steps": trainer.prune_every, "value_without_any_prune":
                       rays_total / max(elapsed - prunes_in * prune_ms * 1e-3, 1e-9)},
             "reference_regime": {"target_samples_per_step": args.ref_target_samples, "rays_per_step_per_gpu": R_ref,

@@ -985,6 +985,42 @@ def raymarch_ray_count(occ_bits, octree, exsum, origins, dirs, near, far, num_sa
 # stream would drain EVERYTHING queued there (with the trainer's one-batch look-ahead: the whole previous step) and leave
 # the GPU idle while the host wakes up and launches again (measured: 43 us per step).  Instead the total is copied to
 # pinned memory on a side stream that only waits for the scan; raymarch_ray_finish() waits for that copy alone.
+def _parse_cpulist(text):
+    """'64-127,192-255' (sysfs cpulist) -> set of CPU numbers"""
+    cpus = set()
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_host_near_device(index=None):
+    """Pin this process's host threads to the CPUs of the GPU's NUMA node (one process per GPU: call it once, before the first
+    launch).  An MI355X node has two CPU sockets; a process the scheduler parks on the far one pays the socket hop on every doorbell,
+    event and read-back - the GPU-paced fused step does not notice, a host-bound loop does: the unchanged reference trainer's step
+    (bench.py's dropin_regime) measured 0.9-1.2 ms or 1.8-2.1 ms per iteration from one run to the next inside one box until it was
+    bound.  -> dict(numa_node, cpus) or None when there is nothing to bind to (no sysfs topology, one node, affinity already narrower).
+    WISP_NUMA_BIND=0 switches it off."""
+    if os.environ.get("WISP_NUMA_BIND", "1") == "0" or not torch.cuda.is_available() or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        p = torch.cuda.get_device_properties(torch.cuda.current_device() if index is None else index)
+        base = "/sys/bus/pci/devices/%04x:%02x:%02x.0/" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        with open(base + "numa_node") as f:
+            node = int(f.read().strip())
+        with open(base + "local_cpulist") as f:
+            text = f.read().strip()
+        allowed = os.sched_getaffinity(0)
+        cpus = _parse_cpulist(text) & allowed
+        if node < 0 or not cpus or cpus == allowed:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return {"numa_node": node, "cpus": len(cpus)}
+    except (OSError, ValueError, AttributeError):
+        return None
+
+
 _reader_pool = {}                       # device index -> idle HostReader handles (wisp_host_reader_*: csrc/misc.hip)
 
 

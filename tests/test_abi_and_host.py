@@ -781,3 +781,32 @@ def test_regime_stats_cuts_a_kernel_trace_into_one_table_per_bench_regime(tmp_pa
         w.writeheader(); w.writerows(rows2)
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "trace_gaps.py"), str(d2)], capture_output=True, text=True)
     assert r2.returncode == 0 and "wall 610.0 us  busy 593.0 us  idle 17.0 us" in r2.stdout, r2.stdout[:400]
+
+
+def test_host_threads_are_bound_to_the_gpus_numa_node(monkeypatch):
+    """wisp._C.bind_host_near_device: the sysfs cpulist of the GPU's PCI function becomes this process's affinity (one process per
+    GPU on a two-socket node); nothing happens without a topology, with one node, or with WISP_NUMA_BIND=0."""
+    import builtins
+    import io
+    import wisp._C as C
+    assert C._parse_cpulist("64-127,192-255\n") == set(range(64, 128)) | set(range(192, 256))
+    assert C._parse_cpulist("3") == {3} and C._parse_cpulist("") == set()
+    assert C.bind_host_near_device(0) is None                      # no GPU here: nothing to bind to
+    props = types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0xf4, pci_device_id=0)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: props)
+    files = {"/sys/bus/pci/devices/0000:f4:00.0/numa_node": "1\n", "/sys/bus/pci/devices/0000:f4:00.0/local_cpulist": "2-3,6\n"}
+    real_open = builtins.open
+    monkeypatch.setattr(builtins, "open", lambda path, *a, **k: io.StringIO(files[path]) if path in files else real_open(path, *a, **k))
+    bound = []
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: bound.append(set(cpus)))
+    assert C.bind_host_near_device(0) == {"numa_node": 1, "cpus": 3} and bound == [{2, 3, 6}]
+    monkeypatch.setenv("WISP_NUMA_BIND", "0")
+    assert C.bind_host_near_device(0) is None and len(bound) == 1
+    monkeypatch.delenv("WISP_NUMA_BIND")
+    files["/sys/bus/pci/devices/0000:f4:00.0/numa_node"] = "-1\n"           # a VM without topology
+    assert C.bind_host_near_device(0) is None and len(bound) == 1
+    files["/sys/bus/pci/devices/0000:f4:00.0/numa_node"] = "0\n"
+    files["/sys/bus/pci/devices/0000:f4:00.0/local_cpulist"] = "0-7\n"       # one node: the affinity already is the list
+    assert C.bind_host_near_device(0) is None and len(bound) == 1
