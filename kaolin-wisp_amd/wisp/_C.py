@@ -403,7 +403,9 @@ class _SlotFit:
     Every CHECK_EVERY-th launch of a shape is followed by wisp_hashgrid_bwd_slot_stats (one tiny kernel + a 64-byte copy to pinned
     memory, never waited for); a later launch picks the result up once the copy has landed: a level whose fullest slot stayed
     below its capacity gets slots of HEADROOM x that fill (as a fraction of the unscaled capacity, which follows the sample
-    count), a level that filled a slot completely - it overflowed into the atomic path - gets GROW x its previous size."""
+    count), a level that filled a slot completely - it overflowed into the atomic path - gets GROW x its previous size.
+    HEADROOM is 1.2 (WISP_HG_SLOT_HEADROOM): the fullest slot of a level moves by 1-5 % from launch to launch at a fixed batch size
+    (profiles/r05_ab_scratch_geometry.txt); it was 1.35 until round 5."""
     CHECK_EVERY, HEADROOM, GROW, FLOOR, ADOPT_AFTER = 32, float(os.environ.get("WISP_HG_SLOT_HEADROOM", "1.2")), 1.6, 0.02, 8
 
     def __init__(self, device, dim, dt, F, res, bitwidth, zero_from_col):
