@@ -257,9 +257,26 @@ def dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev):
     # the timed iterations then contain the steady-state prunes, one per hundred
     for _ in range(102 + min(args.warmup, 10)):
         tr.iterate()
+    # The trainer's first iterations import half of torch's optional machinery (torch.optim -> sympy ...): ~170 K long-lived Python
+    # objects, after which the cyclic collector owes a full collection - 60-90 ms, i.e. +0.6-0.9 ms per iteration when it lands in
+    # a 100-iteration window (it did in about half of the runs: the regime's "slow mode" until round 5,
+    # profiles/r05_dropin_gc_pause.txt).  A training run pays it once; its set-up garbage is collected here and what is alive now
+    # moves to the permanent generation (what an app does with gc.freeze() after building its trainer).  The collector stays ON:
+    # every collection inside the window is counted and timed.
+    import gc
+    gc.collect()
+    gc.freeze()
+    pauses, t_gc = [], [0.0]
+
+    def on_gc(phase, info):
+        if phase == "start":
+            t_gc[0] = time.perf_counter()
+        else:
+            pauses.append(time.perf_counter() - t_gc[0])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    gc.callbacks.append(on_gc)
     t0 = time.perf_counter()
     rays = samples = 0
     for _ in range(args.dropin_steps):
@@ -270,6 +287,8 @@ def dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.callbacks.remove(on_gc)
+    gc.unfreeze()
     if world > 1:
         t = torch.tensor([dt, rays, samples], device=dev, dtype=torch.float64)
         dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
@@ -278,6 +297,8 @@ def dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev):
     return {"value": rays / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / args.dropin_steps, "steps": args.dropin_steps,
             "rays_per_step_per_gpu": rays / args.dropin_steps / world, "samples_per_step_per_gpu": samples / args.dropin_steps / world,
             "loss_scale_at_end": float(tr.scaler.get_scale()), "dtype": "fp16 autocast + GradScaler (tables fp16, decoder bf16 MFMA)",
+            "python_gc_inside_the_window": {"collections": len(pauses), "pause_ms": 1e3 * sum(pauses), "longest_ms": 1e3 * max(pauses or [0.0]),
+                                            "note": "gc.collect() + gc.freeze() after the warm-up iterations; the collector runs during the window"},
             "note": "wisp.trainers.MultiviewTrainer.iterate(): the reference trainer's own step semantics (multiview_trainer.py:111-180, "
                     "base_trainer.py:205-246,316-342) - autograd over the pipeline (PackedRFTracer.trace differentiates lookup + decoder + "
                     "compositing as one node), torch.optim.AdamW, GradScaler, MultiStepLR, SampleRays, loss .item() read-backs, the prune "

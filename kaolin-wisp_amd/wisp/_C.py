@@ -1001,8 +1001,7 @@ def bind_host_near_device(index=None):
     """Pin this process's host threads to the CPUs of the GPU's NUMA node (one process per GPU: call it once, before the first
     launch).  An MI355X node has two CPU sockets; a process the scheduler parks on the far one pays the socket hop on every doorbell,
     event and read-back - the GPU-paced fused step does not notice, a host-bound loop does: the unchanged reference trainer's step
-    (bench.py's dropin_regime) measured 0.9-1.2 ms or 1.8-2.1 ms per iteration from one run to the next inside one box until it was
-    bound.  -> dict(numa_node, cpus) or None when there is nothing to bind to (no sysfs topology, one node, affinity already narrower).
+    (bench.py's dropin_regime) ran 8 % faster on the mean of ten alternating runs (profiles/r05_numa_binding_dropin.txt).  -> dict(numa_node, cpus) or None when there is nothing to bind to (no sysfs topology, one node, affinity already narrower).
     WISP_NUMA_BIND=0 switches it off."""
     if os.environ.get("WISP_NUMA_BIND", "1") == "0" or not torch.cuda.is_available() or not hasattr(os, "sched_setaffinity"):
         return None
