@@ -810,3 +810,40 @@ def test_host_threads_are_bound_to_the_gpus_numa_node(monkeypatch):
     files["/sys/bus/pci/devices/0000:f4:00.0/numa_node"] = "0\n"
     files["/sys/bus/pci/devices/0000:f4:00.0/local_cpulist"] = "0-7\n"       # one node: the affinity already is the list
     assert C.bind_host_near_device(0) is None and len(bound) == 1
+
+
+def test_strip_dealt_buckets_are_a_bijection_with_exact_reciprocal_division():
+    """csrc/hashgrid.hip bucket_of / bucket_row (dense levels of the binned hash-grid backward deal strips of 32 rows to their
+    buckets): restated in numpy with the kernel's arithmetic - round = umulhi(strip, ceil(2^32 / buckets)) must equal strip //
+    buckets for every strip the plan admits (< 2^18) and every bucket count (<= 1024), every row must land in a bucket below the
+    count at an entry below the bucket's 8192 (or 16384 / F) entries, and bucket_row must invert it."""
+    rng = np.random.default_rng(5)
+    for buckets in [2, 3, 5, 7, 16, 32, 63, 64, 100, 511, 1000, 1024]:
+        magic = ((1 << 32) + buckets - 1) // buckets
+        strips = np.concatenate([np.arange(0, min(1 << 18, 70000)), rng.integers(0, 1 << 18, 200000), [(1 << 18) - 1]]).astype(np.uint64)
+        assert np.array_equal((strips * np.uint64(magic)) >> np.uint64(32), strips // np.uint64(buckets)), buckets
+    for csize, entries in [(8192, 25 ** 3), (8192, 32 ** 3), (8192, 80 ** 3), (8192, 50 ** 3), (4096, 20 ** 3), (8192, 8193), (8192, 2 * 8192),
+                           (2048, 101 ** 2), (8192, (1 << 23) - 77)]:
+        buckets = (entries + csize - 1) // csize
+        assert 2 <= buckets <= 1024
+        magic = ((1 << 32) + buckets - 1) // buckets
+        pw = 1
+        while pw * 2 <= buckets:
+            pw *= 2
+        rot_mask = pw - 1
+        row = np.arange(entries, dtype=np.int64)
+        strip = row >> 5
+        rnd = (strip * magic) >> 32
+        t = strip - rnd * buckets + (rnd & rot_mask)
+        b = np.where(t >= buckets, t - buckets, t)
+        loc = (rnd << 5) | (row & 31)
+        assert b.min() >= 0 and b.max() < buckets and loc.max() < csize, (csize, entries)
+        # the inverse (bucket_row)
+        r2 = loc >> 5
+        rot = r2 & rot_mask
+        r = np.where(b >= rot, b - rot, b + buckets - rot)
+        assert np.array_equal(((r2 * buckets + r) << 5) | (loc & 31), row), (csize, entries)
+        # no two rows share (bucket, entry); the buckets' loads differ by at most one strip round
+        assert np.unique(b * csize + loc).size == entries
+        load = np.bincount(b, minlength=buckets)
+        assert load.max() - load.min() <= 64, (csize, entries, load.max(), load.min())
