@@ -463,14 +463,20 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #ifndef EM_MIN_WAVES
 #define EM_MIN_WAVES 2          // waves per SIMD the emit kernel is register-budgeted for
 #endif
-// Threads of the queue emitter's workgroup (the training shape).  512 = two workgroups per CU.  1024 (ONE per CU, one 64-sample group
-// per wave so that the piece stays EM_TILE samples) halves the number of (bucket, workgroup) slots and makes them twice as full:
-// the fullest slot of a hashed level is 1.6-2.1 x the mean instead of 1.9-2.6 x and the scratch falls from 1.12 to 0.92 GB at 2^21
-// samples - for +7 us on the pair (0.411 -> 0.419 ms, three A/B rounds inside one box: profiles/r05_ab_scratch_geometry.txt).
-// Speed was kept.
+// The queue emitter (the training shape) comes in two widths, two 64-sample groups per wave in both:
+//   EQ_THREADS  (512:  1024-sample pieces, two workgroups per CU) - small launches: at the reference trainer's 2^18 samples the wide
+//                form would leave half of the CUs without a workgroup (0.320 -> 0.335-0.346 ms per step);
+//   EQ_WIDE     (1024: 2048-sample pieces, ONE workgroup per CU)  - launches of at least EQ_WIDE_MIN samples: half as many
+//                (bucket, workgroup) slots, twice as full - the fullest slot of a hashed level is 1.6-2.1 x the mean instead of
+//                1.9-2.6 x, the scratch the capacities add up to falls by a fifth, the reduce kernel walks fuller chunks; same time
+//                for the pair (0.411-0.413 vs 0.409-0.415 ms).  (1024 threads with ONE group per wave - 1024-sample pieces - cost
+//                +7 us: the per-piece set-up of a wave is then paid per 64 samples; profiles/r05_ab_scratch_geometry.txt.)
+//   WISP_HG_EMIT_WIDE=0 keeps the narrow form everywhere.
 #ifndef EQ_THREADS
 #define EQ_THREADS 512
 #endif
+#define EQ_WIDE 1024
+#define EQ_WIDE_MIN ((int64_t)1 << 20)
 #define RD_THREADS 1024
 #define BIN_MAX_CHUNKS 1024
 #ifndef HG_ACC_PLANES
@@ -655,8 +661,8 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
 //     (tail, corner) entry: ceil(tails / 8) passes instead of 8.  LDS instructions of one wave execute in order, so the
 //     hand-over needs no barrier.
 #define EQ_MAX_ROW 16
-template <typename T, int DIM>
-__global__ void __launch_bounds__(EQ_THREADS, EM_MIN_WAVES)
+template <typename T, int DIM, int THREADS>
+__global__ void __launch_bounds__(THREADS, EM_MIN_WAVES)
 hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ grad_feats,
                            const int64_t* __restrict__ first_idx, HashLevels lv, LevelList levels, int num_lods,
                            uint32_t tsize, int tsize_pow2, int zero_from_col, int chunk_shift, BinLevels bins,
@@ -666,7 +672,8 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
     typedef RecordCodec<T, F> Codec;
     static_assert(Codec::COMPACT, "two 16-bit features per level");
     constexpr int RW = Codec::RW;
-    constexpr int GROUPS = EM_TILE / EQ_THREADS;
+    constexpr int GROUPS = 2;                            // 64-sample groups per wave
+    constexpr int TILE = THREADS * GROUPS;               // samples per piece
     constexpr int QROW = 3 * NC + 1;                     // dwords per parked tail
     extern __shared__ __attribute__((aligned(16))) uint32_t em_smem[];
     const int total_ranks = bins.rank_base[levels.n];
@@ -679,15 +686,15 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
     uint32_t* s_queue = em_smem + ((total_ranks + 4) & ~3) + wave * (64 * QROW);
     const uint32_t ntiles = gridDim.x;
     const int64_t total_rows = first_idx[num_lods];
-    for (int b = threadIdx.x; b < total_ranks; b += EQ_THREADS) s_rank[b] = 0;
+    for (int b = threadIdx.x; b < total_ranks; b += THREADS) s_rank[b] = 0;
     __syncthreads();
     // lane -> (tail, corner) of a queue pass
     const uint32_t q_lane = (uint32_t)((lane / NC) * QROW + (lane % NC) * 3);
-    // The grid is capped at what the chip holds at once; a workgroup takes the EM_TILE pieces blockIdx, blockIdx + grid, ...
+    // The grid is capped at what the chip holds at once; a workgroup takes the TILE-sample pieces blockIdx, blockIdx + grid, ...
     // and all of them feed the same slots (the rank counters live on).  No barrier inside: the waves drift freely.
-    const int64_t pieces = (n + EM_TILE - 1) / EM_TILE;
+    const int64_t pieces = (n + TILE - 1) / TILE;
     for (int64_t piece = blockIdx.x; piece < pieces; piece += gridDim.x) {
-        const int64_t tile0 = piece * EM_TILE;
+        const int64_t tile0 = piece * TILE;
         float c[GROUPS][DIM];
         bool live[GROUPS];
         typedef uint32_t row_t __attribute__((ext_vector_type(EQ_MAX_ROW)));     // indexed by the (wave-uniform) level: v_movrels
@@ -784,7 +791,7 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
         const uint32_t cap = bins.cap[li];
         const uint32_t* rank_l = s_rank + bins.rank_base[li];
         uint32_t* __restrict__ cnt_l = counts + bins.cnt_base[li];
-        for (int b = threadIdx.x; b < chunks; b += EQ_THREADS) {
+        for (int b = threadIdx.x; b < chunks; b += THREADS) {
             const uint32_t cn = rank_l[b];
             cnt_l[(size_t)b * ntiles + blockIdx.x] = cn < cap ? cn : cap;
         }
@@ -792,19 +799,19 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
 }
 
 // queue + rank counters
-static inline size_t queue_emitter_lds(int total_ranks, int dim) {
-    return ((size_t)((total_ranks + 4) & ~3) + (size_t)(EQ_THREADS / 64) * 64 * (3 * (1 << dim) + 1)) * 4;
+static inline size_t queue_emitter_lds(int total_ranks, int dim, int threads) {
+    return ((size_t)((total_ranks + 4) & ~3) + (size_t)(threads / 64) * 64 * (3 * (1 << dim) + 1)) * 4;
 }
 // Workgroups of the queue emitter one CU holds at once (registers + LDS; asked from the runtime, once per instance; the
 // half and bf16 instances are the same code).  The rank counters vary a little with the level layout: 1024 is a safe figure.
-template <typename T, int DIM>
+template <typename T, int DIM, int THREADS>
 static int queue_emitter_residency() {
     static const int v = [] {
         int nb = 0;
-        auto eq = hashgrid_bwd_emit_q_kernel<T, DIM>;
-        const size_t lds = queue_emitter_lds(1024, DIM);
+        auto eq = hashgrid_bwd_emit_q_kernel<T, DIM, THREADS>;
+        const size_t lds = queue_emitter_lds(1024, DIM, THREADS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eq, EQ_THREADS, lds) != hipSuccess || nb <= 0) nb = EQ_THREADS >= 1024 ? 1 : 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eq, THREADS, lds) != hipSuccess || nb <= 0) nb = THREADS >= 1024 ? 1 : 2;
         return nb;
     }();
     return v;
@@ -1284,12 +1291,12 @@ static int64_t queue_emitter_grid_cap(int resident_per_cu) {
 }
 
 // bin geometry shared by the workspace query and the launcher
-struct BinPlan { int chunk_shift, max_chunks, max_splits, total_blocks, total_ranks; int64_t ntiles; BinLevels bins; int64_t count_bytes, record_bytes; bool ok;
+struct BinPlan { int chunk_shift, max_chunks, max_splits, total_blocks, total_ranks, emit_threads /* queue emitter width, 0 = generic emitter */; int64_t ntiles; BinLevels bins; int64_t count_bytes, record_bytes; bool ok;
                  uint32_t base_cap[HG_MAX_LODS]; };
 // cap_scale (host, indexed by LEVEL, or nullptr = 1): the caller's measured ratio of what a slot of that level really receives
 // to the no-merge expectation the capacities start from - see wisp_hashgrid_bwd_slot_stats.
 static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels, int feature_dim, int64_t tsize, int dim,
-                        int rec_dwords, int64_t max_emitters = 0, const float* cap_scale = nullptr) {
+                        int rec_dwords, int64_t max_emitters = 0, const float* cap_scale = nullptr, int64_t piece = EM_TILE) {
     BinPlan p{};
     const int corners = 1 << dim;
     int64_t centries = 16384 / feature_dim;               // chunk entries: 64 KiB as fp32, 128 KiB as 64-bit fixed point
@@ -1297,11 +1304,12 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
     // "tile" = what ONE emitting workgroup sends: EM_TILE samples, or (queue emitter) several EM_TILE pieces when the grid is
     // capped at the number of workgroups the chip holds at once - fewer, fuller slots for the reduce kernel to walk
     // (its loads then run with all 64 lanes busy: 200 -> 160 us at 2 M samples)
-    p.ntiles = ceil_div64(n, EM_TILE);
-    int64_t tile_samples = EM_TILE;
+    p.ntiles = ceil_div64(n, piece);
+    p.emit_threads = 0;
+    int64_t tile_samples = piece;
     if (max_emitters > 0 && p.ntiles > max_emitters) {
         const int64_t pieces_per_wg = ceil_div64(p.ntiles, max_emitters);
-        tile_samples = pieces_per_wg * EM_TILE;
+        tile_samples = pieces_per_wg * piece;
         p.ntiles = ceil_div64(p.ntiles, pieces_per_wg);       // same makespan as max_emitters workgroups, no idle slots
     }
     int64_t cnt = 0, rec = 0;
@@ -1326,7 +1334,7 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
         int64_t cap = (tile_samples * corners + chunks - 1) / chunks;
         cap = lv.dense[l] ? cap * 2 : cap + cap / 4;
         if (cap < 128) cap = 128;
-        if (lv.dense[l] && cap > 2048 * (tile_samples / EM_TILE)) cap = 2048 * (tile_samples / EM_TILE);
+        if (lv.dense[l] && cap > 2048 * (tile_samples / EM_TILE)) cap = 2048 * (tile_samples / EM_TILE);       // (2048 per 1024 samples)
         if (cap > tile_samples * corners) cap = tile_samples * corners;
         p.base_cap[li] = (uint32_t)cap;
         if (cap_scale) {
@@ -1380,6 +1388,25 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
     return p;
 }
 
+static bool wide_emitter_enabled() { static const bool v = env_flag("WISP_HG_EMIT_WIDE", true); return v; }
+// THE plan of a backward launch of this shape - used by the launcher, the workspace query and the slot statistics alike: the queue
+// emitter's capped grid for two 16-bit features, in its wide form from EQ_WIDE_MIN samples on
+static BinPlan plan_for(int64_t n, const HashLevels& lv, const LevelList& levels, int coord_dim, int feature_dim, int dtype,
+                        int64_t tsize, int num_lods, const float* cap_scale) {
+    const bool compact = dtype != WISP_F32 && feature_dim == 2;
+    if (compact && queue_emitter_enabled() && num_lods <= EQ_MAX_ROW) {
+        const bool wide = wide_emitter_enabled() && n >= EQ_WIDE_MIN;
+        int resident;
+        if (wide) resident = coord_dim == 3 ? queue_emitter_residency<__hip_bfloat16, 3, EQ_WIDE>() : queue_emitter_residency<__hip_bfloat16, 2, EQ_WIDE>();
+        else resident = coord_dim == 3 ? queue_emitter_residency<__hip_bfloat16, 3, EQ_THREADS>() : queue_emitter_residency<__hip_bfloat16, 2, EQ_THREADS>();
+        const int threads = wide ? EQ_WIDE : EQ_THREADS;
+        BinPlan p = bin_plan(n, lv, levels, feature_dim, tsize, coord_dim, 2, queue_emitter_grid_cap(resident), cap_scale, (int64_t)threads * 2);
+        p.emit_threads = threads;
+        return p;
+    }
+    return bin_plan(n, lv, levels, feature_dim, tsize, coord_dim, compact ? 2 : 1 + feature_dim, 0, cap_scale);
+}
+
 template <typename T, int F, int DIM>
 static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, const int64_t* first_idx,
                       const HashLevels& lv, int num_lods, uint32_t tsize, int zero_from_col, float* grad_codebook,
@@ -1396,13 +1423,7 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     for (int l = 0; l < num_lods; ++l)
         if (l * F < zero_from_col) active.lv[active.n++] = l;
     if (active.n == 0) return 0;
-    bool queue_emitter = false;
-    int64_t max_emitters = 0;
-    if constexpr (RecordCodec<T, F>::COMPACT) {
-        queue_emitter = queue_emitter_enabled() && num_lods <= EQ_MAX_ROW;
-        if (queue_emitter) max_emitters = queue_emitter_grid_cap(queue_emitter_residency<__hip_bfloat16, DIM>());   // (as the workspace query)
-    }
-    const BinPlan plan = bin_plan(n, lv, active, F, (int64_t)tsize, DIM, RecordCodec<T, F>::RW, max_emitters, cap_scale);
+    const BinPlan plan = plan_for(n, lv, active, DIM, F, sizeof(T) == 4 ? WISP_F32 : WISP_BF16, (int64_t)tsize, num_lods, cap_scale);
     // emit kernel LDS: rank counters of every (level, bucket) + the tile's gradient rows
     const size_t em_lds = ((size_t)plan.total_ranks + 1 + (size_t)EM_TILE * ((num_lods * ((F * (int)sizeof(T)) / 4)) | 1)) * 4;
     const bool can_bin = merge && bwd_bin_enabled() && workspace && plan.ok && em_lds <= 150 * 1024 &&
@@ -1421,13 +1442,22 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     uint32_t* records = (uint32_t*)((char*)workspace + plan.count_bytes);
     bool launched = false;
     if constexpr (RecordCodec<T, F>::COMPACT) {
-        if (queue_emitter) {
-            const size_t q_lds = queue_emitter_lds(plan.total_ranks, DIM);
-            auto eq = hashgrid_bwd_emit_q_kernel<T, DIM>;
-            if (const hipError_t e = WISP_ALLOW_LDS(eq, q_lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
-            hipLaunchKernelGGL(eq, dim3((unsigned)plan.ntiles), dim3(EQ_THREADS), q_lds, s,
-                               coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
-                               plan.chunk_shift, plan.bins, counts, records, grad_codebook);
+        if (plan.emit_threads != 0) {
+            const size_t q_lds = queue_emitter_lds(plan.total_ranks, DIM, plan.emit_threads);
+            // (one WISP_ALLOW_LDS per kernel instance: the grant is remembered per call site)
+            if (plan.emit_threads == EQ_WIDE) {
+                auto eq = hashgrid_bwd_emit_q_kernel<T, DIM, EQ_WIDE>;
+                if (const hipError_t e = WISP_ALLOW_LDS(eq, q_lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
+                hipLaunchKernelGGL(eq, dim3((unsigned)plan.ntiles), dim3(EQ_WIDE), q_lds, s,
+                                   coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
+                                   plan.chunk_shift, plan.bins, counts, records, grad_codebook);
+            } else {
+                auto eq = hashgrid_bwd_emit_q_kernel<T, DIM, EQ_THREADS>;
+                if (const hipError_t e = WISP_ALLOW_LDS(eq, q_lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
+                hipLaunchKernelGGL(eq, dim3((unsigned)plan.ntiles), dim3(EQ_THREADS), q_lds, s,
+                                   coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
+                                   plan.chunk_shift, plan.bins, counts, records, grad_codebook);
+            }
             launched = true;
         }
     }
@@ -1818,18 +1848,6 @@ extern "C" int wisp_hashgrid_cells(const float* coords, int64_t n, int coord_dim
                            (uint32_t)tsize, pow2, cell, frac, corner_idx);
     WISP_CHECK_LAUNCH();
     return WISP_OK;
-}
-
-// which plan a backward launch of this shape uses (mirrors launch_bwd): the queue emitter's capped grid for two 16-bit features
-static BinPlan plan_for(int64_t n, const HashLevels& lv, const LevelList& levels, int coord_dim, int feature_dim, int dtype,
-                        int64_t tsize, int num_lods, const float* cap_scale) {
-    const bool compact = dtype != WISP_F32 && feature_dim == 2;
-    int64_t max_emitters = 0;
-    if (compact && queue_emitter_enabled() && num_lods <= EQ_MAX_ROW) {
-        const int resident = coord_dim == 3 ? queue_emitter_residency<__hip_bfloat16, 3>() : queue_emitter_residency<__hip_bfloat16, 2>();
-        max_emitters = queue_emitter_grid_cap(resident);
-    }
-    return bin_plan(n, lv, levels, feature_dim, tsize, coord_dim, compact ? 2 : 1 + feature_dim, max_emitters, cap_scale);
 }
 
 extern "C" int64_t wisp_hashgrid_bwd_workspace_bytes(int64_t n, int coord_dim, int dtype, int feature_dim,

@@ -33,8 +33,11 @@ def test_every_code_object_is_read(kern):
 def test_flagship_step_kernels_keep_their_occupancy(kern, dtype):
     """nerf_hash.yaml, 16-bit tables (the bench's default): 512-thread workgroups are 2 waves per SIMD each, so <= 128 VGPRs keep two
     of them resident per CU (4 waves / SIMD) - what the queue emitter's capped grid and the decoder's PIN variant are sized for."""
-    for name, v in _pick(kern, "hashgrid_bwd_emit_q_kernel<" + dtype + ", 3>").items():
+    for name, v in _pick(kern, "hashgrid_bwd_emit_q_kernel<" + dtype + ", 3, 512>").items():
         assert v["scratch"] == 0 and v["vgpr"] <= 96 and v["wg"] == 512, (name, v)           # measured: 87
+    # its wide form (launches of >= 2^20 samples): ONE 1024-thread workgroup per CU, i.e. the same 4 waves per SIMD
+    for name, v in _pick(kern, "hashgrid_bwd_emit_q_kernel<" + dtype + ", 3, 1024>").items():
+        assert v["scratch"] == 0 and v["vgpr"] <= 128 and v["wg"] == 1024, (name, v)         # measured: 87
     # forward decoder, hidden 64: <TIO, NARROW=false, PIN=true, CODED=false|true>
     for coded in ("false", "true"):
         for name, v in _pick(kern, "mlp_fwd_kernel<" + dtype + ", false, true, " + coded + ">").items():
