@@ -110,7 +110,7 @@ def test_hashgrid_backward_scratch_follows_what_the_launches_fill(monkeypatch):
     # Capacity follows the FULLEST slot of a level (x 1.2), the bytes written are the sum over all slots.  On dense levels a bucket
     # of consecutive rows is a slab of space and the slabs a workgroup's rays cross receive several times the average: those
     # levels deal strips of 32 rows to their buckets instead (BinLevels::strip_magic, round 5), which brought this shape from
-    # 5.5 x the records to 4 x (the bench's 2^21-sample step, with fuller slots: 4.6 x -> 3.1 x).  What remains is the clumped-
+    # 5.5 x the records to 4 x (the bench's 2^21-sample step, with fuller slots and the wide emitter: 4.6 x -> 2.5 x).  What remains is the clumped-
     # Poisson spread of 100-250 records per slot on the hashed levels (fullest 1.9-2.6 x the mean).
     assert written > (100 << 20) and st["workspace_bytes"] <= 5 * written, (st["workspace_bytes"], written)
     assert fitted <= 5 * written and fitted < 0.7 * full and ws.numel() <= 3 * fitted + (64 << 20), (fitted, full, ws.numel())
