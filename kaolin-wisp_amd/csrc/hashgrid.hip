@@ -468,8 +468,8 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 //                form would leave half of the CUs without a workgroup (0.320 -> 0.335-0.346 ms per step);
 //   EQ_WIDE     (1024: 2048-sample pieces, ONE workgroup per CU)  - launches of at least EQ_WIDE_MIN samples: half as many
 //                (bucket, workgroup) slots, twice as full - the fullest slot of a hashed level is 1.6-2.1 x the mean instead of
-//                1.9-2.6 x, the scratch the capacities add up to falls by a fifth, the reduce kernel walks fuller chunks; same time
-//                for the pair (0.411-0.413 vs 0.409-0.415 ms).  (1024 threads with ONE group per wave - 1024-sample pieces - cost
+//                1.9-2.6 x, the scratch the capacities add up to falls by a fifth (1.14 -> 0.91 GB at 2^21 samples), the reduce
+//                kernel walks fuller chunks: pair 0.417 vs 0.420 ms in alternating runs.  (1024 threads with ONE group per wave - 1024-sample pieces - cost
 //                +7 us: the per-piece set-up of a wave is then paid per 64 samples; profiles/r05_ab_scratch_geometry.txt.)
 //   WISP_HG_EMIT_WIDE=0 keeps the narrow form everywhere.
 #ifndef EQ_THREADS
