@@ -104,7 +104,7 @@ def _latency_roofline(kernels, bytes_per_launch, steps, replay_ms_per_step):
     return out
 
 
-def _nerf_run(args, dev, pipe, trainer, bank, steps, warmup, label, metric, bytes_fn):
+def _nerf_run(args, dev, pipe, trainer, bank, steps, warmup, label, metric, bytes_fn, extra_bytes_fn=None, roofline_extra=None):
     import wisp._C as C
     from wisp.core import Rays
     import synlego
@@ -151,6 +151,16 @@ def _nerf_run(args, dev, pipe, trainer, bank, steps, warmup, label, metric, byte
     kernels = _kernel_table(sink)
     busy_ms, span_ms = _busy_union_ms(sink)
     S = samples / steps
+    roofline = _roofline(kernels, bytes_fn(S, R), psteps)
+    if roofline and roofline.get("bound") == "hbm":
+        roofline.update(roofline_extra or {})
+        extra = (extra_bytes_fn(S, R) if extra_bytes_fn else {}).get(roofline["kernel"], 0)
+        if extra:
+            both = (roofline["algorithmic_bytes_per_launch"] + extra) / (roofline["avg_launch_ms"] * 1e-3) / 1e9
+            roofline["with_fused_optimizer"] = {
+                "optimizer_bytes_per_launch": extra, "achieved": both, "frac": both / HBM_PEAK_GBS,
+                "note": "NOT the roofline figure: backward bytes + what AdamW's step moves for the table rows the reduce workgroups "
+                        "own (parameter + two moments read and written, bf16 copy written: 26 B per element)"}
     with torch.no_grad():
         eo, ed, ergb = bank_o[:16384], bank_d[:16384], bank_rgb[:16384]
         rb = pipe(rays=Rays(eo, ed, dist_min=synlego.NEAR, dist_max=synlego.FAR), channels=["rgb"])
@@ -165,59 +175,99 @@ def _nerf_run(args, dev, pipe, trainer, bank, steps, warmup, label, metric, byte
             "gpu_busy_note": "union of the launch intervals of the event-timed pass / that pass's own span, first launch to last (<= 1 by "
                              "construction; the pair of event markers around every launch is inside the span, so this is a lower bound "
                              "of the untimed-events steps' busy share)",
-            "roofline": _roofline(kernels, bytes_fn(S, R), psteps), "kernels": kernels}
+            "roofline": roofline, "kernels": kernels}
 
 
-def run_v8(args, dev):
+V8_CLOUD_RAYS, V8_LEVEL = 1 << 20, 7            # C4: SynV8 depth point cloud -> OctreeAS.from_pointcloud(level 7)
+VQAD_CLOUD_RAYS, VQAD_LEVEL = 1 << 21, 8        # C5: level-8 octree from the point cloud
+NGLOD_SURFACE_POINTS, NGLOD_LEVEL = 1 << 20, 7  # C3: level-7 octree from SynArmadillo surface samples
+
+
+def v8_scene(dev):
+    """The C4 scene exactly as `--config v8` times it (tests/test_gpu_0_parity.py checks parity on THIS object graph):
+    -> (cloud, blas, grid, nef, pipe)."""
     import synlego
     from wisp.accelstructs import OctreeAS
     from wisp.models import Pipeline
     from wisp.models.grids import HashGrid
     from wisp.models.nefs import NeuralRadianceField
     from wisp.tracers import PackedRFTracer
-    from wisp.trainers import MultiviewTrainStep
     import bench
     torch.manual_seed(0)
-    cloud = synlego.v8_pointcloud(1 << 20, res=400, device=dev)
-    blas = OctreeAS.from_pointcloud(cloud, 7)
+    cloud = synlego.v8_pointcloud(V8_CLOUD_RAYS, res=400, device=dev)
+    blas = OctreeAS.from_pointcloud(cloud, V8_LEVEL)
     grid = HashGrid.from_geometric(blas, **bench.NGP)
     nef = NeuralRadianceField(grid, pos_embedder='none', view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1,
                               bias=True, prune_density_decay=None, prune_min_density=None).to(dev)
     pipe = Pipeline(nef, PackedRFTracer(raymarch_type='voxel', num_steps=16, bg_color=(1.0, 1.0, 1.0)))
-    tr = MultiviewTrainStep(pipe, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, rgb_loss_type='huber', prune_every=-1,
-                            target_sample_size=args.target_samples, enable_amp=args.precision == "bf16")
-    o, d, _ = synlego.ray_bank(1 << 20, res=400, seed=1000, device=dev, with_gt=False)
-    bank = (o, d, synlego.render_gt_white(o, d))
-    b = 2 if tr.enable_amp else 4
-    # (one GPU: the reduce kernel of the backward also runs AdamW for the table rows it owns - parameter and moments read and
-    #  written + the bf16 copy, 26 B per element updated there - see bench.py)
-    bytes_fn = lambda S, R: {"hashgrid_interpolate_bwd": (12 + 32 * b + 2 * 16 * 8 * 2 * b) * S,
-                             "hashgrid_interpolate_bwd_adamw": (12 + 32 * b + 2 * 16 * 8 * 2 * b) * S
-                                                               + getattr(tr, "fused_elements_last", 0) * (24 + (2 if tr.enable_amp else 0)),
-                             "hashgrid_interpolate_fwd": (12 + 16 * 8 * 2 * b + 32 * b) * S,
-                             "raymarch_voxel_emit": 37 * S, "composite_fwd": 25 * S, "composite_bwd": 41 * S}
-    return _nerf_run(args, dev, pipe, tr, bank, args.steps, args.warmup,
-                     f"C4 (one GPU): nerf_hash model over from_pointcloud(level 7) of SynV8 ({int(blas.pyramid[0, 7])} cells), "
-                     "'voxel' 16 samples per cell, white background, 400x400 rays, AdamW",
-                     "training rays/sec, HashGrid NeRF, synthetic V8 (voxel march)", bytes_fn)
+    return cloud, blas, grid, nef, pipe
 
 
-def run_vqad(args, dev):
+def vqad_scene(dev):
+    """The C5 scene exactly as `--config vqad` times it -> (cloud, blas, grid, nef, pipe)."""
     import synlego
     from wisp.accelstructs import OctreeAS
     from wisp.models import Pipeline
     from wisp.models.grids import CodebookOctreeGrid
     from wisp.models.nefs import NeuralRadianceField
     from wisp.tracers import PackedRFTracer
-    from wisp.trainers import MultiviewTrainStep
     torch.manual_seed(0)
-    cloud = synlego.v8_pointcloud(1 << 21, res=400, device=dev)
-    blas = OctreeAS.from_pointcloud(cloud, 8)
+    cloud = synlego.v8_pointcloud(VQAD_CLOUD_RAYS, res=400, device=dev)
+    blas = OctreeAS.from_pointcloud(cloud, VQAD_LEVEL)
     grid = CodebookOctreeGrid(blas, feature_dim=5, num_lods=4, interpolation_type='linear', multiscale_type='sum', feature_std=0.01,
                               feature_bias=0.0, codebook_bitwidth=4)
     nef = NeuralRadianceField(grid, pos_embedder='none', view_embedder='positional', view_multires=4, hidden_dim=64, num_layers=1,
                               bias=False, prune_density_decay=None, prune_min_density=None).to(dev)
     pipe = Pipeline(nef, PackedRFTracer(raymarch_type='voxel', num_steps=16, bg_color=(1.0, 1.0, 1.0)))
+    return cloud, blas, grid, nef, pipe
+
+
+def nglod_scene(dev):
+    """The C3 scene exactly as `--config nglod` times it -> (surface points, blas, grid, nef)."""
+    import synlego
+    from wisp.accelstructs import OctreeAS
+    from wisp.models.grids import OctreeGrid
+    from wisp.models.nefs import NeuralSDF
+    torch.manual_seed(0)
+    surf = synlego.armadillo_surface_points(NGLOD_SURFACE_POINTS, device=dev)
+    blas = OctreeAS.from_pointcloud(surf, NGLOD_LEVEL)
+    grid = OctreeGrid(blas, feature_dim=16, num_lods=6, interpolation_type='linear', multiscale_type='sum', feature_std=0.01)
+    nef = NeuralSDF(grid, pos_embedder='none', position_input=True, hidden_dim=128, num_layers=1).to(dev)
+    return surf, blas, grid, nef
+
+
+def run_v8(args, dev):
+    import synlego
+    import bench
+    from wisp.trainers import MultiviewTrainStep
+    _, blas, grid, nef, pipe = v8_scene(dev)
+    tr = MultiviewTrainStep(pipe, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, rgb_loss_type='huber', prune_every=-1,
+                            target_sample_size=args.target_samples, enable_amp=args.precision == "bf16")
+    o, d, _ = synlego.ray_bank(1 << 20, res=400, seed=1000, device=dev, with_gt=False)
+    bank = (o, d, synlego.render_gt_white(o, d))
+    # Same bookkeeping as the headline (bench.py::work_table): bytes of the levels the kernels PROCESS - the tracer's lod_idx = 15
+    # zeroes the finest level's columns, so 15 of 16 levels are gathered / scattered: 556 / 1036 B per sample, not SURVEY 8(d)'s
+    # nominal 588 / 1100 - and the AdamW step folded into the reduce launch is a separate quantity under its own key
+    # (`with_fused_optimizer`), never part of `achieved` / `frac`.
+    live = grid.num_lods - 1 if grid.multiscale_type == 'cat' else grid.num_lods
+    work = bench.work_table(tr.enable_amp, 64, grid.num_lods, live)
+    fwd_b, bwd_b = work["hashgrid_fwd"][1], work["hashgrid_bwd"][1]
+    bytes_fn = lambda S, R: {"hashgrid_interpolate_bwd": bwd_b * S, "hashgrid_interpolate_bwd_adamw": bwd_b * S,
+                             "hashgrid_interpolate_fwd": fwd_b * S,
+                             "raymarch_voxel_emit": 37 * S, "composite_fwd": 25 * S, "composite_bwd": 41 * S}
+    extra_fn = lambda S, R: {"hashgrid_interpolate_bwd_adamw":
+                             getattr(tr, "fused_elements_last", 0) * (24 + (2 if tr.enable_amp else 0))}
+    return _nerf_run(args, dev, pipe, tr, bank, args.steps, args.warmup,
+                     f"C4 (one GPU): nerf_hash model over from_pointcloud(level 7) of SynV8 ({int(blas.pyramid[0, 7])} cells), "
+                     "'voxel' 16 samples per cell, white background, 400x400 rays, AdamW",
+                     "training rays/sec, HashGrid NeRF, synthetic V8 (voxel march)", bytes_fn, extra_fn,
+                     dict(levels_processed=live, levels_of_the_table=grid.num_lods, work_per_unit=bwd_b))
+
+
+def run_vqad(args, dev):
+    import synlego
+    from wisp.trainers import MultiviewTrainStep
+    _, blas, grid, nef, pipe = vqad_scene(dev)
     tr = MultiviewTrainStep(pipe, lr=1e-3, eps=1e-8, weight_decay=0.0, grid_lr_weight=100.0, rgb_loss_type='l2', prune_every=-1,
                             target_sample_size=args.target_samples, enable_amp=args.precision == "bf16", optimizer='rmsprop')
     o, d, _ = synlego.ray_bank(1 << 20, res=400, seed=1000, device=dev, with_gt=False)
@@ -253,17 +303,10 @@ def run_nglod(args, dev):
     """C3: SDF regression steps (512 coordinates each) + sphere-traced rendering of the trained field."""
     import synlego
     import wisp._C as C
-    from wisp.accelstructs import OctreeAS
     from wisp.core import Rays
-    from wisp.models.grids import OctreeGrid
-    from wisp.models.nefs import NeuralSDF
     from wisp.tracers import PackedSDFTracer
     from wisp.trainers import SDFTrainStep
-    torch.manual_seed(0)
-    surf = synlego.armadillo_surface_points(1 << 20, device=dev)
-    blas = OctreeAS.from_pointcloud(surf, 7)
-    grid = OctreeGrid(blas, feature_dim=16, num_lods=6, interpolation_type='linear', multiscale_type='sum', feature_std=0.01)
-    nef = NeuralSDF(grid, pos_embedder='none', position_input=True, hidden_dim=128, num_layers=1).to(dev)
+    _, blas, grid, nef = nglod_scene(dev)
     tr = SDFTrainStep(nef, lr=1e-3, eps=1e-15, weight_decay=0.0, grid_lr_weight=1.0)
     coords, gts = synlego.armadillo_training_samples(500000, device=dev)
     # keep coordinates inside occupied cells (OctreeSampledSDFDataset samples the octree: every point has features)

@@ -39,11 +39,8 @@ def sentinel_tag(name, grid, calib):
     return k - 1 if k >= 1 and abs(ratio - k) < 0.02 and (k - 1) in TAGS else None
 
 
-def main():
-    root, prefix = sys.argv[1], sys.argv[2]
-    rows = load(root)
-    if not rows:
-        sys.exit("no *kernel_trace.csv under " + root)
+def regime_windows(rows):
+    """{regime name: (start ns, end ns)} from the sentinel launches bench.py brackets every regime with."""
     fills = [r for r in rows if "FillFunctor<double>" in r[2]]
     if len(fills) < 2:
         sys.exit("no sentinel launches found: run bench.py with WISP_BENCH_SENTINELS=1")
@@ -60,6 +57,15 @@ def main():
             open_at[tag] = e
     if not windows:
         sys.exit("sentinel launches did not pair up")
+    return windows
+
+
+def main():
+    root, prefix = sys.argv[1], sys.argv[2]
+    rows = load(root)
+    if not rows:
+        sys.exit("no *kernel_trace.csv under " + root)
+    windows = regime_windows(rows)
     for name, (lo, hi) in windows.items():
         per = collections.defaultdict(list)
         for s, e, kn, grid, wg in rows:

@@ -10,6 +10,8 @@ python scripts/regime_stats.py /tmp/prof_regime $OUT/${TAG} | tee $OUT/${TAG}_re
 # rocprofv3's own --stats table of the whole command (all regimes averaged together: the per-regime tables above are the ones to read)
 find /tmp/prof_regime -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_whole_command_kernel_stats.csv \;
 find /tmp/prof_regime -name "*marker_api_trace.csv" -exec sh -c 'head -40 "$1" > '"$OUT/${TAG}"'_marker_trace_head.csv; wc -l "$1"' _ {} \;
-python scripts/trace_gaps.py /tmp/prof_regime hashgrid_fwd 100 > $OUT/${TAG}_step_timeline_2p21.txt 2>&1; head -22 $OUT/${TAG}_step_timeline_2p21.txt
-python scripts/trace_gaps.py /tmp/prof_regime > $OUT/${TAG}_step_timeline_2p18.txt 2>&1; head -6 $OUT/${TAG}_step_timeline_2p18.txt
+# one timeline per regime, each cut from that regime's own sentinel bracket
+python scripts/trace_gaps.py /tmp/prof_regime hashgrid_fwd 0 headline > $OUT/${TAG}_step_timeline_2p21.txt 2>&1; head -22 $OUT/${TAG}_step_timeline_2p21.txt
+python scripts/trace_gaps.py /tmp/prof_regime hashgrid_fwd 0 reference_regime > $OUT/${TAG}_step_timeline_2p18.txt 2>&1; head -8 $OUT/${TAG}_step_timeline_2p18.txt
+python scripts/trace_gaps.py /tmp/prof_regime hashgrid_fwd 0 dropin_regime > $OUT/${TAG}_step_timeline_dropin.txt 2>&1; head -8 $OUT/${TAG}_step_timeline_dropin.txt
 tail -1 $OUT/${TAG}_regime_prof.log | cut -c1-300

@@ -1,5 +1,8 @@
 """Idle time between kernels of the steady-state training step, from a rocprofv3 --kernel-trace CSV.
-usage: python scripts/trace_gaps.py <dir with *_kernel_trace.csv> [marker kernel substring = hashgrid_fwd] [min marker us]
+usage: python scripts/trace_gaps.py <dir with *_kernel_trace.csv> [marker kernel substring = hashgrid_fwd] [min marker us] [regime]
+`regime` (headline | reference_regime | dropin_regime) keeps only the launches between that regime's sentinel launches
+(WISP_BENCH_SENTINELS=1; scripts/regime_stats.py) - without it the LAST steps of the command are taken, whatever regime ran last
+(that is how the drop-in loop's steps were once filed as the 2^18 regime's).
 Steps are delimited by the marker kernel; the last 5 complete steps are summarised: busy time, idle time and the idle
 time attributed to the kernel that FOLLOWS each gap (the launch that arrived late).  With a minimum marker duration only
 steps whose marker kernel ran at least that long count (bench.py times the 2^21 regime first and the 2^18 regime last:
@@ -15,6 +18,14 @@ for f in files:
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
+regime = sys.argv[4] if len(sys.argv) > 4 else None
+if regime:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import regime_stats
+    full = regime_stats.load(root)
+    lo, hi = regime_stats.regime_windows(full)[regime]
+    rows = [r for r in rows if r[0] >= lo and r[1] <= hi and "FillFunctor<double>" not in r[2]]
+    print(f"regime {regime}: {len(rows)} launches between its sentinels")
 min_ns = float(sys.argv[3]) * 1e3 if len(sys.argv) > 3 else 0.0
 marks = [i for i, r in enumerate(rows) if marker in r[2]]
 if len(marks) < 7:
