@@ -5,6 +5,7 @@
 // parameter buffer - 16 B read + 12 B written per parameter (+4 B when the gradient is zeroed in the same
 // pass), against ~28 B/param/step for the unfused optimizer plus a separate zero_grad memset.
 #include "wisp_common.h"
+#include <mutex>
 
 thread_local char g_wisp_err[512] = "";
 
@@ -333,13 +334,19 @@ struct HostReader {
     int device;
 };
 static hipStream_t g_reader_stream[64] = {nullptr};
+static std::mutex g_reader_stream_lock;       // ctypes calls run without the GIL: two threads may create their first reader at once
 
+// The reader binds the side stream of the device that is CURRENT here; the caller makes that the device of the tensors it will
+// read (wisp/_C.py::_read_total_async switches devices around this call when they differ).
 extern "C" void* wisp_host_reader_create(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     HostReader* r = new HostReader{nullptr, nullptr, nullptr, nullptr, dev};
-    if (!g_reader_stream[dev] && hipStreamCreateWithFlags(&g_reader_stream[dev], hipStreamNonBlocking) != hipSuccess) { delete r; return nullptr; }
-    r->side = g_reader_stream[dev];
+    {
+        std::lock_guard<std::mutex> hold(g_reader_stream_lock);
+        if (!g_reader_stream[dev] && hipStreamCreateWithFlags(&g_reader_stream[dev], hipStreamNonBlocking) != hipSuccess) { delete r; return nullptr; }
+        r->side = g_reader_stream[dev];
+    }
     if (hipHostMalloc((void**)&r->host, sizeof(int64_t), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&r->ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&r->done, hipEventDisableTiming) != hipSuccess) {

@@ -450,6 +450,9 @@ codebook_grad_finalize_kernel(SgLods ml, int lod_begin, int lod_end, int K, int 
 #pragma unroll
             for (int k = 0; k < KR; ++k) if (k < K) { e[k] = expf(x[k] - mx); denom += e[k]; }
             inv = 1.0f / denom;
+            // argmax of the softmax VALUES, first index on ties (codebook_softmax_pick, wisp_common.h), on the registers at hand
+#pragma unroll
+            for (int k = KR - 1; k >= 0; --k) if (k < best && e[k] * inv == inv) best = k;
             float dot = 0.0f;
 #pragma unroll
             for (int k = 0; k < KR; ++k)
@@ -474,6 +477,7 @@ codebook_grad_finalize_kernel(SgLods ml, int lod_begin, int lod_end, int K, int 
             float denom = 0.0f;
             for (int k = 0; k < K; ++k) denom += expf(lrow[k] - mx);
             inv = 1.0f / denom;
+            best = codebook_softmax_pick(lrow, best, mx, inv);
             float dot = 0.0f;
             for (int k = 0; k < K; ++k) {
                 float dk = 0.0f;

@@ -284,6 +284,7 @@ codebook_trilinear_fwd_kernel(const float* __restrict__ coords, const I* __restr
                 for (int k = 0; k < K; ++k) denom += expf(row[k] - mx);
                 const float pb = 1.0f / denom;                    // softmax probability of the argmax
                 scale = (1.0f - pb) + pb;
+                best = codebook_softmax_pick(row, best, mx, pb);
             }
             const float* drow = dictionary + (int64_t)best * F;
             for (int f = 0; f < F; ++f) acc[f] += drow[f] * scale * w[j];
@@ -333,6 +334,7 @@ codebook_decode_rows_kernel(const float* __restrict__ logits, const float* __res
         for (int k = 0; k < K; ++k) denom += expf(row[k] - mx);
         const float pb = 1.0f / denom;                    // softmax probability of the argmax
         scale = (1.0f - pb) + pb;
+        best = codebook_softmax_pick(row, best, mx, pb);
     }
     const float* drow = dictionary + (int64_t)best * F;
     for (int f = 0; f < F; ++f) decoded[r * F + f] = drow[f] * scale;

@@ -105,3 +105,19 @@ static __host__ __device__ __forceinline__ float wisp_uniform01(uint64_t seed, u
 static __host__ __device__ __forceinline__ uint32_t wisp_cell_bit(uint32_t x, uint32_t y, uint32_t z, int level) {
     return x | (y << level) | (z << (2 * level));
 }
+
+// CodebookOctreeGrid._index_features in TRAINING mode (codebook_grid.py:116-121) takes `y_soft.max(-1)[1]`: the argmax of the
+// SOFTMAX VALUES, first index on ties (torch.max's documented rule) - not of the logits.  The two differ whenever an earlier logit
+// lies so close below the maximum that exp(x - max) rounds to 1.0f (a gap under 2^-25: any exponential accurate to an ulp returns
+// exactly 1 there), because then both entries carry the same softmax value and the EARLIER one wins.  With nerf_codebook.yaml's
+// initialisation (logits ~ N(0, 0.01^2), 16 per row) that is ~1 row in 20 000 - found by the bench-shape parity test of round 6.
+// logit_best = first index of the largest logit, mx = that logit, inv = 1 / sum exp(x - mx)  ->  the reference's index.
+// (Evaluation mode indexes by torch.max(logits): logit_best itself.)
+static __device__ __forceinline__ int codebook_softmax_pick(const float* __restrict__ row, int logit_best, float mx, float inv) {
+    int best = logit_best;
+    for (int k = logit_best - 1; k >= 0; --k) {
+        const float d = row[k] - mx;
+        if (d > -2.4e-7f && expf(d) * inv == inv) best = k;      // (the cheap bound first: 2^-22, anything below cannot round to 1)
+    }
+    return best;
+}

@@ -1025,28 +1025,64 @@ def bind_host_near_device(index=None):
 _reader_pool = {}                       # device index -> idle HostReader handles (wisp_host_reader_*: csrc/misc.hip)
 
 
+class _PendingRead:
+    """One issued read-back: owns a HostReader handle until its value is taken - or until the march state holding it is dropped
+    (a prune, new rays, an exception between count and finish), in which case the finaliser waits for the 8-byte copy and hands
+    the reader back to its device's pool instead of leaking a pinned word and two events."""
+    __slots__ = ("dev", "reader")
+
+    def __init__(self, dev, reader):
+        self.dev, self.reader = dev, reader
+
+    def take(self):
+        reader, self.reader = self.reader, None
+        if reader is None:
+            raise RuntimeError("read-back already taken")
+        value = ctypes.c_int64(0)
+        try:
+            _check(lib.wisp_host_reader_wait(reader, ctypes.byref(value)), "host_reader_wait")
+        finally:
+            _reader_pool.setdefault(self.dev, []).append(reader)      # (the handle stays valid after a failed wait)
+        return int(value.value)
+
+    def __del__(self):
+        reader, self.reader = self.reader, None
+        if reader is None:
+            return
+        try:
+            value = ctypes.c_int64(0)
+            lib.wisp_host_reader_wait(reader, ctypes.byref(value))       # the copy still targets the reader's pinned word
+            _reader_pool.setdefault(self.dev, []).append(reader)
+        except Exception:                                                # interpreter shutdown: the library may be gone
+            pass
+
+
 def _read_total_async(st):
     """Issue the read-back of offsets[-1] (the packed sample count): two C calls - event on the compute stream, side stream waits,
     8-byte copy to pinned memory, event.  (Five torch calls until round 5: 25 us of host time per step.)"""
     offsets = st["offsets"]
-    dev = offsets.device.index if offsets.device.index is not None else torch.cuda.current_device()
+    cur = torch.cuda.current_device()
+    dev = offsets.device.index if offsets.device.index is not None else cur
     pool = _reader_pool.setdefault(dev, [])
-    reader = pool.pop() if pool else lib.wisp_host_reader_create()
+    if pool:
+        reader = pool.pop()
+    elif dev == cur:
+        reader = lib.wisp_host_reader_create()
+    else:                               # a reader binds the side stream of the device current at creation: make that the tensor's
+        with torch.cuda.device(dev):
+            reader = lib.wisp_host_reader_create()
     if not reader:
         raise RuntimeError(f"wisp_host_reader_create failed: {last_error()}")
+    pending = _PendingRead(dev, reader)                                  # from here on the handle cannot leak
     _check(lib.wisp_host_reader_issue(reader, c_vp(offsets.data_ptr() + 8 * (offsets.numel() - 1)), _stream()), "host_reader_issue")
-    st["total_reader"] = (dev, reader)
+    st["total_reader"] = pending
 
 
 def _total(st):
     pending = st.pop("total_reader", None)
     if pending is None:
         return int(st["offsets"][-1].item())
-    dev, reader = pending
-    value = ctypes.c_int64(0)
-    _check(lib.wisp_host_reader_wait(reader, ctypes.byref(value)), "host_reader_wait")
-    _reader_pool[dev].append(reader)
-    return int(value.value)
+    return pending.take()
 
 
 def raymarch_ray_finish(st, with_dirs=False):

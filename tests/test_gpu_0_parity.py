@@ -1676,7 +1676,7 @@ def test_c4_shape_parity_v8_pointcloud_octree_voxel16():
     e_rgb = float((rb.rgb.cpu() - wt["rgb"]).abs().max())
     e_a = float((rb.alpha.cpu().reshape(-1) - wt["alpha"].reshape(-1)).abs().max())
     assert e_rgb <= 1e-4 and e_a <= 1e-4, (e_rgb, e_a)
-    assert float(wt["alpha"].max()) > 0.5 and float(wt["alpha"].min()) < 0.05            # (both hit and background rays in the sample)
+    assert float(wt["alpha"].max()) > 0.2 and float(wt["alpha"].min()) == 0.0             # (rays through cells and rays that miss them all)
     # ---- the bf16 training path at full batch
     from wisp.ops.nerf_mlp import fused_nerf_decoder
     table16 = grid.codebook.feats.detach().to(torch.bfloat16)
@@ -1731,7 +1731,7 @@ def test_c5_shape_parity_vqad_codebook_level8():
     pd, pyd = ospc.make_dual(oblas.points, oblas.pyramid)
     tr, _ = ospc.make_trinkets(oblas.points, oblas.pyramid, pd, pyd)
     assert np.array_equal(grid.trinkets.cpu().numpy(), tr) and np.array_equal(grid.pyramid_dual.cpu().numpy(), pyd)
-    assert [int(f.shape[0]) for f in grid.features] == [int(pyd[0, l]) for l in grid.active_lods]
+    assert [int(f.shape[0]) for f in grid.features] == [int(pyd[0, l]) + 1 for l in grid.active_lods]    # (codebook_grid.py:74-77: + 1)
     o, d, _ = synlego.ray_bank(R, res=400, seed=1002, device=DEV, with_gt=False)
     o, d = o.cpu().numpy(), d.cpu().numpy()
     march_level = grid.base_lod                   # OctreeGrid.raymarch samples the COARSEST feature level (octree_grid.py:221-226)
@@ -1761,6 +1761,30 @@ def test_c5_shape_parity_vqad_codebook_level8():
             outs.append(ref.detach().float())
         return torch.cat(outs), fc, dc
 
+    def undefined_rows():
+        """Rows of every LOD whose choice no restatement can pin: training mode takes argmax of the SOFTMAX VALUES
+        (codebook_grid.py:118-119), so an earlier logit whose exp(x - max) rounds to 1.0f wins over the maximum.  A gap under 2^-25
+        always does (checked, not excluded: any exponential accurate to an ulp returns 1 there); a gap of 2^-25 .. 2^-22 does or
+        does not depending on the last bit of the exp implementation (torch's CPU softmax, CUDA's and this kernel's expf differ
+        there) - those rows are excluded, with every sample that touches one."""
+        bad = []
+        for f in grid.features:
+            x = f.detach().cpu()
+            mx, am = x.max(-1, keepdim=True)
+            gap = mx - x
+            earlier = torch.arange(x.shape[1])[None] < am
+            bad.append(((gap >= 2.0 ** -25 * 0.999) & (gap <= 2.0 ** -22) & earlier).any(-1))
+        return bad
+
+    def sample_mask(bad, n):
+        ch = torch.from_numpy(ospc.query(oblas.octree, oblas.exsum, coords[:n], grid.active_lods[L - 1], with_parents=True))
+        ok = torch.ones(n, dtype=torch.bool)
+        for i, lv in enumerate(grid.active_lods[:L]):
+            pid = ch[:, lv]
+            rows_bad = bad[i][torch.from_numpy(tr.astype(np.int64))[pid.clamp(min=0)]].any(-1)        # [n] any of the 8 corners
+            ok &= ~(rows_bad & (pid >= 0))
+        return ok
+
     for std in (None, 0.7):                       # the bench's own initialisation, then logits with a real spread
         if std is not None:
             torch.manual_seed(42)
@@ -1769,12 +1793,34 @@ def test_c5_shape_parity_vqad_codebook_level8():
                     f.copy_(torch.randn_like(f) * std)
                 for q in grid.dictionary:
                     q.copy_(torch.randn_like(q) * 0.5)
+        else:
+            # plant decidable ties in rows the samples touch: an EARLIER entry one ulp (~2e-9) below the row's maximum must win in training
+            with torch.no_grad():
+                for f in grid.features:
+                    x = f.detach()
+                    mx, am = x.max(-1)
+                    rows = torch.nonzero(am >= 1).reshape(-1)[::5]
+                    x[rows, am[rows] - 1] = torch.nextafter(mx[rows], torch.full_like(mx[rows], -1.0))
+                    assert bool((x[rows, am[rows] - 1] < mx[rows]).all())
+        bad = undefined_rows()
+        planted = sum(int(((f.detach().cpu().max(-1, keepdim=True)[0] - f.detach().cpu()).gt(0) &
+                           (f.detach().cpu().max(-1, keepdim=True)[0] - f.detach().cpu()).lt(2.0 ** -26)).any(-1).sum()) for f in grid.features)
+        assert (planted > 10000) if std is None else True, planted
         out = grid.interpolate(rm.samples, L - 1)
         assert out.shape == (S, F)
         ref, _, _ = oracle_pass(None, torch.float32)
-        e = float((out.detach()[:ref.shape[0]].cpu() - ref).abs().max())
+        ok = sample_mask(bad, ref.shape[0])
+        assert float(ok.float().mean()) > 0.98, float(ok.float().mean())
+        e = float((out.detach()[:ref.shape[0]].cpu() - ref)[ok].abs().max())
         assert e <= 1e-5, (std, e)
-    # ---- backward at the full batch (logits std 0.7), the entry point the direct-issue step launches
+    # ---- backward at the full batch (logits std 0.7), the entry point the direct-issue step launches.  The float64 oracle has no
+    # softmax ties at all: lift the maximum of any row with a near-tie so that fp32 and float64 agree on every index
+    with torch.no_grad():
+        for f in grid.features:
+            x = f.detach()
+            mx, am = x.max(-1, keepdim=True)
+            near = (((mx - x) <= 2.0 ** -20) & (torch.arange(x.shape[1], device=x.device)[None] != am)).any(-1)
+            x[near, am[near, 0]] += 1e-3
     rng = np.random.default_rng(43)
     g_out = torch.from_numpy(rng.normal(size=(S, F)).astype(np.float32))
     g_out[::7] *= 1e-3
@@ -1856,6 +1902,7 @@ def test_c3_shape_parity_nglod_level7_six_lods():
     nef.zero_grad()
     step.flat.grad.zero_()
     loss = step._forward_backward(c, gt)
+    want_loss = want_loss.detach()
     assert abs(float(loss) - float(want_loss)) <= 2e-5 * max(1.0, abs(float(want_loss))), (float(loss), float(want_loss))
     for i in range(6):
         sc = float(feats_cpu[i].grad.abs().max())
@@ -1879,10 +1926,10 @@ def test_c3_shape_parity_nglod_level7_six_lods():
     # the marched field differs by its fp16 roundings' last place (<= 2e-4 above), which moves a ray whose |sdf| sits within that
     # of the 3e-4 stopping rule by one iteration: the hit flags may disagree on such rays, the depths by one (small) step
     both = hit_g & hit_o
-    margin("nglod render: rays whose hit flag differs", float((hit_g != hit_o).float().mean()), 0.01)
+    margin("nglod render: rays whose hit flag differs", float((hit_g != hit_o).float().mean()), 0.002)
     dd = (rb.depth.cpu().reshape(-1) - want["depth"].reshape(-1)).abs()[both]
     margin("nglod render: median depth difference", float(dd.median()), 1e-5)
-    margin("nglod render: 99th percentile depth difference", float(dd.quantile(0.99)), 2e-3)
+    margin("nglod render: 99th percentile depth difference", float(dd.quantile(0.99)), 2e-4)
 
 
 def test_sdf_train_step_matches_torch_adam():
