@@ -13,9 +13,13 @@ density + colour MLPs, packed compositing, huber loss, backward, (RCCL all-reduc
 Prints ONE JSON line (rank 0).  Inputs are synthetic (synlego.py) and resident in HBM before the timed region.
 
 Sequence: dense level-7 octree (nerf_hash.yaml:16-17) -> `--pretrain` untimed optimisation steps with the trainer's own
-adaptive ray count and pruning -> W warm-up + exactly K timed steps at `--target-samples` packed samples per step (the
-headline `value`) -> W + K steps at the reference trainer's 2^18 samples per step (`reference_regime`) -> one prune timed on
-its own (`prune`) -> PSNR on held-out rays -> live rocprofv3 --pmc passes for `roofline.traffic` -> CPU oracle baseline.
+adaptive ray count and pruning -> W warm-up + exactly K timed steps at `--target-samples` packed samples per step - the
+reference trainer's own batch, 2^18 (multiview_trainer.py:58): the headline `value` -> W + K steps at `--large-target-samples`
+(2^21, 8 x the reference's) with the learning rates scaled by sqrt(batch ratio) (`large_batch_regime`: more rays per second,
+less quality per ray - `quality` holds the held-out PSNR of both regimes against rays consumed and against wall-clock,
+profiles/r06_time_to_psnr_*.txt) -> the unchanged trainer (`dropin_regime`) -> one prune timed on its own (`prune`) -> PSNR on
+held-out rays -> live rocprofv3 --pmc passes for `roofline.traffic` -> the N > 1 launch structure on one GPU
+(`dp_path_regime`) -> CPU oracle baseline.
 """
 import argparse
 import json
@@ -47,10 +51,17 @@ def parse(argv=None):
                     help="untimed optimisation steps from the DENSE level-7 octree before warm-up (prune every 100, adaptive "
                          "ray count): the timed steps then run on an occupancy the model has learned, and the PSNR means something")
     ap.add_argument("--num-steps", type=int, default=2048, help="raymarch candidates per ray (nerf_hash.yaml:49)")
-    ap.add_argument("--target-samples", type=int, default=2 ** 21,
-                    help="packed samples per step per GPU of the headline regime (reference trainer default: 2^18, reported "
-                         "next to it as reference_regime)")
-    ap.add_argument("--ref-target-samples", type=int, default=2 ** 18, help="multiview_trainer.py:58")
+    ap.add_argument("--target-samples", type=int, default=2 ** 18,
+                    help="packed samples per step per GPU of the headline regime: the reference trainer's target_sample_size "
+                         "(multiview_trainer.py:58)")
+    ap.add_argument("--large-target-samples", type=int, default=2 ** 21,
+                    help="packed samples per step per GPU of large_batch_regime (the headline until round 5; 0 skips it)")
+    ap.add_argument("--large-lr-scale", type=float, default=None,
+                    help="learning-rate multiplier of large_batch_regime; default sqrt(large / target) - the rule "
+                         "profiles/r06_time_to_psnr_*.txt measured (x 2-3 at 8 x the batch)")
+    ap.add_argument("--quality-budget", type=float, default=4.096e7,
+                    help="rays each regime trains a fresh model on for `quality` (held-out PSNR at equal rays and equal seconds); "
+                         "default = the reference's 100 epochs x 100 views x 4096 rays; 0 skips it")
     ap.add_argument("--bank-rays", type=int, default=2 ** 21)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
@@ -68,6 +79,12 @@ def parse(argv=None):
     ap.add_argument("--dropin-steps", type=int, default=100,
                     help="timed iterations of the reference trainer's own step (fp16 autocast + GradScaler + torch.optim), reported "
                          "as dropin_regime; 0 skips it")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --target-samples per GPU (per-GPU work fixed as N grows); strong: --target-samples is the GLOBAL "
+                         "batch, every rank takes 1/N of it (the reference trainer's batch stays the reference's as GPUs are added)")
+    ap.add_argument("--dp-steps", type=int, default=30,
+                    help="one GPU only: timed steps of the N > 1 launch structure (gradient collective on a side stream + separate "
+                         "optimizer) over a one-rank RCCL group, reported as dp_path_regime; 0 skips it")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -233,6 +250,110 @@ def hidden128_line(args, dev, pipe, batch, size_batch, steps=30):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def quality_table(args, dev, train_bank, amp, large_lr):
+    """`quality`: held-out PSNR of a FRESH nerf_hash.yaml model trained under the headline regime and under large_batch_regime on
+    the same ray budget (default: the reference's 100 epochs = 4.1e7 rays) - against rays consumed and against training seconds
+    (bench_quality.time_to_psnr; evaluation excluded from the seconds).  BASELINE.json's metric is rays/sec + PSNR: this is the
+    PSNR half, per regime."""
+    import bench_quality as bq
+    import synlego
+    try:
+        eval_bank = synlego.ray_bank(2 ** 15, seed=7, device=dev)
+        budget = int(args.quality_budget)
+        marks = tuple(m for m in (1e7, 2e7, 4e7) if m <= budget) or (float(budget) * (1 - 1e-9),)
+        out = {"ray_budget": budget, "held_out_rays": int(eval_bank[0].shape[0]),
+               "note": "fresh model per regime, dense level-7 start, prune every 100 steps, MultiStepLR x0.333 at 50/75/90 % of the ray "
+                       "budget, same ray stream and seed; curve rows = (rays consumed, optimizer steps, training seconds, dB)"}
+        for key, target, lr in (("headline", args.target_samples, 1.0), ("large_batch_regime", args.large_target_samples, large_lr)):
+            if target <= 0:
+                continue
+            r = bq.time_to_psnr(dev, dict(target=target, accum=1), train_bank, eval_bank, ray_budget=budget, checkpoints=marks,
+                                hidden=args.hidden, num_steps=args.num_steps, amp=amp, lr_scale=lr,
+                                log_every_rays=budget / 8)
+            out[key] = {"target_samples_per_step": target, "lr_scale": lr, "psnr_at_rays": r["psnr_at_rays"],
+                        "optimizer_steps": r["optimizer_steps"], "train_seconds": r["train_seconds"],
+                        "final_psnr_db": r["curve"][-1][3] if r["curve"] else None, "curve": [list(c) for c in r["curve"]]}
+        return out
+    except Exception as e:                                  # a quality side-run must not take the headline down
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def dp_path_regime(args, dev, pipe, batch, R, headline_ms):
+    """One GPU: the launch structure a rank runs when N > 1 - gradient collective + optimizer on a side stream, the table's AdamW
+    NOT folded into the backward, the next step's raymarch overlapping the exchange - over a ONE-rank RCCL group
+    (WISP_FORCE_ALLREDUCE=1), on a copy of the trained model at the headline batch: both exchange paths (all-reduce + replicated
+    optimizer; reduce-scatter + optimizer on the own slice + all-gather of the bf16 shadow).  With one rank RCCL's collectives
+    are device-local copies, so what this measures is everything of the N > 1 step EXCEPT the wire: the only unknown left for an
+    8-GPU node is xGMI itself.  `projected` adds the wire from the link rate alone and is labelled as a projection."""
+    import copy
+    import socket
+    from wisp.trainers import MultiviewTrainStep
+    out = {}
+    try:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    except Exception as e:
+        return {"error": f"one-rank process group: {type(e).__name__}: {e}"}
+    had = os.environ.get("WISP_FORCE_ALLREDUCE")
+    os.environ["WISP_FORCE_ALLREDUCE"] = "1"
+    try:
+        for name, sharded in (("allreduce", False), ("sharded", True)):
+            twin = copy.deepcopy(pipe)
+            tr = MultiviewTrainStep(twin, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, rgb_loss_type='huber',
+                                    prune_every=-1, target_sample_size=args.target_samples, max_rays=2 ** 18,
+                                    enable_amp=args.precision == "bf16", sharded_optimizer=sharded)
+            assert tr.force_allreduce and tr.sharded_optimizer == sharded
+            rays, gts = batch(R)
+            for _ in range(5):
+                nrays, ngts = batch(R)
+                tr.step(rays, gts, prefetch=nrays)
+                rays, gts = nrays, ngts
+            tr.comm_timing = []
+            _sync()
+            t0 = time.perf_counter()
+            for _ in range(args.dp_steps):
+                nrays, ngts = batch(R)
+                tr.step(rays, gts, prefetch=nrays)
+                rays, gts = nrays, ngts
+            _sync()
+            dt = time.perf_counter() - t0
+            comm = tr.comm_summary() or {}
+            tr.comm_timing = None
+            wire = 4 * min(tr._live_grad_numel(), tr.flat.grad.numel())
+            ms = 1e3 * dt / args.dp_steps
+            # wire time at N = 8 from the link rate alone (MI355X_MICROARCH.md: 7 xGMI links x ~153 GB/s per GPU, fully connected):
+            # a direct reduce-scatter / all-gather sends 7/8 of the buffer over 7 links in parallel = bytes / 8 / 153e9 per phase;
+            # a ring is bound by ONE link: 2 x 7/8 x bytes / 153e9
+            back = 2 if sharded else 4                                   # bytes per element on the way back (bf16 shadow / fp32 sum)
+            direct_us = 1e6 * (wire / 8 / 153e9 + wire * back / 4 / 8 / 153e9)
+            ring_us = 1e6 * (7 / 8) * (wire + wire * back / 4) / 153e9
+            hidden = comm.get("hidden_ms", 0.0)
+            out[name] = {"ms_per_step": ms, "value": R * args.dp_steps / dt, "unit": "rays/s", "steps": args.dp_steps,
+                         "over_headline_ms": ms - headline_ms, "comm": comm, "grad_bytes_per_step": wire,
+                         "projected_n8": {
+                             "wire_us_direct": direct_us, "wire_us_ring": ring_us,
+                             "rays_per_sec_direct": 8 * R / ((ms + max(0.0, direct_us * 1e-3 - hidden)) * 1e-3),
+                             "rays_per_sec_ring": 8 * R / ((ms + max(0.0, ring_us * 1e-3 - hidden)) * 1e-3),
+                             "note": "PROJECTION, not a measurement: this one-GPU step + the part of the wire time (link rate only, no "
+                                     "latency, no RCCL protocol overhead) that does not fit the window the overlap hides today "
+                                     "(`comm.hidden_ms`); weak scaling, 8 x this GPU's rays"}}
+            del tr, twin
+            torch.cuda.empty_cache()
+        out["note"] = ("N > 1 launch structure on one GPU (one-rank RCCL group): the table's AdamW is a separate launch again and the "
+                       "collective + optimizer run on a side stream under the next step's raymarch; `over_headline_ms` is what that "
+                       "structure costs against the one-GPU step whose optimizer is folded into the backward")
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        if had is None:
+            os.environ.pop("WISP_FORCE_ALLREDUCE", None)
+        else:
+            os.environ["WISP_FORCE_ALLREDUCE"] = had
+    return out
+
+
 def dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev):
     """wisp.trainers.MultiviewTrainer - the mirror of the reference class, equal to its method bodies on the CPU
     (tests/test_reference_modules.py::test_dropin_trainer_class_equals_the_reference_methods) - configured like nerf_hash.yaml's
@@ -248,7 +369,7 @@ def dropin_regime(pipe, bank_o, bank_d, bank_rgb, args, world, dev):
                                 bank_rgb[:views * per_view].view(shape), synlego.NEAR, synlego.FAR, transform=SampleRays(4096))
     cfg = ConfigMultiviewTrainer(optimizer=ConfigAdamW(lr=1e-3, eps=1e-16, weight_decay=1e-6), grid_lr_weight=500.0, enable_amp=True,
                                  scheduler=True, prune_every=100, rgb_loss_type='huber', rgb_loss_denom='rays', max_epochs=10 ** 6,
-                                 target_sample_size=args.ref_target_samples)
+                                 target_sample_size=args.target_samples)
     twin = copy.deepcopy(pipe)
     twin.tracer.prev_num_samples = None                       # the trainer's first call is its warm-up raymarch
     tr = MultiviewTrainer(cfg, twin, ds, device=dev)
@@ -438,7 +559,7 @@ def _sync():
 
 
 SENTINEL_ELEMS = 1_000_003            # x (tag + 1) float64 elements: a fill launch no other code of the run issues
-REGIME_TAGS = {"headline": 0, "reference_regime": 1, "dropin_regime": 2}
+REGIME_TAGS = {"headline": 0, "large_batch_regime": 1, "dropin_regime": 2}
 
 
 class _regime:
@@ -520,6 +641,13 @@ def main(argv=None):
         return bench_configs.main(args, dev)
     if args.pmc_child:                                     # profiling child: fixed occupancy, a handful of steps, no extras
         args.occupancy, args.pretrain, args.warmup, args.steps = "analytic", 0, 2, 4
+    global_target = args.target_samples
+    if args.scaling == "strong" and world > 1:
+        # the global batch is fixed: every rank takes 1/N of the packed-sample target (and so ~1/N of the rays)
+        args.target_samples = max(4096, args.target_samples // world)
+        args.large_target_samples = max(4096, args.large_target_samples // world) if args.large_target_samples > 0 else 0
+    large_lr = args.large_lr_scale if args.large_lr_scale is not None else \
+        math.sqrt(max(1.0, args.large_target_samples / max(args.target_samples, 1)))
     true_cells = synlego.occupied_cells(7, device=dev)
     cells = _initial_cells(args, dev, true_cells)
     pipe = build_pipeline(dev, args.hidden, args.num_steps, cells)
@@ -606,6 +734,7 @@ def main(argv=None):
         elapsed, total_samples, prunes_in = timed_steps(R, args.warmup, args.steps, timing)
     comm = trainer.comm_summary()
     trainer.comm_timing = None
+    fused_elems_headline = int(getattr(trainer, "fused_elements_last", 0))
     # scratch of the binned hash-grid backward in this regime (record slots sized from what earlier launches filled)
     fits = [f.last for f in getattr(C, "_slot_fits", {}).values() if f.last]
     scratch = None
@@ -632,12 +761,18 @@ def main(argv=None):
             dist.destroy_process_group()
         return None
 
-    # ---- the reference trainer's own regime: 2^18 samples per step (multiview_trainer.py:58), same model state
-    R_ref = size_batch(args.ref_target_samples)
-    with _regime("reference_regime", dev):
-        ref_elapsed, ref_samples, ref_prunes = timed_steps(R_ref, min(args.warmup, 3), args.steps)
-    ref_samples_all = all_sum(ref_samples)
-    trainer.target_sample_size = args.target_samples
+    # ---- large_batch_regime: 8 x the reference's batch (the headline until round 5), learning rates x sqrt(batch ratio), same model
+    large = None
+    if args.large_target_samples > 0:
+        R_large = size_batch(args.large_target_samples)
+        base_lr, trainer.lr = trainer.lr, trainer.lr * large_lr
+        timing_large = {}
+        with _regime("large_batch_regime", dev):
+            lg_elapsed, lg_samples, lg_prunes = timed_steps(R_large, min(args.warmup, 3), args.steps, timing_large)
+        trainer.lr = base_lr
+        large = dict(R=R_large, elapsed=lg_elapsed, samples=all_sum(lg_samples), prunes=lg_prunes, timing=timing_large,
+                     fused_elems=int(getattr(trainer, "fused_elements_last", 0)))
+        trainer.target_sample_size = args.target_samples
 
     # ---- the unchanged-application regime: the reference trainer's own step (multiview_trainer.py:111-180 through
     # BaseTrainer.iterate, base_trainer.py:316-342) over a copy of the same model state: fp16 autocast + GradScaler, autograd over
@@ -654,69 +789,73 @@ def main(argv=None):
     prune_ms = 1e3 * (time.perf_counter() - tp)
 
     # ---- per-kernel roofline from the live HIP events (algorithmic bytes: SURVEY.md 8d / DESIGN.md)
-    kern = {}
-    for name, evs in timing.items():
-        ms = [a.elapsed_time(b) for a, b, _ in evs]
-        units = [u for _, _, u in evs]
-        kern[name] = dict(avg_ms=float(np.mean(ms)), launches=len(ms), avg_units=float(np.mean(units)), total_ms=float(np.sum(ms)))
     d = getattr(trainer, "_direct", None)
     hash_direct = d is not None and getattr(d, "hash_fast", False) and not getattr(trainer, "_last_step_modular", True)
     live_levels = min(NGP["num_lods"], d.zero_from_col // NGP["feature_dim"]) if hash_direct else NGP["num_lods"]
     work = work_table(amp, args.hidden, NGP["num_lods"], live_levels)
     peaks = {"hbm": (HBM_PEAK_GBS, "GB/s"), "mfma": (2500.0 if amp else 157.3, "TFLOP/s")}
 
-    # One GPU: the grid's AdamW step runs inside the hash-grid backward's reduce kernel (MultiviewTrainStep._fused_update_args), so
-    # that launch also does the optimizer's work for the elements it updates: parameter and both moments read and written (24 B) +
-    # the bf16 copy (2 B); the gradient itself never leaves LDS.  That is a DIFFERENT quantity from SURVEY 8(d)'s backward bytes:
-    # `achieved` / `frac` are the backward's algorithmic bytes alone; the variant with the optimizer's bytes has its own key.
-    fused_elems = int(getattr(trainer, "fused_elements_last", 0))
-    fused_opt_bytes = fused_elems * (24 + (2 if amp else 0))
+    def roofline_of(timing, fused_elems):
+        """roofline object of one regime from its HIP-event sink {entry point: [(start, end, units)]}.
+        One GPU: the grid's AdamW step runs inside the hash-grid backward's reduce kernel (MultiviewTrainStep._fused_update_args), so
+        that launch also does the optimizer's work for the `fused_elems` elements it updates: parameter and both moments read and
+        written (24 B) + the bf16 copy (2 B); the gradient itself never leaves LDS.  That is a DIFFERENT quantity from SURVEY 8(d)'s
+        backward bytes: `achieved` / `frac` are the backward's algorithmic bytes alone; the variant with the optimizer's bytes has
+        its own key."""
+        kern = {}
+        for name, evs in timing.items():
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            units = [u for _, _, u in evs]
+            kern[name] = dict(avg_ms=float(np.mean(ms)), launches=len(ms), avg_units=float(np.mean(units)), total_ms=float(np.sum(ms)))
+        fused_opt_bytes = fused_elems * (24 + (2 if amp else 0))
 
-    def rate(name, v):
-        bound, per = work[name]
-        r = per * v["avg_units"] / (v["avg_ms"] * 1e-3)
-        return bound, (r / 1e9 if bound == "hbm" else r / 1e12)
+        def rate(name, v):
+            bound, per = work[name]
+            r = per * v["avg_units"] / (v["avg_ms"] * 1e-3)
+            return bound, (r / 1e9 if bound == "hbm" else r / 1e12)
 
-    kern = {n: v for n, v in kern.items() if n in work}
-    dominant = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
-    roofline = None
-    if dominant:
-        k = kern[dominant]
-        bound, achieved = rate(dominant, k)
-        peak, unit = peaks[bound]
-        roofline = dict(bound=bound, kernel=dominant, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
-                        traffic=None, traffic_note="not measured (--no-pmc, multi-GPU run or profiler unavailable); see profiles/",
-                        avg_launch_ms=k["avg_ms"], units_per_launch=k["avg_units"], work_per_unit=work[dominant][1],
-                        levels_processed=live_levels, levels_of_the_table=NGP["num_lods"],
-                        work_note="algorithmic bytes of the levels the kernels process: lod_idx = 15 zeroes the finest level's columns "
-                                  "(hash_grid.py:226-229), so 15 of 16 levels are gathered / scattered; SURVEY 8(d)'s nominal 16-level "
-                                  f"figures would be {work_table(amp, args.hidden)['hashgrid_fwd'][1]} / "
-                                  f"{work_table(amp, args.hidden)['hashgrid_bwd'][1]} B per sample",
-                        all_kernels={n: dict(avg_ms=v["avg_ms"], bound=rate(n, v)[0], achieved=rate(n, v)[1],
-                                             frac=rate(n, v)[1] / peaks[rate(n, v)[0]][0], work_per_unit=work[n][1])
-                                     for n, v in kern.items()})
-        if fused_opt_bytes and "hashgrid_bwd" in roofline["all_kernels"]:
-            k = kern["hashgrid_bwd"]
-            both = (work["hashgrid_bwd"][1] * k["avg_units"] + fused_opt_bytes) / (k["avg_ms"] * 1e-3) / 1e9
-            roofline["all_kernels"]["hashgrid_bwd"]["with_fused_optimizer"] = {
-                "elements_updated_in_the_launch": fused_elems, "optimizer_bytes_per_launch": fused_opt_bytes,
-                "achieved": both, "frac": both / HBM_PEAK_GBS,
-                "note": "NOT the headline figure: backward bytes + what torch.optim.AdamW's step moves for the table rows the reduce "
-                        "workgroups own (parameter + two moments read and written, bf16 copy written: 26 B per element); the "
-                        "separate optimizer launch only covers the coarse levels, the frozen finest level and the decoder"}
-            if dominant == "hashgrid_bwd":
-                roofline["with_fused_optimizer"] = roofline["all_kernels"]["hashgrid_bwd"]["with_fused_optimizer"]
-        if "hashgrid_fwd" in roofline["all_kernels"]:
-            # SURVEY 8(d)'s algorithmic bytes (588 B/sample, 512 of them gathered table entries) over the launch time exceed the HBM
-            # peak: the 20.9 MB of tables are re-read from L2 / Infinity Cache, so that figure is NOT an HBM fraction and is kept
-            # only under its own name.  What bounds the kernel is the L2-miss fill path (half of its L2 requests miss a 4 MB L2
-            # holding a 20.9 MB table); its measured memory-side traffic replaces `achieved` / `frac` below when the PMC pass ran.
-            e = roofline["all_kernels"]["hashgrid_fwd"]
-            e["algorithmic_model"] = {"achieved": e["achieved"], "frac_of_hbm_peak": e["frac"],
-                                      "note": "SURVEY 8(d) bytes / launch time; > 1 is possible because table gathers hit L2 / MALL"}
-            e["bound"], e["achieved"], e["frac"] = "l2-miss-fill", None, None
-            e["note"] = "memory-side traffic of the L2s (FETCH_SIZE x2 + WRITE_SIZE) over launch time against the 8 TB/s peak; not measured in this run"
+        kern = {n: v for n, v in kern.items() if n in work}
+        dominant = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
+        roofline = None
+        if dominant:
+            k = kern[dominant]
+            bound, achieved = rate(dominant, k)
+            peak, unit = peaks[bound]
+            roofline = dict(bound=bound, kernel=dominant, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
+                            traffic=None, traffic_note="not measured (--no-pmc, multi-GPU run or profiler unavailable); see profiles/",
+                            avg_launch_ms=k["avg_ms"], units_per_launch=k["avg_units"], work_per_unit=work[dominant][1],
+                            levels_processed=live_levels, levels_of_the_table=NGP["num_lods"],
+                            work_note="algorithmic bytes of the levels the kernels process: lod_idx = 15 zeroes the finest level's columns "
+                                      "(hash_grid.py:226-229), so 15 of 16 levels are gathered / scattered; SURVEY 8(d)'s nominal 16-level "
+                                      f"figures would be {work_table(amp, args.hidden)['hashgrid_fwd'][1]} / "
+                                      f"{work_table(amp, args.hidden)['hashgrid_bwd'][1]} B per sample",
+                            all_kernels={n: dict(avg_ms=v["avg_ms"], bound=rate(n, v)[0], achieved=rate(n, v)[1],
+                                                 frac=rate(n, v)[1] / peaks[rate(n, v)[0]][0], work_per_unit=work[n][1])
+                                         for n, v in kern.items()})
+            if fused_opt_bytes and "hashgrid_bwd" in roofline["all_kernels"]:
+                k = kern["hashgrid_bwd"]
+                both = (work["hashgrid_bwd"][1] * k["avg_units"] + fused_opt_bytes) / (k["avg_ms"] * 1e-3) / 1e9
+                roofline["all_kernels"]["hashgrid_bwd"]["with_fused_optimizer"] = {
+                    "elements_updated_in_the_launch": fused_elems, "optimizer_bytes_per_launch": fused_opt_bytes,
+                    "achieved": both, "frac": both / HBM_PEAK_GBS,
+                    "note": "NOT the headline figure: backward bytes + what torch.optim.AdamW's step moves for the table rows the reduce "
+                            "workgroups own (parameter + two moments read and written, bf16 copy written: 26 B per element); the "
+                            "separate optimizer launch only covers the coarse levels, the frozen finest level and the decoder"}
+                if dominant == "hashgrid_bwd":
+                    roofline["with_fused_optimizer"] = roofline["all_kernels"]["hashgrid_bwd"]["with_fused_optimizer"]
+            if "hashgrid_fwd" in roofline["all_kernels"]:
+                # SURVEY 8(d)'s algorithmic bytes (588 B/sample, 512 of them gathered table entries) over the launch time exceed the HBM
+                # peak: the 20.9 MB of tables are re-read from L2 / Infinity Cache, so that figure is NOT an HBM fraction and is kept
+                # only under its own name.  What bounds the kernel is the L2-miss fill path (half of its L2 requests miss a 4 MB L2
+                # holding a 20.9 MB table); its measured memory-side traffic replaces `achieved` / `frac` below when the PMC pass ran.
+                e = roofline["all_kernels"]["hashgrid_fwd"]
+                e["algorithmic_model"] = {"achieved": e["achieved"], "frac_of_hbm_peak": e["frac"],
+                                          "note": "SURVEY 8(d) bytes / launch time; > 1 is possible because table gathers hit L2 / MALL"}
+                e["bound"], e["achieved"], e["frac"] = "l2-miss-fill", None, None
+                e["note"] = "memory-side traffic of the L2s (FETCH_SIZE x2 + WRITE_SIZE) over launch time against the 8 TB/s peak; not measured in this run"
+        return roofline
 
+    roofline = roofline_of(timing, fused_elems_headline)
     out = None
     if rank == 0:
         # quality: PSNR on held-out rays after pretrain + warm-up + both timed loops (real optimisation steps all of them)
@@ -731,15 +870,28 @@ def main(argv=None):
                 mse = float(((torch.cat(chunks) - ergb) ** 2).mean())
             psnr = 10 * math.log10(1.0 / max(mse, 1e-12))
         rays_total = R * args.steps * world
-        ref_rays_total = R_ref * args.steps * world
         # "prune amortised".  A window of K steps holds K/100 prunes on average but floor or ceil of that in fact
         # (none at all in the driver's 20 steps): `value` and `ms_per_step` always charge exactly K/100 prunes, at the cost of
         # the prune timed on its own below; the raw window is kept under `timed_window`.
         amort = elapsed + (args.steps / trainer.prune_every - prunes_in) * prune_ms * 1e-3 if trainer.prune_every > 0 else elapsed
+        large_line = None
+        if large is not None:
+            lg_rays = large["R"] * args.steps * world
+            lg_amort = large["elapsed"] + (args.steps / trainer.prune_every - large["prunes"]) * prune_ms * 1e-3 \
+                if trainer.prune_every > 0 else large["elapsed"]
+            large_line = {"target_samples_per_step": args.large_target_samples, "rays_per_step_per_gpu": large["R"],
+                          "lr_scale": large_lr, "value": lg_rays / lg_amort, "unit": "rays/s", "ms_per_step": 1e3 * lg_amort / args.steps,
+                          "timed_window": {"seconds": large["elapsed"], "ms_per_step": 1e3 * large["elapsed"] / args.steps,
+                                           "value": lg_rays / large["elapsed"], "prunes_inside": large["prunes"]},
+                          "samples_per_sec": large["samples"] / large["elapsed"],
+                          "roofline": roofline_of(large["timing"], large["fused_elems"]),
+                          "note": "8 x the reference trainer's batch (the headline `value` until round 5), learning rates x sqrt(batch "
+                                  "ratio): more rays per second, each worth less - `quality` and profiles/r06_time_to_psnr_*.txt hold "
+                                  "the held-out PSNR of both regimes at equal rays and at equal training seconds"}
         out = {
             "metric": "training rays/sec, HashGrid NeRF (nerf_hash.yaml), synthetic Lego 800x800",
             "value": rays_total / amort, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * amort / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * amort / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "timed_window": {"seconds": elapsed, "ms_per_step": 1e3 * elapsed / args.steps, "value": rays_total / elapsed,
                              "prunes_inside": prunes_in, "prunes_charged": args.steps / trainer.prune_every if trainer.prune_every > 0 else 0.0,
                              "note": "`value` = rays / (window seconds + (steps / prune_every - prunes_inside) x prune.ms)"},
@@ -749,6 +901,14 @@ def main(argv=None):
                                    f"SynLego 800x800 rays; occupancy: {args.occupancy} level-7 start, pruned every 100 steps "
                                    f"({args.pretrain} untimed pre-training steps before the timed ones)",
                        "rays_per_step_per_gpu": R, "target_samples_per_step": args.target_samples,
+                       "batch_note": "the reference trainer's own batch: target_sample_size = 2**18 packed samples per step "
+                                     "(multiview_trainer.py:58,95-109); until round 5 `value` was quoted at 8 x that (now "
+                                     "large_batch_regime) - at equal rays the large batch ends 1.0 dB (lr x 3) to 3.6 dB (lr x 1) lower, "
+                                     "profiles/r06_time_to_psnr_equal_rays.txt",
+                       "global_target_samples_per_step": args.target_samples * world,
+                       "scaling_note": ("strong: the global batch of --target-samples = %d packed samples is split over the ranks"
+                                        % global_target) if args.scaling == "strong" else
+                                       "weak: every GPU takes --target-samples packed samples per step (global batch grows with N)",
                        "samples_per_ray": total_samples_all / max(rays_total, 1), "parallelism": f"ray-sharded dp{world}",
                        "occupied_cells": cells_now, "true_occupied_cells": int(true_cells.shape[0]),
                        "prunes_inside_timed_steps": prunes_in},
@@ -756,15 +916,7 @@ def main(argv=None):
             "host_binding": host_binding or "none (no NUMA topology to bind to, or WISP_NUMA_BIND=0)",
             "prune": {"ms": prune_ms, "every_steps": trainer.prune_every, "value_without_any_prune":
                       rays_total / max(elapsed - prunes_in * prune_ms * 1e-3, 1e-9)},
-            "reference_regime": {"target_samples_per_step": args.ref_target_samples, "rays_per_step_per_gpu": R_ref,
-                                 "value": ref_rays_total / ref_elapsed, "unit": "rays/s",
-                                 "ms_per_step": 1e3 * ref_elapsed / args.steps, "samples_per_sec": ref_samples_all / ref_elapsed,
-                                 "prunes_inside_timed_steps": ref_prunes, "hip_event_timing_inside_the_loop": False,
-                                 "value_with_amortised_prune": ref_rays_total / (ref_elapsed + (args.steps / trainer.prune_every - ref_prunes)
-                                                                                 * prune_ms * 1e-3) if trainer.prune_every > 0 else None,
-                                 # (what the prunes that fell into the window cost: round 3's 0.362 -> 0.389 ms was two of them)
-                                 "ms_per_step_without_its_prunes": 1e3 * (ref_elapsed - ref_prunes * prune_ms * 1e-3) / args.steps,
-                                 "note": "multiview_trainer.py:58 default batch (2^18 packed samples per step), same run"},
+            "large_batch_regime": large_line,
             "dropin_regime": dropin, "comm": comm,
             "psnr_db": psnr, "optimisation_steps_before_psnr": trainer.total_iterations,
             "roofline": roofline,
@@ -795,6 +947,10 @@ def main(argv=None):
             import bench_configs
             out["configs"] = bench_configs.secondary_lines(args, dev)
             out["configs"]["hidden128"] = hidden128_line(args, dev, pipe, batch, size_batch)
+        if world == 1 and args.quality_budget > 0:
+            out["quality"] = quality_table(args, dev, (bank_o, bank_d, bank_rgb), amp, large_lr)
+        if world == 1 and args.dp_steps > 0 and not dist.is_initialized():
+            out["dp_path_regime"] = dp_path_regime(args, dev, pipe, batch, R, out["ms_per_step"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(true_cells, args.hidden, args.num_steps)
         print(json.dumps(out))

@@ -113,7 +113,8 @@ int wisp_hashgrid_grad_coords(const float* coords, int64_t n, int coord_dim, con
  * caller's to update (wisp_adamw_step_groups over the remaining ranges).  Levels that were not binned or whose buckets are
  * shared by several workgroups (the coarse ones) report 0; with feature_dim != 2 everything reports 0 (plain backward).
  * The trailing levels behind zero_from_col (no gradient reaches them; nerf_hash.yaml: the finest) are stepped by extra workgroups
- * of the same launch and report all their rows (WISP_ADAM_TAIL=0: they report 0 and stay the caller's).
+ * of the same launch - every row the caller's first_idx gives those levels, whatever their spacing - and report 2^62 ("the whole
+ * level": clamp to first_idx[l + 1] - first_idx[l]); WISP_ADAM_TAIL=0: they report 0 and stay the caller's.
  * Single-GPU only by construction: a data-parallel step has to exchange the gradient first. */
 int wisp_hashgrid_interpolate_bwd_adamw(const float* coords, int64_t n, int coord_dim,
                                         const void* grad_feats, int dtype, int feature_dim,

@@ -862,6 +862,7 @@ struct AdamFlush {
 };
 // levels [first_level, end_level) of the table that receive no gradient, stepped by `blocks` extra workgroups of the reduce launch
 #define HG_TAIL_ROWS 8192
+#define WISP_WHOLE_LEVEL ((int64_t)1 << 62)               // covered_rows[l]: all rows of level l, whatever its spacing in first_idx
 struct TailLevels { int first_level, end_level, blocks; };
 
 template <typename T, int F, typename ACC, bool ADAM>
@@ -1171,16 +1172,22 @@ hashgrid_bwd_reduce_kernel(const int64_t* __restrict__ first_idx, LevelList leve
         if (blockIdx.x < (unsigned)tail.blocks) {                // FIRST in dispatch order: short streaming workgroups that are gone
             const int64_t k = (int64_t)blockIdx.x;               // before the record walks need the bandwidth (at the END of the grid
                                                                  // they lengthened the launch by their own 6 us)
-            const int64_t lo = first_idx[tail.first_level] * F + k * (int64_t)(HG_TAIL_ROWS * F);
-            const int64_t end = first_idx[tail.end_level] * F;
-            const int64_t hi = lo + HG_TAIL_ROWS * F < end ? lo + HG_TAIL_ROWS * F : end;
-            for (int64_t e = lo + threadIdx.x; e < hi; e += RD_THREADS) {
-                const float c = grad_codebook[e];
-                float x = ad.p[e], m1 = ad.m[e], m2 = ad.v[e];
-                wisp_adamw_update(x, m1, m2, c * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
-                ad.p[e] = x; ad.m[e] = m1; ad.v[e] = m2;
-                if (c != 0.0f) grad_codebook[e] = 0.0f;
-                if (ad.shadow) ad.shadow[e] = __float2bfloat16(x);
+            // EVERY row of the tail levels as the caller's first_idx lays them out - [first_idx[first_level], first_idx[end_level]) -
+            // in pieces of HG_TAIL_ROWS dealt round-robin to the tail workgroups: the launcher sizes their number from
+            // min(res^dim, T) per level, but a padded or custom table may space its levels differently, and a fixed
+            // "blocks x 8192 rows from the start" walk would then step some rows twice (here and in the caller's launch) and
+            // others never.  covered_rows says "the whole level" for these levels.
+            const int64_t begin = first_idx[tail.first_level] * F, end = first_idx[tail.end_level] * F;
+            for (int64_t lo = begin + k * (int64_t)(HG_TAIL_ROWS * F); lo < end; lo += (int64_t)tail.blocks * (HG_TAIL_ROWS * F)) {
+                const int64_t hi = lo + HG_TAIL_ROWS * F < end ? lo + HG_TAIL_ROWS * F : end;
+                for (int64_t e = lo + threadIdx.x; e < hi; e += RD_THREADS) {
+                    const float c = grad_codebook[e];
+                    float x = ad.p[e], m1 = ad.m[e], m2 = ad.v[e];
+                    wisp_adamw_update(x, m1, m2, c * ad.gscale, ad.lr, ad.wd, ad.b1, ad.b2, ad.eps, ad.bc1, ad.bc2_sqrt);
+                    ad.p[e] = x; ad.m[e] = m1; ad.v[e] = m2;
+                    if (c != 0.0f) grad_codebook[e] = 0.0f;
+                    if (ad.shadow) ad.shadow[e] = __float2bfloat16(x);
+                }
             }
             return;
         }
@@ -1489,8 +1496,8 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
                 int64_t entries = (int64_t)tsize;
                 if (lv.dense[l]) { entries = 1; for (int a = 0; a < DIM; ++a) entries *= (int64_t)lv.res[l]; }
                 if (entries > (int64_t)tsize) entries = (int64_t)tsize;
-                covered_rows[l] = entries;                     // (the caller clamps to first_idx[l + 1] - first_idx[l])
-                rows += entries;
+                covered_rows[l] = WISP_WHOLE_LEVEL;            // every row the caller's first_idx gives the level (it clamps)
+                rows += entries;                               // (an estimate: it only sizes the number of tail workgroups)
             }
             tail = TailLevels{first_dead, num_lods, (int)ceil_div64(rows, HG_TAIL_ROWS)};
         }

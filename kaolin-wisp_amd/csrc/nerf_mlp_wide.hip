@@ -636,6 +636,18 @@ template <int HH, int T0, int T1> DEV void fwd_l4(const LaneW<HH>& L, ActsW<HH>&
 
 // The two roles are two separate loops (each with the same ten barriers per round) so that a wave's registers hold only its own
 // role's state - one loop with role branches made the allocator keep both roles' state live (1 KB of spills per lane).
+// The producers' and the consumers' barriers are DIFFERENT call sites that pair up by COUNT only: s_barrier counts arriving waves,
+// not program counters, which is what the hardware does but nothing the HIP programming model promises.  Both loops therefore
+// name every barrier by what it separates - WD_STAGE_BARRIER(stage, FILLED | DRAINED), stages 5 .. 1 - and
+// tests/test_abi_and_host.py::test_wide_dw2_roles_issue_the_same_barrier_sequence holds the two sequences (and the prologue's
+// single barrier on either side) to each other, so a barrier added to, dropped from or reordered in one role fails the CPU suite
+// instead of hanging a GPU.  WISP_WIDE_DW=1 keeps the one-role, barrier-per-stage kernel; the GPU suite compares the two bitwise.
+#define WD_FILLED 0                 // the stage's X / dY images are complete in LDS: consumers may read them
+#define WD_DRAINED 1                // the consumers are done with the images: producers may overwrite them
+#define FILLED WD_FILLED
+#define DRAINED WD_DRAINED
+#define WD_STAGE_BARRIER(stage, phase) do { static_assert((stage) >= 1 && (stage) <= 5 && ((phase) == WD_FILLED || (phase) == WD_DRAINED), \
+                                                          "wide_dw2: unknown pipeline barrier"); __syncthreads(); } while (0)
 template <int HH, typename TIO>
 DEV void dw2_producer(const LaneW<HH>& L, const TIO* __restrict__ feats, const float* __restrict__ dirs, int64_t num_samples,
                       int in_dim, int64_t rounds, unsigned char* imgX, int my_tile, int lane) {
@@ -662,37 +674,37 @@ DEV void dw2_producer(const LaneW<HH>& L, const TIO* __restrict__ feats, const f
         // stage 5: X = h3 (chained); meanwhile layer 1 of the next round
 #pragma unroll
         for (int kb = 0; kb < NK; ++kb) store_chained(imgX + wc_off, kb, A.h3[kb]);
-        __syncthreads();
+        WD_STAGE_BARRIER(5, FILLED);
         fwd_l1<HH>(L, N);
-        __syncthreads();
+        WD_STAGE_BARRIER(5, DRAINED);
         // stage 4: X = h2; meanwhile layers 2 + 3
 #pragma unroll
         for (int kb = 0; kb < NK; ++kb) store_chained(imgX + wc_off, kb, A.h2[kb]);
-        __syncthreads();
+        WD_STAGE_BARRIER(4, FILLED);
         fwd_l2_l3<HH>(L, nd, N);
-        __syncthreads();
+        WD_STAGE_BARRIER(4, DRAINED);
         // stage 3: X = x2 (chained block 0, natural blocks 1, 2); meanwhile the first half of layer 4
         store_chained(imgX + wc_off, 0, A.x2[0]);
         store_natural(imgX + wn_off, 1, A.x2[1]);
         store_natural(imgX + wn_off, 2, A.x2[2]);
-        __syncthreads();
+        WD_STAGE_BARRIER(3, FILLED);
         fwd_l4<HH, 0, W::NB / 2>(L, N);
-        __syncthreads();
+        WD_STAGE_BARRIER(3, DRAINED);
         // stage 2: X = h1; meanwhile the second half of layer 4
 #pragma unroll
         for (int kb = 0; kb < NK; ++kb) store_chained(imgX + wc_off, kb, A.h1[kb]);
-        __syncthreads();
+        WD_STAGE_BARRIER(2, FILLED);
         fwd_l4<HH, W::NB / 2, W::NB>(L, N);
-        __syncthreads();
+        WD_STAGE_BARRIER(2, DRAINED);
         // stage 1: X = x0 (natural, 2 blocks); meanwhile: hand over, fetch the inputs of the round after next
         store_natural(imgX + wn_off, 0, A.x0[0]);
         store_natural(imgX + wn_off, 1, A.x0[1]);
-        __syncthreads();
+        WD_STAGE_BARRIER(1, FILLED);
         A = N;
         const int64_t r2 = rd + 2 * step;
         const int64_t s2 = (r2 * WD_TILES + my_tile) * TS + n;
         fetch_inputs_wide<TIO>(feats, dirs, s2, r2 < rounds && s2 < num_samples, g, in_dim, N.x0, nd);
-        __syncthreads();
+        WD_STAGE_BARRIER(1, DRAINED);
     }
 }
 
@@ -728,7 +740,7 @@ DEV void dw2_consumer(const bf16x8* __restrict__ scratch, int64_t num_tiles, int
         const bf16x8* in = DY_PTR(rd);
         // ================= stage 5: dY5 (natural, 1 block) x h3 -> dW5, b5
         store_natural(imgY + wn_off, 0, yb[0]);
-        __syncthreads();
+        WD_STAGE_BARRIER(5, FILLED);
 #pragma unroll
         for (int kb = 0; kb < NK; ++kb) yb[kb] = have ? in[(W::S4Y + kb) * 64] : zero8;
 #pragma unroll
@@ -740,11 +752,11 @@ DEV void dw2_consumer(const bf16x8* __restrict__ scratch, int64_t num_tiles, int
             G.dW5[0] = mma16(a, b0, G.dW5[0]);
             G.dW5[1] = mma16(a, b1, G.dW5[1]);
         }
-        __syncthreads();
+        WD_STAGE_BARRIER(5, DRAINED);
         // ================= stage 4: dH3 x h2 -> dW4, b4
 #pragma unroll
         for (int kb = 0; kb < NK; ++kb) store_chained(imgY + wc_off, kb, yb[kb]);
-        __syncthreads();
+        WD_STAGE_BARRIER(4, FILLED);
 #pragma unroll
         for (int kb = 0; kb < NK; ++kb) yb[kb] = have ? in[(W::S3Y + kb) * 64] : zero8;
 #pragma unroll
@@ -762,11 +774,11 @@ DEV void dw2_consumer(const bf16x8* __restrict__ scratch, int64_t num_tiles, int
                 G.dW4[1][kt] = mma16(a1, b[kt], G.dW4[1][kt]);
             }
         }
-        __syncthreads();
+        WD_STAGE_BARRIER(4, DRAINED);
         // ================= stage 3: dH2 x x2 -> dW3 (+ b3 on the ones slot)
 #pragma unroll
         for (int kb = 0; kb < NK; ++kb) store_chained(imgY + wc_off, kb, yb[kb]);
-        __syncthreads();
+        WD_STAGE_BARRIER(3, FILLED);
         yb[0] = have ? in[W::S2Y * 64] : zero8;
 #pragma unroll
         for (int tl = 0; tl < WD_TILES; ++tl) {
@@ -781,10 +793,10 @@ DEV void dw2_consumer(const bf16x8* __restrict__ scratch, int64_t num_tiles, int
                 G.dW3[1][kt] = mma16(a1, b[kt], G.dW3[1][kt]);
             }
         }
-        __syncthreads();
+        WD_STAGE_BARRIER(3, DRAINED);
         // ================= stage 2: dY2 (chained, 1 block) x h1 -> dW2, b2
         store_chained(imgY + wc_off, 0, yb[0]);
-        __syncthreads();
+        WD_STAGE_BARRIER(2, FILLED);
 #pragma unroll
         for (int kb = 0; kb < NK; ++kb) yb[kb] = have ? in[(W::S1Y + kb) * 64] : zero8;
 #pragma unroll
@@ -796,11 +808,11 @@ DEV void dw2_consumer(const bf16x8* __restrict__ scratch, int64_t num_tiles, int
             G.dW2[0] = mma16(a, b0, G.dW2[0]);
             G.dW2[1] = mma16(a, b1, G.dW2[1]);
         }
-        __syncthreads();
+        WD_STAGE_BARRIER(2, DRAINED);
         // ================= stage 1: dH1 x x0 (natural, 2 blocks) -> dW1, b1
 #pragma unroll
         for (int kb = 0; kb < NK; ++kb) store_chained(imgY + wc_off, kb, yb[kb]);
-        __syncthreads();
+        WD_STAGE_BARRIER(1, FILLED);
         yb[0] = DY_HAVE(rd + step) ? DY_PTR(rd + step)[W::S5Y * 64] : zero8;
 #pragma unroll
         for (int tl = 0; tl < WD_TILES; ++tl) {
@@ -814,7 +826,7 @@ DEV void dw2_consumer(const bf16x8* __restrict__ scratch, int64_t num_tiles, int
             G.dW1[1][0] = mma16(a1, b0, G.dW1[1][0]);
             G.dW1[1][1] = mma16(a1, b1, G.dW1[1][1]);
         }
-        __syncthreads();
+        WD_STAGE_BARRIER(1, DRAINED);
     }
 #undef DY_PTR
 #undef DY_HAVE

@@ -291,10 +291,11 @@ def _check_first_idx(first_idx, num_lods, rows):
     if key not in _first_idx_ok:
         if len(_first_idx_ok) > 64:
             _first_idx_ok.clear()
-        end = int(first_idx[num_lods].item())
-        if end > rows:
-            raise RuntimeError(f"codebook_first_idx[{num_lods}] = {end} exceeds the {rows} rows of the table")
-        _first_idx_ok[key] = True
+        host = [int(v) for v in first_idx[:num_lods + 1].tolist()]
+        if host[num_lods] > rows:
+            raise RuntimeError(f"codebook_first_idx[{num_lods}] = {host[num_lods]} exceeds the {rows} rows of the table")
+        _first_idx_ok[key] = host
+    return _first_idx_ok[key]
 
 
 def hashgrid_interpolate(coords, codebook, first_idx, resolutions, codebook_bitwidth, zero_from_col=None):
@@ -329,7 +330,7 @@ def hashgrid_interpolate_backward(coords, grad_feats, codebook_shape, first_idx,
     first_idx = _need(first_idx, torch.int64, "codebook_first_idx")
     n, dim = coords.shape
     L, F = len(resolutions), codebook_shape[1]
-    _check_first_idx(first_idx, L, codebook_shape[0])
+    first_host = _check_first_idx(first_idx, L, codebook_shape[0])
     if zero_from_col is None:
         zero_from_col = L * F
     res_key, res_arr, res_ptr = _host_res(resolutions)
@@ -337,7 +338,7 @@ def hashgrid_interpolate_backward(coords, grad_feats, codebook_shape, first_idx,
     assert grad.dtype == torch.float32 and grad.is_contiguous()
     dt = _DTYPE_CODE[grad_feats.dtype]
     # scratch for the binned reduction; its record slots are sized from what earlier launches of this shape really filled
-    fit = _slot_fit(coords.device, dim, dt, F, res_key, codebook_bitwidth, zero_from_col) if n >= 4096 else None
+    fit = _slot_fit(coords.device, dim, dt, F, res_key, codebook_bitwidth, zero_from_col, n >= HASHGRID_EMIT_WIDE_MIN) if n >= 4096 else None
     scale_arr, scale_ptr = fit.scales(n) if fit is not None else (None, None)
     ws_bytes = int(lib.wisp_hashgrid_bwd_workspace_bytes(n, dim, dt, F, res_ptr, L, codebook_bitwidth, scale_ptr))
     ws = _bwd_workspace(coords.device, ws_bytes) if 0 < ws_bytes <= HASHGRID_BWD_WORKSPACE_LIMIT else None
@@ -363,7 +364,8 @@ def hashgrid_interpolate_backward(coords, grad_feats, codebook_shape, first_idx,
                                                            int(adamw["step"]), float(adamw.get("grad_scale", 1.0)),
                                                            ctypes.cast(cov, ctypes.c_void_p), _stream()),
                    "hashgrid_interpolate_bwd_adamw")
-            covered = list(cov)
+            # (levels stepped whole by the launch's tail workgroups report 2^62: rows as THIS table's first_idx spaces them)
+            covered = [min(int(c), first_host[l + 1] - first_host[l]) for l, c in enumerate(cov)]
     if fit is not None and ws is not None:
         fit.after_launch(n, res_ptr, scale_arr, scale_ptr, ws, ws_bytes)
     return grad if adamw is None else (grad, covered)
@@ -472,10 +474,17 @@ class _SlotFit:
         self.pending = dict(event=ev, cap=list(cap), base=list(base), ws_bytes=int(ws_bytes), at=self.calls)
 
 
-def _slot_fit(device, dim, dt, F, res, bitwidth, zero_from_col):
+# csrc/hashgrid.hip EQ_WIDE_MIN: launches of at least this many samples use the 1024-thread emitter (2048-sample pieces).  The
+# fullest-slot-to-mean ratio differs between the two emitter widths (1.6-2.1 x wide, 1.9-2.6 x narrow), so slot scales learned in
+# one width must not be applied to the other: the width is part of the fit's key.  tests/test_abi_and_host.py holds
+# this constant to the #define.
+HASHGRID_EMIT_WIDE_MIN = 1 << 20
+
+
+def _slot_fit(device, dim, dt, F, res, bitwidth, zero_from_col, wide=False):
     if not SLOT_FIT_ENABLED:
         return None
-    key = (device, _stream().value, dim, dt, F, res, bitwidth, zero_from_col)
+    key = (device, _stream().value, dim, dt, F, res, bitwidth, zero_from_col, bool(wide))
     fit = _slot_fits.get(key)
     if fit is None:
         fit = _slot_fits[key] = _SlotFit(device, dim, dt, F, res, bitwidth, zero_from_col)

@@ -499,6 +499,11 @@ class MultiviewTrainStep:
         self.fuse_grid_optimizer = os.environ.get("WISP_ADAM_IN_FLUSH", "1") != "0"
         self._fused_cover = None
         self.fused_elements_last = 0
+        # gradient accumulation: accumulate() runs forward + backward of a micro-batch and leaves its gradient ADDED in the flat
+        # buffer; the step() that follows exchanges and applies the MEAN over grad_accum_steps micro-batches - the arithmetic of
+        # grad_accum_steps data-parallel ranks on one GPU (each rank's loss is a mean over its own rays, the all-reduced sum is
+        # divided by the world size).  scripts/time_to_psnr.py emulates the 8-GPU weak-scaling batch with it.
+        self.grad_accum_steps = 1
         if os.environ.get("WISP_DIRECT_STEP", "1") != "0" and _DirectNeRFStep.supports(pipeline):
             d = _DirectNeRFStep(self)
             self._direct = d if d.ok else None
@@ -518,7 +523,7 @@ class MultiviewTrainStep:
         traffic runs under the reduce kernel's record walk."""
         d, f = self._direct, self.flat
         if (not self.fuse_grid_optimizer or d is None or not d.hash_fast or self.optimizer != 'adamw' or self.world > 1
-                or self.force_allreduce or not f.data.is_cuda or d.table.shape[1] != 2):
+                or self.force_allreduce or not f.data.is_cuda or d.table.shape[1] != 2 or getattr(self, "grad_accum_steps", 1) > 1):
             return None
         if 'optimizer_step' in self.__dict__ or type(self).optimizer_step is not MultiviewTrainStep.optimizer_step \
                 or type(self).reduce_and_update is not MultiviewTrainStep.reduce_and_update:
@@ -562,7 +567,7 @@ class MultiviewTrainStep:
         self.opt_steps += 1
         s = self._lr_scale()
         f = self.flat
-        gs = 1.0 / self.world
+        gs = 1.0 / (self.world * max(1, int(getattr(self, "grad_accum_steps", 1))))
         groups = []
         for g, lr in (("decoder", self.lr), ("grid", self.lr * self.grid_lr_weight), ("rest", self.lr)):
             a, b = f.ranges[g]
@@ -865,6 +870,24 @@ class MultiviewTrainStep:
         if self.rgb_loss_type == 'huber':
             return torch.nn.functional.smooth_l1_loss(rgb, gts, reduction='none').mean()
         raise NotImplementedError
+
+    def accumulate(self, rays: Rays, img_gts, jitter=None):
+        """Forward + backward of ONE micro-batch: its gradient is ADDED to the flat buffer, nothing is exchanged or applied.
+        Call grad_accum_steps - 1 times, then step() with the last micro-batch (set grad_accum_steps first: it is the divisor).
+        Returns (loss tensor, num_samples)."""
+        assert self.grad_accum_steps > 1, "set grad_accum_steps to the number of micro-batches per optimizer step first"
+        self._refuse_stale_master_forward()
+        if self._direct is not None and self.pipeline.nef.training:
+            with torch.no_grad():
+                loss, _ = self._direct.run(rays, img_gts, jitter, None, fused_update=None)
+        else:
+            self.wait_for_parameters()
+            kw = {} if jitter is None else {"jitter": jitter}
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.enable_amp):
+                rb = self.pipeline(rays=rays, lod_idx=None, channels=["rgb"], **kw)
+                loss = self.loss_fn(rb.rgb.float(), img_gts)
+            loss.backward()
+        return loss.detach(), self.pipeline.tracer.get_prev_num_samples()
 
     def step(self, rays: Rays, img_gts, jitter=None, prefetch: Optional[Rays] = None):
         """One optimisation step on this rank's ray shard.  Returns (loss tensor, num_samples).

@@ -1,6 +1,6 @@
 """Hidden-128 decoder backward (chain kernel + dW kernel) at 2 M samples: time and parameter gradients of ONE library variant
 (WISP_WIDE_DW=1: the barrier-per-stage dW kernel of rounds 2-4; default: the producer / consumer pipeline of round 5).
-usage: python scripts/bench_wide_dw.py OUT.pt     ->  prints the medians, saves grad_params / grad_feats for a bitwise comparison"""
+usage: python scripts/bench_wide_dw.py OUT.pt [S,S,...]     ->  prints the medians, saves grad_params / grad_feats for a bitwise comparison"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "kaolin-wisp_amd")]
@@ -9,7 +9,8 @@ import wisp._C as C
 dev = "cuda:0"
 out = sys.argv[1]
 res = {}
-for S in (2_000_000, 70_001):
+sizes = tuple(int(v) for v in sys.argv[2].split(',')) if len(sys.argv) > 2 else (2_000_000, 70_001)
+for S in sizes:
     g = torch.Generator(device=dev).manual_seed(0)
     d = torch.nn.functional.normalize(torch.randn(S, 3, device=dev, generator=g), dim=1)
     g_rgb = torch.randn(S, 3, device=dev, generator=g) * 1e-3

@@ -3,7 +3,8 @@
     WISP_BENCH_SENTINELS=1 rocprofv3 --kernel-trace --marker-trace --output-format csv -d DIR -o bench -- python bench.py ...
     python scripts/regime_stats.py DIR OUT_PREFIX            ->  OUT_PREFIX_<regime>_kernel_stats.csv (+ a summary on stdout)
 
-bench.py brackets every regime (headline = 2^21 samples per step, reference_regime = 2^18, dropin_regime = the unchanged trainer)
+bench.py brackets every regime (headline = the reference trainer's 2^18 samples per step, large_batch_regime = 2^21, dropin_regime = the
+unchanged trainer)
 with a float64 fill launch of SENTINEL_ELEMS x (tag + 1) elements on either side (bench._regime).  A window includes the regime's
 warm-up steps (they run the same launches); columns follow rocprofv3's own *_kernel_stats.csv.  VERDICT r4 weak-2(ii): the
 whole-command stats file averages the three regimes together; roofline.frac is reproducible from the headline table alone."""
@@ -14,7 +15,7 @@ import os
 import sys
 
 SENTINEL_ELEMS = 1_000_003
-TAGS = {0: "headline", 1: "reference_regime", 2: "dropin_regime"}
+TAGS = {0: "headline", 1: "large_batch_regime", 2: "dropin_regime"}
 
 
 def load(root):

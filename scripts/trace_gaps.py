@@ -1,6 +1,6 @@
 """Idle time between kernels of the steady-state training step, from a rocprofv3 --kernel-trace CSV.
 usage: python scripts/trace_gaps.py <dir with *_kernel_trace.csv> [marker kernel substring = hashgrid_fwd] [min marker us] [regime]
-`regime` (headline | reference_regime | dropin_regime) keeps only the launches between that regime's sentinel launches
+`regime` (headline | large_batch_regime | dropin_regime) keeps only the launches between that regime's sentinel launches
 (WISP_BENCH_SENTINELS=1; scripts/regime_stats.py) - without it the LAST steps of the command are taken, whatever regime ran last
 (that is how the drop-in loop's steps were once filed as the 2^18 regime's).
 Steps are delimited by the marker kernel; the last 5 complete steps are summarised: busy time, idle time and the idle

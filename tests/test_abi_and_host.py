@@ -734,7 +734,7 @@ def test_regime_stats_cuts_a_kernel_trace_into_one_table_per_bench_regime(tmp_pa
     spec = __import__("importlib.util").util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
     bench = __import__("importlib.util").util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    assert bench.SENTINEL_ELEMS == 1_000_003 and bench.REGIME_TAGS == {"headline": 0, "reference_regime": 1, "dropin_regime": 2}
+    assert bench.SENTINEL_ELEMS == 1_000_003 and bench.REGIME_TAGS == {"headline": 0, "large_batch_regime": 1, "dropin_regime": 2}
     fill = ("void at::native::vectorized_elementwise_kernel<4, at::native::FillFunctor<double>, std::array<char*, 1ul>>"
             "(int, at::native::FillFunctor<double>, std::array<char*, 1ul>)")
     rows, t = [], [0]
@@ -762,7 +762,7 @@ def test_regime_stats_cuts_a_kernel_trace_into_one_table_per_bench_regime(tmp_pa
     head = list(csv.DictReader(open(tmp_path / "out_headline_kernel_stats.csv")))
     assert {h["Name"]: (int(h["Calls"]), float(h["AverageNs"])) for h in head} == {"hashgrid_bwd_emit_q_kernel": (5, 240.0),
                                                                                   "hashgrid_bwd_reduce_kernel": (5, 160.0)}
-    ref = list(csv.DictReader(open(tmp_path / "out_reference_regime_kernel_stats.csv")))
+    ref = list(csv.DictReader(open(tmp_path / "out_large_batch_regime_kernel_stats.csv")))
     assert [(h["Name"], int(h["Calls"]), float(h["AverageNs"])) for h in ref] == [("hashgrid_bwd_emit_q_kernel", 4, 60.0)]
     assert not os.path.exists(tmp_path / "out_dropin_regime_kernel_stats.csv")
     # trace_gaps: a copy overlapping the forward is busy time, not a gap
@@ -847,3 +847,35 @@ def test_strip_dealt_buckets_are_a_bijection_with_exact_reciprocal_division():
         assert np.unique(b * csize + loc).size == entries
         load = np.bincount(b, minlength=buckets)
         assert load.max() - load.min() <= 64, (csize, entries, load.max(), load.min())
+
+
+def test_wide_dw2_roles_issue_the_same_barrier_sequence():
+    """the producer and consumer waves of wide_dw2_kernel run different functions whose barriers pair up by count
+    only.  Every barrier of the two loops is a named WD_STAGE_BARRIER(stage, phase): the two sequences must be identical - stages
+    5 .. 1, FILLED then DRAINED - neither loop may hold a bare __syncthreads(), and the kernel gives each role exactly one
+    prologue barrier."""
+    import re
+    src = open(os.path.join(ROOT, "kaolin-wisp_amd", "csrc", "nerf_mlp_wide.hip")).read()
+    prod = src[src.index("DEV void dw2_producer("):src.index("DEV void dw2_consumer(")]
+    cons = src[src.index("DEV void dw2_consumer("):src.index("wide_dw2_kernel(")]
+    kern = src[src.index("wide_dw2_kernel("):src.index("wide_reduce_kernel(")]
+    want = [(str(st), ph) for st in (5, 4, 3, 2, 1) for ph in ("FILLED", "DRAINED")]
+    for name, body in (("producer", prod), ("consumer", cons)):
+        loop = body[body.index("for (int64_t rd = rd0; rd < rounds; rd += step)"):]
+        got = re.findall(r"WD_STAGE_BARRIER\((\d), (FILLED|DRAINED)\)", loop)
+        assert got == want, (name, got)
+        assert "__syncthreads()" not in body, f"{name}: a barrier outside the named sequence"
+    role_a, role_b = kern[kern.index("if (wave < WD_TILES)"):kern.index("} else {")], kern[kern.index("} else {"):]
+    assert role_a.count("__syncthreads()") == 1 and role_b.count("__syncthreads()") == 1
+
+
+def test_slot_fit_key_follows_the_emitter_width_switch():
+    """slot scales learned with one emitter width must not be applied to the other - the Python constant that puts
+    the width into the fit's key is the kernel file's EQ_WIDE_MIN."""
+    import re
+    import wisp._C as C
+    src = open(os.path.join(ROOT, "kaolin-wisp_amd", "csrc", "hashgrid.hip")).read()
+    m = re.search(r"#define EQ_WIDE_MIN \(\(int64_t\)1 << (\d+)\)", src)
+    assert m and C.HASHGRID_EMIT_WIDE_MIN == 1 << int(m.group(1))
+    import inspect
+    assert "HASHGRID_EMIT_WIDE_MIN" in inspect.getsource(C.hashgrid_interpolate_backward)

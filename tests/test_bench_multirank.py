@@ -20,7 +20,7 @@ from test_distributed_gloo import _free_port
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench_worker(rank, world, port, out, break_reduce_scatter, precision):
+def _bench_worker(rank, world, port, out, break_reduce_scatter, precision, extra=()):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     os.environ.pop("WISP_SHARDED_OPTIM", None)
     sys.path[:0] = [ROOT, os.path.join(ROOT, "kaolin-wisp_amd")]
@@ -30,8 +30,8 @@ def _bench_worker(rank, world, port, out, break_reduce_scatter, precision):
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         res = bench.main(["--gpus", str(world), "--steps", "4", "--warmup", "1", "--pretrain", "3", "--precision", precision,
-                          "--target-samples", "65536", "--ref-target-samples", "16384", "--bank-rays", "8192", "--eval-rays", "512",
-                          "--dropin-steps", "0", "--no-pmc", "--no-configs", "--no-cpu-baseline"])
+                          "--target-samples", "16384", "--large-target-samples", "65536", "--bank-rays", "8192", "--eval-rays", "512",
+                          "--dropin-steps", "0", "--no-pmc", "--no-configs", "--no-cpu-baseline"] + list(extra))
     printed = [l for l in buf.getvalue().splitlines() if l.startswith("{")]
     out[rank] = {"printed": printed, "returned": res is not None, "sharded_env": os.environ.get("WISP_SHARDED_OPTIM")}
 
@@ -55,8 +55,9 @@ def test_bench_main_world2_gloo_prints_one_line_with_common_ray_counts(break_red
     assert line["config"]["parallelism"] == "ray-sharded dp2"
     R = line["config"]["rays_per_step_per_gpu"]
     # rank 0 saw 8 samples per probe ray, rank 1 twelve: the common count is rank 1's (the minimum), for both regimes
-    assert R == max(256, int(4096 * 65536 / (4096 * 12)))
-    assert line["reference_regime"]["rays_per_step_per_gpu"] == max(256, int(4096 * 16384 / (4096 * 12)))
+    assert R == max(256, int(4096 * 16384 / (4096 * 12)))
+    assert line["large_batch_regime"]["rays_per_step_per_gpu"] == max(256, int(4096 * 65536 / (4096 * 12)))
+    assert abs(line["large_batch_regime"]["lr_scale"] - 2.0) < 1e-9                 # sqrt(65536 / 16384)
     assert abs(line["value"] - R * 4 * 2 / (line["ms_per_step"] * 4e-3)) <= 1e-6 * line["value"]     # whole-job rays / max-over-ranks time
     comm = line["comm"]
     assert comm is not None and comm["selftest"]["rccl_ranks"] == 2 and comm["selftest"]["allreduce_ok"] is True
@@ -71,8 +72,26 @@ def test_bench_main_world2_gloo_prints_one_line_with_common_ray_counts(break_red
     assert line["psnr_db"] is not None and line["prune"]["ms"] >= 0.0
 
 
-STANDIN_ARGS = ["--steps", "3", "--warmup", "1", "--pretrain", "2", "--precision", "fp32", "--target-samples", "65536",
-                "--ref-target-samples", "16384", "--bank-rays", "8192", "--eval-rays", "512", "--dropin-steps", "0", "--no-pmc",
+def test_bench_main_world2_gloo_strong_scaling_splits_the_global_batch():
+    """`--scaling strong` keeps the GLOBAL batch at --target-samples and gives every rank 1/N of it (the
+    reference trainer's batch stays the reference's as GPUs are added): half the rays per rank of the weak run above, both
+    regimes, and the line says so."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bench_worker, args=(world, _free_port(), out, False, "fp32", ("--scaling", "strong")), nprocs=world, join=True)
+    line = json.loads(dict(out)[0]["printed"][0])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    cfg = line["config"]
+    assert cfg["target_samples_per_step"] == 16384 // 2 and cfg["global_target_samples_per_step"] == 16384
+    assert cfg["rays_per_step_per_gpu"] == max(256, int(4096 * (16384 // 2) / (4096 * 12)))
+    assert line["large_batch_regime"]["rays_per_step_per_gpu"] == max(256, int(4096 * (65536 // 2) / (4096 * 12)))
+    R = cfg["rays_per_step_per_gpu"]
+    assert abs(line["value"] - R * 4 * 2 / (line["ms_per_step"] * 4e-3)) <= 1e-6 * line["value"]      # still the whole job's rays / s
+
+
+STANDIN_ARGS = ["--steps", "3", "--warmup", "1", "--pretrain", "2", "--precision", "fp32", "--target-samples", "16384",
+                "--large-target-samples", "65536", "--bank-rays", "8192", "--eval-rays", "512", "--dropin-steps", "0", "--no-pmc",
                 "--no-configs", "--no-cpu-baseline"]
 
 

@@ -1190,3 +1190,24 @@ def test_tracer_as_one_autograd_node_equals_the_modular_graph_bit_for_bit(amp, m
             assert float((ga[n] - gb[n]).abs().max()) <= 2e-6 * sc, n
         else:
             assert torch.equal(ga[n], gb[n]), n
+
+
+def test_hidden_128_pipelined_dw_kernel_equals_the_barrier_per_stage_kernel_bitwise(tmp_path):
+    """wide_dw2_kernel (producer / consumer waves, barriers paired by count) against the one-role kernel it replaced
+    (WISP_WIDE_DW=1; read once per process, hence the child): the same sums in the same order - parameter gradients and
+    feature gradients bit for bit, at a sample count that leaves ragged rounds."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("", "1"):
+        out = str(tmp_path / f"dw{mode or 0}.pt")
+        env = dict(os.environ, WISP_WIDE_DW=mode)
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "bench_wide_dw.py"), out, "70001,300007"], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        outs[mode] = torch.load(out)
+    for S in outs[""]:
+        gp_a, gf_a = outs[""][S]
+        gp_b, gf_b = outs["1"][S]
+        assert float(gp_a.abs().max()) > 0 and torch.equal(gp_a, gp_b) and torch.equal(gf_a, gf_b), S
