@@ -187,10 +187,10 @@ def collective_selftest(dev, rank):
     return ok
 
 
-def hidden128_line(args, dev, pipe, batch, size_batch, steps=30):
+def hidden128_line(args, dev, pipe, batch, target_samples, steps=30):
     """nerf_hash.yaml with hidden_dim 128 - the reference's best published row (docs/pages/app_nerf.md:185-192) - on the
     occupancy the main run has learned: a fresh model of that width over a copy of the current octree, a few steps at the
-    headline batch size (direct-issue step under amp, like the headline)."""
+    given batch size (direct-issue step under amp, like the headline)."""
     from wisp.accelstructs import OctreeAS
     from wisp.models import Pipeline
     from wisp.models.grids import HashGrid
@@ -207,7 +207,7 @@ def hidden128_line(args, dev, pipe, batch, size_batch, steps=30):
                                   prune_min_density=None).to(dev)
         wide = Pipeline(nef, PackedRFTracer(raymarch_type='ray', num_steps=args.num_steps, step_size=1.0, bg_color=(0.0, 0.0, 0.0)))
         tr = MultiviewTrainStep(wide, lr=1e-3, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, rgb_loss_type='huber',
-                                prune_every=-1, target_sample_size=args.target_samples, max_rays=2 ** 18, enable_amp=args.precision == "bf16")
+                                prune_every=-1, target_sample_size=target_samples, max_rays=2 ** 18, enable_amp=args.precision == "bf16")
         probe, _ = batch(4096)
         rm = grid.raymarch(probe, level=grid.active_lods[-1], num_samples=args.num_steps, raymarch_type='ray')
         wide.tracer.prev_num_samples = rm.samples.shape[0]
@@ -946,7 +946,10 @@ def main(argv=None):
             # the other BASELINE.json configurations + the reference's best published row (hidden 128), a few steps each
             import bench_configs
             out["configs"] = bench_configs.secondary_lines(args, dev)
-            out["configs"]["hidden128"] = hidden128_line(args, dev, pipe, batch, size_batch)
+            out["configs"]["hidden128"] = hidden128_line(args, dev, pipe, batch, args.target_samples)
+            if args.large_target_samples > 0 and "error" not in out["configs"]["hidden128"]:
+                big = hidden128_line(args, dev, pipe, batch, args.large_target_samples)
+                out["configs"]["hidden128"]["large_batch_regime"] = big
         if world == 1 and args.quality_budget > 0:
             out["quality"] = quality_table(args, dev, (bank_o, bank_d, bank_rgb), amp, large_lr)
         if world == 1 and args.dp_steps > 0 and not dist.is_initialized():

@@ -417,10 +417,27 @@ def run_nglod(args, dev):
 
 def secondary_lines(args, dev, budget_s=6.0):
     """Short in-process runs of the other BASELINE.json configurations for bench.py's default line (`configs`): same code as
-    `--config ...`, a handful of steps each, only the summary fields.  The full lines (kernel tables) come from `--config`."""
-    import copy
+    `--config ...`, a handful of steps each, only the summary fields.  The full lines (kernel tables) come from `--config`.
+    The radiance-field configs run at the reference trainer's batch (`--target-samples`, 2^18 packed samples per step: `value`) and
+    again at `--large-target-samples` (`large_batch_regime`: the figure these lines carried until round 5)."""
     import types
     out = {}
+
+    def summary(r, t0):
+        top = list(r["kernels"].items())[:4]
+        line = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "roofline") if k in r}
+        line["workload"] = r["config"]["workload"]
+        for k in ("gpu_busy_fraction", "gpu_busy_fraction_eager", "samples_per_sec", "psnr_db_train_rays", "eager", "issue", "dropin_regime"):
+            if k in r:
+                line[k] = r[k]
+        if "samples_per_step" in r["config"]:
+            line["samples_per_step"] = r["config"]["samples_per_step"]
+        if "render" in r:
+            line["render"] = {k: r["render"][k] for k in ("rays", "ms", "rays_per_sec", "marching_steps")}
+        line["top_launches"] = {k: {"avg_ms": v["avg_ms"], "share": v["share"], "launches": v["launches"]} for k, v in top}
+        line["wall_s"] = time.perf_counter() - t0
+        return line
+
     for name, fn, over in (("v8", run_v8, dict(pretrain=30, steps=30, warmup=3)),
                            ("vqad", run_vqad, dict(pretrain=30, steps=30, warmup=3)),
                            ("nglod", run_nglod, dict(pretrain=40, steps=200, warmup=5))):
@@ -429,21 +446,16 @@ def secondary_lines(args, dev, budget_s=6.0):
             setattr(a, k, v)
         t0 = time.perf_counter()
         try:
-            r = fn(a, dev)
+            out[name] = summary(fn(a, dev), t0)
+            large = int(getattr(args, "large_target_samples", 0) or 0)
+            if name != "nglod" and large > 0 and large != a.target_samples:
+                a.target_samples = large
+                t1 = time.perf_counter()
+                big = summary(fn(a, dev), t1)
+                out[name]["large_batch_regime"] = {k: big[k] for k in ("value", "unit", "ms_per_step", "samples_per_step", "roofline",
+                                                                        "gpu_busy_fraction", "top_launches", "wall_s") if k in big}
         except Exception as e:                                  # a secondary line must not take the headline down
             out[name] = {"error": f"{type(e).__name__}: {e}"}
-            continue
-        top = list(r["kernels"].items())[:4]
-        line = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "roofline") if k in r}
-        line["workload"] = r["config"]["workload"]
-        for k in ("gpu_busy_fraction", "gpu_busy_fraction_eager", "samples_per_sec", "psnr_db_train_rays", "eager", "issue", "dropin_regime"):
-            if k in r:
-                line[k] = r[k]
-        if "render" in r:
-            line["render"] = {k: r["render"][k] for k in ("rays", "ms", "rays_per_sec", "marching_steps")}
-        line["top_launches"] = {k: {"avg_ms": v["avg_ms"], "share": v["share"], "launches": v["launches"]} for k, v in top}
-        line["wall_s"] = time.perf_counter() - t0
-        out[name] = line
         torch.cuda.empty_cache()
     return out
 

@@ -1211,3 +1211,51 @@ def test_hidden_128_pipelined_dw_kernel_equals_the_barrier_per_stage_kernel_bitw
         gp_a, gf_a = outs[""][S]
         gp_b, gf_b = outs["1"][S]
         assert float(gp_a.abs().max()) > 0 and torch.equal(gp_a, gp_b) and torch.equal(gf_a, gf_b), S
+
+
+@pytest.mark.parametrize("direct", [True, False])
+def test_gradient_accumulation_equals_one_step_over_the_union_of_the_micro_batches(direct, monkeypatch):
+    """MultiviewTrainStep.accumulate (scripts/time_to_psnr.py emulates the 8-GPU weak-scaling batch with it): two micro-batches of R
+    rays each, accumulated, then applied with grad_accum_steps = 2 - the mean of the two per-batch mean losses - against ONE
+    step over the 2 R rays (the mean over the union): same gradient up to summation order, same parameters after the
+    optimizer step; and the optimizer of the hash table is NOT folded into the backward while a gradient is being accumulated."""
+    from wisp.core import Rays
+    from wisp.models import Pipeline
+    from wisp.tracers import PackedRFTracer
+    from wisp.trainers import MultiviewTrainStep
+    import copy
+    if not direct:
+        monkeypatch.setenv("WISP_DIRECT_STEP", "0")
+    nef, _, _ = _build_pair(lods=16)
+    nef2 = copy.deepcopy(nef)
+    o, d = make_rays(600, 291)
+    jit = cuda(np.random.default_rng(292).uniform(size=(600, 96)).astype(np.float32))
+    gts = cuda(np.random.default_rng(293).uniform(size=(600, 3)).astype(np.float32))
+    mk = lambda a, b: Rays(cuda(o[a:b]), cuda(d[a:b]), dist_min=1.0, dist_max=5.0)
+    tr1 = MultiviewTrainStep(Pipeline(nef, PackedRFTracer(raymarch_type='ray', num_steps=96, bg_color=(0, 0, 0))), prune_every=-1)
+    tr2 = MultiviewTrainStep(Pipeline(nef2, PackedRFTracer(raymarch_type='ray', num_steps=96, bg_color=(0, 0, 0))), prune_every=-1)
+    assert (tr1._direct is not None) == direct
+    tr1.grad_accum_steps = 2
+    assert tr1._fused_update_args() is None
+    grads = {}
+    for name, tr in (("accum", tr1), ("union", tr2)):
+        inner = tr.optimizer_step
+
+        def snap(*a, tr=tr, name=name, inner=inner, **kw):
+            grads[name] = tr.flat.grad.clone()
+            return inner(*a, **kw)
+        tr.optimizer_step = snap
+    la, sa = tr1.accumulate(mk(0, 300), gts[:300], jitter=jit[:300])
+    lb, sb = tr1.step(mk(300, 600), gts[300:], jitter=jit[300:])
+    lu, su = tr2.step(mk(0, 600), gts, jitter=jit)
+    assert sa + sb == su
+    assert abs(0.5 * (float(la) + float(lb)) - float(lu)) <= 1e-6 * max(1.0, abs(float(lu)))
+    g1, g2 = grads["accum"].cpu().numpy() * 0.5, grads["union"].cpu().numpy()      # (the optimizer divides by grad_accum_steps)
+    np.testing.assert_allclose(g1, g2, rtol=0, atol=2e-6 * float(np.abs(g2).max()))
+    tr1.wait_for_parameters(); tr2.wait_for_parameters()
+    p1, p2 = tr1.flat.data.cpu().numpy(), tr2.flat.data.cpu().numpy()
+    # (Adam's first step moves every parameter with a non-zero gradient by ~lr whatever its size: compare where the gradient is
+    #  clearly non-zero, i.e. where add-order noise cannot flip a sign)
+    sure = np.abs(g2) > 1e-4 * float(np.abs(g2).max())
+    np.testing.assert_allclose(p1[sure], p2[sure], rtol=0, atol=2e-5)
+    assert float(tr1.flat.grad.abs().max()) == 0.0                                 # consumed and zeroed
