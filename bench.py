@@ -712,6 +712,8 @@ def main(argv=None):
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        if timing_sink is not None and hasattr(trainer, "native_timing_into"):
+            trainer.native_timing_into(timing_sink)               # (the natively issued steps time their entry points themselves)
         C.TIMING = None
         prunes = sum(1 for it in range(it0, it0 + steps) if it > 1 and it % trainer.prune_every == 0)
         if world > 1:

@@ -27,7 +27,9 @@ enum {
     WISP_OK = 0,
     WISP_ERR_INVALID = -1,   /* bad argument (null pointer, unsupported dtype / dim / level) */
     WISP_ERR_LAUNCH = -2,    /* hipGetLastError() after a launch; see wisp_last_error() */
-    WISP_ERR_UNSUPPORTED = -3
+    WISP_ERR_UNSUPPORTED = -3,
+    WISP_ERR_CAPACITY = -4   /* wisp_nerf_step_*: the batch does not fit the buffers the step was created for (or is empty): nothing
+                                was changed; the caller takes this batch through the per-op entry points */
 };
 
 const char* wisp_last_error(void);
@@ -35,7 +37,7 @@ const char* wisp_last_error(void);
  * passes, raytrace nugget cache, optimizer kinds, per-ray view codes, corner query, decoded codebook rows; 3 = round 3: per-level
  * slot scales of the hash-grid backward; 4 = round 4: workspace + row counts of the order-free trilinear / codebook backward.
  * Entry points that are only ADDED - wisp_spc_query_chain, wisp_composite_loss, wisp_codebook_trilinear_multi_bwd,
- * wisp_sdf_train_step, wisp_hashgrid_grad_coords, wisp_host_reader_* - do not bump it). */
+ * wisp_sdf_train_step, wisp_hashgrid_grad_coords, wisp_host_reader_*, wisp_nerf_step_* - do not bump it). */
 int wisp_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -593,6 +595,95 @@ void* wisp_host_reader_create(void);
 int wisp_host_reader_issue(void* reader, const int64_t* src, wisp_stream_t stream);
 int wisp_host_reader_wait(void* reader, int64_t* value /* HOST */);
 void wisp_host_reader_destroy(void* reader);
+
+/* ------------------------------------------------------------------------------------------------
+ * One training step of the nerf_hash.yaml shape issued from native code (round 6): what MultiviewTrainer.step
+ * (wisp/trainers/multiview_trainer.py:111-180) runs per iteration - PackedRFTracer.trace (packed_rf_tracer.py:84-181) over
+ * OctreeAS._raymarch_ray (octree_as.py:247-309), HashGrid.interpolate (hash_grid.py:205-233), NeuralRadianceField.rgba
+ * (nerf.py:219-264), compositing, the rgb loss, backward and the optimizer (base_trainer.py:205-246) - as ONE call: the function
+ * issues the per-op entry points of this header in the order the Python host layer does (trainers/multiview_trainer.py::
+ * _DirectNeRFStep.run), on buffers carved out of one caller-owned workspace.  Same kernels, same arguments, same bits; what it saves
+ * is the host: ~0.2 ms of interpreter time per step against ~0.3 ms of kernels at the reference trainer's 2^18 samples per step.
+ *
+ * All pointers of the config are BORROWED for the life of the handle (device pointers unless marked host; the two host arrays are
+ * copied).  struct_bytes = sizeof the struct as the caller compiled it (checked against the library's: wisp_nerf_step_config_bytes).
+ * A batch is COUNTED first (occupancy test of every candidate + per-ray offsets + an asynchronous read-back of the sample total,
+ * wisp_host_reader_*) into one of two slots - normally one step ahead, by the `next_*` arguments of wisp_nerf_step_run - and RUN
+ * later from that slot; the ray tensors given to the count must stay alive and unchanged until the run.  Jitter comes from the
+ * counter-based generator keyed by `seed` (as in wisp_raymarch_ray_count / _emit with jitter = NULL).
+ * Shapes covered: 'ray' march, two-feature 'cat' table of <= 16 levels read through a 16-bit copy (dtype_table), hidden 64, four
+ * view frequencies (the per-ray view code kernels), in_dim = num_lods * 2.  Anything else: the per-op entry points. */
+typedef struct wisp_nerf_step_config {
+    int64_t struct_bytes;
+    /* occupancy structure at `level` (OctreeAS: octree_as.py:42-63) */
+    const uint32_t* occ_bits;        /* bitfield of `level` (wisp_spc_build_bitfield) or NULL */
+    const uint8_t* octree;
+    const int32_t* exsum;
+    const uint32_t* coarse_bits;     /* optional coarser bitfield (see wisp_raymarch_ray_count) or NULL */
+    /* hash table */
+    const void* table_lookup;        /* dtype_table [rows, feature_dim]: what the forward gathers from (the bf16 shadow under amp) */
+    const int64_t* first_idx;        /* device i64 [num_lods + 1] */
+    const int64_t* first_idx_host;   /* HOST copy of the same */
+    const int32_t* resolutions;      /* HOST i32 [num_lods] */
+    float* table_param;              /* fp32 master table / its gradient / AdamW moments / bf16 copy (may be NULL): the folded update */
+    float* table_grad;
+    float* table_exp_avg;
+    float* table_exp_avg_sq;
+    void* table_shadow;
+    /* decoder: packed parameters as wisp_nerf_mlp_* take them, and where their gradient is accumulated */
+    const float* dec_params;
+    float* dec_grad;
+    /* the flat optimizer buffers all of the above live in, and their parameter groups (elements; base_trainer.py:216-235) */
+    float* flat_param;
+    float* flat_grad;
+    float* flat_exp_avg;
+    float* flat_exp_avg_sq;
+    void* grid_shadow;               /* bf16 copy of the grid group [grid_len] or NULL */
+    int64_t decoder_begin, decoder_len, grid_begin, grid_len, rest_begin, rest_len;
+    int64_t table_offset;            /* element offset of the hash table inside the flat buffers */
+    int64_t max_rays, max_samples;   /* capacities the workspace is sized for */
+    int32_t level, coarse_level, num_samples /* candidates per ray */, loss_kind /* 0 huber, 1 l2, 2 l1 */;
+    int32_t dtype_table, num_lods, feature_dim, bitwidth;
+    int32_t zero_from_col, in_dim, hidden, view_freqs;
+    float near, range /* fl32(dist_max - dist_min) */;
+    float bg[3];
+    float reserved;
+} wisp_nerf_step_config;
+
+typedef struct wisp_nerf_step_hyper {
+    int64_t struct_bytes;
+    int64_t step;                    /* optimizer step number, 1-based (bias correction) */
+    float lr_decoder, lr_grid, lr_rest, weight_decay, beta1, beta2, eps, grad_scale;
+    int32_t optimizer;               /* 0: none (gradients are left accumulated: the caller exchanges / applies them);
+                                        1: one AdamW launch over all groups; 2: the table's AdamW folded into its backward
+                                        (wisp_hashgrid_interpolate_bwd_adamw) + one launch for everything else */
+    int32_t reserved;
+} wisp_nerf_step_hyper;
+
+int64_t wisp_nerf_step_config_bytes(void);
+int64_t wisp_nerf_step_workspace_bytes(const wisp_nerf_step_config* cfg);
+void* wisp_nerf_step_create(const wisp_nerf_step_config* cfg, void* workspace, int64_t workspace_bytes);
+/* The same handle over other buffers of the same shapes and capacities (a prune replaces the octree and its bitfields): workspace,
+ * read-back slots and timing events stay; batches counted against the old configuration are dropped. */
+int wisp_nerf_step_reconfigure(void* step, const wisp_nerf_step_config* cfg);
+void wisp_nerf_step_destroy(void* step);
+int wisp_nerf_step_count(void* step, int slot, const float* origins, const float* dirs, int64_t num_rays, uint64_t seed,
+                         wisp_stream_t stream);
+/* Runs the batch counted into `slot`: waits for its sample total (host), emits the samples, counts the NEXT batch into the other
+ * slot when next_origins is given, then forward, loss, backward and - hp->optimizer - the update.  gts: f32 [num_rays, 3].
+ * level_cap_scale / hashgrid_workspace(_bytes): as for wisp_hashgrid_interpolate_bwd (the caller keeps the slot statistics).
+ * Outputs (host): *num_samples; covered_rows [num_lods] (hp->optimizer == 2, else zeros; may be NULL); *loss = DEVICE pointer to
+ * the f32 loss of this step (a ring of 8: valid until the eighth step after this one).  record_timing: bracket the four roofline
+ * entry points with HIP events on `stream` (read them with wisp_nerf_step_read_timing after a synchronize).
+ * WISP_ERR_CAPACITY: the batch holds more than max_samples samples, or none - the slot is consumed, nothing else was touched. */
+int wisp_nerf_step_run(void* step, int slot, const float* gts, const float* next_origins, const float* next_dirs,
+                       int64_t next_num_rays, uint64_t next_seed, const wisp_nerf_step_hyper* hp,
+                       const float* level_cap_scale, void* hashgrid_workspace, int64_t hashgrid_workspace_bytes,
+                       int record_timing, int64_t* num_samples, int64_t* covered_rows, float** loss, wisp_stream_t stream);
+/* ms: host f32 [max_steps][4] = hashgrid_fwd, nerf_mlp_fwd, nerf_mlp_bwd, hashgrid_bwd of every timed step since the last read;
+ * units: host i64 [max_steps] packed samples of those steps; *num_steps: how many were written.  Resets the record (which holds at
+ * most 512 steps: later steps go untimed until it is read). */
+int wisp_nerf_step_read_timing(void* step, int max_steps, float* ms, int64_t* units, int* num_steps);
 
 #ifdef __cplusplus
 }

@@ -477,6 +477,14 @@ hashgrid_bwd_kernel(const float* __restrict__ coords, int64_t n, const T* __rest
 #endif
 #define EQ_WIDE 1024
 #define EQ_WIDE_MIN ((int64_t)1 << 20)
+//   EQ_SMALL    (1024 threads, ONE 64-sample group per wave: 1024-sample pieces, one workgroup per CU) - launches below
+//                WISP_HG_EMIT_SMALL_BELOW samples (default EQ_WIDE_MIN; 0 = never): at the reference trainer's 2^18 samples the 512-thread form makes 256
+//                workgroups of one piece each - two waves per SIMD walking two groups x 15 levels one after the other, a pass whose
+//                latency nothing hides; the same 256 pieces as 16 waves of one group each put four waves on a SIMD.
+//                (256 threads x 2 groups - 512-sample pieces, twice the slots - was measured: pair 143 -> 201 us, the reduce
+//                kernel pays for every slot.)
+#define EQ_SMALL 1024
+#define EQ_SMALL_GROUPS 1
 #define RD_THREADS 1024
 #define BIN_MAX_CHUNKS 1024
 #ifndef HG_ACC_PLANES
@@ -661,7 +669,7 @@ hashgrid_bwd_emit_kernel(const float* __restrict__ coords, int64_t n, const T* _
 //     (tail, corner) entry: ceil(tails / 8) passes instead of 8.  LDS instructions of one wave execute in order, so the
 //     hand-over needs no barrier.
 #define EQ_MAX_ROW 16
-template <typename T, int DIM, int THREADS>
+template <typename T, int DIM, int THREADS, int GROUPS = 2>
 __global__ void __launch_bounds__(THREADS, EM_MIN_WAVES)
 hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T* __restrict__ grad_feats,
                            const int64_t* __restrict__ first_idx, HashLevels lv, LevelList levels, int num_lods,
@@ -672,8 +680,7 @@ hashgrid_bwd_emit_q_kernel(const float* __restrict__ coords, int64_t n, const T*
     typedef RecordCodec<T, F> Codec;
     static_assert(Codec::COMPACT, "two 16-bit features per level");
     constexpr int RW = Codec::RW;
-    constexpr int GROUPS = 2;                            // 64-sample groups per wave
-    constexpr int TILE = THREADS * GROUPS;               // samples per piece
+    constexpr int TILE = THREADS * GROUPS;               // samples per piece (GROUPS = 64-sample groups per wave)
     constexpr int QROW = 3 * NC + 1;                     // dwords per parked tail
     extern __shared__ __attribute__((aligned(16))) uint32_t em_smem[];
     const int total_ranks = bins.rank_base[levels.n];
@@ -804,11 +811,11 @@ static inline size_t queue_emitter_lds(int total_ranks, int dim, int threads) {
 }
 // Workgroups of the queue emitter one CU holds at once (registers + LDS; asked from the runtime, once per instance; the
 // half and bf16 instances are the same code).  The rank counters vary a little with the level layout: 1024 is a safe figure.
-template <typename T, int DIM, int THREADS>
+template <typename T, int DIM, int THREADS, int GROUPS = 2>
 static int queue_emitter_residency() {
     static const int v = [] {
         int nb = 0;
-        auto eq = hashgrid_bwd_emit_q_kernel<T, DIM, THREADS>;
+        auto eq = hashgrid_bwd_emit_q_kernel<T, DIM, THREADS, GROUPS>;
         const size_t lds = queue_emitter_lds(1024, DIM, THREADS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(eq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eq, THREADS, lds) != hipSuccess || nb <= 0) nb = THREADS >= 1024 ? 1 : 2;
@@ -1307,6 +1314,15 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
     BinPlan p{};
     const int corners = 1 << dim;
     int64_t centries = 16384 / feature_dim;               // chunk entries: 64 KiB as fp32, 128 KiB as 64-bit fixed point
+    {   // (A/B switch: WISP_HG_CHUNK_ENTRIES_BELOW="<entries>:<n>" uses smaller buckets for launches below n samples)
+        static const struct { int64_t entries, below; } alt = [] {
+            const char* e = getenv("WISP_HG_CHUNK_ENTRIES_BELOW");
+            long long a = 0, b = 0;
+            if (e && sscanf(e, "%lld:%lld", &a, &b) == 2 && a >= 256 && b > 0) return decltype(alt){(int64_t)a, (int64_t)b};
+            return decltype(alt){0, 0};
+        }();
+        if (alt.entries > 0 && n < alt.below && alt.entries < centries) centries = alt.entries;
+    }
     while (((int64_t)1 << (p.chunk_shift + 1)) <= centries) ++p.chunk_shift;
     // "tile" = what ONE emitting workgroup sends: EM_TILE samples, or (queue emitter) several EM_TILE pieces when the grid is
     // capped at the number of workgroups the chip holds at once - fewer, fuller slots for the reduce kernel to walk
@@ -1396,6 +1412,13 @@ static BinPlan bin_plan(int64_t n, const HashLevels& lv, const LevelList& levels
 }
 
 static bool wide_emitter_enabled() { static const bool v = env_flag("WISP_HG_EMIT_WIDE", true); return v; }
+// launches below this many samples use the one-group-per-wave emitter (EQ_SMALL): measured on the bench's own step at 2^18 / 2^19 /
+// 10^6 samples per step: pair 145 -> 137 / 176 -> 171 / 249 -> 248 us (profiles/r06_ab_emit_small*.txt); WISP_HG_EMIT_SMALL_BELOW=0
+// keeps the 512-thread form
+static int64_t small_emitter_below() {
+    static const int64_t v = [] { const char* e = getenv("WISP_HG_EMIT_SMALL_BELOW"); return e ? (int64_t)atoll(e) : EQ_WIDE_MIN; }();
+    return v;
+}
 // THE plan of a backward launch of this shape - used by the launcher, the workspace query and the slot statistics alike: the queue
 // emitter's capped grid for two 16-bit features, in its wide form from EQ_WIDE_MIN samples on
 static BinPlan plan_for(int64_t n, const HashLevels& lv, const LevelList& levels, int coord_dim, int feature_dim, int dtype,
@@ -1403,12 +1426,15 @@ static BinPlan plan_for(int64_t n, const HashLevels& lv, const LevelList& levels
     const bool compact = dtype != WISP_F32 && feature_dim == 2;
     if (compact && queue_emitter_enabled() && num_lods <= EQ_MAX_ROW) {
         const bool wide = wide_emitter_enabled() && n >= EQ_WIDE_MIN;
+        const bool small = !wide && n < small_emitter_below();
         int resident;
         if (wide) resident = coord_dim == 3 ? queue_emitter_residency<__hip_bfloat16, 3, EQ_WIDE>() : queue_emitter_residency<__hip_bfloat16, 2, EQ_WIDE>();
+        else if (small) resident = coord_dim == 3 ? queue_emitter_residency<__hip_bfloat16, 3, EQ_SMALL, EQ_SMALL_GROUPS>() : queue_emitter_residency<__hip_bfloat16, 2, EQ_SMALL, EQ_SMALL_GROUPS>();
         else resident = coord_dim == 3 ? queue_emitter_residency<__hip_bfloat16, 3, EQ_THREADS>() : queue_emitter_residency<__hip_bfloat16, 2, EQ_THREADS>();
-        const int threads = wide ? EQ_WIDE : EQ_THREADS;
-        BinPlan p = bin_plan(n, lv, levels, feature_dim, tsize, coord_dim, 2, queue_emitter_grid_cap(resident), cap_scale, (int64_t)threads * 2);
-        p.emit_threads = threads;
+        const int threads = wide ? EQ_WIDE : small ? EQ_SMALL : EQ_THREADS;
+        BinPlan p = bin_plan(n, lv, levels, feature_dim, tsize, coord_dim, 2, queue_emitter_grid_cap(resident), cap_scale,
+                             (int64_t)threads * (small ? EQ_SMALL_GROUPS : 2));
+        p.emit_threads = small ? -EQ_SMALL : threads;              // (negative: the one-group-per-wave form)
         return p;
     }
     return bin_plan(n, lv, levels, feature_dim, tsize, coord_dim, compact ? 2 : 1 + feature_dim, 0, cap_scale);
@@ -1450,12 +1476,18 @@ static int launch_bwd(const float* coords, int64_t n, const void* grad_feats, co
     bool launched = false;
     if constexpr (RecordCodec<T, F>::COMPACT) {
         if (plan.emit_threads != 0) {
-            const size_t q_lds = queue_emitter_lds(plan.total_ranks, DIM, plan.emit_threads);
+            const size_t q_lds = queue_emitter_lds(plan.total_ranks, DIM, plan.emit_threads < 0 ? -plan.emit_threads : plan.emit_threads);
             // (one WISP_ALLOW_LDS per kernel instance: the grant is remembered per call site)
             if (plan.emit_threads == EQ_WIDE) {
                 auto eq = hashgrid_bwd_emit_q_kernel<T, DIM, EQ_WIDE>;
                 if (const hipError_t e = WISP_ALLOW_LDS(eq, q_lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
                 hipLaunchKernelGGL(eq, dim3((unsigned)plan.ntiles), dim3(EQ_WIDE), q_lds, s,
+                                   coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
+                                   plan.chunk_shift, plan.bins, counts, records, grad_codebook);
+            } else if (plan.emit_threads == -EQ_SMALL) {
+                auto eq = hashgrid_bwd_emit_q_kernel<T, DIM, EQ_SMALL, EQ_SMALL_GROUPS>;
+                if (const hipError_t e = WISP_ALLOW_LDS(eq, q_lds)) return wisp_fail(WISP_ERR_LAUNCH, __func__, hipGetErrorString(e));
+                hipLaunchKernelGGL(eq, dim3((unsigned)plan.ntiles), dim3(EQ_SMALL), q_lds, s,
                                    coords, n, (const T*)grad_feats, first_idx, lv, active, num_lods, tsize, pow2, zero_from_col,
                                    plan.chunk_shift, plan.bins, counts, records, grad_codebook);
             } else {

@@ -110,11 +110,21 @@ SIGNATURES = {
     "wisp_host_reader_issue": [c_vp, c_vp, c_vp],
     "wisp_host_reader_wait": [c_vp, c_vp],
     "wisp_host_reader_destroy": [c_vp],
+    "wisp_nerf_step_config_bytes": [],
+    "wisp_nerf_step_workspace_bytes": [c_vp],
+    "wisp_nerf_step_create": [c_vp, c_vp, c_i64],
+    "wisp_nerf_step_reconfigure": [c_vp, c_vp],
+    "wisp_nerf_step_destroy": [c_vp],
+    "wisp_nerf_step_count": [c_vp, c_i32, c_vp, c_vp, c_i64, c_u64, c_vp],
+    "wisp_nerf_step_run": [c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_u64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "wisp_nerf_step_read_timing": [c_vp, c_i32, c_vp, c_vp, c_vp],
     "wisp_last_error": [],
     "wisp_abi_version": [],
 }
 _RESTYPES = {"wisp_nerf_mlp_bwd_workspace_bytes": c_i64, "wisp_spc_bwd_workspace_bytes": c_i64, "wisp_sdf_train_scratch_bytes": c_i64, "wisp_hashgrid_bwd_workspace_bytes": c_i64, "wisp_scan_workspace_bytes": c_i64, "wisp_nerf_mlp_param_count": c_i64, "wisp_nerf_mlp_workspace_floats": c_i64,
-             "wisp_last_error": ctypes.c_char_p, "wisp_host_reader_create": c_vp, "wisp_host_reader_destroy": None}
+             "wisp_last_error": ctypes.c_char_p, "wisp_host_reader_create": c_vp, "wisp_host_reader_destroy": None,
+             "wisp_nerf_step_config_bytes": c_i64, "wisp_nerf_step_workspace_bytes": c_i64, "wisp_nerf_step_create": c_vp,
+             "wisp_nerf_step_destroy": None}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here == header/library mismatch: fail loudly
@@ -125,6 +135,35 @@ ABI_VERSION = 4                        # include/wisp_hip.h: wisp_abi_version();
 if lib.wisp_abi_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} implements ABI version {lib.wisp_abi_version()}, this binding is written for version "
                       f"{ABI_VERSION}: rebuild the library (make -C {os.path.dirname(LIB_PATH)})")
+
+
+WISP_ERR_CAPACITY = -4                 # include/wisp_hip.h
+
+
+class NerfStepConfig(ctypes.Structure):
+    """include/wisp_hip.h: wisp_nerf_step_config, field for field (sizeof is checked against the library's at import)."""
+    _fields_ = ([("struct_bytes", c_i64)]
+                + [(n, c_vp) for n in ("occ_bits", "octree", "exsum", "coarse_bits", "table_lookup", "first_idx", "first_idx_host",
+                                       "resolutions", "table_param", "table_grad", "table_exp_avg", "table_exp_avg_sq", "table_shadow",
+                                       "dec_params", "dec_grad", "flat_param", "flat_grad", "flat_exp_avg", "flat_exp_avg_sq",
+                                       "grid_shadow")]
+                + [(n, c_i64) for n in ("decoder_begin", "decoder_len", "grid_begin", "grid_len", "rest_begin", "rest_len", "table_offset",
+                                        "max_rays", "max_samples")]
+                + [(n, c_i32) for n in ("level", "coarse_level", "num_samples", "loss_kind", "dtype_table", "num_lods", "feature_dim",
+                                        "bitwidth", "zero_from_col", "in_dim", "hidden", "view_freqs")]
+                + [("near", c_f32), ("range", c_f32), ("bg", c_f32 * 3), ("reserved", c_f32)])
+
+
+class NerfStepHyper(ctypes.Structure):
+    """include/wisp_hip.h: wisp_nerf_step_hyper."""
+    _fields_ = ([("struct_bytes", c_i64), ("step", c_i64)]
+                + [(n, c_f32) for n in ("lr_decoder", "lr_grid", "lr_rest", "weight_decay", "beta1", "beta2", "eps", "grad_scale")]
+                + [("optimizer", c_i32), ("reserved", c_i32)])
+
+
+if ctypes.sizeof(NerfStepConfig) != lib.wisp_nerf_step_config_bytes():
+    raise ImportError(f"wisp_nerf_step_config: this binding lays it out in {ctypes.sizeof(NerfStepConfig)} bytes, {LIB_PATH} in "
+                      f"{lib.wisp_nerf_step_config_bytes()}: rebuild the library")
 
 
 # Live HIP-event timing of selected kernels (bench.py sets TIMING = {} around its timed region).  Events are

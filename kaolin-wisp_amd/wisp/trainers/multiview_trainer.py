@@ -298,7 +298,9 @@ class _DirectNeRFStep:
             else:
                 ridx, samples, depths, deltas, boundary, offsets, dirs = C.raymarch_ray_finish(st, with_dirs=True)
             if prefetch is not None:
-                self._pending = self._count(prefetch, None)
+                # (a seed the native step already drew for this batch before it handed the step over: one jitter stream either way)
+                seed, self._next_seed = getattr(self, "_next_seed", None), None
+                self._pending = self._count(prefetch, None, seed=seed)
             return ridx, samples, deltas, offsets, dirs
         st, self._pending = self._pending, None
         kw = {} if (jitter is None or tracer.raymarch_type == 'uniform') else {"jitter": jitter}
@@ -504,9 +506,14 @@ class MultiviewTrainStep:
         # grad_accum_steps data-parallel ranks on one GPU (each rank's loss is a mean over its own rays, the all-reduced sum is
         # divided by the world size).  scripts/time_to_psnr.py emulates the 8-GPU weak-scaling batch with it.
         self.grad_accum_steps = 1
+        self._native = None
         if os.environ.get("WISP_DIRECT_STEP", "1") != "0" and _DirectNeRFStep.supports(pipeline):
             d = _DirectNeRFStep(self)
             self._direct = d if d.ok else None
+            if self._direct is not None and self._direct.hash_fast:
+                # the whole step issued by one call into the library where its shape is covered (csrc/train_step.hip); decided per batch
+                from wisp.trainers._native_step import NativeHashStep
+                self._native = NativeHashStep(self)
 
     # -------------------------------------------------------------------------------------------- schedule / groups
     def _lr_scale(self, step=None):
@@ -871,6 +878,12 @@ class MultiviewTrainStep:
             return torch.nn.functional.smooth_l1_loss(rgb, gts, reduction='none').mean()
         raise NotImplementedError
 
+    def native_timing_into(self, sink):
+        """bench.py: the native step brackets its four roofline entry points with its own HIP events; after a synchronize this
+        moves them into the (start, end, units) sink the Python-issued launches fill through wisp._C.TIMING."""
+        if self._native is not None:
+            self._native.drain_timing(sink)
+
     def accumulate(self, rays: Rays, img_gts, jitter=None):
         """Forward + backward of ONE micro-batch: its gradient is ADDED to the flat buffer, nothing is exchanged or applied.
         Call grad_accum_steps - 1 times, then step() with the last micro-batch (set grad_accum_steps first: it is the divisor).
@@ -900,6 +913,14 @@ class MultiviewTrainStep:
             self.total_iterations += 1
             self._fused_cover = None                         # (a step that raised between run() and optimizer_step leaves none behind)
             self._last_step_modular = not (self._direct is not None and self.pipeline.nef.training)
+            done = None
+            if not self._last_step_modular and self._native is not None and self._native.applies(rays, jitter):
+                # one call into the library issues every launch of the step, the optimizer included (csrc/train_step.hip)
+                done = self._native.step(rays, img_gts, prefetch)
+            if done is not None:
+                loss = done[0]
+                self.calc_adaptive_rays(rays.origins.shape[0])
+                return loss, done[1]
             if not self._last_step_modular:
                 with torch.no_grad():
                     loss, _ = self._direct.run(rays, img_gts, jitter, prefetch, fused_update=self._fused_update_args())

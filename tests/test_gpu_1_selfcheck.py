@@ -1259,3 +1259,98 @@ def test_gradient_accumulation_equals_one_step_over_the_union_of_the_micro_batch
     sure = np.abs(g2) > 1e-4 * float(np.abs(g2).max())
     np.testing.assert_allclose(p1[sure], p2[sure], rtol=0, atol=2e-5)
     assert float(tr1.flat.grad.abs().max()) == 0.0                                 # consumed and zeroed
+
+
+def _native_pair(num_steps=96):
+    from wisp.models import Pipeline
+    from wisp.tracers import PackedRFTracer
+    from wisp.trainers import MultiviewTrainStep
+    import copy
+    nef, _, _ = _build_pair(lods=16)
+    nef2 = copy.deepcopy(nef)
+    mk = lambda n: MultiviewTrainStep(Pipeline(n, PackedRFTracer(raymarch_type='ray', num_steps=num_steps, bg_color=(0, 0, 0))),
+                                      prune_every=-1, enable_amp=True, target_sample_size=2 ** 17)
+    return mk(nef), mk(nef2)
+
+
+def _run_steps(tr, batches, gts, steps, seed):
+    """`steps` optimisation steps with the one-batch look-ahead of bench.py's loop; -> losses, sample counts"""
+    from wisp.core import Rays
+    torch.manual_seed(seed)                                   # the jitter seeds follow torch's CPU generator (OctreeAS._draw_seed)
+    rays = [Rays(cuda(o), cuda(d), dist_min=1.0, dist_max=5.0) for o, d in batches]
+    losses, counts = [], []
+    for i in range(steps):
+        nxt = rays[(i + 1) % len(rays)] if i + 1 < steps else None
+        loss, S = tr.step(rays[i % len(rays)], gts[i % len(rays)], prefetch=nxt)
+        losses.append(loss.clone())
+        counts.append(S)
+    tr.wait_for_parameters()
+    torch.cuda.synchronize()
+    return [float(l) for l in losses], counts
+
+
+def _close(l1, l2, rel=1e-5):
+    return len(l1) == len(l2) and all(abs(a - b) <= rel * max(1.0, abs(b)) for a, b in zip(l1, l2))
+
+
+def test_native_step_equals_the_python_issued_step():
+    """csrc/train_step.hip (wisp_nerf_step_run: every launch of the nerf_hash.yaml step issued by one call into the library) against
+    _DirectNeRFStep.run + reduce_and_update issuing the same entry points from Python: same jitter seeds, same kernels, same
+    arguments.  Two Python-issued runs of this shape are not bit-identical themselves (the coarse table levels are flushed with
+    float atomics by several workgroups), so the comparison is: identical sample counts and ray counts every step, the first
+    step's loss bit for bit, its first moment (0.1 x the gradient) to 1e-5 of its largest entry, and the losses of six steps with
+    the look-ahead count and the table's AdamW folded into the backward to 1e-5."""
+    tr1, tr2 = _native_pair()
+    assert tr1._native is not None
+    tr2._native = None
+    rng = np.random.default_rng(311)
+    batches = [make_rays(3000, 312 + k) for k in range(3)]
+    gts = [cuda(rng.uniform(size=(3000, 3)).astype(np.float32)) for _ in range(3)]
+    l1, c1 = _run_steps(tr1, batches, gts, 1, seed=77)
+    l2, c2 = _run_steps(tr2, batches, gts, 1, seed=77)
+    assert l1 == l2 and c1 == c2
+    m1, m2 = tr1.flat.exp_avg, tr2.flat.exp_avg
+    assert float(m2.abs().max()) > 0 and float((m1 - m2).abs().max()) <= 1e-5 * float(m2.abs().max())
+    assert torch.equal(tr1.flat.shadow, tr1.flat.data[slice(*tr1.flat.ranges["grid"])].bfloat16())       # the bf16 copy follows the master
+    l1, c1 = _run_steps(tr1, batches, gts, 6, seed=78)
+    l2, c2 = _run_steps(tr2, batches, gts, 6, seed=78)
+    assert tr1._native.steps == 7 and tr1._native.fallbacks == 0, (tr1._native.steps, tr1._native.fallbacks)
+    assert c1 == c2 and min(c1) > 8192, (c1, c2)
+    assert _close(l1, l2), (l1, l2)
+    assert tr1.opt_steps == tr2.opt_steps == 7 and tr1.num_rays == tr2.num_rays
+    assert float(tr1.flat.grad.abs().max()) == 0.0 and float(tr2.flat.grad.abs().max()) == 0.0
+
+
+def test_native_step_hands_a_batch_it_cannot_hold_to_the_python_issued_step(monkeypatch):
+    """More packed samples than the native step's buffers were sized for (WISP_ERR_CAPACITY): the batch is counted again from the
+    same seed and taken by the Python-issued step; a run that alternates between the two (every other batch fits) stays on the
+    trajectory of a run that never used the native step."""
+    from wisp.trainers._native_step import NativeHashStep
+    rng = np.random.default_rng(321)
+    batches = [make_rays(3000, 322), make_rays(700, 323)]
+    gts = [cuda(rng.uniform(size=(3000, 3)).astype(np.float32)), cuda(rng.uniform(size=(700, 3)).astype(np.float32))]
+    tr0, tr2 = _native_pair()
+    tr2._native = None
+    l2, c2 = _run_steps(tr2, batches, gts, 6, seed=78)
+    cap = (min(c2) + max(c2)) // 2                              # the 3000-ray batches overflow, the 700-ray ones fit
+    monkeypatch.setattr(NativeHashStep, "_capacity", lambda self: (int(self.t.max_rays), int(cap)))
+    l1, c1 = _run_steps(tr0, batches, gts, 6, seed=78)
+    assert tr0._native.fallbacks == 3 and tr0._native.steps == 3, (tr0._native.fallbacks, tr0._native.steps)
+    assert c1 == c2 and _close(l1, l2), (l1, l2)
+
+
+def test_native_step_survives_a_prune_and_a_change_of_batch_size():
+    """The handle borrows the octree's buffers: a prune replaces them (the handle is rebuilt, the batch counted ahead is counted
+    again from its seed) and a larger target re-sizes the workspace - the run stays on the Python-issued one's trajectory."""
+    tr1, tr2 = _native_pair()
+    tr2._native = None
+    rng = np.random.default_rng(331)
+    batches = [make_rays(3000, 332 + k) for k in range(2)]
+    gts = [cuda(rng.uniform(size=(3000, 3)).astype(np.float32)) for _ in range(2)]
+    for tr in (tr1, tr2):
+        _run_steps(tr, batches, gts, 3, seed=79)
+        tr.prune()
+        tr.target_sample_size = 2 ** 18
+    l1, c1 = _run_steps(tr1, batches, gts, 4, seed=80)
+    l2, c2 = _run_steps(tr2, batches, gts, 4, seed=80)
+    assert tr1._native.steps == 7 and c1 == c2 and _close(l1, l2), (c1, c2, l1, l2)
