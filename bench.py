@@ -611,13 +611,54 @@ def _leaf_cells(pipe):
     return int(blas.pyramid[0, blas.max_level])                          # leaf cells of the (pruned) octree
 
 
+class _StdoutForTheLineOnly:
+    """The contract is ONE JSON line on stdout.  Libraries write there too - RCCL prints a version banner from C stdio when a process
+    group comes up, and its buffered tail is flushed at exit, i.e. AFTER a line printed from Python - so file descriptor 1 points at
+    stderr for the whole run and is handed back, with the C buffers flushed, only for the line itself."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        try:
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+        except OSError:
+            self.saved = None                       # (no real descriptor behind stdout: a captured stream - nothing to protect)
+        return self
+
+    def emit(self, text):
+        self.restore()
+        print(text, flush=True)
+
+    def restore(self):
+        if self.saved is not None:
+            sys.stdout.flush()
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)      # whatever C code left in its stdio buffers goes where it was meant to go
+            except Exception:
+                pass
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+            self.saved = None
+
+    def __exit__(self, *exc):
+        self.restore()
+        return False
+
+
 def main(argv=None):
+    with _StdoutForTheLineOnly() as guard:
+        return _main(argv, guard)
+
+
+def _main(argv, guard):
     args = parse(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ       # started by torch.distributed.run
     if args.gpus > 1 and not launched and world == 1:
+        guard.restore()                                    # (the ranks started below own stdout now: rank 0's line passes through)
         return _self_launch(args, argv)                    # N ranks were asked for and nobody started them: do it here
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, launched by torch.distributed.run"
     dev = _device(local)
@@ -638,7 +679,7 @@ def main(argv=None):
     if args.config != "nerf_hash":
         import bench_configs
         assert world == 1, "the secondary configs are single-GPU lines"
-        return bench_configs.main(args, dev)
+        return bench_configs.main(args, dev, emit=guard.emit)
     if args.pmc_child:                                     # profiling child: fixed occupancy, a handful of steps, no extras
         args.occupancy, args.pretrain, args.warmup, args.steps = "analytic", 0, 2, 4
     global_target = args.target_samples
@@ -958,10 +999,11 @@ def main(argv=None):
             out["dp_path_regime"] = dp_path_regime(args, dev, pipe, batch, R, out["ms_per_step"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(true_cells, args.hidden, args.num_steps)
-        print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        guard.emit(json.dumps(out))
     return out
 
 

@@ -460,7 +460,7 @@ def secondary_lines(args, dev, budget_s=6.0):
     return out
 
 
-def main(args, dev):
+def main(args, dev, emit=print):
     out = {"v8": run_v8, "vqad": run_vqad, "nglod": run_nglod}[args.config](args, dev)
-    print(json.dumps(out))
+    emit(json.dumps(out))
     return out
