@@ -950,12 +950,13 @@ def test_fused_decoder_matches_torch_fp32_modules(mode, io_dtype, tol, bias, in_
 
 @pytest.mark.parametrize("io_dtype,bias,in_dim,S", [(torch.bfloat16, True, 32, 5003), (torch.float32, False, 32, 5003),
                                                      (torch.bfloat16, False, 5, 70001), (torch.float16, True, 12, 5003),
-                                                     (torch.bfloat16, True, 32, 1100003)])
+                                                     (torch.bfloat16, True, 32, 1100003), (torch.bfloat16, True, 32, 2200003)])
 def test_fused_wide_decoder_hidden_128(io_dtype, bias, in_dim, S):
     """hidden_dim = 128 (the reference's best nerf_hash row and the documented VQAD command, docs/pages/app_nerf.md:175-192):
     csrc/nerf_mlp_wide.hip - chained forward, chain backward + scratch, dW kernel - against the fp32 torch modules, judged
     like the hidden-64 bf16 kernel by what torch's own bf16 autocast loses.  70 001 samples: several dW rounds per
-    workgroup; 1 100 003: two chunks of the scratch (accumulating partial rows)."""
+    workgroup; 2 200 003 (> WIDE_CHUNK_SAMPLES = 2^21, the sample count of bench.py's hidden-128 line at its large batch): two chunks of
+    the scratch, the second accumulating into the first's partial rows (1 100 003 was that case while the chunk was 2^20)."""
     from wisp.ops.nerf_mlp import supports
     nef = _decoder_pair(bias, in_dim, hidden=128)
     nef.decoder_compute = 'fp32'
