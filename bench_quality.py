@@ -43,7 +43,8 @@ def _psnr(pipe, bank, amp, Rays, near, far):
 
 
 def time_to_psnr(dev, regime, train_bank, eval_bank, ray_budget=REFERENCE_RAY_BUDGET, checkpoints=(1e7, 2e7, 4e7), seed=0,
-                 hidden=64, num_steps=2048, amp=True, lr_scale=1.0, log_every_rays=None, max_rays=2 ** 18, scheduler=True):
+                 hidden=64, num_steps=2048, amp=True, lr_scale=1.0, log_every_rays=None, max_rays=2 ** 18, scheduler=True,
+                 prune_every=100):
     """Train one fresh nerf_hash.yaml model under `regime` (a REGIMES key or a dict(target=, accum=)) until `ray_budget` rays have
     been consumed.  scheduler: nerf_hash.yaml's MultiStepLR (x 0.333 at 0.5 / 0.75 / 0.9 of the run, base_trainer.py:238-246), placed at
     those fractions of the RAY budget so that every regime decays at the same point of its data.  -> dict(psnr_at_rays={rays: dB}, curve=[(rays, steps, train seconds, dB)], ...)."""
@@ -58,7 +59,7 @@ def time_to_psnr(dev, regime, train_bank, eval_bank, ray_budget=REFERENCE_RAY_BU
     cells = OctreeAS.make_dense(level=7).points[-(128 ** 3):].to(dev)            # nerf_hash.yaml:16-17
     pipe = bench.build_pipeline(dev, hidden, num_steps, cells)                    # (seeds torch with 0: same initial weights)
     tr = MultiviewTrainStep(pipe, lr=1e-3 * lr_scale, eps=1e-16, weight_decay=1e-6, grid_lr_weight=500.0, rgb_loss_type='huber',
-                            prune_every=100, target_sample_size=target, max_rays=max_rays, enable_amp=amp, seed=seed)
+                            prune_every=prune_every, target_sample_size=target, max_rays=max_rays, enable_amp=amp, seed=seed)
     tr.grad_accum_steps = accum
     bank_o, bank_d, bank_rgb = train_bank
     gen = torch.Generator(device=dev).manual_seed(4321 + seed)
@@ -106,6 +107,6 @@ def time_to_psnr(dev, regime, train_bank, eval_bank, ray_budget=REFERENCE_RAY_BU
     torch.cuda.synchronize()
     blas = pipe.nef.grid.blas
     return dict(regime=regime if isinstance(regime, str) else "custom", target_samples_per_step=target, micro_batches_per_step=accum,
-                lr_scale=lr_scale, seed=seed, rays=rays_done, optimizer_steps=steps, train_seconds=train_s,
+                lr_scale=lr_scale, prune_every=prune_every, seed=seed, rays=rays_done, optimizer_steps=steps, train_seconds=train_s,
                 rays_per_step_at_end=R * accum, leaf_cells_at_end=int(blas.pyramid[0, blas.max_level]),
                 psnr_at_rays={str(k): v for k, v in at.items()}, curve=curve)
