@@ -879,3 +879,75 @@ def test_slot_fit_key_follows_the_emitter_width_switch():
     assert m and C.HASHGRID_EMIT_WIDE_MIN == 1 << int(m.group(1))
     import inspect
     assert "HASHGRID_EMIT_WIDE_MIN" in inspect.getsource(C.hashgrid_interpolate_backward)
+
+
+def test_native_step_config_is_validated_without_a_gpu():
+    """wisp_nerf_step_* (csrc/train_step.hip): the struct the binding lays out is the library's, a config with another
+    struct_bytes, a table of more than two features or a decoder shape the step does not cover is refused with a message, and
+    a well-formed one gets a workspace size that grows with the capacities - all host arithmetic, no device needed."""
+    import wisp._C as C
+    assert ctypes.sizeof(C.NerfStepConfig) == C.lib.wisp_nerf_step_config_bytes()
+
+    def cfg(**over):
+        c = C.NerfStepConfig()
+        c.struct_bytes = ctypes.sizeof(C.NerfStepConfig)
+        dummy = 0x1000                                     # (never dereferenced by the size query)
+        for name in ("octree", "exsum", "table_lookup", "first_idx", "table_grad", "dec_params", "dec_grad", "flat_param", "flat_grad",
+                     "flat_exp_avg", "flat_exp_avg_sq"):
+            setattr(c, name, dummy)
+        keep = ((ctypes.c_int64 * 17)(*range(17)), (ctypes.c_int32 * 16)(*[16] * 16))
+        c.first_idx_host, c.resolutions = ctypes.cast(keep[0], ctypes.c_void_p), ctypes.cast(keep[1], ctypes.c_void_p)
+        c.level, c.num_samples, c.loss_kind, c.dtype_table, c.num_lods, c.feature_dim, c.bitwidth = 7, 2048, 0, C.BF16, 16, 2, 19
+        c.zero_from_col, c.in_dim, c.hidden, c.view_freqs, c.near, c.range = 30, 32, 64, 4, 1.0, 4.0
+        c.max_rays, c.max_samples = 4096, 1 << 18
+        for k, v in over.items():
+            setattr(c, k, v)
+        return c, keep
+
+    good, keep = cfg()
+    small = C.lib.wisp_nerf_step_workspace_bytes(ctypes.byref(good))
+    assert small > (1 << 18) * (8 + 12 + 64 + 64)          # ridx + samples + features + their gradient, at least
+    big, keep2 = cfg(max_samples=1 << 20)
+    assert C.lib.wisp_nerf_step_workspace_bytes(ctypes.byref(big)) > 2 * small            # (the per-ray buffers do not grow)
+    for bad, text in ((dict(struct_bytes=8), "another size"), (dict(feature_dim=4, in_dim=64), "two-feature"), (dict(hidden=128), "decoder shape"),
+                      (dict(dtype_table=C.F32), "16-bit"), (dict(range=0.0), "dist_max"), (dict(max_samples=0), "capacities")):
+        c, k = cfg(**bad)
+        assert C.lib.wisp_nerf_step_workspace_bytes(ctypes.byref(c)) < 0 and text in C.last_error(), (bad, C.last_error())
+    assert not C.lib.wisp_nerf_step_create(ctypes.byref(good), None, 0) and "workspace" in C.last_error()
+
+
+def test_trace_gaps_keeps_only_the_named_regimes_launches(tmp_path):
+    """scripts/trace_gaps.py with a regime name: only the launches between that regime's sentinel launches are summarised
+    (the 2^18 timeline once held the drop-in loop's steps)."""
+    import csv
+    import subprocess
+    import sys
+    import bench
+    rows, t = [], [1000]
+
+    def launch(name, dur, grid=256):
+        rows.append({"Kernel_Name": name, "Start_Timestamp": t[0], "End_Timestamp": t[0] + dur, "Grid_Size_X": grid, "Workgroup_Size_X": 256})
+        t[0] += dur + 500
+
+    def sentinel(tag):
+        launch("void at::native::vectorized_elementwise_kernel<4, at::native::FillFunctor<double>, std::array<char*, 1ul> >", 2000,
+               grid=1000 * (tag + 1))
+    for tag, fwd_ns in ((0, 30000), (1, 140000)):
+        sentinel(tag)
+        for _ in range(9):
+            launch("void hashgrid_fwd_kernel<__hip_bfloat16, 2, 3>(float const*)", fwd_ns)
+            launch("composite_loss_kernel<4>", 5000)
+        sentinel(tag)
+    d = tmp_path / "trace"
+    d.mkdir()
+    with open(d / "x_kernel_trace.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    for regime, want_us in (("headline", 30.0), ("large_batch_regime", 140.0)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "trace_gaps.py"), str(d), "hashgrid_fwd", "0", regime],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout
+        line = next(l for l in r.stdout.splitlines() if l.startswith("hashgrid_fwd_kernel"))
+        assert abs(float(line.split()[2]) - want_us) < 0.5, (regime, line)
+        assert f"regime {regime}: 18 launches" in r.stdout

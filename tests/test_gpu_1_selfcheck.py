@@ -1261,15 +1261,15 @@ def test_gradient_accumulation_equals_one_step_over_the_union_of_the_micro_batch
     assert float(tr1.flat.grad.abs().max()) == 0.0                                 # consumed and zeroed
 
 
-def _native_pair(num_steps=96):
+def _native_pair(num_steps=96, loss='huber', bg=(0, 0, 0)):
     from wisp.models import Pipeline
     from wisp.tracers import PackedRFTracer
     from wisp.trainers import MultiviewTrainStep
     import copy
     nef, _, _ = _build_pair(lods=16)
     nef2 = copy.deepcopy(nef)
-    mk = lambda n: MultiviewTrainStep(Pipeline(n, PackedRFTracer(raymarch_type='ray', num_steps=num_steps, bg_color=(0, 0, 0))),
-                                      prune_every=-1, enable_amp=True, target_sample_size=2 ** 17)
+    mk = lambda n: MultiviewTrainStep(Pipeline(n, PackedRFTracer(raymarch_type='ray', num_steps=num_steps, bg_color=bg)),
+                                      prune_every=-1, enable_amp=True, target_sample_size=2 ** 17, rgb_loss_type=loss)
     return mk(nef), mk(nef2)
 
 
@@ -1319,6 +1319,37 @@ def test_native_step_equals_the_python_issued_step():
     assert _close(l1, l2), (l1, l2)
     assert tr1.opt_steps == tr2.opt_steps == 7 and tr1.num_rays == tr2.num_rays
     assert float(tr1.flat.grad.abs().max()) == 0.0 and float(tr2.flat.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("loss,bg", [("l2", (1.0, 1.0, 1.0)), ("l1", (0.1, 0.2, 0.3))])
+def test_native_step_other_losses_and_backgrounds(loss, bg):
+    """the loss kind and the background colour travel in the step's configuration: L2 over a white background (the V8 / VQAD
+    command lines), L1 over a coloured one - first step's loss bit for bit, four steps to 1e-5"""
+    tr1, tr2 = _native_pair(loss=loss, bg=bg)
+    tr2._native = None
+    rng = np.random.default_rng(341)
+    batches = [make_rays(2500, 342 + k) for k in range(2)]
+    gts = [cuda(rng.uniform(size=(2500, 3)).astype(np.float32)) for _ in range(2)]
+    l1, c1 = _run_steps(tr1, batches, gts, 4, seed=81)
+    l2, c2 = _run_steps(tr2, batches, gts, 4, seed=81)
+    assert tr1._native.steps == 4 and c1 == c2 and l1[0] == l2[0] and _close(l1, l2), (l1, l2)
+
+
+def test_time_to_psnr_runs_both_regimes_and_the_model_learns():
+    """bench_quality.time_to_psnr (bench.py's `quality`, scripts/time_to_psnr.py) on a small budget: a plain regime and one with
+    gradient accumulation - PSNR on held-out rays rises with the rays consumed, the bookkeeping adds up"""
+    import bench_quality as bq
+    import synlego
+    dev = torch.device(DEV)
+    train = synlego.ray_bank(1 << 17, seed=1000, device=dev)
+    held = synlego.ray_bank(1 << 12, seed=7, device=dev)
+    for regime in (dict(target=2 ** 17, accum=1), dict(target=2 ** 16, accum=2)):
+        r = bq.time_to_psnr(dev, regime, train, held, ray_budget=300000, checkpoints=(100000, 299999), num_steps=512, prune_every=50)
+        assert r["rays"] >= 300000 and r["micro_batches_per_step"] == regime["accum"] and len(r["curve"]) >= 2
+        first, last = r["curve"][0], r["curve"][-1]
+        assert last[0] > first[0] and last[2] > first[2] > 0.0
+        assert last[3] > first[3] and last[3] > 18.0, r["curve"]                    # it learns
+        assert set(r["psnr_at_rays"]) == {"100000", "299999"}
 
 
 def test_native_step_hands_a_batch_it_cannot_hold_to_the_python_issued_step(monkeypatch):
