@@ -951,3 +951,4 @@ def test_trace_gaps_keeps_only_the_named_regimes_launches(tmp_path):
         line = next(l for l in r.stdout.splitlines() if l.startswith("hashgrid_fwd_kernel"))
         assert abs(float(line.split()[2]) - want_us) < 0.5, (regime, line)
         assert f"regime {regime}: 18 launches" in r.stdout
+
