@@ -261,7 +261,10 @@ def quality_table(args, dev, train_bank, amp, large_lr):
         eval_bank = synlego.ray_bank(2 ** 15, seed=7, device=dev)
         budget = int(args.quality_budget)
         marks = tuple(m for m in (1e7, 2e7, 4e7) if m <= budget) or (float(budget) * (1 - 1e-9),)
-        out = {"ray_budget": budget, "held_out_rays": int(eval_bank[0].shape[0]),
+        out = {"ray_budget": budget, "held_out_rays": int(eval_bank[0].shape[0]), "train_bank_rays": int(train_bank[0].shape[0]),
+               "bank_note": "the bench's resident ray bank (--bank-rays, 2^21 by default) is drawn ~20 times over by a 4.1e7-ray budget; "
+                            "profiles/r06_time_to_psnr_*.txt use a 2^23-ray bank and end ~4 dB higher in every regime - the ORDER of the "
+                            "regimes is the same",
                "note": "fresh model per regime, dense level-7 start, prune every 100 steps, MultiStepLR x0.333 at 50/75/90 % of the ray "
                        "budget, same ray stream and seed; curve rows = (rays consumed, optimizer steps, training seconds, dB)"}
         for key, target, lr in (("headline", args.target_samples, 1.0), ("large_batch_regime", args.large_target_samples, large_lr)):
