@@ -1385,3 +1385,39 @@ def test_native_step_survives_a_prune_and_a_change_of_batch_size():
     l1, c1 = _run_steps(tr1, batches, gts, 4, seed=80)
     l2, c2 = _run_steps(tr2, batches, gts, 4, seed=80)
     assert tr1._native.steps == 7 and c1 == c2 and _close(l1, l2), (c1, c2, l1, l2)
+
+
+def test_bench_line_on_the_gpu_has_the_contract_fields_and_is_alone_on_stdout():
+    """`python bench.py` in a short form, as a subprocess on the real device: exactly ONE line on stdout (RCCL's banner of the
+    one-rank group of dp_path_regime must not reach it), and in it the contract's fields - metric / value / unit / n_gpus / steps
+    / warmup / ms_per_step / scaling / dtype / config.workload, `roofline` (bound, achieved, peak, unit, frac, traffic) - plus
+    this repository's regimes: large_batch_regime with its own roofline, quality, dropin_regime, dp_path_regime."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--pretrain", "30",
+           "--bank-rays", "131072", "--eval-rays", "4096", "--large-target-samples", "524288", "--quality-budget", "200000",
+           "--dp-steps", "4", "--dropin-steps", "5", "--no-configs", "--no-cpu-baseline", "--no-pmc"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["dtype"] == "bf16" and d["vs_baseline"] is None
+    assert d["config"]["target_samples_per_step"] == 2 ** 18 and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["rays_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    roof = d["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s") and 0.0 < roof["frac"] < 1.5
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and "traffic" in roof
+    assert set(roof["all_kernels"]) >= {"hashgrid_fwd", "hashgrid_bwd", "nerf_mlp_fwd", "nerf_mlp_bwd"}
+    lg = d["large_batch_regime"]
+    assert lg["target_samples_per_step"] == 524288 and abs(lg["lr_scale"] - 2 ** 0.5) < 1e-9 and lg["roofline"]["frac"] > 0
+    q = d["quality"]
+    assert "error" not in q and q["headline"]["optimizer_steps"] > 0 and q["large_batch_regime"]["final_psnr_db"] > 10.0
+    assert d["dropin_regime"]["ms_per_step"] > 0
+    dp = d["dp_path_regime"]
+    assert "error" not in dp and dp["allreduce"]["ms_per_step"] > 0 and dp["sharded"]["comm"]["path"].startswith("reduce-scatter")
+    assert "PROJECTION" in dp["allreduce"]["projected_n8"]["note"]
